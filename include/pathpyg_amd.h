@@ -1,0 +1,139 @@
+/* pathpyg_amd — C ABI of the MI355X-native (gfx950) higher-order graph engine.
+ *
+ * This is the drop-in boundary for ONE hot path of pathpy/pathpyG: the k-th order De Bruijn lift
+ * of temporal edge streams / walk data and the DBGNN forward/backward that consumes it.  The
+ * reference has no FFI seam of its own (it is pure Python on torch + torch_geometric), so every
+ * entry point below names the reference function (file:line, relative to the pathpyG repository
+ * root) whose tensor work it replaces; the Python shims in pathpyg_amd/ keep the reference's
+ * signatures and call these through ctypes.
+ *
+ * Conventions
+ *   - plain C, no torch types: raw DEVICE pointers, element counts, a hipStream_t passed as void*.
+ *   - every function returns PP_OK (0) or a negative PP_ERR_* code; pp_last_error() gives the text.
+ *   - index tensors at the boundary are int64 row-major [2,E] exactly like the reference;
+ *     internal ids are 32-bit, so element counts per call must stay below 2^31 (PP_ERR_TOO_LARGE).
+ *   - all memory is owned by the caller (PyTorch's caching allocator in the Python shims).
+ *     Scratch comes from a caller-provided workspace sized by the matching *_ws_bytes() query.
+ *   - data-dependent output sizes use two calls: *_count leaves its state in the workspace and
+ *     writes the size to a device scalar; the caller reads it (one 8-byte D2H copy), allocates the
+ *     output and calls *_fill with the SAME workspace.
+ *   - everything is asynchronous on `stream`; nothing here synchronises the device.
+ */
+#ifndef PATHPYG_AMD_H
+#define PATHPYG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_VERSION 100 /* 0.1.0 */
+
+typedef void* pp_stream_t; /* hipStream_t */
+
+enum pp_status { PP_OK = 0, PP_ERR_HIP = -1, PP_ERR_ARG = -2, PP_ERR_WORKSPACE = -3, PP_ERR_TOO_LARGE = -4 };
+
+/* element types of caller tensors */
+enum pp_dtype { PP_I32 = 0, PP_I64 = 1, PP_F32 = 2, PP_F64 = 3 };
+
+/* per-edge attribute from the two endpoints: reference aggregate_node_attributes,
+ * src/pathpyG/algorithms/lift_order.py:33-44 */
+enum pp_edge_aggr { PP_AGGR_SRC = 0, PP_AGGR_DST = 1, PP_AGGR_MAX = 2, PP_AGGR_MUL = 3, PP_AGGR_ADD = 4 };
+
+/* duplicate-edge reduction: reference aggregate_edge_index(aggr=...), lift_order.py:139-144 (PyG coalesce) */
+enum pp_reduce { PP_REDUCE_SUM = 0, PP_REDUCE_MEAN = 1, PP_REDUCE_MIN = 2, PP_REDUCE_MAX = 3 };
+
+/* how `delta` reached torch.tensor(delta) in the reference (src/pathpyG/algorithms/temporal.py:30,43):
+ * the threshold t+delta and the <= comparison are evaluated in torch's promoted dtype. */
+enum pp_delta_kind { PP_DELTA_I64 = 0, PP_DELTA_F32 = 1, PP_DELTA_F64 = 2 };
+
+int pp_version(void);
+const char* pp_last_error(void);
+
+/* ------------------------------------------------------------------ primitives (pp_scan.hip, pp_sort.hip) */
+
+/* torch_geometric.utils.cumsum as used at lift_order.py:74,77: out[0..n] = exclusive prefix sums, out[n] = total */
+size_t pp_scan_ws_bytes(int64_t n);
+int pp_exclusive_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream);
+int pp_exclusive_scan_i64(const int64_t* in, int64_t n, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream);
+
+/* torch_geometric.utils.degree(index, num_nodes) as used at lift_order.py:65: bins[v] = #occurrences of v */
+int pp_degree_i64(const int64_t* index, int64_t n, int64_t num_bins, int32_t* bins, pp_stream_t stream);
+
+/* out2 = {min, max} of a (INT64_MAX, INT64_MIN when n == 0) */
+int pp_minmax_i64(const int64_t* a, int64_t n, int64_t* out2, pp_stream_t stream);
+
+/* stable LSD radix sort of (key, 32-bit value) pairs on key bits [begin_bit, end_bit);
+ * vals_in == NULL means values 0..n-1 (argsort).  Replaces torch.argsort / index_sort / torch.unique's sort
+ * (temporal_graph.py:58, lift_order.py:133,139, graph.py:103,115).  in/out buffers must differ. */
+size_t pp_sort_ws_bytes(int64_t n, int key_bytes);
+int pp_sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, int64_t n,
+                      int begin_bit, int end_bit, void* ws, size_t ws_bytes, pp_stream_t stream);
+int pp_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, int64_t n,
+                      int begin_bit, int end_bit, void* ws, size_t ws_bytes, pp_stream_t stream);
+
+/* ------------------------------------------------------------------ order lifts (pp_lift.hip) */
+
+/* lift_order_temporal(g, delta) -> [2,E2] int64, src/pathpyG/algorithms/temporal.py:17-54.
+ *   edge_index : [2,m] int64, events in time order (TemporalGraph.__init__ sorted them, temporal_graph.py:58-63)
+ *   time       : [m] int64 (PP_I64) or float64 (PP_F64), ascending
+ *   delta      : as torch.tensor(delta) sees it: PP_DELTA_I64 -> delta_i; PP_DELTA_F32 / PP_DELTA_F64 -> delta_f
+ *                (for PP_DELTA_F32 pass the float32-rounded value).  With float64 time only delta_f is used.
+ * pp_temporal_count builds the per-node event lists, counts each event's continuations and scans them;
+ * pp_lift_result_ptr(ws)[0] = E2, [1] = status (bit 0: node index outside [0,num_nodes)).
+ * pp_temporal_fill writes out[0][p] = i, out[1][p] = j for all pairs in lexicographic (i,j) order. */
+size_t pp_temporal_ws_bytes(int64_t m, int64_t num_nodes);
+int pp_temporal_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind,
+                      int64_t delta_i, double delta_f, void* ws, size_t ws_bytes, pp_stream_t stream);
+int pp_temporal_fill(int64_t m, int64_t num_nodes, int64_t total, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream);
+
+/* lift_order_edge_index(edge_index, num_nodes) -> [2,E'] int64, src/pathpyG/algorithms/lift_order.py:48-79.
+ * edge_index must be grouped by source like the reference demands (:52,55). */
+size_t pp_linegraph_ws_bytes(int64_t n_edges, int64_t num_nodes);
+int pp_linegraph_count(const int64_t* edge_index, int64_t n_edges, int64_t num_nodes, void* ws, size_t ws_bytes, pp_stream_t stream);
+int pp_linegraph_fill(int64_t n_edges, int64_t num_nodes, int64_t total, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream);
+const int64_t* pp_lift_result_ptr(void* ws); /* device pointer to {size, status} */
+
+/* aggregate_node_attributes(edge_index, node_attribute, aggr), src/pathpyG/algorithms/lift_order.py:10-45.
+ * attr is [num_nodes, width] row-major of `dtype`; out is [n_edges, width]; *status as above (device int64). */
+int pp_edge_attr(const int64_t* edge_index, int64_t n_edges, const void* attr, int dtype, int64_t num_nodes, int64_t width, int aggr,
+                 void* out, int64_t* status, pp_stream_t stream);
+
+/* cat([ns[ei[0]], ns[ei[1]][:, -1:]], 1), src/pathpyG/core/multi_order_model.py:114,165: rows [n_rows,k] -> out [n_edges,k+1] */
+int pp_extend_node_sequence(const int64_t* edge_index, int64_t n_edges, const int64_t* rows, int64_t n_rows, int k, int64_t* out,
+                            int64_t* status, pp_stream_t stream);
+
+/* ------------------------------------------------------------------ De Bruijn aggregation (pp_aggregate.hip) */
+
+/* torch.unique(node_sequence, dim=0, return_inverse=True), src/pathpyG/algorithms/lift_order.py:133.
+ * rows [n_rows,k] int64 with every value in [min_value, max_value].  _count writes inverse[n_rows] and
+ * {U, 0} to pp_aggregate_result_ptr(ws); _fill writes the U unique rows in lexicographic order. */
+size_t pp_unique_rows_ws_bytes(int64_t n_rows);
+int pp_unique_rows_count(const int64_t* rows, int64_t n_rows, int k, int64_t min_value, int64_t max_value, int64_t* inverse, void* ws,
+                         size_t ws_bytes, pp_stream_t stream);
+int pp_unique_rows_fill(const int64_t* rows, int64_t n_rows, int k, int64_t n_unique, int64_t* unique_rows, void* ws, size_t ws_bytes,
+                        pp_stream_t stream);
+
+/* coalesce(remap[edge_index], edge_attr, num_nodes, reduce), src/pathpyG/algorithms/lift_order.py:135-144.
+ * remap may be NULL (edges already hold node ids).  _count -> {A, status}; _fill writes out_index [2,A]
+ * sorted by (row, col) and the reduced weights (weight may be NULL). */
+size_t pp_coalesce_ws_bytes(int64_t n_edges);
+int pp_coalesce_count(const int64_t* edge_index, int64_t n_edges, const int64_t* remap, int64_t remap_len, int64_t num_nodes, void* ws,
+                      size_t ws_bytes, pp_stream_t stream);
+int pp_coalesce_fill(const void* weight, int dtype, int reduce, int64_t n_edges, int64_t n_out, int64_t num_nodes, int64_t* out_index,
+                     void* out_weight, void* ws, size_t ws_bytes, pp_stream_t stream);
+const int64_t* pp_aggregate_result_ptr(void* ws);
+
+/* Graph.__init__ helpers, src/pathpyG/core/graph.py:103-115 (EdgeIndex.sort_by("row"), get_csr, get_csc) */
+int pp_count_descents_i64(const int64_t* a, int64_t n, int64_t* descents, pp_stream_t stream);
+size_t pp_argsort_ws_bytes(int64_t n);
+int pp_argsort_i64(const int64_t* keys, int64_t n, int64_t min_value, int64_t max_value, int64_t* perm_out, void* ws, size_t ws_bytes,
+                   pp_stream_t stream);
+int pp_ptr_from_sorted_i64(const int64_t* sorted, int64_t n, int64_t num_rows, int64_t* ptr, pp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATHPYG_AMD_H */

@@ -1,0 +1,300 @@
+"""Device-tensor level wrappers over the C ABI (include/pathpyg_amd.h).
+
+Every function here takes tensors that already live on an MI355X (``tensor.is_cuda``), allocates
+outputs and workspaces through PyTorch's caching allocator, launches on the current stream and
+returns new tensors on the same device.  PyTorch is only plumbing (memory, streams); all arithmetic
+happens in the HIP kernels.  There is no CPU implementation behind these calls.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, lib
+
+_DTYPE_CODE = {torch.int32: 0, torch.int64: 1, torch.float32: 2, torch.float64: 3}
+_EDGE_AGGR = {"src": 0, "dst": 1, "max": 2, "mul": 3, "add": 4}
+_REDUCE = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3}
+DELTA_I64, DELTA_F32, DELTA_F64 = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: torch.Tensor | None):
+    return None if t is None else t.data_ptr()
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _result(ws: torch.Tensor) -> tuple[int, int]:
+    """{size, status} that *_count left at the start of its workspace (one 16-byte D2H copy)."""
+    size, status = ws[:16].view(torch.int64).tolist()
+    return size, status
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("pathpyg_amd kernels need tensors on an MI355X device (got a CPU tensor); there is no CPU path")
+        if dev is not None and t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} and {t.device}")
+        dev = t.device
+    return dev
+
+
+def _edge_index(edge_index: torch.Tensor) -> torch.Tensor:
+    if edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
+    ei = torch.as_tensor(edge_index)
+    if type(ei) is not torch.Tensor:          # tensor subclasses (e.g. an EdgeIndex) -> plain view
+        ei = ei.as_subclass(torch.Tensor)
+    if ei.dtype != torch.int64:
+        ei = ei.to(torch.int64)
+    return ei.contiguous()
+
+
+def _bad_index(status: int, what: str) -> None:
+    if status & 1:
+        raise IndexError(f"{what}: node index out of range")
+
+
+# ------------------------------------------------------------------ primitives
+def minmax(a: torch.Tensor) -> tuple[int, int]:
+    a = a.contiguous()
+    dev = require_device(a)
+    with torch.cuda.device(dev):
+        out = torch.empty(2, dtype=torch.int64, device=dev)
+        check(lib().pp_minmax_i64(_p(a), a.numel(), _p(out), _stream()), "pp_minmax_i64")
+        lo, hi = out.tolist()
+    return lo, hi
+
+
+def degree(index: torch.Tensor, num_bins: int) -> torch.Tensor:
+    index = index.contiguous()
+    dev = require_device(index)
+    with torch.cuda.device(dev):
+        bins = torch.empty(num_bins, dtype=torch.int32, device=dev)
+        check(lib().pp_degree_i64(_p(index), index.numel(), num_bins, _p(bins), _stream()), "pp_degree_i64")
+    return bins
+
+
+def exclusive_scan(values: torch.Tensor) -> torch.Tensor:
+    """[0, v0, v0+v1, ..., total] as int64 (PyG ``cumsum``)."""
+    values = values.contiguous()
+    dev = require_device(values)
+    n = values.numel()
+    with torch.cuda.device(dev):
+        out = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        ws = _workspace(lib().pp_scan_ws_bytes(n), dev)
+        if values.dtype == torch.int32:
+            fn, name = lib().pp_exclusive_scan_i32, "pp_exclusive_scan_i32"
+        elif values.dtype == torch.int64:
+            fn, name = lib().pp_exclusive_scan_i64, "pp_exclusive_scan_i64"
+        else:
+            raise TypeError("exclusive_scan: int32 or int64 input")
+        check(fn(_p(values), n, _p(out), _p(ws), ws.numel(), _stream()), name)
+    return out
+
+
+def sort_pairs(keys: torch.Tensor, values: torch.Tensor | None, begin_bit: int, end_bit: int):
+    """Stable radix sort of (key, value) pairs; keys int32/int64 holding NON-NEGATIVE values."""
+    keys = keys.contiguous()
+    dev = require_device(keys, values)
+    n = keys.numel()
+    with torch.cuda.device(dev):
+        keys_out = torch.empty_like(keys)
+        vals_out = torch.empty(n, dtype=torch.int32, device=dev)
+        if keys.dtype == torch.int32:
+            fn, name, kb = lib().pp_sort_pairs_u32, "pp_sort_pairs_u32", 4
+        elif keys.dtype == torch.int64:
+            fn, name, kb = lib().pp_sort_pairs_u64, "pp_sort_pairs_u64", 8
+        else:
+            raise TypeError("sort_pairs: int32 or int64 keys")
+        if values is not None:
+            values = values.contiguous()
+            if values.dtype != torch.int32:
+                raise TypeError("sort_pairs: int32 values")
+        ws = _workspace(lib().pp_sort_ws_bytes(n, kb), dev)
+        check(fn(_p(keys), _p(values), _p(keys_out), _p(vals_out), n, begin_bit, end_bit, _p(ws), ws.numel(), _stream()), name)
+    return keys_out, vals_out
+
+
+# ------------------------------------------------------------------ lifts
+def resolve_delta(time_dtype: torch.dtype, delta) -> tuple[int, int, float]:
+    """(kind, delta_i, delta_f) describing ``torch.tensor(delta)`` the way the reference's
+    ``lift_order_temporal`` sees it (src/pathpyG/algorithms/temporal.py:30,43)."""
+    d = delta.detach().cpu() if isinstance(delta, torch.Tensor) else torch.tensor(delta)
+    if d.dim() != 0:
+        raise ValueError("delta must be a scalar")
+    if time_dtype == torch.float64:
+        return DELTA_F64, 0, float(d)                  # int / float32 / float64 delta all widen to float64
+    if d.dtype.is_floating_point:
+        if d.dtype == torch.float64:
+            return DELTA_F64, 0, float(d)
+        return DELTA_F32, 0, float(d.to(torch.float32))  # python float -> float32 tensor in the reference
+    return DELTA_I64, int(d), 0.0
+
+
+def temporal_lift(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta) -> torch.Tensor:
+    """Second-order event graph of a TIME-SORTED event list: all (i, j) with head(i) == tail(j) and
+    t_i < t_j <= t_i + delta, lexicographic, int64 [2, E2]."""
+    ei = _edge_index(edge_index)
+    dev = require_device(ei, time)
+    if time.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
+        time = time.to(torch.int64)
+    if time.dtype not in (torch.int64, torch.float64):
+        raise TypeError(f"timestamps must be int64 or float64, got {time.dtype}")
+    time = time.contiguous()
+    m = ei.size(1)
+    if time.numel() != m:
+        raise ValueError("time and edge_index disagree on the number of events")
+    kind, di, df = resolve_delta(time.dtype, delta)
+    L = lib()
+    with torch.cuda.device(dev):
+        ws = _workspace(L.pp_temporal_ws_bytes(m, num_nodes), dev)
+        check(L.pp_temporal_count(_p(ei), _p(time), _DTYPE_CODE[time.dtype], m, num_nodes, kind, di, df, _p(ws), ws.numel(), _stream()),
+              "pp_temporal_count")
+        total, status = _result(ws)
+        _bad_index(status, "lift_order_temporal")
+        out = torch.empty((2, total), dtype=torch.int64, device=dev)
+        check(L.pp_temporal_fill(m, num_nodes, total, _p(out), _p(ws), ws.numel(), _stream()), "pp_temporal_fill")
+    return out
+
+
+def linegraph_lift(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    ei = _edge_index(edge_index)
+    dev = require_device(ei)
+    e = ei.size(1)
+    L = lib()
+    with torch.cuda.device(dev):
+        ws = _workspace(L.pp_linegraph_ws_bytes(e, num_nodes), dev)
+        check(L.pp_linegraph_count(_p(ei), e, num_nodes, _p(ws), ws.numel(), _stream()), "pp_linegraph_count")
+        total, status = _result(ws)
+        _bad_index(status, "lift_order_edge_index")
+        out = torch.empty((2, total), dtype=torch.int64, device=dev)
+        check(L.pp_linegraph_fill(e, num_nodes, total, _p(out), _p(ws), ws.numel(), _stream()), "pp_linegraph_fill")
+    return out
+
+
+def edge_attr(edge_index: torch.Tensor, attr: torch.Tensor, aggr: str) -> torch.Tensor:
+    if aggr not in _EDGE_AGGR:
+        raise ValueError(f"Unknown aggregation method {aggr}")
+    ei = _edge_index(edge_index)
+    dev = require_device(ei, attr)
+    if attr.dtype not in _DTYPE_CODE:
+        raise TypeError(f"aggregate_node_attributes: unsupported attribute dtype {attr.dtype}")
+    attr = attr.contiguous()
+    n = attr.size(0)
+    width = attr.numel() // n if n else 1
+    e = ei.size(1)
+    with torch.cuda.device(dev):
+        out = torch.empty((e,) + tuple(attr.shape[1:]), dtype=attr.dtype, device=dev)
+        status = torch.empty(1, dtype=torch.int64, device=dev)
+        check(lib().pp_edge_attr(_p(ei), e, _p(attr), _DTYPE_CODE[attr.dtype], n, max(width, 1), _EDGE_AGGR[aggr], _p(out), _p(status),
+                                 _stream()), "pp_edge_attr")
+        _bad_index(int(status.item()), "aggregate_node_attributes")
+    return out
+
+
+def extend_node_sequence(edge_index: torch.Tensor, node_sequence: torch.Tensor) -> torch.Tensor:
+    ei = _edge_index(edge_index)
+    dev = require_device(ei, node_sequence)
+    ns = node_sequence.to(torch.int64).contiguous()
+    n_rows, k = ns.shape
+    e = ei.size(1)
+    with torch.cuda.device(dev):
+        out = torch.empty((e, k + 1), dtype=torch.int64, device=dev)
+        status = torch.empty(1, dtype=torch.int64, device=dev)
+        check(lib().pp_extend_node_sequence(_p(ei), e, _p(ns), n_rows, k, _p(out), _p(status), _stream()), "pp_extend_node_sequence")
+        _bad_index(int(status.item()), "node sequence extension")
+    return out
+
+
+# ------------------------------------------------------------------ aggregation
+def unique_rows(rows: torch.Tensor, value_range: tuple[int, int] | None = None):
+    """``torch.unique(rows, dim=0, return_inverse=True)`` for int64 ``[M, k]`` rows."""
+    dev = require_device(rows)
+    rows = rows.to(torch.int64).contiguous()
+    m, k = rows.shape
+    L = lib()
+    with torch.cuda.device(dev):
+        inverse = torch.empty(m, dtype=torch.int64, device=dev)
+        if m == 0:
+            return rows.new_empty((0, k)), inverse
+        lo, hi = value_range if value_range is not None else minmax(rows)
+        ws = _workspace(L.pp_unique_rows_ws_bytes(m), dev)
+        check(L.pp_unique_rows_count(_p(rows), m, k, lo, hi, _p(inverse), _p(ws), ws.numel(), _stream()), "pp_unique_rows_count")
+        n_unique, _ = _result(ws)
+        uniq = torch.empty((n_unique, k), dtype=torch.int64, device=dev)
+        check(L.pp_unique_rows_fill(_p(rows), m, k, n_unique, _p(uniq), _p(ws), ws.numel(), _stream()), "pp_unique_rows_fill")
+    return uniq, inverse
+
+
+def coalesce(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: int, reduce: str = "sum",
+             remap: torch.Tensor | None = None):
+    """PyG ``coalesce`` of ``remap[edge_index]`` (or ``edge_index``): (row, col)-sorted distinct edges + reduced weights."""
+    if reduce not in _REDUCE:
+        raise ValueError(f"unknown reduce {reduce}")
+    ei = _edge_index(edge_index)
+    dev = require_device(ei, weight, remap)
+    e = ei.size(1)
+    if weight is not None:
+        if weight.dtype not in _DTYPE_CODE:
+            raise TypeError(f"edge weights of dtype {weight.dtype} are not supported")
+        if weight.dim() != 1 or weight.numel() != e:
+            raise ValueError("edge_weight must be a vector with one entry per edge")
+        weight = weight.contiguous()
+    if remap is not None:
+        remap = remap.to(torch.int64).contiguous()
+    L = lib()
+    with torch.cuda.device(dev):
+        ws = _workspace(L.pp_coalesce_ws_bytes(e), dev)
+        check(L.pp_coalesce_count(_p(ei), e, _p(remap), 0 if remap is None else remap.numel(), num_nodes, _p(ws), ws.numel(), _stream()),
+              "pp_coalesce_count")
+        n_out, status = _result(ws)
+        _bad_index(status, "aggregate_edge_index")
+        out_index = torch.empty((2, n_out), dtype=torch.int64, device=dev)
+        out_weight = None if weight is None else torch.empty(n_out, dtype=weight.dtype, device=dev)
+        check(L.pp_coalesce_fill(_p(weight), 2 if weight is None else _DTYPE_CODE[weight.dtype], _REDUCE[reduce], e, n_out, num_nodes,
+                                 _p(out_index), _p(out_weight), _p(ws), ws.numel(), _stream()), "pp_coalesce_fill")
+    return out_index, out_weight
+
+
+# ------------------------------------------------------------------ Graph bookkeeping
+def is_sorted(a: torch.Tensor) -> bool:
+    a = a.contiguous()
+    dev = require_device(a)
+    with torch.cuda.device(dev):
+        out = torch.empty(1, dtype=torch.int64, device=dev)
+        check(lib().pp_count_descents_i64(_p(a), a.numel(), _p(out), _stream()), "pp_count_descents_i64")
+        return int(out.item()) == 0
+
+
+def argsort(keys: torch.Tensor, value_range: tuple[int, int] | None = None) -> torch.Tensor:
+    """Stable argsort of an int64 vector -> int64 permutation."""
+    keys = keys.to(torch.int64).contiguous()
+    dev = require_device(keys)
+    n = keys.numel()
+    with torch.cuda.device(dev):
+        perm = torch.empty(n, dtype=torch.int64, device=dev)
+        if n == 0:
+            return perm
+        lo, hi = value_range if value_range is not None else minmax(keys)
+        ws = _workspace(lib().pp_argsort_ws_bytes(n), dev)
+        check(lib().pp_argsort_i64(_p(keys), n, lo, hi, _p(perm), _p(ws), ws.numel(), _stream()), "pp_argsort_i64")
+    return perm
+
+
+def ptr_from_sorted(sorted_index: torch.Tensor, num_rows: int) -> torch.Tensor:
+    sorted_index = sorted_index.to(torch.int64).contiguous()
+    dev = require_device(sorted_index)
+    with torch.cuda.device(dev):
+        ptr = torch.empty(num_rows + 1, dtype=torch.int64, device=dev)
+        check(lib().pp_ptr_from_sorted_i64(_p(sorted_index), sorted_index.numel(), num_rows, _p(ptr), _stream()), "pp_ptr_from_sorted_i64")
+    return ptr

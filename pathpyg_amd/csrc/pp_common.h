@@ -1,0 +1,152 @@
+// pathpyg_amd — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// Wave width is 64 everywhere; nothing here is meant to build for another target.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pathpyg_amd.h"
+
+namespace pp {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;            // 4 waves: one per SIMD of a CU
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxGrid = 256 * 8;      // grid-stride cap: 256 CUs x 8 resident 256-thread blocks
+
+void set_error(const char* fmt, ...);
+
+#define PP_HIP(call)                                                                  \
+    do {                                                                              \
+        hipError_t e__ = (call);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            pp::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return PP_ERR_HIP;                                                        \
+        }                                                                             \
+    } while (0)
+
+#define PP_LAUNCH_CHECK() PP_HIP(hipGetLastError())
+
+#define PP_REQUIRE(cond, code, ...)                                                   \
+    do {                                                                              \
+        if (!(cond)) {                                                                \
+            pp::set_error(__VA_ARGS__);                                               \
+            return (code);                                                            \
+        }                                                                             \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int grid_for(int64_t n, int per_block) {
+    int64_t g = ceil_div(n, per_block);
+    return (int)(g < 1 ? 1 : g);
+}
+
+// Carves 256-byte aligned pieces out of a caller-provided workspace (torch owns the memory).
+struct Arena {
+    char* base;
+    size_t cap;
+    size_t used = 0;
+    Arena(void* p, size_t bytes) : base((char*)p), cap(bytes) {}
+    template <typename T>
+    T* take(int64_t count) {
+        size_t bytes = align_up((size_t)(count < 1 ? 1 : count) * sizeof(T));
+        char* p = base ? base + used : nullptr;
+        used += bytes;
+        return (T*)p;
+    }
+    bool ok() const { return used <= cap; }
+};
+
+static inline int bits_for(uint64_t max_value) {       // number of significant bits of max_value
+    int b = 0;
+    while (max_value) { ++b; max_value >>= 1; }
+    return b < 1 ? 1 : b;
+}
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    return (1ull << lane_id()) - 1ull;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_sum(T v) {
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        T o = __shfl_up(v, d, kWave);
+        if (lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        T o = __shfl_xor(v, d, kWave);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        T o = __shfl_xor(v, d, kWave);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// Block-wide exclusive sum of one value per thread (kBlock threads). `scratch` holds >= kWavesPerBlock+1 Ts.
+// Returns the exclusive prefix; *total receives the block sum (same in every thread).
+template <typename T>
+__device__ __forceinline__ T block_exclusive_sum(T v, T* scratch, T* total) {
+    T inc = wave_inclusive_sum(v);
+    if (lane_id() == kWave - 1) scratch[wave_id()] = inc;
+    __syncthreads();
+    T wave_base = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        T s = scratch[w];
+        if (w < wave_id()) wave_base += s;
+        sum += s;
+    }
+    __syncthreads();
+    *total = sum;
+    return wave_base + inc - v;
+}
+
+// first index in [lo, hi) with a[idx] > key (upper bound), a ascending
+template <typename T, typename I>
+__device__ __forceinline__ I upper_bound_dev(const T* __restrict__ a, I lo, I hi, T key) {
+    while (lo < hi) {
+        I mid = lo + ((hi - lo) >> 1);
+        if (a[mid] > key) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// first index in [lo, hi) with a[idx] >= key (lower bound), a ascending
+template <typename T, typename I>
+__device__ __forceinline__ I lower_bound_dev(const T* __restrict__ a, I lo, I hi, T key) {
+    while (lo < hi) {
+        I mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+}  // namespace pp

@@ -1,0 +1,24 @@
+// pathpyg_amd — declarations shared between the .hip translation units (host side only).
+#pragma once
+#include "pp_common.h"
+
+namespace pp {
+
+// pp_scan.hip
+size_t scan_ws_bytes(int64_t n);
+template <typename InT, typename OutT>
+int exclusive_scan(const InT* in, int64_t n, OutT* out, bool with_total, int64_t* total_dev, void* ws, size_t ws_bytes,
+                   hipStream_t st);
+template <typename IdxT>
+int histogram(const IdxT* idx, int64_t n, int64_t nbins, int32_t* bins, hipStream_t st);
+int minmax_i64(const int64_t* a, int64_t n, int64_t* out2, hipStream_t st);
+
+// pp_sort.hip
+size_t sort_ws_bytes(int64_t n, int key_bytes);
+// Stable LSD radix sort of (key, value) pairs on key bits [begin_bit, end_bit).
+// vals_in == nullptr means "values are 0..n-1".
+template <typename KeyT>
+int sort_pairs(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out, int64_t n, int begin_bit,
+               int end_bit, void* ws, size_t ws_bytes, hipStream_t st);
+
+}  // namespace pp

@@ -1,0 +1,424 @@
+// pathpyg_amd — order lifts on gfx950: temporal event-graph lift and line-graph lift.
+//
+// Reference functions replaced (paths relative to the pathpyG repository root):
+//   lift_order_temporal             src/pathpyG/algorithms/temporal.py:17-54
+//   lift_order_edge_index           src/pathpyG/algorithms/lift_order.py:48-79
+//   aggregate_node_attributes       src/pathpyG/algorithms/lift_order.py:10-45
+//   node-sequence extension         src/pathpyG/core/multi_order_model.py:114,165
+//
+// Both lifts are "count -> exclusive scan -> fill" over a CSR of continuations; none of the reference's
+// per-timestamp loop, masks or cartesian products exist here.
+//
+// Temporal lift, events i = 0..m-1 in (stable) time order:
+//   1. radix-sort event ids by tail node (pp_sort.hip; stable => ids ascend inside a node's list),
+//      row pointers from the run boundaries of the sorted keys.
+//   2. k_temporal_count: the admissible continuations of event i are the event ids in
+//      [g_lo, g_hi) = {j : t_j > t_i and t_j <= t_i + delta}, a contiguous id range because events are
+//      time-sorted; both ends come from binary searches on the time array with the comparison done in
+//      the dtype torch promotes to (temporal.py:30,43).  Inside the id list of head(i) the ids of that
+//      range are again contiguous: two more binary searches give (first position, count).
+//   3. exclusive scan of the counts (pp_scan.hip) -> output offsets and E2.
+//   4. k_expand: one workgroup per 2048 output slots; the sources overlapping the tile are found with
+//      two binary searches, their offsets staged in LDS, every lane resolves (source, rank) for its slots
+//      from LDS and stores int64 pairs with fully coalesced 8-byte-per-lane writes into the
+//      row-major [2,E2] result (lexicographic (i,j) order by construction).
+// HBM algorithmic bytes: 24*m (tail, head, time) + 16*E2 (result).
+#include "pp_internal.h"
+
+#include <type_traits>
+
+namespace pp {
+
+constexpr int kExpandItems = 8;
+constexpr int kExpandTile = kBlock * kExpandItems;   // output slots per workgroup
+constexpr int kExpandCap = kExpandTile + 1;          // sources whose offsets are staged in LDS
+
+// status word bits reported next to the size (see pp_*_count)
+constexpr int64_t kBadIndex = 1;
+
+// ------------------------------------------------------------------ small element-wise kernels
+__global__ __launch_bounds__(kBlock) void k_tail_keys(const int64_t* __restrict__ tail, int64_t m, int64_t num_nodes,
+                                                     uint32_t* __restrict__ keys, int64_t* __restrict__ status) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    int64_t v = tail[i];
+    if (v < 0 || v >= num_nodes) { atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex); v = 0; }
+    keys[i] = (uint32_t)v;
+}
+
+// rowptr[v] = first position p with sorted_keys[p] >= v, for v in [0, num_rows]; one thread per boundary.
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_rowptr_from_sorted(const KeyT* __restrict__ sorted_keys, int64_t n, int64_t num_rows,
+                                                              uint32_t* __restrict__ rowptr) {
+    int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p > n) return;
+    int64_t a = p == 0 ? -1 : (int64_t)sorted_keys[p - 1];
+    int64_t b = p == n ? num_rows : (int64_t)sorted_keys[p];
+    if (b > num_rows) b = num_rows;
+    for (int64_t v = a + 1; v <= b; ++v) rowptr[v] = (uint32_t)p;
+}
+
+// ------------------------------------------------------------------ temporal window arithmetic
+// kMode 0: native dtype (int64 time + int64 delta, or float64 time + float64 delta)
+// kMode 1: int64 time, float32 delta tensor  -> everything in float32 (torch promotion)
+// kMode 2: int64 time, float64 delta tensor  -> everything in float64
+template <typename TimeT, int kMode>
+struct Window;
+template <typename TimeT>
+struct Window<TimeT, 0> {
+    using Thr = TimeT;
+    __device__ static Thr threshold(TimeT t, int64_t di, double df) {
+        if constexpr (std::is_integral<TimeT>::value) return (TimeT)(t + (TimeT)di);
+        else return (TimeT)(t + (TimeT)df);
+    }
+    __device__ static bool admits(TimeT tj, Thr thr) { return tj <= thr; }
+};
+template <>
+struct Window<int64_t, 1> {
+    using Thr = float;
+    __device__ static Thr threshold(int64_t t, int64_t, double df) { return (float)t + (float)df; }
+    __device__ static bool admits(int64_t tj, Thr thr) { return (float)tj <= thr; }
+};
+template <>
+struct Window<int64_t, 2> {
+    using Thr = double;
+    __device__ static Thr threshold(int64_t t, int64_t, double df) { return (double)t + df; }
+    __device__ static bool admits(int64_t tj, Thr thr) { return (double)tj <= thr; }
+};
+
+template <typename TimeT, int kMode>
+__global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __restrict__ head, const TimeT* __restrict__ time, int64_t m,
+                                                          int64_t num_nodes, int64_t delta_i, double delta_f,
+                                                          const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids_by_tail,
+                                                          uint32_t* __restrict__ first_pos, int32_t* __restrict__ count,
+                                                          int64_t* __restrict__ status) {
+    using W = Window<TimeT, kMode>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const TimeT ti = time[i];
+    // g_lo: first id with t > t_i.  Without timestamp ties this is i+1: probe, then gallop, then bisect.
+    int64_t g_lo = i + 1;
+    if (g_lo < m && !(time[g_lo] > ti)) {
+        int64_t step = 2;
+        while (i + step < m && !(time[i + step] > ti)) step <<= 1;
+        int64_t hi = i + step < m ? i + step : m;
+        g_lo = upper_bound_dev<TimeT, int64_t>(time, i + (step >> 1) + 1, hi, ti);
+    }
+    // g_hi: first id >= g_lo whose time is no longer admitted by the (promoted-dtype) threshold
+    const typename W::Thr thr = W::threshold(ti, delta_i, delta_f);
+    int64_t lo = g_lo, hi = m;
+    while (lo < hi) {
+        int64_t mid = lo + ((hi - lo) >> 1);
+        if (W::admits(time[mid], thr)) lo = mid + 1; else hi = mid;
+    }
+    const int64_t g_hi = lo;
+    const int64_t v = head[i];
+    uint32_t pos = 0;
+    int32_t c = 0;
+    if (v < 0 || v >= num_nodes) {
+        atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex);
+    } else if (g_hi > g_lo) {
+        const uint32_t s0 = rowptr[v], s1 = rowptr[v + 1];
+        pos = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, s0, s1, (uint32_t)g_lo);
+        uint32_t end = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, pos, s1, (uint32_t)g_hi);
+        c = (int32_t)(end - pos);
+    }
+    first_pos[i] = pos;
+    count[i] = c;
+}
+
+// ------------------------------------------------------------------ line-graph count
+__global__ __launch_bounds__(kBlock) void k_linegraph_count(const int64_t* __restrict__ head, int64_t n_edges, int64_t num_nodes,
+                                                           const int32_t* __restrict__ outdeg, const uint32_t* __restrict__ rowptr,
+                                                           uint32_t* __restrict__ first_pos, int32_t* __restrict__ count,
+                                                           int64_t* __restrict__ status) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_edges) return;
+    const int64_t v = head[e];
+    uint32_t pos = 0;
+    int32_t c = 0;
+    if (v < 0 || v >= num_nodes) {
+        atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex);
+    } else {
+        pos = rowptr[v];
+        c = outdeg[v];
+    }
+    first_pos[e] = pos;
+    count[e] = c;
+}
+
+// ------------------------------------------------------------------ fill: load-balanced expansion
+// Source s owns output slots [offset[s], offset[s+1]).  Slot p of source s, rank r = p - offset[s]:
+//   out[0][p] = s ;  out[1][p] = kList ? list[first_pos[s] + r] : first_pos[s] + r
+template <bool kList>
+__global__ __launch_bounds__(kBlock) void k_expand(const int64_t* __restrict__ offset, const uint32_t* __restrict__ first_pos,
+                                                  const uint32_t* __restrict__ list, int64_t n_src, int64_t total,
+                                                  int64_t* __restrict__ out) {
+    __shared__ int32_t s_rel[kExpandCap + 1];
+    __shared__ int64_t s_range[2];
+    const int64_t p0 = (int64_t)blockIdx.x * kExpandTile;
+    const int64_t p1 = p0 + kExpandTile < total ? p0 + kExpandTile : total;
+    if (threadIdx.x < 2) {
+        const int64_t p = threadIdx.x == 0 ? p0 : p1 - 1;
+        // last source whose first slot is <= p (it is non-empty and contains p)
+        s_range[threadIdx.x] = upper_bound_dev<int64_t, int64_t>(offset, 0, n_src + 1, p) - 1;
+    }
+    __syncthreads();
+    const int64_t s_first = s_range[0];
+    const int64_t n_in_tile = s_range[1] - s_first + 1;
+    const bool staged = n_in_tile <= kExpandCap;
+    if (staged) {
+        for (int64_t k = threadIdx.x; k <= n_in_tile; k += kBlock) {       // n_in_tile+1 boundaries
+            int64_t rel = offset[s_first + k] - p0;
+            s_rel[k] = rel < -1 ? -1 : (rel > kExpandTile ? kExpandTile + 1 : (int32_t)rel);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kExpandItems; ++k) {
+        const int q = k * kBlock + threadIdx.x;
+        const int64_t p = p0 + q;
+        if (p >= p1) break;
+        int64_t s;
+        if (staged) {
+            int lo = 0, hi = (int)n_in_tile;          // last boundary index with s_rel <= q
+            while (lo < hi) {
+                int mid = lo + ((hi - lo) >> 1);
+                if (s_rel[mid] > q) hi = mid; else lo = mid + 1;
+            }
+            s = s_first + lo - 1;
+        } else {
+            s = upper_bound_dev<int64_t, int64_t>(offset, s_first, s_first + n_in_tile, p) - 1;
+        }
+        const int64_t r = p - offset[s];
+        const uint32_t at = first_pos[s] + (uint32_t)r;
+        out[p] = s;
+        out[total + p] = kList ? (int64_t)list[at] : (int64_t)at;
+    }
+}
+
+// ------------------------------------------------------------------ aggregate_node_attributes
+template <typename T>
+__device__ __forceinline__ T combine(T a, T b, int aggr) {
+    switch (aggr) {
+        case PP_AGGR_SRC: return a;
+        case PP_AGGR_DST: return b;
+        case PP_AGGR_MAX: return a > b ? a : b;
+        case PP_AGGR_MUL: return a * b;
+        default: return a + b;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_edge_attr(const int64_t* __restrict__ edge_index, int64_t n_edges, const T* __restrict__ attr,
+                                                     int64_t num_nodes, int64_t width, int aggr, T* __restrict__ out,
+                                                     int64_t* __restrict__ status) {
+    const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= n_edges * width) return;
+    const int64_t e = idx / width, c = idx - e * width;
+    int64_t a = edge_index[e], b = edge_index[n_edges + e];
+    if (a < 0 || a >= num_nodes || b < 0 || b >= num_nodes) {
+        atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex);
+        return;
+    }
+    T va = aggr == PP_AGGR_DST ? (T)0 : attr[a * width + c];
+    T vb = aggr == PP_AGGR_SRC ? (T)0 : attr[b * width + c];
+    out[idx] = combine<T>(va, vb, aggr);
+}
+
+// order-(k+1) instance sequences: row e = node_sequence[tail(e)] ++ last element of node_sequence[head(e)]
+__global__ __launch_bounds__(kBlock) void k_extend_rows(const int64_t* __restrict__ edge_index, int64_t n_edges,
+                                                       const int64_t* __restrict__ rows, int64_t n_rows, int k,
+                                                       int64_t* __restrict__ out, int64_t* __restrict__ status) {
+    const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int kk = k + 1;
+    if (idx >= n_edges * kk) return;
+    const int64_t e = idx / kk;
+    const int c = (int)(idx - e * kk);
+    const int64_t r = c < k ? edge_index[e] : edge_index[n_edges + e];
+    if (r < 0 || r >= n_rows) {
+        atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex);
+        return;
+    }
+    out[idx] = rows[r * k + (c < k ? c : k - 1)];
+}
+
+// ------------------------------------------------------------------ workspace layouts
+struct LiftWs {
+    int64_t* result;        // [2]: {total, status}
+    int64_t* offset;        // [n_src + 1]
+    uint32_t* first_pos;    // [n_src]
+    int32_t* count;         // [n_src]
+    uint32_t* rowptr;       // [num_nodes + 1]
+    uint32_t* ids;          // temporal: event ids grouped by tail [n_src]
+    uint32_t* keys;         // temporal: tail keys [n_src];  line graph: outdeg (as int32) [num_nodes]
+    uint32_t* sorted_keys;  // temporal only [n_src]
+    void* scratch;          // sort / scan workspace
+    size_t scratch_bytes;
+    size_t total_bytes;
+};
+
+static LiftWs carve_lift(void* ws, int64_t n_src, int64_t num_nodes, bool temporal) {
+    Arena a(ws, (size_t)-1);
+    LiftWs w;
+    w.result = a.take<int64_t>(2);
+    w.offset = a.take<int64_t>(n_src + 1);
+    w.first_pos = a.take<uint32_t>(n_src);
+    w.count = a.take<int32_t>(n_src);
+    w.rowptr = a.take<uint32_t>(num_nodes + 1);
+    w.ids = temporal ? a.take<uint32_t>(n_src) : nullptr;
+    w.keys = a.take<uint32_t>(temporal ? n_src : num_nodes);
+    w.sorted_keys = temporal ? a.take<uint32_t>(n_src) : nullptr;
+    size_t sb = scan_ws_bytes(n_src > num_nodes ? n_src : num_nodes);
+    if (temporal) { size_t s2 = sort_ws_bytes(n_src, 4); sb = s2 > sb ? s2 : sb; }
+    w.scratch_bytes = sb;
+    w.scratch = a.take<char>((int64_t)sb);
+    w.total_bytes = a.used;
+    return w;
+}
+
+template <typename TimeT>
+static int launch_temporal_count(int delta_kind, unsigned grid, hipStream_t st, const int64_t* head, const TimeT* time, int64_t m,
+                                 int64_t n, int64_t di, double df, const LiftWs& w);
+
+template <>
+int launch_temporal_count<int64_t>(int delta_kind, unsigned grid, hipStream_t st, const int64_t* head, const int64_t* time, int64_t m,
+                                   int64_t n, int64_t di, double df, const LiftWs& w) {
+    if (delta_kind == PP_DELTA_I64)
+        k_temporal_count<int64_t, 0><<<grid, kBlock, 0, st>>>(head, time, m, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+    else if (delta_kind == PP_DELTA_F32)
+        k_temporal_count<int64_t, 1><<<grid, kBlock, 0, st>>>(head, time, m, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+    else
+        k_temporal_count<int64_t, 2><<<grid, kBlock, 0, st>>>(head, time, m, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+template <>
+int launch_temporal_count<double>(int, unsigned grid, hipStream_t st, const int64_t* head, const double* time, int64_t m, int64_t n,
+                                  int64_t di, double df, const LiftWs& w) {
+    k_temporal_count<double, 0><<<grid, kBlock, 0, st>>>(head, time, m, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" {
+
+// ---------------------------------------------------------------- temporal lift
+size_t pp_temporal_ws_bytes(int64_t m, int64_t num_nodes) { return carve_lift(nullptr, m, num_nodes, true).total_bytes; }
+
+int pp_temporal_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind,
+                      int64_t delta_i, double delta_f, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(m >= 0 && num_nodes >= 0, PP_ERR_ARG, "pp_temporal_count: negative size");
+    PP_REQUIRE(m < (int64_t)0x7fffffff && num_nodes < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_temporal_count: m or num_nodes >= 2^31");
+    PP_REQUIRE(time_dtype == PP_I64 || time_dtype == PP_F64, PP_ERR_ARG, "pp_temporal_count: time must be int64 or float64");
+    PP_REQUIRE(delta_kind >= PP_DELTA_I64 && delta_kind <= PP_DELTA_F64, PP_ERR_ARG, "pp_temporal_count: bad delta kind");
+    LiftWs w = carve_lift(ws, m, num_nodes, true);
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_temporal_count: workspace too small");
+    PP_HIP(hipMemsetAsync(w.result, 0, 2 * sizeof(int64_t), st));
+    if (m == 0) return PP_OK;
+    const int64_t* tail = edge_index;
+    const int64_t* head = edge_index + m;
+    const unsigned grid = (unsigned)ceil_div(m, kBlock);
+    // 1. CSR of event ids by tail node
+    k_tail_keys<<<grid, kBlock, 0, st>>>(tail, m, num_nodes, w.keys, w.result + 1);
+    PP_LAUNCH_CHECK();
+    const int key_bits = bits_for((uint64_t)(num_nodes > 0 ? num_nodes - 1 : 0));
+    int rc = sort_pairs<uint32_t>(w.keys, nullptr, w.sorted_keys, w.ids, m, 0, key_bits, w.scratch, w.scratch_bytes, st);
+    if (rc != PP_OK) return rc;
+    k_rowptr_from_sorted<uint32_t><<<(unsigned)ceil_div(m + 1, kBlock), kBlock, 0, st>>>(w.sorted_keys, m, num_nodes, w.rowptr);
+    PP_LAUNCH_CHECK();
+    // 2. per-event continuation window
+    if (time_dtype == PP_I64)
+        rc = launch_temporal_count<int64_t>(delta_kind, grid, st, head, (const int64_t*)time, m, num_nodes, delta_i, delta_f, w);
+    else
+        rc = launch_temporal_count<double>(delta_kind, grid, st, head, (const double*)time, m, num_nodes, delta_i, delta_f, w);
+    if (rc != PP_OK) return rc;
+    // 3. offsets + total
+    return exclusive_scan<int32_t, int64_t>(w.count, m, w.offset, true, w.result, w.scratch, w.scratch_bytes, st);
+}
+
+int pp_temporal_fill(int64_t m, int64_t num_nodes, int64_t total, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LiftWs w = carve_lift(ws, m, num_nodes, true);
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_temporal_fill: workspace too small");
+    if (total <= 0) return PP_OK;
+    k_expand<true><<<(unsigned)ceil_div(total, kExpandTile), kBlock, 0, st>>>(w.offset, w.first_pos, w.ids, m, total, out);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+// ---------------------------------------------------------------- line-graph lift
+size_t pp_linegraph_ws_bytes(int64_t n_edges, int64_t num_nodes) { return carve_lift(nullptr, n_edges, num_nodes, false).total_bytes; }
+
+int pp_linegraph_count(const int64_t* edge_index, int64_t n_edges, int64_t num_nodes, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_edges >= 0 && num_nodes >= 0, PP_ERR_ARG, "pp_linegraph_count: negative size");
+    PP_REQUIRE(n_edges < (int64_t)0x7fffffff && num_nodes < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_linegraph_count: E or N >= 2^31");
+    LiftWs w = carve_lift(ws, n_edges, num_nodes, false);
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_linegraph_count: workspace too small");
+    PP_HIP(hipMemsetAsync(w.result, 0, 2 * sizeof(int64_t), st));
+    if (n_edges == 0) return PP_OK;
+    int32_t* outdeg = (int32_t*)w.keys;
+    int rc = histogram<int64_t>(edge_index, n_edges, num_nodes, outdeg, st);      // degree(edge_index[0])
+    if (rc != PP_OK) return rc;
+    rc = exclusive_scan<int32_t, int32_t>(outdeg, num_nodes, (int32_t*)w.rowptr, true, nullptr, w.scratch, w.scratch_bytes, st);
+    if (rc != PP_OK) return rc;
+    k_linegraph_count<<<(unsigned)ceil_div(n_edges, kBlock), kBlock, 0, st>>>(edge_index + n_edges, n_edges, num_nodes, outdeg, w.rowptr,
+                                                                             w.first_pos, w.count, w.result + 1);
+    PP_LAUNCH_CHECK();
+    return exclusive_scan<int32_t, int64_t>(w.count, n_edges, w.offset, true, w.result, w.scratch, w.scratch_bytes, st);
+}
+
+int pp_linegraph_fill(int64_t n_edges, int64_t num_nodes, int64_t total, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LiftWs w = carve_lift(ws, n_edges, num_nodes, false);
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_linegraph_fill: workspace too small");
+    if (total <= 0) return PP_OK;
+    k_expand<false><<<(unsigned)ceil_div(total, kExpandTile), kBlock, 0, st>>>(w.offset, w.first_pos, nullptr, n_edges, total, out);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+// {total, status} written by the last *_count on this workspace (two int64 at the start of the workspace)
+const int64_t* pp_lift_result_ptr(void* ws) { return (const int64_t*)ws; }
+
+// ---------------------------------------------------------------- aggregate_node_attributes
+int pp_edge_attr(const int64_t* edge_index, int64_t n_edges, const void* attr, int dtype, int64_t num_nodes, int64_t width, int aggr,
+                 void* out, int64_t* status, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(aggr >= PP_AGGR_SRC && aggr <= PP_AGGR_ADD, PP_ERR_ARG, "Unknown aggregation method %d", aggr);
+    PP_REQUIRE(width >= 1, PP_ERR_ARG, "pp_edge_attr: width must be >= 1");
+    PP_HIP(hipMemsetAsync(status, 0, sizeof(int64_t), st));
+    const int64_t total = n_edges * width;
+    if (total == 0) return PP_OK;
+    const unsigned grid = (unsigned)ceil_div(total, kBlock);
+    switch (dtype) {
+        case PP_I32: k_edge_attr<int32_t><<<grid, kBlock, 0, st>>>(edge_index, n_edges, (const int32_t*)attr, num_nodes, width, aggr, (int32_t*)out, status); break;
+        case PP_I64: k_edge_attr<int64_t><<<grid, kBlock, 0, st>>>(edge_index, n_edges, (const int64_t*)attr, num_nodes, width, aggr, (int64_t*)out, status); break;
+        case PP_F32: k_edge_attr<float><<<grid, kBlock, 0, st>>>(edge_index, n_edges, (const float*)attr, num_nodes, width, aggr, (float*)out, status); break;
+        case PP_F64: k_edge_attr<double><<<grid, kBlock, 0, st>>>(edge_index, n_edges, (const double*)attr, num_nodes, width, aggr, (double*)out, status); break;
+        default: PP_REQUIRE(false, PP_ERR_ARG, "pp_edge_attr: unsupported dtype %d", dtype);
+    }
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+// ---------------------------------------------------------------- node-sequence extension
+int pp_extend_node_sequence(const int64_t* edge_index, int64_t n_edges, const int64_t* rows, int64_t n_rows, int k, int64_t* out,
+                            int64_t* status, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(k >= 1, PP_ERR_ARG, "pp_extend_node_sequence: k must be >= 1");
+    PP_HIP(hipMemsetAsync(status, 0, sizeof(int64_t), st));
+    const int64_t total = n_edges * (k + 1);
+    if (total == 0) return PP_OK;
+    k_extend_rows<<<(unsigned)ceil_div(total, kBlock), kBlock, 0, st>>>(edge_index, n_edges, rows, n_rows, k, out, status);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // extern "C"

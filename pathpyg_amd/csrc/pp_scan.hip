@@ -1,0 +1,214 @@
+// pathpyg_amd — prefix sums, histograms and small reductions (gfx950).
+//
+// These replace the torch/PyG calls the reference's lifts are built from:
+//   torch_geometric.utils.cumsum / degree   (reference src/pathpyG/algorithms/lift_order.py:65,74,77)
+// All of them are pure HBM streams: 16-byte loads per lane, wave shuffles for the
+// intra-wave step, LDS only for the 4 per-wave partials of a 256-thread workgroup.
+#include "pp_common.h"
+
+#include <stdarg.h>
+
+namespace pp {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+constexpr int kScanItems = 8;                       // consecutive items per thread
+constexpr int kScanTile = kBlock * kScanItems;      // 2048 items per workgroup
+
+// ---- pass 1: one partial sum per tile ---------------------------------------------------------
+template <typename InT>
+__global__ __launch_bounds__(kBlock) void k_tile_sums(const InT* __restrict__ in, int64_t n, int64_t* __restrict__ tile_sum) {
+    __shared__ int64_t part[kWavesPerBlock];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        int64_t i = base + k;
+        if (i < n) s += (int64_t)in[i];
+    }
+    s = wave_sum(s);
+    if (lane_id() == 0) part[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) t += part[w];
+        tile_sum[blockIdx.x] = t;
+    }
+}
+
+// ---- pass 2: exclusive scan of the tile sums, in place, by ONE workgroup ------------------------
+__global__ __launch_bounds__(kBlock) void k_scan_tile_sums(int64_t* __restrict__ tile_sum, int64_t ntiles, int64_t* __restrict__ total_out) {
+    __shared__ int64_t scratch[kWavesPerBlock + 1];
+    int64_t carry = 0;
+    for (int64_t start = 0; start < ntiles; start += kBlock) {
+        int64_t i = start + threadIdx.x;
+        int64_t v = i < ntiles ? tile_sum[i] : 0;
+        int64_t tot;
+        int64_t ex = block_exclusive_sum(v, scratch, &tot);
+        if (i < ntiles) tile_sum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+// ---- pass 3: rescan every tile with its base ------------------------------------------------------
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(const InT* __restrict__ in, int64_t n, const int64_t* __restrict__ tile_base,
+                                                      OutT* __restrict__ out, int write_total) {
+    __shared__ int64_t scratch[kWavesPerBlock + 1];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int64_t v[kScanItems];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        int64_t i = base + k;
+        v[k] = i < n ? (int64_t)in[i] : 0;
+        s += v[k];
+    }
+    int64_t tot;
+    int64_t run = tile_base[blockIdx.x] + block_exclusive_sum(s, scratch, &tot);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        int64_t i = base + k;
+        if (i < n) out[i] = (OutT)run;
+        run += v[k];
+        if (write_total && i == n - 1) out[n] = (OutT)run;   // out has n+1 entries
+    }
+}
+
+size_t scan_ws_bytes(int64_t n) { return align_up((size_t)(ceil_div(n > 0 ? n : 1, kScanTile) + 1) * sizeof(int64_t)); }
+
+// out[i] = sum(in[0..i)), i in [0,n]; out[n] (= total) is written when `with_total`; *total_dev optional.
+template <typename InT, typename OutT>
+int exclusive_scan(const InT* in, int64_t n, OutT* out, bool with_total, int64_t* total_dev, void* ws, size_t ws_bytes,
+                   hipStream_t st) {
+    PP_REQUIRE(n >= 0, PP_ERR_ARG, "exclusive_scan: negative length");
+    PP_REQUIRE(ws_bytes >= scan_ws_bytes(n), PP_ERR_WORKSPACE, "exclusive_scan: workspace too small");
+    int64_t* tile_sum = (int64_t*)ws;
+    if (n == 0) {
+        if (with_total) PP_HIP(hipMemsetAsync(out, 0, sizeof(OutT), st));
+        if (total_dev) PP_HIP(hipMemsetAsync(total_dev, 0, sizeof(int64_t), st));
+        return PP_OK;
+    }
+    const int64_t ntiles = ceil_div(n, kScanTile);
+    k_tile_sums<InT><<<(unsigned)ntiles, kBlock, 0, st>>>(in, n, tile_sum);
+    PP_LAUNCH_CHECK();
+    k_scan_tile_sums<<<1, kBlock, 0, st>>>(tile_sum, ntiles, total_dev);
+    PP_LAUNCH_CHECK();
+    k_scan_tiles<InT, OutT><<<(unsigned)ntiles, kBlock, 0, st>>>(in, n, tile_sum, out, with_total ? 1 : 0);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+template int exclusive_scan<int32_t, int64_t>(const int32_t*, int64_t, int64_t*, bool, int64_t*, void*, size_t, hipStream_t);
+template int exclusive_scan<int32_t, int32_t>(const int32_t*, int64_t, int32_t*, bool, int64_t*, void*, size_t, hipStream_t);
+template int exclusive_scan<int64_t, int64_t>(const int64_t*, int64_t, int64_t*, bool, int64_t*, void*, size_t, hipStream_t);
+template int exclusive_scan<uint32_t, uint32_t>(const uint32_t*, int64_t, uint32_t*, bool, int64_t*, void*, size_t, hipStream_t);
+
+// ---- histogram of an index vector (PyG degree) ---------------------------------------------------
+// Runs of equal values inside a wave (the common case: the line-graph lift's input is source-sorted)
+// are folded into ONE atomic by the run's first lane; unsorted input degrades to one atomic per lane.
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void k_histogram(const IdxT* __restrict__ idx, int64_t n, int64_t nbins, int32_t* __restrict__ bins) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < n; i0 += stride) {   // wave-uniform trip count
+        const int64_t i = i0 + threadIdx.x;
+        const bool live = i < n;
+        int64_t v = live ? (int64_t)idx[i] : -1;
+        int64_t prev = __shfl_up(v, 1, kWave);
+        bool head = live && (lane_id() == 0 || prev != v);
+        uint64_t heads = __ballot(head);
+        uint64_t lives = __ballot(live);
+        if (head) {
+            // run length = distance to the next head (or to the end of the live lanes)
+            uint64_t later = heads & ~((2ull << lane_id()) - 1ull);
+            int next = later ? __ffsll((long long)later) - 1 : (int)__popcll(lives);
+            int len = next - lane_id();
+            if (v >= 0 && v < nbins) atomicAdd(&bins[v], len);
+        }
+    }
+}
+
+template <typename IdxT>
+int histogram(const IdxT* idx, int64_t n, int64_t nbins, int32_t* bins, hipStream_t st) {
+    PP_HIP(hipMemsetAsync(bins, 0, (size_t)(nbins > 0 ? nbins : 0) * sizeof(int32_t), st));
+    if (n == 0 || nbins == 0) return PP_OK;
+    int64_t g = ceil_div(n, kBlock);
+    if (g > kMaxGrid * 4) g = kMaxGrid * 4;
+    k_histogram<IdxT><<<(unsigned)g, kBlock, 0, st>>>(idx, n, nbins, bins);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+template int histogram<int64_t>(const int64_t*, int64_t, int64_t, int32_t*, hipStream_t);
+template int histogram<uint32_t>(const uint32_t*, int64_t, int64_t, int32_t*, hipStream_t);
+
+// ---- min / max of an int64 vector (index validation, radix pass count) ------------------------------
+__global__ __launch_bounds__(kBlock) void k_minmax_i64(const int64_t* __restrict__ a, int64_t n, int64_t* __restrict__ out /*[2]: min,max*/) {
+    __shared__ int64_t smin[kWavesPerBlock], smax[kWavesPerBlock];
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        int64_t v = a[i];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+    hi = wave_max(hi);
+    lo = wave_min(lo);
+    if (lane_id() == 0) { smin[wave_id()] = lo; smax[wave_id()] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            lo = smin[w] < lo ? smin[w] : lo;
+            hi = smax[w] > hi ? smax[w] : hi;
+        }
+        atomicMin((long long*)&out[0], (long long)lo);
+        atomicMax((long long*)&out[1], (long long)hi);
+    }
+}
+
+__global__ void k_init_minmax(int64_t* out) { out[0] = INT64_MAX; out[1] = INT64_MIN; }
+
+int minmax_i64(const int64_t* a, int64_t n, int64_t* out2, hipStream_t st) {
+    k_init_minmax<<<1, 1, 0, st>>>(out2);
+    PP_LAUNCH_CHECK();
+    if (n == 0) return PP_OK;
+    int64_t g = ceil_div(n, kBlock * 4);
+    if (g > kMaxGrid) g = kMaxGrid;
+    if (g < 1) g = 1;
+    k_minmax_i64<<<(unsigned)g, kBlock, 0, st>>>(a, n, out2);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // namespace pp
+
+// =================================================================== C ABI
+extern "C" {
+
+int pp_version(void) { return PP_VERSION; }
+const char* pp_last_error(void) { return pp::g_err; }
+
+size_t pp_scan_ws_bytes(int64_t n) { return pp::scan_ws_bytes(n); }
+
+int pp_exclusive_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    return pp::exclusive_scan<int32_t, int64_t>(in, n, out, true, nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+int pp_exclusive_scan_i64(const int64_t* in, int64_t n, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    return pp::exclusive_scan<int64_t, int64_t>(in, n, out, true, nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+int pp_degree_i64(const int64_t* index, int64_t n, int64_t num_bins, int32_t* bins, pp_stream_t stream) {
+    return pp::histogram<int64_t>(index, n, num_bins, bins, (hipStream_t)stream);
+}
+int pp_minmax_i64(const int64_t* a, int64_t n, int64_t* out2, pp_stream_t stream) {
+    return pp::minmax_i64(a, n, out2, (hipStream_t)stream);
+}
+
+}  // extern "C"

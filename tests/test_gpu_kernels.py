@@ -1,0 +1,254 @@
+"""GPU parity tests of the HIP kernels, called through the C ABI (ctypes), against the CPU oracle
+and the golden vectors produced by the reference's own source.  Run with ``-m gpu`` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_delta
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from pathpyg_amd import _hip
+    return _hip
+
+
+def cu(x):
+    return x.to(DEV)
+
+
+# ---------------------------------------------------------------- primitives
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 2047, 2048, 2049, 100_003, 3_000_001])
+def test_exclusive_scan(hip, n):
+    g = torch.Generator().manual_seed(n)
+    for dtype in (torch.int32, torch.int64):
+        v = torch.randint(0, 1000, (n,), generator=g, dtype=dtype)
+        want = torch.zeros(n + 1, dtype=torch.int64)
+        want[1:] = torch.cumsum(v.long(), 0)
+        assert torch.equal(hip.exclusive_scan(cu(v)).cpu(), want)
+
+
+@pytest.mark.parametrize("sorted_input", [True, False])
+def test_degree(hip, sorted_input):
+    g = torch.Generator().manual_seed(1)
+    idx = torch.randint(0, 5000, (1_000_003,), generator=g)
+    idx[:70000] = 17                       # a hub: long runs inside waves
+    if sorted_input:
+        idx = idx.sort().values
+    want = torch.bincount(idx, minlength=6000).int()
+    assert torch.equal(hip.degree(cu(idx), 6000).cpu(), want)
+    assert hip.minmax(cu(idx)) == (int(idx.min()), int(idx.max()))
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 4095, 4096, 4097, 10_000, 1_000_003])
+@pytest.mark.parametrize("bits", [1, 7, 8, 9, 19, 32])
+def test_sort_pairs_u32(hip, n, bits):
+    g = torch.Generator().manual_seed(n * 31 + bits)
+    hi = 2 ** min(bits, 31)
+    keys = torch.randint(0, hi, (n,), generator=g, dtype=torch.int64).int()
+    ks, vs = hip.sort_pairs(cu(keys), None, 0, bits)
+    order = torch.sort(keys.long(), stable=True)
+    assert torch.equal(ks.cpu().long(), order.values)
+    assert torch.equal(vs.cpu().long(), order.indices)
+    # explicit values + a bit window: stable w.r.t. the masked key
+    vals = torch.randint(0, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int64).int()
+    ks2, vs2 = hip.sort_pairs(cu(keys), cu(vals), 2, max(bits, 3))
+    masked = (keys.long() >> 2) & ((1 << (max(bits, 3) - 2)) - 1)
+    perm = torch.sort(masked, stable=True).indices
+    assert torch.equal(ks2.cpu(), keys[perm])
+    assert torch.equal(vs2.cpu(), vals[perm])
+
+
+@pytest.mark.parametrize("n", [3, 4097, 300_001])
+@pytest.mark.parametrize("bits", [5, 33, 48, 64])
+def test_sort_pairs_u64(hip, n, bits):
+    g = torch.Generator().manual_seed(n + bits)
+    keys = torch.randint(0, 2 ** min(bits, 62), (n,), generator=g, dtype=torch.int64)
+    ks, vs = hip.sort_pairs(cu(keys), None, 0, bits)
+    order = torch.sort(keys, stable=True)
+    assert torch.equal(ks.cpu(), order.values)
+    assert torch.equal(vs.cpu().long(), order.indices)
+
+
+# ---------------------------------------------------------------- lifts vs golden (reference source) vectors
+TEMPORAL = ["int_ties", "int_unique", "int_wide", "int_delta0", "int_fdelta", "int_f64delta",
+            "f64_ties", "f64_npdelta", "f64_intdelta", "int_big"]
+
+
+@pytest.mark.parametrize("name", TEMPORAL)
+def test_temporal_lift_golden(hip, golden, name):
+    ei = torch.from_numpy(golden[f"temporal/{name}/edge_index"])
+    t = torch.from_numpy(golden[f"temporal/{name}/time"])
+    out = hip.temporal_lift(cu(ei), cu(t), int(golden[f"temporal/{name}/num_nodes"]), golden_delta(golden, name))
+    want = torch.from_numpy(golden[f"temporal/{name}/out"])
+    assert out.dtype == torch.int64 and out.is_contiguous()
+    assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.parametrize("name", ["small", "multi", "isolated", "hub", "wide"])
+def test_linegraph_lift_golden(hip, golden, name):
+    ei = torch.from_numpy(golden[f"linegraph/{name}/edge_index"])
+    n = int(golden[f"linegraph/{name}/num_nodes"])
+    out = hip.linegraph_lift(cu(ei), n)
+    assert torch.equal(out.cpu(), torch.from_numpy(golden[f"linegraph/{name}/out"]))
+    w = torch.from_numpy(golden[f"linegraph/{name}/edge_weight"])
+    for aggr in ("src", "dst", "max", "mul", "add"):
+        got = hip.edge_attr(out, cu(w), aggr)
+        assert torch.equal(got.cpu(), torch.from_numpy(golden[f"linegraph/{name}/w_{aggr}"]))
+
+
+def test_chained_lifts_golden(hip, golden):
+    ei = cu(torch.from_numpy(golden["chain/edge_index"]))
+    t = cu(torch.from_numpy(golden["chain/time"]))
+    ho = hip.temporal_lift(ei, t, int(golden["chain/num_nodes"]), int(golden["chain/delta"]))
+    assert torch.equal(ho.cpu(), torch.from_numpy(golden["chain/k2"]))
+    n_inst = ei.size(1)
+    for k in (3, 4, 5):
+        nxt = hip.linegraph_lift(ho, n_inst)
+        n_inst, ho = ho.size(1), nxt
+        assert torch.equal(ho.cpu(), torch.from_numpy(golden[f"chain/k{k}"]))
+
+
+# ---------------------------------------------------------------- lifts vs the oracle on seeded streams
+def _stream(seed, m, n, span, float_time=False):
+    rng = np.random.default_rng(seed)
+    ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+    t = np.sort(np.round(rng.random(m) * span, 1) if float_time else rng.integers(0, span, m))
+    return ei, torch.from_numpy(t)
+
+
+@pytest.mark.parametrize("seed,m,n,span,delta,ft", [
+    (1, 20_000, 50, 400, 7, False),          # heavy ties, hubs
+    (2, 200_000, 10_000, 10 ** 6, 30_000, False),
+    (3, 100_000, 300, 5_000, 2.5, True),
+    (4, 100_000, 300, 10 ** 9, 1.0e6, False),  # python float delta on int64 time: float32 path
+    (5, 50_000, 3, 50_000, 40, False),        # 3 nodes: very long per-node lists
+    (6, 1, 4, 10, 3, False),
+    (7, 4097, 1, 4097, 5, False),             # single node, every event continues every close one
+])
+def test_temporal_lift_oracle(hip, seed, m, n, span, delta, ft):
+    from oracle import lift as ol
+    ei, t = _stream(seed, m, n, span, ft)
+    want = ol.temporal_lift_sorted(ei, t, delta, n)
+    got = hip.temporal_lift(cu(ei), cu(t), n, delta)
+    assert got.shape == want.shape
+    assert torch.equal(got.cpu(), want)
+
+
+def test_temporal_lift_empty_and_errors(hip):
+    ei = torch.empty((2, 0), dtype=torch.long)
+    out = hip.temporal_lift(cu(ei), cu(torch.empty(0, dtype=torch.long)), 5, 1)
+    assert out.shape == (2, 0)
+    ei = torch.tensor([[0, 9], [1, 2]])
+    with pytest.raises(IndexError):
+        hip.temporal_lift(cu(ei), cu(torch.tensor([1, 2])), 3, 1)
+    with pytest.raises(TypeError):
+        hip.temporal_lift(cu(torch.tensor([[0], [1]])), cu(torch.tensor([1.0])), 3, 1)
+
+
+@pytest.mark.parametrize("seed,e,n", [(1, 100_000, 1000), (2, 300_000, 50_000), (3, 20_000, 7)])
+def test_linegraph_lift_oracle(hip, seed, e, n):
+    from oracle import lift as ol
+    rng = np.random.default_rng(seed)
+    src = np.sort(rng.integers(0, n, e))
+    dst = rng.integers(0, n, e)
+    ei = torch.from_numpy(np.stack([src, dst]))
+    want = ol.line_graph_lift(ei, n)
+    got = hip.linegraph_lift(cu(ei), n)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_edge_attr_dtypes_and_rows(hip):
+    from oracle import lift as ol
+    g = torch.Generator().manual_seed(0)
+    ei = torch.randint(0, 100, (2, 5000), generator=g)
+    for dtype in (torch.int32, torch.int64, torch.float32, torch.float64):
+        a = (torch.rand(100, generator=g) * 50).to(dtype)
+        for aggr in ("src", "dst", "max", "mul", "add"):
+            assert torch.equal(hip.edge_attr(cu(ei), cu(a), aggr).cpu(), ol.edge_attribute_from_nodes(ei, a, aggr))
+    a2 = torch.rand(100, 3, generator=g)
+    assert torch.equal(hip.edge_attr(cu(ei), cu(a2), "add").cpu(), ol.edge_attribute_from_nodes(ei, a2, "add"))
+    with pytest.raises(ValueError):
+        hip.edge_attr(cu(ei), cu(a2), "unknown")
+
+
+def test_extend_node_sequence(hip):
+    from oracle import model as om
+    g = torch.Generator().manual_seed(0)
+    for k in (1, 2, 4):
+        ns = torch.randint(0, 50, (300, k), generator=g)
+        ei = torch.randint(0, 300, (2, 2000), generator=g)
+        assert torch.equal(hip.extend_node_sequence(cu(ei), cu(ns)).cpu(), om.extend_node_sequence(ns, ei))
+
+
+# ---------------------------------------------------------------- aggregation
+@pytest.mark.parametrize("m,k,hi", [(1, 1, 5), (1000, 1, 50), (5000, 2, 30), (200_000, 2, 3000), (100_000, 3, 40),
+                                     (50_000, 5, 6), (10_000, 2, 2 ** 40)])
+def test_unique_rows(hip, m, k, hi):
+    g = torch.Generator().manual_seed(m + k)
+    rows = torch.randint(0, hi, (m, k), generator=g)
+    if hi > 2 ** 32:
+        rows[::2] = rows[1::2] if m % 2 == 0 else rows[::2]
+    uniq, inv = hip.unique_rows(cu(rows))
+    wu, wi = torch.unique(rows, dim=0, return_inverse=True)
+    assert torch.equal(uniq.cpu(), wu)
+    assert torch.equal(inv.cpu(), wi)
+
+
+def test_unique_rows_negative_values(hip):
+    rows = torch.tensor([[3, -1], [-5, 2], [3, -1], [0, 0], [-5, 1]])
+    uniq, inv = hip.unique_rows(cu(rows))
+    wu, wi = torch.unique(rows, dim=0, return_inverse=True)
+    assert torch.equal(uniq.cpu(), wu) and torch.equal(inv.cpu(), wi)
+
+
+@pytest.mark.parametrize("e,n", [(1, 1), (1000, 10), (100_000, 300), (300_000, 70_000)])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+def test_coalesce(hip, e, n, reduce):
+    from oracle import aggregate as oa
+    g = torch.Generator().manual_seed(e)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    for w in (torch.randint(1, 5, (e,), generator=g).float(), torch.rand(e, generator=g),
+              torch.randint(-9, 9, (e,), generator=g), torch.rand(e, generator=g, dtype=torch.float64)):
+        wi, ww = oa.coalesce(ei, w, n, reduce)
+        gi, gw = hip.coalesce(cu(ei), cu(w), n, reduce)
+        assert torch.equal(gi.cpu(), wi)
+        if w.is_floating_point() and reduce == "mean":
+            torch.testing.assert_close(gw.cpu(), ww, rtol=1e-6, atol=0)
+        else:
+            assert torch.equal(gw.cpu(), ww)          # left-to-right accumulation order matches the CPU scatter
+
+
+def test_coalesce_remap_and_bad_index(hip):
+    from oracle import aggregate as oa
+    g = torch.Generator().manual_seed(3)
+    remap = torch.randint(0, 40, (500,), generator=g)
+    ei = torch.randint(0, 500, (2, 20_000), generator=g)
+    w = torch.ones(20_000)
+    wi, ww = oa.coalesce(remap[ei], w, 40, "sum")
+    gi, gw = hip.coalesce(cu(ei), cu(w), 40, "sum", remap=cu(remap))
+    assert torch.equal(gi.cpu(), wi) and torch.equal(gw.cpu(), ww)
+    with pytest.raises(IndexError):
+        hip.coalesce(cu(ei), cu(w), 10, "sum", remap=cu(remap))
+
+
+def test_graph_bookkeeping(hip):
+    from oracle import aggregate as oa
+    g = torch.Generator().manual_seed(5)
+    ei = torch.randint(0, 1000, (2, 50_000), generator=g)
+    assert not hip.is_sorted(cu(ei[0]))
+    perm = hip.argsort(cu(ei[0]))
+    s, wperm = oa.sort_by_row(ei)
+    assert torch.equal(perm.cpu(), wperm)
+    assert hip.is_sorted(cu(s[0]))
+    c = oa.csr_csc(s, 1200)
+    assert torch.equal(hip.ptr_from_sorted(cu(s[0]), 1200).cpu(), c["row_ptr"])
+    by_col = hip.argsort(cu(s[1]))
+    assert torch.equal(by_col.cpu(), c["csc_perm"])
+    assert torch.equal(hip.ptr_from_sorted(cu(s[1])[by_col], 1200).cpu(), c["col_ptr"])
