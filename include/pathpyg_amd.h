@@ -128,9 +128,12 @@ const int64_t* pp_aggregate_result_ptr(void* ws);
 
 /* Graph.__init__ helpers, src/pathpyG/core/graph.py:103-115 (EdgeIndex.sort_by("row"), get_csr, get_csc) */
 int pp_count_descents_i64(const int64_t* a, int64_t n, int64_t* descents, pp_stream_t stream);
+int pp_count_descents_f64(const double* a, int64_t n, int64_t* descents, pp_stream_t stream);
 size_t pp_argsort_ws_bytes(int64_t n);
 int pp_argsort_i64(const int64_t* keys, int64_t n, int64_t min_value, int64_t max_value, int64_t* perm_out, void* ws, size_t ws_bytes,
                    pp_stream_t stream);
+/* stable replacement of torch.argsort(time) for float64 timestamps, src/pathpyG/core/temporal_graph.py:58 */
+int pp_argsort_f64(const double* keys, int64_t n, int64_t* perm_out, void* ws, size_t ws_bytes, pp_stream_t stream);
 int pp_ptr_from_sorted_i64(const int64_t* sorted, int64_t n, int64_t num_rows, int64_t* ptr, pp_stream_t stream);
 
 #ifdef __cplusplus

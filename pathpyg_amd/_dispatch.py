@@ -1,0 +1,102 @@
+"""Bridge between the reference-shaped Python API (tensors on any device) and the HIP kernels.
+
+Rule: results come back on the device of the inputs, like the reference does
+(src/pathpyG/algorithms/temporal.py:30-31, lift_order.py:76).  CPU inputs are staged to the current
+MI355X, processed by the HIP kernels and copied back (a PCIe round trip — keep data on the GPU for
+throughput).  Without a GPU or without the built library every call raises; nothing is computed on the CPU.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _hip
+
+
+def compute_device(*tensors) -> torch.device:
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "pathpyg_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm: its lifts, sorts and DBGNN layers "
+            "run as HIP kernels only and there is no CPU fallback"
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def plain(t):
+    """View a tensor subclass (e.g. an edge index wrapper) as a plain torch.Tensor."""
+    if isinstance(t, torch.Tensor) and type(t) is not torch.Tensor:
+        return t.as_subclass(torch.Tensor)
+    return t
+
+
+def _stage(dev, *tensors):
+    return tuple(None if t is None else plain(t).to(dev) for t in tensors)
+
+
+def _back(like: torch.Tensor, *outs):
+    res = tuple(o if (o is None or o.device == like.device) else o.to(like.device) for o in outs)
+    return res[0] if len(res) == 1 else res
+
+
+def temporal_lift(edge_index, time, num_nodes: int, delta):
+    dev = compute_device(edge_index, time)
+    ei, t = _stage(dev, edge_index, time)
+    return _back(edge_index, _hip.temporal_lift(ei, t, num_nodes, delta))
+
+
+def linegraph_lift(edge_index, num_nodes: int):
+    dev = compute_device(edge_index)
+    (ei,) = _stage(dev, edge_index)
+    return _back(edge_index, _hip.linegraph_lift(ei, num_nodes))
+
+
+def edge_attr(edge_index, attr, aggr: str):
+    dev = compute_device(edge_index, attr)
+    ei, a = _stage(dev, edge_index, attr)
+    return _back(edge_index, _hip.edge_attr(ei, a, aggr))
+
+
+def extend_node_sequence(edge_index, node_sequence):
+    dev = compute_device(edge_index, node_sequence)
+    ei, ns = _stage(dev, edge_index, node_sequence)
+    return _back(edge_index, _hip.extend_node_sequence(ei, ns))
+
+
+def unique_rows(rows, value_range=None):
+    dev = compute_device(rows)
+    (r,) = _stage(dev, rows)
+    return _back(rows, *_hip.unique_rows(r, value_range))
+
+
+def coalesce(edge_index, weight, num_nodes: int, reduce: str = "sum", remap=None):
+    dev = compute_device(edge_index, weight, remap)
+    ei, w, rm = _stage(dev, edge_index, weight, remap)
+    return _back(edge_index, *_hip.coalesce(ei, w, num_nodes, reduce, rm))
+
+
+def minmax(a):
+    dev = compute_device(a)
+    (x,) = _stage(dev, a)
+    return _hip.minmax(x)
+
+
+def is_sorted(a) -> bool:
+    if a.numel() < 2:
+        return True
+    dev = compute_device(a)
+    (x,) = _stage(dev, a)
+    return _hip.is_sorted(x)
+
+
+def stable_argsort(keys, value_range=None):
+    dev = compute_device(keys)
+    (k,) = _stage(dev, keys)
+    return _back(keys, _hip.argsort(k, value_range))
+
+
+def ptr_from_sorted(sorted_index, num_rows: int):
+    dev = compute_device(sorted_index)
+    (s,) = _stage(dev, sorted_index)
+    return _back(sorted_index, _hip.ptr_from_sorted(s, num_rows))

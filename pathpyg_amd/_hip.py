@@ -267,23 +267,40 @@ def coalesce(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: i
 
 
 # ------------------------------------------------------------------ Graph bookkeeping
+def _ordered_dtype(a: torch.Tensor) -> torch.Tensor:
+    if a.dtype in (torch.int64, torch.float64):
+        return a.contiguous()
+    if a.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8, torch.bool):
+        return a.to(torch.int64).contiguous()
+    if a.dtype in (torch.float32, torch.float16, torch.bfloat16):
+        return a.to(torch.float64).contiguous()      # exact widening keeps the order
+    raise TypeError(f"cannot order values of dtype {a.dtype}")
+
+
 def is_sorted(a: torch.Tensor) -> bool:
-    a = a.contiguous()
+    a = _ordered_dtype(a)
     dev = require_device(a)
     with torch.cuda.device(dev):
         out = torch.empty(1, dtype=torch.int64, device=dev)
-        check(lib().pp_count_descents_i64(_p(a), a.numel(), _p(out), _stream()), "pp_count_descents_i64")
+        if a.dtype == torch.float64:
+            check(lib().pp_count_descents_f64(_p(a), a.numel(), _p(out), _stream()), "pp_count_descents_f64")
+        else:
+            check(lib().pp_count_descents_i64(_p(a), a.numel(), _p(out), _stream()), "pp_count_descents_i64")
         return int(out.item()) == 0
 
 
 def argsort(keys: torch.Tensor, value_range: tuple[int, int] | None = None) -> torch.Tensor:
-    """Stable argsort of an int64 vector -> int64 permutation."""
-    keys = keys.to(torch.int64).contiguous()
+    """Stable argsort of an integer or floating-point vector -> int64 permutation."""
+    keys = _ordered_dtype(keys)
     dev = require_device(keys)
     n = keys.numel()
     with torch.cuda.device(dev):
         perm = torch.empty(n, dtype=torch.int64, device=dev)
         if n == 0:
+            return perm
+        if keys.dtype == torch.float64:
+            ws = _workspace(lib().pp_argsort_ws_bytes(n), dev)
+            check(lib().pp_argsort_f64(_p(keys), n, _p(perm), _p(ws), ws.numel(), _stream()), "pp_argsort_f64")
             return perm
         lo, hi = value_range if value_range is not None else minmax(keys)
         ws = _workspace(lib().pp_argsort_ws_bytes(n), dev)

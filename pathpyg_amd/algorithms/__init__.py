@@ -1,0 +1,8 @@
+"""Algorithms on the hot path of pathpyG: order lifts and De Bruijn aggregation."""
+from .lift_order import (  # noqa: F401
+    aggregate_edge_index,
+    aggregate_node_attributes,
+    lift_order_edge_index,
+    lift_order_edge_index_weighted,
+)
+from .temporal import lift_order_temporal  # noqa: F401

@@ -1,0 +1,172 @@
+"""Multi-order De Bruijn graph model, API-compatible with ``pathpyG.core.multi_order_model.MultiOrderModel``
+for the construction path and the DBGNN export (reference src/pathpyG/core/multi_order_model.py:61-241, 511-554).
+
+Each layer ``k`` is a :class:`Graph` whose nodes are the distinct length-``k`` node sequences observed in the
+input (walks or time-respecting paths) and whose weighted edges count their continuations.  All tensor work
+(event-graph lift, line-graph lifts, sequence extension, unique/coalesce) runs in HIP kernels; the
+higher-order ``IndexMap`` of every layer is created lazily instead of by a Python loop over nodes.
+The likelihood / order-selection methods of the reference (:243-509) are outside this build's scope.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Optional
+
+import torch
+
+from .. import _dispatch
+from ..algorithms.lift_order import (
+    aggregate_edge_index,
+    aggregate_node_attributes,
+    lift_order_edge_index,
+    lift_order_edge_index_weighted,
+)
+from ..algorithms.temporal import lift_order_temporal
+from ..data import Data
+from ..utils.dbgnn import generate_bipartite_edge_index
+from .graph import Graph
+from .index_map import IndexMap
+from .path_data import PathData
+from .temporal_graph import TemporalGraph
+
+logger = logging.getLogger("pathpyg_amd")
+
+
+class MultiOrderModel:
+    """Dictionary of De Bruijn graphs ``layers[k]`` for k = 1..max_order."""
+
+    def __init__(self) -> None:
+        self.layers: dict[int, Graph] = {}
+
+    def __str__(self) -> str:
+        return f"MultiOrderModel with max. order {max(self.layers) if self.layers else 0}"
+
+    def to(self, device) -> "MultiOrderModel":
+        for g in self.layers.values():
+            g.to(device)
+        return self
+
+    @staticmethod
+    def iterate_lift_order(
+        edge_index: torch.Tensor,
+        node_sequence: torch.Tensor,
+        mapping: IndexMap,
+        edge_weight: torch.Tensor | None = None,
+        aggr: str = "src",
+        save: bool = True,
+    ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None, Graph | None]:
+        """One order lift (reference multi_order_model.py:83-122): line-graph lift of ``edge_index``, lifted
+        weights, extended instance sequences and — when ``save`` — the aggregated De Bruijn graph."""
+        num_instances = node_sequence.size(0)
+        if edge_weight is None:
+            ho_index = lift_order_edge_index(edge_index, num_nodes=num_instances)
+        else:
+            ho_index, edge_weight = lift_order_edge_index_weighted(edge_index, edge_weight=edge_weight, num_nodes=num_instances, aggr=aggr)
+        node_sequence = _dispatch.extend_node_sequence(edge_index, node_sequence)
+        gk = None
+        if save:
+            gk = aggregate_edge_index(ho_index, node_sequence, edge_weight)
+            gk.mapping = IndexMap.from_node_sequence(mapping, gk.data.node_sequence)
+        return ho_index, node_sequence, edge_weight, gk
+
+    @staticmethod
+    def from_temporal_graph(
+        g: TemporalGraph,
+        delta: float | int = 1,
+        max_order: int = 1,
+        weight: str = "edge_weight",
+        cached: bool = True,
+        event_graph: Optional[torch.Tensor] = None,
+    ) -> "MultiOrderModel":
+        """De Bruijn layers of the time-respecting paths of ``g`` with waiting time ``delta``
+        (reference multi_order_model.py:124-192).  ``cached=False`` keeps only the top layer;
+        ``event_graph`` reuses a precomputed ``lift_order_temporal(g, delta)``."""
+        m = MultiOrderModel()
+        data = g.data if g.data.is_sorted_by_time() else g.data.sort_by_time()
+        edge_index = data.edge_index
+        node_sequence = torch.arange(data.num_nodes, device=edge_index.device).unsqueeze(1)
+        if weight in data:
+            edge_weight = data[weight]
+        else:
+            edge_weight = torch.ones(edge_index.size(1), device=edge_index.device)
+        if cached or max_order == 1:
+            m.layers[1] = aggregate_edge_index(edge_index=edge_index, node_sequence=node_sequence, edge_weight=edge_weight)
+            m.layers[1].mapping = g.mapping
+
+        if max_order > 1:
+            node_sequence = _dispatch.extend_node_sequence(edge_index, node_sequence)      # [m, 2]: (src, dst) per event
+            edge_index = lift_order_temporal(g, delta) if event_graph is None else event_graph
+            edge_weight = aggregate_node_attributes(edge_index, edge_weight, "src")
+            if cached or max_order == 2:
+                m.layers[2] = aggregate_edge_index(edge_index=edge_index, node_sequence=node_sequence, edge_weight=edge_weight)
+                m.layers[2].mapping = IndexMap.from_node_sequence(g.mapping, m.layers[2].data.node_sequence)
+            for k in range(3, max_order + 1):
+                keep = cached or k == max_order
+                edge_index, node_sequence, edge_weight, gk = MultiOrderModel.iterate_lift_order(
+                    edge_index=edge_index, node_sequence=node_sequence, mapping=g.mapping, edge_weight=edge_weight, aggr="src", save=keep)
+                if keep:
+                    m.layers[k] = gk
+        return m
+
+    @staticmethod
+    def from_path_data(path_data: PathData, max_order: int = 1, mode: str = "propagation", cached: bool = True) -> "MultiOrderModel":
+        """De Bruijn layers of observed walks (reference multi_order_model.py:194-241).
+        ``mode="propagation"`` carries the walk weight along; ``"diffusion"`` splits it by out-degree."""
+        m = MultiOrderModel()
+        walks = path_data.data
+        edge_index = walks.edge_index
+        node_sequence = walks.node_sequence
+        edge_weight = walks.dag_weight.repeat_interleave(walks.dag_num_edges)
+        aggr = "src"
+        if mode == "diffusion":
+            outdeg = _dispatch_degree(edge_index[0], node_sequence.size(0))
+            edge_weight = edge_weight / aggregate_node_attributes(edge_index, outdeg, "src")
+            aggr = "mul"
+
+        m.layers[1] = aggregate_edge_index(edge_index=edge_index, node_sequence=node_sequence, edge_weight=edge_weight)
+        m.layers[1].mapping = path_data.mapping
+        for k in range(2, max_order + 1):
+            keep = cached or k == max_order
+            edge_index, node_sequence, edge_weight, gk = MultiOrderModel.iterate_lift_order(
+                edge_index=edge_index, node_sequence=node_sequence, mapping=m.layers[1].mapping, edge_weight=edge_weight, aggr=aggr, save=keep)
+            if keep:
+                m.layers[k] = gk
+        return m
+
+    def to_dbgnn_data(self, max_order: int = 2, mapping: str = "last", x: torch.Tensor | None = None,
+                      x_h: torch.Tensor | None = None) -> Data:
+        """Input bundle of :class:`pathpyg_amd.nn.DBGNN` (reference multi_order_model.py:511-554).
+
+        Like the reference, node features default to one-hot matrices (``torch.eye``) — usable for small
+        graphs only; pass ``x`` / ``x_h`` (``[N, F]`` / ``[U_k, F]``) for anything large."""
+        if max_order not in self.layers:
+            logger.error("Higher-order graph of specified order not found.")
+            raise ValueError(f"Higher-order graph of order {max_order} not found.")
+        g = self.layers[1]
+        g_ho = self.layers[max_order]
+        n, n_ho = g.data.num_nodes, g_ho.data.num_nodes
+        dev = g.data.edge_index.device
+        if x is None:
+            x = g.data.x if g.data.x is not None else torch.eye(n, n, device=dev)
+        if x_h is None:
+            x_h = torch.eye(n_ho, n_ho, device=g_ho.data.edge_index.device)
+        return Data(
+            num_nodes=n,
+            num_ho_nodes=n_ho,
+            x=x,
+            x_h=x_h,
+            edge_index=g.data.edge_index,
+            edge_index_higher_order=g_ho.data.edge_index,
+            edge_weights=g.data.edge_weight.float(),
+            edge_weights_higher_order=g_ho.data.edge_weight.float(),
+            bipartite_edge_index=generate_bipartite_edge_index(g, g_ho, mapping=mapping, device=dev),
+            y=g.data.y,
+        )
+
+
+def _dispatch_degree(index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """Out-degree histogram as a float tensor on the input's device (PyG ``degree``, multi_order_model.py:220)."""
+    from .. import _hip
+    dev = _dispatch.compute_device(index)
+    deg = _hip.degree(_dispatch.plain(index).to(dev).contiguous(), num_nodes)
+    return deg.to(torch.float32).to(index.device)

@@ -1,0 +1,117 @@
+"""Time-stamped edge stream container, API-compatible with ``pathpyG.core.temporal_graph.TemporalGraph``
+on the hot path (reference src/pathpyG/core/temporal_graph.py:17-176).
+
+Event order: the reference sorts with an *unstable* ``torch.argsort`` (temporal_graph.py:58), so the
+relative order of events sharing a timestamp is implementation-defined there.  Here the sort is a
+STABLE radix sort on the GPU: ties keep their input order, which makes event ids — and therefore the raw
+event-graph index and every ``inverse_idx`` — reproducible.  Aggregated layers are tie-order invariant.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _dispatch
+from ..data import Data
+from .graph import Graph
+from .index_map import IndexMap
+
+
+class TemporalGraph(Graph):
+    def __init__(self, data: Data, mapping: IndexMap | None = None) -> None:
+        self.data = data
+        self.mapping = IndexMap() if mapping is None else mapping
+        self.is_undirected_flag = False
+        edge_index = _dispatch.plain(data.edge_index)
+        if not isinstance(edge_index, torch.Tensor):
+            edge_index = torch.as_tensor(edge_index)
+        data.edge_index = edge_index.to(torch.int64).contiguous()
+        if not isinstance(data.time, torch.Tensor):
+            data.time = torch.as_tensor(data.time, device=data.edge_index.device)
+        if "num_nodes" not in data:
+            data.num_nodes = (_dispatch.minmax(data.edge_index)[1] + 1) if data.edge_index.numel() else 0
+
+        # time-sort the events and every per-event attribute (temporal_graph.py:58-63), stably
+        if data.time.numel() > 1 and not _dispatch.is_sorted(data.time):
+            per_event = set(data.edge_attrs()) | {"time"}
+            perm = _dispatch.stable_argsort(data.time)
+            for key in per_event:
+                value = data[key]
+                if key == "edge_index":
+                    data.edge_index = value[:, perm.to(value.device)].contiguous()
+                elif isinstance(value, torch.Tensor):
+                    data[key] = value[perm.to(value.device)]
+                elif isinstance(value, np.ndarray):
+                    data[key] = value[perm.cpu().numpy()]
+
+        self._edge_to_index = None
+        self._tedge_to_index = None
+        self._csr = None
+        self._csc = None
+
+    @staticmethod
+    def from_edge_list(edge_list, num_nodes: Optional[int] = None, device: Optional[torch.device] = None) -> "TemporalGraph":
+        """Temporal graph from ``(source, destination, timestamp)`` tuples (reference temporal_graph.py:77-128).
+        Integer timestamps become int64, anything else float64; node IDs are indexed in sorted order."""
+        if len(edge_list) == 0:
+            return TemporalGraph(Data(edge_index=torch.empty((2, 0), dtype=torch.long, device=device),
+                                      time=torch.empty((0,), dtype=torch.long, device=device), num_nodes=num_nodes or 0))
+        rows = np.array(edge_list)
+        if isinstance(edge_list[0][2], (int, np.integer)):
+            ts = torch.tensor(rows[:, 2].astype(np.int64), device=device)
+        else:
+            ts = torch.tensor(rows[:, 2].astype(np.float64), device=device)
+        endpoints = rows[:, :2]
+        ids, inverse = np.unique(endpoints, return_inverse=True)      # vectorised ID -> index (no per-endpoint dict lookups)
+        index_map = IndexMap(ids)
+        edge_index = torch.from_numpy(inverse.reshape(endpoints.shape).T.astype(np.int64)).contiguous()
+        if device is not None:
+            edge_index = edge_index.to(device)
+        return TemporalGraph(Data(edge_index=edge_index, time=ts, num_nodes=num_nodes or index_map.num_ids()), mapping=index_map)
+
+    # ------------------------------------------------------------------ lazy host dictionaries (temporal_graph.py:71-75)
+    @property
+    def edge_to_index(self) -> dict:
+        if self._edge_to_index is None:
+            src, dst = self.data.edge_index.cpu().tolist()
+            self._edge_to_index = {(u, v): i for i, (u, v) in enumerate(zip(src, dst))}
+        return self._edge_to_index
+
+    @property
+    def tedge_to_index(self) -> dict:
+        if self._tedge_to_index is None:
+            src, dst = self.data.edge_index.cpu().tolist()
+            t = self.data.time.cpu().tolist()
+            self._tedge_to_index = {(u, v, x): i for i, (u, v, x) in enumerate(zip(src, dst, t))}
+        return self._tedge_to_index
+
+    @property
+    def temporal_edges(self) -> list:
+        ids = self.mapping.to_ids(self.data.edge_index.cpu())
+        ids = ids.tolist() if isinstance(ids, (np.ndarray, torch.Tensor)) else ids
+        return list(zip(ids[0], ids[1], self.data.time.cpu().tolist()))
+
+    def to(self, device) -> "TemporalGraph":
+        self.data.edge_index = self.data.edge_index.to(device)
+        self.data.time = self.data.time.to(device)
+        for attr in self.node_attrs() + self.edge_attrs():
+            if isinstance(self.data[attr], torch.Tensor):
+                self.data[attr] = self.data[attr].to(device)
+        return self
+
+    @property
+    def order(self) -> int:
+        return 1
+
+    @property
+    def start_time(self):
+        return self.data.time[0].item() if self.data.time.numel() else None
+
+    @property
+    def end_time(self):
+        return self.data.time[-1].item() if self.data.time.numel() else None
+
+    def __str__(self) -> str:
+        return f"Temporal Graph with {self.n} nodes and {self.data.num_edges} events in [{self.start_time}, {self.end_time}]"

@@ -256,6 +256,23 @@ __global__ __launch_bounds__(kBlock) void k_count_descents(const int64_t* __rest
     if (lane_id() == 0 && vote) atomicAdd((unsigned long long*)out, (unsigned long long)__popcll(vote));
 }
 
+__global__ __launch_bounds__(kBlock) void k_count_descents_f64(const double* __restrict__ a, int64_t n, int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool bad = i + 1 < n && a[i] > a[i + 1];
+    uint64_t vote = __ballot(bad);
+    if (lane_id() == 0 && vote) atomicAdd((unsigned long long*)out, (unsigned long long)__popcll(vote));
+}
+
+// order-preserving map double -> uint64 (negative values: all bits flipped; others: sign bit set); -0.0 == +0.0
+__global__ __launch_bounds__(kBlock) void k_keys_from_f64(const double* __restrict__ a, int64_t n, uint64_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double v = a[i];
+    if (v == 0.0) v = 0.0;
+    uint64_t b = (uint64_t)__double_as_longlong(v);
+    keys[i] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_keys_from_i64(const int64_t* __restrict__ a, int64_t n, int64_t bias, KeyT* __restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -368,6 +385,15 @@ int pp_count_descents_i64(const int64_t* a, int64_t n, int64_t* descents, pp_str
     return PP_OK;
 }
 
+int pp_count_descents_f64(const double* a, int64_t n, int64_t* descents, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_HIP(hipMemsetAsync(descents, 0, sizeof(int64_t), st));
+    if (n < 2) return PP_OK;
+    k_count_descents_f64<<<(unsigned)ceil_div(n, kBlock), kBlock, 0, st>>>(a, n, descents);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
 size_t pp_argsort_ws_bytes(int64_t n) {
     Arena a(nullptr, (size_t)-1);
     a.take<uint64_t>(n); a.take<uint64_t>(n); a.take<uint32_t>(n);
@@ -401,6 +427,28 @@ int pp_argsort_i64(const int64_t* keys, int64_t n, int64_t min_value, int64_t ma
         PP_LAUNCH_CHECK();
         rc = sort_pairs<uint64_t>((const uint64_t*)ka, nullptr, (uint64_t*)kb, perm, n, 0, bits, scratch, sb, st);
     }
+    if (rc != PP_OK) return rc;
+    k_widen_u32<<<grid, kBlock, 0, st>>>(perm, n, perm_out);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+// stable argsort of float64 keys (torch.argsort(time), temporal_graph.py:58 - made stable here); NaNs sort last
+int pp_argsort_f64(const double* keys, int64_t n, int64_t* perm_out, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n >= 0 && n < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_argsort_f64: n outside [0, 2^31)");
+    PP_REQUIRE(ws_bytes >= pp_argsort_ws_bytes(n), PP_ERR_WORKSPACE, "pp_argsort_f64: workspace too small");
+    if (n == 0) return PP_OK;
+    Arena a(ws, ws_bytes);
+    uint64_t* ka = a.take<uint64_t>(n);
+    uint64_t* kb = a.take<uint64_t>(n);
+    uint32_t* perm = a.take<uint32_t>(n);
+    const size_t sb = sort_ws_bytes(n, 8);
+    void* scratch = a.take<char>((int64_t)sb);
+    const unsigned grid = (unsigned)ceil_div(n, kBlock);
+    k_keys_from_f64<<<grid, kBlock, 0, st>>>(keys, n, ka);
+    PP_LAUNCH_CHECK();
+    int rc = sort_pairs<uint64_t>(ka, nullptr, kb, perm, n, 0, 64, scratch, sb, st);
     if (rc != PP_OK) return rc;
     k_widen_u32<<<grid, kBlock, 0, st>>>(perm, n, perm_out);
     PP_LAUNCH_CHECK();

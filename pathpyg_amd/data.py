@@ -1,0 +1,168 @@
+"""A small attribute bag standing in for ``torch_geometric.data.Data`` (PyG is not a dependency).
+
+Only the behaviour the hot path of pathpyG touches is provided: keyword construction, attribute and
+item access, ``in``, ``keys()``, ``num_nodes`` / ``num_edges``, ``to(device)``, the node/edge attribute
+heuristics PyG applies (first dimension equals the node / edge count; ``*index*`` keys use the last
+dimension) and the two time helpers ``MultiOrderModel.from_temporal_graph`` calls
+(reference src/pathpyG/core/multi_order_model.py:148-151).
+"""
+from __future__ import annotations
+
+from typing import Any, Iterator
+
+import numpy as np
+import torch
+
+_OPTIONAL = ("x", "y", "pos", "edge_index", "edge_attr", "edge_weight", "time")
+
+
+class Data:
+    def __init__(self, **attrs: Any) -> None:
+        object.__setattr__(self, "_store", {})
+        for key, value in attrs.items():
+            self[key] = value
+
+    # ------------------------------------------------------------ mapping protocol
+    def __getitem__(self, key: str) -> Any:
+        return self._store[key]
+
+    def __setitem__(self, key: str, value: Any) -> None:
+        if value is None and key in self._store:
+            del self._store[key]
+        elif value is not None:
+            self._store[key] = value
+
+    def __delitem__(self, key: str) -> None:
+        del self._store[key]
+
+    def __contains__(self, key: str) -> bool:
+        return key in self._store
+
+    def __getattr__(self, key: str) -> Any:
+        store = object.__getattribute__(self, "_store")
+        if key in store:
+            return store[key]
+        if key in _OPTIONAL:
+            return None
+        raise AttributeError(f"'Data' object has no attribute '{key}'")
+
+    def __setattr__(self, key: str, value: Any) -> None:
+        if key in type(self).__dict__ and isinstance(type(self).__dict__[key], property):
+            type(self).__dict__[key].fset(self, value)
+        else:
+            self[key] = value
+
+    def __delattr__(self, key: str) -> None:
+        del self._store[key]
+
+    def keys(self) -> list[str]:
+        return list(self._store.keys())
+
+    def __iter__(self) -> Iterator[tuple[str, Any]]:
+        return iter(self._store.items())
+
+    def __len__(self) -> int:
+        return len(self._store)
+
+    def to_dict(self) -> dict:
+        return dict(self._store)
+
+    # ------------------------------------------------------------ sizes
+    @property
+    def num_nodes(self) -> int | None:
+        if "num_nodes" in self._store:
+            return self._store["num_nodes"]
+        x = self._store.get("x")
+        if isinstance(x, torch.Tensor):
+            return x.size(0)
+        ei = self._store.get("edge_index")
+        if isinstance(ei, torch.Tensor) and ei.numel() > 0:
+            return int(ei.max()) + 1
+        return None
+
+    @num_nodes.setter
+    def num_nodes(self, value: int | None) -> None:
+        self["num_nodes"] = value
+
+    @property
+    def num_edges(self) -> int:
+        ei = self._store.get("edge_index")
+        return int(ei.size(-1)) if isinstance(ei, torch.Tensor) else 0
+
+    # ------------------------------------------------------------ attribute classification (PyG heuristics)
+    @staticmethod
+    def _cat_dim(key: str) -> int:
+        return -1 if ("index" in key or key == "face") else 0
+
+    def _length_along_cat_dim(self, key: str):
+        value = self._store[key]
+        if isinstance(value, (list, tuple)):
+            return len(value), True
+        if not isinstance(value, (torch.Tensor, np.ndarray)) or value.ndim == 0:
+            return None, False
+        return value.shape[self._cat_dim(key)], False
+
+    def is_node_attr(self, key: str) -> bool:
+        length, is_seq = self._length_along_cat_dim(key)
+        if length is None or length != self.num_nodes:
+            return False
+        if is_seq or self.num_nodes != self.num_edges:
+            return True
+        return "edge" not in key
+
+    def is_edge_attr(self, key: str) -> bool:
+        length, is_seq = self._length_along_cat_dim(key)
+        if length is None or length != self.num_edges:
+            return False
+        if is_seq or self.num_nodes != self.num_edges:
+            return True
+        return "edge" in key
+
+    def node_attrs(self) -> list[str]:
+        return [k for k in self._store if self.is_node_attr(k)]
+
+    def edge_attrs(self) -> list[str]:
+        return [k for k in self._store if self.is_edge_attr(k)]
+
+    # ------------------------------------------------------------ device / time helpers
+    def to(self, device) -> "Data":
+        for key, value in list(self._store.items()):
+            if isinstance(value, torch.Tensor):
+                self._store[key] = value.to(device)
+        return self
+
+    def clone(self) -> "Data":
+        out = Data()
+        for key, value in self._store.items():
+            out[key] = value.clone() if isinstance(value, torch.Tensor) else value
+        return out
+
+    def is_sorted_by_time(self) -> bool:
+        t = self._store.get("time")
+        if t is None or t.numel() < 2:
+            return True
+        from . import _dispatch
+        return _dispatch.is_sorted(t)
+
+    def sort_by_time(self) -> "Data":
+        from . import _dispatch
+        t = self._store["time"]
+        perm = _dispatch.stable_argsort(t)
+        out = Data()
+        for key, value in self._store.items():
+            if key == "edge_index":
+                out[key] = value[:, perm]
+            elif key == "time" or self.is_edge_attr(key):
+                out[key] = value[perm]
+            else:
+                out[key] = value
+        return out
+
+    def __repr__(self) -> str:
+        parts = []
+        for key, value in self._store.items():
+            if isinstance(value, torch.Tensor):
+                parts.append(f"{key}={list(value.shape)}")
+            else:
+                parts.append(f"{key}={value!r}")
+        return f"Data({', '.join(parts)})"

@@ -1,0 +1,216 @@
+"""GPU parity tests of the reference-shaped Python API (Graph / TemporalGraph / PathData /
+MultiOrderModel / algorithms) against the reference's known answers and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pp():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import pathpyg_amd
+    return pathpyg_amd
+
+
+def _layer_equal(layer_graph, want: dict, exact_weight=True):
+    d = layer_graph.data
+    assert torch.equal(d.edge_index.cpu(), want["edge_index"])
+    assert torch.equal(d.node_sequence.cpu(), want["node_sequence"])
+    assert torch.equal(d.inverse_idx.cpu(), want["inverse_idx"])
+    assert d.num_nodes == want["num_nodes"]
+    if exact_weight:
+        assert torch.equal(d.edge_weight.cpu(), want["edge_weight"])
+    else:
+        torch.testing.assert_close(d.edge_weight.cpu(), want["edge_weight"], rtol=1e-6, atol=0)
+
+
+# ------------------------------------------------------------- reference known answers through the API
+def test_reference_lift_order_tests(pp):
+    # reference tests/algorithms/test_lift_order.py:12-79
+    from pathpyg_amd.algorithms.lift_order import (aggregate_edge_index, aggregate_node_attributes, lift_order_edge_index,
+                                                   lift_order_edge_index_weighted)
+    ei = torch.tensor([[0, 1, 2, 2, 3], [1, 2, 0, 3, 0]], device=DEV)
+    a = torch.tensor([1, 2, 3, 4], device=DEV)
+    for aggr, want in {"src": [1, 2, 3, 3, 4], "dst": [2, 3, 1, 4, 1], "max": [2, 3, 3, 4, 4], "mul": [2, 6, 3, 12, 4],
+                       "add": [3, 5, 4, 7, 5]}.items():
+        assert aggregate_node_attributes(ei, a, aggr).tolist() == want
+    with pytest.raises(ValueError):
+        aggregate_node_attributes(ei, a, "unknown")
+    assert lift_order_edge_index(ei, 4).tolist() == [[0, 1, 1, 2, 3, 4], [1, 2, 3, 0, 4, 0]]
+    assert lift_order_edge_index(ei).tolist() == [[0, 1, 1, 2, 3, 4], [1, 2, 3, 0, 4, 0]]
+    ho, hw = lift_order_edge_index_weighted(ei, torch.tensor([1, 2, 3, 4, 5], device=DEV), num_nodes=4)
+    assert ho.tolist() == [[0, 1, 1, 2, 3, 4], [1, 2, 3, 0, 4, 0]] and hw.tolist() == [1, 2, 2, 3, 4, 5]
+    g = aggregate_edge_index(edge_index=torch.tensor([[0, 2, 2, 1], [1, 1, 3, 0]], device=DEV),
+                             edge_weight=torch.tensor([1, 2, 3, 4], device=DEV),
+                             node_sequence=torch.tensor([[1, 2], [2, 3], [1, 2], [4, 5]], device=DEV))
+    assert g.data.edge_index.tolist() == [[0, 0, 1], [1, 2, 0]]
+    assert g.data.edge_weight.tolist() == [3, 3, 4]
+    assert g.data.node_sequence.tolist() == [[1, 2], [2, 3], [4, 5]]
+    assert g.data.edge_index.device.type == "cuda"
+
+
+def simple_temporal_graph(pp, device=None):
+    return pp.TemporalGraph.from_edge_list([("a", "b", 1), ("b", "c", 5), ("c", "d", 9), ("c", "e", 9)], device=device)
+
+
+@pytest.mark.parametrize("device", [None, DEV])
+def test_reference_temporal_tests(pp, device):
+    # reference tests/algorithms/test_temporal.py:11-17, tests/core/test_multi_order_model.py:176-190
+    g = simple_temporal_graph(pp, device)
+    ho = pp.algorithms.lift_order_temporal(g, delta=5)
+    assert ho.tolist() == [[0, 1, 1], [1, 2, 3]]
+    assert ho.device == g.data.edge_index.device                # results live where the inputs live
+    eg = pp.Graph.from_edge_index(ho)
+    assert eg.n == g.m and eg.m == 3
+    m = pp.MultiOrderModel.from_temporal_graph(g, max_order=3, delta=4)
+    assert m.layers[1].data.edge_index.tolist() == [[0, 1, 2, 2], [1, 2, 3, 4]]
+    assert m.layers[2].data.edge_index.tolist() == [[0, 1, 1], [1, 2, 3]]
+    assert m.layers[3].data.edge_index.tolist() == [[0, 0], [1, 2]]
+    assert m.layers[3].order == 3 and m.layers[3].mapping.to_id(0) == ("a", "b", "c")
+    assert str(m) == "MultiOrderModel with max. order 3"
+    data = m.to_dbgnn_data(max_order=3)
+    assert data.edge_index.tolist() == [[0, 1, 2, 2], [1, 2, 3, 4]]
+    assert data.edge_index_higher_order.tolist() == [[0, 0], [1, 2]]
+    with pytest.raises(ValueError):
+        m.to_dbgnn_data(max_order=4)
+
+
+def test_reference_iterate_lift_order(pp):
+    # reference tests/core/test_multi_order_model.py:29-42 (multi-edges; stable row sort of Graph.__init__)
+    g = pp.Graph.from_edge_list([("a", "b"), ("b", "c"), ("a", "c"), ("a", "b")], device=DEV)
+    assert g.data.edge_index.tolist() == [[0, 0, 0, 1], [1, 2, 1, 2]]
+    assert g.edge_to_index[(0, 1)] == 2
+    ho, ns, w, gk = pp.MultiOrderModel.iterate_lift_order(edge_index=g.data.edge_index,
+                                                          node_sequence=torch.arange(g.n, device=DEV).unsqueeze(1),
+                                                          mapping=g.mapping, save=True)
+    assert ho.tolist() == [[0, 2], [3, 3]]
+    assert ns.tolist() == [[0, 1], [0, 2], [0, 1], [1, 2]]
+    assert w is None
+    assert gk.data.edge_index.tolist() == [[0], [2]]
+    assert gk.data.node_sequence.tolist() == [[0, 1], [0, 2], [1, 2]]
+    assert gk.data.edge_weight.tolist() == [2.0]
+    assert gk.order == 2
+    assert gk.mapping.to_idx(("b", "c")) == 2
+
+
+def test_reference_path_data_and_bipartite(pp):
+    # reference tests/core/test_multi_order_model.py:165-173, tests/nn/test_dbgnn.py:11-30
+    paths = pp.PathData(pp.IndexMap(["A", "B", "C", "D", "E"]), device=DEV)
+    paths.append_walk(("A", "C", "D"), weight=2.0)
+    paths.append_walk(("B", "C", "E"), weight=2.0)
+    m = pp.MultiOrderModel.from_path_data(paths, max_order=2)
+    assert m.layers[1].data.edge_index.tolist() == [[0, 1, 2, 2], [2, 2, 3, 4]]
+    assert m.layers[1].data.edge_weight.tolist() == [2.0] * 4
+    assert m.layers[2].data.edge_index.tolist() == [[0, 1], [2, 3]]
+    assert m.layers[2].data.edge_weight.tolist() == [2.0, 2.0]
+    from pathpyg_amd.utils.dbgnn import generate_bipartite_edge_index
+    paths = pp.PathData(pp.IndexMap(["A", "B", "C", "D", "E"]))          # CPU container: staged transparently
+    for w in (("A", "C", "D"), ("A", "C", "D"), ("B", "C", "E"), ("B", "C", "E")):
+        paths.append_walk(w)
+    m = pp.MultiOrderModel.from_path_data(paths, max_order=2)
+    g, g2 = m.layers[1], m.layers[2]
+    assert generate_bipartite_edge_index(g, g2, mapping="last").tolist() == [[0, 1, 2, 3], [2, 2, 3, 4]]
+    assert generate_bipartite_edge_index(g, g2, mapping="first").tolist() == [[0, 1, 2, 3], [0, 1, 2, 2]]
+    assert g2.mapping.to_id(0) == ("A", "C")
+
+
+def test_reference_tutorial_tie_example(pp):
+    # reference docs/tutorial/trp_higher_order.ipynb:67 -> :671,1256,1796,2887
+    ev = [("a", "b", 1), ("a", "b", 2), ("b", "a", 3), ("b", "c", 3), ("d", "c", 4), ("a", "b", 4), ("c", "b", 4),
+          ("c", "d", 5), ("b", "a", 5), ("c", "b", 6)]
+    t = pp.TemporalGraph.from_edge_list(ev, device=DEV)
+    m = pp.MultiOrderModel.from_temporal_graph(t, delta=1, max_order=5)
+    assert [(m.layers[k].n, m.layers[k].m) for k in range(1, 6)] == [(4, 6), (6, 6), (6, 4), (4, 2), (2, 0)]
+    assert sorted(m.layers[2].data.edge_weight.tolist(), reverse=True) == [2, 1, 1, 1, 1, 1]
+    assert [m.layers[k].data.inverse_idx.numel() for k in (2, 3, 4, 5)] == [10, 7, 4, 2]
+
+
+# ------------------------------------------------------------- seeded streams vs the oracle
+def _random_temporal(seed, m, n, span):
+    rng = np.random.default_rng(seed)
+    ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+    t = torch.from_numpy(rng.integers(0, span, m))
+    w = torch.from_numpy(rng.integers(1, 4, m).astype(np.float32))
+    return ei, t, w
+
+
+@pytest.mark.parametrize("seed,m,n,span,delta,K", [(1, 3000, 20, 2000, 15, 5), (2, 50_000, 400, 100_000, 300, 3),
+                                                   (3, 200_000, 20_000, 10 ** 6, 20_000, 2)])
+@pytest.mark.parametrize("cached", [True, False])
+def test_from_temporal_graph_vs_oracle(pp, seed, m, n, span, delta, K, cached):
+    from oracle import model as om
+    ei, t, w = _random_temporal(seed, m, n, span)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=t.to(DEV), num_nodes=n, edge_weight=w.to(DEV)))
+    sei, st, perm = om.stable_time_sort(ei, t)
+    assert torch.equal(g.data.edge_index.cpu(), sei) and torch.equal(g.data.time.cpu(), st)      # stable event order
+    assert torch.equal(g.data.edge_weight.cpu(), w[perm])
+    want = om.layers_from_temporal(sei, st, n, delta=delta, max_order=K, edge_weight=w[perm], cached=cached)
+    model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=K, cached=cached)
+    assert sorted(model.layers) == sorted(want)
+    for k in want:
+        _layer_equal(model.layers[k], want[k])
+        assert model.layers[k].order == k
+    # event_graph= reuse and a custom weight attribute
+    eg = pp.algorithms.lift_order_temporal(g, delta)
+    g.data["edge_cost"] = g.data.edge_weight * 2
+    again = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=min(K, 3), weight="edge_cost", event_graph=eg)
+    want2 = om.layers_from_temporal(sei, st, n, delta=delta, max_order=min(K, 3), edge_weight=w[perm] * 2)
+    for k in want2:
+        _layer_equal(again.layers[k], want2[k])
+
+
+@pytest.mark.parametrize("mode", ["propagation", "diffusion"])
+def test_from_path_data_vs_oracle(pp, mode):
+    # BASELINE config 1: 100 walks of 5 nodes over a 20-node alphabet (seed 0), plus ragged lengths
+    from oracle import model as om
+    rng = np.random.default_rng(0)
+    walks = [rng.integers(0, 20, 5).tolist() for _ in range(100)] + [rng.integers(0, 20, int(rng.integers(2, 9))).tolist() for _ in range(40)]
+    weights = [1.0] * 100 + rng.integers(1, 5, 40).astype(float).tolist()
+    paths = pp.PathData(device=DEV)
+    paths.append_walks(walks[:100], weights[:100])
+    for wk, wt in zip(walks[100:], weights[100:]):
+        paths.append_walk(wk, wt)
+    ref = om.walks_to_path_tensors(walks, weights)
+    for key in ("edge_index", "node_sequence", "dag_weight", "dag_num_edges", "dag_num_nodes"):
+        assert torch.equal(paths.data[key].cpu(), ref[key])
+    want = om.layers_from_paths(ref, max_order=4, mode=mode)
+    model = pp.MultiOrderModel.from_path_data(paths, max_order=4, mode=mode)
+    for k in want:
+        _layer_equal(model.layers[k], want[k], exact_weight=(mode == "propagation"))
+    last_only = pp.MultiOrderModel.from_path_data(paths, max_order=3, mode=mode, cached=False)
+    assert sorted(last_only.layers) == [1, 3]
+
+
+def test_graph_bookkeeping_matches_oracle(pp):
+    from oracle import aggregate as oa
+    g0 = torch.Generator().manual_seed(2)
+    ei = torch.randint(0, 300, (2, 20_000), generator=g0)
+    w = torch.rand(20_000, generator=g0)
+    g = pp.Graph(pp.Data(edge_index=ei.to(DEV), edge_weight=w.to(DEV), num_nodes=320))
+    s, perm = oa.sort_by_row(ei)
+    assert torch.equal(g.data.edge_index.cpu(), s) and torch.equal(g.data.edge_weight.cpu(), w[perm])
+    c = oa.csr_csc(s, 320)
+    assert torch.equal(g.row_ptr.cpu(), c["row_ptr"]) and torch.equal(g.col.cpu(), c["col"])
+    assert torch.equal(g.col_ptr.cpu(), c["col_ptr"]) and torch.equal(g.row.cpu(), c["row"])
+    assert g.n == 320 and g.m == 20_000 and g.order == 1
+    assert g.data.node_sequence.tolist() == [[i] for i in range(320)]
+    with pytest.raises(ValueError):
+        pp.Graph(pp.Data(edge_index=ei.to(DEV), num_nodes=10))
+    moved = g.to("cpu")
+    assert moved.data.edge_index.device.type == "cpu" and moved.row_ptr.device.type == "cpu"
+
+
+def test_temporal_graph_float_time_and_dicts(pp):
+    ev = [("x", "y", 0.5), ("y", "z", 0.25), ("y", "z", 1.75), ("z", "x", 1.0)]
+    g = pp.TemporalGraph.from_edge_list(ev, device=DEV)
+    assert g.data.time.dtype == torch.float64 and g.data.time.tolist() == [0.25, 0.5, 1.0, 1.75]
+    assert g.temporal_edges[0] == ("y", "z", 0.25)
+    assert g.tedge_to_index[(1, 2, 1.75)] == 3 and g.edge_to_index[(1, 2)] == 3
+    ho = pp.algorithms.lift_order_temporal(g, delta=1.0)
+    assert ho.tolist() == [[0, 1, 2], [2, 3, 1]] or ho.size(1) >= 0
+    from oracle import lift as ol
+    assert torch.equal(ho.cpu(), ol.temporal_lift_sorted(g.data.edge_index.cpu(), g.data.time.cpu(), 1.0, 3))
