@@ -136,6 +136,39 @@ int pp_argsort_i64(const int64_t* keys, int64_t n, int64_t min_value, int64_t ma
 int pp_argsort_f64(const double* keys, int64_t n, int64_t* perm_out, void* ws, size_t ws_bytes, pp_stream_t stream);
 int pp_ptr_from_sorted_i64(const int64_t* sorted, int64_t n, int64_t num_rows, int64_t* ptr, pp_stream_t stream);
 
+/* ------------------------------------------------------------------ DBGNN message passing (pp_dbgnn.hip) */
+
+/* What PyG's gcn_norm computes on every GCNConv call of DBGNN.forward (src/pathpyG/nn/dbgnn.py:133,139):
+ * add_remaining_self_loops(fill 1), weighted in-degree, d^-1/2, norm_e = d[row] w_e d[col] — built ONCE per graph:
+ *   in_*  : CSR over DESTINATION nodes (in_ptr [N+1], in_idx = source of each incoming edge, in_val = norm)   forward
+ *   out_* : CSR over SOURCE nodes      (out_idx = destination, out_val = norm)                               backward
+ *   self_coef[i] = d[i]^2 * (weight of node i's self loop, 1 if it had none); existing self-loop edges get norm 0.
+ * edge_weight may be NULL (all ones).  pp_plan_result_ptr(ws)[1] = status (bit 0: index out of range). */
+size_t pp_gcn_plan_ws_bytes(int64_t n_edges, int64_t n_nodes);
+int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int32_t* in_ptr, int32_t* in_idx,
+                float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, void* ws, size_t ws_bytes,
+                pp_stream_t stream);
+
+/* CSR views of DBGNN's bipartite_edge_index [2,n_pairs] (row 0: higher-order node, row 1: first-order node),
+ * src/pathpyG/nn/dbgnn.py:64-69: in_* grouped by first-order node (+ its in-degree as float), out_* by higher-order node.
+ * Workspace: pp_gcn_plan_ws_bytes(n_pairs, max(n_ho, n_fo)). */
+int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n_ho, int64_t n_fo, int32_t* in_ptr, int32_t* in_idx,
+                      float* in_degree, int32_t* out_ptr, int32_t* out_idx, void* ws, size_t ws_bytes, pp_stream_t stream);
+const int64_t* pp_plan_result_ptr(void* ws);
+
+/* Y[r,:] = act( sum_{p in [ptr[r],ptr[r+1])} val[p] * X[idx[p],:] + self_coef[r] * S[r,:] + bias ),  X:[*,F], Y:[n_rows,F] fp32.
+ * val NULL = 1, self_coef NULL = no self term, S NULL = X, bias NULL = none, act 0 = identity / 1 = ELU.
+ * GCNConv.propagate + bias + F.elu (dbgnn.py:133,139), the bipartite propagate + elu (:143-144) and all their transposes. */
+int pp_spmm_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* X, int F, const float* self_coef,
+                const float* S, const float* bias, int act, float* Y, pp_stream_t stream);
+
+/* dpre = dY * elu'(.) from the stored OUTPUT y (1 if y > 0 else y + 1); act 0: dpre = dY; dbias[F] = column sums of dpre.
+ * dpre or dbias may be NULL. */
+int pp_act_backward_f32(const float* dY, const float* Y, int64_t n_rows, int F, int act, float* dpre, float* dbias, pp_stream_t stream);
+
+/* out[r,:] = coef[r] * X[r,:] (gradient of the bipartite self term) */
+int pp_scale_rows_f32(const float* X, const float* coef, int64_t n_rows, int F, float* out, pp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

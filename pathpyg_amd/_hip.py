@@ -315,3 +315,94 @@ def ptr_from_sorted(sorted_index: torch.Tensor, num_rows: int) -> torch.Tensor:
         ptr = torch.empty(num_rows + 1, dtype=torch.int64, device=dev)
         check(lib().pp_ptr_from_sorted_i64(_p(sorted_index), sorted_index.numel(), num_rows, _p(ptr), _stream()), "pp_ptr_from_sorted_i64")
     return ptr
+
+
+# ------------------------------------------------------------------ DBGNN message passing
+class CsrPlan:
+    """CSR pair of one propagation: ``fwd`` rows are the destinations, ``bwd`` rows the sources (transposed)."""
+
+    __slots__ = ("n_dst", "n_src", "fwd_ptr", "fwd_idx", "fwd_val", "bwd_ptr", "bwd_idx", "bwd_val", "self_coef")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nodes: int) -> CsrPlan:
+    """GCN normalisation of a weighted graph, once per graph (see pp_gcn_plan in the C header)."""
+    ei = _edge_index(edge_index)
+    dev = require_device(ei, edge_weight)
+    e = ei.size(1)
+    if edge_weight is not None:
+        edge_weight = edge_weight.to(torch.float32).contiguous()
+        if edge_weight.numel() != e:
+            raise ValueError("edge_weights must hold one value per edge")
+    L = lib()
+    with torch.cuda.device(dev):
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        plan = CsrPlan(n_dst=num_nodes, n_src=num_nodes,
+                       fwd_ptr=torch.empty(num_nodes + 1, **i32), fwd_idx=torch.empty(e, **i32), fwd_val=torch.empty(e, **f32),
+                       bwd_ptr=torch.empty(num_nodes + 1, **i32), bwd_idx=torch.empty(e, **i32), bwd_val=torch.empty(e, **f32),
+                       self_coef=torch.empty(num_nodes, **f32))
+        ws = _workspace(L.pp_gcn_plan_ws_bytes(e, num_nodes), dev)
+        check(L.pp_gcn_plan(_p(ei), _p(edge_weight), e, num_nodes, _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val), _p(plan.bwd_ptr),
+                            _p(plan.bwd_idx), _p(plan.bwd_val), _p(plan.self_coef), _p(ws), ws.numel(), _stream()), "pp_gcn_plan")
+        _bad_index(_result(ws)[1], "GCNConv")
+    return plan
+
+
+def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int) -> CsrPlan:
+    bi = _edge_index(bipartite_index)
+    dev = require_device(bi)
+    nb = bi.size(1)
+    L = lib()
+    with torch.cuda.device(dev):
+        i32 = dict(dtype=torch.int32, device=dev)
+        plan = CsrPlan(n_dst=n_fo, n_src=n_ho,
+                       fwd_ptr=torch.empty(n_fo + 1, **i32), fwd_idx=torch.empty(nb, **i32),
+                       bwd_ptr=torch.empty(n_ho + 1, **i32), bwd_idx=torch.empty(nb, **i32),
+                       self_coef=torch.empty(n_fo, dtype=torch.float32, device=dev))
+        ws = _workspace(L.pp_gcn_plan_ws_bytes(nb, max(n_ho, n_fo)), dev)
+        check(L.pp_bipartite_plan(_p(bi), nb, n_ho, n_fo, _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.self_coef), _p(plan.bwd_ptr),
+                                  _p(plan.bwd_idx), _p(ws), ws.numel(), _stream()), "pp_bipartite_plan")
+        _bad_index(_result(ws)[1], "BipartiteGraphOperator")
+    return plan
+
+
+def spmm(ptr, idx, val, n_rows: int, x: torch.Tensor, self_coef=None, s=None, bias=None, act: bool = False) -> torch.Tensor:
+    """Y[r] = act(sum_p val[p] * x[idx[p]] + self_coef[r] * s[r] + bias) — fp32, rows of width F."""
+    dev = require_device(x, s, bias)
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        raise TypeError("DBGNN kernels are fp32")
+    f = x.size(1)
+    if s is not None:
+        s = s.contiguous()
+    if bias is not None:
+        bias = bias.contiguous()
+    with torch.cuda.device(dev):
+        y = torch.empty((n_rows, f), dtype=torch.float32, device=dev)
+        check(lib().pp_spmm_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(x), f, _p(self_coef), _p(s), _p(bias), 1 if act else 0, _p(y),
+                                _stream()), "pp_spmm_f32")
+    return y
+
+
+def act_backward(dy: torch.Tensor, y: torch.Tensor | None, act: bool, want_dpre: bool = True, want_dbias: bool = False):
+    dev = require_device(dy, y)
+    dy = dy.contiguous()
+    n, f = dy.shape
+    with torch.cuda.device(dev):
+        dpre = torch.empty_like(dy) if want_dpre else None
+        dbias = torch.empty(f, dtype=torch.float32, device=dev) if want_dbias else None
+        check(lib().pp_act_backward_f32(_p(dy), _p(y), n, f, 1 if act else 0, _p(dpre), _p(dbias), _stream()), "pp_act_backward_f32")
+    return dpre, dbias
+
+
+def scale_rows(x: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
+    dev = require_device(x, coef)
+    x = x.contiguous()
+    with torch.cuda.device(dev):
+        out = torch.empty_like(x)
+        check(lib().pp_scale_rows_f32(_p(x), _p(coef), x.size(0), x.size(1), _p(out), _stream()), "pp_scale_rows_f32")
+    return out

@@ -1,0 +1,400 @@
+// pathpyg_amd — DBGNN message passing on gfx950: GCN normalisation plans, CSR segment-reduce SpMM
+// (forward and transposed), bipartite projection, fused bias/ELU epilogue and ELU backward.
+//
+// Reference code replaced (paths relative to the pathpyG repository root):
+//   DBGNN.forward                       src/pathpyG/nn/dbgnn.py:121-151
+//   BipartiteGraphOperator.forward      src/pathpyG/nn/dbgnn.py:50-69
+// and the torch_geometric 2.7.0 pieces those call (not in the reference tree):
+//   gcn_norm / add_remaining_self_loops, GCNConv.propagate (aggr="add"), MessagePassing("add").
+//
+// Design: every propagation is   Y[r,:] = act( sum_p val[p] * X[idx[p],:] + self[r] * S[r,:] + bias )
+// over a CSR whose rows are the DESTINATIONS (forward) or the SOURCES (backward = transposed graph), so
+// no atomics are needed and the accumulation order is fixed.  A row is owned by LPR = F/4 lanes, each
+// holding one float4 of the feature row (F=64: 16 lanes/row, 4 rows per wave; F=256: a whole wave), the
+// gather X[idx[p],:] is one 16-byte load per lane = full 64..1024-byte row segments per edge; bias add and
+// ELU are fused into the store.  The normalisation (self loops, weighted in-degree, d^-1/2, per-edge
+// coefficient) is computed ONCE per graph into a "plan" (the reference recomputes it every forward).
+// The dense X*W^T products stay plain library GEMMs (MFMA through rocBLAS) on the Python side.
+#include "pp_internal.h"
+
+namespace pp {
+
+// ------------------------------------------------------------------ plan construction
+__global__ __launch_bounds__(kBlock) void k_index_key(const int64_t* __restrict__ index, int64_t n, int64_t limit, uint32_t* __restrict__ keys,
+                                                     int64_t* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int64_t v = index[i];
+    if (v < 0 || v >= limit) { atomicOr((unsigned long long*)status, 1ull); v = 0; }
+    keys[i] = (uint32_t)v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_last_self_loop(const int64_t* __restrict__ edge_index, int64_t n_edges, int64_t n_nodes,
+                                                          int32_t* __restrict__ last_loop) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_edges) return;
+    const int64_t r = edge_index[e];
+    if (r >= 0 && r < n_nodes && r == edge_index[n_edges + e]) atomicMax(&last_loop[r], (int32_t)e);
+}
+
+// weighted in-degree over the destination-grouped edge list + the (completed) self loop -> d^-1/2 and the loop weight
+__global__ __launch_bounds__(kBlock) void k_gcn_degree(const int64_t* __restrict__ edge_index, int64_t n_edges, const float* __restrict__ w,
+                                                      const uint32_t* __restrict__ by_dst, const uint32_t* __restrict__ dst_ptr,
+                                                      const int32_t* __restrict__ last_loop, int64_t n_nodes, float* __restrict__ dinv,
+                                                      float* __restrict__ loop_w) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes) return;
+    const float lw = last_loop[i] >= 0 ? (w ? w[last_loop[i]] : 1.0f) : 1.0f;
+    float deg = 0.0f;
+    for (uint32_t p = dst_ptr[i]; p < dst_ptr[i + 1]; ++p) {
+        const uint32_t e = by_dst[p];
+        if (edge_index[e] != i) deg += w ? w[e] : 1.0f;          // existing self loops are replaced by the one below
+    }
+    deg += lw;
+    float d = 1.0f / sqrtf(deg);                                  // deg^-1/2 ; inf -> 0 like masked_fill_(== inf, 0)
+    if (isinf(d)) d = 0.0f;
+    dinv[i] = d;
+    loop_w[i] = lw;
+}
+
+__global__ __launch_bounds__(kBlock) void k_gcn_coefficients(const int64_t* __restrict__ edge_index, int64_t n_edges, const float* __restrict__ w,
+                                                            const uint32_t* __restrict__ order, const float* __restrict__ dinv,
+                                                            int by_dst, int32_t* __restrict__ idx_out, float* __restrict__ val_out) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n_edges) return;
+    const int64_t e = order ? (int64_t)order[p] : p;
+    const int64_t r = edge_index[e], c = edge_index[n_edges + e];
+    idx_out[p] = (int32_t)(by_dst ? r : c);
+    val_out[p] = r == c ? 0.0f : dinv[r] * (w ? w[e] : 1.0f) * dinv[c];
+}
+
+__global__ __launch_bounds__(kBlock) void k_self_coefficient(const float* __restrict__ dinv, const float* __restrict__ loop_w, int64_t n,
+                                                            float* __restrict__ self_coef) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) self_coef[i] = dinv[i] * loop_w[i] * dinv[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_u32_to_i32_ptr(const uint32_t* __restrict__ in, int64_t n, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = (int32_t)in[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_index(const int64_t* __restrict__ values, const uint32_t* __restrict__ order, int64_t n,
+                                                        int32_t* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p < n) out[p] = (int32_t)values[order ? order[p] : p];
+}
+
+__global__ __launch_bounds__(kBlock) void k_ptr_diff_f32(const int32_t* __restrict__ ptr, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = (float)(ptr[i + 1] - ptr[i]);
+}
+
+// rowptr[v] = first position p with sorted_keys[p] >= v (same gap-fill as pp_lift.hip, int32 output)
+__global__ __launch_bounds__(kBlock) void k_ptr_from_sorted_u32(const uint32_t* __restrict__ sorted_keys, int64_t n, int64_t num_rows,
+                                                               uint32_t* __restrict__ ptr) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p > n) return;
+    int64_t a = p == 0 ? -1 : (int64_t)sorted_keys[p - 1];
+    int64_t b = p == n ? num_rows : (int64_t)sorted_keys[p];
+    if (b > num_rows) b = num_rows;
+    for (int64_t v = a + 1; v <= b; ++v) ptr[v] = (uint32_t)p;
+}
+
+// ------------------------------------------------------------------ SpMM (segment reduce over CSR rows)
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
+
+template <int kLanes>   // lanes per row, each lane owns one float4 of a column block of kLanes*4 columns
+__global__ __launch_bounds__(kBlock) void k_spmm_v4(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+                                                   int64_t n_rows, const float* __restrict__ X, int F, const float* __restrict__ self_coef,
+                                                   const float* __restrict__ S, const float* __restrict__ bias, int act, float* __restrict__ Y) {
+    constexpr int kRowsPerBlock = kBlock / kLanes;
+    const int64_t r = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x / kLanes;
+    const int lane = threadIdx.x % kLanes;
+    if (r >= n_rows) return;
+    const int p0 = ptr[r], p1 = ptr[r + 1];
+    const float sc = self_coef ? self_coef[r] : 0.0f;
+    for (int c0 = lane * 4; c0 < F; c0 += kLanes * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int p = p0;
+        for (; p + 4 <= p1; p += 4) {                       // 4 independent row gathers in flight
+            int j0 = idx[p], j1 = idx[p + 1], j2 = idx[p + 2], j3 = idx[p + 3];
+            float v0 = val ? val[p] : 1.f, v1 = val ? val[p + 1] : 1.f, v2 = val ? val[p + 2] : 1.f, v3 = val ? val[p + 3] : 1.f;
+            const float4 x0 = *(const float4*)(X + (int64_t)j0 * F + c0);
+            const float4 x1 = *(const float4*)(X + (int64_t)j1 * F + c0);
+            const float4 x2 = *(const float4*)(X + (int64_t)j2 * F + c0);
+            const float4 x3 = *(const float4*)(X + (int64_t)j3 * F + c0);
+            acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
+            acc.x += v1 * x1.x; acc.y += v1 * x1.y; acc.z += v1 * x1.z; acc.w += v1 * x1.w;
+            acc.x += v2 * x2.x; acc.y += v2 * x2.y; acc.z += v2 * x2.z; acc.w += v2 * x2.w;
+            acc.x += v3 * x3.x; acc.y += v3 * x3.y; acc.z += v3 * x3.z; acc.w += v3 * x3.w;
+        }
+        for (; p < p1; ++p) {
+            const int j = idx[p];
+            const float v = val ? val[p] : 1.f;
+            const float4 x = *(const float4*)(X + (int64_t)j * F + c0);
+            acc.x += v * x.x; acc.y += v * x.y; acc.z += v * x.z; acc.w += v * x.w;
+        }
+        if (self_coef) {
+            const float4 s = *(const float4*)(S + r * F + c0);
+            acc.x += sc * s.x; acc.y += sc * s.y; acc.z += sc * s.z; acc.w += sc * s.w;
+        }
+        if (bias) {
+            const float4 b = *(const float4*)(bias + c0);
+            acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+        }
+        if (act) { acc.x = elu1(acc.x); acc.y = elu1(acc.y); acc.z = elu1(acc.z); acc.w = elu1(acc.w); }
+        *(float4*)(Y + r * F + c0) = acc;
+    }
+}
+
+template <int kLanes>   // scalar-column variant for feature widths that are not multiples of 4
+__global__ __launch_bounds__(kBlock) void k_spmm_s1(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+                                                   int64_t n_rows, const float* __restrict__ X, int F, const float* __restrict__ self_coef,
+                                                   const float* __restrict__ S, const float* __restrict__ bias, int act, float* __restrict__ Y) {
+    constexpr int kRowsPerBlock = kBlock / kLanes;
+    const int64_t r = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x / kLanes;
+    const int lane = threadIdx.x % kLanes;
+    if (r >= n_rows) return;
+    const int p0 = ptr[r], p1 = ptr[r + 1];
+    for (int c = lane; c < F; c += kLanes) {
+        float acc = 0.f;
+        for (int p = p0; p < p1; ++p) acc += (val ? val[p] : 1.f) * X[(int64_t)idx[p] * F + c];
+        if (self_coef) acc += self_coef[r] * S[r * F + c];
+        if (bias) acc += bias[c];
+        Y[r * F + c] = act ? elu1(acc) : acc;
+    }
+}
+
+// ------------------------------------------------------------------ ELU backward (+ column sums for the bias gradient)
+// dpre = dY * elu'(pre) with elu'(pre) = 1 for y > 0 and y + 1 otherwise (y = elu(pre)); act == 0: dpre = dY.
+// kFixedColumn: the grid stride is a multiple of F, so a thread always meets the same column and keeps
+// its partial bias gradient in a register (one LDS atomic per thread at the end instead of one per element).
+template <bool kFixedColumn>
+__global__ __launch_bounds__(kBlock) void k_act_backward(const float* __restrict__ dY, const float* __restrict__ Y, int64_t n_rows, int F, int act,
+                                                        float* __restrict__ dpre, float* __restrict__ dbias) {
+    extern __shared__ float s_col[];                      // [F] partial column sums of this workgroup
+    for (int c = threadIdx.x; c < F; c += kBlock) s_col[c] = 0.f;
+    __syncthreads();
+    const int64_t total = n_rows * (int64_t)F;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t first = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    float mine = 0.f;
+    for (int64_t i = first; i < total; i += stride) {
+        float g = dY[i];
+        if (act) { const float y = Y[i]; g *= (y > 0.f ? 1.f : y + 1.f); }
+        if (dpre) dpre[i] = g;
+        if (dbias) {
+            if (kFixedColumn) mine += g;
+            else atomicAdd(&s_col[(int)(i % F)], g);
+        }
+    }
+    if (dbias && kFixedColumn && first < total) atomicAdd(&s_col[(int)(first % F)], mine);
+    __syncthreads();
+    if (dbias)
+        for (int c = threadIdx.x; c < F; c += kBlock) atomicAdd(&dbias[c], s_col[c]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_scale_rows(const float* __restrict__ X, const float* __restrict__ coef, int64_t n_rows, int F,
+                                                      float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_rows * (int64_t)F) out[i] = X[i] * coef[i / F];
+}
+
+struct PlanWs {
+    int64_t* status;       // [2]
+    uint32_t* keys;        // [E]
+    uint32_t* sorted;      // [E]
+    uint32_t* order;       // [E]
+    uint32_t* ptr;         // [N+1]
+    int32_t* last_loop;    // [N]
+    float* dinv;           // [N]
+    float* loop_w;         // [N]
+    void* scratch;
+    size_t scratch_bytes;
+    size_t total_bytes;
+};
+
+static PlanWs carve_plan(void* ws, int64_t e, int64_t n) {
+    Arena a(ws, (size_t)-1);
+    PlanWs w;
+    w.status = a.take<int64_t>(2);
+    w.keys = a.take<uint32_t>(e);
+    w.sorted = a.take<uint32_t>(e);
+    w.order = a.take<uint32_t>(e);
+    w.ptr = a.take<uint32_t>(n + 1);
+    w.last_loop = a.take<int32_t>(n);
+    w.dinv = a.take<float>(n);
+    w.loop_w = a.take<float>(n);
+    w.scratch_bytes = sort_ws_bytes(e, 4);
+    w.scratch = a.take<char>((int64_t)w.scratch_bytes);
+    w.total_bytes = a.used;
+    return w;
+}
+
+// group edge ids by `index` (stable): order[p] = edge id, ptr = CSR pointer over [0, n_groups]
+static int group_by(const int64_t* index, int64_t e, int64_t n_groups, PlanWs& w, hipStream_t st) {
+    const unsigned grid = (unsigned)ceil_div(e > 0 ? e : 1, kBlock);
+    if (e > 0) {
+        k_index_key<<<grid, kBlock, 0, st>>>(index, e, n_groups, w.keys, w.status + 1);
+        PP_LAUNCH_CHECK();
+        int rc = sort_pairs<uint32_t>(w.keys, nullptr, w.sorted, w.order, e, 0, bits_for((uint64_t)(n_groups > 0 ? n_groups - 1 : 0)),
+                                      w.scratch, w.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+    }
+    k_ptr_from_sorted_u32<<<(unsigned)ceil_div(e + 1, kBlock), kBlock, 0, st>>>(w.sorted, e, n_groups, w.ptr);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+static int launch_spmm(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* X, int F, const float* self_coef,
+                       const float* S, const float* bias, int act, float* Y, hipStream_t st) {
+    if (n_rows == 0 || F == 0) return PP_OK;
+#define PP_SPMM_CASE(KERNEL, L)                                                                                         \
+    KERNEL<L><<<(unsigned)ceil_div(n_rows, kBlock / L), kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, Y)
+    const bool vec = (F % 4 == 0) && (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)S | (uintptr_t)bias) % 16 == 0);
+    if (vec) {
+        const int q = F / 4;
+        if (q <= 1) PP_SPMM_CASE(k_spmm_v4, 1);
+        else if (q <= 2) PP_SPMM_CASE(k_spmm_v4, 2);
+        else if (q <= 4) PP_SPMM_CASE(k_spmm_v4, 4);
+        else if (q <= 8) PP_SPMM_CASE(k_spmm_v4, 8);
+        else if (q <= 16) PP_SPMM_CASE(k_spmm_v4, 16);
+        else if (q <= 32) PP_SPMM_CASE(k_spmm_v4, 32);
+        else PP_SPMM_CASE(k_spmm_v4, 64);
+    } else {
+        if (F <= 4) PP_SPMM_CASE(k_spmm_s1, 4);
+        else if (F <= 16) PP_SPMM_CASE(k_spmm_s1, 16);
+        else PP_SPMM_CASE(k_spmm_s1, 64);
+    }
+#undef PP_SPMM_CASE
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" {
+
+// ---------------------------------------------------------------- GCN plan
+size_t pp_gcn_plan_ws_bytes(int64_t n_edges, int64_t n_nodes) { return carve_plan(nullptr, n_edges, n_nodes).total_bytes; }
+
+int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int32_t* in_ptr, int32_t* in_idx,
+                float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, void* ws, size_t ws_bytes,
+                pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_edges >= 0 && n_nodes >= 0, PP_ERR_ARG, "pp_gcn_plan: negative size");
+    PP_REQUIRE(n_edges < (int64_t)0x7fffffff && n_nodes < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_plan: E or N >= 2^31");
+    PlanWs w = carve_plan(ws, n_edges, n_nodes);
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_gcn_plan: workspace too small");
+    PP_HIP(hipMemsetAsync(w.status, 0, 2 * sizeof(int64_t), st));
+    if (n_nodes == 0) return PP_OK;
+    const unsigned egrid = (unsigned)ceil_div(n_edges > 0 ? n_edges : 1, kBlock);
+    const unsigned ngrid = (unsigned)ceil_div(n_nodes, kBlock);
+    const unsigned pgrid = (unsigned)ceil_div(n_nodes + 1, kBlock);
+    // edges grouped by destination (forward aggregation)
+    int rc = group_by(edge_index + n_edges, n_edges, n_nodes, w, st);
+    if (rc != PP_OK) return rc;
+    PP_HIP(hipMemsetAsync(w.last_loop, 0xff, (size_t)n_nodes * sizeof(int32_t), st));     // -1
+    if (n_edges > 0) {
+        // validate sources too before they are used as indices
+        k_index_key<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, n_nodes, w.keys, w.status + 1);
+        PP_LAUNCH_CHECK();
+        k_last_self_loop<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, n_nodes, w.last_loop);
+        PP_LAUNCH_CHECK();
+    }
+    k_gcn_degree<<<ngrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, w.ptr, w.last_loop, n_nodes, w.dinv, w.loop_w);
+    PP_LAUNCH_CHECK();
+    k_self_coefficient<<<ngrid, kBlock, 0, st>>>(w.dinv, w.loop_w, n_nodes, self_coef);
+    PP_LAUNCH_CHECK();
+    k_u32_to_i32_ptr<<<pgrid, kBlock, 0, st>>>(w.ptr, n_nodes + 1, in_ptr);
+    PP_LAUNCH_CHECK();
+    if (n_edges > 0) {
+        k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, w.dinv, 1, in_idx, in_val);
+        PP_LAUNCH_CHECK();
+    }
+    // edges grouped by source (backward = transposed aggregation)
+    rc = group_by(edge_index, n_edges, n_nodes, w, st);
+    if (rc != PP_OK) return rc;
+    k_u32_to_i32_ptr<<<pgrid, kBlock, 0, st>>>(w.ptr, n_nodes + 1, out_ptr);
+    PP_LAUNCH_CHECK();
+    if (n_edges > 0) {
+        k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, w.dinv, 0, out_idx, out_val);
+        PP_LAUNCH_CHECK();
+    }
+    return PP_OK;
+}
+
+// bipartite higher-order -> first-order projection plan: forward rows = first-order nodes, backward rows = higher-order nodes
+int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n_ho, int64_t n_fo, int32_t* in_ptr, int32_t* in_idx,
+                      float* in_degree, int32_t* out_ptr, int32_t* out_idx, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_pairs >= 0 && n_ho >= 0 && n_fo >= 0, PP_ERR_ARG, "pp_bipartite_plan: negative size");
+    const int64_t nmax = n_ho > n_fo ? n_ho : n_fo;
+    PP_REQUIRE(n_pairs < (int64_t)0x7fffffff && nmax < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_bipartite_plan: size >= 2^31");
+    PlanWs w = carve_plan(ws, n_pairs, nmax);
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_bipartite_plan: workspace too small");
+    PP_HIP(hipMemsetAsync(w.status, 0, 2 * sizeof(int64_t), st));
+    const unsigned egrid = (unsigned)ceil_div(n_pairs > 0 ? n_pairs : 1, kBlock);
+    int rc = group_by(bipartite_index + n_pairs, n_pairs, n_fo, w, st);           // by first-order destination
+    if (rc != PP_OK) return rc;
+    k_u32_to_i32_ptr<<<(unsigned)ceil_div(n_fo + 1, kBlock), kBlock, 0, st>>>(w.ptr, n_fo + 1, in_ptr);
+    PP_LAUNCH_CHECK();
+    if (n_fo > 0) {
+        k_ptr_diff_f32<<<(unsigned)ceil_div(n_fo, kBlock), kBlock, 0, st>>>(in_ptr, n_fo, in_degree);
+        PP_LAUNCH_CHECK();
+    }
+    if (n_pairs > 0) {
+        k_gather_index<<<egrid, kBlock, 0, st>>>(bipartite_index, w.order, n_pairs, in_idx);
+        PP_LAUNCH_CHECK();
+    }
+    rc = group_by(bipartite_index, n_pairs, n_ho, w, st);                        // by higher-order source
+    if (rc != PP_OK) return rc;
+    k_u32_to_i32_ptr<<<(unsigned)ceil_div(n_ho + 1, kBlock), kBlock, 0, st>>>(w.ptr, n_ho + 1, out_ptr);
+    PP_LAUNCH_CHECK();
+    if (n_pairs > 0) {
+        k_gather_index<<<egrid, kBlock, 0, st>>>(bipartite_index + n_pairs, w.order, n_pairs, out_idx);
+        PP_LAUNCH_CHECK();
+    }
+    return PP_OK;
+}
+
+const int64_t* pp_plan_result_ptr(void* ws) { return (const int64_t*)ws; }
+
+// ---------------------------------------------------------------- propagation
+int pp_spmm_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* X, int F, const float* self_coef,
+                const float* S, const float* bias, int act, float* Y, pp_stream_t stream) {
+    PP_REQUIRE(n_rows >= 0 && F >= 0, PP_ERR_ARG, "pp_spmm_f32: negative size");
+    PP_REQUIRE(act == 0 || act == 1, PP_ERR_ARG, "pp_spmm_f32: act must be 0 (none) or 1 (elu)");
+    return launch_spmm(ptr, idx, val, n_rows, X, F, self_coef, self_coef ? (S ? S : X) : nullptr, bias, act, Y, (hipStream_t)stream);
+}
+
+int pp_act_backward_f32(const float* dY, const float* Y, int64_t n_rows, int F, int act, float* dpre, float* dbias, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0 && F >= 0, PP_ERR_ARG, "pp_act_backward_f32: negative size");
+    if (dbias) PP_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), st));
+    const int64_t total = n_rows * (int64_t)F;
+    if (total == 0) return PP_OK;
+    int64_t g = ceil_div(total, kBlock * 8);
+    if (g > kMaxGrid) g = kMaxGrid;
+    if (g < 1) g = 1;
+    if ((g * kBlock) % F == 0)
+        k_act_backward<true><<<(unsigned)g, kBlock, (size_t)F * sizeof(float), st>>>(dY, Y, n_rows, F, act, dpre, dbias);
+    else
+        k_act_backward<false><<<(unsigned)g, kBlock, (size_t)F * sizeof(float), st>>>(dY, Y, n_rows, F, act, dpre, dbias);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+int pp_scale_rows_f32(const float* X, const float* coef, int64_t n_rows, int F, float* out, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = n_rows * (int64_t)F;
+    if (total <= 0) return PP_OK;
+    k_scale_rows<<<(unsigned)ceil_div(total, kBlock), kBlock, 0, st>>>(X, coef, n_rows, F, out);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+"""GPU parity of the HIP DBGNN (forward, loss, every parameter gradient) against the CPU oracle.
+Tolerance: 1e-5 relative fp32 (BASELINE.json north_star) with a 1e-6 absolute floor for values near zero.
+The oracle itself is unpinned by the reference (its DBGNN test asserts only ``out is not None``); it is
+cross-checked against a dense evaluation in tests/test_oracle_dbgnn.py."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RTOL, ATOL = 1e-5, 2e-6
+
+
+@pytest.fixture(scope="module")
+def pp():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import pathpyg_amd
+    return pathpyg_amd
+
+
+def _bundle(seed, n, e, n_ho, e_ho, f, mapping="last", loops=True):
+    g = torch.Generator().manual_seed(seed)
+
+    def graph(nn, ee):
+        ei = torch.randint(0, nn, (2, ee), generator=g)
+        if loops and ee >= 10:
+            ei[:, : ee // 10] = torch.randint(0, nn, (1, ee // 10), generator=g).repeat(2, 1)
+        key = torch.unique(ei[0] * nn + ei[1])                      # layers are coalesced: distinct, (row, col)-sorted
+        ei = torch.stack((key // nn, key % nn))
+        return ei, torch.randint(1, 6, (ei.size(1),), generator=g).float()
+
+    ei, w = graph(n, e)
+    ei_h, w_h = graph(n_ho, e_ho)
+    ns = torch.randint(0, n, (n_ho, 2), generator=g)
+    from oracle import model as om
+    data = {
+        "num_nodes": n, "num_ho_nodes": n_ho,
+        "x": torch.randn(n, f[0], generator=g), "x_h": torch.randn(n_ho, f[1], generator=g),
+        "edge_index": ei, "edge_weights": w, "edge_index_higher_order": ei_h, "edge_weights_higher_order": w_h,
+        "bipartite_edge_index": om.bipartite_edge_index(ns, mapping),
+    }
+    return data, torch.randint(0, 3, (n,), generator=g)
+
+
+def _to_module(pp, params, num_classes, num_features, hidden):
+    model = pp.nn.DBGNN(num_classes=num_classes, num_features=num_features, hidden_dims=hidden, p_dropout=0.0)
+    missing = model.load_state_dict(params, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model.to(DEV)
+
+
+@pytest.mark.parametrize("seed,n,e,n_ho,e_ho,f,hidden,mapping", [
+    (0, 30, 120, 70, 200, (8, 12), [16, 32, 8], "last"),
+    (1, 200, 3000, 900, 4000, (64, 64), [64, 64, 64], "last"),
+    (2, 50, 20, 40, 0, (5, 7), [6, 10, 3], "first"),                # scalar-width kernels, empty higher-order graph
+    (3, 120, 900, 500, 1500, (16, 16), [32, 16], "both"),            # single GCN layer per order
+    (4, 3000, 40000, 20000, 60000, (64, 64), [128, 256, 64], "last"),
+])
+def test_dbgnn_forward_backward_matches_oracle(pp, seed, n, e, n_ho, e_ho, f, hidden, mapping):
+    from oracle import dbgnn as od
+    data, y = _bundle(seed, n, e, n_ho, e_ho, f, mapping)
+    params = od.init_params(3, f, hidden, seed=seed)
+    want_out, want_loss, want_grads = od.loss_and_grads(params, data, y)
+
+    model = _to_module(pp, params, 3, f, hidden)
+    gdata = pp.Data(**{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in data.items()})
+    out = model(gdata)
+    loss = F.cross_entropy(out, y.to(DEV))
+    loss.backward()
+    torch.testing.assert_close(out.detach().cpu(), want_out, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(loss.detach().cpu(), want_loss, rtol=RTOL, atol=ATOL)
+    for name, p in model.named_parameters():
+        scale = float(want_grads[name].abs().max()) + 1e-12
+        torch.testing.assert_close(p.grad.cpu(), want_grads[name], rtol=RTOL * 10, atol=max(ATOL, 2e-5 * scale)), name
+    # cached plans: second call reuses them and gives the same numbers
+    out2 = model(gdata)
+    assert torch.equal(out2, out)
+
+
+def test_gcn_conv_layer_alone_with_self_loops_and_isolated_nodes(pp):
+    from oracle import dbgnn as od
+    ei = torch.tensor([[0, 0, 1, 3, 3], [0, 1, 0, 3, 1]])          # node 2 and 4 isolated; loops on 0 and 3
+    w = torch.tensor([3.0, 2.0, 5.0, 0.5, 1.5])
+    x = torch.randn(5, 4, generator=torch.Generator().manual_seed(0))
+    conv = pp.nn.GCNConv(4, 6).to(DEV)
+    want = od.gcn_conv(x, ei, w, conv.lin.weight.detach().cpu(), conv.bias.detach().cpu())
+    got = conv(x.to(DEV), ei.to(DEV), w.to(DEV))
+    torch.testing.assert_close(got.detach().cpu(), want, rtol=RTOL, atol=ATOL)
+
+
+def test_reference_dbgnn_smoke(pp):
+    # reference tests/nn/test_dbgnn.py:33-43 (one-hot features, dropout 0.4, train mode): output exists, right shape
+    paths = pp.PathData(pp.IndexMap(["A", "B", "C", "D", "E"]), device=DEV)
+    for wk in (("A", "C", "D"), ("A", "C", "D"), ("B", "C", "E"), ("B", "C", "E")):
+        paths.append_walk(wk)
+    m = pp.MultiOrderModel.from_path_data(paths, max_order=2)
+    data = m.to_dbgnn_data()
+    g1, g2 = m.layers[1], m.layers[2]
+    data.y = torch.tensor([0, 0, 1, 1, 1], device=DEV)
+    model = pp.nn.DBGNN(num_features=[g1.n, g2.n], num_classes=2, hidden_dims=[16, 32, 8], p_dropout=0.4).to(DEV)
+    out = model(data)
+    assert out is not None and out.shape == (5, 2) and torch.isfinite(out).all()
+    # and deterministic parity in eval mode against the oracle
+    from oracle import dbgnn as od
+    model.eval()
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cpu_data = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in data.to_dict().items()}
+    torch.testing.assert_close(model(data).detach().cpu(), od.forward(params, cpu_data), rtol=RTOL, atol=ATOL)
