@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Headline benchmark: k=2 De Bruijn lift of a synthetic temporal edge stream + one DBGNN train step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+One STEP = one pass of the hot path over one batch of synthetic events that are already resident in HBM:
+    MultiOrderModel.from_temporal_graph(g, delta, max_order=2)      (event-graph lift + layers 1 and 2)
+    -> to_dbgnn_data(x, x_h) -> DBGNN forward, cross-entropy, backward, Adam step (plans rebuilt each step)
+Workload (SURVEY.md §8d "10M temporal edges" headline of BASELINE.json): temporal ER stream, m = 10^7 events,
+N = 5*10^5 nodes, int64 timestamps uniform in [0, 10^7), delta = 10^6 (E2 ~ 2*10^7), 64-dim features,
+hidden_dims [64, 64, 64], 8 classes, fp32.  The printed JSON line follows the driver's contract and adds
+`roofline` (dominant kernel, live HIP-event timing) and `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guide: MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--events", type=int, default=10_000_000, help="temporal edges per GPU")
+    ap.add_argument("--nodes", type=int, default=500_000)
+    ap.add_argument("--span", type=int, default=10_000_000)
+    ap.add_argument("--delta", type=int, default=1_000_000)
+    ap.add_argument("--features", type=int, default=64)
+    ap.add_argument("--classes", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-events", type=int, default=14_000, help="events of the CPU-oracle sample (per-timestamp loop)")
+    return ap.parse_args()
+
+
+def synth_stream(events: int, nodes: int, span: int, seed: int, device):
+    """Temporal Erdos-Renyi stream: endpoints and timestamps i.i.d. uniform (self loops kept), unsorted."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    edge_index = torch.randint(0, nodes, (2, events), generator=g, device=device, dtype=torch.int64)
+    time_ = torch.randint(0, span, (events,), generator=g, device=device, dtype=torch.int64)
+    return edge_index, time_
+
+
+class KernelClock:
+    """HIP events around every launch of one C-ABI entry point, on the stream it is launched on."""
+
+    def __init__(self, lib, name: str, bytes_of):
+        self.lib, self.name, self.bytes_of = lib, name, bytes_of
+        self.orig = getattr(lib, name)
+        self.records = []
+        self.enabled = False
+
+    def __enter__(self):
+        def wrapped(*args):
+            if not self.enabled:
+                return self.orig(*args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            rc = self.orig(*args)
+            e1.record(torch.cuda.current_stream())
+            self.records.append((e0, e1, self.bytes_of(*args)))
+            return rc
+        setattr(self.lib, self.name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.lib, self.name, self.orig)
+
+    def summary(self):
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
+        return len(self.records), ms, sum(b for _, _, b in self.records)
+
+
+def spmm_bytes(ptr, idx, val, n_rows, x, f, self_coef, s, bias, act, y, stream):
+    """Algorithmic HBM bytes of one pp_spmm_f32 launch: CSR (ptr + idx + val) read once,
+    every source feature row read once, every output row written once (+ the self-term rows when separate)."""
+    nnz, n_src = spmm_bytes.shape_of[ptr]
+    total = 4 * (n_rows + 1) + nnz * (4 + (4 if val else 0)) + 4 * f * (n_src + n_rows)
+    if self_coef:
+        total += 4 * n_rows + (4 * f * n_rows if (s and s != x) else 0)
+    return total
+
+
+spmm_bytes.shape_of = {}
+
+
+def cpu_baseline(args, seed: int) -> dict:
+    """The CPU oracle (port of the reference algorithm incl. its per-timestamp lift loop) on a bounded sample of
+    the same generator: events scaled down, nodes and delta scaled to keep E2/m of the full workload."""
+    from oracle import dbgnn as od
+    from oracle import model as om
+    scale = args.cpu_events / args.events
+    m = args.cpu_events
+    n = max(int(args.nodes * scale), 16)
+    span = args.span
+    delta = args.delta                                   # E2/m = m*delta/(n*span) is unchanged when m and n scale together
+    ei, t = synth_stream(m, n, span, seed, torch.device("cpu"))
+    t0 = time.perf_counter()
+    ei, t, _ = om.stable_time_sort(ei, t)
+    layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2, loop_lift=True)
+    t_lift = time.perf_counter() - t0
+    e2 = int(om.temporal_lift_sorted(ei, t, delta, n).size(1))
+    g = torch.Generator().manual_seed(seed + 1)
+    data = om.dbgnn_inputs(layers, 2, "last", x=torch.randn(n, args.features, generator=g),
+                           x_h=torch.randn(layers[2]["num_nodes"], args.features, generator=g))
+    y = torch.randint(0, args.classes, (n,), generator=g)
+    params = {k: v.requires_grad_(True) for k, v in od.init_params(args.classes, (args.features, args.features),
+                                                                   [args.features] * 3, seed=seed).items()}
+    opt = torch.optim.Adam(params.values(), lr=1e-3)
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    loss = torch.nn.functional.cross_entropy(od.forward(params, data), y)
+    loss.backward()
+    opt.step()
+    t_train = time.perf_counter() - t0
+    # vectorised CPU lift (sort + searchsorted) on a larger sample, for context
+    m2 = min(args.events, 1_000_000)
+    n2 = max(int(args.nodes * m2 / args.events), 16)
+    ei2, t2 = synth_stream(m2, n2, span, seed + 2, torch.device("cpu"))
+    ei2, t2, _ = om.stable_time_sort(ei2, t2)
+    t0 = time.perf_counter()
+    ho = om.temporal_lift_sorted(ei2, t2, delta, n2)
+    t_sorted = time.perf_counter() - t0
+    return {
+        "value": e2 / (t_lift + t_train),
+        "unit": "lifted k-edges/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"oracle (reference per-timestamp lift loop + aggregation + 1 DBGNN train step) on m={m} events, "
+                  f"N={n}, delta={delta}, E2={e2}: lift+aggregate {t_lift:.2f}s, train step {t_train:.2f}s",
+        "events_per_s": m / (t_lift + t_train),
+        "vectorised_lift_k_edges_per_s": ho.size(1) / t_sorted,
+        "vectorised_lift_sample": f"sort+searchsorted CPU lift only, m={m2}, E2={ho.size(1)}, {t_sorted:.2f}s",
+    }
+
+
+def main() -> int:
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: pathpyg_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import pathpyg_amd as pp
+    from pathpyg_amd import _hip
+    from pathpyg_amd._lib import lib
+
+    # ---- inputs, resident in HBM before the timed region (each rank owns an independent stream: weak scaling)
+    ei, t = synth_stream(args.events, args.nodes, args.span, seed=1 + rank, device=dev)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=args.nodes))       # stable time sort (HIP radix sort)
+    del ei, t
+    model0 = pp.MultiOrderModel.from_temporal_graph(g, delta=args.delta, max_order=2)
+    n_ho = model0.layers[2].n
+    feat = torch.Generator(device=dev).manual_seed(7 + rank)
+    x = torch.randn(args.nodes, args.features, generator=feat, device=dev)
+    x_h = torch.randn(n_ho, args.features, generator=feat, device=dev)
+    y = torch.randint(0, args.classes, (args.nodes,), generator=feat, device=dev)
+    sizes = {"m": args.events, "N": args.nodes, "E2": int(pp.algorithms.lift_order_temporal(g, args.delta).size(1)),
+             "U2": n_ho, "A1": model0.layers[1].m, "A2": model0.layers[2].m}
+    del model0
+    net = pp.nn.DBGNN(num_classes=args.classes, num_features=(args.features, args.features),
+                      hidden_dims=[args.features] * 3, p_dropout=0.0).to(dev)
+    if world > 1:   # data-parallel over independent streams: only the (tiny) weight gradients are exchanged
+        net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank])
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    lift_ms = []
+
+    def step(timed: bool):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        mom = pp.MultiOrderModel.from_temporal_graph(g, delta=args.delta, max_order=2)
+        data = mom.to_dbgnn_data(max_order=2, mapping="last", x=x, x_h=x_h)
+        e1.record()
+        opt.zero_grad(set_to_none=True)
+        out = net(data)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        loss.backward()
+        opt.step()
+        if timed:
+            lift_ms.append((e0, e1))
+        return loss
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    L = lib()
+
+    # shapes (nnz, source rows) of each CSR are recorded when the plan is built
+    orig_gcn_plan, orig_bip_plan = _hip.gcn_plan, _hip.bipartite_plan
+
+    def gcn_plan(edge_index, edge_weight, num_nodes):
+        p = orig_gcn_plan(edge_index, edge_weight, num_nodes)
+        spmm_bytes.shape_of[p.fwd_ptr.data_ptr()] = (p.fwd_idx.numel(), num_nodes)
+        spmm_bytes.shape_of[p.bwd_ptr.data_ptr()] = (p.bwd_idx.numel(), num_nodes)
+        return p
+
+    def bip_plan(bip, n_ho_, n_fo_):
+        p = orig_bip_plan(bip, n_ho_, n_fo_)
+        spmm_bytes.shape_of[p.fwd_ptr.data_ptr()] = (p.fwd_idx.numel(), n_ho_)
+        spmm_bytes.shape_of[p.bwd_ptr.data_ptr()] = (p.bwd_idx.numel(), n_fo_)
+        return p
+
+    _hip.gcn_plan, _hip.bipartite_plan = gcn_plan, bip_plan
+
+    with KernelClock(L, "pp_spmm_f32", spmm_bytes) as spmm_clock, \
+            KernelClock(L, "pp_temporal_fill", lambda m, n, total, *r: 16 * total) as fill_clock:
+        for _ in range(args.warmup):
+            step(False)
+        barrier()
+        spmm_clock.enabled = fill_clock.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step(True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        spmm_clock.enabled = fill_clock.enabled = False
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        e2_all = torch.tensor([sizes["E2"]], device=dev, dtype=torch.float64)
+        dist.all_reduce(e2_all)
+        e2_total = float(e2_all.item())
+    else:
+        e2_total = float(sizes["E2"])
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        lift = sum(a.elapsed_time(b) for a, b in lift_ms) / len(lift_ms)
+        n_spmm, spmm_ms, spmm_b = spmm_clock.summary()
+        n_fill, fill_ms, fill_b = fill_clock.summary()
+        dominant = ("k_spmm_v4 (pp_spmm_f32)", n_spmm, spmm_ms, spmm_b) if spmm_ms >= fill_ms else \
+                   ("k_expand (pp_temporal_fill)", n_fill, fill_ms, fill_b)
+        achieved = dominant[3] / (dominant[2] * 1e-3) / 1e9 if dominant[2] > 0 else 0.0
+        line = {
+            "metric": "lifted k-edges/s (k=2 De Bruijn lift + aggregation + 1 DBGNN train step per pass, 10M temporal edges)",
+            "value": e2_total * args.steps / elapsed,
+            "unit": "lifted k-edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64 lift / f32 DBGNN",
+            "data": "synthetic",
+            "config": {"workload": f"temporal ER stream per GPU: m={args.events} events, N={args.nodes} nodes, t~U[0,{args.span}), "
+                                   f"delta={args.delta}, k=2, F={args.features}, hidden=[{args.features}]*3, classes={args.classes}",
+                       "parallelism": "1 GPU" if world == 1 else f"{world} independent streams, weight-gradient all-reduce (RCCL)",
+                       **sizes},
+            "temporal_events_per_s": world * args.events * args.steps / elapsed,
+            "lift_ms": lift,
+            "lift_k_edges_per_s": sizes["E2"] / (lift * 1e-3),
+            "dbgnn_step_ms": ms_step - lift,
+            "dbgnn_steps_per_s": 1e3 / max(ms_step - lift, 1e-9),
+            "loss": float(loss.detach()),
+            "roofline": {"bound": "hbm", "kernel": dominant[0], "launches": dominant[1],
+                         "avg_launch_ms": dominant[2] / max(dominant[1], 1), "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+            "lift_fill_roofline": {"kernel": "k_expand (pp_temporal_fill)", "launches": n_fill,
+                                   "avg_launch_ms": fill_ms / max(n_fill, 1),
+                                   "achieved": (fill_b / (fill_ms * 1e-3) / 1e9) if fill_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": (fill_b / (fill_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fill_ms > 0 else 0.0},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, seed=11)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -169,6 +169,13 @@ int pp_act_backward_f32(const float* dY, const float* Y, int64_t n_rows, int F, 
 /* out[r,:] = coef[r] * X[r,:] (gradient of the bipartite self term) */
 int pp_scale_rows_f32(const float* X, const float* coef, int64_t n_rows, int F, float* out, pp_stream_t stream);
 
+/* Weight gradient of a dense layer of the DBGNN (autograd of lin / lin1 / lin2 / GCNConv.lin, dbgnn.py:64,133,139,149):
+ * dW[M,K] = dH[N,M]^T X[N,K] and, when db != NULL, db[M] = column sums of dH.  fp32 on the matrix cores
+ * (v_mfma_f32_32x32x2_f32, operands read straight from the row-major inputs), deterministic two-stage reduction. */
+size_t pp_weight_grad_ws_bytes(int64_t n_rows, int M, int K);
+int pp_weight_grad_f32(const float* dH, const float* X, int64_t n_rows, int M, int K, float* dW, float* db, void* ws, size_t ws_bytes,
+                       pp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -406,3 +406,18 @@ def scale_rows(x: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
         out = torch.empty_like(x)
         check(lib().pp_scale_rows_f32(_p(x), _p(coef), x.size(0), x.size(1), _p(out), _stream()), "pp_scale_rows_f32")
     return out
+
+
+def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
+    """(dW [M,K], db [M] or None) of y = x W^T (+ b) from dy [N,M] and x [N,K] — MFMA kernel, fp32."""
+    dev = require_device(dy, x)
+    dy, x = dy.contiguous(), x.contiguous()
+    n, m = dy.shape
+    k = x.size(1)
+    L = lib()
+    with torch.cuda.device(dev):
+        dw = torch.empty((m, k), dtype=torch.float32, device=dev)
+        db = torch.empty(m, dtype=torch.float32, device=dev) if want_bias else None
+        ws = _workspace(L.pp_weight_grad_ws_bytes(n, m, k), dev)
+        check(L.pp_weight_grad_f32(_p(dy), _p(x), n, m, k, _p(dw), _p(db), _p(ws), ws.numel(), _stream()), "pp_weight_grad_f32")
+    return dw, db

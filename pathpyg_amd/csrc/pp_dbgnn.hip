@@ -398,3 +398,152 @@ int pp_scale_rows_f32(const float* X, const float* coef, int64_t n_rows, int F, 
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// Weight gradient of a dense layer on the matrix cores:  dW[M,K] = dH^T X  (+ db[M] = column sums of dH)
+//   dH : [N, M] row-major (gradient of the layer output),  X : [N, K] row-major (layer input),  N >> M, K.
+// This is the one GEMM of the train step a vendor library handles badly (reduction length N ~ 10^7, output
+// 64x64): rocBLAS needs 4.7 ms for it at N = 10^7, the HBM floor for reading dH and X once is ~0.9 ms.
+// v_mfma_f32_32x32x2_f32 takes its A operand as A[i = lane&31][k = lane>>5] and B as B[k = lane>>5][j = lane&31];
+// with the reduction index k running over ROWS n of dH and X, both operands are plain coalesced row reads
+// (lanes 0-31: 128 contiguous bytes of row n, lanes 32-63: of row n+1) - no LDS staging, no transposes.
+// Each wave owns a contiguous range of rows and a TMxTK block of 32x32 output tiles in accumulators; the
+// waves of all workgroups write partial tiles that a second tiny kernel sums in a fixed order (deterministic).
+namespace pp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kWgTile = 2;                 // 2x2 tiles of 32x32 per wave = 64x64 outputs, 64 accumulator registers
+constexpr int kWgUnroll = 8;               // row pairs in flight per iteration (16 rows of dH and X)
+
+__global__ __launch_bounds__(kBlock) void k_weight_grad(const float* __restrict__ dH, const float* __restrict__ X, int64_t n_rows, int M, int K,
+                                                       int64_t rows_per_wave, float* __restrict__ partial, float* __restrict__ partial_bias) {
+    // blockIdx.y selects the 64x64 output block (i-block major), blockIdx.x the row range
+    const int k_blocks = (K + 63) / 64;
+    const int i_base = (blockIdx.y / k_blocks) * 64;
+    const int j_base = (blockIdx.y % k_blocks) * 64;
+    const int lane = lane_id();
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
+    const int64_t n_begin = wave_global * rows_per_wave;
+    int64_t n_end = n_begin + rows_per_wave;
+    if (n_end > n_rows) n_end = n_rows;
+
+    f32x16 acc[kWgTile][kWgTile];
+#pragma unroll
+    for (int a = 0; a < kWgTile; ++a)
+#pragma unroll
+        for (int b = 0; b < kWgTile; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bias_acc[kWgTile] = {0.f, 0.f};
+    const bool ok_i[kWgTile] = {i_base + c < M, i_base + 32 + c < M};
+    const bool ok_j[kWgTile] = {j_base + c < K, j_base + 32 + c < K};
+
+    for (int64_t n0 = n_begin; n0 < n_end; n0 += 2 * kWgUnroll) {
+        float a[kWgUnroll][kWgTile], b[kWgUnroll][kWgTile];
+#pragma unroll
+        for (int u = 0; u < kWgUnroll; ++u) {
+            const int64_t n = n0 + 2 * u + h;
+            const bool live = n < n_end;
+#pragma unroll
+            for (int t = 0; t < kWgTile; ++t) {
+                a[u][t] = (live && ok_i[t]) ? dH[n * M + i_base + 32 * t + c] : 0.f;
+                b[u][t] = (live && ok_j[t]) ? X[n * K + j_base + 32 * t + c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kWgUnroll; ++u) {
+#pragma unroll
+            for (int ti = 0; ti < kWgTile; ++ti) {
+                bias_acc[ti] += a[u][ti];
+#pragma unroll
+                for (int tj = 0; tj < kWgTile; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][ti], b[u][tj], acc[ti][tj], 0, 0, 0);
+            }
+        }
+    }
+    // partial[(wave_global * gridDim.y + blockIdx.y)][64][64]; C/D layout: row = (r&3) + 8*(r>>2) + 4*h, col = c
+    float* out = partial + ((wave_global * gridDim.y + blockIdx.y) << 12);
+#pragma unroll
+    for (int ti = 0; ti < kWgTile; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < kWgTile; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[row * 64 + 32 * tj + c] = acc[ti][tj][r];
+            }
+    if (partial_bias && (blockIdx.y % k_blocks) == 0) {
+        // lanes c and c+32 hold the two row parities of the same output column
+        float* pb = partial_bias + (wave_global * ((M + 63) / 64) + blockIdx.y / k_blocks) * 64;
+#pragma unroll
+        for (int t = 0; t < kWgTile; ++t) {
+            float v = bias_acc[t] + __shfl_xor(bias_acc[t], 32, kWave);
+            if (h == 0) pb[32 * t + c] = v;
+        }
+    }
+}
+
+// sums the per-wave partial tiles in wave order (fixed order => bitwise reproducible results)
+__global__ __launch_bounds__(kBlock) void k_weight_grad_reduce(const float* __restrict__ partial, const float* __restrict__ partial_bias,
+                                                              int64_t n_waves, int M, int K, float* __restrict__ dW, float* __restrict__ db) {
+    const int k_blocks = (K + 63) / 64, i_blocks = (M + 63) / 64;
+    const int n_blocks = k_blocks * i_blocks;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx < M * K) {
+        const int i = idx / K, j = idx - i * K;
+        const int blk = (i / 64) * k_blocks + (j / 64);
+        const float* p = partial + ((int64_t)blk << 12) + (i % 64) * 64 + (j % 64);
+        float s = 0.f;
+        for (int64_t w = 0; w < n_waves; ++w) s += p[(w * n_blocks) << 12];
+        dW[idx] = s;
+    }
+    if (db && idx < M) {
+        const float* p = partial_bias + (idx / 64) * 64 + (idx % 64);
+        float s = 0.f;
+        for (int64_t w = 0; w < n_waves; ++w) s += p[w * i_blocks * 64];
+        db[idx] = s;
+    }
+}
+
+static inline int64_t weight_grad_waves(int64_t n_rows) {
+    int64_t waves = ceil_div(n_rows, 2 * kWgUnroll * 8);        // at least 128 rows per wave
+    const int64_t cap = 256 * 4 * kWavesPerBlock;               // 4 workgroups per CU
+    if (waves > cap) waves = cap;
+    if (waves < 1) waves = 1;
+    return ceil_div(waves, kWavesPerBlock) * kWavesPerBlock;
+}
+
+}  // namespace pp
+
+extern "C" {
+
+size_t pp_weight_grad_ws_bytes(int64_t n_rows, int M, int K) {
+    const int64_t blocks = (int64_t)((M + 63) / 64) * ((K + 63) / 64);
+    const int64_t waves = pp::weight_grad_waves(n_rows);
+    return pp::align_up((size_t)waves * blocks * 4096 * sizeof(float)) + pp::align_up((size_t)waves * ((M + 63) / 64) * 64 * sizeof(float));
+}
+
+// dW[M,K] = dH[N,M]^T X[N,K], db[M] = column sums of dH (db may be NULL); fp32 on v_mfma_f32_32x32x2_f32
+int pp_weight_grad_f32(const float* dH, const float* X, int64_t n_rows, int M, int K, float* dW, float* db, void* ws, size_t ws_bytes,
+                       pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0 && M >= 1 && K >= 1, PP_ERR_ARG, "pp_weight_grad_f32: bad shape");
+    PP_REQUIRE(ws_bytes >= pp_weight_grad_ws_bytes(n_rows, M, K), PP_ERR_WORKSPACE, "pp_weight_grad_f32: workspace too small");
+    const int i_blocks = (M + 63) / 64, k_blocks = (K + 63) / 64;
+    const int64_t waves = pp::weight_grad_waves(n_rows);
+    const int64_t rows_per_wave = pp::ceil_div(pp::ceil_div(n_rows > 0 ? n_rows : 1, waves), 2) * 2;
+    float* partial = (float*)ws;
+    float* partial_bias = (float*)((char*)ws + pp::align_up((size_t)waves * i_blocks * k_blocks * 4096 * sizeof(float)));
+    dim3 grid((unsigned)(waves / pp::kWavesPerBlock), (unsigned)(i_blocks * k_blocks));
+    pp::k_weight_grad<<<grid, pp::kBlock, 0, st>>>(dH, X, n_rows, M, K, rows_per_wave, partial, db ? partial_bias : nullptr);
+    PP_LAUNCH_CHECK();
+    const int outs = M * K > M ? M * K : M;
+    pp::k_weight_grad_reduce<<<(unsigned)pp::ceil_div(outs, pp::kBlock), pp::kBlock, 0, st>>>(partial, db ? partial_bias : nullptr, waves, M, K,
+                                                                                             dW, db);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // extern "C"

@@ -58,6 +58,33 @@ class _Propagate(torch.autograd.Function):
         return None, dx, ds, dbias, None
 
 
+class _Dense(torch.autograd.Function):
+    """y = x W^T (+ b).  Forward and the input gradient are library GEMMs; the weight/bias gradient — a
+    [M, N] x [N, K] product with N ~ 10^7 that vendor GEMMs handle poorly — is the hand-written MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy @ weight
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = _hip.weight_grad(dy, x, want_bias=ctx.has_bias)
+        return dx, dw, db
+
+
+def dense(x, linear: Linear):
+    if x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda:
+        return _Dense.apply(x, linear.weight, linear.bias)
+    return linear(x)
+
+
 def _plan_cache(data) -> dict:
     cache = getattr(data, "_pp_plan_cache", None)
     if cache is None:
@@ -99,7 +126,7 @@ class GCNConv(Module):
     def forward(self, x, edge_index, edge_weight=None, *, plan=None, activation: bool = False):
         if plan is None:
             plan = _hip.gcn_plan(edge_index, edge_weight, x.size(0))
-        return _Propagate.apply(plan, self.lin(x), None, self.bias, activation)
+        return _Propagate.apply(plan, dense(x, self.lin), None, self.bias, activation)
 
 
 class BipartiteGraphOperator(Module):
@@ -114,7 +141,7 @@ class BipartiteGraphOperator(Module):
     def forward(self, x: tuple, bipartite_index: torch.Tensor, n_ho: int, n_fo: int, *, plan=None, activation: bool = False):
         if plan is None:
             plan = _hip.bipartite_plan(bipartite_index, n_ho, n_fo)
-        return _Propagate.apply(plan, self.lin1(x[0]), self.lin2(x[1]), None, activation)
+        return _Propagate.apply(plan, dense(x[0], self.lin1), dense(x[1], self.lin2), None, activation)
 
 
 class DBGNN(Module):
@@ -158,4 +185,4 @@ class DBGNN(Module):
 
         x = self.bipartite_layer((x_h, x), data.bipartite_edge_index, n_ho=n_ho, n_fo=n_fo, plan=plan_bi, activation=True)
         x = self._dropout(x)
-        return self.lin(x)
+        return dense(x, self.lin)

@@ -108,3 +108,18 @@ def test_reference_dbgnn_smoke(pp):
     params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     cpu_data = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in data.to_dict().items()}
     torch.testing.assert_close(model(data).detach().cpu(), od.forward(params, cpu_data), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("n,m,k", [(1, 1, 1), (100, 8, 64), (5000, 64, 64), (70_001, 64, 64), (3000, 40, 100), (2000, 256, 128), (999, 3, 70)])
+def test_weight_grad_kernel(pp, n, m, k):
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(n + m + k)
+    dy = torch.randn(n, m, generator=g)
+    x = torch.randn(n, k, generator=g)
+    dw, db = _hip.weight_grad(dy.to(DEV), x.to(DEV), want_bias=True)
+    want = (dy.double().t() @ x.double())
+    scale = float(want.abs().max()) + 1e-9
+    torch.testing.assert_close(dw.cpu().double(), want, rtol=1e-5, atol=1e-5 * scale)
+    torch.testing.assert_close(db.cpu().double(), dy.double().sum(0), rtol=1e-5, atol=1e-5 * float(dy.abs().sum(0).max()))
+    dw2, none = _hip.weight_grad(dy.to(DEV), x.to(DEV), want_bias=False)
+    assert none is None and torch.equal(dw2, dw)          # two-stage reduction is order-fixed: bitwise reproducible
