@@ -83,11 +83,15 @@ int pp_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t
  *                (for PP_DELTA_F32 pass the float32-rounded value).  With float64 time only delta_f is used.
  * pp_temporal_count builds the per-node event lists, counts each event's continuations and scans them;
  * pp_lift_result_ptr(ws)[0] = E2, [1] = status (bit 0: node index outside [0,num_nodes)).
- * pp_temporal_fill writes out[0][p] = i, out[1][p] = j for all pairs in lexicographic (i,j) order. */
+ * pp_temporal_fill writes out[0][p] = i, out[1][p] = j for all pairs in lexicographic (i,j) order.
+ * Edge-range sharding (one shard per GPU): pass the shard's events followed by its forward halo (all later events
+ * with t <= t_last_owned + delta); only the first n_own events act as sources (n_own = m, or < 0, for the whole
+ * stream) and id_offset (the global id of the shard's first event) is added to both rows of the result. */
 size_t pp_temporal_ws_bytes(int64_t m, int64_t num_nodes);
-int pp_temporal_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind,
-                      int64_t delta_i, double delta_f, void* ws, size_t ws_bytes, pp_stream_t stream);
-int pp_temporal_fill(int64_t m, int64_t num_nodes, int64_t total, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream);
+int pp_temporal_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t n_own, int64_t num_nodes,
+                      int delta_kind, int64_t delta_i, double delta_f, void* ws, size_t ws_bytes, pp_stream_t stream);
+int pp_temporal_fill(int64_t m, int64_t num_nodes, int64_t total, int64_t id_offset, int64_t* out, void* ws, size_t ws_bytes,
+                     pp_stream_t stream);
 
 /* lift_order_edge_index(edge_index, num_nodes) -> [2,E'] int64, src/pathpyG/algorithms/lift_order.py:48-79.
  * edge_index must be grouped by source like the reference demands (:52,55). */

@@ -40,10 +40,10 @@ def _back(like: torch.Tensor, *outs):
     return res[0] if len(res) == 1 else res
 
 
-def temporal_lift(edge_index, time, num_nodes: int, delta):
+def temporal_lift(edge_index, time, num_nodes: int, delta, n_own=None, id_offset: int = 0):
     dev = compute_device(edge_index, time)
     ei, t = _stage(dev, edge_index, time)
-    return _back(edge_index, _hip.temporal_lift(ei, t, num_nodes, delta))
+    return _back(edge_index, _hip.temporal_lift(ei, t, num_nodes, delta, n_own, id_offset))
 
 
 def linegraph_lift(edge_index, num_nodes: int):

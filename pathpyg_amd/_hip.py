@@ -141,9 +141,11 @@ def resolve_delta(time_dtype: torch.dtype, delta) -> tuple[int, int, float]:
     return DELTA_I64, int(d), 0.0
 
 
-def temporal_lift(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta) -> torch.Tensor:
+def temporal_lift(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, n_own: int | None = None,
+                  id_offset: int = 0) -> torch.Tensor:
     """Second-order event graph of a TIME-SORTED event list: all (i, j) with head(i) == tail(j) and
-    t_i < t_j <= t_i + delta, lexicographic, int64 [2, E2]."""
+    t_i < t_j <= t_i + delta, lexicographic, int64 [2, E2].  ``n_own`` / ``id_offset``: edge-range shard —
+    only the first ``n_own`` events are sources and ``id_offset`` is added to every id of the result."""
     ei = _edge_index(edge_index)
     dev = require_device(ei, time)
     if time.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
@@ -158,12 +160,12 @@ def temporal_lift(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, 
     L = lib()
     with torch.cuda.device(dev):
         ws = _workspace(L.pp_temporal_ws_bytes(m, num_nodes), dev)
-        check(L.pp_temporal_count(_p(ei), _p(time), _DTYPE_CODE[time.dtype], m, num_nodes, kind, di, df, _p(ws), ws.numel(), _stream()),
-              "pp_temporal_count")
+        check(L.pp_temporal_count(_p(ei), _p(time), _DTYPE_CODE[time.dtype], m, m if n_own is None else int(n_own), num_nodes, kind, di, df,
+                                  _p(ws), ws.numel(), _stream()), "pp_temporal_count")
         total, status = _result(ws)
         _bad_index(status, "lift_order_temporal")
         out = torch.empty((2, total), dtype=torch.int64, device=dev)
-        check(L.pp_temporal_fill(m, num_nodes, total, _p(out), _p(ws), ws.numel(), _stream()), "pp_temporal_fill")
+        check(L.pp_temporal_fill(m, num_nodes, total, int(id_offset), _p(out), _p(ws), ws.numel(), _stream()), "pp_temporal_fill")
     return out
 
 

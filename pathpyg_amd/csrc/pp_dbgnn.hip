@@ -463,47 +463,66 @@ __global__ __launch_bounds__(kBlock) void k_weight_grad(const float* __restrict_
             }
         }
     }
-    // partial[(wave_global * gridDim.y + blockIdx.y)][64][64]; C/D layout: row = (r&3) + 8*(r>>2) + 4*h, col = c
-    float* out = partial + ((wave_global * gridDim.y + blockIdx.y) << 12);
+    // the 4 waves of the workgroup fold their 64x64 tiles through LDS in wave order, then ONE partial tile per
+    // workgroup goes to HBM: partial[blockIdx.x * gridDim.y + blockIdx.y][64][64].
+    // C/D layout of the 32x32 MFMA: row = (r&3) + 8*(r>>2) + 4*h, col = c
+    __shared__ float s_tile[64 * 64];
+    __shared__ float s_bias[64];
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        if (wave_id() == w) {
 #pragma unroll
-    for (int ti = 0; ti < kWgTile; ++ti)
+            for (int ti = 0; ti < kWgTile; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < kWgTile; ++tj)
+                for (int tj = 0; tj < kWgTile; ++tj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h;
-                out[row * 64 + 32 * tj + c] = acc[ti][tj][r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int at = (32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + 32 * tj + c;
+                        s_tile[at] = (w == 0 ? 0.f : s_tile[at]) + acc[ti][tj][r];
+                    }
+#pragma unroll
+            for (int t = 0; t < kWgTile; ++t) {
+                const float v = bias_acc[t] + __shfl_xor(bias_acc[t], 32, kWave);   // both row parities of column c
+                if (h == 0) s_bias[32 * t + c] = (w == 0 ? 0.f : s_bias[32 * t + c]) + v;
             }
-    if (partial_bias && (blockIdx.y % k_blocks) == 0) {
-        // lanes c and c+32 hold the two row parities of the same output column
-        float* pb = partial_bias + (wave_global * ((M + 63) / 64) + blockIdx.y / k_blocks) * 64;
-#pragma unroll
-        for (int t = 0; t < kWgTile; ++t) {
-            float v = bias_acc[t] + __shfl_xor(bias_acc[t], 32, kWave);
-            if (h == 0) pb[32 * t + c] = v;
         }
+        __syncthreads();
     }
+    float* out = partial + (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) << 12);
+    for (int e = threadIdx.x; e < 64 * 64; e += kBlock) out[e] = s_tile[e];
+    if (partial_bias && (blockIdx.y % k_blocks) == 0 && threadIdx.x < 64)
+        partial_bias[((int64_t)blockIdx.x * ((M + 63) / 64) + blockIdx.y / k_blocks) * 64 + threadIdx.x] = s_bias[threadIdx.x];
 }
 
-// sums the per-wave partial tiles in wave order (fixed order => bitwise reproducible results)
+// Sums the per-workgroup partial tiles: 16 outputs x 16 interleaved slices of partials per workgroup, every slice
+// accumulated sequentially and the 16 slice sums folded in a fixed order => bitwise reproducible results.
+constexpr int kWgSlices = 16;
 __global__ __launch_bounds__(kBlock) void k_weight_grad_reduce(const float* __restrict__ partial, const float* __restrict__ partial_bias,
-                                                              int64_t n_waves, int M, int K, float* __restrict__ dW, float* __restrict__ db) {
+                                                              int64_t n_parts, int M, int K, float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float s_sum[kWgSlices][kBlock / kWgSlices];
     const int k_blocks = (K + 63) / 64, i_blocks = (M + 63) / 64;
     const int n_blocks = k_blocks * i_blocks;
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx < M * K) {
+    const int o = threadIdx.x % (kBlock / kWgSlices), g = threadIdx.x / (kBlock / kWgSlices);
+    const int idx = blockIdx.x * (kBlock / kWgSlices) + o;            // output element (weights first, then bias)
+    const int n_w = M * K;
+    float s = 0.f;
+    if (idx < n_w) {
         const int i = idx / K, j = idx - i * K;
         const int blk = (i / 64) * k_blocks + (j / 64);
         const float* p = partial + ((int64_t)blk << 12) + (i % 64) * 64 + (j % 64);
-        float s = 0.f;
-        for (int64_t w = 0; w < n_waves; ++w) s += p[(w * n_blocks) << 12];
-        dW[idx] = s;
+        for (int64_t w = g; w < n_parts; w += kWgSlices) s += p[(w * n_blocks) << 12];
+    } else if (db && idx < n_w + M) {
+        const int i = idx - n_w;
+        const float* p = partial_bias + (i / 64) * 64 + (i % 64);
+        for (int64_t w = g; w < n_parts; w += kWgSlices) s += p[w * i_blocks * 64];
     }
-    if (db && idx < M) {
-        const float* p = partial_bias + (idx / 64) * 64 + (idx % 64);
-        float s = 0.f;
-        for (int64_t w = 0; w < n_waves; ++w) s += p[w * i_blocks * 64];
-        db[idx] = s;
+    s_sum[g][o] = s;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < kWgSlices; ++q) t += s_sum[q][o];
+        if (idx < n_w) dW[idx] = t;
+        else if (db && idx < n_w + M) db[idx - n_w] = t;
     }
 }
 
@@ -521,8 +540,8 @@ extern "C" {
 
 size_t pp_weight_grad_ws_bytes(int64_t n_rows, int M, int K) {
     const int64_t blocks = (int64_t)((M + 63) / 64) * ((K + 63) / 64);
-    const int64_t waves = pp::weight_grad_waves(n_rows);
-    return pp::align_up((size_t)waves * blocks * 4096 * sizeof(float)) + pp::align_up((size_t)waves * ((M + 63) / 64) * 64 * sizeof(float));
+    const int64_t parts = pp::weight_grad_waves(n_rows) / pp::kWavesPerBlock;
+    return pp::align_up((size_t)parts * blocks * 4096 * sizeof(float)) + pp::align_up((size_t)parts * ((M + 63) / 64) * 64 * sizeof(float));
 }
 
 // dW[M,K] = dH[N,M]^T X[N,K], db[M] = column sums of dH (db may be NULL); fp32 on v_mfma_f32_32x32x2_f32
@@ -535,13 +554,14 @@ int pp_weight_grad_f32(const float* dH, const float* X, int64_t n_rows, int M, i
     const int64_t waves = pp::weight_grad_waves(n_rows);
     const int64_t rows_per_wave = pp::ceil_div(pp::ceil_div(n_rows > 0 ? n_rows : 1, waves), 2) * 2;
     float* partial = (float*)ws;
-    float* partial_bias = (float*)((char*)ws + pp::align_up((size_t)waves * i_blocks * k_blocks * 4096 * sizeof(float)));
+    const int64_t parts = waves / pp::kWavesPerBlock;
+    float* partial_bias = (float*)((char*)ws + pp::align_up((size_t)parts * i_blocks * k_blocks * 4096 * sizeof(float)));
     dim3 grid((unsigned)(waves / pp::kWavesPerBlock), (unsigned)(i_blocks * k_blocks));
     pp::k_weight_grad<<<grid, pp::kBlock, 0, st>>>(dH, X, n_rows, M, K, rows_per_wave, partial, db ? partial_bias : nullptr);
     PP_LAUNCH_CHECK();
-    const int outs = M * K > M ? M * K : M;
-    pp::k_weight_grad_reduce<<<(unsigned)pp::ceil_div(outs, pp::kBlock), pp::kBlock, 0, st>>>(partial, db ? partial_bias : nullptr, waves, M, K,
-                                                                                             dW, db);
+    const int outs = M * K + (db ? M : 0);
+    pp::k_weight_grad_reduce<<<(unsigned)pp::ceil_div(outs, pp::kBlock / pp::kWgSlices), pp::kBlock, 0, st>>>(
+        partial, db ? partial_bias : nullptr, parts, M, K, dW, db);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

@@ -88,13 +88,18 @@ struct Window<int64_t, 2> {
 
 template <typename TimeT, int kMode>
 __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __restrict__ head, const TimeT* __restrict__ time, int64_t m,
-                                                          int64_t num_nodes, int64_t delta_i, double delta_f,
+                                                          int64_t n_own, int64_t num_nodes, int64_t delta_i, double delta_f,
                                                           const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids_by_tail,
                                                           uint32_t* __restrict__ first_pos, int32_t* __restrict__ count,
                                                           int64_t* __restrict__ status) {
     using W = Window<TimeT, kMode>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
+    if (i >= n_own) {                 // halo event of an edge-range shard: a candidate, never a source
+        first_pos[i] = 0;
+        count[i] = 0;
+        return;
+    }
     const TimeT ti = time[i];
     // g_lo: first id with t > t_i.  Without timestamp ties this is i+1: probe, then gallop, then bisect.
     int64_t g_lo = i + 1;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void k_linegraph_count(const int64_t* __res
 template <bool kList>
 __global__ __launch_bounds__(kBlock) void k_expand(const int64_t* __restrict__ offset, const uint32_t* __restrict__ first_pos,
                                                   const uint32_t* __restrict__ list, int64_t n_src, int64_t total,
-                                                  int64_t* __restrict__ out) {
+                                                  int64_t id_offset, int64_t* __restrict__ out) {
     __shared__ int32_t s_rel[kExpandCap + 1];
     __shared__ int64_t s_range[2];
     const int64_t p0 = (int64_t)blockIdx.x * kExpandTile;
@@ -192,8 +197,8 @@ __global__ __launch_bounds__(kBlock) void k_expand(const int64_t* __restrict__ o
         }
         const int64_t r = p - offset[s];
         const uint32_t at = first_pos[s] + (uint32_t)r;
-        out[p] = s;
-        out[total + p] = kList ? (int64_t)list[at] : (int64_t)at;
+        out[p] = s + id_offset;
+        out[total + p] = (kList ? (int64_t)list[at] : (int64_t)at) + id_offset;
     }
 }
 
@@ -279,24 +284,24 @@ static LiftWs carve_lift(void* ws, int64_t n_src, int64_t num_nodes, bool tempor
 
 template <typename TimeT>
 static int launch_temporal_count(int delta_kind, unsigned grid, hipStream_t st, const int64_t* head, const TimeT* time, int64_t m,
-                                 int64_t n, int64_t di, double df, const LiftWs& w);
+                                 int64_t n_own, int64_t n, int64_t di, double df, const LiftWs& w);
 
 template <>
 int launch_temporal_count<int64_t>(int delta_kind, unsigned grid, hipStream_t st, const int64_t* head, const int64_t* time, int64_t m,
-                                   int64_t n, int64_t di, double df, const LiftWs& w) {
+                                   int64_t n_own, int64_t n, int64_t di, double df, const LiftWs& w) {
     if (delta_kind == PP_DELTA_I64)
-        k_temporal_count<int64_t, 0><<<grid, kBlock, 0, st>>>(head, time, m, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+        k_temporal_count<int64_t, 0><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
     else if (delta_kind == PP_DELTA_F32)
-        k_temporal_count<int64_t, 1><<<grid, kBlock, 0, st>>>(head, time, m, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+        k_temporal_count<int64_t, 1><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
     else
-        k_temporal_count<int64_t, 2><<<grid, kBlock, 0, st>>>(head, time, m, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+        k_temporal_count<int64_t, 2><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
 template <>
-int launch_temporal_count<double>(int, unsigned grid, hipStream_t st, const int64_t* head, const double* time, int64_t m, int64_t n,
-                                  int64_t di, double df, const LiftWs& w) {
-    k_temporal_count<double, 0><<<grid, kBlock, 0, st>>>(head, time, m, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+int launch_temporal_count<double>(int, unsigned grid, hipStream_t st, const int64_t* head, const double* time, int64_t m, int64_t n_own,
+                                  int64_t n, int64_t di, double df, const LiftWs& w) {
+    k_temporal_count<double, 0><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
@@ -310,10 +315,11 @@ extern "C" {
 // ---------------------------------------------------------------- temporal lift
 size_t pp_temporal_ws_bytes(int64_t m, int64_t num_nodes) { return carve_lift(nullptr, m, num_nodes, true).total_bytes; }
 
-int pp_temporal_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind,
-                      int64_t delta_i, double delta_f, void* ws, size_t ws_bytes, pp_stream_t stream) {
+int pp_temporal_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t n_own, int64_t num_nodes,
+                      int delta_kind, int64_t delta_i, double delta_f, void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(m >= 0 && num_nodes >= 0, PP_ERR_ARG, "pp_temporal_count: negative size");
+    if (n_own < 0 || n_own > m) n_own = m;
     PP_REQUIRE(m < (int64_t)0x7fffffff && num_nodes < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_temporal_count: m or num_nodes >= 2^31");
     PP_REQUIRE(time_dtype == PP_I64 || time_dtype == PP_F64, PP_ERR_ARG, "pp_temporal_count: time must be int64 or float64");
     PP_REQUIRE(delta_kind >= PP_DELTA_I64 && delta_kind <= PP_DELTA_F64, PP_ERR_ARG, "pp_temporal_count: bad delta kind");
@@ -334,20 +340,21 @@ int pp_temporal_count(const int64_t* edge_index, const void* time, int time_dtyp
     PP_LAUNCH_CHECK();
     // 2. per-event continuation window
     if (time_dtype == PP_I64)
-        rc = launch_temporal_count<int64_t>(delta_kind, grid, st, head, (const int64_t*)time, m, num_nodes, delta_i, delta_f, w);
+        rc = launch_temporal_count<int64_t>(delta_kind, grid, st, head, (const int64_t*)time, m, n_own, num_nodes, delta_i, delta_f, w);
     else
-        rc = launch_temporal_count<double>(delta_kind, grid, st, head, (const double*)time, m, num_nodes, delta_i, delta_f, w);
+        rc = launch_temporal_count<double>(delta_kind, grid, st, head, (const double*)time, m, n_own, num_nodes, delta_i, delta_f, w);
     if (rc != PP_OK) return rc;
     // 3. offsets + total
     return exclusive_scan<int32_t, int64_t>(w.count, m, w.offset, true, w.result, w.scratch, w.scratch_bytes, st);
 }
 
-int pp_temporal_fill(int64_t m, int64_t num_nodes, int64_t total, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream) {
+int pp_temporal_fill(int64_t m, int64_t num_nodes, int64_t total, int64_t id_offset, int64_t* out, void* ws, size_t ws_bytes,
+                     pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     LiftWs w = carve_lift(ws, m, num_nodes, true);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_temporal_fill: workspace too small");
     if (total <= 0) return PP_OK;
-    k_expand<true><<<(unsigned)ceil_div(total, kExpandTile), kBlock, 0, st>>>(w.offset, w.first_pos, w.ids, m, total, out);
+    k_expand<true><<<(unsigned)ceil_div(total, kExpandTile), kBlock, 0, st>>>(w.offset, w.first_pos, w.ids, m, total, id_offset, out);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
@@ -379,7 +386,7 @@ int pp_linegraph_fill(int64_t n_edges, int64_t num_nodes, int64_t total, int64_t
     LiftWs w = carve_lift(ws, n_edges, num_nodes, false);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_linegraph_fill: workspace too small");
     if (total <= 0) return PP_OK;
-    k_expand<false><<<(unsigned)ceil_div(total, kExpandTile), kBlock, 0, st>>>(w.offset, w.first_pos, nullptr, n_edges, total, out);
+    k_expand<false><<<(unsigned)ceil_div(total, kExpandTile), kBlock, 0, st>>>(w.offset, w.first_pos, nullptr, n_edges, total, 0, out);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

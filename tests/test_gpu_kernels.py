@@ -252,3 +252,17 @@ def test_graph_bookkeeping(hip):
     by_col = hip.argsort(cu(s[1]))
     assert torch.equal(by_col.cpu(), c["csc_perm"])
     assert torch.equal(hip.ptr_from_sorted(cu(s[1])[by_col], 1200).cpu(), c["col_ptr"])
+
+
+def test_temporal_lift_edge_range_shards_reassemble(hip):
+    """The multi-GPU decomposition on one GPU: lifting every edge-range shard (own events + forward halo,
+    ``n_own`` sources, ``id_offset``) and concatenating in shard order gives the whole result."""
+    from pathpyg_amd.distributed import event_ranges, halo_end
+    ei, t = _stream(11, 150_000, 700, 30_000)
+    full = hip.temporal_lift(cu(ei), cu(t), 700, 250)
+    for world in (2, 5):
+        parts = []
+        for lo, hi in event_ranges(ei.size(1), world):
+            end = halo_end(t, hi, 250)
+            parts.append(hip.temporal_lift(cu(ei[:, lo:end]), cu(t[lo:end]), 700, 250, n_own=hi - lo, id_offset=lo))
+        assert torch.equal(torch.cat(parts, dim=1), full)

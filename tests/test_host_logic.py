@@ -1,0 +1,165 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol of include/pathpyg_amd.h,
+host containers behave like the reference's, and compute entry points fail loudly without a GPU."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import pathpyg_amd as pp
+from pathpyg_amd import _hip, _lib
+
+NO_GPU = not torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    protos = _lib.declared_functions()
+    text = re.sub(r"/\*.*?\*/", " ", _lib.HEADER.read_text(), flags=re.S)
+    names_in_header = set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", text))
+    assert names_in_header == set(protos), "header parser missed a declaration"
+    assert len(protos) >= 40
+    handle = _lib.lib()
+    for name, (restype, argtypes) in protos.items():
+        fn = getattr(handle, name)
+        assert fn.restype is restype and list(fn.argtypes) == argtypes
+    assert handle.pp_version() == 100
+    assert isinstance(handle.pp_last_error(), bytes)
+    # size queries are pure host code: callable without a GPU
+    assert handle.pp_temporal_ws_bytes(1000, 10) > 0
+    assert handle.pp_sort_ws_bytes(4096, 4) >= 4096 * 8
+    assert handle.pp_weight_grad_ws_bytes(1000, 64, 64) >= 64 * 64 * 4
+    assert handle.pp_gcn_plan_ws_bytes(100, 10) > 0
+
+
+def test_library_is_a_plain_c_abi_without_torch():
+    # the .so must not link torch / c10: it is a C ABI over HIP only
+    import subprocess
+    out = subprocess.run(["ldd", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "libamdhip64" in out
+    assert "torch" not in out and "c10" not in out
+
+
+@pytest.mark.skipif(not NO_GPU, reason="checks the no-GPU failure mode")
+def test_compute_entry_points_fail_loudly_without_gpu():
+    ei = torch.tensor([[0, 1], [1, 2]])
+    with pytest.raises(RuntimeError, match="MI355X"):
+        pp.algorithms.lift_order_edge_index(ei, 3)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        pp.algorithms.aggregate_node_attributes(ei, torch.ones(3), "src")
+    with pytest.raises(RuntimeError, match="MI355X"):
+        pp.Graph.from_edge_list([("a", "b"), ("b", "c")])
+    with pytest.raises(RuntimeError, match="MI355X"):
+        pp.TemporalGraph.from_edge_list([("a", "b", 2), ("b", "c", 1)])
+    with pytest.raises(RuntimeError):
+        _hip.temporal_lift(ei, torch.tensor([1, 2]), 3, 1)
+    with pytest.raises(ValueError):                               # argument errors come first, like the reference
+        pp.algorithms.aggregate_node_attributes(ei, torch.ones(3), "unknown")
+
+
+def test_delta_resolution_follows_torch_promotion():
+    i64, f64 = torch.int64, torch.float64
+    assert _hip.resolve_delta(i64, 5) == (_hip.DELTA_I64, 5, 0.0)
+    kind, _, df = _hip.resolve_delta(i64, 0.1)
+    assert kind == _hip.DELTA_F32 and df == float(np.float32(0.1))           # python float -> float32 tensor
+    assert _hip.resolve_delta(i64, np.float64(0.1)) == (_hip.DELTA_F64, 0, 0.1)
+    assert _hip.resolve_delta(f64, 3) == (_hip.DELTA_F64, 0, 3.0)
+    assert _hip.resolve_delta(f64, 0.1)[2] == float(np.float32(0.1))          # float32-rounded, then widened
+    assert _hip.resolve_delta(f64, np.float64(0.1))[2] == 0.1
+    with pytest.raises(ValueError):
+        _hip.resolve_delta(i64, torch.tensor([1, 2]))
+
+
+def test_data_bag():
+    d = pp.Data(edge_index=torch.tensor([[0, 1, 1], [1, 2, 0]]), edge_weight=torch.ones(3), node_size=torch.zeros(4), num_nodes=4,
+                time=torch.tensor([3, 1, 2]))
+    assert d.num_nodes == 4 and d.num_edges == 3
+    assert "edge_weight" in d and "x" not in d and d.x is None and d.y is None
+    with pytest.raises(AttributeError):
+        d.not_there
+    assert set(d.keys()) == {"edge_index", "edge_weight", "node_size", "num_nodes", "time"}
+    assert d.is_edge_attr("edge_weight") and d.is_edge_attr("edge_index") and d.is_edge_attr("time")
+    assert d.is_node_attr("node_size") and not d.is_node_attr("edge_weight")
+    d["foo"] = 3
+    d.bar = torch.ones(2)
+    assert d.foo == 3 and d["bar"].tolist() == [1.0, 1.0]
+    d.foo = None
+    assert "foo" not in d
+    inferred = pp.Data(edge_index=torch.tensor([[0, 5], [1, 2]]))
+    assert inferred.num_nodes == 6
+    c = d.clone()
+    c.edge_weight[0] = 7
+    assert d.edge_weight[0] == 1
+
+
+def test_index_map_matches_reference_behaviour():
+    m = pp.IndexMap(["A", "C", "B"])
+    assert str(m) == "A -> 0\nC -> 1\nB -> 2\n"
+    assert m.to_idx("C") == 1 and m.to_id(2) == "B" and m.num_ids() == 3 and m.has_ids
+    assert m.to_ids([0, 2]).tolist() == ["A", "B"]
+    assert m.to_idxs([["A", "B"], ["B", "C"]]).tolist() == [[0, 2], [2, 1]]
+    m.add_id("D")
+    assert m.to_idx("D") == 3
+    m.add_ids(["F", "E"])
+    assert m.to_idx("E") == 5
+    with pytest.raises(ValueError):
+        m.add_id("A")
+    with pytest.raises(ValueError):
+        pp.IndexMap(["a", "a"])
+    h = pp.IndexMap([("A", "B"), ("A", "C"), ("B", "C")])
+    assert h.id_shape == (-1, 2) and h.to_id(1) == ("A", "C") and h.to_idx(("B", "C")) == 2
+    assert h.to_ids([[0], [2]]).shape == (2, 1, 2)
+    assert h.to_idxs([("A", "B"), ("B", "C")]).tolist() == [0, 2]
+    e = pp.IndexMap()
+    assert not e.has_ids and e.num_ids() == 0 and e.to_idx(7) == 7 and e.to_id(3) == 3
+    assert e.to_idxs([1, 0]).tolist() == [1, 0]
+    # lazy higher-order map = what reference multi_order_model.py:119 builds with a Python loop
+    lazy = pp.IndexMap.from_node_sequence(pp.IndexMap(list("abcd")), torch.tensor([[0, 1], [2, 3], [1, 1]]))
+    eager = pp.IndexMap([("a", "b"), ("c", "d"), ("b", "b")])
+    assert lazy.num_ids() == 3 and lazy.to_id(1) == eager.to_id(1) and lazy.to_idx(("b", "b")) == eager.to_idx(("b", "b"))
+    assert str(lazy) == str(eager)
+    assert pp.IndexMap.from_node_sequence(pp.IndexMap(), torch.tensor([[4, 5]])).to_id(0) == (4, 5)
+
+
+def test_path_data_layout_matches_oracle():
+    from oracle import model as om
+    walks = [[0, 2, 3], [1, 2, 4, 0], [3, 3]]
+    weights = [2.0, 1.0, 4.0]
+    p = pp.PathData()
+    p.append_walk(walks[0], weights[0])
+    p.append_walks(walks[1:], weights[1:])
+    ref = om.walks_to_path_tensors(walks, weights)
+    for key in ("edge_index", "node_sequence", "dag_weight", "dag_num_edges", "dag_num_nodes"):
+        assert torch.equal(p.data[key], ref[key]), key
+    assert p.num_paths == 3 and p.data.num_nodes == 9
+    assert p.get_walk(1) == (1, 2, 4, 0)
+    assert str(p) == "PathData with 3 paths with total weight 7.0"
+    named = pp.PathData(pp.IndexMap(list("ABCDE")))
+    named.append_walk(("A", "C", "D"), weight=2.0)
+    assert named.get_walk(0) == ("A", "C", "D") and named.map_node_seq([0, 2]) == ["A", "C"]
+
+
+def test_multi_order_model_shell():
+    m = pp.MultiOrderModel()
+    assert m.layers == {} and str(m) == "MultiOrderModel with max. order 0"
+    m.layers[5] = "x"
+    assert str(m) == "MultiOrderModel with max. order 5"
+    with pytest.raises(ValueError):
+        pp.MultiOrderModel().to_dbgnn_data(max_order=2)
+
+
+def test_dbgnn_module_state_dict_layout():
+    net = pp.nn.DBGNN(num_classes=3, num_features=(7, 9), hidden_dims=[16, 32, 8], p_dropout=0.4)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert shapes == {
+        "higher_order_layers.0.bias": (16,), "higher_order_layers.0.lin.weight": (16, 9),
+        "higher_order_layers.1.bias": (32,), "higher_order_layers.1.lin.weight": (32, 16),
+        "first_order_layers.0.bias": (16,), "first_order_layers.0.lin.weight": (16, 7),
+        "first_order_layers.1.bias": (32,), "first_order_layers.1.lin.weight": (32, 16),
+        "bipartite_layer.lin1.weight": (8, 32), "bipartite_layer.lin1.bias": (8,),
+        "bipartite_layer.lin2.weight": (8, 32), "bipartite_layer.lin2.bias": (8,),
+        "lin.weight": (3, 8), "lin.bias": (3,),
+    }
+    from oracle import dbgnn as od
+    net.load_state_dict(od.init_params(3, (7, 9), [16, 32, 8]))          # oracle parameter dict == state_dict layout
+    assert float(net.first_order_layers[0].bias.abs().sum()) == 0.0
