@@ -17,6 +17,8 @@
 // The dense X*W^T products stay plain library GEMMs (MFMA through rocBLAS) on the Python side.
 #include "pp_internal.h"
 
+#include <stdlib.h>
+
 namespace pp {
 
 // ------------------------------------------------------------------ plan construction
@@ -107,9 +109,17 @@ __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x)
 template <int kLanes>   // lanes per row, each lane owns one float4 of a column block of kLanes*4 columns
 __global__ __launch_bounds__(kBlock) void k_spmm_v4(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
                                                    int64_t n_rows, const float* __restrict__ X, int F, const float* __restrict__ self_coef,
-                                                   const float* __restrict__ S, const float* __restrict__ bias, int act, float* __restrict__ Y) {
+                                                   const float* __restrict__ S, const float* __restrict__ bias, int act, float* __restrict__ Y,
+                                                   int swizzle) {
     constexpr int kRowsPerBlock = kBlock / kLanes;
-    const int64_t r = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x / kLanes;
+    // XCD-aware row mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD one contiguous
+    // eighth of the rows so that neighbouring rows - which share source rows in De Bruijn graphs - share an L2.
+    int64_t bid = blockIdx.x;
+    if (swizzle) {
+        const int64_t per_xcd = (gridDim.x + 7) / 8;
+        bid = (bid % 8) * per_xcd + bid / 8;
+    }
+    const int64_t r = bid * kRowsPerBlock + threadIdx.x / kLanes;
     const int lane = threadIdx.x % kLanes;
     if (r >= n_rows) return;
     const int p0 = ptr[r], p1 = ptr[r + 1];
@@ -151,9 +161,15 @@ __global__ __launch_bounds__(kBlock) void k_spmm_v4(const int32_t* __restrict__ 
 template <int kLanes>   // scalar-column variant for feature widths that are not multiples of 4
 __global__ __launch_bounds__(kBlock) void k_spmm_s1(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
                                                    int64_t n_rows, const float* __restrict__ X, int F, const float* __restrict__ self_coef,
-                                                   const float* __restrict__ S, const float* __restrict__ bias, int act, float* __restrict__ Y) {
+                                                   const float* __restrict__ S, const float* __restrict__ bias, int act, float* __restrict__ Y,
+                                                   int swizzle) {
     constexpr int kRowsPerBlock = kBlock / kLanes;
-    const int64_t r = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x / kLanes;
+    int64_t bid = blockIdx.x;
+    if (swizzle) {
+        const int64_t per_xcd = (gridDim.x + 7) / 8;
+        bid = (bid % 8) * per_xcd + bid / 8;
+    }
+    const int64_t r = bid * kRowsPerBlock + threadIdx.x / kLanes;
     const int lane = threadIdx.x % kLanes;
     if (r >= n_rows) return;
     const int p0 = ptr[r], p1 = ptr[r + 1];
@@ -250,8 +266,10 @@ static int group_by(const int64_t* index, int64_t e, int64_t n_groups, PlanWs& w
 static int launch_spmm(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* X, int F, const float* self_coef,
                        const float* S, const float* bias, int act, float* Y, hipStream_t st) {
     if (n_rows == 0 || F == 0) return PP_OK;
+    static const int swizzle = getenv("PP_SPMM_SWIZZLE") ? atoi(getenv("PP_SPMM_SWIZZLE")) : 1;
 #define PP_SPMM_CASE(KERNEL, L)                                                                                         \
-    KERNEL<L><<<(unsigned)ceil_div(n_rows, kBlock / L), kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, Y)
+    KERNEL<L><<<(unsigned)(swizzle ? ceil_div(ceil_div(n_rows, kBlock / L), 8) * 8 : ceil_div(n_rows, kBlock / L)), kBlock, 0, st>>>(   \
+        ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, Y, swizzle)
     const bool vec = (F % 4 == 0) && (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)S | (uintptr_t)bias) % 16 == 0);
     if (vec) {
         const int q = F / 4;

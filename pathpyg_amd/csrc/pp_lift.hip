@@ -18,9 +18,8 @@
 //      the dtype torch promotes to (temporal.py:30,43).  Inside the id list of head(i) the ids of that
 //      range are again contiguous: two more binary searches give (first position, count).
 //   3. exclusive scan of the counts (pp_scan.hip) -> output offsets and E2.
-//   4. k_expand: one workgroup per 2048 output slots; the sources overlapping the tile are found with
-//      two binary searches, their offsets staged in LDS, every lane resolves (source, rank) for its slots
-//      from LDS and stores int64 pairs with fully coalesced 8-byte-per-lane writes into the
+//   4. k_expand: one WAVE per 512 output slots (no workgroup barriers); the sources overlapping the tile are
+//      staged in LDS, a running maximum maps slots to sources, every lane stores 16 bytes per row into the
 //      row-major [2,E2] result (lexicographic (i,j) order by construction).
 // HBM algorithmic bytes: 24*m (tail, head, time) + 16*E2 (result).
 #include "pp_internal.h"
@@ -28,10 +27,6 @@
 #include <type_traits>
 
 namespace pp {
-
-constexpr int kExpandItems = 8;
-constexpr int kExpandTile = kBlock * kExpandItems;   // output slots per workgroup
-constexpr int kExpandCap = kExpandTile + 1;          // sources whose offsets are staged in LDS
 
 // status word bits reported next to the size (see pp_*_count)
 constexpr int64_t kBadIndex = 1;
@@ -155,50 +150,212 @@ __global__ __launch_bounds__(kBlock) void k_linegraph_count(const int64_t* __res
 // ------------------------------------------------------------------ fill: load-balanced expansion
 // Source s owns output slots [offset[s], offset[s+1]).  Slot p of source s, rank r = p - offset[s]:
 //   out[0][p] = s ;  out[1][p] = kList ? list[first_pos[s] + r] : first_pos[s] + r
+//
+// The unit of work is ONE WAVE and 512 consecutive output slots; waves never wait for each other (no workgroup
+// barrier: measured 2x faster than a 2048-slot workgroup tile, whose five barriers serialised on the slowest wave).
+//   k_tile_sources  one thread per tile: the source owning the tile's first slot (binary search on `offset`).
+//   k_expand        the wave loads the boundaries + first positions of its <= 513 sources with 9 back-to-back
+//                   coalesced loads (a run-time loop here costs one HBM round trip per iteration), marks every
+//                   non-empty source at its first slot in an LDS slot array, spreads the marks with an inclusive
+//                   running maximum (8 slots per lane + wave shuffles), transposes (source, position) through LDS
+//                   so that each lane owns slot PAIRS, gathers the list entries and stores 16 bytes per lane and row.
+constexpr int kWaveTile = 512;                       // output slots per wave
+constexpr int kWaveCap = kWaveTile + 1;              // sources whose boundaries are staged (else: per-slot search)
+constexpr int kStageIters = (kWaveCap + 1 + kWave - 1) / kWave;
+
+__global__ __launch_bounds__(kBlock) void k_tile_sources(const int64_t* __restrict__ offset, int64_t n_src, int64_t total, int64_t n_tiles,
+                                                        int64_t* __restrict__ tile_src) {
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (b > n_tiles) return;
+    const int64_t p = b * kWaveTile;
+    tile_src[b] = p < total ? upper_bound_dev<int64_t, int64_t>(offset, 0, n_src + 1, p) - 1 : n_src - 1;
+}
+
+struct alignas(16) I64x2 { int64_t a, b; };
+struct alignas(16) I32x4 { int32_t x, y, z, w; };
+
 template <bool kList>
 __global__ __launch_bounds__(kBlock) void k_expand(const int64_t* __restrict__ offset, const uint32_t* __restrict__ first_pos,
                                                   const uint32_t* __restrict__ list, int64_t n_src, int64_t total,
-                                                  int64_t id_offset, int64_t* __restrict__ out) {
-    __shared__ int32_t s_rel[kExpandCap + 1];
-    __shared__ int64_t s_range[2];
-    const int64_t p0 = (int64_t)blockIdx.x * kExpandTile;
-    const int64_t p1 = p0 + kExpandTile < total ? p0 + kExpandTile : total;
-    if (threadIdx.x < 2) {
-        const int64_t p = threadIdx.x == 0 ? p0 : p1 - 1;
-        // last source whose first slot is <= p (it is non-empty and contains p)
-        s_range[threadIdx.x] = upper_bound_dev<int64_t, int64_t>(offset, 0, n_src + 1, p) - 1;
+                                                  int64_t id_offset, const int64_t* __restrict__ tile_src, int64_t* __restrict__ out) {
+    __shared__ int32_t s_rel_all[kWavesPerBlock][kWaveCap + 3];                                   // boundaries relative to the tile start
+    __shared__ __attribute__((aligned(16))) uint32_t s_pos_all[kWavesPerBlock][kWaveCap + 3];    // first positions, later slot -> position
+    __shared__ __attribute__((aligned(16))) int32_t s_src_all[kWavesPerBlock][kWaveTile];        // slot -> local source index
+    const int w = wave_id(), l = lane_id();
+    int32_t* s_rel = s_rel_all[w];
+    uint32_t* s_pos = s_pos_all[w];
+    int32_t* s_src = s_src_all[w];
+    // tiles are taken from the END of the output first: the stretches of empty sources (slow path below) sit at the
+    // end of a temporal stream, and starting them first keeps them off the kernel's tail
+    const int64_t tile = ((int64_t)gridDim.x - 1 - blockIdx.x) * kWavesPerBlock + w;
+    const int64_t p0 = tile * kWaveTile;
+    if (p0 >= total) return;
+    const int64_t p1 = p0 + kWaveTile < total ? p0 + kWaveTile : total;
+    int64_t s_first, s_beyond;          // boundaries s_first .. s_beyond + 1 bracket every slot of the tile
+    if (tile_src) {
+        s_first = tile_src[tile];
+        s_beyond = tile_src[tile + 1];
+    } else {
+        s_first = upper_bound_dev<int64_t, int64_t>(offset, 0, n_src + 1, p0) - 1;
+        s_beyond = upper_bound_dev<int64_t, int64_t>(offset, s_first, n_src + 1, p1 - 1) - 1;
     }
-    __syncthreads();
-    const int64_t s_first = s_range[0];
-    const int64_t n_in_tile = s_range[1] - s_first + 1;
-    const bool staged = n_in_tile <= kExpandCap;
+    const bool staged = (s_beyond - s_first + 1) <= kWaveCap;       // else: a sea of empty sources, resolve per slot
+    int64_t src[8];
+    uint32_t at2[8];
     if (staged) {
-        for (int64_t k = threadIdx.x; k <= n_in_tile; k += kBlock) {       // n_in_tile+1 boundaries
-            int64_t rel = offset[s_first + k] - p0;
-            s_rel[k] = rel < -1 ? -1 : (rel > kExpandTile ? kExpandTile + 1 : (int32_t)rel);
+        const int n_bound = (int)(s_beyond - s_first + 1);
+        const int64_t rel0 = offset[s_first] - p0;          // <= 0, exact (the first source may start before the tile)
+        int64_t g_off[kStageIters];
+        uint32_t g_pos[kStageIters];
+#pragma unroll
+        for (int it = 0; it < kStageIters; ++it) {
+            const int k = it * kWave + l;
+            g_off[it] = k <= n_bound ? offset[s_first + k] : 0;
+            g_pos[it] = k < n_bound ? first_pos[s_first + k] : 0u;
+        }
+#pragma unroll
+        for (int it = 0; it < kStageIters; ++it) {
+            const int k = it * kWave + l;
+            if (k <= n_bound) {
+                const int64_t rel = g_off[it] - p0;
+                s_rel[k] = rel < 0 ? -1 : (rel > kWaveTile ? kWaveTile + 1 : (int32_t)rel);
+                s_pos[k] = g_pos[it];
+            }
+        }
+        *(I32x4*)(s_src + 8 * l) = I32x4{0, 0, 0, 0};
+        *(I32x4*)(s_src + 8 * l + 4) = I32x4{0, 0, 0, 0};
+        __builtin_amdgcn_wave_barrier();
+        // every non-empty source that starts inside the tile marks its first slot with its index ...
+#pragma unroll
+        for (int it = 0; it < kStageIters; ++it) {
+            const int k = it * kWave + l;
+            if (k >= 1 && k < n_bound) {
+                const int rel = s_rel[k];
+                if (rel < kWaveTile && s_rel[k + 1] > rel) s_src[rel] = k;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ... and an inclusive running maximum spreads it over the source's slots (lane l: slots 8l .. 8l+7)
+        const I32x4 lo4 = *(const I32x4*)(s_src + 8 * l), hi4 = *(const I32x4*)(s_src + 8 * l + 4);
+        int kk[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+        for (int j = 1; j < 8; ++j) kk[j] = kk[j] > kk[j - 1] ? kk[j] : kk[j - 1];
+        int upto = kk[7];
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int o = __shfl_up(upto, d, kWave);
+            if (l >= d) upto = o > upto ? o : upto;
+        }
+        int before = __shfl_up(upto, 1, kWave);
+        if (l == 0) before = 0;
+        uint32_t at[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kk[j] > before ? kk[j] : before;
+            const int q = 8 * l + j;
+            kk[j] = k;
+            at[j] = s_pos[k] + (uint32_t)(k == 0 ? (int64_t)q - rel0 : (int64_t)(q - s_rel[k]));
+        }
+        __builtin_amdgcn_wave_barrier();                   // all reads of s_pos done: reuse it as slot -> position
+        *(I32x4*)(s_src + 8 * l) = I32x4{kk[0], kk[1], kk[2], kk[3]};
+        *(I32x4*)(s_src + 8 * l + 4) = I32x4{kk[4], kk[5], kk[6], kk[7]};
+        *(I32x4*)(s_pos + 8 * l) = I32x4{(int)at[0], (int)at[1], (int)at[2], (int)at[3]};
+        *(I32x4*)(s_pos + 8 * l + 4) = I32x4{(int)at[4], (int)at[5], (int)at[6], (int)at[7]};
+        __builtin_amdgcn_wave_barrier();
+        // transposed read: lane l owns slot pairs (2u, 2u+1), u = j * 64 + l
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = 2 * (u * kWave + l);
+            const int2 k2 = *(const int2*)(s_src + q);
+            const uint2 a2 = *(const uint2*)(s_pos + q);
+            src[2 * u] = s_first + k2.x;
+            src[2 * u + 1] = s_first + k2.y;
+            at2[2 * u] = a2.x;
+            at2[2 * u + 1] = a2.y;
+        }
+    } else {
+        // More than 513 sources for 512 slots: a stretch of (mostly) empty sources, e.g. the end of a stream whose
+        // events have no continuation left.  Same marking + running maximum, but the boundaries are streamed
+        // through registers (4 independent coalesced loads per step) instead of being staged in LDS, and the two
+        // per-slot lookups go to global memory.
+        const int64_t n_bound = s_beyond - s_first + 1;
+        *(I32x4*)(s_src + 8 * l) = I32x4{0, 0, 0, 0};
+        *(I32x4*)(s_src + 8 * l + 4) = I32x4{0, 0, 0, 0};
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t base = 1; base < n_bound; base += 4 * kWave) {
+            int64_t o[4], o1[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t k = base + c * kWave + l;
+                o[c] = k < n_bound ? offset[s_first + k] : 0;
+                o1[c] = k < n_bound ? offset[s_first + k + 1] : 0;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t k = base + c * kWave + l;
+                const int64_t rel = o[c] - p0;
+                if (k < n_bound && o1[c] > o[c] && rel < kWaveTile) s_src[rel] = (int32_t)k;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const I32x4 lo4 = *(const I32x4*)(s_src + 8 * l), hi4 = *(const I32x4*)(s_src + 8 * l + 4);
+        int kk[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+        for (int j = 1; j < 8; ++j) kk[j] = kk[j] > kk[j - 1] ? kk[j] : kk[j - 1];
+        int upto = kk[7];
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int o = __shfl_up(upto, d, kWave);
+            if (l >= d) upto = o > upto ? o : upto;
+        }
+        int before = __shfl_up(upto, 1, kWave);
+        if (l == 0) before = 0;
+        uint32_t at[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kk[j] > before ? kk[j] : before;
+            const int64_t p = p0 + 8 * l + j;
+            kk[j] = k;
+            at[j] = p < p1 ? first_pos[s_first + k] + (uint32_t)(p - offset[s_first + k]) : 0u;
+        }
+        *(I32x4*)(s_src + 8 * l) = I32x4{kk[0], kk[1], kk[2], kk[3]};
+        *(I32x4*)(s_src + 8 * l + 4) = I32x4{kk[4], kk[5], kk[6], kk[7]};
+        *(I32x4*)(s_pos + 8 * l) = I32x4{(int)at[0], (int)at[1], (int)at[2], (int)at[3]};
+        *(I32x4*)(s_pos + 8 * l + 4) = I32x4{(int)at[4], (int)at[5], (int)at[6], (int)at[7]};
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = 2 * (u * kWave + l);
+            const int2 k2 = *(const int2*)(s_src + q);
+            const uint2 a2 = *(const uint2*)(s_pos + q);
+            src[2 * u] = s_first + k2.x;
+            src[2 * u + 1] = s_first + k2.y;
+            at2[2 * u] = a2.x;
+            at2[2 * u + 1] = a2.y;
         }
     }
-    __syncthreads();
+    int64_t dst[8];
 #pragma unroll
-    for (int k = 0; k < kExpandItems; ++k) {
-        const int q = k * kBlock + threadIdx.x;
-        const int64_t p = p0 + q;
-        if (p >= p1) break;
-        int64_t s;
-        if (staged) {
-            int lo = 0, hi = (int)n_in_tile;          // last boundary index with s_rel <= q
-            while (lo < hi) {
-                int mid = lo + ((hi - lo) >> 1);
-                if (s_rel[mid] > q) hi = mid; else lo = mid + 1;
+    for (int j = 0; j < 8; ++j) {
+        const int64_t p = p0 + 2 * ((j >> 1) * kWave + l) + (j & 1);
+        dst[j] = (kList ? (p < p1 ? (int64_t)list[at2[j]] : 0) : (int64_t)at2[j]) + id_offset;
+    }
+    const bool row1_aligned = (total & 1) == 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t p = p0 + 2 * (u * kWave + l);
+        if (p + 1 < p1) {
+            *(I64x2*)(out + p) = I64x2{src[2 * u] + id_offset, src[2 * u + 1] + id_offset};
+            if (row1_aligned) {
+                *(I64x2*)(out + total + p) = I64x2{dst[2 * u], dst[2 * u + 1]};
+            } else {
+                out[total + p] = dst[2 * u];
+                out[total + p + 1] = dst[2 * u + 1];
             }
-            s = s_first + lo - 1;
-        } else {
-            s = upper_bound_dev<int64_t, int64_t>(offset, s_first, s_first + n_in_tile, p) - 1;
+        } else if (p < p1) {
+            out[p] = src[2 * u] + id_offset;
+            out[total + p] = dst[2 * u];
         }
-        const int64_t r = p - offset[s];
-        const uint32_t at = first_pos[s] + (uint32_t)r;
-        out[p] = s + id_offset;
-        out[total + p] = (kList ? (int64_t)list[at] : (int64_t)at) + id_offset;
     }
 }
 
@@ -258,6 +415,8 @@ struct LiftWs {
     uint32_t* ids;          // temporal: event ids grouped by tail [n_src]
     uint32_t* keys;         // temporal: tail keys [n_src];  line graph: outdeg (as int32) [num_nodes]
     uint32_t* sorted_keys;  // temporal only [n_src]
+    int64_t* tile_src;      // first source of every 512-slot output tile (k_tile_sources) [tile_cap + 1]
+    int64_t tile_cap;
     void* scratch;          // sort / scan workspace
     size_t scratch_bytes;
     size_t total_bytes;
@@ -274,12 +433,31 @@ static LiftWs carve_lift(void* ws, int64_t n_src, int64_t num_nodes, bool tempor
     w.ids = temporal ? a.take<uint32_t>(n_src) : nullptr;
     w.keys = a.take<uint32_t>(temporal ? n_src : num_nodes);
     w.sorted_keys = temporal ? a.take<uint32_t>(n_src) : nullptr;
+    w.tile_cap = n_src / 16 > 65536 ? n_src / 16 : 65536;       // covers results up to 32x the number of sources
+    w.tile_src = a.take<int64_t>(w.tile_cap + 1);
     size_t sb = scan_ws_bytes(n_src > num_nodes ? n_src : num_nodes);
     if (temporal) { size_t s2 = sort_ws_bytes(n_src, 4); sb = s2 > sb ? s2 : sb; }
     w.scratch_bytes = sb;
     w.scratch = a.take<char>((int64_t)sb);
     w.total_bytes = a.used;
     return w;
+}
+
+// the per-tile start sources are precomputed when the result is at most 32x the source count; beyond that every
+// wave searches for its own start (amortised by the amount of output per source)
+template <bool kList>
+static int launch_expand(const LiftWs& w, int64_t n_src, int64_t total, int64_t id_offset, int64_t* out, hipStream_t st) {
+    const int64_t n_tiles = ceil_div(total, kWaveTile);
+    int64_t* tile_src = nullptr;
+    if (n_tiles <= w.tile_cap) {
+        tile_src = w.tile_src;
+        k_tile_sources<<<(unsigned)ceil_div(n_tiles + 1, kBlock), kBlock, 0, st>>>(w.offset, n_src, total, n_tiles, tile_src);
+        PP_LAUNCH_CHECK();
+    }
+    k_expand<kList><<<(unsigned)ceil_div(n_tiles, kWavesPerBlock), kBlock, 0, st>>>(w.offset, w.first_pos, kList ? w.ids : nullptr, n_src, total,
+                                                                                       id_offset, tile_src, out);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
 }
 
 template <typename TimeT>
@@ -354,9 +532,7 @@ int pp_temporal_fill(int64_t m, int64_t num_nodes, int64_t total, int64_t id_off
     LiftWs w = carve_lift(ws, m, num_nodes, true);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_temporal_fill: workspace too small");
     if (total <= 0) return PP_OK;
-    k_expand<true><<<(unsigned)ceil_div(total, kExpandTile), kBlock, 0, st>>>(w.offset, w.first_pos, w.ids, m, total, id_offset, out);
-    PP_LAUNCH_CHECK();
-    return PP_OK;
+    return launch_expand<true>(w, m, total, id_offset, out, st);
 }
 
 // ---------------------------------------------------------------- line-graph lift
@@ -386,9 +562,7 @@ int pp_linegraph_fill(int64_t n_edges, int64_t num_nodes, int64_t total, int64_t
     LiftWs w = carve_lift(ws, n_edges, num_nodes, false);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_linegraph_fill: workspace too small");
     if (total <= 0) return PP_OK;
-    k_expand<false><<<(unsigned)ceil_div(total, kExpandTile), kBlock, 0, st>>>(w.offset, w.first_pos, nullptr, n_edges, total, 0, out);
-    PP_LAUNCH_CHECK();
-    return PP_OK;
+    return launch_expand<false>(w, n_edges, total, 0, out, st);
 }
 
 // {total, status} written by the last *_count on this workspace (two int64 at the start of the workspace)
