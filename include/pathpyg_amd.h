@@ -109,6 +109,11 @@ int pp_edge_attr(const int64_t* edge_index, int64_t n_edges, const void* attr, i
 int pp_extend_node_sequence(const int64_t* edge_index, int64_t n_edges, const int64_t* rows, int64_t n_rows, int k, int64_t* out,
                             int64_t* status, pp_stream_t stream);
 
+/* out[i,:k] = rows[idx[i],:], out[i,k] = suffix[i]: the order-(k+1) node sequence of a node whose first k entries are the
+ * order-k node idx[i] (multi_order_model.py:114 applied to DISTINCT nodes only, so instance sequences are never materialised) */
+int pp_gather_concat(const int64_t* rows, int64_t n_rows, int k, const int64_t* idx, const int64_t* suffix, int64_t n, int64_t* out,
+                     int64_t* status, pp_stream_t stream);
+
 /* ------------------------------------------------------------------ De Bruijn aggregation (pp_aggregate.hip) */
 
 /* torch.unique(node_sequence, dim=0, return_inverse=True), src/pathpyG/algorithms/lift_order.py:133.
@@ -128,6 +133,10 @@ int pp_coalesce_count(const int64_t* edge_index, int64_t n_edges, const int64_t*
                       size_t ws_bytes, pp_stream_t stream);
 int pp_coalesce_fill(const void* weight, int dtype, int reduce, int64_t n_edges, int64_t n_out, int64_t num_nodes, int64_t* out_index,
                      void* out_weight, void* ws, size_t ws_bytes, pp_stream_t stream);
+/* inverse[n_edges] = position of every input edge's merged edge (call between _count and the end of the workspace's life).
+ * For a first-order event list this equals the inverse_idx of torch.unique over the (src,dst) rows, lift_order.py:133, i.e.
+ * layer 2's node ids come for free from layer 1's coalesce. */
+int pp_coalesce_inverse(int64_t n_edges, int64_t* inverse, void* ws, size_t ws_bytes, pp_stream_t stream);
 const int64_t* pp_aggregate_result_ptr(void* ws);
 
 /* Graph.__init__ helpers, src/pathpyG/core/graph.py:103-115 (EdgeIndex.sort_by("row"), get_csr, get_csc) */

@@ -64,16 +64,22 @@ def extend_node_sequence(edge_index, node_sequence):
     return _back(edge_index, _hip.extend_node_sequence(ei, ns))
 
 
+def gather_concat(rows, idx, suffix):
+    dev = compute_device(rows, idx, suffix)
+    r, i, sfx = _stage(dev, rows, idx, suffix)
+    return _back(rows, _hip.gather_concat(r, i, sfx))
+
+
 def unique_rows(rows, value_range=None):
     dev = compute_device(rows)
     (r,) = _stage(dev, rows)
     return _back(rows, *_hip.unique_rows(r, value_range))
 
 
-def coalesce(edge_index, weight, num_nodes: int, reduce: str = "sum", remap=None):
+def coalesce(edge_index, weight, num_nodes: int, reduce: str = "sum", remap=None, want_inverse: bool = False):
     dev = compute_device(edge_index, weight, remap)
     ei, w, rm = _stage(dev, edge_index, weight, remap)
-    return _back(edge_index, *_hip.coalesce(ei, w, num_nodes, reduce, rm))
+    return _back(edge_index, *_hip.coalesce(ei, w, num_nodes, reduce, rm, want_inverse))
 
 
 def minmax(a):

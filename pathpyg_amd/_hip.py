@@ -218,6 +218,21 @@ def extend_node_sequence(edge_index: torch.Tensor, node_sequence: torch.Tensor) 
     return out
 
 
+def gather_concat(rows: torch.Tensor, idx: torch.Tensor, suffix: torch.Tensor) -> torch.Tensor:
+    """``cat([rows[idx], suffix[:, None]], 1)`` for int64 ``rows [R, k]`` -> ``[n, k+1]``."""
+    dev = require_device(rows, idx, suffix)
+    rows = rows.to(torch.int64).contiguous()
+    idx = idx.to(torch.int64).contiguous()
+    suffix = suffix.to(torch.int64).contiguous()
+    n, k = idx.numel(), rows.size(1)
+    with torch.cuda.device(dev):
+        out = torch.empty((n, k + 1), dtype=torch.int64, device=dev)
+        status = torch.empty(1, dtype=torch.int64, device=dev)
+        check(lib().pp_gather_concat(_p(rows), rows.size(0), k, _p(idx), _p(suffix), n, _p(out), _p(status), _stream()), "pp_gather_concat")
+        _bad_index(int(status.item()), "node sequence gather")
+    return out
+
+
 # ------------------------------------------------------------------ aggregation
 def unique_rows(rows: torch.Tensor, value_range: tuple[int, int] | None = None):
     """``torch.unique(rows, dim=0, return_inverse=True)`` for int64 ``[M, k]`` rows."""
@@ -239,8 +254,9 @@ def unique_rows(rows: torch.Tensor, value_range: tuple[int, int] | None = None):
 
 
 def coalesce(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: int, reduce: str = "sum",
-             remap: torch.Tensor | None = None):
-    """PyG ``coalesce`` of ``remap[edge_index]`` (or ``edge_index``): (row, col)-sorted distinct edges + reduced weights."""
+             remap: torch.Tensor | None = None, want_inverse: bool = False):
+    """PyG ``coalesce`` of ``remap[edge_index]`` (or ``edge_index``): (row, col)-sorted distinct edges + reduced weights.
+    ``want_inverse`` additionally returns, per input edge, the index of the merged edge it went into."""
     if reduce not in _REDUCE:
         raise ValueError(f"unknown reduce {reduce}")
     ei = _edge_index(edge_index)
@@ -265,6 +281,10 @@ def coalesce(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: i
         out_weight = None if weight is None else torch.empty(n_out, dtype=weight.dtype, device=dev)
         check(L.pp_coalesce_fill(_p(weight), 2 if weight is None else _DTYPE_CODE[weight.dtype], _REDUCE[reduce], e, n_out, num_nodes,
                                  _p(out_index), _p(out_weight), _p(ws), ws.numel(), _stream()), "pp_coalesce_fill")
+        if want_inverse:
+            inverse = torch.empty(e, dtype=torch.int64, device=dev)
+            check(L.pp_coalesce_inverse(e, _p(inverse), _p(ws), ws.numel(), _stream()), "pp_coalesce_inverse")
+            return out_index, out_weight, inverse
     return out_index, out_weight
 
 

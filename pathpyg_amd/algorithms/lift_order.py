@@ -58,13 +58,21 @@ def aggregate_edge_index(
     if edge_weight is None:
         edge_weight = torch.ones(edge_index.size(1), device=edge_index.device)
     unique_nodes, inverse_idx = _dispatch.unique_rows(node_sequence)
+    return _aggregate_with_known_nodes(edge_index, node_sequence.size(1), node_sequence, unique_nodes, inverse_idx, edge_weight, aggr)
+
+
+def _aggregate_with_known_nodes(edge_index, order, node_sequence, unique_nodes, inverse_idx, edge_weight, aggr="sum",
+                                want_inverse: bool = False):
+    """Second half of :func:`aggregate_edge_index` for callers that already know the distinct node rows and the
+    row -> node map (``MultiOrderModel`` derives them from the previous layer instead of re-sorting the rows)."""
     num_nodes = unique_nodes.size(0)
-    if node_sequence.size(1) == 1:
+    if order == 1:
         # first order: the entries of the node sequence already are the node ids (reference :135-136)
         remap = _dispatch.plain(node_sequence).reshape(-1)
     else:
         remap = inverse_idx
-    merged_index, merged_weight = _dispatch.coalesce(edge_index, edge_weight, num_nodes, aggr, remap=remap)
+    merged = _dispatch.coalesce(edge_index, edge_weight, num_nodes, aggr, remap=remap, want_inverse=want_inverse)
+    merged_index, merged_weight = merged[0], merged[1]
     data = Data(
         edge_index=merged_index,
         num_nodes=num_nodes,
@@ -72,4 +80,5 @@ def aggregate_edge_index(
         edge_weight=merged_weight,
         inverse_idx=inverse_idx,
     )
-    return Graph(data, _row_sorted=True)      # coalesce output is (row, col)-sorted: skip graph.py:103's re-sort
+    g = Graph(data, _row_sorted=True)         # coalesce output is (row, col)-sorted: skip graph.py:103's re-sort
+    return (g, merged[2]) if want_inverse else g

@@ -80,32 +80,38 @@ class MultiOrderModel:
     ) -> "MultiOrderModel":
         """De Bruijn layers of the time-respecting paths of ``g`` with waiting time ``delta``
         (reference multi_order_model.py:124-192).  ``cached=False`` keeps only the top layer;
-        ``event_graph`` reuses a precomputed ``lift_order_temporal(g, delta)``."""
+        ``event_graph`` reuses a precomputed ``lift_order_temporal(g, delta)``.
+
+        Same layers as the reference, computed without ever materialising the per-instance node sequences
+        (``[E_k, k+1]`` tensors): see :class:`_LiftChain`."""
         m = MultiOrderModel()
         data = g.data if g.data.is_sorted_by_time() else g.data.sort_by_time()
         edge_index = data.edge_index
-        node_sequence = torch.arange(data.num_nodes, device=edge_index.device).unsqueeze(1)
+        n = int(data.num_nodes)
+        dev = edge_index.device
         if weight in data:
             edge_weight = data[weight]
         else:
-            edge_weight = torch.ones(edge_index.size(1), device=edge_index.device)
+            edge_weight = torch.ones(edge_index.size(1), device=dev)
+        first_order = torch.arange(n, device=dev).unsqueeze(1)
+        chain = _LiftChain.first_order(edge_index, first_order, edge_weight, identity_nodes=True, num_first_order=n,
+                                       want_pairs=max_order > 1)
         if cached or max_order == 1:
-            m.layers[1] = aggregate_edge_index(edge_index=edge_index, node_sequence=node_sequence, edge_weight=edge_weight)
+            m.layers[1] = chain.graph
             m.layers[1].mapping = g.mapping
-
         if max_order > 1:
-            node_sequence = _dispatch.extend_node_sequence(edge_index, node_sequence)      # [m, 2]: (src, dst) per event
-            edge_index = lift_order_temporal(g, delta) if event_graph is None else event_graph
-            edge_weight = aggregate_node_attributes(edge_index, edge_weight, "src")
+            ho_index = lift_order_temporal(g, delta) if event_graph is None else event_graph
+            chain = chain.to_second_order(edge_index, ho_index, aggregate_node_attributes(ho_index, edge_weight, "src"),
+                                          save=cached or max_order == 2)
             if cached or max_order == 2:
-                m.layers[2] = aggregate_edge_index(edge_index=edge_index, node_sequence=node_sequence, edge_weight=edge_weight)
-                m.layers[2].mapping = IndexMap.from_node_sequence(g.mapping, m.layers[2].data.node_sequence)
+                m.layers[2] = chain.graph
+                m.layers[2].mapping = IndexMap.from_node_sequence(g.mapping, chain.graph.data.node_sequence)
             for k in range(3, max_order + 1):
                 keep = cached or k == max_order
-                edge_index, node_sequence, edge_weight, gk = MultiOrderModel.iterate_lift_order(
-                    edge_index=edge_index, node_sequence=node_sequence, mapping=g.mapping, edge_weight=edge_weight, aggr="src", save=keep)
+                chain = chain.lift("src", save=keep)
                 if keep:
-                    m.layers[k] = gk
+                    m.layers[k] = chain.graph
+                    m.layers[k].mapping = IndexMap.from_node_sequence(g.mapping, chain.graph.data.node_sequence)
         return m
 
     @staticmethod
@@ -122,15 +128,16 @@ class MultiOrderModel:
             outdeg = _dispatch_degree(edge_index[0], node_sequence.size(0))
             edge_weight = edge_weight / aggregate_node_attributes(edge_index, outdeg, "src")
             aggr = "mul"
-
-        m.layers[1] = aggregate_edge_index(edge_index=edge_index, node_sequence=node_sequence, edge_weight=edge_weight)
+        chain = _LiftChain.first_order(edge_index, node_sequence, edge_weight, identity_nodes=False, num_first_order=None,
+                                       want_pairs=False)
+        m.layers[1] = chain.graph
         m.layers[1].mapping = path_data.mapping
         for k in range(2, max_order + 1):
             keep = cached or k == max_order
-            edge_index, node_sequence, edge_weight, gk = MultiOrderModel.iterate_lift_order(
-                edge_index=edge_index, node_sequence=node_sequence, mapping=m.layers[1].mapping, edge_weight=edge_weight, aggr=aggr, save=keep)
+            chain = chain.lift(aggr, save=keep)
             if keep:
-                m.layers[k] = gk
+                m.layers[k] = chain.graph
+                m.layers[k].mapping = IndexMap.from_node_sequence(m.layers[1].mapping, chain.graph.data.node_sequence)
         return m
 
     def to_dbgnn_data(self, max_order: int = 2, mapping: str = "last", x: torch.Tensor | None = None,
@@ -162,6 +169,64 @@ class MultiOrderModel:
             bipartite_edge_index=generate_bipartite_edge_index(g, g_ho, mapping=mapping, device=dev),
             y=g.data.y,
         )
+
+
+class _LiftChain:
+    """State of the order-k instance graph while climbing orders, WITHOUT per-instance node sequences.
+
+    The reference extends an ``[instances, k]`` node-sequence tensor at every order and runs ``torch.unique(dim=0)``
+    on it (multi_order_model.py:114, lift_order.py:133).  The same node numbering follows from two vectors per
+    order: ``inv[i]`` = De Bruijn node of instance i (its lexicographic rank) and ``last[i]`` = its last first-order
+    node.  An order-(k+1) instance is an edge (a -> b) of the order-k instance graph; its node sequence is
+    ``seq(a) ++ last[b]``, so its lexicographic rank is the rank of the PAIR ``(inv[a], last[b])`` — a 2-column unique
+    instead of a (k+1)-column one — and the distinct sequences are ``unique_k[first] ++ second`` for the distinct pairs.
+    """
+
+    def __init__(self, index, inv, last, unique_nodes, weight, graph, pair_id=None):
+        self.index = index              # [2, E_k] edges between order-k instances (source-sorted)
+        self.inv = inv                  # [M_k] instance -> De Bruijn node id
+        self.last = last                # [M_k] last first-order node of every instance
+        self.unique_nodes = unique_nodes  # [U_k, k]
+        self.weight = weight            # [E_k] or None
+        self.graph = graph              # aggregated layer k (or None when not saved)
+        self.pair_id = pair_id          # first order only: id of each edge's distinct (src, dst) pair
+
+    @staticmethod
+    def first_order(edge_index, node_sequence, edge_weight, identity_nodes: bool, num_first_order, want_pairs: bool):
+        from ..algorithms.lift_order import _aggregate_with_known_nodes
+        if identity_nodes:       # temporal graphs: node_sequence = arange(N): every node distinct, already ordered
+            unique_nodes = node_sequence
+            inv = torch.arange(num_first_order, device=edge_index.device)
+        else:
+            unique_nodes, inv = _dispatch.unique_rows(node_sequence)
+        out = _aggregate_with_known_nodes(edge_index, 1, node_sequence, unique_nodes, inv, edge_weight, "sum", want_inverse=want_pairs)
+        graph, pair_id = out if want_pairs else (out, None)
+        return _LiftChain(edge_index, inv, _dispatch.plain(node_sequence).reshape(-1), unique_nodes, edge_weight, graph, pair_id)
+
+    def to_second_order(self, event_index, ho_index, ho_weight, save: bool):
+        """Temporal special case: the order-2 instances are the events themselves, their distinct (src, dst) pairs are
+        layer 1's merged edges (already sorted), and ``pair_id`` from layer 1's coalesce is their inverse map."""
+        from ..algorithms.lift_order import _aggregate_with_known_nodes
+        unique_nodes = self.graph.data.edge_index.t().contiguous()
+        inv = self.pair_id
+        graph = _aggregate_with_known_nodes(ho_index, 2, None, unique_nodes, inv, ho_weight, "sum") if save else None
+        return _LiftChain(ho_index, inv, _dispatch.plain(event_index)[1], unique_nodes, ho_weight, graph)
+
+    def lift(self, aggr: str, save: bool):
+        from ..algorithms.lift_order import _aggregate_with_known_nodes
+        num_instances = self.inv.numel()
+        if self.weight is None:
+            ho_index, weight = lift_order_edge_index(self.index, num_nodes=num_instances), None
+        else:
+            ho_index, weight = lift_order_edge_index_weighted(self.index, self.weight, num_nodes=num_instances, aggr=aggr)
+        last = aggregate_node_attributes(self.index, self.last, "dst")                 # last node of every new instance
+        k = self.unique_nodes.size(1)
+        pairs = _dispatch.gather_concat(self.inv.unsqueeze(1), _dispatch.plain(self.index)[0], last)     # (inv[a], last[b])
+        hi = max(self.unique_nodes.size(0), int(_dispatch.minmax(self.unique_nodes)[1]) + 1 if self.unique_nodes.numel() else 1)
+        unique_pairs, inv = _dispatch.unique_rows(pairs, (0, max(hi - 1, 0)))
+        unique_nodes = _dispatch.gather_concat(self.unique_nodes, unique_pairs[:, 0], unique_pairs[:, 1])
+        graph = _aggregate_with_known_nodes(ho_index, k + 1, None, unique_nodes, inv, weight, "sum") if save else None
+        return _LiftChain(ho_index, inv, last, unique_nodes, weight, graph)
 
 
 def _dispatch_degree(index: torch.Tensor, num_nodes: int) -> torch.Tensor:

@@ -182,6 +182,13 @@ __global__ __launch_bounds__(kBlock) void k_coalesce_fill(const KeyT* __restrict
     }
 }
 
+// inverse[e] = index of the merged edge that input edge e ended up in
+__global__ __launch_bounds__(kBlock) void k_coalesce_inverse(int64_t n, const uint32_t* __restrict__ perm, const int32_t* __restrict__ head,
+                                                            const int32_t* __restrict__ heads_before, int64_t* __restrict__ inverse) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p < n) inverse[perm[p]] = heads_before[p] + head[p] - 1;
+}
+
 struct CoalesceWs {
     int64_t* result;          // {A, status}
     void* keys_a;
@@ -369,6 +376,19 @@ int pp_coalesce_fill(const void* weight, int dtype, int reduce, int64_t n_edges,
     const int shift = coalesce_shift(num_nodes);
     return 2 * shift <= 32 ? coalesce_fill_impl<uint32_t>(weight, dtype, reduce, n_out, shift, out_index, out_weight, w, st)
                            : coalesce_fill_impl<uint64_t>(weight, dtype, reduce, n_out, shift, out_index, out_weight, w, st);
+}
+
+// inverse[n_edges]: for every input edge the position of its merged edge in the coalesced output (after *_count).
+// For a first-order edge list this IS torch.unique(stack(src,dst).T, dim=0, return_inverse=True)[1]: the sorted distinct
+// (src,dst) pairs are the order-2 De Bruijn nodes, so layer 2's unique/inverse comes for free from layer 1's coalesce.
+int pp_coalesce_inverse(int64_t n_edges, int64_t* inverse, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    CoalesceWs w = carve_coalesce(ws, n_edges);
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_coalesce_inverse: workspace too small");
+    if (n_edges <= 0) return PP_OK;
+    k_coalesce_inverse<<<(unsigned)ceil_div(n_edges, kBlock), kBlock, 0, st>>>(n_edges, w.perm, w.head, w.heads_before, inverse);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
 }
 
 // {size, status} of the last *_count on a unique/coalesce workspace

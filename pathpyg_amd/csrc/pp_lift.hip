@@ -405,6 +405,21 @@ __global__ __launch_bounds__(kBlock) void k_extend_rows(const int64_t* __restric
     out[idx] = rows[r * k + (c < k ? c : k - 1)];
 }
 
+// out[i, :k] = rows[idx[i], :],  out[i, k] = suffix[i]   (rows [n_rows, k], out [n, k+1])
+__global__ __launch_bounds__(kBlock) void k_gather_concat(const int64_t* __restrict__ rows, int64_t n_rows, int k, const int64_t* __restrict__ idx,
+                                                         const int64_t* __restrict__ suffix, int64_t n, int64_t* __restrict__ out,
+                                                         int64_t* __restrict__ status) {
+    const int64_t at = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int kk = k + 1;
+    if (at >= n * kk) return;
+    const int64_t i = at / kk;
+    const int c = (int)(at - i * kk);
+    if (c == k) { out[at] = suffix[i]; return; }
+    const int64_t r = idx[i];
+    if (r < 0 || r >= n_rows) { atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex); return; }
+    out[at] = rows[r * k + c];
+}
+
 // ------------------------------------------------------------------ workspace layouts
 struct LiftWs {
     int64_t* result;        // [2]: {total, status}
@@ -585,6 +600,18 @@ int pp_edge_attr(const int64_t* edge_index, int64_t n_edges, const void* attr, i
         case PP_F64: k_edge_attr<double><<<grid, kBlock, 0, st>>>(edge_index, n_edges, (const double*)attr, num_nodes, width, aggr, (double*)out, status); break;
         default: PP_REQUIRE(false, PP_ERR_ARG, "pp_edge_attr: unsupported dtype %d", dtype);
     }
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+// ---------------------------------------------------------------- prefix-row gather + suffix column
+int pp_gather_concat(const int64_t* rows, int64_t n_rows, int k, const int64_t* idx, const int64_t* suffix, int64_t n, int64_t* out,
+                     int64_t* status, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(k >= 1 && n >= 0, PP_ERR_ARG, "pp_gather_concat: bad shape");
+    PP_HIP(hipMemsetAsync(status, 0, sizeof(int64_t), st));
+    if (n == 0) return PP_OK;
+    k_gather_concat<<<(unsigned)ceil_div(n * (k + 1), kBlock), kBlock, 0, st>>>(rows, n_rows, k, idx, suffix, n, out, status);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
