@@ -156,11 +156,13 @@ int pp_ptr_from_sorted_i64(const int64_t* sorted, int64_t n, int64_t num_rows, i
  *   in_*  : CSR over DESTINATION nodes (in_ptr [N+1], in_idx = source of each incoming edge, in_val = norm)   forward
  *   out_* : CSR over SOURCE nodes      (out_idx = destination, out_val = norm)                               backward
  *   self_coef[i] = d[i]^2 * (weight of node i's self loop, 1 if it had none); existing self-loop edges get norm 0.
- * edge_weight may be NULL (all ones).  pp_plan_result_ptr(ws)[1] = status (bit 0: index out of range). */
+ * edge_weight may be NULL (all ones).  row_sorted != 0: the caller guarantees edge_index[0] is non-decreasing (every Graph's
+ * edge index is, graph.py:103) and the source-major grouping reuses the edge order instead of sorting.
+ * pp_plan_result_ptr(ws)[1] = status (bit 0: index out of range). */
 size_t pp_gcn_plan_ws_bytes(int64_t n_edges, int64_t n_nodes);
-int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int32_t* in_ptr, int32_t* in_idx,
-                float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, void* ws, size_t ws_bytes,
-                pp_stream_t stream);
+int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int row_sorted, int32_t* in_ptr,
+                int32_t* in_idx, float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, void* ws,
+                size_t ws_bytes, pp_stream_t stream);
 
 /* CSR views of DBGNN's bipartite_edge_index [2,n_pairs] (row 0: higher-order node, row 1: first-order node),
  * src/pathpyG/nn/dbgnn.py:64-69: in_* grouped by first-order node (+ its in-degree as float), out_* by higher-order node.

@@ -350,9 +350,12 @@ class CsrPlan:
             setattr(self, k, kw.get(k))
 
 
-def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nodes: int) -> CsrPlan:
-    """GCN normalisation of a weighted graph, once per graph (see pp_gcn_plan in the C header)."""
+def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nodes: int, row_sorted: bool | None = None) -> CsrPlan:
+    """GCN normalisation of a weighted graph, once per graph (see pp_gcn_plan in the C header).
+    ``row_sorted=None`` checks on the device whether the sources are non-decreasing (one tiny kernel + 8-byte read)."""
     ei = _edge_index(edge_index)
+    if row_sorted is None:
+        row_sorted = ei.size(1) < 2 or is_sorted(ei[0])
     dev = require_device(ei, edge_weight)
     e = ei.size(1)
     if edge_weight is not None:
@@ -368,7 +371,7 @@ def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nod
                        bwd_ptr=torch.empty(num_nodes + 1, **i32), bwd_idx=torch.empty(e, **i32), bwd_val=torch.empty(e, **f32),
                        self_coef=torch.empty(num_nodes, **f32))
         ws = _workspace(L.pp_gcn_plan_ws_bytes(e, num_nodes), dev)
-        check(L.pp_gcn_plan(_p(ei), _p(edge_weight), e, num_nodes, _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val), _p(plan.bwd_ptr),
+        check(L.pp_gcn_plan(_p(ei), _p(edge_weight), e, num_nodes, 1 if row_sorted else 0, _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val), _p(plan.bwd_ptr),
                             _p(plan.bwd_idx), _p(plan.bwd_val), _p(plan.self_coef), _p(ws), ws.numel(), _stream()), "pp_gcn_plan")
         _bad_index(_result(ws)[1], "GCNConv")
     return plan

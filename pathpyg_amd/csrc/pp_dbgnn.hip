@@ -70,6 +70,56 @@ __global__ __launch_bounds__(kBlock) void k_gcn_coefficients(const int64_t* __re
     val_out[p] = r == c ? 0.0f : dinv[r] * (w ? w[e] : 1.0f) * dinv[c];
 }
 
+// destination-grouped copies: in_idx[p] = source of the p-th incoming edge, w_by_dst[p] = its weight
+__global__ __launch_bounds__(kBlock) void k_gather_by_dst(const int64_t* __restrict__ edge_index, int64_t n_edges, const float* __restrict__ w,
+                                                         const uint32_t* __restrict__ order, int32_t* __restrict__ in_idx,
+                                                         float* __restrict__ w_by_dst) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n_edges) return;
+    const uint32_t e = order[p];
+    in_idx[p] = (int32_t)edge_index[e];
+    w_by_dst[p] = w ? w[e] : 1.0f;
+}
+
+// weighted in-degree from the destination-grouped (contiguous) weights; existing self loops are replaced by ONE loop
+__global__ __launch_bounds__(kBlock) void k_gcn_degree_grouped(const int32_t* __restrict__ in_idx, const float* __restrict__ w_by_dst,
+                                                              const uint32_t* __restrict__ dst_ptr, const int32_t* __restrict__ last_loop,
+                                                              const float* __restrict__ w, int64_t n_nodes, float* __restrict__ dinv,
+                                                              float* __restrict__ self_coef) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes) return;
+    const float lw = last_loop[i] >= 0 ? (w ? w[last_loop[i]] : 1.0f) : 1.0f;
+    float deg = 0.0f;
+    for (uint32_t p = dst_ptr[i]; p < dst_ptr[i + 1]; ++p)
+        if (in_idx[p] != (int32_t)i) deg += w_by_dst[p];
+    deg += lw;
+    float d = 1.0f / sqrtf(deg);                                  // deg^-1/2 ; inf -> 0 like masked_fill_(== inf, 0)
+    if (isinf(d)) d = 0.0f;
+    dinv[i] = d;
+    self_coef[i] = d * lw * d;
+}
+
+// in place: weight of the p-th incoming edge -> its normalised coefficient
+__global__ __launch_bounds__(kBlock) void k_in_coefficients(const int32_t* __restrict__ in_idx, const uint32_t* __restrict__ dst_of,
+                                                           const float* __restrict__ dinv, int64_t n_edges, float* __restrict__ val) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n_edges) return;
+    const int32_t r = in_idx[p];
+    const uint32_t c = dst_of[p];
+    val[p] = (uint32_t)r == c ? 0.0f : dinv[r] * val[p] * dinv[c];
+}
+
+__global__ __launch_bounds__(kBlock) void k_ptr_from_sorted_i64_i32(const int64_t* __restrict__ sorted, int64_t n, int64_t num_rows,
+                                                                   int32_t* __restrict__ ptr) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p > n) return;
+    int64_t a = p == 0 ? -1 : sorted[p - 1];
+    int64_t b = p == n ? num_rows : sorted[p];
+    if (a < -1) a = -1;
+    if (b > num_rows) b = num_rows;
+    for (int64_t v = a + 1; v <= b; ++v) ptr[v] = (int32_t)p;
+}
+
 __global__ __launch_bounds__(kBlock) void k_self_coefficient(const float* __restrict__ dinv, const float* __restrict__ loop_w, int64_t n,
                                                             float* __restrict__ self_coef) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -299,9 +349,9 @@ extern "C" {
 // ---------------------------------------------------------------- GCN plan
 size_t pp_gcn_plan_ws_bytes(int64_t n_edges, int64_t n_nodes) { return carve_plan(nullptr, n_edges, n_nodes).total_bytes; }
 
-int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int32_t* in_ptr, int32_t* in_idx,
-                float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, void* ws, size_t ws_bytes,
-                pp_stream_t stream) {
+int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int row_sorted, int32_t* in_ptr,
+                int32_t* in_idx, float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, void* ws,
+                size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_edges >= 0 && n_nodes >= 0, PP_ERR_ARG, "pp_gcn_plan: negative size");
     PP_REQUIRE(n_edges < (int64_t)0x7fffffff && n_nodes < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_plan: E or N >= 2^31");
@@ -312,28 +362,39 @@ int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_e
     const unsigned egrid = (unsigned)ceil_div(n_edges > 0 ? n_edges : 1, kBlock);
     const unsigned ngrid = (unsigned)ceil_div(n_nodes, kBlock);
     const unsigned pgrid = (unsigned)ceil_div(n_nodes + 1, kBlock);
-    // edges grouped by destination (forward aggregation)
-    int rc = group_by(edge_index + n_edges, n_edges, n_nodes, w, st);
-    if (rc != PP_OK) return rc;
     PP_HIP(hipMemsetAsync(w.last_loop, 0xff, (size_t)n_nodes * sizeof(int32_t), st));     // -1
     if (n_edges > 0) {
-        // validate sources too before they are used as indices
+        // validate the sources before they are used as indices (the destinations are validated by group_by)
         k_index_key<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, n_nodes, w.keys, w.status + 1);
         PP_LAUNCH_CHECK();
         k_last_self_loop<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, n_nodes, w.last_loop);
         PP_LAUNCH_CHECK();
     }
-    k_gcn_degree<<<ngrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, w.ptr, w.last_loop, n_nodes, w.dinv, w.loop_w);
-    PP_LAUNCH_CHECK();
-    k_self_coefficient<<<ngrid, kBlock, 0, st>>>(w.dinv, w.loop_w, n_nodes, self_coef);
-    PP_LAUNCH_CHECK();
+    // edges grouped by destination (forward aggregation): order[p] = edge id, sorted[p] = its destination
+    int rc = group_by(edge_index + n_edges, n_edges, n_nodes, w, st);
+    if (rc != PP_OK) return rc;
     k_u32_to_i32_ptr<<<pgrid, kBlock, 0, st>>>(w.ptr, n_nodes + 1, in_ptr);
     PP_LAUNCH_CHECK();
     if (n_edges > 0) {
-        k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, w.dinv, 1, in_idx, in_val);
+        k_gather_by_dst<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, in_idx, in_val);
+        PP_LAUNCH_CHECK();
+    }
+    k_gcn_degree_grouped<<<ngrid, kBlock, 0, st>>>(in_idx, in_val, w.ptr, w.last_loop, edge_weight, n_nodes, w.dinv, self_coef);
+    PP_LAUNCH_CHECK();
+    if (n_edges > 0) {
+        k_in_coefficients<<<egrid, kBlock, 0, st>>>(in_idx, w.sorted, w.dinv, n_edges, in_val);
         PP_LAUNCH_CHECK();
     }
     // edges grouped by source (backward = transposed aggregation)
+    if (row_sorted) {       // De Bruijn layers come out of coalesce (row, col)-sorted: the edge order already is the grouping
+        k_ptr_from_sorted_i64_i32<<<(unsigned)ceil_div(n_edges + 1, kBlock), kBlock, 0, st>>>(edge_index, n_edges, n_nodes, out_ptr);
+        PP_LAUNCH_CHECK();
+        if (n_edges > 0) {
+            k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, nullptr, w.dinv, 0, out_idx, out_val);
+            PP_LAUNCH_CHECK();
+        }
+        return PP_OK;
+    }
     rc = group_by(edge_index, n_edges, n_nodes, w, st);
     if (rc != PP_OK) return rc;
     k_u32_to_i32_ptr<<<pgrid, kBlock, 0, st>>>(w.ptr, n_nodes + 1, out_ptr);

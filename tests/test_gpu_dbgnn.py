@@ -123,3 +123,21 @@ def test_weight_grad_kernel(pp, n, m, k):
     torch.testing.assert_close(db.cpu().double(), dy.double().sum(0), rtol=1e-5, atol=1e-5 * float(dy.abs().sum(0).max()))
     dw2, none = _hip.weight_grad(dy.to(DEV), x.to(DEV), want_bias=False)
     assert none is None and torch.equal(dw2, dw)          # two-stage reduction is order-fixed: bitwise reproducible
+
+
+def test_gcn_plan_unsorted_edges_equal_sorted(pp):
+    """The plan must not depend on the edge order: row-sorted fast path vs the general (sorting) path."""
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(9)
+    n, e = 500, 6000
+    ei = torch.randint(0, n, (2, e), generator=g)
+    w = torch.rand(e, generator=g) + 0.5
+    x = torch.randn(n, 16, generator=g).to(DEV)
+    perm = torch.sort(ei[0], stable=True).indices
+    outs = []
+    for idx, ww in ((ei, w), (ei[:, perm], w[perm])):
+        plan = _hip.gcn_plan(idx.to(DEV), ww.to(DEV), n)
+        outs.append((_hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n, x, plan.self_coef),
+                     _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, n, x, plan.self_coef)))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)
