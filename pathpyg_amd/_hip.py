@@ -377,20 +377,28 @@ def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nod
     return plan
 
 
-def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int) -> CsrPlan:
+def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_value: torch.Tensor | None = None) -> CsrPlan:
+    """CSR pair of a [2, n_pairs] (source, destination) index between two node sets (``n_ho`` sources, ``n_fo``
+    destinations); ``self_coef`` = in-degree of every destination.  ``pair_value``: optional coefficient per pair."""
     bi = _edge_index(bipartite_index)
-    dev = require_device(bi)
+    dev = require_device(bi, pair_value)
     nb = bi.size(1)
+    if pair_value is not None:
+        pair_value = pair_value.to(torch.float32).contiguous()
     L = lib()
     with torch.cuda.device(dev):
         i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
         plan = CsrPlan(n_dst=n_fo, n_src=n_ho,
                        fwd_ptr=torch.empty(n_fo + 1, **i32), fwd_idx=torch.empty(nb, **i32),
                        bwd_ptr=torch.empty(n_ho + 1, **i32), bwd_idx=torch.empty(nb, **i32),
-                       self_coef=torch.empty(n_fo, dtype=torch.float32, device=dev))
+                       self_coef=torch.empty(n_fo, **f32))
+        if pair_value is not None:
+            plan.fwd_val, plan.bwd_val = torch.empty(nb, **f32), torch.empty(nb, **f32)
         ws = _workspace(L.pp_gcn_plan_ws_bytes(nb, max(n_ho, n_fo)), dev)
-        check(L.pp_bipartite_plan(_p(bi), nb, n_ho, n_fo, _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.self_coef), _p(plan.bwd_ptr),
-                                  _p(plan.bwd_idx), _p(ws), ws.numel(), _stream()), "pp_bipartite_plan")
+        check(L.pp_bipartite_plan(_p(bi), nb, n_ho, n_fo, _p(pair_value), _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val),
+                                  _p(plan.self_coef), _p(plan.bwd_ptr), _p(plan.bwd_idx), _p(plan.bwd_val), _p(ws), ws.numel(), _stream()),
+              "pp_bipartite_plan")
         _bad_index(_result(ws)[1], "BipartiteGraphOperator")
     return plan
 

@@ -137,6 +137,12 @@ __global__ __launch_bounds__(kBlock) void k_gather_index(const int64_t* __restri
     if (p < n) out[p] = (int32_t)values[order ? order[p] : p];
 }
 
+__global__ __launch_bounds__(kBlock) void k_gather_f32(const float* __restrict__ values, const uint32_t* __restrict__ order, int64_t n,
+                                                      float* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p < n) out[p] = values[order ? order[p] : p];
+}
+
 __global__ __launch_bounds__(kBlock) void k_ptr_diff_f32(const int32_t* __restrict__ ptr, int64_t n, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[i] = (float)(ptr[i + 1] - ptr[i]);
@@ -435,8 +441,9 @@ int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_e
 }
 
 // bipartite higher-order -> first-order projection plan: forward rows = first-order nodes, backward rows = higher-order nodes
-int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n_ho, int64_t n_fo, int32_t* in_ptr, int32_t* in_idx,
-                      float* in_degree, int32_t* out_ptr, int32_t* out_idx, void* ws, size_t ws_bytes, pp_stream_t stream) {
+int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n_ho, int64_t n_fo, const float* pair_value, int32_t* in_ptr,
+                      int32_t* in_idx, float* in_val, float* in_degree, int32_t* out_ptr, int32_t* out_idx, float* out_val, void* ws,
+                      size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_pairs >= 0 && n_ho >= 0 && n_fo >= 0, PP_ERR_ARG, "pp_bipartite_plan: negative size");
     const int64_t nmax = n_ho > n_fo ? n_ho : n_fo;
@@ -456,6 +463,10 @@ int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n
     if (n_pairs > 0) {
         k_gather_index<<<egrid, kBlock, 0, st>>>(bipartite_index, w.order, n_pairs, in_idx);
         PP_LAUNCH_CHECK();
+        if (pair_value && in_val) {
+            k_gather_f32<<<egrid, kBlock, 0, st>>>(pair_value, w.order, n_pairs, in_val);
+            PP_LAUNCH_CHECK();
+        }
     }
     rc = group_by(bipartite_index, n_pairs, n_ho, w, st);                        // by higher-order source
     if (rc != PP_OK) return rc;
@@ -464,6 +475,10 @@ int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n
     if (n_pairs > 0) {
         k_gather_index<<<egrid, kBlock, 0, st>>>(bipartite_index + n_pairs, w.order, n_pairs, out_idx);
         PP_LAUNCH_CHECK();
+        if (pair_value && out_val) {
+            k_gather_f32<<<egrid, kBlock, 0, st>>>(pair_value, w.order, n_pairs, out_val);
+            PP_LAUNCH_CHECK();
+        }
     }
     return PP_OK;
 }

@@ -109,17 +109,188 @@ def gather_lifted(local: torch.Tensor, group=None) -> torch.Tensor:
     return torch.cat([p[:, : int(s.item())] for p, s in zip(parts, sizes)], dim=1)
 
 
-def all_reduce_gradients(module: torch.nn.Module, group=None) -> None:
-    """Average the (small) DBGNN weight gradients across ranks in ONE flattened all-reduce (latency-bound:
-    ~20 k floats; per-tensor calls would pay the xGMI launch latency 14 times)."""
+def all_reduce_gradients(module: torch.nn.Module, group=None, average: bool = True) -> None:
+    """Sum (``average=False``) or average the (small) DBGNN weight gradients across ranks in ONE flattened all-reduce
+    (latency-bound: ~20 k floats; per-tensor calls would pay the xGMI launch latency 14 times)."""
     _, world = _world(group)
     grads = [p.grad for p in module.parameters() if p.grad is not None]
     if world == 1 or not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, group=group)
-    flat /= world
+    if average:
+        flat /= world
     at = 0
     for g in grads:
         g.copy_(flat[at: at + g.numel()].view_as(g))
         at += g.numel()
+
+
+# =====================================================================================================
+# Destination-partitioned DBGNN (SURVEY §8e): rank r owns a contiguous slice of the DESTINATION rows of the
+# first-order graph, of the higher-order graph and of the bipartite map, i.e. the rows of every feature matrix.
+# Per propagation: all-gather of the transformed features H (every rank needs the source rows its edges point
+# to), local atomics-free CSR aggregation of the owned rows, and in the backward pass a reduce-scatter of the
+# source-row gradients.  Weight gradients are averaged with one flattened all-reduce.  xGMI is point-to-point:
+# the row all-gather moves N*F*4 bytes per layer in total, each rank receiving (R-1)/R of it over its 7 links.
+# =====================================================================================================
+from . import _hip  # noqa: E402
+
+
+def node_ranges(num_nodes: int, world_size: int) -> list[tuple[int, int]]:
+    return [((num_nodes * r) // world_size, (num_nodes * (r + 1)) // world_size) for r in range(world_size)]
+
+
+def _gather_rows(x_local: torch.Tensor, ranges, group) -> torch.Tensor:
+    """Concatenate the row slices of all ranks (rank order) -> [N, F]."""
+    world = len(ranges)
+    if world == 1:
+        return x_local
+    cap = max(hi - lo for lo, hi in ranges)
+    padded = x_local.new_zeros((cap, x_local.size(1)))
+    padded[: x_local.size(0)] = x_local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, ranges)], dim=0)
+
+
+def _reduce_scatter_rows(x_full: torch.Tensor, ranges, rank: int, group) -> torch.Tensor:
+    """Sum the [N, F] partials of all ranks and keep this rank's row slice."""
+    world = len(ranges)
+    lo, hi = ranges[rank]
+    if world == 1:
+        return x_full[lo:hi]
+    backend = dist.get_backend(group)
+    if backend == "nccl":
+        cap = max(b - a for a, b in ranges)
+        chunks = []
+        for a, b in ranges:
+            c = x_full.new_zeros((cap, x_full.size(1)))
+            c[: b - a] = x_full[a:b]
+            chunks.append(c)
+        out = torch.empty_like(chunks[0])
+        dist.reduce_scatter(out, chunks, group=group)
+        return out[: hi - lo].contiguous()
+    summed = x_full.clone()                      # gloo has no reduce_scatter: all-reduce and slice (tests only)
+    dist.all_reduce(summed, group=group)
+    return summed[lo:hi].contiguous()
+
+
+class _AllGatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_local, ranges, rank, group):
+        ctx.ranges, ctx.rank, ctx.group = ranges, rank, group
+        return _gather_rows(x_local, ranges, group)
+
+    @staticmethod
+    def backward(ctx, d_full):
+        return _reduce_scatter_rows(d_full.contiguous(), ctx.ranges, ctx.rank, ctx.group), None, None, None
+
+
+class _LocalPropagate(torch.autograd.Function):
+    """y_local = act(A_local x_full + self_coef * s_local + bias): rows = this rank's destinations, columns = all sources."""
+
+    @staticmethod
+    def forward(ctx, plan, x_full, s_local, bias, act: bool):
+        y = _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x_full, plan.self_coef, s_local, bias, act)
+        ctx.plan, ctx.act, ctx.has_bias = plan, act, bias is not None
+        ctx.save_for_backward(y if act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        plan = ctx.plan
+        (y,) = ctx.saved_tensors
+        need_b = ctx.has_bias and ctx.needs_input_grad[3]
+        if ctx.act or need_b:
+            dpre, dbias = _hip.act_backward(dy, y, ctx.act, want_dpre=ctx.act, want_dbias=need_b)
+            if not ctx.act:
+                dpre = dy.contiguous()
+        else:
+            dpre, dbias = dy.contiguous(), None
+        dx_full = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre) if ctx.needs_input_grad[1] else None
+        ds = _hip.scale_rows(dpre, plan.self_coef) if ctx.needs_input_grad[2] else None
+        return None, dx_full, ds, dbias, None
+
+
+def _rect_plan(src_global, dst_local, value, n_src: int, n_dst: int, self_coef):
+    plan = _hip.bipartite_plan(torch.stack((src_global, dst_local)), n_src, n_dst, pair_value=value)
+    plan.self_coef = self_coef
+    return plan
+
+
+def partition_gcn(edge_index: torch.Tensor, edge_weight: torch.Tensor, num_nodes: int, rank: int, world: int, group=None):
+    """This rank's share of the GCN propagation of one graph: the edges pointing into its destination rows with their
+    symmetric normalisation (PyG gcn_norm semantics: one self loop per node, weighted in-degree, d^-1/2)."""
+    ranges = node_ranges(num_nodes, world)
+    lo, hi = ranges[rank]
+    src, dst = edge_index[0], edge_index[1]
+    mine = (dst >= lo) & (dst < hi)
+    src, dst, w = src[mine], dst[mine], edge_weight[mine].to(torch.float32)
+    loop = src == dst
+    loop_w = torch.ones(hi - lo, dtype=torch.float32, device=w.device)
+    loop_w[dst[loop] - lo] = w[loop]                                     # an existing self loop keeps its weight
+    src, dst, w = src[~loop], dst[~loop], w[~loop]
+    deg = torch.zeros(hi - lo, dtype=torch.float32, device=w.device).index_add_(0, dst - lo, w) + loop_w
+    dinv_local = deg.pow(-0.5)
+    dinv_local[torch.isinf(dinv_local)] = 0
+    dinv = _gather_rows(dinv_local.unsqueeze(1), ranges, group).squeeze(1)       # every rank needs d^-1/2 of all sources
+    value = dinv[src] * w * dinv[dst]
+    plan = _rect_plan(src, dst - lo, value, num_nodes, hi - lo, (dinv_local * loop_w * dinv_local).contiguous())
+    return plan, ranges
+
+
+def partition_bipartite(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, rank: int, world: int):
+    fo_ranges = node_ranges(n_fo, world)
+    lo, hi = fo_ranges[rank]
+    mine = (bipartite_index[1] >= lo) & (bipartite_index[1] < hi)
+    plan = _hip.bipartite_plan(torch.stack((bipartite_index[0][mine], bipartite_index[1][mine] - lo)), n_ho, hi - lo)
+    return plan
+
+
+class ShardedDBGNN(torch.nn.Module):
+    """Runs a :class:`pathpyg_amd.nn.DBGNN` with every graph partitioned by destination rows across the process group.
+
+    ``prepare(data)`` slices the (replicated) input bundle for this rank and builds the rectangular CSR plans;
+    ``forward(shard)`` returns the logits of the first-order nodes this rank owns.  Parameters are replicated; call
+    :func:`all_reduce_gradients` after ``backward``."""
+
+    def __init__(self, model, group=None):
+        super().__init__()
+        self.model = model
+        self.group = group
+        self.rank, self.world = _world(group)
+
+    def prepare(self, data) -> dict:
+        n_fo, n_ho = int(data.num_nodes), int(data.num_ho_nodes)
+        plan_fo, fo_ranges = partition_gcn(data.edge_index, data.edge_weights, n_fo, self.rank, self.world, self.group)
+        plan_ho, ho_ranges = partition_gcn(data.edge_index_higher_order, data.edge_weights_higher_order, n_ho, self.rank, self.world, self.group)
+        plan_bi = partition_bipartite(data.bipartite_edge_index, n_ho, n_fo, self.rank, self.world)
+        (flo, fhi), (hlo, hhi) = fo_ranges[self.rank], ho_ranges[self.rank]
+        return {"plan_fo": plan_fo, "plan_ho": plan_ho, "plan_bi": plan_bi, "fo_ranges": fo_ranges, "ho_ranges": ho_ranges,
+                "x": data.x[flo:fhi].contiguous(), "x_h": data.x_h[hlo:hhi].contiguous(),
+                "y": None if data.y is None else data.y[flo:fhi], "n_fo": n_fo}
+
+    def _gcn_stack(self, layers, x_local, plan, ranges):
+        from .nn.dbgnn import dense
+        for layer in layers:
+            h_local = dense(x_local, layer.lin)
+            h_full = _AllGatherRows.apply(h_local, ranges, self.rank, self.group)
+            x_local = _LocalPropagate.apply(plan, h_full, h_local, layer.bias, True)
+        return x_local
+
+    def forward(self, shard: dict) -> torch.Tensor:
+        from .nn.dbgnn import dense
+        m = self.model
+        x = self._gcn_stack(m.first_order_layers, shard["x"], shard["plan_fo"], shard["fo_ranges"])
+        x_h = self._gcn_stack(m.higher_order_layers, shard["x_h"], shard["plan_ho"], shard["ho_ranges"])
+        h_ho = _AllGatherRows.apply(dense(x_h, m.bipartite_layer.lin1), shard["ho_ranges"], self.rank, self.group)
+        h_fo = dense(x, m.bipartite_layer.lin2)
+        x = _LocalPropagate.apply(shard["plan_bi"], h_ho, h_fo, None, True)
+        return dense(x, m.lin)
+
+    def loss(self, shard: dict) -> torch.Tensor:
+        """Cross-entropy over ALL first-order nodes: local sum divided by the global node count, so that summing the
+        per-rank gradients (``all_reduce_gradients(..., average=False)``) reproduces the single-process gradient."""
+        out = self.forward(shard)
+        return torch.nn.functional.cross_entropy(out, shard["y"], reduction="sum") / shard["n_fo"]

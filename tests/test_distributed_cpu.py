@@ -96,3 +96,104 @@ def test_sharded_lift_and_gradient_allreduce_gloo(world):
         p.join(180)
         assert p.exitcode == 0
     assert dict(results) == {r: "ok" for r in range(world)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Destination-partitioned DBGNN: the sharding, the rectangular plans and the collectives run for real (gloo);
+# the four device kernels it calls are replaced by small torch-CPU equivalents (test-only stand-ins).
+class _CpuPlan:
+    pass
+
+
+def _cpu_bipartite_plan(bipartite_index, n_src, n_dst, pair_value=None):
+    src, dst = bipartite_index[0], bipartite_index[1]
+    plan = _CpuPlan()
+    plan.n_dst, plan.n_src = n_dst, n_src
+    by_dst = torch.sort(dst, stable=True).indices
+    by_src = torch.sort(src, stable=True).indices
+    plan.fwd_ptr = torch.zeros(n_dst + 1, dtype=torch.int32)
+    plan.fwd_ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_dst), 0)
+    plan.bwd_ptr = torch.zeros(n_src + 1, dtype=torch.int32)
+    plan.bwd_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=n_src), 0)
+    plan.fwd_idx, plan.bwd_idx = src[by_dst].int(), dst[by_src].int()
+    plan.fwd_val = None if pair_value is None else pair_value[by_dst].float()
+    plan.bwd_val = None if pair_value is None else pair_value[by_src].float()
+    plan.self_coef = torch.bincount(dst, minlength=n_dst).float()
+    return plan
+
+
+def _cpu_spmm(ptr, idx, val, n_rows, x, self_coef=None, s=None, bias=None, act=False):
+    counts = (ptr[1:] - ptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n_rows), counts)
+    contrib = x[idx.long()] * (1.0 if val is None else val.unsqueeze(1))
+    y = torch.zeros(n_rows, x.size(1)).index_add_(0, rows, contrib)
+    if self_coef is not None:
+        y = y + self_coef.unsqueeze(1) * (x if s is None else s)
+    if bias is not None:
+        y = y + bias
+    return torch.nn.functional.elu(y) if act else y
+
+
+def _cpu_act_backward(dy, y, act, want_dpre=True, want_dbias=False):
+    g = dy * torch.where(y > 0, torch.ones_like(y), y + 1) if act else dy
+    return (g if want_dpre else None), (g.sum(0) if want_dbias else None)
+
+
+def _dbgnn_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pathpyg_amd as pp
+        from pathpyg_amd import _hip, distributed as pd
+        from oracle import dbgnn as od
+        _hip.bipartite_plan, _hip.spmm, _hip.act_backward = _cpu_bipartite_plan, _cpu_spmm, _cpu_act_backward
+        _hip.scale_rows = lambda x, coef: x * coef.unsqueeze(1)
+        g = torch.Generator().manual_seed(0)
+        n, n_ho, f = 37, 90, 8
+
+        def graph(nn, ee):
+            key = torch.unique(torch.randint(0, nn * nn, (ee,), generator=g))
+            ei = torch.stack((key // nn, key % nn))
+            return ei, torch.randint(1, 4, (ei.size(1),), generator=g).float()
+        ei, w = graph(n, 150)
+        ei_h, w_h = graph(n_ho, 260)
+        ns = torch.randint(0, n, (n_ho, 2), generator=g)
+        bundle = dict(num_nodes=n, num_ho_nodes=n_ho, x=torch.randn(n, f, generator=g), x_h=torch.randn(n_ho, f, generator=g),
+                      edge_index=ei, edge_weights=w, edge_index_higher_order=ei_h, edge_weights_higher_order=w_h,
+                      bipartite_edge_index=torch.stack((torch.arange(n_ho), ns[:, 1])), y=torch.randint(0, 3, (n,), generator=g))
+        params = od.init_params(3, (f, f), [12, 10, 6], seed=3)
+        want_out, want_loss, want_grads = od.loss_and_grads(params, bundle, bundle["y"])
+
+        net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=[12, 10, 6])
+        net.load_state_dict(params)
+        sharded = pd.ShardedDBGNN(net)
+        shard = sharded.prepare(pp.Data(**bundle))
+        out_local = sharded(shard)
+        lo, hi = shard["fo_ranges"][rank]
+        torch.testing.assert_close(out_local.detach(), want_out[lo:hi], rtol=1e-4, atol=1e-5)
+        loss = sharded.loss(shard)
+        loss.backward()
+        pd.all_reduce_gradients(net, average=False)
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        torch.testing.assert_close(total, want_loss, rtol=1e-5, atol=1e-6)
+        for name, p in net.named_parameters():
+            torch.testing.assert_close(p.grad, want_grads[name], rtol=1e-3, atol=1e-5), name
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_destination_partitioned_dbgnn_matches_single_process_oracle(world):
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_dbgnn_worker, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert dict(results) == {r: "ok" for r in range(world)}

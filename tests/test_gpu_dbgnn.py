@@ -141,3 +141,25 @@ def test_gcn_plan_unsorted_edges_equal_sorted(pp):
                      _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, n, x, plan.self_coef)))
     torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)
+
+
+def test_sharded_dbgnn_world1_matches_oracle_on_gpu(pp):
+    """The destination-partitioned code path (rectangular plans with per-pair coefficients, local propagate) on real
+    kernels; the multi-rank logic itself is covered by the gloo tests in tests/test_distributed_cpu.py."""
+    from oracle import dbgnn as od
+    from pathpyg_amd import distributed as pd
+    data, y = _bundle(5, 300, 4000, 1500, 6000, (32, 32))
+    params = od.init_params(3, (32, 32), [64, 32, 16], seed=5)
+    want_out, want_loss, want_grads = od.loss_and_grads(params, data, y)
+    net = _to_module(pp, params, 3, (32, 32), [64, 32, 16])
+    gdata = pp.Data(**{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}, y=y.to(DEV))
+    sharded = pd.ShardedDBGNN(net)
+    shard = sharded.prepare(gdata)
+    out = sharded(shard)
+    torch.testing.assert_close(out.detach().cpu(), want_out, rtol=RTOL, atol=ATOL)
+    loss = sharded.loss(shard)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), want_loss, rtol=RTOL, atol=ATOL)
+    for name, p in net.named_parameters():
+        scale = float(want_grads[name].abs().max()) + 1e-12
+        torch.testing.assert_close(p.grad.cpu(), want_grads[name], rtol=RTOL * 10, atol=max(ATOL, 2e-5 * scale)), name
