@@ -195,6 +195,15 @@ size_t pp_weight_grad_ws_bytes(int64_t n_rows, int M, int K);
 int pp_weight_grad_f32(const float* dH, const float* X, int64_t n_rows, int M, int K, float* dW, float* db, void* ws, size_t ws_bytes,
                        pp_stream_t stream);
 
+/* Dense layer on the matrix cores (the Linear / GCNConv.lin calls of dbgnn.py:64,133,139,149 and their input gradients):
+ *   out[N,Q] = ( A[N,P] . B + bias ) (*) g'      B = W^T for w_transposed != 0 (W is [Q,P]: forward), W otherwise (W is [P,Q])
+ *   grad_act : [N,Q] or NULL: the stored activation y = ELU(pre) of the layer below; the result is multiplied by
+ *              ELU'(pre) = (y > 0 ? 1 : y + 1) and, with colsum [Q], its column sums (= that layer's bias gradient) accumulate.
+ * fp32 on v_mfma_f32_16x16x4_f32.  Supported layer widths: P, Q in {16, 32, 64} (pp_dense_supported); others: library GEMM. */
+int pp_dense_supported(int P, int Q);
+int pp_dense_f32(const float* A, const float* W, int w_transposed, int64_t n_rows, int P, int Q, const float* bias,
+                 const float* grad_act, float* colsum, float* out, pp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -454,3 +454,30 @@ def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
         ws = _workspace(L.pp_weight_grad_ws_bytes(n, m, k), dev)
         check(L.pp_weight_grad_f32(_p(dy), _p(x), n, m, k, _p(dw), _p(db), _p(ws), ws.numel(), _stream()), "pp_weight_grad_f32")
     return dw, db
+
+
+def dense_supported(p: int, q: int) -> bool:
+    return bool(lib().pp_dense_supported(int(p), int(q)))
+
+
+def dense(a: torch.Tensor, weight: torch.Tensor, transposed: bool, bias: torch.Tensor | None = None,
+          grad_act: torch.Tensor | None = None, want_colsum: bool = False):
+    """``out = (a @ (weight.T if transposed else weight) + bias) * elu'`` on the matrix cores (fp32) where ``elu'`` is the ELU
+    derivative recovered from the stored activation ``grad_act`` (``y > 0 ? 1 : y + 1``); returns ``(out, colsum or None)``.
+    Shapes must satisfy :func:`dense_supported`."""
+    dev = require_device(a, weight, bias, grad_act)
+    a, weight = a.contiguous(), weight.contiguous()
+    n, p = a.shape
+    q = weight.size(0) if transposed else weight.size(1)
+    if (weight.size(1) if transposed else weight.size(0)) != p:
+        raise ValueError("dense: inner dimensions do not match")
+    if bias is not None:
+        bias = bias.contiguous()
+    if grad_act is not None:
+        grad_act = grad_act.contiguous()
+    with torch.cuda.device(dev):
+        out = torch.empty((n, q), dtype=torch.float32, device=dev)
+        colsum = torch.empty(q, dtype=torch.float32, device=dev) if want_colsum else None
+        check(lib().pp_dense_f32(_p(a), _p(weight), 1 if transposed else 0, n, p, q, _p(bias), _p(grad_act), _p(colsum), _p(out), _stream()),
+              "pp_dense_f32")
+    return out, colsum

@@ -539,7 +539,8 @@ constexpr int kWgTile = 2;                 // 2x2 tiles of 32x32 per wave = 64x6
 constexpr int kWgUnroll = 8;               // row pairs in flight per iteration (16 rows of dH and X)
 
 __global__ __launch_bounds__(kBlock) void k_weight_grad(const float* __restrict__ dH, const float* __restrict__ X, int64_t n_rows, int M, int K,
-                                                       int64_t rows_per_wave, float* __restrict__ partial, float* __restrict__ partial_bias) {
+                                                       int64_t rows_per_wave, float* __restrict__ partial,
+                                                       float* __restrict__ partial_bias) {
     // blockIdx.y selects the 64x64 output block (i-block major), blockIdx.x the row range
     const int k_blocks = (K + 63) / 64;
     const int i_base = (blockIdx.y / k_blocks) * 64;
@@ -684,6 +685,151 @@ int pp_weight_grad_f32(const float* dH, const float* X, int64_t n_rows, int M, i
     const int outs = M * K + (db ? M : 0);
     pp::k_weight_grad_reduce<<<(unsigned)pp::ceil_div(outs, pp::kBlock / pp::kWgSlices), pp::kBlock, 0, st>>>(
         partial, db ? partial_bias : nullptr, parts, M, K, dW, db);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Dense layer on the matrix cores, optionally with the ELU backward of the layer BELOW fused into its epilogue:
+//     out[N,Q] = ( A[N,P] . B[P,Q] + bias ) (*) g'               B = W^T (W is [Q,P], forward) or W (W is [P,Q], input gradient)
+//   grad_act : y = ELU(pre) of the layer below, stored by its forward; g' = ELU'(pre) = (y > 0 ? 1 : y + 1) is multiplied into
+//              the result and colsum[q] accumulates it: the input-gradient GEMM then directly yields the gradient w.r.t. the
+//              lower layer's PRE-activation and that layer's bias gradient - no separate 3-pass ELU-backward kernel.
+// v_mfma_f32_16x16x4_f32: lane (i = lane&15, kq = lane>>4) owns row i of a 16-row tile and the k-range [kq*P/4, (kq+1)*P/4):
+// the reduction order inside a dot product is free, so each lane reads P/16 float4 of its row (contiguous quarter row) and
+// the matching rows of B live in registers for the whole kernel (P*Q/64 VGPRs: 64 for 64x64).  Waves are persistent and
+// prefetch the next tile's A registers while the MFMAs of the current tile run.
+namespace pp {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int P, int Q>
+__global__ __launch_bounds__(kBlock) void k_dense(const float* __restrict__ A, const float* __restrict__ W, int w_transposed, int64_t n_rows,
+                                                 const float* __restrict__ bias, const float* __restrict__ grad_act,
+                                                 float* __restrict__ colsum, float* __restrict__ out) {
+    constexpr int KQ = P / 4;            // k values per lane
+    constexpr int CT = Q / 16;           // 16-column output tiles
+    const int lane = lane_id(), i = lane & 15, kq = lane >> 4;
+    float b[KQ][CT];
+#pragma unroll
+    for (int t = 0; t < KQ; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int k = kq * KQ + t, j = ct * 16 + i;
+            b[t][ct] = w_transposed ? W[j * P + k] : W[k * Q + j];
+        }
+    float bias_c[CT], col_acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        bias_c[ct] = bias ? bias[ct * 16 + i] : 0.f;
+        col_acc[ct] = 0.f;
+    }
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
+    float4 a_cur[KQ / 4], a_nxt[KQ / 4];
+    auto load_tile = [&](int64_t t, float4 (&dst)[KQ / 4]) {
+        const int64_t r = t * 16 + i;
+        const bool live = t < n_tiles && r < n_rows;
+#pragma unroll
+        for (int c = 0; c < KQ / 4; ++c)
+            dst[c] = live ? *(const float4*)(A + r * P + kq * KQ + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    load_tile(tile, a_cur);
+    for (; tile < n_tiles; tile += n_waves) {
+        load_tile(tile + n_waves, a_nxt);
+        // the activation values of the gradient epilogue are fetched BEFORE the MFMAs so that their latency hides behind them
+        float gp[CT][4];
+        if (grad_act) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int64_t r = tile * 16 + 4 * kq + reg;
+                    gp[ct][reg] = r < n_rows ? grad_act[r * Q + ct * 16 + i] : 0.f;
+                }
+        }
+        f32x4 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KQ / 4; ++c) {
+            float av[4] = {a_cur[c].x, a_cur[c].y, a_cur[c].z, a_cur[c].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b[4 * c + e][ct], acc[ct], 0, 0, 0);
+            }
+        }
+        // C/D layout of the 16x16 MFMA: row = 4*(lane>>4) + reg, col = lane&15
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t r = tile * 16 + 4 * kq + reg;
+                if (r < n_rows) {
+                    float v = acc[ct][reg] + bias_c[ct];
+                    if (grad_act) {
+                        const float y = gp[ct][reg];
+                        v *= y > 0.f ? 1.f : y + 1.f;            // ELU'(pre) from the stored activation y = ELU(pre)
+                        col_acc[ct] += v;
+                    }
+                    out[r * Q + ct * 16 + i] = v;
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < KQ / 4; ++c) a_cur[c] = a_nxt[c];
+    }
+    if (colsum) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            float v = col_acc[ct];
+            v += __shfl_xor(v, 16, kWave);
+            v += __shfl_xor(v, 32, kWave);
+            if (kq == 0) atomicAdd(&colsum[ct * 16 + i], v);
+        }
+    }
+}
+
+template <int P>
+static int launch_dense_q(int Q, unsigned grid, hipStream_t st, const float* A, const float* W, int wt, int64_t n,
+                          const float* bias, const float* grad_act, float* colsum, float* out) {
+    switch (Q) {
+        case 16: k_dense<P, 16><<<grid, kBlock, 0, st>>>(A, W, wt, n, bias, grad_act, colsum, out); break;
+        case 32: k_dense<P, 32><<<grid, kBlock, 0, st>>>(A, W, wt, n, bias, grad_act, colsum, out); break;
+        case 64: k_dense<P, 64><<<grid, kBlock, 0, st>>>(A, W, wt, n, bias, grad_act, colsum, out); break;
+        default: return PP_ERR_ARG;
+    }
+    return PP_OK;
+}
+
+}  // namespace pp
+
+extern "C" {
+
+int pp_dense_supported(int P, int Q) { return (P == 16 || P == 32 || P == 64) && (Q == 16 || Q == 32 || Q == 64); }
+
+int pp_dense_f32(const float* A, const float* W, int w_transposed, int64_t n_rows, int P, int Q, const float* bias,
+                 const float* grad_act, float* colsum, float* out, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_dense_f32: negative size");
+    PP_REQUIRE(pp_dense_supported(P, Q), PP_ERR_ARG, "pp_dense_f32: unsupported layer shape %dx%d (supported: 16/32/64)", P, Q);
+    PP_REQUIRE(((uintptr_t)A | (uintptr_t)out) % 16 == 0, PP_ERR_ARG, "pp_dense_f32: A and out must be 16-byte aligned");
+    if (colsum) PP_HIP(hipMemsetAsync(colsum, 0, (size_t)Q * sizeof(float), st));
+    if (n_rows == 0) return PP_OK;
+    int64_t blocks = pp::ceil_div(pp::ceil_div(n_rows, 16), pp::kWavesPerBlock);
+    const int64_t cap = 256 * 3;                       // 3 workgroups (12 waves) per CU: the kernel is register-heavy
+    if (blocks > cap) blocks = cap;
+    int rc;
+    switch (P) {
+        case 16: rc = pp::launch_dense_q<16>(Q, (unsigned)blocks, st, A, W, w_transposed, n_rows, bias, grad_act, colsum, out); break;
+        case 32: rc = pp::launch_dense_q<32>(Q, (unsigned)blocks, st, A, W, w_transposed, n_rows, bias, grad_act, colsum, out); break;
+        default: rc = pp::launch_dense_q<64>(Q, (unsigned)blocks, st, A, W, w_transposed, n_rows, bias, grad_act, colsum, out); break;
+    }
+    if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

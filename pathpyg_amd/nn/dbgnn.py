@@ -29,11 +29,14 @@ class _Propagate(torch.autograd.Function):
     """y = act(A x + diag(self_coef) s + bias) with A given by a CsrPlan; s is x itself (GCN) or a second input."""
 
     @staticmethod
-    def forward(ctx, plan, x, s, bias, act: bool):
+    def forward(ctx, plan, x, s, bias, act: bool, grad_is_pre: bool = False):
+        """``grad_is_pre``: the (single) consumer of ``y`` is a :class:`_Dense` with ``fuse_act`` — it hands back the gradient
+        w.r.t. the PRE-activation and computes this layer's bias gradient itself, so nothing of that is redone here."""
         y = _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x, plan.self_coef, s, bias, act)
         ctx.plan, ctx.act, ctx.separate_self = plan, act, s is not None
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(y if act else None)
+        ctx.grad_is_pre = grad_is_pre
+        ctx.save_for_backward(y if (act and not grad_is_pre) else None)
         return y
 
     @staticmethod
@@ -41,7 +44,9 @@ class _Propagate(torch.autograd.Function):
         plan = ctx.plan
         (y,) = ctx.saved_tensors
         need_x, need_s, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3] and ctx.has_bias
-        if ctx.act or need_b:
+        if ctx.grad_is_pre:
+            dpre, dbias = dy.contiguous(), None
+        elif ctx.act or need_b:
             dpre, dbias = _hip.act_backward(dy, y, ctx.act, want_dpre=ctx.act, want_dbias=need_b)
             if not ctx.act:
                 dpre = dy.contiguous()
@@ -55,33 +60,47 @@ class _Propagate(torch.autograd.Function):
                 ds = _hip.scale_rows(dpre, plan.self_coef)
         elif need_x:      # the self term acts on x itself: A^T dpre + diag(self_coef) dpre in one pass
             dx = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, dpre)
-        return None, dx, ds, dbias, None
+        return None, dx, ds, dbias, None, None
 
 
 class _Dense(torch.autograd.Function):
-    """y = x W^T (+ b).  Forward and the input gradient are library GEMMs; the weight/bias gradient — a
-    [M, N] x [N, K] product with N ~ 10^7 that vendor GEMMs handle poorly — is the hand-written MFMA kernel."""
+    """y = x W^T (+ b) on the matrix cores (hand-written fp32 MFMA kernels; library GEMM for unsupported layer widths).
+
+    ``fuse_act``: ``x`` is the stored activation ELU(pre) of the layer below and that layer was told ``grad_is_pre``: the
+    input-gradient GEMM multiplies ELU'(pre) into its epilogue and accumulates the lower layer's bias gradient (returned as
+    the gradient of ``act_bias``), replacing a separate three-pass ELU-backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, fuse_act: bool, act_bias):
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.fuse_act, ctx.has_act_bias = bias is not None, fuse_act, act_bias is not None
+        ctx.fast = _hip.dense_supported(weight.size(1), weight.size(0))
+        if ctx.fast:
+            return _hip.dense(x, weight, True, bias)[0]
         return F.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dx = dw = db = None
+        dy = dy.contiguous()
+        dx = dw = db = dact = None
         if ctx.needs_input_grad[0]:
-            dx = dy @ weight
+            want_sum = ctx.has_act_bias and ctx.needs_input_grad[4]
+            if ctx.fuse_act:
+                if ctx.fast:
+                    dx, dact = _hip.dense(dy, weight, False, None, grad_act=x, want_colsum=want_sum)
+                else:
+                    dx, dact = _hip.act_backward(dy @ weight, x, True, want_dpre=True, want_dbias=want_sum)
+            else:
+                dx = _hip.dense(dy, weight, False)[0] if ctx.fast else dy @ weight
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = _hip.weight_grad(dy, x, want_bias=ctx.has_bias)
-        return dx, dw, db
+        return dx, dw, db, None, dact
 
 
-def dense(x, linear: Linear):
+def dense(x, linear: Linear, fuse_act: bool = False, act_bias=None):
     if x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda:
-        return _Dense.apply(x, linear.weight, linear.bias)
+        return _Dense.apply(x, linear.weight, linear.bias, fuse_act, act_bias)
     return linear(x)
 
 
@@ -176,13 +195,28 @@ class DBGNN(Module):
         plan_bi = _cached(data, "bi", (data.bipartite_edge_index,),
                           lambda: _hip.bipartite_plan(data.bipartite_edge_index, n_ho, n_fo))
 
-        for layer in self.first_order_layers:                       # dropout -> GCNConv -> ELU (fused)
-            x = layer(self._dropout(x), data.edge_index, data.edge_weights, plan=plan_fo, activation=True)
-        x = self._dropout(x)
-        for layer in self.higher_order_layers:
-            x_h = layer(self._dropout(x_h), data.edge_index_higher_order, data.edge_weights_higher_order, plan=plan_ho, activation=True)
-        x_h = self._dropout(x_h)
+        if self.p_dropout > 0 and self.training:
+            for layer in self.first_order_layers:                   # dropout -> GCNConv -> ELU (fused into the aggregation)
+                x = layer(self._dropout(x), data.edge_index, data.edge_weights, plan=plan_fo, activation=True)
+            x = self._dropout(x)
+            for layer in self.higher_order_layers:
+                x_h = layer(self._dropout(x_h), data.edge_index_higher_order, data.edge_weights_higher_order, plan=plan_ho, activation=True)
+            x_h = self._dropout(x_h)
+            x = self.bipartite_layer((x_h, x), data.bipartite_edge_index, n_ho=n_ho, n_fo=n_fo, plan=plan_bi, activation=True)
+            return dense(self._dropout(x), self.lin)
 
-        x = self.bipartite_layer((x_h, x), data.bipartite_edge_index, n_ho=n_ho, n_fo=n_fo, plan=plan_bi, activation=True)
-        x = self._dropout(x)
-        return dense(x, self.lin)
+        # No dropout between an activation and the dense layer that consumes it: every ELU backward is fused into the
+        # epilogue of that dense layer's input-gradient GEMM (see _Dense / _Propagate.grad_is_pre).
+        def stack(layers, h, plan):
+            below = None                                            # bias of the layer whose activation `h` is
+            for i, layer in enumerate(layers):
+                t = dense(h, layer.lin, fuse_act=i > 0, act_bias=below)
+                h = _Propagate.apply(plan, t, None, layer.bias, True, True)
+                below = layer.bias
+            return h, below
+
+        x, bias_fo = stack(self.first_order_layers, x, plan_fo)
+        x_h, bias_ho = stack(self.higher_order_layers, x_h, plan_ho)
+        bl = self.bipartite_layer
+        x = _Propagate.apply(plan_bi, dense(x_h, bl.lin1, True, bias_ho), dense(x, bl.lin2, True, bias_fo), None, True, True)
+        return dense(x, self.lin, True, None)

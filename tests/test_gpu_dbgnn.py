@@ -163,3 +163,25 @@ def test_sharded_dbgnn_world1_matches_oracle_on_gpu(pp):
     for name, p in net.named_parameters():
         scale = float(want_grads[name].abs().max()) + 1e-12
         torch.testing.assert_close(p.grad.cpu(), want_grads[name], rtol=RTOL * 10, atol=max(ATOL, 2e-5 * scale)), name
+
+
+@pytest.mark.parametrize("n,p,q", [(1, 16, 16), (15, 64, 64), (16, 32, 64), (1000, 64, 32), (70_001, 64, 64), (4097, 16, 64)])
+def test_dense_mfma_kernel(pp, n, p, q):
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(n + p + q)
+    a = torch.randn(n, p, generator=g)
+    w_t = torch.randn(q, p, generator=g)          # forward layout [Q, P]
+    w_n = torch.randn(p, q, generator=g)          # gradient layout [P, Q]
+    bias = torch.randn(q, generator=g)
+    y = F.elu(torch.randn(n, q, generator=g))     # a stored activation
+    tol = dict(rtol=2e-5, atol=2e-5)
+    out, none = _hip.dense(a.to(DEV), w_t.to(DEV), True)
+    assert none is None
+    torch.testing.assert_close(out.cpu(), a @ w_t.t(), **tol)
+    out, _ = _hip.dense(a.to(DEV), w_t.to(DEV), True, bias.to(DEV))
+    torch.testing.assert_close(out.cpu(), a @ w_t.t() + bias, **tol)
+    out, colsum = _hip.dense(a.to(DEV), w_n.to(DEV), False, None, y.to(DEV), True)
+    want = (a @ w_n) * torch.where(y > 0, torch.ones_like(y), y + 1)
+    torch.testing.assert_close(out.cpu(), want, **tol)
+    torch.testing.assert_close(colsum.cpu(), want.sum(0), rtol=1e-4, atol=1e-4 * float(want.abs().sum(0).max() + 1))
+    assert not _hip.dense_supported(8, 64) and _hip.dense_supported(64, 16)
