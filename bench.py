@@ -193,7 +193,7 @@ def main() -> int:
         e1.record()
         opt.zero_grad(set_to_none=True)
         out = net(data)
-        loss = torch.nn.functional.cross_entropy(out, y)
+        loss = pp.nn.cross_entropy(out, y)
         loss.backward()
         if launched:        # data-parallel over independent streams: only the ~20 k weight gradients cross xGMI (one all-reduce)
             ppd.all_reduce_gradients(net)

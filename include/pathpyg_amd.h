@@ -204,6 +204,10 @@ int pp_dense_supported(int P, int Q);
 int pp_dense_f32(const float* A, const float* W, int w_transposed, int64_t n_rows, int P, int Q, const float* bias,
                  const float* grad_act, float* colsum, float* out, pp_stream_t stream);
 
+/* Mean softmax cross-entropy of logits [n,C] (C <= 64) against int64 targets [n] and its gradient dlogits [n,C] (may be NULL) in
+ * one pass - the loss of the train step bench.py times (the reference ships no training loop). */
+int pp_cross_entropy_f32(const float* logits, const int64_t* target, int64_t n, int C, float* loss, float* dlogits, pp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

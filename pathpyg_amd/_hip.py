@@ -481,3 +481,16 @@ def dense(a: torch.Tensor, weight: torch.Tensor, transposed: bool, bias: torch.T
         check(lib().pp_dense_f32(_p(a), _p(weight), 1 if transposed else 0, n, p, q, _p(bias), _p(grad_act), _p(colsum), _p(out), _stream()),
               "pp_dense_f32")
     return out, colsum
+
+
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = True):
+    """(mean cross-entropy [scalar tensor], d loss / d logits or None) in one pass; logits [N, C<=64] fp32, target int64 [N]."""
+    dev = require_device(logits, target)
+    logits = logits.contiguous()
+    target = target.to(torch.int64).contiguous()
+    n, c = logits.shape
+    with torch.cuda.device(dev):
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(logits) if want_grad else None
+        check(lib().pp_cross_entropy_f32(_p(logits), _p(target), n, c, _p(loss), _p(grad), _stream()), "pp_cross_entropy_f32")
+    return loss[0], grad

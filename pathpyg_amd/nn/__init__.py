@@ -1,1 +1,1 @@
-from .dbgnn import DBGNN, BipartiteGraphOperator, GCNConv  # noqa: F401
+from .dbgnn import DBGNN, BipartiteGraphOperator, GCNConv, cross_entropy  # noqa: F401

@@ -104,6 +104,27 @@ def dense(x, linear: Linear, fuse_act: bool = False, act_bias=None):
     return linear(x)
 
 
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        loss, grad = _hip.cross_entropy(logits, target, want_grad=True)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (grad,) = ctx.saved_tensors
+        return grad * dloss, None
+
+
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Mean softmax cross-entropy (``F.cross_entropy`` semantics for class-index targets) with its gradient computed in the
+    same HIP pass; falls back to torch for CPU tensors or more than 64 classes."""
+    if logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and logits.size(1) <= 64:
+        return _CrossEntropy.apply(logits, target)
+    return F.cross_entropy(logits, target)
+
+
 def _plan_cache(data) -> dict:
     cache = getattr(data, "_pp_plan_cache", None)
     if cache is None:

@@ -185,3 +185,17 @@ def test_dense_mfma_kernel(pp, n, p, q):
     torch.testing.assert_close(out.cpu(), want, **tol)
     torch.testing.assert_close(colsum.cpu(), want.sum(0), rtol=1e-4, atol=1e-4 * float(want.abs().sum(0).max() + 1))
     assert not _hip.dense_supported(8, 64) and _hip.dense_supported(64, 16)
+
+
+@pytest.mark.parametrize("n,c", [(1, 2), (1000, 8), (100_003, 8), (5000, 13), (300, 64)])
+def test_cross_entropy_kernel(pp, n, c):
+    g = torch.Generator().manual_seed(n + c)
+    z = (torch.randn(n, c, generator=g) * 3).requires_grad_(True)
+    y = torch.randint(0, c, (n,), generator=g)
+    want = F.cross_entropy(z, y)
+    want.backward()
+    zg = z.detach().to(DEV).requires_grad_(True)
+    got = pp.nn.cross_entropy(zg, y.to(DEV))
+    (got * 2).backward()
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(zg.grad.cpu(), 2 * z.grad, rtol=1e-5, atol=1e-8)
