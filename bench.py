@@ -94,6 +94,19 @@ def spmm_bytes(ptr, idx, val, n_rows, x, f, self_coef, s, bias, act, y, stream):
 spmm_bytes.shape_of = {}
 
 
+def pmc_traffic(kernel_key: str, args) -> float | None:
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/, separate FETCH_SIZE
+    and WRITE_SIZE runs of this same command, gfx950 FETCH correction applied).  Only valid for the default workload."""
+    defaults = (10_000_000, 500_000, 10_000_000, 1_000_000, 64)
+    if (args.events, args.nodes, args.span, args.delta, args.features) != defaults:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            return float(json.load(fh)[kernel_key]["hbm_bytes_per_dispatch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(args, seed: int) -> dict:
     """The CPU oracle (port of the reference algorithm incl. its per-timestamp lift loop) on a bounded sample of
     the same generator: events scaled down, nodes and delta scaled to keep E2/m of the full workload."""
@@ -257,6 +270,7 @@ def main() -> int:
         n_fill, fill_ms, fill_b = fill_clock.summary()
         dominant = ("k_spmm_v4 (pp_spmm_f32)", n_spmm, spmm_ms, spmm_b) if spmm_ms >= fill_ms else \
                    ("k_expand (pp_temporal_fill)", n_fill, fill_ms, fill_b)
+        traffic = pmc_traffic("k_spmm_v4", args) if spmm_ms >= fill_ms else None
         achieved = dominant[3] / (dominant[2] * 1e-3) / 1e9 if dominant[2] > 0 else 0.0
         line = {
             "metric": "lifted k-edges/s (k=2 De Bruijn lift + aggregation + 1 DBGNN train step per pass, 10M temporal edges)",
@@ -283,7 +297,8 @@ def main() -> int:
             "loss": float(loss.detach()),
             "roofline": {"bound": "hbm", "kernel": dominant[0], "launches": dominant[1],
                          "avg_launch_ms": dominant[2] / max(dominant[1], 1), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dominant[3] / max(dominant[1], 1)},
             "lift_fill_roofline": {"kernel": "k_expand (pp_temporal_fill)", "launches": n_fill,
                                    "avg_launch_ms": fill_ms / max(n_fill, 1),
                                    "achieved": (fill_b / (fill_ms * 1e-3) / 1e9) if fill_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
