@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--features", type=int, default=64)
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-events", type=int, default=14_000, help="events of the CPU-oracle sample (per-timestamp loop)")
+    ap.add_argument("--cpu-events", type=int, default=12_000, help="first size of the CPU-oracle sample (grows x1.5 until ~10 s)")
     return ap.parse_args()
 
 
@@ -108,41 +108,51 @@ def pmc_traffic(kernel_key: str, args) -> float | None:
 
 
 def cpu_baseline(args, seed: int) -> dict:
-    """The CPU oracle (port of the reference algorithm incl. its per-timestamp lift loop) on a bounded sample of
-    the same generator: events scaled down, nodes and delta scaled to keep E2/m of the full workload."""
+    """The CPU oracle (port of the reference algorithm incl. its per-timestamp lift loop) on a bounded sample of the same
+    generator: events and nodes scaled down together (E2/m of the full workload is preserved), largest sample that keeps the
+    reference-style loop within ~10-30 s on this host (its cost grows faster than quadratically in m)."""
     from oracle import dbgnn as od
     from oracle import model as om
-    scale = args.cpu_events / args.events
-    m = args.cpu_events
-    n = max(int(args.nodes * scale), 16)
-    span = args.span
-    delta = args.delta                                   # E2/m = m*delta/(n*span) is unchanged when m and n scale together
-    ei, t = synth_stream(m, n, span, seed, torch.device("cpu"))
-    t0 = time.perf_counter()
-    ei, t, _ = om.stable_time_sort(ei, t)
-    layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2, loop_lift=True)
-    t_lift = time.perf_counter() - t0
-    e2 = int(om.temporal_lift_sorted(ei, t, delta, n).size(1))
-    g = torch.Generator().manual_seed(seed + 1)
-    data = om.dbgnn_inputs(layers, 2, "last", x=torch.randn(n, args.features, generator=g),
-                           x_h=torch.randn(layers[2]["num_nodes"], args.features, generator=g))
-    y = torch.randint(0, args.classes, (n,), generator=g)
-    params = {k: v.requires_grad_(True) for k, v in od.init_params(args.classes, (args.features, args.features),
-                                                                   [args.features] * 3, seed=seed).items()}
-    opt = torch.optim.Adam(params.values(), lr=1e-3)
-    t0 = time.perf_counter()
-    opt.zero_grad()
-    loss = torch.nn.functional.cross_entropy(od.forward(params, data), y)
-    loss.backward()
-    opt.step()
-    t_train = time.perf_counter() - t0
+
+    def one_sample(m):
+        n = max(int(args.nodes * m / args.events), 16)
+        ei, t = synth_stream(m, n, args.span, seed, torch.device("cpu"))
+        t0 = time.perf_counter()
+        ei, t, _ = om.stable_time_sort(ei, t)
+        layers = om.layers_from_temporal(ei, t, n, delta=args.delta, max_order=2, loop_lift=True)
+        t_lift = time.perf_counter() - t0
+        e2 = int(om.temporal_lift_sorted(ei, t, args.delta, n).size(1))
+        g = torch.Generator().manual_seed(seed + 1)
+        data = om.dbgnn_inputs(layers, 2, "last", x=torch.randn(n, args.features, generator=g),
+                               x_h=torch.randn(layers[2]["num_nodes"], args.features, generator=g))
+        y = torch.randint(0, args.classes, (n,), generator=g)
+        params = {k: v.requires_grad_(True) for k, v in od.init_params(args.classes, (args.features, args.features),
+                                                                       [args.features] * 3, seed=seed).items()}
+        opt = torch.optim.Adam(params.values(), lr=1e-3)
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(od.forward(params, data), y)
+        loss.backward()
+        opt.step()
+        return m, n, e2, t_lift, time.perf_counter() - t0
+
+    best = None
+    m = min(args.cpu_events, args.events)
+    while True:
+        best = one_sample(m)
+        nxt = int(m * 1.5)
+        predicted = best[3] * (nxt / m) ** 3              # pessimistic growth law
+        if best[3] >= 8.0 or predicted > 40.0 or nxt > args.events or nxt > 30_000:
+            break
+        m = nxt
+    m, n, e2, t_lift, t_train = best
     # vectorised CPU lift (sort + searchsorted) on a larger sample, for context
     m2 = min(args.events, 1_000_000)
     n2 = max(int(args.nodes * m2 / args.events), 16)
-    ei2, t2 = synth_stream(m2, n2, span, seed + 2, torch.device("cpu"))
+    ei2, t2 = synth_stream(m2, n2, args.span, seed + 2, torch.device("cpu"))
     ei2, t2, _ = om.stable_time_sort(ei2, t2)
     t0 = time.perf_counter()
-    ho = om.temporal_lift_sorted(ei2, t2, delta, n2)
+    ho = om.temporal_lift_sorted(ei2, t2, args.delta, n2)
     t_sorted = time.perf_counter() - t0
     return {
         "value": e2 / (t_lift + t_train),
@@ -150,7 +160,7 @@ def cpu_baseline(args, seed: int) -> dict:
         "cores": torch.get_num_threads(),
         "kind": "port",
         "sample": f"oracle (reference per-timestamp lift loop + aggregation + 1 DBGNN train step) on m={m} events, "
-                  f"N={n}, delta={delta}, E2={e2}: lift+aggregate {t_lift:.2f}s, train step {t_train:.2f}s",
+                  f"N={n}, delta={args.delta}, E2={e2}: lift+aggregate {t_lift:.2f}s, train step {t_train:.2f}s",
         "events_per_s": m / (t_lift + t_train),
         "vectorised_lift_k_edges_per_s": ho.size(1) / t_sorted,
         "vectorised_lift_sample": f"sort+searchsorted CPU lift only, m={m2}, E2={ho.size(1)}, {t_sorted:.2f}s",
