@@ -1,0 +1,102 @@
+"""BASELINE.json configurations at FULL size on the GPU.
+
+configs[1] (100k nodes / 2M events, k=2) is still within reach of the vectorised CPU oracle, so the raw event graph and both
+aggregated layers are compared bit-for-bit.  configs[2] (1M nodes / 20M events, K=1..3, lift only) is checked through
+size-independent properties: lexicographic sortedness, the line-graph edge-count identity E_{k+1} = sum_e outdeg(dst_e),
+source-sortedness of every lifted index (the precondition of the next lift), conservation of weight under aggregation, and
+exact agreement with the oracle on a random sample of source events."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pp():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import pathpyg_amd
+    return pathpyg_amd
+
+
+def _stream(seed, m, n, span, zipf=False):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    src = torch.randint(0, n, (m,), generator=g, device=DEV)
+    if zipf:        # scale-free destinations: heavy hubs
+        u = torch.rand(m, generator=g, device=DEV, dtype=torch.float64)
+        dst = (n * u.pow(6.0)).long().clamp_(max=n - 1)
+    else:
+        dst = torch.randint(0, n, (m,), generator=g, device=DEV)
+    t = torch.randint(0, span, (m,), generator=g, device=DEV)
+    return torch.stack((src, dst)), t
+
+
+def test_config1_2m_events_matches_oracle_exactly(pp):
+    from oracle import model as om
+    n, m, delta = 100_000, 2_000_000, 100_000
+    ei, t = _stream(1, m, n, 1_000_000)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=n))
+    sei, st, _ = om.stable_time_sort(ei.cpu(), t.cpu())
+    assert torch.equal(g.data.edge_index.cpu(), sei)
+    ho = pp.algorithms.lift_order_temporal(g, delta)
+    want = om.layers_from_temporal(sei, st, n, delta=delta, max_order=2)
+    from oracle import lift as ol
+    assert torch.equal(ho.cpu(), ol.temporal_lift_sorted(sei, st, delta, n))
+    model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=2)
+    for k in (1, 2):
+        d = model.layers[k].data
+        for key in ("edge_index", "edge_weight", "node_sequence", "inverse_idx"):
+            assert torch.equal(d[key].cpu(), want[k][key]), (k, key)
+
+
+def _is_lexsorted(index):
+    a, b = index[0], index[1]
+    ok = (a[1:] > a[:-1]) | ((a[1:] == a[:-1]) & (b[1:] > b[:-1]))
+    return bool(ok.all())
+
+
+def test_config2_20m_scale_free_lift_properties(pp):
+    from oracle import lift as ol
+    n, m = 1_000_000, 20_000_000
+    ei, t = _stream(3, m, n, 10_000_000, zipf=True)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=n))
+    ei, t = g.data.edge_index, g.data.time
+    assert bool((t[1:] >= t[:-1]).all())
+    delta = 1_500_000                                                # ~3 continuations per event
+    ho = pp.algorithms.lift_order_temporal(g, delta)
+    e2 = ho.size(1)
+    assert e2 > m // 4 and ho.dtype == torch.int64 and ho.is_contiguous()
+    assert _is_lexsorted(ho)                                           # lexicographic (i, j), no duplicates
+    i, j = ho[0], ho[1]
+    assert bool((ei[1][i] == ei[0][j]).all())                           # head(i) == tail(j)
+    assert bool(((t[j] > t[i]) & (t[j] <= t[i] + delta)).all())        # inside the waiting-time window
+    # completeness on a sample of source events: exactly the oracle's continuations
+    rng = np.random.default_rng(0)
+    for i0 in rng.integers(0, m, 40).tolist():
+        cand = torch.nonzero((ei[0] == ei[1][i0]) & (t > t[i0]) & (t <= t[i0] + delta)).flatten()
+        lo = torch.searchsorted(i, torch.tensor(i0, device=DEV))
+        hi = torch.searchsorted(i, torch.tensor(i0, device=DEV), right=True)
+        assert torch.equal(j[lo:hi], cand)
+    # k = 3: line-graph lift of the event graph
+    from pathpyg_amd.algorithms.lift_order import lift_order_edge_index
+    ho3 = lift_order_edge_index(ho, num_nodes=m)
+    outdeg = torch.bincount(i, minlength=m)
+    assert ho3.size(1) == int(outdeg[j].sum())                          # E3 = sum_e outdeg(dst_e)
+    assert _is_lexsorted(ho3)
+    assert bool((ho[1][ho3[0]] == ho[0][ho3[1]]).all())                 # consecutive instance edges share the middle event
+    # aggregation K = 1..3 conserves the total weight and yields sorted, duplicate-free layers
+    model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=3, event_graph=ho)
+    totals = {1: m, 2: e2, 3: ho3.size(1)}
+    for k in (1, 2, 3):
+        d = model.layers[k].data
+        assert _is_lexsorted(d.edge_index)
+        assert float(d.edge_weight.double().sum()) == float(totals[k])
+        assert d.node_sequence.size(1) == k and d.node_sequence.size(0) == d.num_nodes
+        ns = d.node_sequence
+        key = ns[:, 0]
+        for c in range(1, k):
+            key = key * n + ns[:, c]
+        assert bool((key[1:] > key[:-1]).all())                         # unique rows in lexicographic order
+    del ol
