@@ -213,6 +213,38 @@ class Graph:
         ids = ids.tolist() if isinstance(ids, (np.ndarray, torch.Tensor)) else ids
         return list(zip(ids[0], ids[1]))
 
+    def degrees(self, mode: str = "in", edge_attr: str | None = None, return_tensor: bool = False):
+        """(Weighted) in- or out-degrees (reference graph.py:486-516): counts as int32, weighted sums in the dtype of the
+        attribute; a tensor with ``return_tensor`` else ``{node: degree}``.  Counting and the segment sums run on the GPU."""
+        from .. import _hip
+        ei = self.data.edge_index
+        dev = _dispatch.compute_device(ei)
+        which = ei[1] if mode == "in" else ei[0]
+        if not edge_attr:
+            d = _hip.degree(which.to(dev).contiguous(), self.n).to(torch.int32).to(ei.device)
+        else:
+            w = getattr(self.data, edge_attr, None)
+            if w is None:
+                raise AttributeError(f"graph has no edge attribute {edge_attr}")
+            wf = w.to(dev).to(torch.float32).reshape(-1, 1).contiguous()
+            if mode == "in":
+                ptr, perm = self.col_ptr.to(dev).to(torch.int32), self.csc_perm.to(dev).to(torch.int32)
+            else:
+                ptr, perm = self.row_ptr.to(dev).to(torch.int32), torch.arange(ei.size(1), device=dev, dtype=torch.int32)
+            d = _hip.spmm(ptr, perm, None, self.n, wf).reshape(-1).to(ei.device)       # segment sum over the node's edges
+            if not w.is_floating_point():
+                d = d.round().to(w.dtype)
+        if return_tensor:
+            return d
+        return {node: deg.item() for node, deg in zip(self.nodes, d)}
+
+    def transition_probabilities(self, edge_attr: str | None = None) -> torch.Tensor:
+        """Per-edge transition probability ``w_e / (weighted) out-degree of its source`` (reference graph.py:518-533)."""
+        out = self.degrees(mode="out", edge_attr=edge_attr, return_tensor=True)
+        ei = self.data.edge_index
+        w = torch.ones(ei.size(1), device=ei.device) if edge_attr is None else getattr(self.data, edge_attr)
+        return w / _dispatch.edge_attr(ei, out.to(w.dtype if w.is_floating_point() else torch.float32), "src")
+
     def successors(self, node) -> list:
         i = self.mapping.to_idx(node)
         ptr = self.row_ptr

@@ -5,7 +5,7 @@ Each layer ``k`` is a :class:`Graph` whose nodes are the distinct length-``k`` n
 input (walks or time-respecting paths) and whose weighted edges count their continuations.  All tensor work
 (event-graph lift, line-graph lifts, sequence extension, unique/coalesce) runs in HIP kernels; the
 higher-order ``IndexMap`` of every layer is created lazily instead of by a Python loop over nodes.
-The likelihood / order-selection methods of the reference (:243-509) are outside this build's scope.
+The likelihood / order-selection methods (:243-509) reuse the lift kernels for their path counts.
 """
 from __future__ import annotations
 
@@ -13,6 +13,7 @@ import logging
 from typing import Optional
 
 import torch
+from scipy.stats import chi2
 
 from .. import _dispatch
 from ..algorithms.lift_order import (
@@ -139,6 +140,119 @@ class MultiOrderModel:
                 m.layers[k] = chain.graph
                 m.layers[k].mapping = IndexMap.from_node_sequence(m.layers[1].mapping, chain.graph.data.node_sequence)
         return m
+
+    # ------------------------------------------------------------------ model selection
+    def get_mon_dof(self, max_order: Optional[int] = None, assumption: str = "paths") -> int:
+        """Degrees of freedom of the multi-order model up to ``max_order`` (reference multi_order_model.py:243-309).
+
+        "paths": sum over k of the number of length-k paths of the first-order topology (k-1 line-graph lifts of layer 1)
+        minus, per order, the nodes that start at least one length-k path (their transition rows sum to one);
+        "ngrams": all ``n^k (n-1)`` combinations.  The reference counts the row constraint with a sparse matrix power; here
+        ``starts_k = A starts_{k-1} > 0`` is propagated instead — same count, no sparse-sparse product."""
+        if max_order is None:
+            max_order = max(self.layers)
+        if max_order > max(self.layers):
+            logger.error("max_order cannot be larger than maximum order of multi-order network")
+            raise ValueError("max_order cannot be larger than maximum order of multi-order network")
+        g1 = self.layers[1]
+        n = int(g1.data.num_nodes)
+        dof = n - 1
+        if assumption == "paths":
+            from .. import _hip
+            edge_index = g1.data.edge_index
+            for k in range(1, max_order + 1):
+                if k > 1:
+                    num_nodes = 0 if edge_index.numel() == 0 else _dispatch.minmax(edge_index)[1] + 1
+                    edge_index = lift_order_edge_index(edge_index, num_nodes)
+                dof += int(edge_index.shape[1])                      # number of paths of length k
+            dev = _dispatch.compute_device(g1.data.edge_index)
+            ptr = g1.row_ptr.to(dev).to(torch.int32)
+            col = g1.col.to(dev).to(torch.int32).contiguous()
+            starts = torch.ones((n, 1), device=dev)
+            for k in range(1, max_order + 1):
+                starts = (_hip.spmm(ptr, col, None, n, starts) > 0).to(torch.float32)    # has a length-k path leaving it
+                dof -= int(starts.sum().item())
+        elif assumption == "ngrams":
+            for order in range(1, max_order + 1):
+                dof += (n ** order) * (n - 1)
+        else:
+            logger.error("Unknown assumption %s. Only 'path' and 'ngram' are accepted.", assumption)
+            raise ValueError(f"Unknown assumption {assumption}. Only 'path' and 'ngram' are accepted.")
+        return int(dof)
+
+    def get_zeroth_order_log_likelihood(self, dag_graph: Data) -> float:
+        """Log-likelihood of the walks' first nodes under the node-frequency model (reference multi_order_model.py:311-336)."""
+        frequencies = dag_graph.dag_weight
+        is_start = torch.ones(dag_graph.num_nodes, dtype=torch.bool, device=frequencies.device)
+        is_start[dag_graph.edge_index[1]] = False
+        start_nodes = dag_graph.node_sequence.squeeze()[is_start]
+        _, counts = torch.unique(dag_graph.node_sequence, return_counts=True)
+        emission = counts / counts.sum()
+        return torch.mul(frequencies, torch.log(emission[start_nodes])).sum().item()
+
+    def get_intermediate_order_log_likelihood(self, dag_graph: Data, order: int) -> float:
+        """Contribution of the first order-``order`` transition of every walk (reference multi_order_model.py:338-369)."""
+        frequencies = dag_graph.dag_weight
+        lengths_ho = dag_graph.dag_num_nodes - order                 # walks shrink by `order` nodes in order-k encoding
+        keep = lengths_ho > 0
+        frequencies = frequencies[keep]
+        kept = lengths_ho[keep]
+        first_of_walk = torch.cumsum(kept, 0) - kept                 # start position of each surviving walk
+        probs = self.layers[order].transition_probabilities()[self.layers[order + 1].data.inverse_idx[first_of_walk]]
+        return torch.mul(frequencies, torch.log(probs)).sum().item()
+
+    def get_mon_log_likelihood(self, dag_graph: Data, max_order: int = 1) -> float:
+        """Log-likelihood of the walks under the multi-order model with layers 0..``max_order``
+        (reference multi_order_model.py:371-409)."""
+        if max_order > 0:
+            llh = self.get_zeroth_order_log_likelihood(dag_graph)
+            for order in range(1, max_order):
+                llh += self.get_intermediate_order_log_likelihood(dag_graph, order)
+            top = self.layers[max_order]
+            probs = top.transition_probabilities(edge_attr="edge_weight")
+            return llh + (torch.log(probs) * top.data.edge_weight).sum().item()
+        frequencies = dag_graph.dag_weight
+        counts = torch.bincount(dag_graph.node_sequence.squeeze(), frequencies.repeat_interleave(dag_graph.dag_num_nodes))
+        emission = counts / counts.sum()
+        return torch.mul(torch.log(emission), counts).sum().item()
+
+    def likelihood_ratio_test(self, dag_graph: Data, max_order_null: int = 0, max_order: int = 1, assumption: str = "paths",
+                              significance_threshold: float = 0.01) -> tuple:
+        """Likelihood-ratio test of order ``max_order`` against ``max_order_null`` (reference multi_order_model.py:411-459):
+        ``(null rejected?, p-value)`` with ``x = -2 (log L0 - log L1)`` chi-square distributed in the dof difference."""
+        if max_order_null >= max_order:
+            logger.error("order of null hypothesis must be smaller than order of alternative hypothesis")
+            raise ValueError("order of null hypothesis must be smaller than order of alternative hypothesis")
+        if max_order > max(self.layers):
+            logger.error("order of hypotheses must be smaller than max. order of MultiOrderModel")
+            raise ValueError(f"order of hypotheses ({max_order_null} and {max_order}) must be smaller than max. order of "
+                             f"MultiOrderModel {max(self.layers)}")
+        x = -2 * (self.get_mon_log_likelihood(dag_graph, max_order=max_order_null)
+                  - self.get_mon_log_likelihood(dag_graph, max_order=max_order))
+        dof_diff = self.get_mon_dof(max_order, assumption=assumption) - self.get_mon_dof(max_order_null, assumption=assumption)
+        p = 1 - chi2.cdf(x, dof_diff)
+        return (p < significance_threshold), p
+
+    def estimate_order(self, dag_data: PathData, max_order: Optional[int] = None, significance_threshold: float = 0.01) -> int:
+        """Highest order whose layer significantly improves the likelihood of the walks (reference multi_order_model.py:461-509)."""
+        if max_order is None:
+            max_order = max(self.layers)
+        if max_order > max(self.layers):
+            logger.error("max_order cannot be larger than maximum order of multi-order network")
+            raise ValueError("max_order cannot be larger than maximum order of multi-order network")
+        if max_order <= 1:
+            logger.error("max_order must be larger than one")
+            raise ValueError("max_order must be larger than one")
+        ours = set(self.layers[1].mapping.node_ids)
+        if not set(dag_data.mapping.node_ids).issubset(ours):
+            logger.error("Input paths do not have same set of nodes as multi-order network")
+            raise ValueError("Input paths do not have same set of nodes as multi-order network")
+        accepted = 1
+        for k in range(2, max_order + 1):
+            if self.likelihood_ratio_test(dag_data.data, max_order_null=k - 1, max_order=k,
+                                          significance_threshold=significance_threshold)[0]:
+                accepted = k
+        return accepted
 
     def to_dbgnn_data(self, max_order: int = 2, mapping: str = "last", x: torch.Tensor | None = None,
                       x_h: torch.Tensor | None = None) -> Data:
