@@ -208,6 +208,14 @@ int pp_dense_f32(const float* A, const float* W, int w_transposed, int64_t n_row
  * one pass - the loss of the train step bench.py times (the reference ships no training loop). */
 int pp_cross_entropy_f32(const float* logits, const int64_t* target, int64_t n, int C, float* loss, float* dlogits, pp_stream_t stream);
 
+/* Whole backward of a dense layer y = x W^T (+ b) in one pass over dH [N,M] and x [N,K] (W is [M,K]; M, K in {16,32,64}):
+ *   d_in[N,K] = (dH . W) (*) ELU'(x) when fuse_act (x is then the stored activation of the layer below), colsum_in[K] = its column
+ *   sums (that layer's bias gradient); dW[M,K] = dH^T x; db[M] = column sums of dH.  d_in/colsum_in/db may be NULL.
+ * Replaces pp_dense_f32(input gradient) + pp_weight_grad_f32: 3 instead of 5 passes over N x 64 matrices. */
+size_t pp_dense_backward_ws_bytes(int64_t n_rows);
+int pp_dense_backward_f32(const float* dH, const float* X, const float* W, int64_t n_rows, int M, int K, int fuse_act, float* d_in,
+                          float* colsum_in, float* dW, float* db, void* ws, size_t ws_bytes, pp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -494,3 +494,24 @@ def cross_entropy(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = 
         grad = torch.empty_like(logits) if want_grad else None
         check(lib().pp_cross_entropy_f32(_p(logits), _p(target), n, c, _p(loss), _p(grad), _stream()), "pp_cross_entropy_f32")
     return loss[0], grad
+
+
+def dense_backward(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, fuse_act: bool, want_input_grad: bool, want_colsum: bool,
+                   want_bias: bool):
+    """Backward of ``y = x @ weight.T (+ b)`` in one pass: ``(d_in or None, colsum_in or None, dW, db or None)`` with
+    ``d_in = (dy @ weight) * elu'(x)`` when ``fuse_act``.  Shapes must satisfy :func:`dense_supported`."""
+    dev = require_device(dy, x, weight)
+    dy, x, weight = dy.contiguous(), x.contiguous(), weight.contiguous()
+    n, m = dy.shape
+    k = x.size(1)
+    L = lib()
+    with torch.cuda.device(dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_in = torch.empty((n, k), **f32) if want_input_grad else None
+        colsum = torch.empty(k, **f32) if (want_input_grad and want_colsum) else None
+        dw = torch.empty((m, k), **f32)
+        db = torch.empty(m, **f32) if want_bias else None
+        ws = _workspace(L.pp_dense_backward_ws_bytes(n), dev)
+        check(L.pp_dense_backward_f32(_p(dy), _p(x), _p(weight), n, m, k, 1 if fuse_act else 0, _p(d_in), _p(colsum), _p(dw), _p(db),
+                                      _p(ws), ws.numel(), _stream()), "pp_dense_backward_f32")
+    return d_in, colsum, dw, db

@@ -908,3 +908,202 @@ int pp_cross_entropy_f32(const float* logits, const int64_t* target, int64_t n, 
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// Whole backward of a dense layer y = x W^T (+ b) in ONE pass over its two big operands:
+//     d_in[N,K] = (dH . W) (*) ELU'(x)      colsum_in[K] = column sums of d_in        (gradient for the layer below, as in k_dense)
+//     dW[M,K]   = dH^T x                    db[M]        = column sums of dH           (this layer's parameter gradients)
+// Separately (k_dense + k_weight_grad) dH and x are each read twice: 5 feature-matrix passes; fused: 3 (read dH, read x, write d_in).
+// Per 16-row tile a wave runs two MFMA streams on v_mfma_f32_16x16x4_f32:
+//   rows x W    : A = dH quarter rows (float4 loads, lane = (row, k-quarter)), B = W in registers            -> d_in tile
+//   dH^T x rows : the contraction runs over the tile's 16 ROWS; both operands are natural coalesced row reads: A[i'][k] =
+//                 dH[row 4k+reg][col], B[k][j] = x[row 4k+reg][col] - the SAME registers that feed the ELU' epilogue.
+// dW lives in (M/16)(K/16) accumulators for the whole persistent wave, is folded through LDS per workgroup and summed in a fixed
+// order by k_weight_grad_reduce (partial layout [workgroup][64][64]); M, K <= 64.
+namespace pp {
+
+template <int M, int K>
+__global__ __launch_bounds__(kBlock) void k_dense_backward(const float* __restrict__ dH, const float* __restrict__ X, const float* __restrict__ W,
+                                                          int64_t n_rows, int fuse_act, float* __restrict__ d_in,
+                                                          float* __restrict__ colsum_in, float* __restrict__ partial_w,
+                                                          float* __restrict__ partial_b) {
+    constexpr int KQ = M / 4;            // dH columns per lane in the quarter-row layout
+    constexpr int MT = M / 16, CT = K / 16;
+    const int lane = lane_id(), i = lane & 15, kq = lane >> 4;
+    float b[KQ][CT];                     // W[k][j]: d_in = dH . W, W is [M, K]
+#pragma unroll
+    for (int t = 0; t < KQ; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) b[t][ct] = W[(kq * KQ + t) * K + ct * 16 + i];
+    f32x4 acc_w[MT][CT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc_w[mt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float col_in[CT], col_b[MT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) col_in[ct] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) col_b[mt] = 0.f;
+
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
+    float4 a_cur[KQ / 4], a_nxt[KQ / 4];
+    auto load_tile = [&](int64_t t, float4 (&dst)[KQ / 4]) {
+        const int64_t r = t * 16 + i;
+        const bool live = t < n_tiles && r < n_rows;
+#pragma unroll
+        for (int c = 0; c < KQ / 4; ++c)
+            dst[c] = live ? *(const float4*)(dH + r * M + kq * KQ + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    load_tile(tile, a_cur);
+    for (; tile < n_tiles; tile += n_waves) {
+        load_tile(tile + n_waves, a_nxt);
+        // natural-layout rows of this tile: x (ELU' epilogue AND B operand of dW) and dH (A operand of dW)
+        float xr[CT][4], hr[MT][4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t r = tile * 16 + 4 * kq + reg;
+            const bool live = r < n_rows;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) xr[ct][reg] = live ? X[r * K + ct * 16 + i] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hr[mt][reg] = live ? dH[r * M + mt * 16 + i] : 0.f;
+        }
+        f32x4 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KQ / 4; ++c) {
+            const float av[4] = {a_cur[c].x, a_cur[c].y, a_cur[c].z, a_cur[c].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b[4 * c + e][ct], acc[ct], 0, 0, 0);
+        }
+        // dW += dH_tile^T x_tile : step `reg` contracts the rows {reg, 4+reg, 8+reg, 12+reg} (k = lane>>4)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                col_b[mt] += hr[mt][reg];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc_w[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[mt][reg], xr[ct][reg], acc_w[mt][ct], 0, 0, 0);
+            }
+        if (d_in) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int64_t r = tile * 16 + 4 * kq + reg;
+                    if (r < n_rows) {
+                        float v = acc[ct][reg];
+                        if (fuse_act) {
+                            const float y = xr[ct][reg];
+                            v *= y > 0.f ? 1.f : y + 1.f;
+                        }
+                        col_in[ct] += v;
+                        d_in[r * K + ct * 16 + i] = v;
+                    }
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < KQ / 4; ++c) a_cur[c] = a_nxt[c];
+    }
+    if (colsum_in) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            float v = col_in[ct];
+            v += __shfl_xor(v, 16, kWave);
+            v += __shfl_xor(v, 32, kWave);
+            if (kq == 0) atomicAdd(&colsum_in[ct * 16 + i], v);
+        }
+    }
+    // fold the 4 waves' dW (and db) through LDS in wave order, one partial [64][64] tile per workgroup (zero padded)
+    __shared__ float s_tile[64 * 64];
+    __shared__ float s_bias[64];
+    for (int e = threadIdx.x; e < 64 * 64; e += kBlock) s_tile[e] = 0.f;
+    if (threadIdx.x < 64) s_bias[threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        if (wave_id() == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)          // C/D layout: row = 4*(lane>>4) + reg, col = lane&15
+                        s_tile[(mt * 16 + 4 * kq + reg) * 64 + ct * 16 + i] += acc_w[mt][ct][reg];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float v = col_b[mt];
+                v += __shfl_xor(v, 16, kWave);
+                v += __shfl_xor(v, 32, kWave);
+                if (kq == 0) s_bias[mt * 16 + i] += v;
+            }
+        }
+        __syncthreads();
+    }
+    float* out = partial_w + ((int64_t)blockIdx.x << 12);
+    for (int e = threadIdx.x; e < 64 * 64; e += kBlock) out[e] = s_tile[e];
+    if (partial_b && threadIdx.x < 64) partial_b[(int64_t)blockIdx.x * 64 + threadIdx.x] = s_bias[threadIdx.x];
+}
+
+template <int M>
+static int launch_dense_backward_k(int K, unsigned grid, hipStream_t st, const float* dH, const float* X, const float* W, int64_t n, int fuse,
+                                   float* d_in, float* colsum_in, float* pw, float* pb) {
+    switch (K) {
+        case 16: k_dense_backward<M, 16><<<grid, kBlock, 0, st>>>(dH, X, W, n, fuse, d_in, colsum_in, pw, pb); break;
+        case 32: k_dense_backward<M, 32><<<grid, kBlock, 0, st>>>(dH, X, W, n, fuse, d_in, colsum_in, pw, pb); break;
+        case 64: k_dense_backward<M, 64><<<grid, kBlock, 0, st>>>(dH, X, W, n, fuse, d_in, colsum_in, pw, pb); break;
+        default: return PP_ERR_ARG;
+    }
+    return PP_OK;
+}
+
+static inline int64_t dense_backward_blocks(int64_t n_rows) {
+    int64_t blocks = ceil_div(ceil_div(n_rows > 0 ? n_rows : 1, 16), kWavesPerBlock);
+    const int64_t cap = 256 * 2;                       // 2 workgroups (8 waves) per CU: ~230 registers per lane
+    return blocks > cap ? cap : blocks;
+}
+
+}  // namespace pp
+
+extern "C" {
+
+size_t pp_dense_backward_ws_bytes(int64_t n_rows) {
+    const int64_t blocks = pp::dense_backward_blocks(n_rows);
+    return pp::align_up((size_t)blocks * 4096 * sizeof(float)) + pp::align_up((size_t)blocks * 64 * sizeof(float));
+}
+
+// dH [N,M], X [N,K] (the layer's input), W [M,K].  d_in [N,K] / colsum_in [K] may be NULL (input gradient not needed),
+// db [M] may be NULL.  fuse_act: multiply d_in by ELU'(.) recovered from X as a stored activation.  M, K in {16, 32, 64}.
+int pp_dense_backward_f32(const float* dH, const float* X, const float* W, int64_t n_rows, int M, int K, int fuse_act, float* d_in,
+                          float* colsum_in, float* dW, float* db, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_dense_backward_f32: negative size");
+    PP_REQUIRE(pp_dense_supported(M, K), PP_ERR_ARG, "pp_dense_backward_f32: unsupported layer shape %dx%d", M, K);
+    PP_REQUIRE(ws_bytes >= pp_dense_backward_ws_bytes(n_rows), PP_ERR_WORKSPACE, "pp_dense_backward_f32: workspace too small");
+    PP_REQUIRE(((uintptr_t)dH) % 16 == 0, PP_ERR_ARG, "pp_dense_backward_f32: dH must be 16-byte aligned");
+    if (colsum_in) PP_HIP(hipMemsetAsync(colsum_in, 0, (size_t)K * sizeof(float), st));
+    const int64_t blocks = pp::dense_backward_blocks(n_rows);
+    float* pw = (float*)ws;
+    float* pb = (float*)((char*)ws + pp::align_up((size_t)blocks * 4096 * sizeof(float)));
+    int rc;
+    switch (M) {
+        case 16: rc = pp::launch_dense_backward_k<16>(K, (unsigned)blocks, st, dH, X, W, n_rows, fuse_act, d_in, colsum_in, pw, db ? pb : nullptr); break;
+        case 32: rc = pp::launch_dense_backward_k<32>(K, (unsigned)blocks, st, dH, X, W, n_rows, fuse_act, d_in, colsum_in, pw, db ? pb : nullptr); break;
+        default: rc = pp::launch_dense_backward_k<64>(K, (unsigned)blocks, st, dH, X, W, n_rows, fuse_act, d_in, colsum_in, pw, db ? pb : nullptr); break;
+    }
+    if (rc != PP_OK) return rc;
+    PP_LAUNCH_CHECK();
+    const int outs = M * K + (db ? M : 0);
+    pp::k_weight_grad_reduce<<<(unsigned)pp::ceil_div(outs, pp::kBlock / pp::kWgSlices), pp::kBlock, 0, st>>>(pw, db ? pb : nullptr, blocks, M, K, dW, db);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // extern "C"

@@ -84,8 +84,13 @@ class _Dense(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dw = db = dact = None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        want_sum = ctx.fuse_act and ctx.has_act_bias and ctx.needs_input_grad[4]
+        if ctx.fast and ctx.needs_input_grad[0] and need_w:
+            # everything in one pass over dy and x: input gradient (+ fused ELU' and the lower layer's bias gradient), dW, db
+            dx, dact, dw, db = _hip.dense_backward(dy, x, weight, ctx.fuse_act, True, want_sum, ctx.has_bias)
+            return dx, dw, db, None, dact
         if ctx.needs_input_grad[0]:
-            want_sum = ctx.has_act_bias and ctx.needs_input_grad[4]
             if ctx.fuse_act:
                 if ctx.fast:
                     dx, dact = _hip.dense(dy, weight, False, None, grad_act=x, want_colsum=want_sum)
@@ -93,7 +98,7 @@ class _Dense(torch.autograd.Function):
                     dx, dact = _hip.act_backward(dy @ weight, x, True, want_dpre=True, want_dbias=want_sum)
             else:
                 dx = _hip.dense(dy, weight, False)[0] if ctx.fast else dy @ weight
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if need_w:
             dw, db = _hip.weight_grad(dy, x, want_bias=ctx.has_bias)
         return dx, dw, db, None, dact
 

@@ -199,3 +199,24 @@ def test_cross_entropy_kernel(pp, n, c):
     (got * 2).backward()
     torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(zg.grad.cpu(), 2 * z.grad, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("n,m,k", [(1, 16, 16), (17, 64, 64), (1000, 32, 64), (70_001, 64, 64), (4097, 64, 16)])
+def test_dense_backward_kernel(pp, n, m, k):
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(n + m + k)
+    dy = torch.randn(n, m, generator=g)
+    x = F.elu(torch.randn(n, k, generator=g))
+    w = torch.randn(m, k, generator=g)
+    d_in, colsum, dw, db = _hip.dense_backward(dy.to(DEV), x.to(DEV), w.to(DEV), True, True, True, True)
+    want_in = (dy @ w) * torch.where(x > 0, torch.ones_like(x), x + 1)
+    torch.testing.assert_close(d_in.cpu(), want_in, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(colsum.cpu(), want_in.sum(0), rtol=1e-4, atol=1e-4 * float(want_in.abs().sum(0).max() + 1))
+    ref = dy.double().t() @ x.double()
+    torch.testing.assert_close(dw.cpu().double(), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max() + 1e-9))
+    torch.testing.assert_close(db.cpu().double(), dy.double().sum(0), rtol=1e-5, atol=1e-5 * float(dy.abs().sum(0).max() + 1e-9))
+    d2, c2, dw2, db2 = _hip.dense_backward(dy.to(DEV), x.to(DEV), w.to(DEV), False, True, False, False)
+    torch.testing.assert_close(d2.cpu(), dy @ w, rtol=2e-5, atol=2e-5)
+    assert c2 is None and db2 is None and torch.equal(dw2, dw)
+    d3, c3, dw3, _ = _hip.dense_backward(dy.to(DEV), x.to(DEV), w.to(DEV), False, False, False, False)
+    assert d3 is None and torch.equal(dw3, dw)
