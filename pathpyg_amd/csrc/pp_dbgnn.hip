@@ -17,8 +17,6 @@
 // The dense X*W^T products stay plain library GEMMs (MFMA through rocBLAS) on the Python side.
 #include "pp_internal.h"
 
-#include <stdlib.h>
-
 namespace pp {
 
 // ------------------------------------------------------------------ plan construction
@@ -37,26 +35,6 @@ __global__ __launch_bounds__(kBlock) void k_last_self_loop(const int64_t* __rest
     if (e >= n_edges) return;
     const int64_t r = edge_index[e];
     if (r >= 0 && r < n_nodes && r == edge_index[n_edges + e]) atomicMax(&last_loop[r], (int32_t)e);
-}
-
-// weighted in-degree over the destination-grouped edge list + the (completed) self loop -> d^-1/2 and the loop weight
-__global__ __launch_bounds__(kBlock) void k_gcn_degree(const int64_t* __restrict__ edge_index, int64_t n_edges, const float* __restrict__ w,
-                                                      const uint32_t* __restrict__ by_dst, const uint32_t* __restrict__ dst_ptr,
-                                                      const int32_t* __restrict__ last_loop, int64_t n_nodes, float* __restrict__ dinv,
-                                                      float* __restrict__ loop_w) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_nodes) return;
-    const float lw = last_loop[i] >= 0 ? (w ? w[last_loop[i]] : 1.0f) : 1.0f;
-    float deg = 0.0f;
-    for (uint32_t p = dst_ptr[i]; p < dst_ptr[i + 1]; ++p) {
-        const uint32_t e = by_dst[p];
-        if (edge_index[e] != i) deg += w ? w[e] : 1.0f;          // existing self loops are replaced by the one below
-    }
-    deg += lw;
-    float d = 1.0f / sqrtf(deg);                                  // deg^-1/2 ; inf -> 0 like masked_fill_(== inf, 0)
-    if (isinf(d)) d = 0.0f;
-    dinv[i] = d;
-    loop_w[i] = lw;
 }
 
 __global__ __launch_bounds__(kBlock) void k_gcn_coefficients(const int64_t* __restrict__ edge_index, int64_t n_edges, const float* __restrict__ w,
@@ -118,12 +96,6 @@ __global__ __launch_bounds__(kBlock) void k_ptr_from_sorted_i64_i32(const int64_
     if (a < -1) a = -1;
     if (b > num_rows) b = num_rows;
     for (int64_t v = a + 1; v <= b; ++v) ptr[v] = (int32_t)p;
-}
-
-__global__ __launch_bounds__(kBlock) void k_self_coefficient(const float* __restrict__ dinv, const float* __restrict__ loop_w, int64_t n,
-                                                            float* __restrict__ self_coef) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) self_coef[i] = dinv[i] * loop_w[i] * dinv[i];
 }
 
 __global__ __launch_bounds__(kBlock) void k_u32_to_i32_ptr(const uint32_t* __restrict__ in, int64_t n, int32_t* __restrict__ out) {
@@ -301,7 +273,6 @@ struct PlanWs {
     uint32_t* ptr;         // [N+1]
     int32_t* last_loop;    // [N]
     float* dinv;           // [N]
-    float* loop_w;         // [N]
     void* scratch;
     size_t scratch_bytes;
     size_t total_bytes;
@@ -317,7 +288,6 @@ static PlanWs carve_plan(void* ws, int64_t e, int64_t n) {
     w.ptr = a.take<uint32_t>(n + 1);
     w.last_loop = a.take<int32_t>(n);
     w.dinv = a.take<float>(n);
-    w.loop_w = a.take<float>(n);
     w.scratch_bytes = sort_ws_bytes(e, 4);
     w.scratch = a.take<char>((int64_t)w.scratch_bytes);
     w.total_bytes = a.used;
@@ -342,16 +312,8 @@ static int group_by(const int64_t* index, int64_t e, int64_t n_groups, PlanWs& w
 static int launch_spmm(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* X, int F, const float* self_coef,
                        const float* S, const float* bias, int act, float* Y, hipStream_t st) {
     if (n_rows == 0 || F == 0) return PP_OK;
-    static const int rows_per_group = getenv("PP_SPMM_ROWS") ? atoi(getenv("PP_SPMM_ROWS")) : 2;
-#define PP_SPMM_V4(L)                                                                                                                   \
-    do {                                                                                                                                \
-        if (rows_per_group == 1)                                                                                                        \
-            k_spmm_v4<L, 1><<<(unsigned)ceil_div(n_rows, kBlock / L), kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, Y); \
-        else if (rows_per_group == 4)                                                                                                   \
-            k_spmm_v4<L, 4><<<(unsigned)ceil_div(n_rows, (kBlock / L) * 4), kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, Y); \
-        else                                                                                                                            \
-            k_spmm_v4<L, 2><<<(unsigned)ceil_div(n_rows, (kBlock / L) * 2), kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, Y); \
-    } while (0)
+#define PP_SPMM_V4(L) \
+    k_spmm_v4<L, 2><<<(unsigned)ceil_div(n_rows, (kBlock / L) * 2), kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, Y)
 #define PP_SPMM_S1(L) k_spmm_s1<L><<<(unsigned)ceil_div(n_rows, kBlock / L), kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, Y)
     const bool vec = (F % 4 == 0) && (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)S | (uintptr_t)bias) % 16 == 0);
     if (vec) {
