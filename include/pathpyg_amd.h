@@ -166,13 +166,14 @@ int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_e
 
 /* CSR views of DBGNN's bipartite_edge_index [2,n_pairs] (row 0: higher-order node, row 1: first-order node),
  * src/pathpyG/nn/dbgnn.py:64-69: in_* grouped by first-order node (+ its in-degree as float), out_* by higher-order node.
+ * src_sorted != 0: row 0 is non-decreasing (arange for the reference's "last"/"first" mappings): no source-major sort.
  * pair_value (optional, with in_val/out_val): a coefficient per pair carried into both groupings — this makes the call a
  * general RECTANGULAR plan builder (sources x destinations), used for the destination-partitioned multi-GPU DBGNN where a rank
  * owns a slice of the destination rows but aggregates from all source rows.
  * Workspace: pp_gcn_plan_ws_bytes(n_pairs, max(n_ho, n_fo)). */
-int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n_ho, int64_t n_fo, const float* pair_value, int32_t* in_ptr,
-                      int32_t* in_idx, float* in_val, float* in_degree, int32_t* out_ptr, int32_t* out_idx, float* out_val, void* ws,
-                      size_t ws_bytes, pp_stream_t stream);
+int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n_ho, int64_t n_fo, int src_sorted, const float* pair_value,
+                      int32_t* in_ptr, int32_t* in_idx, float* in_val, float* in_degree, int32_t* out_ptr, int32_t* out_idx, float* out_val,
+                      void* ws, size_t ws_bytes, pp_stream_t stream);
 const int64_t* pp_plan_result_ptr(void* ws);
 
 /* Y[r,:] = act( sum_{p in [ptr[r],ptr[r+1])} val[p] * X[idx[p],:] + self_coef[r] * S[r,:] + bias ),  X:[*,F], Y:[n_rows,F] fp32.

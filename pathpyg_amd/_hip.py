@@ -385,6 +385,7 @@ def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_val
     nb = bi.size(1)
     if pair_value is not None:
         pair_value = pair_value.to(torch.float32).contiguous()
+    src_sorted = nb < 2 or is_sorted(bi[0])
     L = lib()
     with torch.cuda.device(dev):
         i32 = dict(dtype=torch.int32, device=dev)
@@ -396,7 +397,7 @@ def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_val
         if pair_value is not None:
             plan.fwd_val, plan.bwd_val = torch.empty(nb, **f32), torch.empty(nb, **f32)
         ws = _workspace(L.pp_gcn_plan_ws_bytes(nb, max(n_ho, n_fo)), dev)
-        check(L.pp_bipartite_plan(_p(bi), nb, n_ho, n_fo, _p(pair_value), _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val),
+        check(L.pp_bipartite_plan(_p(bi), nb, n_ho, n_fo, 1 if src_sorted else 0, _p(pair_value), _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val),
                                   _p(plan.self_coef), _p(plan.bwd_ptr), _p(plan.bwd_idx), _p(plan.bwd_val), _p(ws), ws.numel(), _stream()),
               "pp_bipartite_plan")
         _bad_index(_result(ws)[1], "BipartiteGraphOperator")

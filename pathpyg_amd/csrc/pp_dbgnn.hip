@@ -403,9 +403,9 @@ int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_e
 }
 
 // bipartite higher-order -> first-order projection plan: forward rows = first-order nodes, backward rows = higher-order nodes
-int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n_ho, int64_t n_fo, const float* pair_value, int32_t* in_ptr,
-                      int32_t* in_idx, float* in_val, float* in_degree, int32_t* out_ptr, int32_t* out_idx, float* out_val, void* ws,
-                      size_t ws_bytes, pp_stream_t stream) {
+int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n_ho, int64_t n_fo, int src_sorted, const float* pair_value,
+                      int32_t* in_ptr, int32_t* in_idx, float* in_val, float* in_degree, int32_t* out_ptr, int32_t* out_idx, float* out_val,
+                      void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_pairs >= 0 && n_ho >= 0 && n_fo >= 0, PP_ERR_ARG, "pp_bipartite_plan: negative size");
     const int64_t nmax = n_ho > n_fo ? n_ho : n_fo;
@@ -414,6 +414,10 @@ int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_bipartite_plan: workspace too small");
     PP_HIP(hipMemsetAsync(w.status, 0, 2 * sizeof(int64_t), st));
     const unsigned egrid = (unsigned)ceil_div(n_pairs > 0 ? n_pairs : 1, kBlock);
+    if (n_pairs > 0) {      // validate the sources (the destinations are validated by group_by)
+        k_index_key<<<egrid, kBlock, 0, st>>>(bipartite_index, n_pairs, n_ho, w.keys, w.status + 1);
+        PP_LAUNCH_CHECK();
+    }
     int rc = group_by(bipartite_index + n_pairs, n_pairs, n_fo, w, st);           // by first-order destination
     if (rc != PP_OK) return rc;
     k_u32_to_i32_ptr<<<(unsigned)ceil_div(n_fo + 1, kBlock), kBlock, 0, st>>>(w.ptr, n_fo + 1, in_ptr);
@@ -429,6 +433,16 @@ int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n
             k_gather_f32<<<egrid, kBlock, 0, st>>>(pair_value, w.order, n_pairs, in_val);
             PP_LAUNCH_CHECK();
         }
+    }
+    if (src_sorted) {       // bipartite_edge_index[0] = arange(U) for the "last"/"first" mappings: the pair order IS the grouping
+        k_ptr_from_sorted_i64_i32<<<(unsigned)ceil_div(n_pairs + 1, kBlock), kBlock, 0, st>>>(bipartite_index, n_pairs, n_ho, out_ptr);
+        PP_LAUNCH_CHECK();
+        if (n_pairs > 0) {
+            k_gather_index<<<egrid, kBlock, 0, st>>>(bipartite_index + n_pairs, nullptr, n_pairs, out_idx);
+            PP_LAUNCH_CHECK();
+            if (pair_value && out_val) PP_HIP(hipMemcpyAsync(out_val, pair_value, (size_t)n_pairs * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        return PP_OK;
     }
     rc = group_by(bipartite_index, n_pairs, n_ho, w, st);                        // by higher-order source
     if (rc != PP_OK) return rc;

@@ -21,17 +21,35 @@ void set_error(const char* fmt, ...) {
 constexpr int kScanItems = 8;                       // consecutive items per thread
 constexpr int kScanTile = kBlock * kScanItems;      // 2048 items per workgroup
 
+// 8 consecutive items of one lane: 16-byte loads when the array is 16-byte aligned (always, for torch allocations) and the
+// lane's chunk lies fully inside the array; scalar loads otherwise.
+template <typename InT>
+__device__ __forceinline__ void load_items(const InT* __restrict__ in, int64_t base, int64_t n, bool aligned, int64_t (&v)[8]) {
+    if (aligned && base + 8 <= n) {
+        constexpr int kVec = 16 / sizeof(InT);               // items per 16-byte load
+        struct alignas(16) Chunk { InT x[kVec]; };
+#pragma unroll
+        for (int c = 0; c < 8 / kVec; ++c) {
+            const Chunk ch = *reinterpret_cast<const Chunk*>(in + base + c * kVec);
+#pragma unroll
+            for (int e = 0; e < kVec; ++e) v[c * kVec + e] = (int64_t)ch.x[e];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = base + k < n ? (int64_t)in[base + k] : 0;
+    }
+}
+
 // ---- pass 1: one partial sum per tile ---------------------------------------------------------
 template <typename InT>
 __global__ __launch_bounds__(kBlock) void k_tile_sums(const InT* __restrict__ in, int64_t n, int64_t* __restrict__ tile_sum) {
     __shared__ int64_t part[kWavesPerBlock];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int64_t v[kScanItems];
+    load_items<InT>(in, base, n, ((uintptr_t)in & 15) == 0, v);
     int64_t s = 0;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        int64_t i = base + k;
-        if (i < n) s += (int64_t)in[i];
-    }
+    for (int k = 0; k < kScanItems; ++k) s += v[k];
     s = wave_sum(s);
     if (lane_id() == 0) part[wave_id()] = s;
     __syncthreads();
@@ -65,13 +83,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(const InT* __restrict__ i
     __shared__ int64_t scratch[kWavesPerBlock + 1];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     int64_t v[kScanItems];
+    load_items<InT>(in, base, n, ((uintptr_t)in & 15) == 0, v);
     int64_t s = 0;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        int64_t i = base + k;
-        v[k] = i < n ? (int64_t)in[i] : 0;
-        s += v[k];
-    }
+    for (int k = 0; k < kScanItems; ++k) s += v[k];
     int64_t tot;
     int64_t run = tile_base[blockIdx.x] + block_exclusive_sum(s, scratch, &tot);
 #pragma unroll
