@@ -236,14 +236,14 @@ def main() -> int:
     # shapes (nnz, source rows) of each CSR are recorded when the plan is built
     orig_gcn_plan, orig_bip_plan = _hip.gcn_plan, _hip.bipartite_plan
 
-    def gcn_plan(edge_index, edge_weight, num_nodes):
-        p = orig_gcn_plan(edge_index, edge_weight, num_nodes)
+    def gcn_plan(edge_index, edge_weight, num_nodes, *a, **kw):
+        p = orig_gcn_plan(edge_index, edge_weight, num_nodes, *a, **kw)
         spmm_bytes.shape_of[p.fwd_ptr.data_ptr()] = (p.fwd_idx.numel(), num_nodes)
         spmm_bytes.shape_of[p.bwd_ptr.data_ptr()] = (p.bwd_idx.numel(), num_nodes)
         return p
 
-    def bip_plan(bip, n_ho_, n_fo_):
-        p = orig_bip_plan(bip, n_ho_, n_fo_)
+    def bip_plan(bip, n_ho_, n_fo_, *a, **kw):
+        p = orig_bip_plan(bip, n_ho_, n_fo_, *a, **kw)
         spmm_bytes.shape_of[p.fwd_ptr.data_ptr()] = (p.fwd_idx.numel(), n_ho_)
         spmm_bytes.shape_of[p.bwd_ptr.data_ptr()] = (p.bwd_idx.numel(), n_fo_)
         return p
@@ -262,6 +262,20 @@ def main() -> int:
         barrier()
         elapsed = time.perf_counter() - t0
         spmm_clock.enabled = fill_clock.enabled = False
+    # untimed extra: the k=2 -> k=3 line-graph lift of the same event graph (the lift kernel WITHOUT the continuation-list gather)
+    k3 = None
+    if rank == 0:
+        ho = pp.algorithms.lift_order_temporal(g, args.delta)
+        with KernelClock(L, "pp_linegraph_fill", lambda e, n, total, *r: 16 * total) as lg_clock:
+            lg_clock.enabled = True
+            for _ in range(3):
+                e3 = pp.algorithms.lift_order_edge_index(ho, num_nodes=args.events).size(1)
+            torch.cuda.synchronize()
+        n_lg, lg_ms, lg_b = lg_clock.summary()
+        k3 = {"kernel": "k_tile_sources + k_expand<no list> (pp_linegraph_fill)", "E3": e3, "launches": n_lg,
+              "avg_launch_ms": lg_ms / max(n_lg, 1), "achieved": lg_b / (lg_ms * 1e-3) / 1e9 if lg_ms > 0 else 0.0,
+              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (lg_b / (lg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lg_ms > 0 else 0.0}
+        del ho
     if launched:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -314,6 +328,7 @@ def main() -> int:
                                    "achieved": (fill_b / (fill_ms * 1e-3) / 1e9) if fill_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": (fill_b / (fill_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fill_ms > 0 else 0.0},
         }
+        line["linegraph_fill_roofline"] = k3
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, seed=11)
         print(json.dumps(line), flush=True)

@@ -350,9 +350,12 @@ class CsrPlan:
             setattr(self, k, kw.get(k))
 
 
-def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nodes: int, row_sorted: bool | None = None) -> CsrPlan:
+def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nodes: int, row_sorted: bool | None = None,
+             status_out: list | None = None) -> CsrPlan:
     """GCN normalisation of a weighted graph, once per graph (see pp_gcn_plan in the C header).
-    ``row_sorted=None`` checks on the device whether the sources are non-decreasing (one tiny kernel + 8-byte read)."""
+    ``row_sorted=None`` checks on the device whether the sources are non-decreasing (one tiny kernel + 8-byte read).
+    ``status_out``: append the device status word instead of reading it now (the caller checks several plans with ONE
+    device-to-host copy, see :func:`check_plan_status`)."""
     ei = _edge_index(edge_index)
     if row_sorted is None:
         row_sorted = ei.size(1) < 2 or is_sorted(ei[0])
@@ -373,11 +376,22 @@ def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nod
         ws = _workspace(L.pp_gcn_plan_ws_bytes(e, num_nodes), dev)
         check(L.pp_gcn_plan(_p(ei), _p(edge_weight), e, num_nodes, 1 if row_sorted else 0, _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val), _p(plan.bwd_ptr),
                             _p(plan.bwd_idx), _p(plan.bwd_val), _p(plan.self_coef), _p(ws), ws.numel(), _stream()), "pp_gcn_plan")
-        _bad_index(_result(ws)[1], "GCNConv")
+        if status_out is None:
+            _bad_index(_result(ws)[1], "GCNConv")
+        else:
+            status_out.append(ws[8:16].view(torch.int64).clone())
     return plan
 
 
-def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_value: torch.Tensor | None = None) -> CsrPlan:
+def check_plan_status(statuses: list, what: str = "DBGNN") -> None:
+    """One device-to-host copy for the status words collected by several plan builders."""
+    if statuses:
+        if int(torch.cat(statuses).max().item()) & 1:
+            raise IndexError(f"{what}: node index out of range")
+
+
+def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_value: torch.Tensor | None = None,
+                   src_sorted: bool | None = None, status_out: list | None = None) -> CsrPlan:
     """CSR pair of a [2, n_pairs] (source, destination) index between two node sets (``n_ho`` sources, ``n_fo``
     destinations); ``self_coef`` = in-degree of every destination.  ``pair_value``: optional coefficient per pair."""
     bi = _edge_index(bipartite_index)
@@ -385,7 +399,8 @@ def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_val
     nb = bi.size(1)
     if pair_value is not None:
         pair_value = pair_value.to(torch.float32).contiguous()
-    src_sorted = nb < 2 or is_sorted(bi[0])
+    if src_sorted is None:
+        src_sorted = nb < 2 or is_sorted(bi[0])
     L = lib()
     with torch.cuda.device(dev):
         i32 = dict(dtype=torch.int32, device=dev)
@@ -400,7 +415,10 @@ def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_val
         check(L.pp_bipartite_plan(_p(bi), nb, n_ho, n_fo, 1 if src_sorted else 0, _p(pair_value), _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val),
                                   _p(plan.self_coef), _p(plan.bwd_ptr), _p(plan.bwd_idx), _p(plan.bwd_val), _p(ws), ws.numel(), _stream()),
               "pp_bipartite_plan")
-        _bad_index(_result(ws)[1], "BipartiteGraphOperator")
+        if status_out is None:
+            _bad_index(_result(ws)[1], "BipartiteGraphOperator")
+        else:
+            status_out.append(ws[8:16].view(torch.int64).clone())
     return plan
 
 

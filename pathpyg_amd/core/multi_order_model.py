@@ -271,7 +271,7 @@ class MultiOrderModel:
             x = g.data.x if g.data.x is not None else torch.eye(n, n, device=dev)
         if x_h is None:
             x_h = torch.eye(n_ho, n_ho, device=g_ho.data.edge_index.device)
-        return Data(
+        out = Data(
             num_nodes=n,
             num_ho_nodes=n_ho,
             x=x,
@@ -283,6 +283,9 @@ class MultiOrderModel:
             bipartite_edge_index=generate_bipartite_edge_index(g, g_ho, mapping=mapping, device=dev),
             y=g.data.y,
         )
+        # facts DBGNN.forward would otherwise have to verify on the device (every Graph's edge index is row-sorted)
+        object.__setattr__(out, "_pp_hints", {"rows_sorted": True, "bipartite_sources_sorted": mapping in ("last", "first")})
+        return out
 
 
 class _LiftChain:

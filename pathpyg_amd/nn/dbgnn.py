@@ -214,12 +214,19 @@ class DBGNN(Module):
     def forward(self, data) -> torch.Tensor:
         x, x_h = data.x, data.x_h
         n_fo, n_ho = int(data.num_nodes), int(data.num_ho_nodes)
+        # bundles made by MultiOrderModel.to_dbgnn_data carry hints (every Graph's edge index is row-sorted, the bipartite
+        # sources are arange) that save three device round trips; foreign bundles are checked on the device instead
+        hints = getattr(data, "_pp_hints", None) or {}
+        rows_sorted = True if hints.get("rows_sorted") else None
+        bip_sorted = True if hints.get("bipartite_sources_sorted") else None
+        pending = []
         plan_fo = _cached(data, "fo", (data.edge_index, data.edge_weights),
-                          lambda: _hip.gcn_plan(data.edge_index, data.edge_weights, n_fo))
+                          lambda: _hip.gcn_plan(data.edge_index, data.edge_weights, n_fo, rows_sorted, pending))
         plan_ho = _cached(data, "ho", (data.edge_index_higher_order, data.edge_weights_higher_order),
-                          lambda: _hip.gcn_plan(data.edge_index_higher_order, data.edge_weights_higher_order, n_ho))
+                          lambda: _hip.gcn_plan(data.edge_index_higher_order, data.edge_weights_higher_order, n_ho, rows_sorted, pending))
         plan_bi = _cached(data, "bi", (data.bipartite_edge_index,),
-                          lambda: _hip.bipartite_plan(data.bipartite_edge_index, n_ho, n_fo))
+                          lambda: _hip.bipartite_plan(data.bipartite_edge_index, n_ho, n_fo, None, bip_sorted, pending))
+        _hip.check_plan_status(pending)
 
         if self.p_dropout > 0 and self.training:
             for layer in self.first_order_layers:                   # dropout -> GCNConv -> ELU (fused into the aggregation)
