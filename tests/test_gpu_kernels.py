@@ -266,3 +266,47 @@ def test_temporal_lift_edge_range_shards_reassemble(hip):
             end = halo_end(t, hi, 250)
             parts.append(hip.temporal_lift(cu(ei[:, lo:end]), cu(t[lo:end]), 700, 250, n_own=hi - lo, id_offset=lo))
         assert torch.equal(torch.cat(parts, dim=1), full)
+
+
+@pytest.mark.parametrize("case", ["all_same_time", "negative_delta", "huge_delta", "one_hub", "self_loops_only", "float_ties_exact_boundary"])
+def test_temporal_lift_adversarial_streams(hip, case):
+    """Edge cases of the window logic against the oracle (which is pinned to the reference source on the golden vectors)."""
+    from oracle import lift as ol
+    rng = np.random.default_rng(sum(map(ord, case)))
+    m, n, delta = 20_000, 40, 5
+    ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+    t = torch.from_numpy(np.sort(rng.integers(0, 3000, m)))
+    if case == "all_same_time":
+        t = torch.full((m,), 7, dtype=torch.long)                     # no pair at all: t_j > t_i never holds
+    elif case == "negative_delta":
+        delta = -3
+    elif case == "huge_delta":
+        m = 3000
+        ei, t, delta = ei[:, :m], t[:m], 10 ** 15                     # every later event of the head node continues
+    elif case == "one_hub":
+        ei[1, :] = 3                                                  # every event points at node 3
+        ei[0, ::2] = 3                                                # and half of them leave it: long per-node list, big counts
+    elif case == "self_loops_only":
+        ei[1] = ei[0]
+    elif case == "float_ties_exact_boundary":
+        t = torch.from_numpy(np.sort(rng.integers(0, 400, m)) * 0.25)  # exact binary fractions: t_j == t_i + delta happens often
+        delta = 0.75
+    want = ol.temporal_lift_sorted(ei, t, delta, n)
+    got = hip.temporal_lift(cu(ei), cu(t), n, delta)
+    assert got.shape == want.shape
+    assert torch.equal(got.cpu(), want)
+    if case in ("all_same_time", "negative_delta"):
+        assert got.size(1) == 0
+
+
+def test_linegraph_lift_hub_and_empty(hip):
+    from oracle import lift as ol
+    # star: every edge points into the hub 0, which has 3000 out-edges -> 3000 lifted edges per in-edge
+    src = torch.cat((torch.zeros(3000, dtype=torch.long), torch.arange(1, 501)))
+    dst = torch.cat((torch.arange(1, 3001) % 900 + 1, torch.zeros(500, dtype=torch.long)))
+    ei = torch.stack((src, dst))
+    assert torch.equal(hip.linegraph_lift(cu(ei), 3001).cpu(), ol.line_graph_lift(ei, 3001))
+    empty = torch.empty((2, 0), dtype=torch.long)
+    assert hip.linegraph_lift(cu(empty), 5).shape == (2, 0)
+    no_continuation = torch.tensor([[0, 1], [2, 3]])                 # nobody leaves nodes 2 and 3
+    assert hip.linegraph_lift(cu(no_continuation), 4).shape == (2, 0)
