@@ -11,8 +11,8 @@ from .data import Data  # noqa: F401
 from . import algorithms, utils  # noqa: F401,E402
 
 
-def __getattr__(name):          # ``pp.nn`` pulls in torch.nn machinery; load it on demand
-    if name == "nn":
+def __getattr__(name):          # ``pp.nn`` / ``pp.io`` (pandas) / ``pp.distributed`` are loaded on demand
+    if name in ("nn", "io", "distributed"):
         import importlib
-        return importlib.import_module(".nn", __name__)
+        return importlib.import_module("." + name, __name__)
     raise AttributeError(name)
