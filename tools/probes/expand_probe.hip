@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o tools/probes/expand_probe tools/probes/expand_probe.hip   (stand-alone; run on the GPU box)
 // Stand-alone probe: where does the fill kernel's time go?  hipcc --offload-arch=gfx950 -O3 -o /tmp/expand_probe expand_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdint.h>
