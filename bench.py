@@ -251,7 +251,7 @@ def main() -> int:
     _hip.gcn_plan, _hip.bipartite_plan = gcn_plan, bip_plan
 
     with KernelClock(L, "pp_spmm_f32", spmm_bytes) as spmm_clock, \
-            KernelClock(L, "pp_temporal_fill", lambda m, n, total, *r: 16 * total) as fill_clock:
+            KernelClock(L, "pp_temporal_fill", lambda m, n, total, *r: 16 * total + 12 * m) as fill_clock:
         for _ in range(args.warmup):
             step(False)
         barrier()
@@ -266,7 +266,7 @@ def main() -> int:
     k3 = None
     if rank == 0:
         ho = pp.algorithms.lift_order_temporal(g, args.delta)
-        with KernelClock(L, "pp_linegraph_fill", lambda e, n, total, *r: 16 * total) as lg_clock:
+        with KernelClock(L, "pp_linegraph_fill", lambda e, n, total, *r: 16 * total + 12 * e) as lg_clock:
             lg_clock.enabled = True
             for _ in range(3):
                 e3 = pp.algorithms.lift_order_edge_index(ho, num_nodes=args.events).size(1)
