@@ -59,9 +59,9 @@ def _edge_index(edge_index: torch.Tensor) -> torch.Tensor:
     return ei.contiguous()
 
 
-def _bad_index(status: int, what: str) -> None:
+def _bad_index(status: int, what: str, error=IndexError) -> None:
     if status & 1:
-        raise IndexError(f"{what}: node index out of range")
+        raise error(f"{what}: node index out of range")
 
 
 # ------------------------------------------------------------------ primitives
@@ -276,7 +276,9 @@ def coalesce(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: i
         check(L.pp_coalesce_count(_p(ei), e, _p(remap), 0 if remap is None else remap.numel(), num_nodes, _p(ws), ws.numel(), _stream()),
               "pp_coalesce_count")
         n_out, status = _result(ws)
-        _bad_index(status, "aggregate_edge_index")
+        # the reference fails in EdgeIndex.validate() with a ValueError when an index exceeds the number of distinct nodes
+        # (lift_order.py:133-147: layer-1 quirk, node ids are used as given while num_nodes counts the distinct ones)
+        _bad_index(status, "aggregate_edge_index (an edge refers to a node id >= number of distinct nodes)", ValueError)
         out_index = torch.empty((2, n_out), dtype=torch.int64, device=dev)
         out_weight = None if weight is None else torch.empty(n_out, dtype=weight.dtype, device=dev)
         check(L.pp_coalesce_fill(_p(weight), 2 if weight is None else _DTYPE_CODE[weight.dtype], _REDUCE[reduce], e, n_out, num_nodes,

@@ -214,3 +214,71 @@ def test_temporal_graph_float_time_and_dicts(pp):
     assert ho.tolist() == [[0, 1, 2], [2, 3, 1]] or ho.size(1) >= 0
     from oracle import lift as ol
     assert torch.equal(ho.cpu(), ol.temporal_lift_sorted(g.data.edge_index.cpu(), g.data.time.cpu(), 1.0, 3))
+
+
+def test_fuzz_from_temporal_graph_against_oracle(pp):
+    """120 seeded random configurations (sizes down to a single event, 1-node graphs, delta 0, float/int time, float deltas,
+    K up to 4, cached on/off): every layer bit-exact against the oracle."""
+    from oracle import model as om
+    rng = np.random.default_rng(2024)
+    for case in range(120):
+        m = int(rng.integers(1, 3000))
+        n = int(rng.integers(1, 60))
+        span = int(rng.integers(1, 500))
+        K = int(rng.integers(1, 5))
+        float_time = bool(rng.integers(0, 2))
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        if float_time:
+            t = torch.from_numpy(np.round(rng.random(m) * span, 1))
+            delta = float(np.round(rng.random() * span / 4, 1)) if rng.integers(0, 2) else int(rng.integers(0, max(span // 4, 1) + 1))
+        else:
+            t = torch.from_numpy(rng.integers(0, span, m))
+            delta = int(rng.integers(0, max(span // 4, 1) + 1)) if rng.integers(0, 3) else float(rng.integers(1, 20))
+        w = torch.from_numpy(rng.integers(1, 5, m).astype(np.float32))
+        cached = bool(rng.integers(0, 2))
+        sei, st, perm = om.stable_time_sort(ei, t)
+        want = om.layers_from_temporal(sei, st, n, delta=delta, max_order=K, edge_weight=w[perm], cached=cached)
+        g = pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=t.to(DEV), num_nodes=n, edge_weight=w.to(DEV)))
+        model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=K, cached=cached)
+        assert sorted(model.layers) == sorted(want), (case, m, n, K)
+        for k in want:
+            d = model.layers[k].data
+            for key in ("edge_index", "edge_weight", "node_sequence", "inverse_idx"):
+                assert torch.equal(d[key].cpu(), want[k][key]), (case, m, n, span, K, delta, float_time, k, key)
+            assert d.num_nodes == want[k]["num_nodes"]
+
+
+def test_fuzz_from_path_data_against_oracle(pp):
+    from oracle import model as om
+    rng = np.random.default_rng(7)
+    for case in range(60):
+        n_walks = int(rng.integers(1, 80))
+        alphabet = int(rng.integers(1, 12))
+        raw = [rng.integers(0, alphabet, int(rng.integers(1, 9))) for _ in range(n_walks)]
+        dense = np.unique(np.concatenate(raw), return_inverse=True)[1]          # node ids without gaps (layer-1 precondition)
+        cuts = np.cumsum([len(r) for r in raw])[:-1]
+        walks = [part.tolist() for part in np.split(dense, cuts)]
+        weights = rng.integers(1, 6, n_walks).astype(float).tolist()
+        K = int(rng.integers(1, 5))
+        mode = "diffusion" if rng.integers(0, 2) else "propagation"
+        paths = pp.PathData(device=DEV)
+        paths.append_walks(walks, weights)
+        want = om.layers_from_paths(om.walks_to_path_tensors(walks, weights), max_order=K, mode=mode)
+        model = pp.MultiOrderModel.from_path_data(paths, max_order=K, mode=mode)
+        for k in want:
+            d = model.layers[k].data
+            assert torch.equal(d.edge_index.cpu(), want[k]["edge_index"]), (case, k)
+            assert torch.equal(d.node_sequence.cpu(), want[k]["node_sequence"]), (case, k)
+            assert torch.equal(d.inverse_idx.cpu(), want[k]["inverse_idx"]), (case, k)
+            if mode == "propagation":
+                assert torch.equal(d.edge_weight.cpu(), want[k]["edge_weight"]), (case, k)
+            else:
+                torch.testing.assert_close(d.edge_weight.cpu(), want[k]["edge_weight"], rtol=1e-6, atol=1e-7)
+
+
+def test_layer_one_node_id_gap_raises_like_the_reference(pp):
+    # node id 4 with only 3 distinct nodes: the reference's Graph() rejects it in EdgeIndex.validate() (ValueError)
+    paths = pp.PathData(device=DEV)
+    paths.append_walks([[0, 4, 2]], [1.0])
+    with pytest.raises(ValueError):
+        pp.MultiOrderModel.from_path_data(paths, max_order=1)

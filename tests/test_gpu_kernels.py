@@ -234,7 +234,7 @@ def test_coalesce_remap_and_bad_index(hip):
     wi, ww = oa.coalesce(remap[ei], w, 40, "sum")
     gi, gw = hip.coalesce(cu(ei), cu(w), 40, "sum", remap=cu(remap))
     assert torch.equal(gi.cpu(), wi) and torch.equal(gw.cpu(), ww)
-    with pytest.raises(IndexError):
+    with pytest.raises(ValueError):
         hip.coalesce(cu(ei), cu(w), 10, "sum", remap=cu(remap))
 
 
