@@ -86,14 +86,14 @@ __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __rest
                                                           int64_t n_own, int64_t num_nodes, int64_t delta_i, double delta_f,
                                                           const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids_by_tail,
                                                           uint32_t* __restrict__ first_pos, int32_t* __restrict__ count,
-                                                          int64_t* __restrict__ status) {
+                                                          uint32_t* __restrict__ head4, int64_t* __restrict__ status) {
     using W = Window<TimeT, kMode>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
     if (i >= n_own) {                 // halo event of an edge-range shard: a candidate, never a source
         first_pos[i] = 0;
         count[i] = 0;
-        return;
+        return;                       // its head4 row is never read (count 0)
     }
     const TimeT ti = time[i];
     // g_lo: first id with t > t_i.  Without timestamp ties this is i+1: probe, then gallop, then bisect.
@@ -125,6 +125,13 @@ __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __rest
     }
     first_pos[i] = pos;
     count[i] = c;
+    // the first continuations sit in the cache lines the searches just touched: hand them to the fill kernel in event order
+    uint4 h = make_uint4(0u, 0u, 0u, 0u);
+    if (c > 0) h.x = ids_by_tail[pos];
+    if (c > 1) h.y = ids_by_tail[pos + 1];
+    if (c > 2) h.z = ids_by_tail[pos + 2];
+    if (c > 3) h.w = ids_by_tail[pos + 3];
+    *reinterpret_cast<uint4*>(head4 + i * 4) = h;
 }
 
 // ------------------------------------------------------------------ line-graph count
@@ -174,10 +181,16 @@ __global__ __launch_bounds__(kBlock) void k_tile_sources(const int64_t* __restri
 struct alignas(16) I64x2 { int64_t a, b; };
 struct alignas(16) I32x4 { int32_t x, y, z, w; };
 
+// kList: the second row comes from `list` (temporal lift) instead of being the position itself (line-graph lift).  With
+// `head4` (the first kHead continuations of every source, written by the count kernel while it had their cache lines in
+// hand) the common case r < kHead is a near-sequential 4-byte read instead of a random gather into the node lists.
+constexpr int kHead = 4;
+
 template <bool kList>
 __global__ __launch_bounds__(kBlock) void k_expand(const int64_t* __restrict__ offset, const uint32_t* __restrict__ first_pos,
-                                                  const uint32_t* __restrict__ list, int64_t n_src, int64_t total,
-                                                  int64_t id_offset, const int64_t* __restrict__ tile_src, int64_t* __restrict__ out) {
+                                                  const uint32_t* __restrict__ list, const uint32_t* __restrict__ head4, int64_t n_src,
+                                                  int64_t total, int64_t id_offset, const int64_t* __restrict__ tile_src,
+                                                  int64_t* __restrict__ out) {
     __shared__ int32_t s_rel_all[kWavesPerBlock][kWaveCap + 3];                                   // boundaries relative to the tile start
     __shared__ __attribute__((aligned(16))) uint32_t s_pos_all[kWavesPerBlock][kWaveCap + 3];    // first positions, later slot -> position
     __shared__ __attribute__((aligned(16))) int32_t s_src_all[kWavesPerBlock][kWaveTile];        // slot -> local source index
@@ -254,9 +267,10 @@ __global__ __launch_bounds__(kBlock) void k_expand(const int64_t* __restrict__ o
             const int k = kk[j] > before ? kk[j] : before;
             const int q = 8 * l + j;
             kk[j] = k;
-            at[j] = s_pos[k] + (uint32_t)(k == 0 ? (int64_t)q - rel0 : (int64_t)(q - s_rel[k]));
+            const uint32_t rank = (uint32_t)(k == 0 ? (int64_t)q - rel0 : (int64_t)(q - s_rel[k]));
+            at[j] = (kList && head4) ? rank : s_pos[k] + rank;          // with head4 the slot carries its RANK, else its position
         }
-        __builtin_amdgcn_wave_barrier();                   // all reads of s_pos done: reuse it as slot -> position
+        __builtin_amdgcn_wave_barrier();                   // all reads of s_pos done: reuse it as slot -> position / rank
         *(I32x4*)(s_src + 8 * l) = I32x4{kk[0], kk[1], kk[2], kk[3]};
         *(I32x4*)(s_src + 8 * l + 4) = I32x4{kk[4], kk[5], kk[6], kk[7]};
         *(I32x4*)(s_pos + 8 * l) = I32x4{(int)at[0], (int)at[1], (int)at[2], (int)at[3]};
@@ -316,7 +330,8 @@ __global__ __launch_bounds__(kBlock) void k_expand(const int64_t* __restrict__ o
             const int k = kk[j] > before ? kk[j] : before;
             const int64_t p = p0 + 8 * l + j;
             kk[j] = k;
-            at[j] = p < p1 ? first_pos[s_first + k] + (uint32_t)(p - offset[s_first + k]) : 0u;
+            const uint32_t rank = p < p1 ? (uint32_t)(p - offset[s_first + k]) : 0u;
+            at[j] = (kList && head4) ? rank : (p < p1 ? first_pos[s_first + k] + rank : 0u);
         }
         *(I32x4*)(s_src + 8 * l) = I32x4{kk[0], kk[1], kk[2], kk[3]};
         *(I32x4*)(s_src + 8 * l + 4) = I32x4{kk[4], kk[5], kk[6], kk[7]};
@@ -338,7 +353,18 @@ __global__ __launch_bounds__(kBlock) void k_expand(const int64_t* __restrict__ o
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int64_t p = p0 + 2 * ((j >> 1) * kWave + l) + (j & 1);
-        dst[j] = (kList ? (p < p1 ? (int64_t)list[at2[j]] : 0) : (int64_t)at2[j]) + id_offset;
+        int64_t v;
+        if (!kList) {
+            v = (int64_t)at2[j];
+        } else if (p >= p1) {
+            v = 0;
+        } else if (head4) {
+            const uint32_t rank = at2[j];
+            v = rank < (uint32_t)kHead ? (int64_t)head4[src[j] * kHead + rank] : (int64_t)list[first_pos[src[j]] + rank];
+        } else {
+            v = (int64_t)list[at2[j]];
+        }
+        dst[j] = v + id_offset;
     }
     const bool row1_aligned = (total & 1) == 0;
 #pragma unroll
@@ -430,6 +456,7 @@ struct LiftWs {
     uint32_t* ids;          // temporal: event ids grouped by tail [n_src]
     uint32_t* keys;         // temporal: tail keys [n_src];  line graph: outdeg (as int32) [num_nodes]
     uint32_t* sorted_keys;  // temporal only [n_src]
+    uint32_t* head4;        // temporal only [n_src * 4]: the first 4 continuations of every event
     int64_t* tile_src;      // first source of every 512-slot output tile (k_tile_sources) [tile_cap + 1]
     int64_t tile_cap;
     void* scratch;          // sort / scan workspace
@@ -448,6 +475,7 @@ static LiftWs carve_lift(void* ws, int64_t n_src, int64_t num_nodes, bool tempor
     w.ids = temporal ? a.take<uint32_t>(n_src) : nullptr;
     w.keys = a.take<uint32_t>(temporal ? n_src : num_nodes);
     w.sorted_keys = temporal ? a.take<uint32_t>(n_src) : nullptr;
+    w.head4 = temporal ? a.take<uint32_t>(n_src * 4) : nullptr;
     w.tile_cap = n_src / 16 > 65536 ? n_src / 16 : 65536;       // covers results up to 32x the number of sources
     w.tile_src = a.take<int64_t>(w.tile_cap + 1);
     size_t sb = scan_ws_bytes(n_src > num_nodes ? n_src : num_nodes);
@@ -469,8 +497,9 @@ static int launch_expand(const LiftWs& w, int64_t n_src, int64_t total, int64_t 
         k_tile_sources<<<(unsigned)ceil_div(n_tiles + 1, kBlock), kBlock, 0, st>>>(w.offset, n_src, total, n_tiles, tile_src);
         PP_LAUNCH_CHECK();
     }
-    k_expand<kList><<<(unsigned)ceil_div(n_tiles, kWavesPerBlock), kBlock, 0, st>>>(w.offset, w.first_pos, kList ? w.ids : nullptr, n_src, total,
-                                                                                       id_offset, tile_src, out);
+    k_expand<kList><<<(unsigned)ceil_div(n_tiles, kWavesPerBlock), kBlock, 0, st>>>(w.offset, w.first_pos, kList ? w.ids : nullptr,
+                                                                                       kList ? w.head4 : nullptr, n_src, total, id_offset,
+                                                                                       tile_src, out);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
@@ -483,18 +512,18 @@ template <>
 int launch_temporal_count<int64_t>(int delta_kind, unsigned grid, hipStream_t st, const int64_t* head, const int64_t* time, int64_t m,
                                    int64_t n_own, int64_t n, int64_t di, double df, const LiftWs& w) {
     if (delta_kind == PP_DELTA_I64)
-        k_temporal_count<int64_t, 0><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+        k_temporal_count<int64_t, 0><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.head4, w.result + 1);
     else if (delta_kind == PP_DELTA_F32)
-        k_temporal_count<int64_t, 1><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+        k_temporal_count<int64_t, 1><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.head4, w.result + 1);
     else
-        k_temporal_count<int64_t, 2><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+        k_temporal_count<int64_t, 2><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.head4, w.result + 1);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
 template <>
 int launch_temporal_count<double>(int, unsigned grid, hipStream_t st, const int64_t* head, const double* time, int64_t m, int64_t n_own,
                                   int64_t n, int64_t di, double df, const LiftWs& w) {
-    k_temporal_count<double, 0><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.result + 1);
+    k_temporal_count<double, 0><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.head4, w.result + 1);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
