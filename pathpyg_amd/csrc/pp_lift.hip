@@ -96,6 +96,11 @@ __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __rest
         return;                       // its head4 row is never read (count 0)
     }
     const TimeT ti = time[i];
+    // the head node's list bounds do not depend on the window: fetch them first so that this (random) miss overlaps the
+    // dependent loads of the time search below
+    const int64_t v = head[i];
+    const bool ok = v >= 0 && v < num_nodes;
+    const uint32_t s0 = ok ? rowptr[v] : 0u, s1 = ok ? rowptr[v + 1] : 0u;
     // g_lo: first id with t > t_i.  Without timestamp ties this is i+1: probe, then gallop, then bisect.
     int64_t g_lo = i + 1;
     if (g_lo < m && !(time[g_lo] > ti)) {
@@ -112,15 +117,13 @@ __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __rest
         if (W::admits(time[mid], thr)) lo = mid + 1; else hi = mid;
     }
     const int64_t g_hi = lo;
-    const int64_t v = head[i];
     uint32_t pos = 0;
     int32_t c = 0;
-    if (v < 0 || v >= num_nodes) {
+    if (!ok) {
         atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex);
     } else if (g_hi > g_lo) {
-        const uint32_t s0 = rowptr[v], s1 = rowptr[v + 1];
         pos = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, s0, s1, (uint32_t)g_lo);
-        uint32_t end = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, pos, s1, (uint32_t)g_hi);
+        const uint32_t end = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, pos, s1, (uint32_t)g_hi);
         c = (int32_t)(end - pos);
     }
     first_pos[i] = pos;
