@@ -294,3 +294,95 @@ class ShardedDBGNN(torch.nn.Module):
         per-rank gradients (``all_reduce_gradients(..., average=False)``) reproduces the single-process gradient."""
         out = self.forward(shard)
         return torch.nn.functional.cross_entropy(out, shard["y"], reduction="sum") / shard["n_fo"]
+
+
+# =====================================================================================================
+# Distributed De Bruijn aggregation (SURVEY §8e, row a7): global lexicographic unique / coalesce = a distributed sort with ONE
+# exchange step per layer.  Keys are range-partitioned (rank r owns the keys in [cut_r, cut_{r+1})), every rank sends each key
+# (+ weight) to its owner, the owner coalesces its range with the single-GPU kernels, and an all-gather of the per-rank counts
+# turns local ranks into global ids.  Concatenating the ranks' outputs in rank order IS the single-process result.
+# =====================================================================================================
+def _exchange(buckets: list[torch.Tensor], group=None) -> torch.Tensor:
+    """Send ``buckets[r]`` to rank r, return the concatenation of what the other ranks sent here (rank order).
+    RCCL: one all_to_all of the sizes + one of the payload; gloo (tests) has no all_to_all: all-gather and pick."""
+    rank, world = _world(group)
+    if world == 1:
+        return buckets[0]
+    if dist.get_backend(group) == "nccl":
+        send_sizes = torch.tensor([b.size(0) for b in buckets], dtype=torch.int64, device=buckets[0].device)
+        recv_sizes = torch.empty_like(send_sizes)
+        dist.all_to_all_single(recv_sizes, send_sizes, group=group)
+        recv = list(torch.empty((int(recv_sizes.sum()),) + tuple(buckets[0].shape[1:]), dtype=buckets[0].dtype,
+                                device=buckets[0].device).split(recv_sizes.tolist()))
+        dist.all_to_all(recv, [b.contiguous() for b in buckets], group=group)
+        return torch.cat(recv, dim=0)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [b.cpu() for b in buckets], group=group)
+    return torch.cat([gathered[src][rank] for src in range(world)], dim=0).to(buckets[0].device)
+
+
+def _owner_cuts(num_keys_space: int, world: int) -> torch.Tensor:
+    """Equal-width key ranges over ``[0, num_keys_space)``: ``cuts[r] .. cuts[r+1]`` is owned by rank r."""
+    return torch.tensor([(num_keys_space * r) // world for r in range(world + 1)], dtype=torch.int64)
+
+
+def coalesce_sharded(rows: torch.Tensor, cols: torch.Tensor, weight: torch.Tensor, num_nodes: int, group=None):
+    """Global ``coalesce`` of edges scattered over the ranks.  Rank r ends up with the distinct edges whose ROW lies in
+    ``[cuts[r], cuts[r+1])`` (sorted by (row, col), weights summed); returns ``(edge_index [2, A_r], weight [A_r], cuts)``."""
+    rank, world = _world(group)
+    cuts = _owner_cuts(num_nodes, world).to(rows.device)
+    owner = torch.searchsorted(cuts[1:].contiguous(), rows, right=True).clamp_(max=world - 1)
+    payload = torch.stack((rows, cols, weight.to(torch.float64).view(torch.int64) if weight.dtype == torch.float64
+                           else weight.to(torch.float32).view(torch.int32).to(torch.int64)), dim=1)
+    buckets = [payload[owner == r] for r in range(world)]
+    mine = _exchange(buckets, group)
+    ei = mine[:, :2].t().contiguous()
+    w = mine[:, 2].to(torch.int32).view(torch.float32) if weight.dtype != torch.float64 else mine[:, 2].view(torch.float64)
+    merged_index, merged_weight = _dispatch.coalesce(ei, w.contiguous(), num_nodes, "sum")
+    return merged_index, merged_weight, cuts.cpu()
+
+
+def unique_pairs_sharded(src: torch.Tensor, dst: torch.Tensor, num_nodes: int, group=None):
+    """Global lexicographic numbering of the distinct (src, dst) pairs of events scattered over the ranks (= the order-2
+    De Bruijn nodes).  Returns ``(all_pairs [U, 2] on every rank, ids)`` with ``ids[e]`` the global id of local event e."""
+    rank, world = _world(group)
+    ones = torch.ones(src.numel(), dtype=torch.float32, device=src.device)
+    local_pairs, _, _ = coalesce_sharded(src, dst, ones, num_nodes, group)          # my key range, sorted, distinct
+    counts = torch.tensor([local_pairs.size(1)], dtype=torch.int64, device=src.device)
+    if world > 1:
+        sizes = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(sizes, counts, group=group)
+        cap = max(int(s.item()) for s in sizes)
+        padded = torch.zeros((2, cap), dtype=torch.int64, device=src.device)
+        padded[:, : local_pairs.size(1)] = local_pairs
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+        all_pairs = torch.cat([p[:, : int(s.item())] for p, s in zip(parts, sizes)], dim=1)
+    else:
+        all_pairs = local_pairs
+    keys = all_pairs[0] * num_nodes + all_pairs[1]                                   # ascending: ranks own ascending row ranges
+    ids = torch.searchsorted(keys.contiguous(), (src * num_nodes + dst).contiguous())
+    return all_pairs.t().contiguous(), ids
+
+
+def second_order_layer_sharded(g, delta=1, group=None, edge_weight: torch.Tensor | None = None) -> dict:
+    """Order-2 De Bruijn layer of a temporal graph replicated on every rank, computed cooperatively: edge-range lift (no
+    exchange), global pair numbering (one exchange), global coalesce of the lifted pairs (one exchange).
+    Rank r returns its slice of the layer: the aggregated edges whose source node id lies in its row range."""
+    rank, world = _world(group)
+    data = g.data
+    ei = _dispatch.plain(data.edge_index)
+    n = int(data.num_nodes)
+    w = edge_weight if edge_weight is not None else torch.ones(ei.size(1), device=ei.device)
+    local, _, total = lift_order_temporal_sharded(g, delta, group)                 # (i, j) with global event ids
+    lo, hi = event_ranges(ei.size(1), world)[rank]
+    pairs, own_ids = unique_pairs_sharded(ei[0, lo:hi], ei[1, lo:hi], n, group)     # every rank contributes its own events
+    num_ho = pairs.size(0)
+    # node id of EVERY event the local pairs refer to (own events and halo): look the pair up in the global list
+    pair_keys = (pairs[:, 0] * n + pairs[:, 1]).contiguous()
+    i, j = local[0], local[1]
+    u = torch.searchsorted(pair_keys, (ei[0][i] * n + ei[1][i]).contiguous())
+    v = torch.searchsorted(pair_keys, (ei[0][j] * n + ei[1][j]).contiguous())
+    edges, weights, cuts = coalesce_sharded(u, v, w[i], num_ho, group)
+    return {"edge_index": edges, "edge_weight": weights, "node_sequence": pairs, "num_nodes": num_ho, "row_cuts": cuts,
+            "instance_pairs_total": total, "own_event_ids": own_ids}

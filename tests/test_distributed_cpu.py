@@ -197,3 +197,61 @@ def test_destination_partitioned_dbgnn_matches_single_process_oracle(world):
         p.join(240)
         assert p.exitcode == 0
     assert dict(results) == {r: "ok" for r in range(world)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Distributed aggregation: range-partitioned keys, one exchange per layer (gloo; the local coalesce is the oracle's).
+def _oracle_coalesce(edge_index, weight, num_nodes, reduce="sum", remap=None, want_inverse=False):
+    from oracle import aggregate as oa
+    assert remap is None and not want_inverse
+    return oa.coalesce(edge_index, weight, num_nodes, reduce)
+
+
+def _agg_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pathpyg_amd as pp
+        from pathpyg_amd import _dispatch, distributed as pd
+        from oracle import model as om
+        _dispatch.temporal_lift = _oracle_local_lift
+        _dispatch.coalesce = _oracle_coalesce
+        rng = np.random.default_rng(17)
+        m, n, delta = 4000, 30, 11
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        t = torch.from_numpy(np.sort(rng.integers(0, 500, m)))
+        w = torch.from_numpy(rng.integers(1, 4, m).astype(np.float32))
+        g = type("G", (), {})()
+        g.data = pp.Data(edge_index=ei, time=t, num_nodes=n)
+        want = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2, edge_weight=w)[2]
+        part = pd.second_order_layer_sharded(g, delta=delta, edge_weight=w)
+        assert torch.equal(part["node_sequence"], want["node_sequence"]) and part["num_nodes"] == want["num_nodes"]
+        lo, hi = pd.event_ranges(m, world)[rank]
+        assert torch.equal(part["own_event_ids"], want["inverse_idx"][lo:hi])          # global node ids of my events
+        # my slice = the reference layer's edges whose row falls into my row range; slices concatenate to the whole layer
+        cuts = part["row_cuts"]
+        rows = want["edge_index"][0]
+        mine = (rows >= cuts[rank]) & (rows < cuts[rank + 1])
+        assert torch.equal(part["edge_index"], want["edge_index"][:, mine])
+        assert torch.equal(part["edge_weight"], want["edge_weight"][mine])
+        sizes = [None] * world
+        dist.all_gather_object(sizes, int(part["edge_index"].size(1)))
+        assert sum(sizes) == want["edge_index"].size(1)
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_second_order_layer_matches_oracle(world):
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_agg_worker, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert dict(results) == {r: "ok" for r in range(world)}
