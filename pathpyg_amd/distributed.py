@@ -306,7 +306,7 @@ def _exchange(buckets: list[torch.Tensor], group=None) -> torch.Tensor:
     """Send ``buckets[r]`` to rank r, return the concatenation of what the other ranks sent here (rank order).
     RCCL: one all_to_all of the sizes + one of the payload; gloo (tests) has no all_to_all: all-gather and pick."""
     rank, world = _world(group)
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return buckets[0]
     if dist.get_backend(group) == "nccl":
         send_sizes = torch.tensor([b.size(0) for b in buckets], dtype=torch.int64, device=buckets[0].device)

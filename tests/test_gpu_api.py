@@ -282,3 +282,32 @@ def test_layer_one_node_id_gap_raises_like_the_reference(pp):
     paths.append_walks([[0, 4, 2]], [1.0])
     with pytest.raises(ValueError):
         pp.MultiOrderModel.from_path_data(paths, max_order=1)
+
+
+def test_sharded_second_order_layer_rccl_world1(pp):
+    """Key-range sharded aggregation on real kernels with an initialised RCCL group of one rank: the all-to-all / all-gather
+    code path executes (multi-rank correctness is covered by the gloo tests in tests/test_distributed_cpu.py)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from pathpyg_amd import distributed as pd
+    from oracle import model as om
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        rng = np.random.default_rng(5)
+        m, n, delta = 20_000, 200, 9
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        t = torch.from_numpy(np.sort(rng.integers(0, 3000, m)))
+        g = pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=t.to(DEV), num_nodes=n))
+        w = torch.from_numpy(rng.integers(1, 4, m).astype(np.float32))
+        part = pd.second_order_layer_sharded(g, delta=delta, edge_weight=w.to(DEV))
+        want = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2, edge_weight=w)[2]
+        assert torch.equal(part["node_sequence"].cpu(), want["node_sequence"])
+        assert torch.equal(part["edge_index"].cpu(), want["edge_index"])
+        assert torch.equal(part["edge_weight"].cpu(), want["edge_weight"])
+        assert torch.equal(part["own_event_ids"].cpu(), want["inverse_idx"])
+    finally:
+        dist.destroy_process_group()
