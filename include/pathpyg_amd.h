@@ -217,6 +217,14 @@ size_t pp_dense_backward_ws_bytes(int64_t n_rows);
 int pp_dense_backward_f32(const float* dH, const float* X, const float* W, int64_t n_rows, int M, int K, int fuse_act, float* d_in,
                           float* colsum_in, float* dW, float* db, void* ws, size_t ws_bytes, pp_stream_t stream);
 
+/* A whole GCNConv layer (dbgnn.py:131-140) in one kernel, re-associated as (A_hat X) W^T so that the transformed matrix never
+ * makes a round trip through HBM:
+ *   Y[r, :Q] = act( (sum_e val[e] X[idx[e], :P] + self_coef[r] X[r, :P]) . W^T + bias ),   W is [Q,P] (Linear layout), act 0/1 (ELU)
+ * over the destination-major CSR of a pp_gcn_plan (self_coef may be NULL: no self term); X has n_src rows and must stay below
+ * 4 GiB (rows are addressed by 32-bit byte offsets; PP_ERR_TOO_LARGE otherwise).  P, Q in {16,32,64}. */
+int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
+                       const float* self_coef, const float* W, int Q, const float* bias, int act, float* Y, pp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -504,6 +504,23 @@ def dense(a: torch.Tensor, weight: torch.Tensor, transposed: bool, bias: torch.T
     return out, colsum
 
 
+def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, n_rows: int, x: torch.Tensor,
+                self_coef: torch.Tensor | None, weight: torch.Tensor, bias: torch.Tensor | None, act: bool) -> torch.Tensor:
+    """``act((A x + diag(self_coef) x) @ weight.T + bias)`` in one kernel (aggregation fused with the MFMA product)."""
+    dev = require_device(ptr, idx, val, x, self_coef, weight, bias)
+    x, weight = x.contiguous(), weight.contiguous()
+    q, p = weight.shape
+    if x.size(1) != p:
+        raise ValueError("gcn_forward: inner dimensions do not match")
+    if bias is not None:
+        bias = bias.contiguous()
+    with torch.cuda.device(dev):
+        y = torch.empty((n_rows, q), dtype=torch.float32, device=dev)
+        check(lib().pp_gcn_forward_f32(_p(ptr), _p(idx), _p(val), n_rows, x.size(0), _p(x), p, _p(self_coef), _p(weight), q, _p(bias),
+                                       1 if act else 0, _p(y), _stream()), "pp_gcn_forward_f32")
+    return y
+
+
 def cross_entropy(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = True):
     """(mean cross-entropy [scalar tensor], d loss / d logits or None) in one pass; logits [N, C<=64] fp32, target int64 [N]."""
     dev = require_device(logits, target)

@@ -129,6 +129,24 @@ __device__ __forceinline__ T block_exclusive_sum(T v, T* scratch, T* total) {
     return wave_base + inc - v;
 }
 
+// ELU(x) = x > 0 ? x : exp(x) - 1, branch-free and ~12 VALU instructions (libm's expm1f is ~40 and branches): on (-0.5, 0] the
+// degree-8 Taylor polynomial of expm1 (truncation < 6e-9 relative), below that v_exp_f32 - 1 (the result is <= -0.39, so the
+// 1-ulp error of the exponential stays < 2e-7 relative).
+__device__ __forceinline__ float elu_fast(float x) {
+    float p = 1.f / 40320.f;
+    p = fmaf(p, x, 1.f / 5040.f);
+    p = fmaf(p, x, 1.f / 720.f);
+    p = fmaf(p, x, 1.f / 120.f);
+    p = fmaf(p, x, 1.f / 24.f);
+    p = fmaf(p, x, 1.f / 6.f);
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.f);
+    p *= x;
+    const float e = __expf(x) - 1.f;
+    const float neg = x > -0.5f ? p : e;
+    return x > 0.f ? x : neg;
+}
+
 // first index in [lo, hi) with a[idx] > key (upper bound), a ascending
 template <typename T, typename I>
 __device__ __forceinline__ I upper_bound_dev(const T* __restrict__ a, I lo, I hi, T key) {

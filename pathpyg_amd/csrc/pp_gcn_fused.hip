@@ -1,0 +1,222 @@
+// pathpyg_amd — a whole GCN layer per kernel: CSR aggregation fused with the dense product on the matrix cores.
+//
+//   forward :  Y[r] = act( (sum_e val[e] X[idx[e]] + self[r] X[r]) . W^T + bias )            (reference nn/dbgnn.py:131-140, GCNConv)
+//
+// The reference (and pp_dense_f32 + pp_spmm_f32) evaluate A_hat (X W^T): the transformed matrix H = X W^T makes a round trip
+// through HBM (write N*Q, gather it back).  (A_hat X) W^T is the same product re-associated: a wave aggregates a tile of 16
+// destination rows straight from X into LDS and multiplies the tile by W on v_mfma_f32_16x16x4_f32, so the only N-sized
+// traffic left is the gather itself and the store of Y.  W (<= 64x64 fp32) sits in LDS for the whole persistent workgroup.
+#include "pp_common.h"
+#include "pp_internal.h"
+
+namespace pp {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kGcnThreads = 256;                 // 4 waves share one copy of W
+constexpr int kFirst = 4;                        // neighbours per row fetched in the first, fully overlapped, batch
+constexpr int kGcnWaves = kGcnThreads / kWave;
+
+// One wave per 16-row tile, persistent workgroups of 4 waves.  Gather stage: kLanes = P/4 lanes own a row (one float4 each), a lane
+// group walks its kRows rows kBatch at a time and issues the first kFirst neighbour rows of the batch plus the rows themselves
+// back to back (index / weight chunks come by one coalesced load per row and are handed round by shuffle); longer rows continue
+// four gathers at a time.  The aggregated tile goes through a wave-private LDS buffer into the A layout of the 16x16x4 MFMA
+// (lane (i, kq) = quarter row kq of tile row i), B is read from LDS [k][i][ct] with one ds_read_b128 per k, bias + ELU in the
+// epilogue.  Measured alternatives (MI355X, 10^7 x 64 De Bruijn graph): a three-tile-deep register pipeline (prefetching the next
+// tiles' pointers, chunks and rows; 2 waves/SIMD) and a producer/consumer split (12 gather waves + 4 MFMA waves through an LDS
+// ring) both land on the same 2.0 ms: the kernel moves ~10 GB per launch through L2 at the ~5 TB/s this chip sustains for
+// 256-byte random rows, as do pp_dense_f32 + pp_spmm_f32 with their 12.6 GB in 2.4 ms.
+template <int P, int Q>
+__global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                                 const float* __restrict__ val, int64_t n_rows, const float* __restrict__ X,
+                                                                 const float* __restrict__ self_coef, const float* __restrict__ W,
+                                                                 const float* __restrict__ bias, int act, float* __restrict__ Y) {
+    constexpr int kLanes = P / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = P / 4, CT = Q / 16, TS = P + 4;
+    constexpr int kBatch = kRows < 2 ? kRows : 2;
+    __shared__ __attribute__((aligned(16))) float s_b[P * 16 * CT];
+    __shared__ __attribute__((aligned(16))) float s_tile[kGcnWaves][16 * TS];
+    for (int e = threadIdx.x; e < P * Q; e += kGcnThreads) {
+        const int j = e / P, k = e - j * P;
+        s_b[(k * 16 + (j & 15)) * CT + (j >> 4)] = W[e];
+    }
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int g = lane / kLanes, l = lane % kLanes;
+    const int i = lane & 15, kq = lane >> 4;
+    float* tile = s_tile[wave];
+    float bias_c[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) bias_c[ct] = bias ? bias[ct * 16 + i] : 0.f;
+    const char* xb = (const char*)X;
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    const int64_t step = (int64_t)gridDim.x * kGcnWaves;
+    for (int64_t t = (int64_t)blockIdx.x * kGcnWaves + wave; t < n_tiles; t += step) {
+        const int64_t r0 = t * 16 + g * kRows;
+        int p[kRows + 1];
+#pragma unroll
+        for (int q = 0; q <= kRows; ++q) {
+            const int64_t r = r0 + q < n_rows ? r0 + q : n_rows;
+            p[q] = ptr[r];
+        }
+        int cj[kRows];
+        float cv[kRows], sc[kRows];
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+            const int mine = p[q] + l;
+            const bool in = mine < p[q + 1];
+            cj[q] = in ? idx[mine] : 0;
+            cv[q] = in ? (val ? val[mine] : 1.f) : 0.f;
+            sc[q] = (self_coef != nullptr && r0 + q < n_rows) ? self_coef[r0 + q] : 0.f;
+        }
+#pragma unroll
+        for (int b0 = 0; b0 < kRows; b0 += kBatch) {
+            uint32_t off[kBatch][kFirst], self_off[kBatch];
+#pragma unroll
+            for (int qq = 0; qq < kBatch; ++qq) {
+                const int q = b0 + qq;
+                const bool self_here = self_coef != nullptr && r0 + q < n_rows;
+                const int first = __shfl(cj[q], 0, kLanes);
+                const int dummy = p[q] < p[q + 1] ? first : (self_here ? (int)(r0 + q) : 0);
+                self_off[qq] = (uint32_t)(self_here ? (int)(r0 + q) : dummy) * (uint32_t)(P * 4) + (uint32_t)(16 * l);
+#pragma unroll
+                for (int u = 0; u < kFirst; ++u) {
+                    const int j = u == 0 ? first : __shfl(cj[q], u, kLanes);
+                    off[qq][u] = (uint32_t)(p[q] + u < p[q + 1] ? j : dummy) * (uint32_t)(P * 4) + (uint32_t)(16 * l);
+                }
+            }
+            float4 x[kBatch][kFirst], sr[kBatch];
+#pragma unroll
+            for (int qq = 0; qq < kBatch; ++qq) {
+                sr[qq] = *(const float4*)(xb + self_off[qq]);
+#pragma unroll
+                for (int u = 0; u < kFirst; ++u) x[qq][u] = *(const float4*)(xb + off[qq][u]);
+            }
+#pragma unroll
+            for (int qq = 0; qq < kBatch; ++qq) {
+                const int q = b0 + qq;
+                float4 acc = make_float4(sc[q] * sr[qq].x, sc[q] * sr[qq].y, sc[q] * sr[qq].z, sc[q] * sr[qq].w);
+#pragma unroll
+                for (int u = 0; u < kFirst; ++u) {
+                    const float v = __shfl(cv[q], u, kLanes);
+                    acc.x += v * x[qq][u].x; acc.y += v * x[qq][u].y; acc.z += v * x[qq][u].z; acc.w += v * x[qq][u].w;
+                }
+                int my_j = cj[q];
+                float my_v = cv[q];
+                const int p0 = p[q], p1 = p[q + 1];
+                for (int base = p0; base < p1; base += kLanes) {      // rows with more than kFirst neighbours
+                    if (base != p0) {
+                        const int mine = base + l;
+                        my_j = mine < p1 ? idx[mine] : 0;
+                        my_v = mine < p1 ? (val ? val[mine] : 1.f) : 0.f;
+                    }
+                    const int cnt = p1 - base < kLanes ? p1 - base : kLanes;
+                    for (int e = base == p0 ? kFirst : 0; e < cnt; e += 4) {
+                        float4 y[4];
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int src_lane = (e + u) < cnt ? e + u : e;
+                            const int j = __shfl(my_j, src_lane, kLanes);
+                            v[u] = (e + u) < cnt ? __shfl(my_v, src_lane, kLanes) : 0.f;
+                            y[u] = *(const float4*)(xb + (uint32_t)j * (uint32_t)(P * 4) + (uint32_t)(16 * l));
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc.x += v[u] * y[u].x; acc.y += v[u] * y[u].y; acc.z += v[u] * y[u].z; acc.w += v[u] * y[u].w;
+                        }
+                    }
+                }
+                if (p0 == p1 && sc[q] == 0.f) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float4 a[KQ / 4];
+#pragma unroll
+        for (int c = 0; c < KQ / 4; ++c) a[c] = *(const float4*)(tile + i * TS + kq * KQ + 4 * c);
+        f32x4 out[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) out[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KQ / 4; ++c) {
+            const float av[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* bp = s_b + ((kq * KQ + 4 * c + e) * 16 + i) * CT;
+                float bv[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) bv[ct] = bp[ct];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) out[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[ct], out[ct], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float* yp = Y + (t * 16 + 4 * kq) * Q + i;
+        const int rows_here = n_rows - (t * 16 + 4 * kq) < 4 ? (int)(n_rows - (t * 16 + 4 * kq)) : 4;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float v = out[ct][reg] + bias_c[ct];
+                const float y = act ? elu_fast(v) : v;
+                if (reg < rows_here) yp[reg * Q + ct * 16] = y;
+            }
+    }
+}
+
+// Persistent grid = exactly the workgroups that are resident at once (registers and LDS decide; asked from the runtime once).
+template <int P, int Q>
+static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
+                              const float* X, const float* self_coef, const float* W, const float* bias, int act, float* Y) {
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q>, kGcnThreads, 0));
+        PP_HIP(hipGetDevice(&dev));
+        PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+    }
+    int64_t blocks = ceil_div(n_tiles, kGcnWaves);
+    if (blocks > resident) blocks = resident;
+    k_gcn_forward<P, Q><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, X, self_coef, W, bias, act, Y);
+    return PP_OK;
+}
+
+template <int P>
+static int launch_gcn_forward_q(int Q, int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
+                                const float* X, const float* self_coef, const float* W, const float* bias, int act, float* Y) {
+    switch (Q) {
+        case 16: return launch_gcn_forward<P, 16>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, Y);
+        case 32: return launch_gcn_forward<P, 32>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, Y);
+        case 64: return launch_gcn_forward<P, 64>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, Y);
+        default: return PP_ERR_ARG;
+    }
+}
+
+}  // namespace pp
+
+extern "C" {
+
+int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
+                       const float* self_coef, const float* W, int Q, const float* bias, int act, float* Y, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_forward_f32: negative size");
+    PP_REQUIRE(pp_dense_supported(P, Q), PP_ERR_ARG, "pp_gcn_forward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", P, Q);
+    PP_REQUIRE(act == 0 || act == 1, PP_ERR_ARG, "pp_gcn_forward_f32: act must be 0 (none) or 1 (elu)");
+    PP_REQUIRE(((uintptr_t)X) % 16 == 0, PP_ERR_ARG, "pp_gcn_forward_f32: X must be 16-byte aligned");
+    PP_REQUIRE(n_src >= 0 && (uint64_t)n_src * (uint64_t)P * 4 <= 0xffffffffull, PP_ERR_TOO_LARGE,
+               "pp_gcn_forward_f32: X must be smaller than 4 GiB (use pp_dense_f32 + pp_spmm_f32)");
+    if (n_rows == 0) return PP_OK;
+    const int64_t n_tiles = pp::ceil_div(n_rows, 16);
+    int rc;
+    switch (P) {
+        case 16: rc = pp::launch_gcn_forward_q<16>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, Y); break;
+        case 32: rc = pp::launch_gcn_forward_q<32>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, Y); break;
+        default: rc = pp::launch_gcn_forward_q<64>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, Y); break;
+    }
+    if (rc != PP_OK) return rc;
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // extern "C"

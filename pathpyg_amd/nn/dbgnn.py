@@ -103,6 +103,42 @@ class _Dense(torch.autograd.Function):
         return dx, dw, db, None, dact
 
 
+class _GcnLayer(torch.autograd.Function):
+    """A whole GCN layer ``y = ELU((A x + diag(self_coef) x) W^T + b)`` in ONE kernel (``pp_gcn_forward_f32``): the aggregation
+    runs on the layer INPUT and the 16-row tile it produces is multiplied by ``W`` on the matrix cores before it ever leaves
+    the CU, so the transformed matrix ``x W^T`` of the reference's ``A (x W^T)`` order is neither written nor gathered back.
+
+    Contract (as ``_Propagate(grad_is_pre=True)``): the consumer of ``y`` hands back the gradient w.r.t. the PRE-activation and
+    computes this layer's bias gradient; ``fuse_act`` / ``act_bias`` describe the layer BELOW exactly as in :class:`_Dense`.
+    Backward is the same math as the unfused path: ``G = A^T dpre`` (one SpMM), then input gradient, ELU' of the layer below,
+    its bias gradient and ``dW = G^T x`` in one pass (``pp_dense_backward_f32``)."""
+
+    @staticmethod
+    def supported(plan, x, weight) -> bool:
+        return (plan.self_coef is not None and plan.n_dst == plan.n_src == x.size(0) and x.dtype == torch.float32
+                and _hip.dense_supported(weight.size(1), weight.size(0)) and x.numel() * 4 < (1 << 32))
+
+    @staticmethod
+    def forward(ctx, plan, x, weight, bias, fuse_act: bool, act_bias):
+        ctx.plan, ctx.fuse_act, ctx.has_act_bias = plan, fuse_act, act_bias is not None
+        ctx.save_for_backward(x, weight)
+        return _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x, plan.self_coef, weight, bias, True)
+
+    @staticmethod
+    def backward(ctx, dpre):
+        plan = ctx.plan
+        x, weight = ctx.saved_tensors
+        dpre = dpre.contiguous()
+        g = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, dpre)
+        dx = dw = dact = None
+        want_sum = ctx.fuse_act and ctx.has_act_bias and ctx.needs_input_grad[5]
+        if ctx.needs_input_grad[1]:
+            dx, dact, dw, _ = _hip.dense_backward(g, x, weight, ctx.fuse_act, True, want_sum, False)
+        elif ctx.needs_input_grad[2]:
+            dw, _ = _hip.weight_grad(g, x, want_bias=False)
+        return None, dx, dw, None, None, dact
+
+
 def dense(x, linear: Linear, fuse_act: bool = False, act_bias=None):
     if x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda:
         return _Dense.apply(x, linear.weight, linear.bias, fuse_act, act_bias)
@@ -243,8 +279,11 @@ class DBGNN(Module):
         def stack(layers, h, plan):
             below = None                                            # bias of the layer whose activation `h` is
             for i, layer in enumerate(layers):
-                t = dense(h, layer.lin, fuse_act=i > 0, act_bias=below)
-                h = _Propagate.apply(plan, t, None, layer.bias, True, True)
+                if _GcnLayer.supported(plan, h, layer.lin.weight):
+                    h = _GcnLayer.apply(plan, h, layer.lin.weight, layer.bias, i > 0, below)
+                else:
+                    t = dense(h, layer.lin, fuse_act=i > 0, act_bias=below)
+                    h = _Propagate.apply(plan, t, None, layer.bias, True, True)
                 below = layer.bias
             return h, below
 

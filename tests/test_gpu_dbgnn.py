@@ -220,3 +220,46 @@ def test_dense_backward_kernel(pp, n, m, k):
     assert c2 is None and db2 is None and torch.equal(dw2, dw)
     d3, c3, dw3, _ = _hip.dense_backward(dy.to(DEV), x.to(DEV), w.to(DEV), False, False, False, False)
     assert d3 is None and torch.equal(dw3, dw)
+
+
+@pytest.mark.parametrize("n,e,p,q,with_self,weighted", [
+    (1, 0, 16, 16, True, True), (17, 40, 64, 64, True, True), (1000, 5000, 32, 64, True, False), (4097, 9000, 64, 16, True, True),
+    (70_001, 200_000, 64, 64, True, True), (300, 20_000, 64, 32, True, True),          # last: rows far longer than one index chunk
+    (500, 700, 16, 32, False, True), (2000, 3000, 64, 64, False, False),
+])
+def test_fused_gcn_layer_kernel(pp, n, e, p, q, with_self, weighted):
+    """pp_gcn_forward_f32 (aggregate, then multiply on the matrix cores) against a float64 evaluation of the reference order
+    A (x W^T) + b; isolated rows, rows longer than the first gather batch / the index chunk, no self term, unit weights."""
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(n + e + p)
+    dst = torch.sort(torch.randint(0, n, (e,), generator=g)).values
+    if n > 10 and e > 100:
+        dst[: min(e // 4, 3000)] = dst[min(e // 4, 3000)]           # one long row (fp32 accumulation: keep it to thousands)
+        dst = torch.sort(dst).values
+    ptr = torch.zeros(n + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n), 0).int()
+    idx = torch.randint(0, n, (e,), generator=g, dtype=torch.int32)
+    val = torch.rand(e, generator=g) if weighted else None
+    x = torch.randn(n, p, generator=g)
+    w = torch.randn(q, p, generator=g) / p ** 0.5
+    bias = torch.randn(q, generator=g)
+    self_coef = torch.rand(n, generator=g) if with_self else None
+    a = torch.zeros(n, n, dtype=torch.float64)
+    a.index_put_((dst, idx.long()), (val if weighted else torch.ones(e)).double(), accumulate=True)
+    if with_self:
+        a += torch.diag(self_coef.double())
+    for act in (True, False):
+        pre = a @ (x.double() @ w.double().t()) + bias.double()
+        want = (F.elu(pre) if act else pre).float()
+        got = _hip.gcn_forward(ptr.to(DEV), idx.to(DEV), val.to(DEV) if weighted else None, n, x.to(DEV),
+                               self_coef.to(DEV) if with_self else None, w.to(DEV), bias.to(DEV), act).cpu()
+        scale = float(want.abs().max()) + 1e-12
+        torch.testing.assert_close(got, want, rtol=RTOL, atol=max(ATOL, 1e-6 * scale))
+
+
+def test_fused_gcn_layer_rejects_unsupported_shapes(pp):
+    from pathpyg_amd import _hip
+    ptr = torch.zeros(5, dtype=torch.int32, device=DEV)
+    idx = torch.zeros(1, dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError):
+        _hip.gcn_forward(ptr, idx, None, 4, torch.zeros(4, 48, device=DEV), None, torch.zeros(64, 48, device=DEV), None, True)

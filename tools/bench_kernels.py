@@ -103,6 +103,15 @@ def main():
         p1 = _hip.gcn_plan(mom.layers[1].data.edge_index, mom.layers[1].data.edge_weight, a.nodes)
         x1 = torch.randn(a.nodes, f, device=dev)
         report("spmm fwd fo", lambda: _hip.spmm(p1.fwd_ptr, p1.fwd_idx, p1.fwd_val, a.nodes, x1, p1.self_coef, None, bias, True))
+    if "gcn" in ops:
+        wq = torch.randn(f, f, device=dev) / 8
+        fused = _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, x, plan.self_coef, wq, bias, True)
+        split = _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, _hip.dense(x, wq, True)[0], plan.self_coef, None, bias, True)
+        print("gcn_forward fused vs dense+spmm: max abs diff", float((fused - split).abs().max()), "max abs", float(split.abs().max()))
+        report("gcn_forward fused (gather + MFMA + ELU)", lambda: _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, x, plan.self_coef, wq, bias, True), alg)
+        zp = torch.zeros_like(plan.fwd_ptr)
+        report("gcn_forward fused on an EMPTY graph (self rows only: MFMA stage cost)", lambda: _hip.gcn_forward(zp, plan.fwd_idx, plan.fwd_val, n_ho, x, plan.self_coef, wq, bias, True), 8 * f * n_ho / 1e9)
+        report("dense + spmm (what it replaces)", lambda: _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, _hip.dense(x, wq, True)[0], plan.self_coef, None, bias, True), alg)
     if "dense" in ops:
         w = torch.randn(f, f, device=dev)
         y = torch.randn(n_ho, f, device=dev)
