@@ -182,6 +182,13 @@ const int64_t* pp_plan_result_ptr(void* ws);
 int pp_spmm_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* X, int F, const float* self_coef,
                 const float* S, const float* bias, int act, float* Y, pp_stream_t stream);
 
+/* Transposed aggregation fused with the ELU backward of the layer that produced its input and with that layer's bias gradient:
+ *   dX[r,:] = ( sum_{p in [ptr[r],ptr[r+1])} val[p] * D[idx[p],:] ) * ELU'(Z[r,:]),   colsum[F] (may be NULL) = column sums of dX
+ * with Z the stored activation ELU(pre) and ELU' = (Z > 0 ? 1 : Z + 1).  F a multiple of 4, <= 256.  Used for the backward of the
+ * bipartite aggregation sum_j x_h[j] (dbgnn.py:50-69 re-associated: lin1 is applied AFTER the sum over the higher-order nodes). */
+int pp_spmm_act_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int F, const float* Z,
+                             float* colsum, float* dX, pp_stream_t stream);
+
 /* dpre = dY * elu'(.) from the stored OUTPUT y (1 if y > 0 else y + 1); act 0: dpre = dY; dbias[F] = column sums of dpre.
  * dpre or dbias may be NULL. */
 int pp_act_backward_f32(const float* dY, const float* Y, int64_t n_rows, int F, int act, float* dpre, float* dbias, pp_stream_t stream);
@@ -221,9 +228,11 @@ int pp_dense_backward_f32(const float* dH, const float* X, const float* W, int64
  * makes a round trip through HBM:
  *   Y[r, :Q] = act( (sum_e val[e] X[idx[e], :P] + self_coef[r] X[r, :P]) . W^T + bias ),   W is [Q,P] (Linear layout), act 0/1 (ELU)
  * over the destination-major CSR of a pp_gcn_plan (self_coef may be NULL: no self term); X has n_src rows and must stay below
- * 4 GiB (rows are addressed by 32-bit byte offsets; PP_ERR_TOO_LARGE otherwise).  P, Q in {16,32,64}. */
+ * 4 GiB (rows are addressed by 32-bit byte offsets; PP_ERR_TOO_LARGE otherwise).  P, Q in {16,32,64}.
+ * agg_out [n_rows,P] or NULL: also store the aggregated input A_hat X; the weight gradient of a layer whose input needs no
+ * gradient is then dW = dpre^T agg_out (pp_weight_grad_f32) without any backward aggregation. */
 int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
-                       const float* self_coef, const float* W, int Q, const float* bias, int act, float* Y, pp_stream_t stream);
+                       const float* self_coef, const float* W, int Q, const float* bias, int act, float* agg_out, float* Y, pp_stream_t stream);
 
 #ifdef __cplusplus
 }

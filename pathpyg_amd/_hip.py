@@ -504,9 +504,24 @@ def dense(a: torch.Tensor, weight: torch.Tensor, transposed: bool, bias: torch.T
     return out, colsum
 
 
+def spmm_act_backward(ptr, idx, val, n_rows: int, d: torch.Tensor, z: torch.Tensor, want_colsum: bool):
+    """``dx = (A d) * elu'(z)`` with ``elu'`` from the stored activation ``z`` (``z > 0 ? 1 : z + 1``) and, optionally, the
+    column sums of ``dx`` — one pass."""
+    dev = require_device(d, z)
+    d, z = d.contiguous(), z.contiguous()
+    f = d.size(1)
+    with torch.cuda.device(dev):
+        dx = torch.empty((n_rows, f), dtype=torch.float32, device=dev)
+        colsum = torch.empty(f, dtype=torch.float32, device=dev) if want_colsum else None
+        check(lib().pp_spmm_act_backward_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(d), f, _p(z), _p(colsum), _p(dx), _stream()),
+              "pp_spmm_act_backward_f32")
+    return dx, colsum
+
+
 def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, n_rows: int, x: torch.Tensor,
-                self_coef: torch.Tensor | None, weight: torch.Tensor, bias: torch.Tensor | None, act: bool) -> torch.Tensor:
-    """``act((A x + diag(self_coef) x) @ weight.T + bias)`` in one kernel (aggregation fused with the MFMA product)."""
+                self_coef: torch.Tensor | None, weight: torch.Tensor, bias: torch.Tensor | None, act: bool, want_agg: bool = False):
+    """``act((A x + diag(self_coef) x) @ weight.T + bias)`` in one kernel (aggregation fused with the MFMA product);
+    ``want_agg``: returns ``(y, A x + diag(self_coef) x)``."""
     dev = require_device(ptr, idx, val, x, self_coef, weight, bias)
     x, weight = x.contiguous(), weight.contiguous()
     q, p = weight.shape
@@ -516,9 +531,10 @@ def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, 
         bias = bias.contiguous()
     with torch.cuda.device(dev):
         y = torch.empty((n_rows, q), dtype=torch.float32, device=dev)
+        agg = torch.empty((n_rows, p), dtype=torch.float32, device=dev) if want_agg else None
         check(lib().pp_gcn_forward_f32(_p(ptr), _p(idx), _p(val), n_rows, x.size(0), _p(x), p, _p(self_coef), _p(weight), q, _p(bias),
-                                       1 if act else 0, _p(y), _stream()), "pp_gcn_forward_f32")
-    return y
+                                       1 if act else 0, _p(agg), _p(y), _stream()), "pp_gcn_forward_f32")
+    return (y, agg) if want_agg else y
 
 
 def cross_entropy(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = True):

@@ -132,7 +132,6 @@ __global__ __launch_bounds__(kBlock) void k_ptr_from_sorted_u32(const uint32_t* 
 }
 
 // ------------------------------------------------------------------ SpMM (segment reduce over CSR rows)
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
 
 // kLanes lanes own one row (each lane one float4 of a column block of kLanes*4 columns); every lane group walks kRows
 // consecutive rows TOGETHER so that their index loads, and then their row gathers, are in flight at the same time.
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_v4(const int32_t* __restrict__ 
             float4 o = acc[q];
             o.x += self_c[q] * self_row[q].x + b.x; o.y += self_c[q] * self_row[q].y + b.y;
             o.z += self_c[q] * self_row[q].z + b.z; o.w += self_c[q] * self_row[q].w + b.w;
-            if (act) { o.x = elu1(o.x); o.y = elu1(o.y); o.z = elu1(o.z); o.w = elu1(o.w); }
+            if (act) { o.x = elu_fast(o.x); o.y = elu_fast(o.y); o.z = elu_fast(o.z); o.w = elu_fast(o.w); }
             *(float4*)(Y + (r0 + q) * F + c0) = o;
         }
     }
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_s1(const int32_t* __restrict__ 
         for (int p = p0; p < p1; ++p) acc += (val ? val[p] : 1.f) * X[(int64_t)idx[p] * F + c];
         if (self_coef) acc += self_coef[r] * S[r * F + c];
         if (bias) acc += bias[c];
-        Y[r * F + c] = act ? elu1(acc) : acc;
+        Y[r * F + c] = act ? elu_fast(acc) : acc;
     }
 }
 
@@ -263,6 +262,51 @@ __global__ __launch_bounds__(kBlock) void k_scale_rows(const float* __restrict__
                                                       float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n_rows * (int64_t)F) out[i] = X[i] * coef[i / F];
+}
+
+// dX[r] = (sum_e val[e] D[idx[e]]) (*) ELU'(Z[r]),  colsum[c] += dX[r][c]      (ELU' from the stored activation Z = ELU(pre))
+// The transposed aggregation of a layer whose input was an activation, fused with that activation's backward and the bias
+// gradient of the layer that produced it: one pass (gather D, read Z, write dX) instead of SpMM + a three-pass ELU backward.
+// Persistent lane groups (kLanes = F/4 lanes per row, one float4 each) keep their column sums in registers; one LDS fold and
+// F atomics per workgroup at the end.
+template <int kLanes>
+__global__ __launch_bounds__(kBlock) void k_spmm_act_backward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                             const float* __restrict__ val, int64_t n_rows, const float* __restrict__ D,
+                                                             int F, const float* __restrict__ Z, float* __restrict__ colsum,
+                                                             float* __restrict__ dX) {
+    constexpr int kGroups = kBlock / kLanes;
+    __shared__ float s_col[kGroups][kLanes * 4 + 4];
+    const int g = threadIdx.x / kLanes, l = threadIdx.x % kLanes;
+    const bool col_live = 4 * l < F;
+    float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t r = (int64_t)blockIdx.x * kGroups + g; r < n_rows; r += (int64_t)gridDim.x * kGroups) {
+        if (!col_live) continue;
+        const int p0 = ptr[r], p1 = ptr[r + 1];
+        const float4 z = *(const float4*)(Z + r * F + 4 * l);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = p0; e < p1; e += 2) {                 // two neighbour rows in flight (the mapping plans have one or two)
+            const bool two = e + 1 < p1;
+            const int j0 = idx[e], j1 = two ? idx[e + 1] : j0;
+            const float v0 = val ? val[e] : 1.f, v1 = two ? (val ? val[e + 1] : 1.f) : 0.f;
+            const float4 x0 = *(const float4*)(D + (int64_t)j0 * F + 4 * l);
+            const float4 x1 = *(const float4*)(D + (int64_t)j1 * F + 4 * l);
+            acc.x += v0 * x0.x + v1 * x1.x; acc.y += v0 * x0.y + v1 * x1.y;
+            acc.z += v0 * x0.z + v1 * x1.z; acc.w += v0 * x0.w + v1 * x1.w;
+        }
+        acc.x *= z.x > 0.f ? 1.f : z.x + 1.f; acc.y *= z.y > 0.f ? 1.f : z.y + 1.f;
+        acc.z *= z.z > 0.f ? 1.f : z.z + 1.f; acc.w *= z.w > 0.f ? 1.f : z.w + 1.f;
+        part.x += acc.x; part.y += acc.y; part.z += acc.z; part.w += acc.w;
+        *(float4*)(dX + r * F + 4 * l) = acc;
+    }
+    if (colsum == nullptr) return;
+    *(float4*)&s_col[g][4 * l] = part;
+    __syncthreads();
+    for (int c = threadIdx.x; c < F; c += kBlock) {
+        float t = 0.f;
+#pragma unroll 4
+        for (int q = 0; q < kGroups; ++q) t += s_col[q][c];
+        atomicAdd(&colsum[c], t);
+    }
 }
 
 struct PlanWs {
@@ -482,6 +526,33 @@ int pp_act_backward_f32(const float* dY, const float* Y, int64_t n_rows, int F, 
         k_act_backward<true><<<(unsigned)g, kBlock, (size_t)F * sizeof(float), st>>>(dY, Y, n_rows, F, act, dpre, dbias);
     else
         k_act_backward<false><<<(unsigned)g, kBlock, (size_t)F * sizeof(float), st>>>(dY, Y, n_rows, F, act, dpre, dbias);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+int pp_spmm_act_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int F, const float* Z,
+                             float* colsum, float* dX, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_spmm_act_backward_f32: negative size");
+    PP_REQUIRE(F >= 4 && F % 4 == 0 && F <= 256, PP_ERR_ARG, "pp_spmm_act_backward_f32: F must be a multiple of 4 in [4, 256]");
+    PP_REQUIRE(((uintptr_t)D | (uintptr_t)Z | (uintptr_t)dX) % 16 == 0, PP_ERR_ARG, "pp_spmm_act_backward_f32: 16-byte alignment");
+    if (colsum) PP_HIP(hipMemsetAsync(colsum, 0, (size_t)F * sizeof(float), st));
+    if (n_rows == 0) return PP_OK;
+    const int q = F / 4;
+#define PP_SAB(L)                                                                                                       \
+    do {                                                                                                                \
+        int64_t blocks = ceil_div(n_rows, kBlock / L);                                                                  \
+        if (blocks > kMaxGrid) blocks = kMaxGrid;                                                                       \
+        k_spmm_act_backward<L><<<(unsigned)blocks, kBlock, 0, st>>>(ptr, idx, val, n_rows, D, F, Z, colsum, dX);        \
+    } while (0)
+    if (q <= 1) PP_SAB(1);
+    else if (q <= 2) PP_SAB(2);
+    else if (q <= 4) PP_SAB(4);
+    else if (q <= 8) PP_SAB(8);
+    else if (q <= 16) PP_SAB(16);
+    else if (q <= 32) PP_SAB(32);
+    else PP_SAB(64);
+#undef PP_SAB
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

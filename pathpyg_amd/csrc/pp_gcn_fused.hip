@@ -30,7 +30,8 @@ template <int P, int Q>
 __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                                  const float* __restrict__ val, int64_t n_rows, const float* __restrict__ X,
                                                                  const float* __restrict__ self_coef, const float* __restrict__ W,
-                                                                 const float* __restrict__ bias, int act, float* __restrict__ Y) {
+                                                                 const float* __restrict__ bias, int act, float* __restrict__ agg_out,
+                                                                 float* __restrict__ Y) {
     constexpr int kLanes = P / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = P / 4, CT = Q / 16, TS = P + 4;
     constexpr int kBatch = kRows < 2 ? kRows : 2;
     __shared__ __attribute__((aligned(16))) float s_b[P * 16 * CT];
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
                 }
                 if (p0 == p1 && sc[q] == 0.f) acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc;
+                if (agg_out != nullptr && r0 + q < n_rows) *(float4*)(agg_out + (r0 + q) * P + 4 * l) = acc;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
 // Persistent grid = exactly the workgroups that are resident at once (registers and LDS decide; asked from the runtime once).
 template <int P, int Q>
 static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                              const float* X, const float* self_coef, const float* W, const float* bias, int act, float* Y) {
+                              const float* X, const float* self_coef, const float* W, const float* bias, int act, float* agg_out, float* Y) {
     static int resident = 0;
     if (resident == 0) {
         int per_cu = 0, dev = 0, cus = 0;
@@ -178,17 +180,17 @@ static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const int32_t* pt
     }
     int64_t blocks = ceil_div(n_tiles, kGcnWaves);
     if (blocks > resident) blocks = resident;
-    k_gcn_forward<P, Q><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, X, self_coef, W, bias, act, Y);
+    k_gcn_forward<P, Q><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, X, self_coef, W, bias, act, agg_out, Y);
     return PP_OK;
 }
 
 template <int P>
 static int launch_gcn_forward_q(int Q, int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                                const float* X, const float* self_coef, const float* W, const float* bias, int act, float* Y) {
+                                const float* X, const float* self_coef, const float* W, const float* bias, int act, float* agg_out, float* Y) {
     switch (Q) {
-        case 16: return launch_gcn_forward<P, 16>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, Y);
-        case 32: return launch_gcn_forward<P, 32>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, Y);
-        case 64: return launch_gcn_forward<P, 64>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, Y);
+        case 16: return launch_gcn_forward<P, 16>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, agg_out, Y);
+        case 32: return launch_gcn_forward<P, 32>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, agg_out, Y);
+        case 64: return launch_gcn_forward<P, 64>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, agg_out, Y);
         default: return PP_ERR_ARG;
     }
 }
@@ -198,21 +200,21 @@ static int launch_gcn_forward_q(int Q, int64_t n_tiles, hipStream_t st, const in
 extern "C" {
 
 int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
-                       const float* self_coef, const float* W, int Q, const float* bias, int act, float* Y, pp_stream_t stream) {
+                       const float* self_coef, const float* W, int Q, const float* bias, int act, float* agg_out, float* Y, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_forward_f32: negative size");
     PP_REQUIRE(pp_dense_supported(P, Q), PP_ERR_ARG, "pp_gcn_forward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", P, Q);
     PP_REQUIRE(act == 0 || act == 1, PP_ERR_ARG, "pp_gcn_forward_f32: act must be 0 (none) or 1 (elu)");
-    PP_REQUIRE(((uintptr_t)X) % 16 == 0, PP_ERR_ARG, "pp_gcn_forward_f32: X must be 16-byte aligned");
+    PP_REQUIRE(((uintptr_t)X | (uintptr_t)agg_out) % 16 == 0, PP_ERR_ARG, "pp_gcn_forward_f32: X and agg_out must be 16-byte aligned");
     PP_REQUIRE(n_src >= 0 && (uint64_t)n_src * (uint64_t)P * 4 <= 0xffffffffull, PP_ERR_TOO_LARGE,
                "pp_gcn_forward_f32: X must be smaller than 4 GiB (use pp_dense_f32 + pp_spmm_f32)");
     if (n_rows == 0) return PP_OK;
     const int64_t n_tiles = pp::ceil_div(n_rows, 16);
     int rc;
     switch (P) {
-        case 16: rc = pp::launch_gcn_forward_q<16>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, Y); break;
-        case 32: rc = pp::launch_gcn_forward_q<32>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, Y); break;
-        default: rc = pp::launch_gcn_forward_q<64>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, Y); break;
+        case 16: rc = pp::launch_gcn_forward_q<16>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, agg_out, Y); break;
+        case 32: rc = pp::launch_gcn_forward_q<32>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, agg_out, Y); break;
+        default: rc = pp::launch_gcn_forward_q<64>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, agg_out, Y); break;
     }
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();

@@ -121,22 +121,52 @@ class _GcnLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, x, weight, bias, fuse_act: bool, act_bias):
         ctx.plan, ctx.fuse_act, ctx.has_act_bias = plan, fuse_act, act_bias is not None
+        # first layer of a stack (its input needs no gradient): keep the aggregated input A x; the only gradient left is
+        # dW = dpre^T (A x), so the backward pass needs no aggregation at all
+        ctx.keep_agg = not ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+        out = _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x, plan.self_coef, weight, bias, True, ctx.keep_agg)
+        if ctx.keep_agg:
+            ctx.save_for_backward(out[1], weight)
+            return out[0]
         ctx.save_for_backward(x, weight)
-        return _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x, plan.self_coef, weight, bias, True)
+        return out
 
     @staticmethod
     def backward(ctx, dpre):
         plan = ctx.plan
         x, weight = ctx.saved_tensors
         dpre = dpre.contiguous()
-        g = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, dpre)
         dx = dw = dact = None
+        if ctx.keep_agg:
+            dw, _ = _hip.weight_grad(dpre, x, want_bias=False)           # x is the stored A x here
+            return None, None, dw, None, None, None
+        g = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, dpre)
         want_sum = ctx.fuse_act and ctx.has_act_bias and ctx.needs_input_grad[5]
         if ctx.needs_input_grad[1]:
             dx, dact, dw, _ = _hip.dense_backward(g, x, weight, ctx.fuse_act, True, want_sum, False)
         elif ctx.needs_input_grad[2]:
             dw, _ = _hip.weight_grad(g, x, want_bias=False)
         return None, dx, dw, None, None, dact
+
+
+class _AggregateAct(torch.autograd.Function):
+    """``agg = A y`` for a stored activation ``y = ELU(pre)`` of a layer below that was told ``grad_is_pre``: the backward pass
+    returns the gradient w.r.t. that layer's PRE-activation, ``(A^T d_agg) * ELU'(pre)``, and its bias gradient (as the
+    gradient of ``act_bias``) from one kernel (``pp_spmm_act_backward_f32``)."""
+
+    @staticmethod
+    def forward(ctx, plan, y, act_bias):
+        ctx.plan, ctx.has_act_bias = plan, act_bias is not None
+        ctx.save_for_backward(y)
+        return _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, y)
+
+    @staticmethod
+    def backward(ctx, d_agg):
+        plan = ctx.plan
+        (y,) = ctx.saved_tensors
+        want_sum = ctx.has_act_bias and ctx.needs_input_grad[2]
+        dpre, colsum = _hip.spmm_act_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d_agg.contiguous(), y, want_sum)
+        return None, dpre, colsum
 
 
 def dense(x, linear: Linear, fuse_act: bool = False, act_bias=None):
@@ -290,5 +320,13 @@ class DBGNN(Module):
         x, bias_fo = stack(self.first_order_layers, x, plan_fo)
         x_h, bias_ho = stack(self.higher_order_layers, x_h, plan_ho)
         bl = self.bipartite_layer
+        if plan_bi.fwd_val is None and x_h.size(1) % 4 == 0 and x_h.size(1) <= 256:
+            # sum_j (W1 x_h[j] + b1) = W1 (sum_j x_h[j]) + deg * b1: aggregate the U higher-order rows FIRST (one gather pass over
+            # x_h), then everything else lives on the N first-order rows (N << U) — instead of a dense layer over all U rows
+            # forward and its three-matrix backward.  Same sum, re-associated (linearity of lin1).
+            agg = _AggregateAct.apply(plan_bi, x_h, bias_ho)
+            per_edge = dense(x, bl.lin2, True, bias_fo) + bl.lin1.bias
+            x = F.elu(torch.addcmul(F.linear(agg, bl.lin1.weight), plan_bi.self_coef.unsqueeze(1), per_edge))
+            return F.linear(x, self.lin.weight, self.lin.bias)
         x = _Propagate.apply(plan_bi, dense(x_h, bl.lin1, True, bias_ho), dense(x, bl.lin2, True, bias_fo), None, True, True)
         return dense(x, self.lin, True, None)

@@ -263,3 +263,29 @@ def test_fused_gcn_layer_rejects_unsupported_shapes(pp):
     idx = torch.zeros(1, dtype=torch.int32, device=DEV)
     with pytest.raises(ValueError):
         _hip.gcn_forward(ptr, idx, None, 4, torch.zeros(4, 48, device=DEV), None, torch.zeros(64, 48, device=DEV), None, True)
+
+
+@pytest.mark.parametrize("n_rows,n_src,e,f", [(1, 1, 1, 4), (1000, 300, 1000, 64), (5000, 5000, 12000, 32), (70_001, 900, 70_001, 64), (333, 50, 0, 8)])
+def test_spmm_act_backward_kernel(pp, n_rows, n_src, e, f):
+    """(A d) * elu'(z) + column sums in one pass against float64."""
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(n_rows + e + f)
+    row = torch.sort(torch.randint(0, n_rows, (e,), generator=g)).values
+    ptr = torch.zeros(n_rows + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.bincount(row, minlength=n_rows), 0).int()
+    idx = torch.randint(0, n_src, (max(e, 1),), generator=g, dtype=torch.int32)[:e]
+    val = torch.rand(e, generator=g)
+    d = torch.randn(n_src, f, generator=g)
+    z = F.elu(torch.randn(n_rows, f, generator=g))
+    a = torch.zeros(n_rows, n_src, dtype=torch.float64)
+    a.index_put_((row, idx.long()), val.double(), accumulate=True)
+    want = (a @ d.double()) * torch.where(z > 0, torch.ones_like(z), z + 1).double()
+    for use_val in (True, False):
+        if not use_val:
+            a1 = torch.zeros(n_rows, n_src, dtype=torch.float64)
+            a1.index_put_((row, idx.long()), torch.ones(e, dtype=torch.float64), accumulate=True)
+            want = (a1 @ d.double()) * torch.where(z > 0, torch.ones_like(z), z + 1).double()
+        got, colsum = _hip.spmm_act_backward(ptr.to(DEV), idx.to(DEV), val.to(DEV) if use_val else None, n_rows, d.to(DEV), z.to(DEV), True)
+        torch.testing.assert_close(got.cpu(), want.float(), rtol=RTOL, atol=ATOL)
+        cs = want.sum(0).float()
+        torch.testing.assert_close(colsum.cpu(), cs, rtol=1e-4, atol=1e-5 * float(want.abs().sum(0).max() + 1))
