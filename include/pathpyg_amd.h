@@ -234,6 +234,15 @@ int pp_dense_backward_f32(const float* dH, const float* X, const float* W, int64
 int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
                        const float* self_coef, const float* W, int Q, const float* bias, int act, float* agg_out, float* Y, pp_stream_t stream);
 
+/* Backward of that layer in one kernel (pp_spmm_f32 over the source-major CSR + pp_dense_backward_f32 without the round trip of the
+ * aggregated gradient through HBM):  G = A^T D + diag(self_coef) D with D = dpre [n_rows,M];
+ *   d_in[n_rows,K] = (G . W) (*) ELU'(X) when fuse_act (X [n_rows,K] is then the stored activation of the layer below),
+ *   colsum_in[K] (may be NULL) = column sums of d_in,  dW[M,K] = G^T X.   W is [M,K]; M, K in {16,32,64}; D below 4 GiB. */
+size_t pp_gcn_backward_ws_bytes(int64_t n_rows);
+int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
+                        const float* self_coef, const float* X, int K, const float* W, int fuse_act, float* d_in, float* colsum_in,
+                        float* dW, void* ws, size_t ws_bytes, pp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -537,6 +537,28 @@ def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, 
     return (y, agg) if want_agg else y
 
 
+def gcn_backward(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, x: torch.Tensor, weight: torch.Tensor, fuse_act: bool,
+                 want_colsum: bool):
+    """Backward of :func:`gcn_forward` in one kernel: ``(d_in, colsum_in or None, dW)`` from the gradient ``dpre`` w.r.t. the
+    layer's pre-activation, over the SOURCE-major CSR (``ptr``/``idx``/``val`` = the plan's ``bwd_*`` arrays)."""
+    dev = require_device(ptr, idx, val, dpre, self_coef, x, weight)
+    dpre, x, weight = dpre.contiguous(), x.contiguous(), weight.contiguous()
+    m, k = weight.shape
+    if dpre.size(1) != m or x.size(1) != k or x.size(0) != n_rows or dpre.size(0) != n_rows:
+        raise ValueError("gcn_backward: shapes do not match")
+    L = lib()
+    with torch.cuda.device(dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_in = torch.empty((n_rows, k), **f32)
+        colsum = torch.empty(k, **f32) if want_colsum else None
+        dw = torch.empty((m, k), **f32)
+        ws = _workspace(L.pp_gcn_backward_ws_bytes(n_rows), dev)
+        check(L.pp_gcn_backward_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(dpre), m, _p(self_coef), _p(x), k, _p(weight),
+                                    1 if fuse_act else 0, _p(d_in), _p(colsum), _p(dw), _p(ws), ws.numel(), _stream()),
+              "pp_gcn_backward_f32")
+    return d_in, colsum, dw
+
+
 def cross_entropy(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = True):
     """(mean cross-entropy [scalar tensor], d loss / d logits or None) in one pass; logits [N, C<=64] fp32, target int64 [N]."""
     dev = require_device(logits, target)

@@ -1111,6 +1111,14 @@ static int launch_dense_backward_k(int K, unsigned grid, hipStream_t st, const f
     return PP_OK;
 }
 
+// shared with pp_gcn_fused.hip: fixed-order sum of per-workgroup [64][64] partial weight gradients
+int weight_grad_reduce(const float* partial_w, const float* partial_b, int64_t n_parts, int M, int K, float* dW, float* db, hipStream_t st) {
+    const int outs = M * K + (db ? M : 0);
+    k_weight_grad_reduce<<<(unsigned)ceil_div(outs, kBlock / kWgSlices), kBlock, 0, st>>>(partial_w, db ? partial_b : nullptr, n_parts, M, K, dW, db);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
 static inline int64_t dense_backward_blocks(int64_t n_rows) {
     int64_t blocks = ceil_div(ceil_div(n_rows > 0 ? n_rows : 1, 16), kWavesPerBlock);
     const int64_t cap = 256 * 2;                       // 2 workgroups (8 waves) per CU: ~230 registers per lane

@@ -195,6 +195,241 @@ static int launch_gcn_forward_q(int Q, int64_t n_tiles, hipStream_t st, const in
     }
 }
 
+// =====================================================================================================
+// Backward of such a layer, again in one kernel (the math of pp_spmm_f32 on the transposed CSR + pp_dense_backward_f32):
+//     G      = A^T dpre + diag(self) dpre                       gathered per 16-row tile into LDS, never written to HBM
+//     d_in   = (G . W) (*) ELU'(x),  colsum_in = column sums    gradient w.r.t. the PRE-activation of the layer below + its bias gradient
+//     dW     = G^T x                                             contraction over the tile's rows on a second MFMA stream
+// Saves the write and the re-read of G (2 of the 7 N x 64 matrix passes of the two-kernel form).
+template <int M, int K>
+__global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                             const float* __restrict__ val, int64_t n_rows, const float* __restrict__ D,
+                                                             const float* __restrict__ self_coef, const float* __restrict__ X,
+                                                             const float* __restrict__ W, int fuse_act, float* __restrict__ d_in,
+                                                             float* __restrict__ colsum_in, float* __restrict__ partial_w) {
+    constexpr int kLanes = M / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = M / 4, MT = M / 16, CT = K / 16, TS = M + 4;
+    constexpr int kBatch = kRows < 2 ? kRows : 2;
+    __shared__ __attribute__((aligned(16))) float s_b[M * 16 * CT];          // [k][i][ct] = W[k][ct*16 + i]
+    __shared__ __attribute__((aligned(16))) float s_tile[kGcnWaves][16 * TS];
+    __shared__ float s_fold[64 * 64];
+    for (int e = threadIdx.x; e < M * K; e += kGcnThreads) {
+        const int k = e / K, j = e - k * K;
+        s_b[(k * 16 + (j & 15)) * CT + (j >> 4)] = W[e];
+    }
+    for (int e = threadIdx.x; e < 64 * 64; e += kGcnThreads) s_fold[e] = 0.f;
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int g = lane / kLanes, l = lane % kLanes;
+    const int i = lane & 15, kq = lane >> 4;
+    float* tile = s_tile[wave];
+    const char* db = (const char*)D;
+    f32x4 acc_w[MT][CT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc_w[mt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float col_in[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) col_in[ct] = 0.f;
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    const int64_t step = (int64_t)gridDim.x * kGcnWaves;
+    for (int64_t t = (int64_t)blockIdx.x * kGcnWaves + wave; t < n_tiles; t += step) {
+        // natural-layout rows of the layer input: B operand of the dW stream and source of the ELU' epilogue (in flight during the gather)
+        float xr[CT][4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t r = t * 16 + 4 * kq + reg;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) xr[ct][reg] = r < n_rows ? X[r * K + ct * 16 + i] : 0.f;
+        }
+        const int64_t r0 = t * 16 + g * kRows;
+        int p[kRows + 1];
+#pragma unroll
+        for (int q = 0; q <= kRows; ++q) {
+            const int64_t r = r0 + q < n_rows ? r0 + q : n_rows;
+            p[q] = ptr[r];
+        }
+        int cj[kRows];
+        float cv[kRows], sc[kRows];
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+            const int mine = p[q] + l;
+            const bool in = mine < p[q + 1];
+            cj[q] = in ? idx[mine] : 0;
+            cv[q] = in ? (val ? val[mine] : 1.f) : 0.f;
+            sc[q] = (self_coef != nullptr && r0 + q < n_rows) ? self_coef[r0 + q] : 0.f;
+        }
+#pragma unroll
+        for (int b0 = 0; b0 < kRows; b0 += kBatch) {
+            uint32_t off[kBatch][kFirst], self_off[kBatch];
+#pragma unroll
+            for (int qq = 0; qq < kBatch; ++qq) {
+                const int q = b0 + qq;
+                const bool self_here = self_coef != nullptr && r0 + q < n_rows;
+                const int first = __shfl(cj[q], 0, kLanes);
+                const int dummy = p[q] < p[q + 1] ? first : (self_here ? (int)(r0 + q) : 0);
+                self_off[qq] = (uint32_t)(self_here ? (int)(r0 + q) : dummy) * (uint32_t)(M * 4) + (uint32_t)(16 * l);
+#pragma unroll
+                for (int u = 0; u < kFirst; ++u) {
+                    const int j = u == 0 ? first : __shfl(cj[q], u, kLanes);
+                    off[qq][u] = (uint32_t)(p[q] + u < p[q + 1] ? j : dummy) * (uint32_t)(M * 4) + (uint32_t)(16 * l);
+                }
+            }
+            float4 x[kBatch][kFirst], sr[kBatch];
+#pragma unroll
+            for (int qq = 0; qq < kBatch; ++qq) {
+                sr[qq] = *(const float4*)(db + self_off[qq]);
+#pragma unroll
+                for (int u = 0; u < kFirst; ++u) x[qq][u] = *(const float4*)(db + off[qq][u]);
+            }
+#pragma unroll
+            for (int qq = 0; qq < kBatch; ++qq) {
+                const int q = b0 + qq;
+                float4 acc = make_float4(sc[q] * sr[qq].x, sc[q] * sr[qq].y, sc[q] * sr[qq].z, sc[q] * sr[qq].w);
+#pragma unroll
+                for (int u = 0; u < kFirst; ++u) {
+                    const float v = __shfl(cv[q], u, kLanes);
+                    acc.x += v * x[qq][u].x; acc.y += v * x[qq][u].y; acc.z += v * x[qq][u].z; acc.w += v * x[qq][u].w;
+                }
+                int my_j = cj[q];
+                float my_v = cv[q];
+                const int p0 = p[q], p1 = p[q + 1];
+                for (int base = p0; base < p1; base += kLanes) {      // rows with more than kFirst neighbours
+                    if (base != p0) {
+                        const int mine = base + l;
+                        my_j = mine < p1 ? idx[mine] : 0;
+                        my_v = mine < p1 ? (val ? val[mine] : 1.f) : 0.f;
+                    }
+                    const int cnt = p1 - base < kLanes ? p1 - base : kLanes;
+                    for (int e = base == p0 ? kFirst : 0; e < cnt; e += 4) {
+                        float4 y[4];
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int src_lane = (e + u) < cnt ? e + u : e;
+                            const int j = __shfl(my_j, src_lane, kLanes);
+                            v[u] = (e + u) < cnt ? __shfl(my_v, src_lane, kLanes) : 0.f;
+                            y[u] = *(const float4*)(db + (uint32_t)j * (uint32_t)(M * 4) + (uint32_t)(16 * l));
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc.x += v[u] * y[u].x; acc.y += v[u] * y[u].y; acc.z += v[u] * y[u].z; acc.w += v[u] * y[u].w;
+                        }
+                    }
+                }
+                if (p0 == p1 && sc[q] == 0.f) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---------------------------------------------------------------- G . W  ->  d_in tile
+        float4 a[KQ / 4];
+#pragma unroll
+        for (int c = 0; c < KQ / 4; ++c) a[c] = *(const float4*)(tile + i * TS + kq * KQ + 4 * c);
+        float hr[MT][4];                                              // G in the natural layout: A operand of the dW stream
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hr[mt][reg] = tile[(4 * kq + reg) * TS + mt * 16 + i];
+        f32x4 out[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) out[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KQ / 4; ++c) {
+            const float av[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* bp = s_b + ((kq * KQ + 4 * c + e) * 16 + i) * CT;
+                float bv[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) bv[ct] = bp[ct];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) out[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[ct], out[ct], 0, 0, 0);
+            }
+        }
+        // ---------------------------------------------------------------- dW += G_tile^T x_tile (rows {reg, 4+reg, 8+reg, 12+reg} per step)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc_w[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[mt][reg], xr[ct][reg], acc_w[mt][ct], 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+        float* yp = d_in + (t * 16 + 4 * kq) * K + i;
+        const int rows_here = n_rows - (t * 16 + 4 * kq) < 4 ? (int)(n_rows - (t * 16 + 4 * kq)) : 4;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float v = out[ct][reg];
+                if (fuse_act) {
+                    const float y = xr[ct][reg];
+                    v *= y > 0.f ? 1.f : y + 1.f;
+                }
+                col_in[ct] += v;                                      // rows past the end aggregate nothing: v == 0 there
+                if (reg < rows_here) yp[reg * K + ct * 16] = v;
+            }
+    }
+    if (colsum_in) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            float v = col_in[ct];
+            v += __shfl_xor(v, 16, kWave);
+            v += __shfl_xor(v, 32, kWave);
+            if (kq == 0) atomicAdd(&colsum_in[ct * 16 + i], v);
+        }
+    }
+    // fold the waves' dW through LDS in wave order: one partial [64][64] tile per workgroup (zero padded), summed by weight_grad_reduce
+    for (int w = 0; w < kGcnWaves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) s_fold[(mt * 16 + 4 * kq + reg) * 64 + ct * 16 + i] += acc_w[mt][ct][reg];
+        }
+        __syncthreads();
+    }
+    float* pw = partial_w + ((int64_t)blockIdx.x << 12);
+    for (int e = threadIdx.x; e < 64 * 64; e += kGcnThreads) pw[e] = s_fold[e];
+}
+
+constexpr int64_t kGcnBackwardMaxBlocks = 256 * 4;
+
+template <int M, int K>
+static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
+                               const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, float* d_in,
+                               float* colsum_in, float* partial_w, int64_t* blocks_out) {
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K>, kGcnThreads, 0));
+        PP_HIP(hipGetDevice(&dev));
+        PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+        if (resident > kGcnBackwardMaxBlocks) resident = (int)kGcnBackwardMaxBlocks;
+    }
+    int64_t blocks = ceil_div(n_tiles, kGcnWaves);
+    if (blocks > resident) blocks = resident;
+    *blocks_out = blocks;
+    k_gcn_backward<M, K><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, d_in, colsum_in, partial_w);
+    return PP_OK;
+}
+
+template <int M>
+static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
+                                 const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, float* d_in,
+                                 float* colsum_in, float* partial_w, int64_t* blocks_out) {
+    switch (K) {
+        case 16: return launch_gcn_backward<M, 16>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, d_in, colsum_in, partial_w, blocks_out);
+        case 32: return launch_gcn_backward<M, 32>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, d_in, colsum_in, partial_w, blocks_out);
+        case 64: return launch_gcn_backward<M, 64>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, d_in, colsum_in, partial_w, blocks_out);
+        default: return PP_ERR_ARG;
+    }
+}
+
 }  // namespace pp
 
 extern "C" {
@@ -219,6 +454,41 @@ int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val,
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();
     return PP_OK;
+}
+
+size_t pp_gcn_backward_ws_bytes(int64_t n_rows) {
+    int64_t blocks = pp::ceil_div(pp::ceil_div(n_rows > 0 ? n_rows : 1, 16), pp::kGcnWaves);
+    if (blocks > pp::kGcnBackwardMaxBlocks) blocks = pp::kGcnBackwardMaxBlocks;
+    return pp::align_up((size_t)blocks * 4096 * sizeof(float));
+}
+
+int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
+                        const float* self_coef, const float* X, int K, const float* W, int fuse_act, float* d_in, float* colsum_in,
+                        float* dW, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_backward_f32: negative size");
+    PP_REQUIRE(pp_dense_supported(M, K), PP_ERR_ARG, "pp_gcn_backward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", M, K);
+    PP_REQUIRE(d_in != nullptr && dW != nullptr, PP_ERR_ARG, "pp_gcn_backward_f32: d_in and dW are required");
+    PP_REQUIRE(((uintptr_t)D) % 16 == 0, PP_ERR_ARG, "pp_gcn_backward_f32: D must be 16-byte aligned");
+    PP_REQUIRE((uint64_t)n_rows * (uint64_t)M * 4 <= 0xffffffffull, PP_ERR_TOO_LARGE,
+               "pp_gcn_backward_f32: D must be smaller than 4 GiB (use pp_spmm_f32 + pp_dense_backward_f32)");
+    PP_REQUIRE(ws_bytes >= pp_gcn_backward_ws_bytes(n_rows), PP_ERR_WORKSPACE, "pp_gcn_backward_f32: workspace too small");
+    if (colsum_in) PP_HIP(hipMemsetAsync(colsum_in, 0, (size_t)K * sizeof(float), st));
+    if (n_rows == 0) {
+        PP_HIP(hipMemsetAsync(dW, 0, (size_t)M * K * sizeof(float), st));
+        return PP_OK;
+    }
+    const int64_t n_tiles = pp::ceil_div(n_rows, 16);
+    int64_t blocks = 0;
+    int rc;
+    switch (M) {
+        case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, d_in, colsum_in, (float*)ws, &blocks); break;
+        case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, d_in, colsum_in, (float*)ws, &blocks); break;
+        default: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, d_in, colsum_in, (float*)ws, &blocks); break;
+    }
+    if (rc != PP_OK) return rc;
+    PP_LAUNCH_CHECK();
+    return pp::weight_grad_reduce((const float*)ws, nullptr, blocks, M, K, dW, nullptr, st);
 }
 
 }  // extern "C"

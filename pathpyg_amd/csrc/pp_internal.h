@@ -21,4 +21,7 @@ template <typename KeyT>
 int sort_pairs(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out, int64_t n, int begin_bit,
                int end_bit, void* ws, size_t ws_bytes, hipStream_t st);
 
+// pp_dbgnn.hip
+int weight_grad_reduce(const float* partial_w, const float* partial_b, int64_t n_parts, int M, int K, float* dW, float* db, hipStream_t st);
+
 }  // namespace pp

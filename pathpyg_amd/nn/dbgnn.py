@@ -110,8 +110,8 @@ class _GcnLayer(torch.autograd.Function):
 
     Contract (as ``_Propagate(grad_is_pre=True)``): the consumer of ``y`` hands back the gradient w.r.t. the PRE-activation and
     computes this layer's bias gradient; ``fuse_act`` / ``act_bias`` describe the layer BELOW exactly as in :class:`_Dense`.
-    Backward is the same math as the unfused path: ``G = A^T dpre`` (one SpMM), then input gradient, ELU' of the layer below,
-    its bias gradient and ``dW = G^T x`` in one pass (``pp_dense_backward_f32``)."""
+    Backward is the same math as the unfused path — ``G = A^T dpre``, input gradient ``G W`` with the ELU' of the layer below,
+    its bias gradient and ``dW = G^T x`` — in one kernel as well (``pp_gcn_backward_f32``): ``G`` never reaches HBM."""
 
     @staticmethod
     def supported(plan, x, weight) -> bool:
@@ -140,11 +140,13 @@ class _GcnLayer(torch.autograd.Function):
         if ctx.keep_agg:
             dw, _ = _hip.weight_grad(dpre, x, want_bias=False)           # x is the stored A x here
             return None, None, dw, None, None, None
-        g = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, dpre)
         want_sum = ctx.fuse_act and ctx.has_act_bias and ctx.needs_input_grad[5]
         if ctx.needs_input_grad[1]:
-            dx, dact, dw, _ = _hip.dense_backward(g, x, weight, ctx.fuse_act, True, want_sum, False)
+            # aggregation over the transposed graph, input gradient (+ ELU' and the bias gradient of the layer below) and dW: one kernel
+            dx, dact, dw = _hip.gcn_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, x, weight,
+                                             ctx.fuse_act, want_sum)
         elif ctx.needs_input_grad[2]:
+            g = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, dpre)
             dw, _ = _hip.weight_grad(g, x, want_bias=False)
         return None, dx, dw, None, None, dact
 

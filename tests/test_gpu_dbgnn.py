@@ -289,3 +289,38 @@ def test_spmm_act_backward_kernel(pp, n_rows, n_src, e, f):
         torch.testing.assert_close(got.cpu(), want.float(), rtol=RTOL, atol=ATOL)
         cs = want.sum(0).float()
         torch.testing.assert_close(colsum.cpu(), cs, rtol=1e-4, atol=1e-5 * float(want.abs().sum(0).max() + 1))
+
+
+@pytest.mark.parametrize("n,e,m,k,fuse", [(1, 0, 16, 16, True), (17, 40, 64, 64, True), (1000, 5000, 32, 64, False), (4097, 9000, 64, 16, True),
+                                          (70_001, 200_000, 64, 64, True), (300, 20_000, 64, 32, True)])
+def test_fused_gcn_backward_kernel(pp, n, e, m, k, fuse):
+    """pp_gcn_backward_f32 against float64: G = A^T dpre + self*dpre, d_in = (G W) * elu'(x), column sums, dW = G^T x."""
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(n + e + m + k)
+    row = torch.sort(torch.randint(0, n, (e,), generator=g)).values
+    if n > 10 and e > 100:
+        row[: min(e // 4, 2000)] = row[min(e // 4, 2000)]
+        row = torch.sort(row).values
+    ptr = torch.zeros(n + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.bincount(row, minlength=n), 0).int()
+    idx = torch.randint(0, n, (max(e, 1),), generator=g, dtype=torch.int32)[:e]
+    val = torch.rand(e, generator=g)
+    self_coef = torch.rand(n, generator=g)
+    dpre = torch.randn(n, m, generator=g)
+    x = F.elu(torch.randn(n, k, generator=g))
+    w = torch.randn(m, k, generator=g) / m ** 0.5
+    a = torch.zeros(n, n, dtype=torch.float64)
+    a.index_put_((row, idx.long()), val.double(), accumulate=True)
+    a += torch.diag(self_coef.double())
+    gmat = a @ dpre.double()
+    d_in = gmat @ w.double()
+    if fuse:
+        d_in = d_in * torch.where(x > 0, torch.ones_like(x), x + 1).double()
+    dw = gmat.t() @ x.double()
+    got_in, got_sum, got_w = _hip.gcn_backward(ptr.to(DEV), idx.to(DEV), val.to(DEV), n, dpre.to(DEV), self_coef.to(DEV), x.to(DEV),
+                                               w.to(DEV), fuse, True)
+    scale = float(d_in.abs().max()) + 1e-12
+    torch.testing.assert_close(got_in.cpu(), d_in.float(), rtol=RTOL, atol=max(ATOL, 1e-6 * scale))
+    torch.testing.assert_close(got_sum.cpu(), d_in.sum(0).float(), rtol=1e-4, atol=1e-5 * float(d_in.abs().sum(0).max() + 1))
+    wscale = float((gmat.abs().t() @ x.double().abs()).max()) + 1e-12
+    torch.testing.assert_close(got_w.cpu(), dw.float(), rtol=1e-4, atol=2e-6 * wscale)

@@ -112,6 +112,11 @@ def main():
         zp = torch.zeros_like(plan.fwd_ptr)
         report("gcn_forward fused on an EMPTY graph (self rows only: MFMA stage cost)", lambda: _hip.gcn_forward(zp, plan.fwd_idx, plan.fwd_val, n_ho, x, plan.self_coef, wq, bias, True), 8 * f * n_ho / 1e9)
         report("dense + spmm (what it replaces)", lambda: _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, _hip.dense(x, wq, True)[0], plan.self_coef, None, bias, True), alg)
+    if "gcn" in ops:
+        dpre = torch.randn(n_ho, f, device=dev)
+        xa = torch.nn.functional.elu(torch.randn(n_ho, f, device=dev))
+        report("gcn_backward fused (gather + d_in + ELU' + colsum + dW)", lambda: _hip.gcn_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, n_ho, dpre, plan.self_coef, xa, wq, True, True))
+        report("spmm bwd + dense_backward (what it replaces)", lambda: _hip.dense_backward(_hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, n_ho, dpre, plan.self_coef, dpre), xa, wq, True, True, True, False))
     if "dense" in ops:
         w = torch.randn(f, f, device=dev)
         y = torch.randn(n_ho, f, device=dev)
