@@ -328,7 +328,8 @@ class DBGNN(Module):
             # forward and its three-matrix backward.  Same sum, re-associated (linearity of lin1).
             agg = _AggregateAct.apply(plan_bi, x_h, bias_ho)
             per_edge = dense(x, bl.lin2, True, bias_fo) + bl.lin1.bias
-            x = F.elu(torch.addcmul(F.linear(agg, bl.lin1.weight), plan_bi.self_coef.unsqueeze(1), per_edge))
-            return F.linear(x, self.lin.weight, self.lin.bias)
+            # (dense(): its weight gradients contract over all N rows on the MFMA kernel; the library GEMM is 4x slower there)
+            x = F.elu(torch.addcmul(_Dense.apply(agg, bl.lin1.weight, None, False, None), plan_bi.self_coef.unsqueeze(1), per_edge))
+            return dense(x, self.lin)
         x = _Propagate.apply(plan_bi, dense(x_h, bl.lin1, True, bias_ho), dense(x, bl.lin2, True, bias_fo), None, True, True)
         return dense(x, self.lin, True, None)
