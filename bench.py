@@ -94,6 +94,21 @@ def spmm_bytes(ptr, idx, val, n_rows, x, f, self_coef, s, bias, act, y, stream):
 spmm_bytes.shape_of = {}
 
 
+def gcn_forward_bytes(ptr, idx, val, n_rows, n_src, x, p, self_coef, w, q, bias, act, agg_out, y, stream):
+    """Algorithmic HBM bytes of one fused GCN layer forward (pp_gcn_forward_f32): CSR once, every input row once (P wide), every
+    output row once (Q wide), the optional aggregated-input copy, the self coefficients and W."""
+    nnz, _ = spmm_bytes.shape_of[ptr]
+    return (4 * (n_rows + 1) + nnz * (4 + (4 if val else 0)) + 4 * p * n_src + 4 * q * n_rows + (4 * n_rows if self_coef else 0)
+            + (4 * p * n_rows if agg_out else 0) + 4 * p * q)
+
+
+def gcn_backward_bytes(ptr, idx, val, n_rows, d, m, self_coef, x, k, w, fuse_act, d_in, colsum, dw, ws, ws_bytes, stream):
+    """Algorithmic HBM bytes of one fused GCN layer backward (pp_gcn_backward_f32): CSR, dpre (M wide) and the layer input (K wide)
+    read once, the input gradient (K wide) written once."""
+    nnz, _ = spmm_bytes.shape_of[ptr]
+    return 4 * (n_rows + 1) + nnz * (4 + (4 if val else 0)) + 4 * m * n_rows + 8 * k * n_rows + (4 * n_rows if self_coef else 0) + 8 * m * k
+
+
 def pmc_traffic(kernel_key: str, args) -> float | None:
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/, separate FETCH_SIZE
     and WRITE_SIZE runs of this same command, gfx950 FETCH correction applied).  Only valid for the default workload."""
@@ -251,17 +266,22 @@ def main() -> int:
     _hip.gcn_plan, _hip.bipartite_plan = gcn_plan, bip_plan
 
     with KernelClock(L, "pp_spmm_f32", spmm_bytes) as spmm_clock, \
+            KernelClock(L, "pp_gcn_forward_f32", gcn_forward_bytes) as fwd_clock, \
+            KernelClock(L, "pp_gcn_backward_f32", gcn_backward_bytes) as bwd_clock, \
             KernelClock(L, "pp_temporal_fill", lambda m, n, total, *r: 16 * total + 12 * m) as fill_clock:
+        clocks = (spmm_clock, fwd_clock, bwd_clock, fill_clock)
         for _ in range(args.warmup):
             step(False)
         barrier()
-        spmm_clock.enabled = fill_clock.enabled = True
+        for c in clocks:
+            c.enabled = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step(True)
         barrier()
         elapsed = time.perf_counter() - t0
-        spmm_clock.enabled = fill_clock.enabled = False
+        for c in clocks:
+            c.enabled = False
     # untimed extra: the k=2 -> k=3 line-graph lift of the same event graph (the lift kernel WITHOUT the continuation-list gather)
     k3 = None
     if rank == 0:
@@ -292,10 +312,21 @@ def main() -> int:
         lift = sum(a.elapsed_time(b) for a, b in lift_ms) / len(lift_ms)
         n_spmm, spmm_ms, spmm_b = spmm_clock.summary()
         n_fill, fill_ms, fill_b = fill_clock.summary()
-        dominant = ("k_spmm_v4 (pp_spmm_f32)", n_spmm, spmm_ms, spmm_b) if spmm_ms >= fill_ms else \
-                   ("k_expand (pp_temporal_fill)", n_fill, fill_ms, fill_b)
-        traffic = pmc_traffic("k_spmm_v4", args) if spmm_ms >= fill_ms else None
+        candidates = [("k_spmm_v4 (pp_spmm_f32)", "k_spmm_v4", n_spmm, spmm_ms, spmm_b),
+                      ("k_gcn_forward (pp_gcn_forward_f32)", "k_gcn_forward", *fwd_clock.summary()),
+                      ("k_gcn_backward (pp_gcn_backward_f32)", "k_gcn_backward", *bwd_clock.summary()),
+                      ("k_expand (pp_temporal_fill)", "k_expand", n_fill, fill_ms, fill_b)]
+        best = max(candidates, key=lambda c: c[3])          # the kernel with the most time in the timed region
+        dominant = (best[0], best[2], best[3], best[4])
+        traffic = pmc_traffic(best[1], args)
         achieved = dominant[3] / (dominant[2] * 1e-3) / 1e9 if dominant[2] > 0 else 0.0
+
+        def side(c):
+            n_, ms_, b_ = c[2], c[3], c[4]
+            gbs = b_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
+            return {"kernel": c[0], "launches": n_, "avg_launch_ms": ms_ / max(n_, 1), "achieved": gbs, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(c[1], args),
+                    "algorithmic_bytes_per_launch": b_ / max(n_, 1)}
         line = {
             "metric": "lifted k-edges/s (k=2 De Bruijn lift + aggregation + 1 DBGNN train step per pass, 10M temporal edges)",
             "value": e2_total * args.steps / elapsed,
@@ -323,6 +354,7 @@ def main() -> int:
                          "avg_launch_ms": dominant[2] / max(dominant[1], 1), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dominant[3] / max(dominant[1], 1)},
+            "dbgnn_kernel_rooflines": [side(c) for c in candidates[:3] if c[2] > 0],
             "lift_fill_roofline": {"kernel": "k_expand (pp_temporal_fill)", "launches": n_fill,
                                    "avg_launch_ms": fill_ms / max(n_fill, 1),
                                    "achieved": (fill_b / (fill_ms * 1e-3) / 1e9) if fill_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
