@@ -243,6 +243,16 @@ int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val
                         const float* self_coef, const float* X, int K, const float* W, int fuse_act, float* d_in, float* colsum_in,
                         float* dW, void* ws, size_t ws_bytes, pp_stream_t stream);
 
+/* All-pairs shortest time-respecting paths (temporal_shortest_paths, src/pathpyG/algorithms/temporal.py:57-107: scipy Dijkstra with
+ * unit weights on the event DAG augmented by a virtual source and sink per node) as a frontier BFS per source node on the event graph:
+ *   edge_index [2,m] time-sorted events;  succ_ptr [m+1] / succ [E2]: CSR of lift_order_temporal's result (row i -> events j);
+ *   by_src_ptr [n+1] / by_src [m]: event ids grouped by their source node;
+ *   dist [n,n] int32: number of events on a shortest path, -1 = unreachable, 0 on the diagonal;
+ *   pred [n,n] int64: source node of the latest event that completes a shortest path into the column node (-1 none, s on the diagonal). */
+size_t pp_temporal_bfs_ws_bytes(int64_t m, int64_t n);
+int pp_temporal_bfs(const int64_t* edge_index, int64_t m, int64_t n, const int64_t* succ_ptr, const int64_t* succ, const int64_t* by_src_ptr,
+                    const int64_t* by_src, int32_t* dist, int64_t* pred, void* ws, size_t ws_bytes, pp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,13 @@ def temporal_lift(edge_index, time, num_nodes: int, delta, n_own=None, id_offset
     return _back(edge_index, _hip.temporal_lift(ei, t, num_nodes, delta, n_own, id_offset))
 
 
+def temporal_bfs(edge_index, time, num_nodes: int, delta):
+    dev = compute_device(edge_index, time)
+    ei, t = _stage(dev, edge_index, time)
+    event_graph = _hip.temporal_lift(ei, t, num_nodes, delta)
+    return _hip.temporal_bfs(ei, num_nodes, event_graph)
+
+
 def linegraph_lift(edge_index, num_nodes: int):
     dev = compute_device(edge_index)
     (ei,) = _stage(dev, edge_index)

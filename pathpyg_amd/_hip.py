@@ -341,6 +341,26 @@ def ptr_from_sorted(sorted_index: torch.Tensor, num_rows: int) -> torch.Tensor:
     return ptr
 
 
+def temporal_bfs(edge_index: torch.Tensor, num_nodes: int, event_graph: torch.Tensor):
+    """All-pairs shortest time-respecting paths over a lifted event graph (``event_graph`` = ``temporal_lift`` output of the same
+    time-sorted ``edge_index``): ``(dist int32 [n,n] with -1 = unreachable, pred int64 [n,n])``."""
+    ei = _edge_index(edge_index)
+    dev = require_device(ei, event_graph)
+    m, n = ei.size(1), int(num_nodes)
+    succ_ptr = ptr_from_sorted(event_graph[0], m)
+    succ = event_graph[1].contiguous()
+    by_src = argsort(ei[0], (0, max(n - 1, 0)))
+    by_src_ptr = ptr_from_sorted(ei[0][by_src], n)
+    L = lib()
+    with torch.cuda.device(dev):
+        dist = torch.empty((n, n), dtype=torch.int32, device=dev)
+        pred = torch.empty((n, n), dtype=torch.int64, device=dev)
+        ws = _workspace(L.pp_temporal_bfs_ws_bytes(m, n), dev)
+        check(L.pp_temporal_bfs(_p(ei), m, n, _p(succ_ptr), _p(succ), _p(by_src_ptr), _p(by_src), _p(dist), _p(pred), _p(ws), ws.numel(),
+                                _stream()), "pp_temporal_bfs")
+    return dist, pred
+
+
 # ------------------------------------------------------------------ DBGNN message passing
 class CsrPlan:
     """CSR pair of one propagation: ``fwd`` rows are the destinations, ``bwd`` rows the sources (transposed)."""

@@ -311,3 +311,41 @@ def test_sharded_second_order_layer_rccl_world1(pp):
         assert torch.equal(part["own_event_ids"].cpu(), want["inverse_idx"])
     finally:
         dist.destroy_process_group()
+
+
+def test_reference_temporal_shortest_paths(pp):
+    """tests/algorithms/test_temporal.py:20-93 (long_temporal_graph, delta=10): distance and predecessor matrices."""
+    from test_oracle_golden import LONG_DIST, LONG_PRED, LONG_TEDGES
+    g = pp.TemporalGraph.from_edge_list(LONG_TEDGES, device=DEV)
+    dist, pred = pp.algorithms.temporal.temporal_shortest_paths(g, delta=10)
+    assert dist.shape == (g.n, g.n) and pred.shape == (g.n, g.n)
+    assert np.allclose(dist, LONG_DIST, equal_nan=True)
+    assert np.allclose(pred, LONG_PRED)
+
+
+def test_temporal_shortest_paths_vs_oracle(pp):
+    """Random streams: distances equal the reference's scipy Dijkstra, predecessors equal the oracle's latest-event rule."""
+    from oracle import temporal_paths as tp
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        n = int(rng.integers(2, 60))
+        m = int(rng.integers(1, 1500))
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        t = torch.from_numpy(np.sort(rng.integers(0, 400, m)))
+        delta = int(rng.integers(1, 60))
+        g = pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=t.to(DEV), num_nodes=n))
+        dist, pred = pp.algorithms.temporal.temporal_shortest_paths(g, delta)
+        d_ref, _ = tp.temporal_shortest_paths_reference(ei, t, n, delta)
+        d_bfs, p_bfs = tp.temporal_shortest_paths_bfs(ei, t, n, delta)
+        assert np.array_equal(np.nan_to_num(dist, posinf=-1), np.nan_to_num(d_ref, posinf=-1)), trial
+        assert np.array_equal(np.nan_to_num(dist, posinf=-1), np.nan_to_num(d_bfs, posinf=-1)), trial
+        assert np.array_equal(pred, p_bfs), trial
+
+
+def test_reference_temporal_closeness(pp):
+    """tests/algorithms/test_centrality.py:59-70 (long_temporal_graph, delta=5): exact dictionary."""
+    from test_oracle_golden import LONG_TEDGES
+    g = pp.TemporalGraph.from_edge_list(LONG_TEDGES, device=DEV)
+    c = pp.algorithms.temporal_closeness_centrality(g, delta=5)
+    assert c == {"a": 12.0, "b": 16.0, "c": 16.0, "d": 14.666666666666666, "e": 14.666666666666666, "f": 24.0,
+                 "g": 14.666666666666666, "h": 28.0, "i": 24.0}

@@ -188,3 +188,55 @@ def test_sorted_lift_equals_loop_on_random_streams():
         a = ol.temporal_lift_sorted(ei, t, delta, n)
         if a.size(1):
             assert torch.equal(a, ol.temporal_lift_per_timestamp(ei, t, delta))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# f2: temporal shortest paths (reference known answer: tests/algorithms/test_temporal.py:20-93, fixture conftest.py:58-83)
+LONG_TEDGES = [("a", "b", 1), ("b", "c", 5), ("c", "d", 9), ("c", "e", 9), ("c", "f", 11), ("f", "a", 13), ("a", "g", 18), ("b", "f", 21),
+               ("a", "g", 26), ("c", "f", 27), ("h", "f", 27), ("g", "h", 28), ("a", "c", 30), ("a", "b", 31), ("c", "h", 32), ("f", "h", 33),
+               ("b", "i", 42), ("i", "b", 42), ("c", "i", 47), ("h", "i", 50)]
+INF = float("inf")
+LONG_DIST = np.array([[0, 1, 1, 3, 3, 3, 1, 2, INF], [3, 0, 1, 2, 2, 1, 4, 5, 1], [2, INF, 0, 1, 1, 1, 3, 1, 1],
+                      [INF, INF, INF, 0, INF, INF, INF, INF, INF], [INF, INF, INF, INF, 0, INF, INF, INF, INF],
+                      [1, INF, INF, INF, INF, 0, 2, 1, INF], [INF, INF, INF, INF, INF, INF, 0, 1, INF],
+                      [INF, INF, INF, INF, INF, 1, INF, 0, 1], [INF, 1, INF, INF, INF, INF, INF, INF, 0]])
+LONG_PRED = np.array([[0, 0, 0, 2, 2, 2, 0, 2, -1], [5, 1, 1, 2, 2, 1, 0, 6, 1], [5, -1, 2, 2, 2, 2, 0, 2, 2], [-1, -1, -1, 3, -1, -1, -1, -1, -1],
+                      [-1, -1, -1, -1, 4, -1, -1, -1, -1], [5, -1, -1, -1, -1, 5, 0, 5, -1], [-1, -1, -1, -1, -1, -1, 6, 6, -1],
+                      [-1, -1, -1, -1, -1, 7, -1, 7, 7], [-1, 8, -1, -1, -1, -1, -1, -1, 8]])
+
+
+def long_temporal_arrays():
+    names = sorted({x for e in LONG_TEDGES for x in e[:2]})
+    ix = {k: i for i, k in enumerate(names)}
+    ei = torch.tensor([[ix[a] for a, _, _ in LONG_TEDGES], [ix[b] for _, b, _ in LONG_TEDGES]])
+    return ei, torch.tensor([t for _, _, t in LONG_TEDGES]), len(names)
+
+
+def test_temporal_shortest_paths_reference_known_answer():
+    from oracle import temporal_paths as tp
+    ei, t, n = long_temporal_arrays()
+    for fn in (tp.temporal_shortest_paths_reference, tp.temporal_shortest_paths_bfs):
+        dist, pred = fn(ei, t, n, 10)
+        assert dist.shape == (n, n) and pred.shape == (n, n)
+        assert np.allclose(dist, LONG_DIST, equal_nan=True), fn.__name__
+        assert np.array_equal(pred, LONG_PRED), fn.__name__
+
+
+def test_temporal_shortest_paths_bfs_distances_equal_scipy_and_trees_are_valid():
+    from oracle import temporal_paths as tp
+    rng = np.random.default_rng(3)
+    for _ in range(25):
+        n, m = int(rng.integers(3, 14)), int(rng.integers(5, 80))
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        t = torch.from_numpy(np.sort(rng.integers(0, 50, m)))
+        delta = int(rng.integers(1, 20))
+        d_ref, p_ref = tp.temporal_shortest_paths_reference(ei, t, n, delta)
+        d_bfs, p_bfs = tp.temporal_shortest_paths_bfs(ei, t, n, delta)
+        assert np.array_equal(np.nan_to_num(d_ref, posinf=-1), np.nan_to_num(d_bfs, posinf=-1))
+        assert np.array_equal(p_ref < 0, p_bfs < 0)                      # same reachability
+        # both predecessor matrices name a node with an event into v: a valid last hop
+        has_event = np.zeros((n, n), dtype=bool)
+        has_event[ei[0].numpy(), ei[1].numpy()] = True
+        for p in (p_ref, p_bfs):
+            s_idx, v_idx = np.nonzero((p >= 0) & ~np.eye(n, dtype=bool))
+            assert has_event[p[s_idx, v_idx], v_idx].all()
