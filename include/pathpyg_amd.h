@@ -253,6 +253,16 @@ size_t pp_temporal_bfs_ws_bytes(int64_t m, int64_t n);
 int pp_temporal_bfs(const int64_t* edge_index, int64_t m, int64_t n, const int64_t* succ_ptr, const int64_t* succ, const int64_t* by_src_ptr,
                     const int64_t* by_src, int32_t* dist, int64_t* pred, void* ws, size_t ws_bytes, pp_stream_t stream);
 
+/* Temporal betweenness centrality (temporal_betweenness_centrality, src/pathpyG/algorithms/centrality.py:164-297: Brandes on the event
+ * DAG) in level-synchronous form, one workgroup per source node.  Inputs as pp_temporal_bfs plus the events grouped by their head
+ * node (by_dst_ptr [n+1] / by_dst [m]).  partial [pp_temporal_betweenness_parts(m,n), n] float64: one row per workgroup; the
+ * centrality of node v is the sum of column v over the rows (summed by the caller in row order: bit-reproducible). */
+int64_t pp_temporal_betweenness_parts(int64_t m, int64_t n);
+size_t pp_temporal_betweenness_ws_bytes(int64_t m, int64_t n);
+int pp_temporal_betweenness(const int64_t* edge_index, int64_t m, int64_t n, const int64_t* succ_ptr, const int64_t* succ,
+                            const int64_t* by_src_ptr, const int64_t* by_src, const int64_t* by_dst_ptr, const int64_t* by_dst,
+                            double* partial, void* ws, size_t ws_bytes, pp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

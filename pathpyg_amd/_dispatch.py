@@ -53,6 +53,13 @@ def temporal_bfs(edge_index, time, num_nodes: int, delta):
     return _hip.temporal_bfs(ei, num_nodes, event_graph)
 
 
+def temporal_betweenness(edge_index, time, num_nodes: int, delta):
+    dev = compute_device(edge_index, time)
+    ei, t = _stage(dev, edge_index, time)
+    event_graph = _hip.temporal_lift(ei, t, num_nodes, delta)
+    return _hip.temporal_betweenness(ei, num_nodes, event_graph)
+
+
 def linegraph_lift(edge_index, num_nodes: int):
     dev = compute_device(edge_index)
     (ei,) = _stage(dev, edge_index)

@@ -361,6 +361,27 @@ def temporal_bfs(edge_index: torch.Tensor, num_nodes: int, event_graph: torch.Te
     return dist, pred
 
 
+def temporal_betweenness(edge_index: torch.Tensor, num_nodes: int, event_graph: torch.Tensor) -> torch.Tensor:
+    """Temporal betweenness per node index (float64 [n]) over a lifted event graph of the time-sorted ``edge_index``."""
+    ei = _edge_index(edge_index)
+    dev = require_device(ei, event_graph)
+    m, n = ei.size(1), int(num_nodes)
+    succ_ptr = ptr_from_sorted(event_graph[0], m)
+    succ = event_graph[1].contiguous()
+    by_src = argsort(ei[0], (0, max(n - 1, 0)))
+    by_src_ptr = ptr_from_sorted(ei[0][by_src], n)
+    by_dst = argsort(ei[1], (0, max(n - 1, 0)))
+    by_dst_ptr = ptr_from_sorted(ei[1][by_dst], n)
+    L = lib()
+    with torch.cuda.device(dev):
+        parts = int(L.pp_temporal_betweenness_parts(m, n))
+        partial = torch.zeros((parts, n), dtype=torch.float64, device=dev)
+        ws = _workspace(L.pp_temporal_betweenness_ws_bytes(m, n), dev)
+        check(L.pp_temporal_betweenness(_p(ei), m, n, _p(succ_ptr), _p(succ), _p(by_src_ptr), _p(by_src), _p(by_dst_ptr), _p(by_dst),
+                                        _p(partial), _p(ws), ws.numel(), _stream()), "pp_temporal_betweenness")
+        return partial.sum(dim=0)
+
+
 # ------------------------------------------------------------------ DBGNN message passing
 class CsrPlan:
     """CSR pair of one propagation: ``fwd`` rows are the destinations, ``bwd`` rows the sources (transposed)."""

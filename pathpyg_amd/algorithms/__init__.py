@@ -5,4 +5,9 @@ from .lift_order import (  # noqa: F401
     lift_order_edge_index,
     lift_order_edge_index_weighted,
 )
-from .temporal import lift_order_temporal, temporal_closeness_centrality, temporal_shortest_paths  # noqa: F401
+from .temporal import (  # noqa: F401
+    lift_order_temporal,
+    temporal_betweenness_centrality,
+    temporal_closeness_centrality,
+    temporal_shortest_paths,
+)

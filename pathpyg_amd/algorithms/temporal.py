@@ -56,3 +56,20 @@ def temporal_closeness_centrality(graph, delta: int) -> dict:
         i = graph.mapping.to_idx(x)
         centralities[x] = float(sum((n - 1) / dist[others != i, i]))
     return centralities
+
+
+def temporal_betweenness_centrality(graph, delta: int = 1):
+    """Temporal betweenness centrality based on shortest time-respecting paths with maximum waiting time ``delta`` (reference
+    src/pathpyG/algorithms/centrality.py:164-297: Brandes' algorithm on the event DAG, pure-Python dict/deque loops per source).
+
+    Here every source node runs the level-synchronous form of the same recurrences on the GPU (``pp_temporal_betweenness``):
+    identical path counts, dependencies accumulated in float64 — equal to the reference up to summation order (its known answer
+    is reproduced exactly).  Returns a ``defaultdict`` node id -> centrality with an entry for every node."""
+    from collections import defaultdict
+
+    data = graph.data
+    bw = _dispatch.temporal_betweenness(data.edge_index, data.time, int(data.num_nodes), delta).cpu().tolist()
+    out = defaultdict(lambda: 0.0)
+    for idx, value in enumerate(bw):
+        out[graph.mapping.to_id(idx)] = float(value)
+    return out

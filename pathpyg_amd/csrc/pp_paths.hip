@@ -71,6 +71,144 @@ __global__ __launch_bounds__(kBlock) void k_temporal_bfs(const int64_t* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Temporal betweenness centrality (reference temporal_betweenness_centrality, src/pathpyG/algorithms/centrality.py:164-297:
+// Brandes' algorithm on the event DAG with a virtual source per first-order node, pure-Python dict/deque loops).
+// Level-synchronous form, one workgroup per source node:
+//   forward : BFS levels over the events; sigma[e] = number of shortest event paths from the source (integer-valued doubles:
+//             the atomic adds are exact in any order); dist_fo / sigma_fo per first-order node from the TIGHT events into it;
+//   backward: levels in reverse; every event pulls x * dep[w] from its successors on the next level (x = sigma[v] / sigma[w]) in
+//             CSR order, adds its own target term, and is credited dep[w] * x towards its head node;
+//   per node: credits summed over the node's in-events in event order (no floating-point atomics anywhere);
+//   source  : + sum of dep over its first-level events - (number of reached nodes) + 1, as centrality.py:274-278,295 nets out.
+struct BetweennessWs {
+    int32_t* level;
+    int32_t* order;
+    int32_t* level_start;
+    double* sigma;
+    double* dep;
+    double* credit;
+    int32_t* dist_fo;
+    double* sigma_fo;
+};
+
+__host__ __device__ static inline size_t betweenness_block_bytes(int64_t m, int64_t n) {
+    const size_t me = (size_t)(m > 0 ? m : 1), ne = (size_t)(n > 0 ? n : 1);
+    return align_up(me * 4) + align_up(me * 4) + align_up((me + 2) * 4) + 3 * align_up(me * 8) + align_up(ne * 4) + align_up(ne * 8);
+}
+
+__device__ static inline BetweennessWs carve_betweenness(char* base, int64_t m, int64_t n) {
+    const size_t me = (size_t)(m > 0 ? m : 1), ne = (size_t)(n > 0 ? n : 1);
+    BetweennessWs w;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    w.level = (int32_t*)base; base += up(me * 4);
+    w.order = (int32_t*)base; base += up(me * 4);
+    w.level_start = (int32_t*)base; base += up((me + 2) * 4);
+    w.sigma = (double*)base; base += up(me * 8);
+    w.dep = (double*)base; base += up(me * 8);
+    w.credit = (double*)base; base += up(me * 8);
+    w.dist_fo = (int32_t*)base; base += up(ne * 4);
+    w.sigma_fo = (double*)base;
+    return w;
+}
+
+__global__ __launch_bounds__(kBlock) void k_temporal_betweenness(const int64_t* __restrict__ edge_index, int64_t m, int64_t n,
+                                                                const int64_t* __restrict__ succ_ptr, const int64_t* __restrict__ succ,
+                                                                const int64_t* __restrict__ by_src_ptr, const int64_t* __restrict__ by_src,
+                                                                const int64_t* __restrict__ by_dst_ptr, const int64_t* __restrict__ by_dst,
+                                                                double* __restrict__ bw_blocks, char* __restrict__ ws, size_t block_bytes) {
+    __shared__ int s_tail;
+    __shared__ int s_reached;
+    const int64_t* dst = edge_index + m;
+    const BetweennessWs w = carve_betweenness(ws + (size_t)blockIdx.x * block_bytes, m, n);
+    double* bw = bw_blocks + (int64_t)blockIdx.x * n;
+    for (int64_t v = threadIdx.x; v < n; v += kBlock) bw[v] = 0.0;
+    for (int64_t s = blockIdx.x; s < n; s += gridDim.x) {
+        const int64_t first = by_src_ptr[s];
+        const int n_first = (int)(by_src_ptr[s + 1] - first);
+        if (n_first == 0) continue;                                   // centrality.py:210: only nodes with out-going events are sources
+        for (int64_t e = threadIdx.x; e < m; e += kBlock) { w.level[e] = -1; w.sigma[e] = 0.0; w.credit[e] = 0.0; }
+        for (int64_t v = threadIdx.x; v < n; v += kBlock) { w.dist_fo[v] = -1; w.sigma_fo[v] = 0.0; }
+        if (threadIdx.x == 0) { s_tail = n_first; s_reached = 0; }
+        __syncthreads();
+        if (threadIdx.x == 0) { w.dist_fo[s] = 0; w.sigma_fo[s] = 1.0; w.level_start[1] = 0; }
+        for (int k = threadIdx.x; k < n_first; k += kBlock) {
+            const int32_t e = (int32_t)by_src[first + k];
+            w.order[k] = e;
+            w.level[e] = 1;
+            w.sigma[e] = 1.0;
+        }
+        __syncthreads();
+        int begin = 0, depth = 1;
+        while (true) {
+            const int end = s_tail;
+            if (begin == end) break;
+            if (threadIdx.x == 0) w.level_start[depth + 1] = end;
+            for (int k = begin + threadIdx.x; k < end; k += kBlock) {                       // nodes first reached at this depth
+                const int64_t v = dst[w.order[k]];
+                if (w.dist_fo[v] < 0) w.dist_fo[v] = depth;
+            }
+            __syncthreads();
+            for (int k = begin + threadIdx.x; k < end; k += kBlock) {                       // tight events; claim the next level
+                const int32_t e = w.order[k];
+                const int64_t v = dst[e];
+                if (w.dist_fo[v] == depth) atomicAdd(&w.sigma_fo[v], w.sigma[e]);
+                for (int64_t p = succ_ptr[e]; p < succ_ptr[e + 1]; ++p) {
+                    const int32_t f = (int32_t)succ[p];
+                    if (atomicCAS(&w.level[f], -1, depth + 1) == -1) w.order[atomicAdd(&s_tail, 1)] = f;
+                }
+            }
+            __syncthreads();
+            for (int k = begin + threadIdx.x; k < end; k += kBlock) {                       // path counts of the next level
+                const int32_t e = w.order[k];
+                const double se = w.sigma[e];
+                for (int64_t p = succ_ptr[e]; p < succ_ptr[e + 1]; ++p) {
+                    const int32_t f = (int32_t)succ[p];
+                    if (w.level[f] == depth + 1) atomicAdd(&w.sigma[f], se);
+                }
+            }
+            __syncthreads();
+            begin = end;
+            ++depth;
+        }
+        for (int d = depth - 1; d >= 1; --d) {                                             // dependencies, deepest level first
+            for (int k = w.level_start[d] + threadIdx.x; k < w.level_start[d + 1]; k += kBlock) {
+                const int32_t v = w.order[k];
+                const double sv = w.sigma[v];
+                double acc = 0.0, cr = 0.0;
+                for (int64_t p = succ_ptr[v]; p < succ_ptr[v + 1]; ++p) {
+                    const int32_t f = (int32_t)succ[p];
+                    if (w.level[f] == d + 1) {
+                        const double x = sv / w.sigma[f];
+                        acc += x * w.dep[f];
+                        cr += w.dep[f] * x;
+                    }
+                }
+                const int64_t head = dst[v];
+                if (w.dist_fo[head] == d) acc += sv / w.sigma_fo[head];
+                w.dep[v] = acc;
+                w.credit[v] = cr;
+            }
+            __syncthreads();
+        }
+        int reached = 0;
+        for (int64_t v = threadIdx.x; v < n; v += kBlock) {                                 // credits per node, in event order
+            double t = 0.0;
+            for (int64_t p = by_dst_ptr[v]; p < by_dst_ptr[v + 1]; ++p) t += w.credit[by_dst[p]];
+            bw[v] += t;
+            reached += w.dist_fo[v] >= 0;
+        }
+        atomicAdd(&s_reached, reached);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int k = 0; k < n_first; ++k) t += w.dep[by_src[first + k]];
+            bw[s] += t - (double)s_reached + 1.0;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace pp
 
 extern "C" {
@@ -93,6 +231,31 @@ int pp_temporal_bfs(const int64_t* edge_index, int64_t m, int64_t n, const int64
     if (n == 0) return PP_OK;
     pp::k_temporal_bfs<<<(unsigned)bfs_blocks(m, n), pp::kBlock, 0, (hipStream_t)stream>>>(edge_index, m, n, succ_ptr, succ, by_src_ptr, by_src, dist,
                                                                                            pred, (int32_t*)ws);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+static int64_t betweenness_blocks(int64_t m, int64_t n) {
+    const int64_t budget = (int64_t)1 << 30;
+    int64_t blocks = budget / (int64_t)pp::betweenness_block_bytes(m, n);
+    if (blocks > n) blocks = n;
+    if (blocks > 1024) blocks = 1024;
+    return blocks < 1 ? 1 : blocks;
+}
+
+int64_t pp_temporal_betweenness_parts(int64_t m, int64_t n) { return betweenness_blocks(m, n); }
+
+size_t pp_temporal_betweenness_ws_bytes(int64_t m, int64_t n) { return (size_t)betweenness_blocks(m, n) * pp::betweenness_block_bytes(m, n); }
+
+int pp_temporal_betweenness(const int64_t* edge_index, int64_t m, int64_t n, const int64_t* succ_ptr, const int64_t* succ,
+                            const int64_t* by_src_ptr, const int64_t* by_src, const int64_t* by_dst_ptr, const int64_t* by_dst,
+                            double* partial, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "pp_temporal_betweenness: negative size");
+    PP_REQUIRE(m < (int64_t)0x7fffffff && n < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_temporal_betweenness: size >= 2^31");
+    PP_REQUIRE(ws_bytes >= pp_temporal_betweenness_ws_bytes(m, n), PP_ERR_WORKSPACE, "pp_temporal_betweenness: workspace too small");
+    if (n == 0) return PP_OK;
+    pp::k_temporal_betweenness<<<(unsigned)betweenness_blocks(m, n), pp::kBlock, 0, (hipStream_t)stream>>>(
+        edge_index, m, n, succ_ptr, succ, by_src_ptr, by_src, by_dst_ptr, by_dst, partial, (char*)ws, pp::betweenness_block_bytes(m, n));
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

@@ -349,3 +349,28 @@ def test_reference_temporal_closeness(pp):
     c = pp.algorithms.temporal_closeness_centrality(g, delta=5)
     assert c == {"a": 12.0, "b": 16.0, "c": 16.0, "d": 14.666666666666666, "e": 14.666666666666666, "f": 24.0,
                  "g": 14.666666666666666, "h": 28.0, "i": 24.0}
+
+
+def test_reference_temporal_betweenness(pp):
+    """tests/algorithms/test_centrality.py:45-56 (long_temporal_graph, delta=5): exact values."""
+    from test_oracle_golden import LONG_BETWEENNESS, LONG_TEDGES
+    g = pp.TemporalGraph.from_edge_list(LONG_TEDGES, device=DEV)
+    bw = pp.algorithms.temporal_betweenness_centrality(g, delta=5)
+    for k, v in LONG_BETWEENNESS.items():
+        assert bw[k] == v, k
+
+
+def test_temporal_betweenness_vs_oracle(pp):
+    """Random streams against the statement-by-statement restatement of the reference (float64, summation order differs)."""
+    from oracle import temporal_paths as tp
+    from pathpyg_amd import _dispatch
+    rng = np.random.default_rng(13)
+    for trial in range(10):
+        n = int(rng.integers(2, 40))
+        m = int(rng.integers(1, 700))
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        t = torch.from_numpy(np.sort(rng.integers(0, 300, m)))
+        delta = int(rng.integers(1, 40))
+        got = _dispatch.temporal_betweenness(ei.to(DEV), t.to(DEV), n, delta).cpu().numpy()
+        want = tp.temporal_betweenness_reference(ei, t, n, delta)
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-9, err_msg=str(trial))

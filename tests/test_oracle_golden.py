@@ -240,3 +240,28 @@ def test_temporal_shortest_paths_bfs_distances_equal_scipy_and_trees_are_valid()
         for p in (p_ref, p_bfs):
             s_idx, v_idx = np.nonzero((p >= 0) & ~np.eye(n, dtype=bool))
             assert has_event[p[s_idx, v_idx], v_idx].all()
+
+
+LONG_BETWEENNESS = {"a": 2.0, "b": 2.0, "c": 4.5, "d": 0, "e": 0, "f": 2.0, "g": 0.5, "h": 0, "i": 0}     # test_centrality.py:45-56, delta=5
+
+
+def test_temporal_betweenness_reference_known_answer():
+    from oracle import temporal_paths as tp
+    ei, t, n = long_temporal_arrays()
+    names = sorted({x for e in LONG_TEDGES for x in e[:2]})
+    for fn in (tp.temporal_betweenness_reference, tp.temporal_betweenness_levels):
+        bw = fn(ei, t, n, 5)
+        assert {k: float(bw[i]) for i, k in enumerate(names)} == {k: float(v) for k, v in LONG_BETWEENNESS.items()}, fn.__name__
+
+
+def test_temporal_betweenness_level_form_equals_reference_form():
+    from oracle import temporal_paths as tp
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        n, m = int(rng.integers(3, 14)), int(rng.integers(5, 90))
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        t = torch.from_numpy(np.sort(rng.integers(0, 50, m)))
+        delta = int(rng.integers(1, 20))
+        a = tp.temporal_betweenness_reference(ei, t, n, delta)
+        b = tp.temporal_betweenness_levels(ei, t, n, delta)
+        np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-12)
