@@ -34,10 +34,12 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_is_a_plain_c_abi_without_torch():
     # the .so must not link torch / c10: it is a C ABI over HIP only
+    # (static DT_NEEDED entries: `ldd` would also print where the loader FINDS libamdhip64, which may be torch's bundled copy)
     import subprocess
-    out = subprocess.run(["ldd", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
-    assert "libamdhip64" in out
-    assert "torch" not in out and "c10" not in out
+    out = subprocess.run(["readelf", "-d", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
+    needed = [line.split("[")[1].split("]")[0] for line in out.splitlines() if "(NEEDED)" in line]
+    assert any(lib.startswith("libamdhip64") for lib in needed), needed
+    assert not any("torch" in lib or "c10" in lib for lib in needed), needed
 
 
 @pytest.mark.skipif(not NO_GPU, reason="checks the no-GPU failure mode")
