@@ -8,7 +8,7 @@
 //
 // One pass = 8 key bits, three launches, no inter-workgroup spinning:
 //   k_digit_hist    each 256-thread workgroup counts the digits of its 4096-key tile in LDS
-//   exclusive_scan  over the digit-major table [256][tiles]  -> global base of every (digit, tile)
+//   k_scan_digit_rows  one workgroup per digit scans its row of the digit-major table [256][tiles] (+ 256 row totals)
 //   k_scatter       re-reads the tile; every wave ranks its 1024 consecutive keys with 8 __ballot
 //                   rounds per key (wave-wide multi-split, no atomics), the tile is reordered by digit
 //                   THROUGH LDS, and written out so that consecutive lanes store consecutive addresses
@@ -48,11 +48,32 @@ __global__ __launch_bounds__(kBlock) void k_digit_hist(const KeyT* __restrict__ 
     table[(int64_t)threadIdx.x * ntiles + blockIdx.x] = bins[threadIdx.x];
 }
 
+// One workgroup per digit: exclusive scan of that digit's row of the table (its counts over the tiles, a few thousand entries) in
+// place, row total to totals[digit].  k_scatter adds the exclusive scan of the 256 totals itself, so a pass needs ONE scan launch
+// instead of the three of a generic scan over the flattened [256][tiles] table.
+__global__ __launch_bounds__(kBlock) void k_scan_digit_rows(uint32_t* __restrict__ table, int64_t ntiles, uint32_t* __restrict__ totals) {
+    __shared__ unsigned s_scratch[kWavesPerBlock + 1];
+    uint32_t* row = table + (int64_t)blockIdx.x * ntiles;
+    const int64_t per_thread = (ntiles + kBlock - 1) / kBlock;
+    const int64_t begin = (int64_t)threadIdx.x * per_thread;
+    const int64_t end = begin + per_thread < ntiles ? begin + per_thread : ntiles;
+    unsigned sum = 0;
+    for (int64_t i = begin; i < end; ++i) sum += row[i];
+    unsigned total;
+    unsigned run = block_exclusive_sum<unsigned>(sum, s_scratch, &total);
+    for (int64_t i = begin; i < end; ++i) {
+        const unsigned c = row[i];
+        row[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = total;
+}
+
 template <typename KeyT, bool kIota>
 __global__ __launch_bounds__(kBlock) void k_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                    KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n,
                                                    int shift, unsigned mask, const uint32_t* __restrict__ table,
-                                                   int64_t ntiles) {
+                                                   const uint32_t* __restrict__ totals, int64_t ntiles) {
     __shared__ KeyT s_keys[kSortTile];
     __shared__ uint32_t s_vals[kSortTile];
     __shared__ unsigned s_wcnt[kWavesPerBlock][kRadix];   // per-wave digit counts -> per-wave digit bases
@@ -111,8 +132,9 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KeyT* __restrict__ key
         }
         unsigned total;
         unsigned start = block_exclusive_sum<unsigned>(run, s_scratch, &total);
+        unsigned digit_base = block_exclusive_sum<unsigned>(totals[d], s_scratch, &total);   // keys with a smaller digit, all tiles
         s_dstart[d] = start;
-        s_gofs[d] = table[(int64_t)d * ntiles + blockIdx.x] - start;   // modular arithmetic on purpose
+        s_gofs[d] = digit_base + table[(int64_t)d * ntiles + blockIdx.x] - start;   // modular arithmetic on purpose
     }
     __syncthreads();
 
@@ -168,8 +190,7 @@ int sort_pairs(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uin
     KeyT* tmp_keys = a.take<KeyT>(n);
     uint32_t* tmp_vals = a.take<uint32_t>(n);
     uint32_t* table = a.take<uint32_t>((int64_t)kRadix * ntiles);
-    void* scan_ws = a.take<char>((int64_t)scan_ws_bytes((int64_t)kRadix * ntiles));
-    const size_t scan_bytes = scan_ws_bytes((int64_t)kRadix * ntiles);
+    uint32_t* totals = a.take<uint32_t>(kRadix);       // sort_ws_bytes reserves scan_ws_bytes(...) + 1024 >= 1 KiB behind the table
 
     const int passes = (end_bit - begin_bit + kRadixBits - 1) / kRadixBits;
     if (passes == 0) {   // nothing to order on: identity permutation
@@ -198,12 +219,12 @@ int sort_pairs(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uin
 
         k_digit_hist<KeyT><<<(unsigned)ntiles, kBlock, 0, st>>>(src_k, n, shift, mask, table, ntiles);
         PP_LAUNCH_CHECK();
-        int rc = exclusive_scan<uint32_t, uint32_t>(table, (int64_t)kRadix * ntiles, table, false, nullptr, scan_ws, scan_bytes, st);
-        if (rc != PP_OK) return rc;
+        k_scan_digit_rows<<<kRadix, kBlock, 0, st>>>(table, ntiles, totals);
+        PP_LAUNCH_CHECK();
         if (p == 0 && src_v == nullptr) {
-            k_scatter<KeyT, true><<<(unsigned)ntiles, kBlock, 0, st>>>(src_k, nullptr, dst_k, dst_v, n, shift, mask, table, ntiles);
+            k_scatter<KeyT, true><<<(unsigned)ntiles, kBlock, 0, st>>>(src_k, nullptr, dst_k, dst_v, n, shift, mask, table, totals, ntiles);
         } else {
-            k_scatter<KeyT, false><<<(unsigned)ntiles, kBlock, 0, st>>>(src_k, src_v, dst_k, dst_v, n, shift, mask, table, ntiles);
+            k_scatter<KeyT, false><<<(unsigned)ntiles, kBlock, 0, st>>>(src_k, src_v, dst_k, dst_v, n, shift, mask, table, totals, ntiles);
         }
         PP_LAUNCH_CHECK();
         src_k = dst_k;
