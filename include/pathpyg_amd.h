@@ -127,11 +127,16 @@ int pp_unique_rows_fill(const int64_t* rows, int64_t n_rows, int k, int64_t n_un
 
 /* coalesce(remap[edge_index], edge_attr, num_nodes, reduce), src/pathpyG/algorithms/lift_order.py:135-144.
  * remap may be NULL (edges already hold node ids).  _count -> {A, status}; _fill writes out_index [2,A]
- * sorted by (row, col) and the reduced weights (weight may be NULL). */
+ * sorted by (row, col) and the reduced weights (weight may be NULL).
+ * col_base [num_nodes] / col_bits (NULL / 0 = off; pass the same pair to _count and _fill): the caller knows that every column of row r
+ * lies in [col_base[r], col_base[r] + 2^col_bits) - true for De Bruijn layers, where the successors of a node form one
+ * contiguous id block - and the sort key shrinks from 2*bits(num_nodes) to bits(num_nodes) + col_bits bits (fewer radix passes);
+ * an edge outside its block sets the bad-index status bit. */
 size_t pp_coalesce_ws_bytes(int64_t n_edges);
-int pp_coalesce_count(const int64_t* edge_index, int64_t n_edges, const int64_t* remap, int64_t remap_len, int64_t num_nodes, void* ws,
-                      size_t ws_bytes, pp_stream_t stream);
-int pp_coalesce_fill(const void* weight, int dtype, int reduce, int64_t n_edges, int64_t n_out, int64_t num_nodes, int64_t* out_index,
+int pp_coalesce_count(const int64_t* edge_index, int64_t n_edges, const int64_t* remap, int64_t remap_len, int64_t num_nodes,
+                      const int64_t* col_base, int col_bits, void* ws, size_t ws_bytes, pp_stream_t stream);
+int pp_coalesce_fill(const void* weight, int dtype, int reduce, int64_t n_edges, int64_t n_out, int64_t num_nodes, const int64_t* col_base,
+                     int col_bits, int64_t* out_index,
                      void* out_weight, void* ws, size_t ws_bytes, pp_stream_t stream);
 /* inverse[n_edges] = position of every input edge's merged edge (call between _count and the end of the workspace's life).
  * For a first-order event list this equals the inverse_idx of torch.unique over the (src,dst) rows, lift_order.py:133, i.e.

@@ -90,10 +90,24 @@ def unique_rows(rows, value_range=None):
     return _back(rows, *_hip.unique_rows(r, value_range))
 
 
-def coalesce(edge_index, weight, num_nodes: int, reduce: str = "sum", remap=None, want_inverse: bool = False):
+def coalesce(edge_index, weight, num_nodes: int, reduce: str = "sum", remap=None, want_inverse: bool = False, col_block=None):
     dev = compute_device(edge_index, weight, remap)
     ei, w, rm = _stage(dev, edge_index, weight, remap)
-    return _back(edge_index, *_hip.coalesce(ei, w, num_nodes, reduce, rm, want_inverse))
+    if col_block is not None:
+        col_block = (_stage(dev, col_block[0])[0], col_block[1])
+    return _back(edge_index, *_hip.coalesce(ei, w, num_nodes, reduce, rm, want_inverse, col_block))
+
+
+def successor_blocks(block_key, num_blocks: int, node_block):
+    """Column blocks for :func:`coalesce` on a De Bruijn layer: the nodes are numbered lexicographically, ``block_key[u]`` (sorted,
+    non-decreasing) is the id of node u's prefix and ``node_block[u]`` the prefix id that every SUCCESSOR of u shares.  Returns
+    ``(col_base [U], col_bits)``: successors of u have ids in ``[col_base[u], col_base[u] + 2**col_bits)``."""
+    dev = compute_device(block_key, node_block)
+    key, blk = _stage(dev, block_key, node_block)
+    ptr = _hip.ptr_from_sorted(key, num_blocks)
+    widest = int((ptr[1:] - ptr[:-1]).max().item()) if num_blocks > 0 else 1
+    bits = max(int(widest - 1).bit_length(), 1)
+    return ptr[blk], bits
 
 
 def minmax(a):

@@ -254,9 +254,11 @@ def unique_rows(rows: torch.Tensor, value_range: tuple[int, int] | None = None):
 
 
 def coalesce(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: int, reduce: str = "sum",
-             remap: torch.Tensor | None = None, want_inverse: bool = False):
+             remap: torch.Tensor | None = None, want_inverse: bool = False, col_block: tuple | None = None):
     """PyG ``coalesce`` of ``remap[edge_index]`` (or ``edge_index``): (row, col)-sorted distinct edges + reduced weights.
-    ``want_inverse`` additionally returns, per input edge, the index of the merged edge it went into."""
+    ``want_inverse`` additionally returns, per input edge, the index of the merged edge it went into.
+    ``col_block = (col_base [num_nodes] int64, col_bits)``: every column of row r lies in ``[col_base[r], col_base[r] + 2**col_bits)``
+    (De Bruijn layers): shorter sort keys, same result."""
     if reduce not in _REDUCE:
         raise ValueError(f"unknown reduce {reduce}")
     ei = _edge_index(edge_index)
@@ -270,11 +272,14 @@ def coalesce(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: i
         weight = weight.contiguous()
     if remap is not None:
         remap = remap.to(torch.int64).contiguous()
+    col_base, col_bits = (None, 0) if col_block is None else (col_block[0].to(torch.int64).contiguous(), int(col_block[1]))
+    if col_base is not None and col_base.numel() != num_nodes:
+        raise ValueError("col_base must hold one entry per node")
     L = lib()
     with torch.cuda.device(dev):
         ws = _workspace(L.pp_coalesce_ws_bytes(e), dev)
-        check(L.pp_coalesce_count(_p(ei), e, _p(remap), 0 if remap is None else remap.numel(), num_nodes, _p(ws), ws.numel(), _stream()),
-              "pp_coalesce_count")
+        check(L.pp_coalesce_count(_p(ei), e, _p(remap), 0 if remap is None else remap.numel(), num_nodes, _p(col_base), col_bits,
+                                  _p(ws), ws.numel(), _stream()), "pp_coalesce_count")
         n_out, status = _result(ws)
         # the reference fails in EdgeIndex.validate() with a ValueError when an index exceeds the number of distinct nodes
         # (lift_order.py:133-147: layer-1 quirk, node ids are used as given while num_nodes counts the distinct ones)
@@ -282,7 +287,7 @@ def coalesce(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: i
         out_index = torch.empty((2, n_out), dtype=torch.int64, device=dev)
         out_weight = None if weight is None else torch.empty(n_out, dtype=weight.dtype, device=dev)
         check(L.pp_coalesce_fill(_p(weight), 2 if weight is None else _DTYPE_CODE[weight.dtype], _REDUCE[reduce], e, n_out, num_nodes,
-                                 _p(out_index), _p(out_weight), _p(ws), ws.numel(), _stream()), "pp_coalesce_fill")
+                                 _p(col_base), col_bits, _p(out_index), _p(out_weight), _p(ws), ws.numel(), _stream()), "pp_coalesce_fill")
         if want_inverse:
             inverse = torch.empty(e, dtype=torch.int64, device=dev)
             check(L.pp_coalesce_inverse(e, _p(inverse), _p(ws), ws.numel(), _stream()), "pp_coalesce_inverse")

@@ -62,16 +62,17 @@ def aggregate_edge_index(
 
 
 def _aggregate_with_known_nodes(edge_index, order, node_sequence, unique_nodes, inverse_idx, edge_weight, aggr="sum",
-                                want_inverse: bool = False):
+                                want_inverse: bool = False, col_block=None):
     """Second half of :func:`aggregate_edge_index` for callers that already know the distinct node rows and the
-    row -> node map (``MultiOrderModel`` derives them from the previous layer instead of re-sorting the rows)."""
+    row -> node map (``MultiOrderModel`` derives them from the previous layer instead of re-sorting the rows).
+    ``col_block``: see :func:`pathpyg_amd._dispatch.successor_blocks` (shorter coalesce keys, same result)."""
     num_nodes = unique_nodes.size(0)
     if order == 1:
         # first order: the entries of the node sequence already are the node ids (reference :135-136)
         remap = _dispatch.plain(node_sequence).reshape(-1)
     else:
         remap = inverse_idx
-    merged = _dispatch.coalesce(edge_index, edge_weight, num_nodes, aggr, remap=remap, want_inverse=want_inverse)
+    merged = _dispatch.coalesce(edge_index, edge_weight, num_nodes, aggr, remap=remap, want_inverse=want_inverse, col_block=col_block)
     merged_index, merged_weight = merged[0], merged[1]
     data = Data(
         edge_index=merged_index,

@@ -326,7 +326,10 @@ class _LiftChain:
         from ..algorithms.lift_order import _aggregate_with_known_nodes
         unique_nodes = self.graph.data.edge_index.t().contiguous()
         inv = self.pair_id
-        graph = _aggregate_with_known_nodes(ho_index, 2, None, unique_nodes, inv, ho_weight, "sum") if save else None
+        # a successor of node (a, b) is a node (b, c): all of them sit in the contiguous id block of the pairs that start with b
+        merged = _dispatch.plain(self.graph.data.edge_index)
+        blocks = _dispatch.successor_blocks(merged[0], self.unique_nodes.size(0), merged[1]) if save and merged.size(1) else None
+        graph = _aggregate_with_known_nodes(ho_index, 2, None, unique_nodes, inv, ho_weight, "sum", col_block=blocks) if save else None
         return _LiftChain(ho_index, inv, _dispatch.plain(event_index)[1], unique_nodes, ho_weight, graph)
 
     def lift(self, aggr: str, save: bool):
@@ -342,7 +345,14 @@ class _LiftChain:
         hi = max(self.unique_nodes.size(0), int(_dispatch.minmax(self.unique_nodes)[1]) + 1 if self.unique_nodes.numel() else 1)
         unique_pairs, inv = _dispatch.unique_rows(pairs, (0, max(hi - 1, 0)))
         unique_nodes = _dispatch.gather_concat(self.unique_nodes, unique_pairs[:, 0], unique_pairs[:, 1])
-        graph = _aggregate_with_known_nodes(ho_index, k + 1, None, unique_nodes, inv, weight, "sum") if save else None
+        blocks = None
+        if save and inv.numel():
+            # the new nodes are numbered by (order-k prefix node, last node); every successor of a new node P starts with P's
+            # order-k SUFFIX node, i.e. the order-k node of the second instance of any edge a -> b that realises P
+            suffix = torch.empty(unique_pairs.size(0), dtype=torch.int64, device=inv.device)
+            suffix[inv] = self.inv[_dispatch.plain(self.index)[1]]
+            blocks = _dispatch.successor_blocks(unique_pairs[:, 0].contiguous(), self.unique_nodes.size(0), suffix)
+        graph = _aggregate_with_known_nodes(ho_index, k + 1, None, unique_nodes, inv, weight, "sum", col_block=blocks) if save else None
         return _LiftChain(ho_index, inv, last, unique_nodes, weight, graph)
 
 

@@ -117,7 +117,8 @@ static int lexsort_rows(const int64_t* rows, int64_t m, int k, int64_t bias, int
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_edge_keys(const int64_t* __restrict__ edge_index, int64_t n_edges,
                                                      const int64_t* __restrict__ remap, int64_t remap_len, int64_t num_nodes, int shift,
-                                                     KeyT* __restrict__ keys, int64_t* __restrict__ status) {
+                                                     const int64_t* __restrict__ col_base, KeyT* __restrict__ keys,
+                                                     int64_t* __restrict__ status) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= n_edges) return;
     int64_t r = edge_index[e], c = edge_index[n_edges + e];
@@ -128,6 +129,10 @@ __global__ __launch_bounds__(kBlock) void k_edge_keys(const int64_t* __restrict_
         c = bad ? 0 : remap[c];
     }
     bad = bad || r < 0 || r >= num_nodes || c < 0 || c >= num_nodes;
+    if (!bad && col_base) {                  // block-compressed column: every column of row r lies in [col_base[r], col_base[r] + 2^shift)
+        c -= col_base[r];
+        bad = c < 0 || c >= ((int64_t)1 << shift);
+    }
     if (bad) { atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex); r = 0; c = 0; }
     keys[e] = (KeyT)(((uint64_t)r << shift) | (uint64_t)c);
 }
@@ -167,14 +172,15 @@ __device__ __forceinline__ T mean_of(T sum, uint32_t n) {
 template <typename KeyT, typename T>
 __global__ __launch_bounds__(kBlock) void k_coalesce_fill(const KeyT* __restrict__ sorted_keys, const uint32_t* __restrict__ perm,
                                                          const uint32_t* __restrict__ seg_start, int64_t n_out, int shift,
-                                                         const T* __restrict__ weight, int reduce, int64_t* __restrict__ out_index,
-                                                         T* __restrict__ out_weight) {
+                                                         const int64_t* __restrict__ col_base, const T* __restrict__ weight, int reduce,
+                                                         int64_t* __restrict__ out_index, T* __restrict__ out_weight) {
     const int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (a >= n_out) return;
     const uint32_t p0 = seg_start[a], p1 = seg_start[a + 1];
     const uint64_t key = (uint64_t)sorted_keys[p0];
-    out_index[a] = (int64_t)(key >> shift);
-    out_index[n_out + a] = (int64_t)(key & ((1ull << shift) - 1ull));
+    const int64_t row = (int64_t)(key >> shift);
+    out_index[a] = row;
+    out_index[n_out + a] = (int64_t)(key & ((1ull << shift) - 1ull)) + (col_base ? col_base[row] : 0);
     if (weight) {
         T acc = weight[perm[p0]];
         for (uint32_t p = p0 + 1; p < p1; ++p) acc = reduce_step<T>(acc, weight[perm[p]], reduce);
@@ -223,12 +229,12 @@ static inline int coalesce_shift(int64_t num_nodes) { return bits_for((uint64_t)
 
 template <typename KeyT>
 static int coalesce_count_impl(const int64_t* edge_index, int64_t e, const int64_t* remap, int64_t remap_len, int64_t num_nodes,
-                               CoalesceWs& w, hipStream_t st) {
-    const int shift = coalesce_shift(num_nodes);
+                               const int64_t* col_base, int shift, CoalesceWs& w, hipStream_t st) {
     const unsigned grid = (unsigned)ceil_div(e, kBlock);
-    k_edge_keys<KeyT><<<grid, kBlock, 0, st>>>(edge_index, e, remap, remap_len, num_nodes, shift, (KeyT*)w.keys_a, w.result + 1);
+    k_edge_keys<KeyT><<<grid, kBlock, 0, st>>>(edge_index, e, remap, remap_len, num_nodes, shift, col_base, (KeyT*)w.keys_a, w.result + 1);
     PP_LAUNCH_CHECK();
-    int rc = sort_pairs<KeyT>((const KeyT*)w.keys_a, nullptr, (KeyT*)w.keys_b, w.perm, e, 0, 2 * shift, w.scratch, w.scratch_bytes, st);
+    int rc = sort_pairs<KeyT>((const KeyT*)w.keys_a, nullptr, (KeyT*)w.keys_b, w.perm, e, 0, coalesce_shift(num_nodes) + shift, w.scratch,
+                              w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
     k_key_heads<KeyT><<<grid, kBlock, 0, st>>>((const KeyT*)w.keys_b, e, w.head);
     PP_LAUNCH_CHECK();
@@ -240,15 +246,15 @@ static int coalesce_count_impl(const int64_t* edge_index, int64_t e, const int64
 }
 
 template <typename KeyT>
-static int coalesce_fill_impl(const void* weight, int dtype, int reduce, int64_t n_out, int shift, int64_t* out_index, void* out_weight,
-                              CoalesceWs& w, hipStream_t st) {
+static int coalesce_fill_impl(const void* weight, int dtype, int reduce, int64_t n_out, int shift, const int64_t* col_base,
+                              int64_t* out_index, void* out_weight, CoalesceWs& w, hipStream_t st) {
     const unsigned grid = (unsigned)ceil_div(n_out, kBlock);
     const KeyT* keys = (const KeyT*)w.keys_b;
     switch (weight ? dtype : PP_F32) {
-        case PP_I32: k_coalesce_fill<KeyT, int32_t><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, (const int32_t*)weight, reduce, out_index, (int32_t*)out_weight); break;
-        case PP_I64: k_coalesce_fill<KeyT, int64_t><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, (const int64_t*)weight, reduce, out_index, (int64_t*)out_weight); break;
-        case PP_F32: k_coalesce_fill<KeyT, float><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, (const float*)weight, reduce, out_index, (float*)out_weight); break;
-        case PP_F64: k_coalesce_fill<KeyT, double><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, (const double*)weight, reduce, out_index, (double*)out_weight); break;
+        case PP_I32: k_coalesce_fill<KeyT, int32_t><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, col_base, (const int32_t*)weight, reduce, out_index, (int32_t*)out_weight); break;
+        case PP_I64: k_coalesce_fill<KeyT, int64_t><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, col_base, (const int64_t*)weight, reduce, out_index, (int64_t*)out_weight); break;
+        case PP_F32: k_coalesce_fill<KeyT, float><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, col_base, (const float*)weight, reduce, out_index, (float*)out_weight); break;
+        case PP_F64: k_coalesce_fill<KeyT, double><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, col_base, (const double*)weight, reduce, out_index, (double*)out_weight); break;
         default: PP_REQUIRE(false, PP_ERR_ARG, "pp_coalesce_fill: unsupported weight dtype %d", dtype);
     }
     PP_LAUNCH_CHECK();
@@ -352,8 +358,14 @@ int pp_unique_rows_fill(const int64_t* rows, int64_t n_rows, int k, int64_t n_un
 // ---------------------------------------------------------------- coalesce (PyG coalesce on remapped edges)
 size_t pp_coalesce_ws_bytes(int64_t n_edges) { return carve_coalesce(nullptr, n_edges).total_bytes; }
 
-int pp_coalesce_count(const int64_t* edge_index, int64_t n_edges, const int64_t* remap, int64_t remap_len, int64_t num_nodes, void* ws,
-                      size_t ws_bytes, pp_stream_t stream) {
+// key layout: (row << shift) | col with shift = bits(num_nodes - 1), or with a caller-supplied column block per row
+// (col_base[row] <= col < col_base[row] + 2^col_bits): (row << col_bits) | (col - col_base[row]) - fewer radix passes
+static inline int coalesce_col_shift(int64_t num_nodes, const int64_t* col_base, int col_bits) {
+    return col_base ? col_bits : coalesce_shift(num_nodes);
+}
+
+int pp_coalesce_count(const int64_t* edge_index, int64_t n_edges, const int64_t* remap, int64_t remap_len, int64_t num_nodes,
+                      const int64_t* col_base, int col_bits, void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_edges >= 0 && num_nodes >= 0, PP_ERR_ARG, "pp_coalesce_count: negative size");
     PP_REQUIRE(n_edges < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_coalesce_count: more than 2^31 edges");
@@ -362,20 +374,24 @@ int pp_coalesce_count(const int64_t* edge_index, int64_t n_edges, const int64_t*
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_coalesce_count: workspace too small");
     PP_HIP(hipMemsetAsync(w.result, 0, 2 * sizeof(int64_t), st));
     if (n_edges == 0) return PP_OK;
-    return 2 * coalesce_shift(num_nodes) <= 32 ? coalesce_count_impl<uint32_t>(edge_index, n_edges, remap, remap_len, num_nodes, w, st)
-                                               : coalesce_count_impl<uint64_t>(edge_index, n_edges, remap, remap_len, num_nodes, w, st);
+    PP_REQUIRE(col_base == nullptr || (col_bits >= 0 && col_bits <= 32), PP_ERR_ARG, "pp_coalesce_count: col_bits must be in [0, 32]");
+    const int shift = coalesce_col_shift(num_nodes, col_base, col_bits);
+    return coalesce_shift(num_nodes) + shift <= 32
+               ? coalesce_count_impl<uint32_t>(edge_index, n_edges, remap, remap_len, num_nodes, col_base, shift, w, st)
+               : coalesce_count_impl<uint64_t>(edge_index, n_edges, remap, remap_len, num_nodes, col_base, shift, w, st);
 }
 
-int pp_coalesce_fill(const void* weight, int dtype, int reduce, int64_t n_edges, int64_t n_out, int64_t num_nodes, int64_t* out_index,
-                     void* out_weight, void* ws, size_t ws_bytes, pp_stream_t stream) {
+int pp_coalesce_fill(const void* weight, int dtype, int reduce, int64_t n_edges, int64_t n_out, int64_t num_nodes, const int64_t* col_base,
+                     int col_bits, int64_t* out_index, void* out_weight, void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(reduce >= PP_REDUCE_SUM && reduce <= PP_REDUCE_MAX, PP_ERR_ARG, "pp_coalesce_fill: unknown reduce %d", reduce);
     CoalesceWs w = carve_coalesce(ws, n_edges);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_coalesce_fill: workspace too small");
     if (n_out <= 0) return PP_OK;
-    const int shift = coalesce_shift(num_nodes);
-    return 2 * shift <= 32 ? coalesce_fill_impl<uint32_t>(weight, dtype, reduce, n_out, shift, out_index, out_weight, w, st)
-                           : coalesce_fill_impl<uint64_t>(weight, dtype, reduce, n_out, shift, out_index, out_weight, w, st);
+    const int shift = coalesce_col_shift(num_nodes, col_base, col_bits);
+    return coalesce_shift(num_nodes) + shift <= 32
+               ? coalesce_fill_impl<uint32_t>(weight, dtype, reduce, n_out, shift, col_base, out_index, out_weight, w, st)
+               : coalesce_fill_impl<uint64_t>(weight, dtype, reduce, n_out, shift, col_base, out_index, out_weight, w, st);
 }
 
 // inverse[n_edges]: for every input edge the position of its merged edge in the coalesced output (after *_count).
