@@ -115,8 +115,10 @@ class _GcnLayer(torch.autograd.Function):
 
     @staticmethod
     def supported(plan, x, weight) -> bool:
+        # 32-bit row offsets in both directions: the input [n, P] forward and the output gradient [n, Q] backward stay below 4 GiB
         return (plan.self_coef is not None and plan.n_dst == plan.n_src == x.size(0) and x.dtype == torch.float32
-                and _hip.dense_supported(weight.size(1), weight.size(0)) and x.numel() * 4 < (1 << 32))
+                and _hip.dense_supported(weight.size(1), weight.size(0))
+                and x.size(0) * max(weight.size(0), weight.size(1)) * 4 < (1 << 32))
 
     @staticmethod
     def forward(ctx, plan, x, weight, bias, fuse_act: bool, act_bias):
