@@ -51,6 +51,40 @@ def test_config1_2m_events_matches_oracle_exactly(pp):
             assert torch.equal(d[key].cpu(), want[k][key]), (k, key)
 
 
+def test_config1_2m_events_dbgnn_train_step_matches_float64_oracle(pp):
+    """configs[1] end to end at full size: k=2 layers -> DBGNN (64-dim features, hidden 64) forward / cross-entropy / backward on
+    the GPU against the oracle evaluated in float64 (its own rounding is then negligible): logits and loss within 1e-5 relative,
+    every parameter gradient within 1e-4 of its largest entry (fp32 sums over 2*10^6 rows in a different order)."""
+    from oracle import dbgnn as od
+    from oracle import model as om
+    n, m, delta, f, classes = 100_000, 2_000_000, 100_000, 64, 8
+    ei, t = _stream(1, m, n, 1_000_000)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=n))
+    model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=2)
+    gen = torch.Generator().manual_seed(3)
+    n_ho = model.layers[2].n
+    x, x_h = torch.randn(n, f, generator=gen), torch.randn(n_ho, f, generator=gen)
+    y = torch.randint(0, classes, (n,), generator=gen)
+    data = model.to_dbgnn_data(max_order=2, x=x.to(DEV), x_h=x_h.to(DEV))
+    params = od.init_params(classes, (f, f), [f, f, f], seed=3)
+    net = pp.nn.DBGNN(num_classes=classes, num_features=(f, f), hidden_dims=[f, f, f]).to(DEV)
+    net.load_state_dict(params)
+    out = net(data)
+    loss = pp.nn.dbgnn.cross_entropy(out, y.to(DEV))
+    loss.backward()
+    layers = {k: {key: model.layers[k].data[key].cpu() for key in ("edge_index", "edge_weight", "node_sequence")} | {"num_nodes": model.layers[k].n}
+              for k in (1, 2)}
+    ref = om.dbgnn_inputs(layers, 2, "last", x=x.double(), x_h=x_h.double())
+    ref["edge_weights"], ref["edge_weights_higher_order"] = ref["edge_weights"].double(), ref["edge_weights_higher_order"].double()
+    want_out, want_loss, want_grads = od.loss_and_grads({k: v.double() for k, v in params.items()}, ref, y)
+    scale = float(want_out.abs().max())
+    torch.testing.assert_close(out.detach().cpu().double(), want_out, rtol=1e-5, atol=1e-5 * scale)
+    torch.testing.assert_close(loss.detach().cpu().double(), want_loss, rtol=1e-5, atol=1e-6)
+    for name, p_ in net.named_parameters():
+        gs = float(want_grads[name].abs().max()) + 1e-30
+        torch.testing.assert_close(p_.grad.cpu().double(), want_grads[name], rtol=1e-4, atol=1e-4 * gs), name
+
+
 def _is_lexsorted(index):
     a, b = index[0], index[1]
     ok = (a[1:] > a[:-1]) | ((a[1:] == a[:-1]) & (b[1:] > b[:-1]))
