@@ -81,7 +81,7 @@ class KernelClock:
         return len(self.records), ms, sum(b for _, _, b in self.records)
 
 
-def spmm_bytes(ptr, idx, val, n_rows, x, f, self_coef, s, bias, act, y, stream):
+def spmm_bytes(ptr, idx, val, n_rows, x, f, self_coef, s, bias, act, heavy_slot, heavy_sum, y, stream):
     """Algorithmic HBM bytes of one pp_spmm_f32 launch: CSR (ptr + idx + val) read once,
     every source feature row read once, every output row written once (+ the self-term rows when separate)."""
     nnz, n_src = spmm_bytes.shape_of[ptr]
@@ -94,7 +94,7 @@ def spmm_bytes(ptr, idx, val, n_rows, x, f, self_coef, s, bias, act, y, stream):
 spmm_bytes.shape_of = {}
 
 
-def gcn_forward_bytes(ptr, idx, val, n_rows, n_src, x, p, self_coef, w, q, bias, act, agg_out, y, stream):
+def gcn_forward_bytes(ptr, idx, val, n_rows, n_src, x, p, self_coef, w, q, bias, act, heavy_slot, heavy_sum, agg_out, y, stream):
     """Algorithmic HBM bytes of one fused GCN layer forward (pp_gcn_forward_f32): CSR once, every input row once (P wide), every
     output row once (Q wide), the optional aggregated-input copy, the self coefficients and W."""
     nnz, _ = spmm_bytes.shape_of[ptr]
@@ -102,7 +102,8 @@ def gcn_forward_bytes(ptr, idx, val, n_rows, n_src, x, p, self_coef, w, q, bias,
             + (4 * p * n_rows if agg_out else 0) + 4 * p * q)
 
 
-def gcn_backward_bytes(ptr, idx, val, n_rows, d, m, self_coef, x, k, w, fuse_act, d_in, colsum, dw, ws, ws_bytes, stream):
+def gcn_backward_bytes(ptr, idx, val, n_rows, d, m, self_coef, x, k, w, fuse_act, heavy_slot, heavy_sum, d_in, colsum, dw, ws, ws_bytes,
+                       stream):
     """Algorithmic HBM bytes of one fused GCN layer backward (pp_gcn_backward_f32): CSR, dpre (M wide) and the layer input (K wide)
     read once, the input gradient (K wide) written once."""
     nnz, _ = spmm_bytes.shape_of[ptr]

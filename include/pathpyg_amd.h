@@ -185,7 +185,19 @@ const int64_t* pp_plan_result_ptr(void* ws);
  * val NULL = 1, self_coef NULL = no self term, S NULL = X, bias NULL = none, act 0 = identity / 1 = ELU.
  * GCNConv.propagate + bias + F.elu (dbgnn.py:133,139), the bipartite propagate + elu (:143-144) and all their transposes. */
 int pp_spmm_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* X, int F, const float* self_coef,
-                const float* S, const float* bias, int act, float* Y, pp_stream_t stream);
+                const float* S, const float* bias, int act, const int32_t* heavy_slot, const float* heavy_sum, float* Y, pp_stream_t stream);
+
+/* Hub rows (scale-free graphs: 10^5+ entries in one CSR row).  The row kernels (pp_spmm_f32, pp_gcn_forward_f32, pp_gcn_backward_f32)
+ * walk a row with ONE lane group; for rows the caller marks as heavy (heavy_slot [n_rows] int32: -1 = ordinary, else h) they read the
+ * neighbour sum from heavy_sum [n_heavy, F] instead, which pp_spmm_heavy_f32 computes with a whole workgroup per chunk of
+ * pp_heavy_chunk_entries() entries and a fixed-order combine (bit-reproducible).  heavy_slot NULL = no heavy rows.
+ * pp_max_row_length_i32: out_max[0] (device int64) = longest row of a CSR pointer array, to decide whether a plan needs this. */
+int pp_max_row_length_i32(const int32_t* ptr, int64_t n_rows, int64_t* out_max, pp_stream_t stream);
+int pp_heavy_chunk_entries(void);
+size_t pp_spmm_heavy_ws_bytes(int64_t n_chunks, int F);
+int pp_spmm_heavy_f32(const int32_t* idx, const float* val, const float* X, int F, int64_t n_chunks, const int32_t* chunk_begin,
+                      const int32_t* chunk_end, int64_t n_heavy, const int32_t* heavy_chunk_ptr, float* heavy_sum, void* ws, size_t ws_bytes,
+                      pp_stream_t stream);
 
 /* Transposed aggregation fused with the ELU backward of the layer that produced its input and with that layer's bias gradient:
  *   dX[r,:] = ( sum_{p in [ptr[r],ptr[r+1])} val[p] * D[idx[p],:] ) * ELU'(Z[r,:]),   colsum[F] (may be NULL) = column sums of dX
@@ -237,7 +249,8 @@ int pp_dense_backward_f32(const float* dH, const float* X, const float* W, int64
  * agg_out [n_rows,P] or NULL: also store the aggregated input A_hat X; the weight gradient of a layer whose input needs no
  * gradient is then dW = dpre^T agg_out (pp_weight_grad_f32) without any backward aggregation. */
 int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
-                       const float* self_coef, const float* W, int Q, const float* bias, int act, float* agg_out, float* Y, pp_stream_t stream);
+                       const float* self_coef, const float* W, int Q, const float* bias, int act, const int32_t* heavy_slot, const float* heavy_sum,
+                       float* agg_out, float* Y, pp_stream_t stream);
 
 /* Backward of that layer in one kernel (pp_spmm_f32 over the source-major CSR + pp_dense_backward_f32 without the round trip of the
  * aggregated gradient through HBM):  G = A^T D + diag(self_coef) D with D = dpre [n_rows,M];
@@ -245,8 +258,8 @@ int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val,
  *   colsum_in[K] (may be NULL) = column sums of d_in,  dW[M,K] = G^T X.   W is [M,K]; M, K in {16,32,64}; D below 4 GiB. */
 size_t pp_gcn_backward_ws_bytes(int64_t n_rows);
 int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
-                        const float* self_coef, const float* X, int K, const float* W, int fuse_act, float* d_in, float* colsum_in,
-                        float* dW, void* ws, size_t ws_bytes, pp_stream_t stream);
+                        const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
+                        const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, pp_stream_t stream);
 
 /* All-pairs shortest time-respecting paths (temporal_shortest_paths, src/pathpyG/algorithms/temporal.py:57-107: scipy Dijkstra with
  * unit weights on the event DAG augmented by a virtual source and sink per node) as a frontier BFS per source node on the event graph:

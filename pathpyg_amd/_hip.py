@@ -391,11 +391,81 @@ def temporal_betweenness(edge_index: torch.Tensor, num_nodes: int, event_graph: 
 class CsrPlan:
     """CSR pair of one propagation: ``fwd`` rows are the destinations, ``bwd`` rows the sources (transposed)."""
 
-    __slots__ = ("n_dst", "n_src", "fwd_ptr", "fwd_idx", "fwd_val", "bwd_ptr", "bwd_idx", "bwd_val", "self_coef")
+    __slots__ = ("n_dst", "n_src", "fwd_ptr", "fwd_idx", "fwd_val", "bwd_ptr", "bwd_idx", "bwd_val", "self_coef", "fwd_heavy", "bwd_heavy")
 
     def __init__(self, **kw):
         for k in self.__slots__:
             setattr(self, k, kw.get(k))
+
+
+HEAVY_ROW_ENTRIES = 512      # CSR rows longer than this (hubs of scale-free graphs) are summed by the chunked pre-pass
+
+
+class HeavyRows:
+    """Hub rows of one CSR direction: ``slot`` [n_rows] int32 (-1 = ordinary row) and the chunk table of ``pp_spmm_heavy_f32``."""
+
+    __slots__ = ("slot", "chunk_begin", "chunk_end", "chunk_ptr", "n_heavy", "n_chunks")
+
+    def __init__(self, ptr: torch.Tensor, n_rows: int, threshold: int = HEAVY_ROW_ENTRIES):
+        dev = ptr.device
+        length = ptr[1:] - ptr[:-1]
+        rows = torch.nonzero(length > threshold).flatten()
+        self.n_heavy = int(rows.numel())
+        chunk = int(lib().pp_heavy_chunk_entries())
+        per_row = (length[rows].to(torch.int64) + chunk - 1) // chunk
+        chunk_ptr = torch.zeros(self.n_heavy + 1, dtype=torch.int64, device=dev)
+        chunk_ptr[1:] = torch.cumsum(per_row, 0)
+        self.n_chunks = int(chunk_ptr[-1])
+        owner = torch.repeat_interleave(torch.arange(self.n_heavy, device=dev), per_row)
+        within = torch.arange(self.n_chunks, device=dev) - chunk_ptr[owner]
+        begin = ptr[rows].to(torch.int64)[owner] + within * chunk
+        end = torch.minimum(begin + chunk, ptr[rows + 1].to(torch.int64)[owner])
+        self.chunk_begin, self.chunk_end = begin.to(torch.int32), end.to(torch.int32)
+        self.chunk_ptr = chunk_ptr.to(torch.int32)
+        self.slot = torch.full((n_rows,), -1, dtype=torch.int32, device=dev)
+        self.slot[rows] = torch.arange(self.n_heavy, dtype=torch.int32, device=dev)
+
+    def aggregate(self, idx: torch.Tensor, val: torch.Tensor | None, x: torch.Tensor) -> torch.Tensor:
+        """``[n_heavy, F]`` neighbour sums of the hub rows over ``x`` (chunked, fixed summation order)."""
+        f = x.size(1)
+        L = lib()
+        with torch.cuda.device(x.device):
+            out = torch.empty((self.n_heavy, f), dtype=torch.float32, device=x.device)
+            ws = _workspace(L.pp_spmm_heavy_ws_bytes(self.n_chunks, f), x.device)
+            check(L.pp_spmm_heavy_f32(_p(idx), _p(val), _p(x), f, self.n_chunks, _p(self.chunk_begin), _p(self.chunk_end), self.n_heavy,
+                                      _p(self.chunk_ptr), _p(out), _p(ws), ws.numel(), _stream()), "pp_spmm_heavy_f32")
+        return out
+
+
+def _heavy_args(heavy: "HeavyRows | None", idx, val, x):
+    """(slot, sums) to hand to a row kernel; ``(None, None)`` for plans without hub rows or feature widths the pre-pass cannot take."""
+    if heavy is None or x.size(1) % 4 != 0 or x.size(1) > 256:
+        return None, None
+    return heavy.slot, heavy.aggregate(idx, val, x.contiguous())
+
+
+def _plan_row_lengths(plan: "CsrPlan") -> torch.Tensor:
+    """Device int64 [2]: longest forward / backward CSR row of a plan (two tiny launches, read with the plan status)."""
+    with torch.cuda.device(plan.fwd_ptr.device):
+        out = torch.empty(2, dtype=torch.int64, device=plan.fwd_ptr.device)
+        check(lib().pp_max_row_length_i32(_p(plan.fwd_ptr), plan.n_dst, _p(out), _stream()), "pp_max_row_length_i32")
+        check(lib().pp_max_row_length_i32(_p(plan.bwd_ptr), plan.n_src, out.data_ptr() + 8, _stream()), "pp_max_row_length_i32")
+    return out
+
+
+def _finish_plans(entries: list, what: str) -> None:
+    """ONE device-to-host copy for everything the host must know about freshly built plans: the bad-index status and the longest
+    rows (hub rows get their chunk tables here — the rare path, a few torch ops)."""
+    if not entries:
+        return
+    host = torch.cat([torch.cat((status, lengths)) for status, _, lengths in entries]).tolist()
+    if any(int(host[3 * k]) & 1 for k in range(len(entries))):
+        raise IndexError(f"{what}: node index out of range")
+    for k, (_, plan, _) in enumerate(entries):
+        if host[3 * k + 1] > HEAVY_ROW_ENTRIES:
+            plan.fwd_heavy = HeavyRows(plan.fwd_ptr, plan.n_dst)
+        if host[3 * k + 2] > HEAVY_ROW_ENTRIES:
+            plan.bwd_heavy = HeavyRows(plan.bwd_ptr, plan.n_src)
 
 
 def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nodes: int, row_sorted: bool | None = None,
@@ -424,18 +494,17 @@ def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nod
         ws = _workspace(L.pp_gcn_plan_ws_bytes(e, num_nodes), dev)
         check(L.pp_gcn_plan(_p(ei), _p(edge_weight), e, num_nodes, 1 if row_sorted else 0, _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val), _p(plan.bwd_ptr),
                             _p(plan.bwd_idx), _p(plan.bwd_val), _p(plan.self_coef), _p(ws), ws.numel(), _stream()), "pp_gcn_plan")
+        entry = (ws[8:16].view(torch.int64).clone(), plan, _plan_row_lengths(plan))
         if status_out is None:
-            _bad_index(_result(ws)[1], "GCNConv")
+            _finish_plans([entry], "GCNConv")
         else:
-            status_out.append(ws[8:16].view(torch.int64).clone())
+            status_out.append(entry)
     return plan
 
 
-def check_plan_status(statuses: list, what: str = "DBGNN") -> None:
-    """One device-to-host copy for the status words collected by several plan builders."""
-    if statuses:
-        if int(torch.cat(statuses).max().item()) & 1:
-            raise IndexError(f"{what}: node index out of range")
+def check_plan_status(entries: list, what: str = "DBGNN") -> None:
+    """One device-to-host copy for the status words (and longest rows) collected by several plan builders."""
+    _finish_plans(entries, what)
 
 
 def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_value: torch.Tensor | None = None,
@@ -463,15 +532,18 @@ def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_val
         check(L.pp_bipartite_plan(_p(bi), nb, n_ho, n_fo, 1 if src_sorted else 0, _p(pair_value), _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val),
                                   _p(plan.self_coef), _p(plan.bwd_ptr), _p(plan.bwd_idx), _p(plan.bwd_val), _p(ws), ws.numel(), _stream()),
               "pp_bipartite_plan")
+        entry = (ws[8:16].view(torch.int64).clone(), plan, _plan_row_lengths(plan))
         if status_out is None:
-            _bad_index(_result(ws)[1], "BipartiteGraphOperator")
+            _finish_plans([entry], "BipartiteGraphOperator")
         else:
-            status_out.append(ws[8:16].view(torch.int64).clone())
+            status_out.append(entry)
     return plan
 
 
-def spmm(ptr, idx, val, n_rows: int, x: torch.Tensor, self_coef=None, s=None, bias=None, act: bool = False) -> torch.Tensor:
-    """Y[r] = act(sum_p val[p] * x[idx[p]] + self_coef[r] * s[r] + bias) — fp32, rows of width F."""
+def spmm(ptr, idx, val, n_rows: int, x: torch.Tensor, self_coef=None, s=None, bias=None, act: bool = False,
+         heavy: HeavyRows | None = None) -> torch.Tensor:
+    """Y[r] = act(sum_p val[p] * x[idx[p]] + self_coef[r] * s[r] + bias) — fp32, rows of width F.  ``heavy``: the hub rows of this
+    CSR (``plan.fwd_heavy`` / ``plan.bwd_heavy``), summed by the chunked pre-pass."""
     dev = require_device(x, s, bias)
     x = x.contiguous()
     if x.dtype != torch.float32:
@@ -481,10 +553,11 @@ def spmm(ptr, idx, val, n_rows: int, x: torch.Tensor, self_coef=None, s=None, bi
         s = s.contiguous()
     if bias is not None:
         bias = bias.contiguous()
+    slot, sums = _heavy_args(heavy, idx, val, x)
     with torch.cuda.device(dev):
         y = torch.empty((n_rows, f), dtype=torch.float32, device=dev)
-        check(lib().pp_spmm_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(x), f, _p(self_coef), _p(s), _p(bias), 1 if act else 0, _p(y),
-                                _stream()), "pp_spmm_f32")
+        check(lib().pp_spmm_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(x), f, _p(self_coef), _p(s), _p(bias), 1 if act else 0,
+                                _p(slot), _p(sums), _p(y), _stream()), "pp_spmm_f32")
     return y
 
 
@@ -565,7 +638,8 @@ def spmm_act_backward(ptr, idx, val, n_rows: int, d: torch.Tensor, z: torch.Tens
 
 
 def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, n_rows: int, x: torch.Tensor,
-                self_coef: torch.Tensor | None, weight: torch.Tensor, bias: torch.Tensor | None, act: bool, want_agg: bool = False):
+                self_coef: torch.Tensor | None, weight: torch.Tensor, bias: torch.Tensor | None, act: bool, want_agg: bool = False,
+                heavy: HeavyRows | None = None):
     """``act((A x + diag(self_coef) x) @ weight.T + bias)`` in one kernel (aggregation fused with the MFMA product);
     ``want_agg``: returns ``(y, A x + diag(self_coef) x)``."""
     dev = require_device(ptr, idx, val, x, self_coef, weight, bias)
@@ -578,13 +652,14 @@ def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, 
     with torch.cuda.device(dev):
         y = torch.empty((n_rows, q), dtype=torch.float32, device=dev)
         agg = torch.empty((n_rows, p), dtype=torch.float32, device=dev) if want_agg else None
+        slot, sums = _heavy_args(heavy, idx, val, x)
         check(lib().pp_gcn_forward_f32(_p(ptr), _p(idx), _p(val), n_rows, x.size(0), _p(x), p, _p(self_coef), _p(weight), q, _p(bias),
-                                       1 if act else 0, _p(agg), _p(y), _stream()), "pp_gcn_forward_f32")
+                                       1 if act else 0, _p(slot), _p(sums), _p(agg), _p(y), _stream()), "pp_gcn_forward_f32")
     return (y, agg) if want_agg else y
 
 
 def gcn_backward(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, x: torch.Tensor, weight: torch.Tensor, fuse_act: bool,
-                 want_colsum: bool):
+                 want_colsum: bool, heavy: HeavyRows | None = None):
     """Backward of :func:`gcn_forward` in one kernel: ``(d_in, colsum_in or None, dW)`` from the gradient ``dpre`` w.r.t. the
     layer's pre-activation, over the SOURCE-major CSR (``ptr``/``idx``/``val`` = the plan's ``bwd_*`` arrays)."""
     dev = require_device(ptr, idx, val, dpre, self_coef, x, weight)
@@ -598,9 +673,10 @@ def gcn_backward(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, x: t
         d_in = torch.empty((n_rows, k), **f32)
         colsum = torch.empty(k, **f32) if want_colsum else None
         dw = torch.empty((m, k), **f32)
+        slot, sums = _heavy_args(heavy, idx, val, dpre)
         ws = _workspace(L.pp_gcn_backward_ws_bytes(n_rows), dev)
         check(L.pp_gcn_backward_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(dpre), m, _p(self_coef), _p(x), k, _p(weight),
-                                    1 if fuse_act else 0, _p(d_in), _p(colsum), _p(dw), _p(ws), ws.numel(), _stream()),
+                                    1 if fuse_act else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _p(dw), _p(ws), ws.numel(), _stream()),
               "pp_gcn_backward_f32")
     return d_in, colsum, dw
 

@@ -129,6 +129,13 @@ __device__ __forceinline__ T block_exclusive_sum(T v, T* scratch, T* total) {
     return wave_base + inc - v;
 }
 
+// Rows of a CSR with very many entries (hubs of a scale-free graph) are not walked by the lane group that owns the row: a pre-pass
+// (pp_spmm_heavy_f32) sums them chunk-wise with whole workgroups; the row kernels read the finished sum instead.
+struct HeavyRows {
+    const int32_t* slot;     // [n_rows]: -1 for ordinary rows, else the row of `sum`; nullptr = no heavy rows at all
+    const float* sum;        // [n_heavy, F]
+};
+
 // ELU(x) = x > 0 ? x : exp(x) - 1, branch-free and ~12 VALU instructions (libm's expm1f is ~40 and branches): on (-0.5, 0] the
 // degree-8 Taylor polynomial of expm1 (truncation < 6e-9 relative), below that v_exp_f32 - 1 (the result is <= -0.39, so the
 // 1-ulp error of the exponential stays < 2e-7 relative).

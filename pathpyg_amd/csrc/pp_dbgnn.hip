@@ -137,10 +137,11 @@ __global__ __launch_bounds__(kBlock) void k_ptr_from_sorted_u32(const uint32_t* 
 // consecutive rows TOGETHER so that their index loads, and then their row gathers, are in flight at the same time.
 // The kLanes lanes of a row fetch up to kLanes (index, value) pairs with ONE coalesced load each and hand them round by
 // shuffle: no row gather ever waits for an index load of its own row (measured: 2.12 -> 1.77 ms on the 10^7-row graph).
-template <int kLanes, int kRows>
+template <int kLanes, int kRows, bool kFull>       // kFull: F == kLanes * 4, every lane owns a live column block
 __global__ __launch_bounds__(kBlock) void k_spmm_v4(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
                                                    int64_t n_rows, const float* __restrict__ X, int F, const float* __restrict__ self_coef,
-                                                   const float* __restrict__ S, const float* __restrict__ bias, int act, float* __restrict__ Y) {
+                                                   const float* __restrict__ S, const float* __restrict__ bias, int act, HeavyRows heavy,
+                                                   float* __restrict__ Y) {
     constexpr int kGroups = kBlock / kLanes;
     const int64_t r0 = ((int64_t)blockIdx.x * kGroups + threadIdx.x / kLanes) * kRows;
     const int lane = threadIdx.x % kLanes;
@@ -152,16 +153,26 @@ __global__ __launch_bounds__(kBlock) void k_spmm_v4(const int32_t* __restrict__ 
         p0[q] = live ? ptr[r0 + q] : 0;
         p1[q] = live ? ptr[r0 + q + 1] : 0;
     }
-    for (int c0 = lane * 4; c0 < F; c0 += kLanes * 4) {
+    // kLanes * 4 >= F: one float4 column block per lane, the loop below runs exactly once.  Lanes beyond the feature width (F / 4
+    // not a power of two) still take part in the index chunk loads and shuffles - only their row loads and stores are switched off.
+    for (int c0 = lane * 4; c0 < kLanes * 4; c0 += kLanes * 4) {
+        const bool col_live = kFull || c0 < F;
         float4 acc[kRows];
         int my_j[kRows];
         float my_v[kRows];
 #pragma unroll
         for (int q = 0; q < kRows; ++q) {                  // first chunk of every row: issued back to back
+            acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (heavy.slot != nullptr && r0 + q < n_rows) {               // a hub row: its neighbour sum is already in heavy.sum
+                const int hs = heavy.slot[r0 + q];
+                if (hs >= 0) {
+                    p1[q] = p0[q];
+                    if (col_live) acc[q] = *(const float4*)(heavy.sum + (int64_t)hs * F + c0);
+                }
+            }
             const int mine = p0[q] + lane;
             my_j[q] = mine < p1[q] ? idx[mine] : 0;
             my_v[q] = mine < p1[q] ? (val ? val[mine] : 1.f) : 0.f;
-            acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         float4 self_row[kRows];
         float self_c[kRows];
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_v4(const int32_t* __restrict__ 
         for (int q = 0; q < kRows; ++q) {
             const bool live = self_coef != nullptr && r0 + q < n_rows;
             self_c[q] = live ? self_coef[r0 + q] : 0.f;
-            self_row[q] = live ? *(const float4*)(S + (r0 + q) * F + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            self_row[q] = (live && col_live) ? *(const float4*)(S + (r0 + q) * F + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int q = 0; q < kRows; ++q) {
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_v4(const int32_t* __restrict__ 
                         const int src_lane = (e + u) < cnt ? e + u : e;          // clamp: harmless re-read with weight 0
                         const int j = __shfl(my_j[q], src_lane, kLanes);
                         v[u] = (e + u) < cnt ? __shfl(my_v[q], src_lane, kLanes) : 0.f;
-                        x[u] = *(const float4*)(X + (int64_t)j * F + c0);
+                        x[u] = col_live ? *(const float4*)(X + (int64_t)j * F + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -197,6 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_v4(const int32_t* __restrict__ 
                 }
             }
         }
+        if (!col_live) continue;
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias) b = *(const float4*)(bias + c0);
 #pragma unroll
@@ -214,14 +226,16 @@ __global__ __launch_bounds__(kBlock) void k_spmm_v4(const int32_t* __restrict__ 
 template <int kLanes>   // scalar-column variant for feature widths that are not multiples of 4
 __global__ __launch_bounds__(kBlock) void k_spmm_s1(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
                                                    int64_t n_rows, const float* __restrict__ X, int F, const float* __restrict__ self_coef,
-                                                   const float* __restrict__ S, const float* __restrict__ bias, int act, float* __restrict__ Y) {
+                                                   const float* __restrict__ S, const float* __restrict__ bias, int act, HeavyRows heavy,
+                                                   float* __restrict__ Y) {
     constexpr int kRowsPerBlock = kBlock / kLanes;
     const int64_t r = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x / kLanes;
     const int lane = threadIdx.x % kLanes;
     if (r >= n_rows) return;
-    const int p0 = ptr[r], p1 = ptr[r + 1];
+    const int hs = heavy.slot != nullptr ? heavy.slot[r] : -1;
+    const int p0 = ptr[r], p1 = hs >= 0 ? p0 : ptr[r + 1];
     for (int c = lane; c < F; c += kLanes) {
-        float acc = 0.f;
+        float acc = hs >= 0 ? heavy.sum[(int64_t)hs * F + c] : 0.f;
         for (int p = p0; p < p1; ++p) acc += (val ? val[p] : 1.f) * X[(int64_t)idx[p] * F + c];
         if (self_coef) acc += self_coef[r] * S[r * F + c];
         if (bias) acc += bias[c];
@@ -353,12 +367,78 @@ static int group_by(const int64_t* index, int64_t e, int64_t n_groups, PlanWs& w
     return PP_OK;
 }
 
+// ------------------------------------------------------------------ hub rows: chunked, bit-reproducible neighbour sums
+// One workgroup per chunk of <= kHeavyChunk CSR entries of a heavy row: the kLanes-lane groups stride through the chunk, their
+// partial rows are folded through LDS in group order; k_heavy_combine adds a row's chunks in chunk order.
+constexpr int kHeavyChunk = 2048;
+
+template <int kLanes>
+__global__ __launch_bounds__(kBlock) void k_heavy_partial(const int32_t* __restrict__ idx, const float* __restrict__ val, const float* __restrict__ X,
+                                                         int F, const int32_t* __restrict__ chunk_begin, const int32_t* __restrict__ chunk_end,
+                                                         float* __restrict__ partial) {
+    constexpr int kGroups = kBlock / kLanes;
+    __shared__ __attribute__((aligned(16))) float s_part[kGroups][kLanes * 4];
+    const int g = threadIdx.x / kLanes, l = threadIdx.x % kLanes;
+    const int begin = chunk_begin[blockIdx.x], end = chunk_end[blockIdx.x];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (4 * l < F) {
+        for (int p = begin + g; p < end; p += 2 * kGroups) {            // two gathers in flight per lane group
+            const int q = p + kGroups;
+            const bool two = q < end;
+            const int j0 = idx[p], j1 = two ? idx[q] : j0;
+            const float v0 = val ? val[p] : 1.f, v1 = two ? (val ? val[q] : 1.f) : 0.f;
+            const float4 x0 = *(const float4*)(X + (int64_t)j0 * F + 4 * l);
+            const float4 x1 = *(const float4*)(X + (int64_t)j1 * F + 4 * l);
+            acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
+            acc.x += v1 * x1.x; acc.y += v1 * x1.y; acc.z += v1 * x1.z; acc.w += v1 * x1.w;
+        }
+    }
+    *(float4*)&s_part[g][4 * l] = acc;
+    __syncthreads();
+    for (int c = threadIdx.x; c < F; c += kBlock) {
+        float t = 0.f;
+        for (int q = 0; q < kGroups; ++q) t += s_part[q][c];
+        partial[(int64_t)blockIdx.x * F + c] = t;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_heavy_combine(const float* __restrict__ partial, const int32_t* __restrict__ heavy_chunk_ptr, int F,
+                                                         float* __restrict__ heavy_sum) {
+    const int c0 = heavy_chunk_ptr[blockIdx.x], c1 = heavy_chunk_ptr[blockIdx.x + 1];
+    for (int c = threadIdx.x; c < F; c += kBlock) {
+        float t = 0.f;
+        for (int k = c0; k < c1; ++k) t += partial[(int64_t)k * F + c];
+        heavy_sum[(int64_t)blockIdx.x * F + c] = t;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_max_row_length(const int32_t* __restrict__ ptr, int64_t n_rows, int64_t* __restrict__ out) {
+    __shared__ int s_max[kWavesPerBlock];
+    int best = 0;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * kBlock) {
+        const int len = ptr[r + 1] - ptr[r];
+        best = len > best ? len : best;
+    }
+    best = wave_max(best);
+    if (lane_id() == 0) s_max[wave_id()] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) best = s_max[w] > best ? s_max[w] : best;
+        atomicMax((unsigned long long*)out, (unsigned long long)best);
+    }
+}
+
 static int launch_spmm(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* X, int F, const float* self_coef,
-                       const float* S, const float* bias, int act, float* Y, hipStream_t st) {
+                       const float* S, const float* bias, int act, HeavyRows heavy, float* Y, hipStream_t st) {
     if (n_rows == 0 || F == 0) return PP_OK;
-#define PP_SPMM_V4(L) \
-    k_spmm_v4<L, 2><<<(unsigned)ceil_div(n_rows, (kBlock / L) * 2), kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, Y)
-#define PP_SPMM_S1(L) k_spmm_s1<L><<<(unsigned)ceil_div(n_rows, kBlock / L), kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, Y)
+#define PP_SPMM_V4(L)                                                                                                              \
+    do {                                                                                                                           \
+        const unsigned grid = (unsigned)ceil_div(n_rows, (kBlock / L) * 2);                                                        \
+        if (F == L * 4) k_spmm_v4<L, 2, true><<<grid, kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, heavy, Y);  \
+        else k_spmm_v4<L, 2, false><<<grid, kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, heavy, Y);       \
+    } while (0)
+#define PP_SPMM_S1(L) k_spmm_s1<L><<<(unsigned)ceil_div(n_rows, kBlock / L), kBlock, 0, st>>>(ptr, idx, val, n_rows, X, F, self_coef, S, bias, act, heavy, Y)
     const bool vec = (F % 4 == 0) && (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)S | (uintptr_t)bias) % 16 == 0);
     if (vec) {
         const int q = F / 4;
@@ -507,10 +587,57 @@ const int64_t* pp_plan_result_ptr(void* ws) { return (const int64_t*)ws; }
 
 // ---------------------------------------------------------------- propagation
 int pp_spmm_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* X, int F, const float* self_coef,
-                const float* S, const float* bias, int act, float* Y, pp_stream_t stream) {
+                const float* S, const float* bias, int act, const int32_t* heavy_slot, const float* heavy_sum, float* Y, pp_stream_t stream) {
     PP_REQUIRE(n_rows >= 0 && F >= 0, PP_ERR_ARG, "pp_spmm_f32: negative size");
     PP_REQUIRE(act == 0 || act == 1, PP_ERR_ARG, "pp_spmm_f32: act must be 0 (none) or 1 (elu)");
-    return launch_spmm(ptr, idx, val, n_rows, X, F, self_coef, self_coef ? (S ? S : X) : nullptr, bias, act, Y, (hipStream_t)stream);
+    PP_REQUIRE(heavy_slot == nullptr || heavy_sum != nullptr, PP_ERR_ARG, "pp_spmm_f32: heavy_slot without heavy_sum");
+    return launch_spmm(ptr, idx, val, n_rows, X, F, self_coef, self_coef ? (S ? S : X) : nullptr, bias, act, HeavyRows{heavy_slot, heavy_sum}, Y,
+                       (hipStream_t)stream);
+}
+
+// out_max[0] = max_r (ptr[r+1] - ptr[r]) of a CSR row-pointer array (device int64): does the plan have hub rows?
+int pp_max_row_length_i32(const int32_t* ptr, int64_t n_rows, int64_t* out_max, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_max_row_length_i32: negative size");
+    PP_HIP(hipMemsetAsync(out_max, 0, sizeof(int64_t), st));
+    if (n_rows == 0) return PP_OK;
+    int64_t blocks = ceil_div(n_rows, kBlock);
+    if (blocks > kMaxGrid) blocks = kMaxGrid;
+    k_max_row_length<<<(unsigned)blocks, kBlock, 0, st>>>(ptr, n_rows, out_max);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+int pp_heavy_chunk_entries(void) { return kHeavyChunk; }
+
+size_t pp_spmm_heavy_ws_bytes(int64_t n_chunks, int F) { return align_up((size_t)(n_chunks > 0 ? n_chunks : 1) * (size_t)(F > 0 ? F : 1) * sizeof(float)); }
+
+// heavy_sum[h, :] = sum over the CSR entries of heavy row h of val[p] * X[idx[p], :], h < n_heavy.  The entries of row h are covered
+// by the chunks heavy_chunk_ptr[h] .. heavy_chunk_ptr[h+1], chunk k = entries [chunk_begin[k], chunk_end[k]) (<= pp_heavy_chunk_entries()).
+int pp_spmm_heavy_f32(const int32_t* idx, const float* val, const float* X, int F, int64_t n_chunks, const int32_t* chunk_begin,
+                      const int32_t* chunk_end, int64_t n_heavy, const int32_t* heavy_chunk_ptr, float* heavy_sum, void* ws, size_t ws_bytes,
+                      pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_chunks >= 0 && n_heavy >= 0, PP_ERR_ARG, "pp_spmm_heavy_f32: negative size");
+    PP_REQUIRE(F >= 4 && F % 4 == 0 && F <= 256, PP_ERR_ARG, "pp_spmm_heavy_f32: F must be a multiple of 4 in [4, 256]");
+    PP_REQUIRE(((uintptr_t)X) % 16 == 0, PP_ERR_ARG, "pp_spmm_heavy_f32: X must be 16-byte aligned");
+    PP_REQUIRE(ws_bytes >= pp_spmm_heavy_ws_bytes(n_chunks, F), PP_ERR_WORKSPACE, "pp_spmm_heavy_f32: workspace too small");
+    if (n_heavy == 0 || n_chunks == 0) return PP_OK;
+    float* partial = (float*)ws;
+    const int q = F / 4;
+#define PP_HEAVY(L) k_heavy_partial<L><<<(unsigned)n_chunks, kBlock, 0, st>>>(idx, val, X, F, chunk_begin, chunk_end, partial)
+    if (q <= 1) PP_HEAVY(1);
+    else if (q <= 2) PP_HEAVY(2);
+    else if (q <= 4) PP_HEAVY(4);
+    else if (q <= 8) PP_HEAVY(8);
+    else if (q <= 16) PP_HEAVY(16);
+    else if (q <= 32) PP_HEAVY(32);
+    else PP_HEAVY(64);
+#undef PP_HEAVY
+    PP_LAUNCH_CHECK();
+    k_heavy_combine<<<(unsigned)n_heavy, kBlock, 0, st>>>(partial, heavy_chunk_ptr, F, heavy_sum);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
 }
 
 int pp_act_backward_f32(const float* dY, const float* Y, int64_t n_rows, int F, int act, float* dpre, float* dbias, pp_stream_t stream) {

@@ -26,12 +26,12 @@ constexpr int kGcnWaves = kGcnThreads / kWave;
 // tiles' pointers, chunks and rows; 2 waves/SIMD) and a producer/consumer split (12 gather waves + 4 MFMA waves through an LDS
 // ring) both land on the same 2.0 ms: the kernel moves ~10 GB per launch through L2 at the ~5 TB/s this chip sustains for
 // 256-byte random rows, as do pp_dense_f32 + pp_spmm_f32 with their 12.6 GB in 2.4 ms.
-template <int P, int Q>
+template <int P, int Q, bool kHeavy>      // kHeavy: the plan has hub rows (heavy.slot != nullptr); the common case pays nothing
 __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                                  const float* __restrict__ val, int64_t n_rows, const float* __restrict__ X,
                                                                  const float* __restrict__ self_coef, const float* __restrict__ W,
-                                                                 const float* __restrict__ bias, int act, float* __restrict__ agg_out,
-                                                                 float* __restrict__ Y) {
+                                                                 const float* __restrict__ bias, int act, HeavyRows heavy,
+                                                                 float* __restrict__ agg_out, float* __restrict__ Y) {
     constexpr int kLanes = P / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = P / 4, CT = Q / 16, TS = P + 4;
     constexpr int kBatch = kRows < 2 ? kRows : 2;
     __shared__ __attribute__((aligned(16))) float s_b[P * 16 * CT];
@@ -59,12 +59,14 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
             const int64_t r = r0 + q < n_rows ? r0 + q : n_rows;
             p[q] = ptr[r];
         }
-        int cj[kRows];
+        int cj[kRows], pe[kRows], hs[kRows];
         float cv[kRows], sc[kRows];
 #pragma unroll
         for (int q = 0; q < kRows; ++q) {
+            hs[q] = (kHeavy && r0 + q < n_rows) ? heavy.slot[r0 + q] : -1;
+            pe[q] = (kHeavy && hs[q] >= 0) ? p[q] : p[q + 1];                   // a hub row: its neighbour sum is already in heavy.sum
             const int mine = p[q] + l;
-            const bool in = mine < p[q + 1];
+            const bool in = mine < pe[q];
             cj[q] = in ? idx[mine] : 0;
             cv[q] = in ? (val ? val[mine] : 1.f) : 0.f;
             sc[q] = (self_coef != nullptr && r0 + q < n_rows) ? self_coef[r0 + q] : 0.f;
@@ -77,12 +79,12 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
                 const int q = b0 + qq;
                 const bool self_here = self_coef != nullptr && r0 + q < n_rows;
                 const int first = __shfl(cj[q], 0, kLanes);
-                const int dummy = p[q] < p[q + 1] ? first : (self_here ? (int)(r0 + q) : 0);
+                const int dummy = p[q] < pe[q] ? first : (self_here ? (int)(r0 + q) : 0);
                 self_off[qq] = (uint32_t)(self_here ? (int)(r0 + q) : dummy) * (uint32_t)(P * 4) + (uint32_t)(16 * l);
 #pragma unroll
                 for (int u = 0; u < kFirst; ++u) {
                     const int j = u == 0 ? first : __shfl(cj[q], u, kLanes);
-                    off[qq][u] = (uint32_t)(p[q] + u < p[q + 1] ? j : dummy) * (uint32_t)(P * 4) + (uint32_t)(16 * l);
+                    off[qq][u] = (uint32_t)(p[q] + u < pe[q] ? j : dummy) * (uint32_t)(P * 4) + (uint32_t)(16 * l);
                 }
             }
             float4 x[kBatch][kFirst], sr[kBatch];
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
                 }
                 int my_j = cj[q];
                 float my_v = cv[q];
-                const int p0 = p[q], p1 = p[q + 1];
+                const int p0 = p[q], p1 = pe[q];
                 for (int base = p0; base < p1; base += kLanes) {      // rows with more than kFirst neighbours
                     if (base != p0) {
                         const int mine = base + l;
@@ -128,6 +130,10 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
                     }
                 }
                 if (p0 == p1 && sc[q] == 0.f) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kHeavy && hs[q] >= 0) {
+                    const float4 h = *(const float4*)(heavy.sum + (int64_t)hs[q] * P + 4 * l);
+                    acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
+                }
                 *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc;
                 if (agg_out != nullptr && r0 + q < n_rows) *(float4*)(agg_out + (r0 + q) * P + 4 * l) = acc;
             }
@@ -169,28 +175,35 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
 // Persistent grid = exactly the workgroups that are resident at once (registers and LDS decide; asked from the runtime once).
 template <int P, int Q>
 static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                              const float* X, const float* self_coef, const float* W, const float* bias, int act, float* agg_out, float* Y) {
-    static int resident = 0;
-    if (resident == 0) {
+                              const float* X, const float* self_coef, const float* W, const float* bias, int act, HeavyRows heavy, float* agg_out, float* Y) {
+    static int resident_of[2] = {0, 0};
+    const int hv = heavy.slot != nullptr ? 1 : 0;
+    if (resident_of[hv] == 0) {
         int per_cu = 0, dev = 0, cus = 0;
-        PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q>, kGcnThreads, 0));
+        if (hv) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q, true>, kGcnThreads, 0));
+        else PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q, false>, kGcnThreads, 0));
         PP_HIP(hipGetDevice(&dev));
         PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+        resident_of[hv] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
     }
+    const int resident = resident_of[hv];
     int64_t blocks = ceil_div(n_tiles, kGcnWaves);
     if (blocks > resident) blocks = resident;
-    k_gcn_forward<P, Q><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, X, self_coef, W, bias, act, agg_out, Y);
+    if (heavy.slot != nullptr)
+        k_gcn_forward<P, Q, true><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y);
+    else
+        k_gcn_forward<P, Q, false><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y);
     return PP_OK;
 }
 
 template <int P>
 static int launch_gcn_forward_q(int Q, int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                                const float* X, const float* self_coef, const float* W, const float* bias, int act, float* agg_out, float* Y) {
+                                const float* X, const float* self_coef, const float* W, const float* bias, int act, HeavyRows heavy, float* agg_out,
+                                float* Y) {
     switch (Q) {
-        case 16: return launch_gcn_forward<P, 16>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, agg_out, Y);
-        case 32: return launch_gcn_forward<P, 32>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, agg_out, Y);
-        case 64: return launch_gcn_forward<P, 64>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, agg_out, Y);
+        case 16: return launch_gcn_forward<P, 16>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y);
+        case 32: return launch_gcn_forward<P, 32>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y);
+        case 64: return launch_gcn_forward<P, 64>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y);
         default: return PP_ERR_ARG;
     }
 }
@@ -201,11 +214,11 @@ static int launch_gcn_forward_q(int Q, int64_t n_tiles, hipStream_t st, const in
 //     d_in   = (G . W) (*) ELU'(x),  colsum_in = column sums    gradient w.r.t. the PRE-activation of the layer below + its bias gradient
 //     dW     = G^T x                                             contraction over the tile's rows on a second MFMA stream
 // Saves the write and the re-read of G (2 of the 7 N x 64 matrix passes of the two-kernel form).
-template <int M, int K>
+template <int M, int K, bool kHeavy>
 __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                              const float* __restrict__ val, int64_t n_rows, const float* __restrict__ D,
                                                              const float* __restrict__ self_coef, const float* __restrict__ X,
-                                                             const float* __restrict__ W, int fuse_act, float* __restrict__ d_in,
+                                                             const float* __restrict__ W, int fuse_act, HeavyRows heavy, float* __restrict__ d_in,
                                                              float* __restrict__ colsum_in, float* __restrict__ partial_w) {
     constexpr int kLanes = M / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = M / 4, MT = M / 16, CT = K / 16, TS = M + 4;
     constexpr int kBatch = kRows < 2 ? kRows : 2;
@@ -249,12 +262,14 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
             const int64_t r = r0 + q < n_rows ? r0 + q : n_rows;
             p[q] = ptr[r];
         }
-        int cj[kRows];
+        int cj[kRows], pe[kRows], hs[kRows];
         float cv[kRows], sc[kRows];
 #pragma unroll
         for (int q = 0; q < kRows; ++q) {
+            hs[q] = (kHeavy && r0 + q < n_rows) ? heavy.slot[r0 + q] : -1;
+            pe[q] = (kHeavy && hs[q] >= 0) ? p[q] : p[q + 1];                   // a hub row: its neighbour sum is already in heavy.sum
             const int mine = p[q] + l;
-            const bool in = mine < p[q + 1];
+            const bool in = mine < pe[q];
             cj[q] = in ? idx[mine] : 0;
             cv[q] = in ? (val ? val[mine] : 1.f) : 0.f;
             sc[q] = (self_coef != nullptr && r0 + q < n_rows) ? self_coef[r0 + q] : 0.f;
@@ -267,12 +282,12 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
                 const int q = b0 + qq;
                 const bool self_here = self_coef != nullptr && r0 + q < n_rows;
                 const int first = __shfl(cj[q], 0, kLanes);
-                const int dummy = p[q] < p[q + 1] ? first : (self_here ? (int)(r0 + q) : 0);
+                const int dummy = p[q] < pe[q] ? first : (self_here ? (int)(r0 + q) : 0);
                 self_off[qq] = (uint32_t)(self_here ? (int)(r0 + q) : dummy) * (uint32_t)(M * 4) + (uint32_t)(16 * l);
 #pragma unroll
                 for (int u = 0; u < kFirst; ++u) {
                     const int j = u == 0 ? first : __shfl(cj[q], u, kLanes);
-                    off[qq][u] = (uint32_t)(p[q] + u < p[q + 1] ? j : dummy) * (uint32_t)(M * 4) + (uint32_t)(16 * l);
+                    off[qq][u] = (uint32_t)(p[q] + u < pe[q] ? j : dummy) * (uint32_t)(M * 4) + (uint32_t)(16 * l);
                 }
             }
             float4 x[kBatch][kFirst], sr[kBatch];
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
                 }
                 int my_j = cj[q];
                 float my_v = cv[q];
-                const int p0 = p[q], p1 = p[q + 1];
+                const int p0 = p[q], p1 = pe[q];
                 for (int base = p0; base < p1; base += kLanes) {      // rows with more than kFirst neighbours
                     if (base != p0) {
                         const int mine = base + l;
@@ -318,6 +333,10 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
                     }
                 }
                 if (p0 == p1 && sc[q] == 0.f) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kHeavy && hs[q] >= 0) {
+                    const float4 h = *(const float4*)(heavy.sum + (int64_t)hs[q] * M + 4 * l);
+                    acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
+                }
                 *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc;
             }
         }
@@ -400,32 +419,38 @@ constexpr int64_t kGcnBackwardMaxBlocks = 256 * 4;
 
 template <int M, int K>
 static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                               const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, float* d_in,
-                               float* colsum_in, float* partial_w, int64_t* blocks_out) {
-    static int resident = 0;
-    if (resident == 0) {
+                               const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy,
+                               float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out) {
+    static int resident_of[2] = {0, 0};
+    const int hv = heavy.slot != nullptr ? 1 : 0;
+    if (resident_of[hv] == 0) {
         int per_cu = 0, dev = 0, cus = 0;
-        PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K>, kGcnThreads, 0));
+        if (hv) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K, true>, kGcnThreads, 0));
+        else PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K, false>, kGcnThreads, 0));
         PP_HIP(hipGetDevice(&dev));
         PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
-        if (resident > kGcnBackwardMaxBlocks) resident = (int)kGcnBackwardMaxBlocks;
+        resident_of[hv] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+        if (resident_of[hv] > kGcnBackwardMaxBlocks) resident_of[hv] = (int)kGcnBackwardMaxBlocks;
     }
+    const int resident = resident_of[hv];
     int64_t blocks = ceil_div(n_tiles, kGcnWaves);
     if (blocks > resident) blocks = resident;
     *blocks_out = blocks;
-    k_gcn_backward<M, K><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, d_in, colsum_in, partial_w);
+    if (heavy.slot != nullptr)
+        k_gcn_backward<M, K, true><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w);
+    else
+        k_gcn_backward<M, K, false><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w);
     return PP_OK;
 }
 
 template <int M>
 static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                                 const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, float* d_in,
-                                 float* colsum_in, float* partial_w, int64_t* blocks_out) {
+                                 const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy,
+                                 float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out) {
     switch (K) {
-        case 16: return launch_gcn_backward<M, 16>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, d_in, colsum_in, partial_w, blocks_out);
-        case 32: return launch_gcn_backward<M, 32>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, d_in, colsum_in, partial_w, blocks_out);
-        case 64: return launch_gcn_backward<M, 64>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, d_in, colsum_in, partial_w, blocks_out);
+        case 16: return launch_gcn_backward<M, 16>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w, blocks_out);
+        case 32: return launch_gcn_backward<M, 32>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w, blocks_out);
+        case 64: return launch_gcn_backward<M, 64>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w, blocks_out);
         default: return PP_ERR_ARG;
     }
 }
@@ -435,7 +460,8 @@ static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const i
 extern "C" {
 
 int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
-                       const float* self_coef, const float* W, int Q, const float* bias, int act, float* agg_out, float* Y, pp_stream_t stream) {
+                       const float* self_coef, const float* W, int Q, const float* bias, int act, const int32_t* heavy_slot, const float* heavy_sum,
+                       float* agg_out, float* Y, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_forward_f32: negative size");
     PP_REQUIRE(pp_dense_supported(P, Q), PP_ERR_ARG, "pp_gcn_forward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", P, Q);
@@ -445,11 +471,12 @@ int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val,
                "pp_gcn_forward_f32: X must be smaller than 4 GiB (use pp_dense_f32 + pp_spmm_f32)");
     if (n_rows == 0) return PP_OK;
     const int64_t n_tiles = pp::ceil_div(n_rows, 16);
+    const pp::HeavyRows heavy{heavy_slot, heavy_sum};
     int rc;
     switch (P) {
-        case 16: rc = pp::launch_gcn_forward_q<16>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, agg_out, Y); break;
-        case 32: rc = pp::launch_gcn_forward_q<32>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, agg_out, Y); break;
-        default: rc = pp::launch_gcn_forward_q<64>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, agg_out, Y); break;
+        case 16: rc = pp::launch_gcn_forward_q<16>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, agg_out, Y); break;
+        case 32: rc = pp::launch_gcn_forward_q<32>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, agg_out, Y); break;
+        default: rc = pp::launch_gcn_forward_q<64>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, agg_out, Y); break;
     }
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();
@@ -463,8 +490,8 @@ size_t pp_gcn_backward_ws_bytes(int64_t n_rows) {
 }
 
 int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
-                        const float* self_coef, const float* X, int K, const float* W, int fuse_act, float* d_in, float* colsum_in,
-                        float* dW, void* ws, size_t ws_bytes, pp_stream_t stream) {
+                        const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
+                        const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_backward_f32: negative size");
     PP_REQUIRE(pp_dense_supported(M, K), PP_ERR_ARG, "pp_gcn_backward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", M, K);
@@ -479,12 +506,13 @@ int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val
         return PP_OK;
     }
     const int64_t n_tiles = pp::ceil_div(n_rows, 16);
+    const pp::HeavyRows heavy{heavy_slot, heavy_sum};
     int64_t blocks = 0;
     int rc;
     switch (M) {
-        case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, d_in, colsum_in, (float*)ws, &blocks); break;
-        case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, d_in, colsum_in, (float*)ws, &blocks); break;
-        default: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, d_in, colsum_in, (float*)ws, &blocks); break;
+        case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, (float*)ws, &blocks); break;
+        case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, (float*)ws, &blocks); break;
+        default: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, (float*)ws, &blocks); break;
     }
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();

@@ -192,7 +192,7 @@ class _LocalPropagate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, plan, x_full, s_local, bias, act: bool):
-        y = _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x_full, plan.self_coef, s_local, bias, act)
+        y = _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x_full, plan.self_coef, s_local, bias, act, heavy=plan.fwd_heavy)
         ctx.plan, ctx.act, ctx.has_bias = plan, act, bias is not None
         ctx.save_for_backward(y if act else None)
         return y
@@ -208,7 +208,7 @@ class _LocalPropagate(torch.autograd.Function):
                 dpre = dy.contiguous()
         else:
             dpre, dbias = dy.contiguous(), None
-        dx_full = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre) if ctx.needs_input_grad[1] else None
+        dx_full = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, heavy=plan.bwd_heavy) if ctx.needs_input_grad[1] else None
         ds = _hip.scale_rows(dpre, plan.self_coef) if ctx.needs_input_grad[2] else None
         return None, dx_full, ds, dbias, None
 

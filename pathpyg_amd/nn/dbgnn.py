@@ -32,7 +32,7 @@ class _Propagate(torch.autograd.Function):
     def forward(ctx, plan, x, s, bias, act: bool, grad_is_pre: bool = False):
         """``grad_is_pre``: the (single) consumer of ``y`` is a :class:`_Dense` with ``fuse_act`` — it hands back the gradient
         w.r.t. the PRE-activation and computes this layer's bias gradient itself, so nothing of that is redone here."""
-        y = _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x, plan.self_coef, s, bias, act)
+        y = _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x, plan.self_coef, s, bias, act, heavy=plan.fwd_heavy)
         ctx.plan, ctx.act, ctx.separate_self = plan, act, s is not None
         ctx.has_bias = bias is not None
         ctx.grad_is_pre = grad_is_pre
@@ -55,11 +55,11 @@ class _Propagate(torch.autograd.Function):
         dx = ds = None
         if ctx.separate_self:
             if need_x:
-                dx = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre)
+                dx = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, heavy=plan.bwd_heavy)
             if need_s:
                 ds = _hip.scale_rows(dpre, plan.self_coef)
         elif need_x:      # the self term acts on x itself: A^T dpre + diag(self_coef) dpre in one pass
-            dx = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, dpre)
+            dx = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, dpre, heavy=plan.bwd_heavy)
         return None, dx, ds, dbias, None, None
 
 
@@ -126,7 +126,8 @@ class _GcnLayer(torch.autograd.Function):
         # first layer of a stack (its input needs no gradient): keep the aggregated input A x; the only gradient left is
         # dW = dpre^T (A x), so the backward pass needs no aggregation at all
         ctx.keep_agg = not ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
-        out = _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x, plan.self_coef, weight, bias, True, ctx.keep_agg)
+        out = _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x, plan.self_coef, weight, bias, True, ctx.keep_agg,
+                               heavy=plan.fwd_heavy)
         if ctx.keep_agg:
             ctx.save_for_backward(out[1], weight)
             return out[0]
@@ -146,9 +147,9 @@ class _GcnLayer(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # aggregation over the transposed graph, input gradient (+ ELU' and the bias gradient of the layer below) and dW: one kernel
             dx, dact, dw = _hip.gcn_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, x, weight,
-                                             ctx.fuse_act, want_sum)
+                                             ctx.fuse_act, want_sum, heavy=plan.bwd_heavy)
         elif ctx.needs_input_grad[2]:
-            g = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, dpre)
+            g = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, dpre, heavy=plan.bwd_heavy)
             dw, _ = _hip.weight_grad(g, x, want_bias=False)
         return None, dx, dw, None, None, dact
 
@@ -162,7 +163,7 @@ class _AggregateAct(torch.autograd.Function):
     def forward(ctx, plan, y, act_bias):
         ctx.plan, ctx.has_act_bias = plan, act_bias is not None
         ctx.save_for_backward(y)
-        return _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, y)
+        return _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, y, heavy=plan.fwd_heavy)
 
     @staticmethod
     def backward(ctx, d_agg):

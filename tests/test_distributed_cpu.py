@@ -102,7 +102,7 @@ def test_sharded_lift_and_gradient_allreduce_gloo(world):
 # Destination-partitioned DBGNN: the sharding, the rectangular plans and the collectives run for real (gloo);
 # the four device kernels it calls are replaced by small torch-CPU equivalents (test-only stand-ins).
 class _CpuPlan:
-    pass
+    fwd_heavy = bwd_heavy = None          # hub-row tables of the device plans: not needed by the CPU stand-in
 
 
 def _cpu_bipartite_plan(bipartite_index, n_src, n_dst, pair_value=None):
@@ -122,7 +122,7 @@ def _cpu_bipartite_plan(bipartite_index, n_src, n_dst, pair_value=None):
     return plan
 
 
-def _cpu_spmm(ptr, idx, val, n_rows, x, self_coef=None, s=None, bias=None, act=False):
+def _cpu_spmm(ptr, idx, val, n_rows, x, self_coef=None, s=None, bias=None, act=False, heavy=None):
     counts = (ptr[1:] - ptr[:-1]).long()
     rows = torch.repeat_interleave(torch.arange(n_rows), counts)
     contrib = x[idx.long()] * (1.0 if val is None else val.unsqueeze(1))

@@ -324,3 +324,81 @@ def test_fused_gcn_backward_kernel(pp, n, e, m, k, fuse):
     torch.testing.assert_close(got_sum.cpu(), d_in.sum(0).float(), rtol=1e-4, atol=1e-5 * float(d_in.abs().sum(0).max() + 1))
     wscale = float((gmat.abs().t() @ x.double().abs()).max()) + 1e-12
     torch.testing.assert_close(got_w.cpu(), dw.float(), rtol=1e-4, atol=2e-6 * wscale)
+
+
+def _hub_bundle(seed, n, e, n_ho, e_ho, f, hub_share=0.4):
+    """Like _bundle, but a large share of all edges points at (and leaves from) a handful of hub nodes: rows far beyond
+    HEAVY_ROW_ENTRIES in both CSR directions of both graphs and of the bipartite map."""
+    from oracle import model as om
+    g = torch.Generator().manual_seed(seed)
+
+    def graph(nn, ee):
+        ei = torch.randint(0, nn, (2, ee), generator=g)
+        k = int(ee * hub_share)
+        ei[1, :k] = torch.randint(0, 3, (k,), generator=g)                   # three hubs collect 40 % of the in-edges
+        ei[0, k:2 * k] = torch.randint(3, 5, (k,), generator=g)              # two others emit 40 % of the out-edges
+        key = torch.unique(ei[0] * nn + ei[1])
+        ei = torch.stack((key // nn, key % nn))
+        return ei, torch.randint(1, 4, (ei.size(1),), generator=g).float()
+
+    ei, w = graph(n, e)
+    ei_h, w_h = graph(n_ho, e_ho)
+    ns = torch.randint(0, n, (n_ho, 2), generator=g)
+    ns[: n_ho // 2, 1] = 7                                                    # half of the higher-order nodes map to ONE first-order node
+    data = {"num_nodes": n, "num_ho_nodes": n_ho, "x": torch.randn(n, f, generator=g), "x_h": torch.randn(n_ho, f, generator=g),
+            "edge_index": ei, "edge_weights": w, "edge_index_higher_order": ei_h, "edge_weights_higher_order": w_h,
+            "bipartite_edge_index": om.bipartite_edge_index(ns, "last")}
+    return data, torch.randint(0, 3, (n,), generator=g)
+
+
+@pytest.mark.parametrize("f,hidden", [(32, [32, 32, 16]), (20, [24, 40, 8])])        # fused kernels / generic SpMM + library GEMM
+def test_dbgnn_with_hub_rows_matches_float64_oracle(pp, f, hidden):
+    """Scale-free shape: rows with 10^4 entries go through the chunked hub pre-pass (pp_spmm_heavy_f32) in every kernel that walks
+    CSR rows.  fp32 sums of 10^4 terms in a different order: compared with the float64 oracle at 2e-5 of the largest entry."""
+    from oracle import dbgnn as od
+    from pathpyg_amd import _hip
+    data, y = _hub_bundle(11, 4000, 60_000, 9000, 90_000, f)
+    params = od.init_params(3, (f, f), hidden, seed=2)
+    ref = {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in data.items()}
+    want_out, want_loss, want_grads = od.loss_and_grads({k: v.double() for k, v in params.items()}, ref, y)
+    net = _to_module(pp, params, 3, (f, f), hidden)
+    gdata = pp.Data(**{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in data.items()})
+    out = net(gdata)
+    plans = gdata._pp_plan_cache
+    assert plans["fo"][1].fwd_heavy is not None and plans["fo"][1].bwd_heavy is not None
+    assert plans["ho"][1].fwd_heavy is not None and plans["bi"][1].fwd_heavy is not None
+    assert plans["fo"][1].fwd_heavy.n_heavy >= 3 and plans["fo"][1].fwd_heavy.n_chunks > plans["fo"][1].fwd_heavy.n_heavy
+    loss = F.cross_entropy(out, y.to(DEV))
+    loss.backward()
+    scale = float(want_out.abs().max())
+    torch.testing.assert_close(out.detach().cpu().double(), want_out, rtol=2e-5, atol=2e-5 * scale)
+    torch.testing.assert_close(loss.detach().cpu().double(), want_loss, rtol=2e-5, atol=1e-6)
+    for name, p in net.named_parameters():
+        gs = float(want_grads[name].abs().max()) + 1e-30
+        torch.testing.assert_close(p.grad.cpu().double(), want_grads[name], rtol=1e-4, atol=1e-4 * gs), name
+
+
+@pytest.mark.parametrize("f", [4, 20, 40, 64, 100, 256, 7])
+def test_spmm_with_hub_rows(pp, f):
+    """pp_spmm_f32 with the chunked hub pre-pass against float64 for widths that do and do not fill the lane groups (7: the
+    scalar kernel, where hub rows fall back to the plain row walk)."""
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(f)
+    n, n_src, e = 3000, 2500, 120_000
+    row = torch.randint(0, n, (e,), generator=g)
+    row[:30_000] = 5                                       # 30 000 entries in one row (15 chunks), 9 000 in another
+    row[30_000:39_000] = 77
+    row = torch.sort(row).values
+    ptr = torch.zeros(n + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.bincount(row, minlength=n), 0).int()
+    idx = torch.randint(0, n_src, (e,), generator=g, dtype=torch.int32)
+    val = torch.rand(e, generator=g)
+    x = torch.randn(n_src, f, generator=g)
+    a = torch.zeros(n, n_src, dtype=torch.float64)
+    a.index_put_((row, idx.long()), val.double(), accumulate=True)
+    want = a @ x.double()
+    heavy = _hip.HeavyRows(ptr.to(DEV), n)
+    assert heavy.n_heavy == 2 and heavy.n_chunks == 15 + 5
+    got = _hip.spmm(ptr.to(DEV), idx.to(DEV), val.to(DEV), n, x.to(DEV), heavy=heavy).cpu().double()
+    scale = float(want.abs().max())
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=2e-6 * scale)
