@@ -65,11 +65,37 @@ __global__ __launch_bounds__(kBlock) void k_gcn_degree_grouped(const int32_t* __
                                                               const float* __restrict__ w, int64_t n_nodes, float* __restrict__ dinv,
                                                               float* __restrict__ self_coef) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_nodes) return;
-    const float lw = last_loop[i] >= 0 ? (w ? w[last_loop[i]] : 1.0f) : 1.0f;
+    const bool live = i < n_nodes;
+    const uint32_t p0 = live ? dst_ptr[i] : 0u, p1 = live ? dst_ptr[i + 1] : 0u;
+    const bool is_long = p1 - p0 > 256u;                         // hub: summed by the whole wave below, not by this lane alone
     float deg = 0.0f;
-    for (uint32_t p = dst_ptr[i]; p < dst_ptr[i + 1]; ++p)
-        if (in_idx[p] != (int32_t)i) deg += w_by_dst[p];
+    if (!is_long)
+        for (uint32_t p = p0; p < p1; ++p)
+            if (in_idx[p] != (int32_t)i) deg += w_by_dst[p];
+    // hub rows: the wave strides over the row with 8 independent loads in flight per lane (a lone lane needs ~1 us per entry: 3 ms for
+    // a 10^5-entry row); waves work on different hubs in parallel, partial sums folded by a fixed-order butterfly
+    for (uint64_t todo = __ballot(is_long); todo != 0; todo &= todo - 1) {
+        const int owner = __ffsll((long long)todo) - 1;
+        const uint32_t b = __shfl(p0, owner, kWave), e = __shfl(p1, owner, kWave);
+        const int32_t node = (int32_t)__shfl((int)i, owner, kWave);
+        float part = 0.0f;
+        constexpr int kUnroll = 8;
+        uint32_t p = b + lane_id();
+        for (; p + (kUnroll - 1) * kWave < e; p += kUnroll * kWave) {
+            int32_t jj[kUnroll];
+            float ww[kUnroll];
+#pragma unroll
+            for (int k = 0; k < kUnroll; ++k) { jj[k] = in_idx[p + k * kWave]; ww[k] = w_by_dst[p + k * kWave]; }
+#pragma unroll
+            for (int k = 0; k < kUnroll; ++k) part += jj[k] != node ? ww[k] : 0.0f;
+        }
+        for (; p < e; p += kWave)
+            if (in_idx[p] != node) part += w_by_dst[p];
+        part = wave_sum(part);                                   // butterfly: fixed order, the same total in every lane
+        if (lane_id() == owner) deg = part;
+    }
+    if (!live) return;
+    const float lw = last_loop[i] >= 0 ? (w ? w[last_loop[i]] : 1.0f) : 1.0f;
     deg += lw;
     float d = 1.0f / sqrtf(deg);                                  // deg^-1/2 ; inf -> 0 like masked_fill_(== inf, 0)
     if (isinf(d)) d = 0.0f;

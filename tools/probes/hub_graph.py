@@ -28,3 +28,11 @@ for zipf in (False, True):
     deg1 = torch.bincount(mom.layers[1].data.edge_index[1], minlength=n).max().item()
     deg2 = torch.bincount(mom.layers[2].data.edge_index[1], minlength=n_ho).max().item()
     print(f"zipf={zipf}: layers {t_lift*1e3:.1f} ms, E2={mom.layers[2].data.edge_index.size(1)}, U2={n_ho}, max in-degree fo={deg1} ho={deg2}, train step {dt*1e3:.1f} ms")
+    from pathpyg_amd import _hip
+    for name, gl in (("fo", mom.layers[1]), ("ho", mom.layers[2])):
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            _hip.gcn_plan(gl.data.edge_index, gl.data.edge_weight, gl.n)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        print(f"   gcn_plan {name}: {min(ts)*1e3:.2f} ms")
