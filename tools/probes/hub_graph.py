@@ -3,8 +3,9 @@ import sys, time, torch
 sys.path.insert(0, ".")
 import pathpyg_amd as pp
 dev = "cuda:0"
-m, n, span, delta, f = 2_000_000, 100_000, 2_000_000, 20_000, 64
-for zipf in (False, True):
+import os
+m, n, span, delta, f = (int(x) for x in os.environ.get("HUB_SHAPE", "2000000,100000,2000000,20000,64").split(","))
+for zipf in ((True,) if os.environ.get("HUB_ONLY") else (False, True)):
     g = torch.Generator(device=dev).manual_seed(1)
     src = torch.randint(0, n, (m,), generator=g, device=dev)
     if zipf:
