@@ -175,17 +175,49 @@ __global__ __launch_bounds__(kBlock) void k_coalesce_fill(const KeyT* __restrict
                                                          const int64_t* __restrict__ col_base, const T* __restrict__ weight, int reduce,
                                                          int64_t* __restrict__ out_index, T* __restrict__ out_weight) {
     const int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (a >= n_out) return;
-    const uint32_t p0 = seg_start[a], p1 = seg_start[a + 1];
-    const uint64_t key = (uint64_t)sorted_keys[p0];
-    const int64_t row = (int64_t)(key >> shift);
-    out_index[a] = row;
-    out_index[n_out + a] = (int64_t)(key & ((1ull << shift) - 1ull)) + (col_base ? col_base[row] : 0);
-    if (weight) {
-        T acc = weight[perm[p0]];
-        for (uint32_t p = p0 + 1; p < p1; ++p) acc = reduce_step<T>(acc, weight[perm[p]], reduce);
-        out_weight[a] = reduce == PP_REDUCE_MEAN ? mean_of<T>(acc, p1 - p0) : acc;
+    const bool live = a < n_out;
+    const uint32_t p0 = live ? seg_start[a] : 0u, p1 = live ? seg_start[a + 1] : 0u;
+    if (live) {
+        const uint64_t key = (uint64_t)sorted_keys[p0];
+        const int64_t row = (int64_t)(key >> shift);
+        out_index[a] = row;
+        out_index[n_out + a] = (int64_t)(key & ((1ull << shift) - 1ull)) + (col_base ? col_base[row] : 0);
     }
+    if (!weight) return;
+    // A run of thousands of parallel edges (one node pair carrying a large share of a contact stream) is not walked by its lane
+    // alone (~1 us per entry): the wave strides over it with 8 gathers in flight per lane and folds the partial results in a fixed
+    // butterfly order (sums of integer-valued weights stay exact; other float sums differ from the left-to-right order by rounding).
+    const bool is_long = p1 - p0 > 512u;
+    T acc = T(0);
+    if (live && !is_long) {
+        acc = weight[perm[p0]];
+        for (uint32_t p = p0 + 1; p < p1; ++p) acc = reduce_step<T>(acc, weight[perm[p]], reduce);
+    }
+    for (uint64_t todo = __ballot(is_long); todo != 0; todo &= todo - 1) {
+        const int owner = __ffsll((long long)todo) - 1;
+        const uint32_t b = __shfl(p0, owner, kWave), e = __shfl(p1, owner, kWave);
+        T part = weight[perm[b + (lane_id() < (int)(e - b) ? lane_id() : 0)]];          // every lane starts from a real element
+        constexpr int kUnroll = 8;
+        uint32_t p = b + kWave + lane_id();
+        for (; p + (kUnroll - 1) * kWave < e; p += kUnroll * kWave) {
+            T ww[kUnroll];
+#pragma unroll
+            for (int k = 0; k < kUnroll; ++k) ww[k] = weight[perm[p + k * kWave]];
+#pragma unroll
+            for (int k = 0; k < kUnroll; ++k) part = reduce_step<T>(part, ww[k], reduce);
+        }
+        for (; p < e; p += kWave) part = reduce_step<T>(part, weight[perm[p]], reduce);
+        // lanes beyond a run shorter than the wave hold a duplicate of element 0: harmless for min / max, excluded from sums
+        const bool counted = lane_id() < (int)(e - b);
+        if (!counted && reduce != PP_REDUCE_MIN && reduce != PP_REDUCE_MAX) part = T(0);
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) {
+            const T other = __shfl_xor(part, d, kWave);
+            part = reduce_step<T>(part, other, reduce);
+        }
+        if (lane_id() == owner) acc = part;
+    }
+    if (live) out_weight[a] = reduce == PP_REDUCE_MEAN ? mean_of<T>(acc, p1 - p0) : acc;
 }
 
 // inverse[e] = index of the merged edge that input edge e ended up in

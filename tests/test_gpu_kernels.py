@@ -310,3 +310,23 @@ def test_linegraph_lift_hub_and_empty(hip):
     assert hip.linegraph_lift(cu(empty), 5).shape == (2, 0)
     no_continuation = torch.tensor([[0, 1], [2, 3]])                 # nobody leaves nodes 2 and 3
     assert hip.linegraph_lift(cu(no_continuation), 4).shape == (2, 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.int64, torch.int32])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+def test_coalesce_with_long_duplicate_runs(hip, dtype, reduce):
+    """One node pair carries 40 % of all edges (20 000 parallel edges) and another 900: the wave-cooperative reduction of long runs
+    must give the oracle's result (integer-valued weights: exact also for float sums)."""
+    from oracle import aggregate as oa
+    _hip = hip
+    g = torch.Generator().manual_seed(3)
+    n, e = 500, 50_000
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[:, :20_000] = torch.tensor([[7], [3]])
+    ei[:, 20_000:20_900] = torch.tensor([[400], [400]])
+    ei = ei[:, torch.randperm(e, generator=g)]
+    w = torch.randint(-50, 50, (e,), generator=g).to(dtype)
+    want_index, want_w = oa.coalesce(ei, w, n, reduce)
+    got_index, got_w = _hip.coalesce(ei.to(DEV), w.to(DEV), n, reduce)
+    assert torch.equal(got_index.cpu(), want_index)
+    assert torch.equal(got_w.cpu(), want_w), (dtype, reduce)
