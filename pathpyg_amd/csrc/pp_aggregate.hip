@@ -169,11 +169,14 @@ __device__ __forceinline__ T mean_of(T sum, uint32_t n) {
     }
 }
 
+constexpr uint32_t kLongRun = 512;           // parallel-edge runs longer than this are reduced by a whole workgroup
+
 template <typename KeyT, typename T>
 __global__ __launch_bounds__(kBlock) void k_coalesce_fill(const KeyT* __restrict__ sorted_keys, const uint32_t* __restrict__ perm,
                                                          const uint32_t* __restrict__ seg_start, int64_t n_out, int shift,
                                                          const int64_t* __restrict__ col_base, const T* __restrict__ weight, int reduce,
-                                                         int64_t* __restrict__ out_index, T* __restrict__ out_weight) {
+                                                         int64_t* __restrict__ out_index, T* __restrict__ out_weight,
+                                                         uint32_t* __restrict__ long_runs) {
     const int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = a < n_out;
     const uint32_t p0 = live ? seg_start[a] : 0u, p1 = live ? seg_start[a + 1] : 0u;
@@ -185,39 +188,53 @@ __global__ __launch_bounds__(kBlock) void k_coalesce_fill(const KeyT* __restrict
     }
     if (!weight) return;
     // A run of thousands of parallel edges (one node pair carrying a large share of a contact stream) is not walked by its lane
-    // alone (~1 us per entry): the wave strides over it with 8 gathers in flight per lane and folds the partial results in a fixed
-    // butterfly order (sums of integer-valued weights stay exact; other float sums differ from the left-to-right order by rounding).
-    const bool is_long = p1 - p0 > 512u;
-    T acc = T(0);
-    if (live && !is_long) {
-        acc = weight[perm[p0]];
-        for (uint32_t p = p0 + 1; p < p1; ++p) acc = reduce_step<T>(acc, weight[perm[p]], reduce);
+    // alone (~1 us per entry): it is queued for k_coalesce_long_runs, a workgroup per run.
+    const uint32_t len = p1 - p0;
+    if (!live) return;
+    if (len > kLongRun) {
+        long_runs[1 + atomicAdd(&long_runs[0], 1u)] = (uint32_t)a;
+        return;
     }
-    for (uint64_t todo = __ballot(is_long); todo != 0; todo &= todo - 1) {
-        const int owner = __ffsll((long long)todo) - 1;
-        const uint32_t b = __shfl(p0, owner, kWave), e = __shfl(p1, owner, kWave);
-        T part = weight[perm[b + (lane_id() < (int)(e - b) ? lane_id() : 0)]];          // every lane starts from a real element
+    T acc = weight[perm[p0]];
+    for (uint32_t p = p0 + 1; p < p1; ++p) acc = reduce_step<T>(acc, weight[perm[p]], reduce);
+    out_weight[a] = reduce == PP_REDUCE_MEAN ? mean_of<T>(acc, len) : acc;
+}
+
+// One workgroup per queued run: 256 threads stride over it with 8 gathers in flight each; partial results are folded in a fixed order
+// (wave butterfly, then the waves in wave order) - sums of integer-valued weights stay exact, other float sums differ from the
+// left-to-right order only by rounding.  The queue order is arbitrary, the result of each run is not.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_coalesce_long_runs(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ seg_start,
+                                                              const T* __restrict__ weight, int reduce, const uint32_t* __restrict__ long_runs,
+                                                              T* __restrict__ out_weight) {
+    __shared__ T s_part[kWavesPerBlock];
+    const uint32_t count = long_runs[0];
+    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+        const uint32_t a = long_runs[1 + k];
+        const uint32_t b = seg_start[a], e = seg_start[a + 1];
+        T part = weight[perm[b + threadIdx.x]];                     // len > kLongRun >= kBlock: every thread starts from its own element
         constexpr int kUnroll = 8;
-        uint32_t p = b + kWave + lane_id();
-        for (; p + (kUnroll - 1) * kWave < e; p += kUnroll * kWave) {
+        uint32_t p = b + kBlock + threadIdx.x;
+        for (; p + (kUnroll - 1) * kBlock < e; p += kUnroll * kBlock) {
             T ww[kUnroll];
 #pragma unroll
-            for (int k = 0; k < kUnroll; ++k) ww[k] = weight[perm[p + k * kWave]];
+            for (int u = 0; u < kUnroll; ++u) ww[u] = weight[perm[p + u * kBlock]];
 #pragma unroll
-            for (int k = 0; k < kUnroll; ++k) part = reduce_step<T>(part, ww[k], reduce);
+            for (int u = 0; u < kUnroll; ++u) part = reduce_step<T>(part, ww[u], reduce);
         }
-        for (; p < e; p += kWave) part = reduce_step<T>(part, weight[perm[p]], reduce);
-        // lanes beyond a run shorter than the wave hold a duplicate of element 0: harmless for min / max, excluded from sums
-        const bool counted = lane_id() < (int)(e - b);
-        if (!counted && reduce != PP_REDUCE_MIN && reduce != PP_REDUCE_MAX) part = T(0);
+        for (; p < e; p += kBlock) part = reduce_step<T>(part, weight[perm[p]], reduce);
 #pragma unroll
-        for (int d = kWave / 2; d > 0; d >>= 1) {
-            const T other = __shfl_xor(part, d, kWave);
-            part = reduce_step<T>(part, other, reduce);
+        for (int d = kWave / 2; d > 0; d >>= 1) part = reduce_step<T>(part, __shfl_xor(part, d, kWave), reduce);
+        if (lane_id() == 0) s_part[wave_id()] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            T acc = s_part[0];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) acc = reduce_step<T>(acc, s_part[w], reduce);
+            out_weight[a] = reduce == PP_REDUCE_MEAN ? mean_of<T>(acc, e - b) : acc;
         }
-        if (lane_id() == owner) acc = part;
+        __syncthreads();
     }
-    if (live) out_weight[a] = reduce == PP_REDUCE_MEAN ? mean_of<T>(acc, p1 - p0) : acc;
 }
 
 // inverse[e] = index of the merged edge that input edge e ended up in
@@ -282,13 +299,22 @@ static int coalesce_fill_impl(const void* weight, int dtype, int reduce, int64_t
                               int64_t* out_index, void* out_weight, CoalesceWs& w, hipStream_t st) {
     const unsigned grid = (unsigned)ceil_div(n_out, kBlock);
     const KeyT* keys = (const KeyT*)w.keys_b;
+    uint32_t* long_runs = (uint32_t*)w.scratch;                 // {count, run ids...}: the sort scratch is free again (>= 12 bytes per edge)
+    PP_HIP(hipMemsetAsync(long_runs, 0, sizeof(uint32_t), st));
+#define PP_FILL(T)                                                                                                                 \
+    do {                                                                                                                           \
+        k_coalesce_fill<KeyT, T><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, col_base, (const T*)weight, reduce,  \
+                                                           out_index, (T*)out_weight, long_runs);                                  \
+        if (weight) k_coalesce_long_runs<T><<<256, kBlock, 0, st>>>(w.perm, w.seg_start, (const T*)weight, reduce, long_runs, (T*)out_weight); \
+    } while (0)
     switch (weight ? dtype : PP_F32) {
-        case PP_I32: k_coalesce_fill<KeyT, int32_t><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, col_base, (const int32_t*)weight, reduce, out_index, (int32_t*)out_weight); break;
-        case PP_I64: k_coalesce_fill<KeyT, int64_t><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, col_base, (const int64_t*)weight, reduce, out_index, (int64_t*)out_weight); break;
-        case PP_F32: k_coalesce_fill<KeyT, float><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, col_base, (const float*)weight, reduce, out_index, (float*)out_weight); break;
-        case PP_F64: k_coalesce_fill<KeyT, double><<<grid, kBlock, 0, st>>>(keys, w.perm, w.seg_start, n_out, shift, col_base, (const double*)weight, reduce, out_index, (double*)out_weight); break;
+        case PP_I32: PP_FILL(int32_t); break;
+        case PP_I64: PP_FILL(int64_t); break;
+        case PP_F32: PP_FILL(float); break;
+        case PP_F64: PP_FILL(double); break;
         default: PP_REQUIRE(false, PP_ERR_ARG, "pp_coalesce_fill: unsupported weight dtype %d", dtype);
     }
+#undef PP_FILL
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

@@ -241,10 +241,18 @@ def test_fuzz_from_temporal_graph_against_oracle(pp):
         g = pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=t.to(DEV), num_nodes=n, edge_weight=w.to(DEV)))
         model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=K, cached=cached)
         assert sorted(model.layers) == sorted(want), (case, m, n, K)
+        exact = None
         for k in want:
             d = model.layers[k].data
-            for key in ("edge_index", "edge_weight", "node_sequence", "inverse_idx"):
+            for key in ("edge_index", "node_sequence", "inverse_idx"):
                 assert torch.equal(d[key].cpu(), want[k][key]), (case, m, n, span, K, delta, float_time, k, key)
+            if not torch.equal(d.edge_weight.cpu(), want[k]["edge_weight"]):
+                # runs of > 512 parallel edges are summed by a tree, not left to right: once the fp32 partial sums pass 2^24 the
+                # reference's sequential accumulation is the LESS accurate one - then the float64 evaluation decides
+                if exact is None:
+                    exact = om.layers_from_temporal(sei, st, n, delta=delta, max_order=K, edge_weight=w[perm].double(), cached=cached)
+                assert float(want[k]["edge_weight"].max()) > 2 ** 24, (case, k)
+                torch.testing.assert_close(d.edge_weight.cpu().double(), exact[k]["edge_weight"], rtol=1e-6, atol=0)
             assert d.num_nodes == want[k]["num_nodes"]
 
 
