@@ -299,7 +299,17 @@ __global__ __launch_bounds__(kBlock) void k_expand(const int64_t* __restrict__ o
         *(I32x4*)(s_src + 8 * l) = I32x4{0, 0, 0, 0};
         *(I32x4*)(s_src + 8 * l + 4) = I32x4{0, 0, 0, 0};
         __builtin_amdgcn_wave_barrier();
-        for (int64_t base = 1; base < n_bound; base += 4 * kWave) {
+        // an extremely sparse result (far more sources than output slots: tens of thousands of empty sources per tile) is
+        // cheaper to resolve with one binary search per slot than by streaming every boundary past one wave
+        const bool search = n_bound > 16384;
+        if (search) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t p = p0 + 8 * l + j;
+                if (p < p1) s_src[8 * l + j] = (int32_t)(upper_bound_dev<int64_t, int64_t>(offset, s_first, s_beyond + 2, p) - 1 - s_first);
+            }
+        }
+        for (int64_t base = 1; base < n_bound && !search; base += 4 * kWave) {
             int64_t o[4], o1[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
