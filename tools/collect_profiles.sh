@@ -25,7 +25,7 @@ def grab(path):
             rows[m.group(1).strip()] = (int(m.group(3)), float(m.group(5)))
     return rows
 f, w = grab("$OUT/pmc_FETCH_SIZE.txt"), grab("$OUT/pmc_WRITE_SIZE.txt")
-for key, pat in (("k_gcn_forward", "k_gcn_forward<64, 64>"), ("k_gcn_backward", "k_gcn_backward<64, 64>"), ("k_spmm_v4", "k_spmm_v4<16, 2>"),
+for key, pat in (("k_gcn_forward", "k_gcn_forward<64, 64"), ("k_gcn_backward", "k_gcn_backward<64, 64"), ("k_spmm_v4", "k_spmm_v4<16, 2"),
                  ("k_expand", "k_expand<true>")):
     fk = [k for k in f if pat in k]
     wk = [k for k in w if pat in k]
