@@ -255,6 +255,171 @@ class Graph:
         ptr = self.col_ptr
         return self.mapping.to_ids(self.row[ptr[i]:ptr[i + 1]].cpu()).tolist()
 
+    def get_successors(self, row_idx: int) -> torch.Tensor:
+        """Indices of all successors of the node with index ``row_idx`` (reference graph.py:379-394)."""
+        ptr = self.row_ptr
+        if row_idx + 1 < ptr.size(0):
+            return self.col[ptr[row_idx]:ptr[row_idx + 1]]
+        return torch.tensor([], device=self.data.edge_index.device)
+
+    def get_predecessors(self, col_idx: int) -> torch.Tensor:
+        """Indices of all predecessors of the node with index ``col_idx`` (reference graph.py:396-411)."""
+        ptr = self.col_ptr
+        if col_idx + 1 < ptr.size(0):
+            return self.row[ptr[col_idx]:ptr[col_idx + 1]]
+        return torch.tensor([], device=self.data.edge_index.device)
+
+    def is_edge(self, v, w) -> bool:
+        """Whether the edge (v, w) exists (reference graph.py:447-462)."""
+        row = self.mapping.to_idx(v)
+        ptr = self.row_ptr
+        return bool((self.col[ptr[row]:ptr[row + 1]] == self.mapping.to_idx(w)).any())
+
+    def has_self_loops(self) -> bool:
+        ei = self.data.edge_index
+        return bool((ei[0] == ei[1]).any())
+
+    @property
+    def in_degrees(self) -> dict:
+        return self.degrees(mode="in")
+
+    @property
+    def out_degrees(self) -> dict:
+        return self.degrees(mode="out")
+
+    def sparse_adj_matrix(self, edge_attr=None):
+        """scipy ``coo_matrix`` adjacency matrix, optionally weighted by an edge attribute (reference graph.py:464-478)."""
+        from scipy.sparse import coo_matrix
+        ei = self.data.edge_index.cpu().numpy()
+        if edge_attr is None:
+            values = np.ones(ei.shape[1])
+        else:
+            values = self.data[edge_attr]
+            values = values.detach().cpu().numpy() if isinstance(values, torch.Tensor) else np.asarray(values)
+            values = values.reshape(-1)
+        return coo_matrix((values, (ei[0], ei[1])), shape=(self.n, self.n))
+
+    def laplacian(self, normalization=None, edge_attr: str | None = None):
+        """Graph Laplacian as a scipy ``coo_matrix`` with PyG's ``get_laplacian`` conventions (reference graph.py:535-560):
+        self loops removed, degrees = weighted out-degrees; ``None``: D - A, ``"sym"``: I - D^-1/2 A D^-1/2, ``"rw"``: I - D^-1 A."""
+        from scipy.sparse import coo_matrix
+        if normalization not in (None, "sym", "rw"):
+            raise ValueError(f"unknown normalization {normalization}")
+        ei = self.data.edge_index.cpu()
+        w = torch.ones(ei.size(1)) if edge_attr is None else self.data[edge_attr].detach().cpu().reshape(-1).to(torch.float32)
+        keep = ei[0] != ei[1]
+        ei, w = ei[:, keep], w[keep]
+        n = self.n
+        deg = torch.zeros(n, dtype=w.dtype).index_add_(0, ei[0], w)
+        loops = torch.arange(n).repeat(2, 1)
+        if normalization is None:
+            index, weight = torch.cat((ei, loops), dim=1), torch.cat((-w, deg))
+        else:
+            if normalization == "sym":
+                dis = deg.pow(-0.5)
+                dis[torch.isinf(dis)] = 0
+                a = dis[ei[0]] * w * dis[ei[1]]
+            else:
+                dinv = 1.0 / deg
+                dinv[torch.isinf(dinv)] = 0
+                a = dinv[ei[0]] * w
+            index, weight = torch.cat((ei, loops), dim=1), torch.cat((-a, torch.ones(n, dtype=a.dtype)))
+        return coo_matrix((weight.numpy(), (index[0].numpy(), index[1].numpy())), shape=(n, n))
+
+    # ------------------------------------------------------------------ derived graphs
+    def to_undirected(self) -> "Graph":
+        """Undirected version: every edge is added in the opposite direction and parallel edges are merged; edge attributes follow
+        the first original edge of each merged pair (reference graph.py:211-250, PyG ``to_undirected(reduce="min")``)."""
+        ei = self.data.edge_index
+        ids = torch.arange(ei.size(1), device=ei.device)
+        both = torch.cat((ei, ei.flip(0)), dim=1)
+        merged, attr_idx = _dispatch.coalesce(both, torch.cat((ids, ids)), self.n, "min")
+        data = Data(edge_index=merged, num_nodes=self.n)
+        for key in self.node_attrs():
+            data[key] = self.data[key]
+        for key in self.edge_attrs():
+            value = self.data[key]
+            data[key] = value[attr_idx.to(value.device)] if isinstance(value, torch.Tensor) else value[attr_idx.cpu().numpy()]
+        g = Graph(data, self.mapping, _row_sorted=True)
+        g.is_undirected_flag = True
+        g.data.edge_index.is_undirected = True            # what callers of the reference read from the EdgeIndex
+        return g
+
+    def to_weighted_graph(self) -> "Graph":
+        """Merge parallel edges into single edges with an ``edge_weight`` counting them (reference graph.py:252-271)."""
+        ei = self.data.edge_index
+        merged, weight = _dispatch.coalesce(ei, torch.ones(ei.size(1), device=ei.device), self.n, "sum")
+        return Graph(Data(edge_index=merged, edge_weight=weight, num_nodes=self.n), mapping=self.mapping, _row_sorted=True)
+
+    # ------------------------------------------------------------------ attribute access
+    def __getitem__(self, key):
+        """Graph attribute ``g["name"]``, node attribute ``g["node_x", node]`` or edge attribute ``g["edge_x", v, w]``
+        (reference graph.py:562-578)."""
+        if not isinstance(key, tuple):
+            if key in self.data.keys():
+                return self.data[key]
+            raise KeyError(key + " is not a graph attribute")
+        if key[0] in self.node_attrs():
+            return self.data[key[0]][self.mapping.to_idx(key[1])]
+        if key[0] in self.edge_attrs():
+            return self.data[key[0]][self.edge_to_index[self.mapping.to_idx(key[1]), self.mapping.to_idx(key[2])]]
+        raise KeyError(key[0] + " is not a node or edge attribute")
+
+    def __setitem__(self, key, val) -> None:
+        """Store a graph / node / edge attribute or one of its entries (reference graph.py:580-616)."""
+        if not isinstance(key, tuple):
+            if key.startswith("node_") and val.size(0) != self.n:
+                raise ValueError("Attribute must have same length as number of nodes")
+            if key.startswith("edge_") and val.size(0) != self.m:
+                raise ValueError("Attribute must have same length as number of edges")
+            self.data[key] = val
+        elif key[0].startswith("node_"):
+            if key[0] not in self.data.keys():
+                raise KeyError("Attribute does not yet exist. Setting the value of a specific node attribute requires that the attribute already exists.")
+            self.data[key[0]][self.mapping.to_idx(key[1])] = val
+        elif key[0].startswith("edge_"):
+            if key[0] not in self.data.keys():
+                raise KeyError("Attribute does not yet exist. Setting the value of a specific edge attribute requires that the attribute already exists.")
+            self.data[key[0]][self.edge_to_index[self.mapping.to_idx(key[1]), self.mapping.to_idx(key[2])]] = val
+        else:
+            raise KeyError("node and edge specific attributes should be prefixed with 'node_' or 'edge_'")
+
+    def __add__(self, other: "Graph", reduce: str = "sum") -> "Graph":
+        """Union of two graphs (reference graph.py:673-771): node IDs of both mappings are merged into a new sorted mapping, edges
+        and edge attributes are concatenated, node attributes of nodes present in both graphs are reduced with ``reduce``
+        (``sum``, ``mean``, ``mul``, ``min``, ``max``)."""
+        m1, m2 = self.mapping, other.mapping
+        ids1, ids2 = np.asarray(m1.to_ids(np.arange(self.n))), np.asarray(m2.to_ids(np.arange(other.n)))
+        nodes = np.concatenate([ids1, ids2])
+        mapping = IndexMap(np.unique(nodes, axis=0).tolist())
+        dev = self.data.edge_index.device
+
+        def remap_index(g: "Graph", index: torch.Tensor) -> torch.Tensor:
+            return mapping.to_idxs(np.asarray(g.mapping.to_ids(index.cpu())), device=dev)
+
+        data = Data(edge_index=torch.cat((remap_index(self, self.data.edge_index), remap_index(other, other.data.edge_index)), dim=1),
+                    num_nodes=mapping.num_ids(),
+                    node_sequence=torch.cat((self.data.node_sequence, other.data.node_sequence), dim=0))
+        if "inverse_idx" in self.data and "inverse_idx" in other.data:      # higher-order layers: instances -> merged node ids
+            data.inverse_idx = torch.cat((remap_index(self, self.data.inverse_idx), remap_index(other, other.data.inverse_idx)))
+        for key in self.edge_attrs():
+            if key in other.data:
+                a, b = self.data[key], other.data[key]
+                data[key] = torch.cat((a, b), dim=0) if isinstance(a, torch.Tensor) else np.concatenate((a, b))
+        target = mapping.to_idxs(nodes, device=dev)
+        for key in self.node_attrs():
+            if key not in other.data:
+                continue
+            a, b = self.data[key], other.data[key]
+            if not isinstance(a, torch.Tensor):
+                raise ValueError("Node attribute " + key + " is not a tensor and cannot be reduced.")
+            src = torch.cat((a, b), dim=0)
+            index = target.to(src.device).reshape((-1,) + (1,) * (src.dim() - 1)).expand_as(src)
+            mode = {"sum": "sum", "mean": "mean", "mul": "prod", "min": "amin", "max": "amax"}[reduce]
+            out = torch.zeros((mapping.num_ids(),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+            data[key] = out.scatter_reduce_(0, index, src, reduce=mode, include_self=False)
+        return Graph(data, mapping=mapping)
+
     def __str__(self) -> str:
         kind = "Directed" if self.is_directed() else "Undirected"
         return f"{kind} graph with {self.n} nodes and {self.m} edges (order {self.order})"

@@ -113,5 +113,58 @@ class TemporalGraph(Graph):
     def end_time(self):
         return self.data.time[-1].item() if self.data.time.numel() else None
 
+    def shuffle_time(self) -> None:
+        """Randomly permute the timestamps (reference temporal_graph.py:176-178); the events are re-sorted by their new times."""
+        data = self.data
+        data.time = data.time[torch.randperm(len(data.time), device=data.time.device)]
+        TemporalGraph.__init__(self, data, self.mapping)
+
+    def to_static_graph(self, weighted: bool = False, time_window=None) -> Graph:
+        """Time-aggregated static graph, optionally restricted to ``time_window = (start, end)`` and with multi-edges merged into
+        an ``edge_weight`` (reference temporal_graph.py:180-203)."""
+        edge_index = self.data.edge_index
+        if time_window is not None:
+            keep = (self.data.time >= time_window[0]) & (self.data.time < time_window[1])
+            edge_index = edge_index[:, keep]
+        n = int(edge_index.max().item()) + 1 if edge_index.numel() else 0
+        if weighted:
+            merged, weight = _dispatch.coalesce(edge_index, torch.ones(edge_index.size(1), device=edge_index.device), n, "sum")
+            return Graph(Data(edge_index=merged, edge_weight=weight, num_nodes=n), self.mapping, _row_sorted=True)
+        return Graph.from_edge_index(edge_index.contiguous(), self.mapping if self.mapping.num_ids() in (0, n) else None, num_nodes=n)
+
+    def to_undirected(self) -> "TemporalGraph":
+        """Every event is duplicated in the opposite direction with the same timestamp (reference temporal_graph.py:205-231;
+        like there, edge attributes are not carried over)."""
+        ei = self.data.edge_index
+        return TemporalGraph(Data(edge_index=torch.cat((ei, ei.flip(0)), dim=1), time=torch.cat((self.data.time, self.data.time)),
+                                  num_nodes=self.n), mapping=self.mapping)
+
+    def _subset(self, selector) -> "TemporalGraph":
+        data = Data(edge_index=self.data.edge_index[:, selector], time=self.data.time[selector], num_nodes=self.n)
+        for key in self.node_attrs():
+            data[key] = self.data[key]
+        for key in self.edge_attrs():
+            value = self.data[key]
+            if isinstance(value, torch.Tensor) or isinstance(selector, slice):
+                data[key] = value[selector]
+            else:
+                data[key] = value[selector.cpu().numpy()]
+        return TemporalGraph(data, mapping=self.mapping)
+
+    def get_batch(self, start_idx: int, end_idx: int) -> "TemporalGraph":
+        """Events ``start_idx .. end_idx - 1`` of the time-ordered stream, with their edge attributes (reference :233-264)."""
+        return self._subset(slice(start_idx, end_idx))
+
+    def get_window(self, start_time, end_time) -> "TemporalGraph":
+        """Events with ``start_time <= t < end_time``, with their edge attributes (reference temporal_graph.py:266-298)."""
+        return self._subset((self.data.time >= start_time) & (self.data.time < end_time))
+
+    def __getitem__(self, key):
+        """As :meth:`Graph.__getitem__`; edge attributes also accept ``(name, v, w, t)`` for one time-stamped edge (reference
+        temporal_graph.py:300-324)."""
+        if isinstance(key, tuple) and key[0] in self.edge_attrs() and len(key) == 4:
+            return self.data[key[0]][self.tedge_to_index[self.mapping.to_idx(key[1]), self.mapping.to_idx(key[2]), key[3]]]
+        return Graph.__getitem__(self, key)
+
     def __str__(self) -> str:
         return f"Temporal Graph with {self.n} nodes and {self.data.num_edges} events in [{self.start_time}, {self.end_time}]"
