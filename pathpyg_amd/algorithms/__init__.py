@@ -11,3 +11,5 @@ from .temporal import (  # noqa: F401
     temporal_closeness_centrality,
     temporal_shortest_paths,
 )
+
+from . import centrality  # noqa: E402,F401
