@@ -13,3 +13,4 @@ from .temporal import (  # noqa: F401
 )
 
 from . import centrality  # noqa: E402,F401
+from .rolling_time_window import RollingTimeWindow  # noqa: E402,F401

@@ -130,7 +130,7 @@ class TemporalGraph(Graph):
         if weighted:
             merged, weight = _dispatch.coalesce(edge_index, torch.ones(edge_index.size(1), device=edge_index.device), n, "sum")
             return Graph(Data(edge_index=merged, edge_weight=weight, num_nodes=n), self.mapping, _row_sorted=True)
-        return Graph.from_edge_index(edge_index.contiguous(), self.mapping if self.mapping.num_ids() in (0, n) else None, num_nodes=n)
+        return Graph(Data(edge_index=edge_index.contiguous(), num_nodes=n), self.mapping)
 
     def to_undirected(self) -> "TemporalGraph":
         """Every event is duplicated in the opposite direction with the same timestamp (reference temporal_graph.py:205-231;
