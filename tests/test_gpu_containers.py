@@ -178,3 +178,61 @@ def test_rolling_time_window(pp, long_temporal_graph):
     assert [(g.n, g.m) for g in snapshots] == [(5, 4), (7, 3), (8, 6), (8, 3), (9, 4)]
     g, window = next(iter(pp.algorithms.RollingTimeWindow(long_temporal_graph, 10, 10, return_window=True, weighted=False)))
     assert window == (1, 11) and g.m == 4
+
+
+def test_static_graph_dataframe_io(pp, simple_graph, tmp_path):
+    """tests/io/test_pandas.py:174-298,365-420: df_to_graph, add_node/edge_attributes, graph_to_df, csv round trip."""
+    import pandas as pd
+    io = pp.io
+    g = io.df_to_graph(pd.DataFrame({"v": ["a", "b", "c"], "w": ["b", "c", "a"], "edge_weight": [2.0, 1.0, 42.0]}))
+    assert (g.n, g.m) == (3, 3) and "edge_weight" in g.edge_attrs()
+    assert g.data.edge_weight.tolist() == [2.0, 1.0, 42.0]
+    g = io.df_to_graph(pd.DataFrame([["a", "b", 2.0], ["b", "c", 1.0], ["c", "a", 42.0]]))
+    assert g.data.edge_attr_0.tolist() == [2.0, 1.0, 42.0]
+    multi = pd.DataFrame({"v": ["a", "b", "c", "a"], "w": ["b", "c", "a", "b"], "edge_weight": [2.0, 1.0, 42.0, 3.0]})
+    assert io.df_to_graph(multi, multiedges=False).m == 3 and io.df_to_graph(multi, multiedges=True).m == 4
+    g = io.df_to_graph(pd.DataFrame({"v": ["a", "b", "c"], "w": ["b", "c", "a"], "edge_weight": ["a", "b", "c"]}), is_undirected=True)
+    assert (g.n, g.m) == (3, 3) and g.is_undirected()
+
+    io.add_node_attributes(pd.DataFrame({"v": ["b", "a", "c"], "x": [2, 1, 3], "node_y": [0.2, 0.1, 0.3]}), simple_graph)
+    assert simple_graph.data["node_x"].tolist() == [1, 2, 3]
+    assert torch.allclose(simple_graph.data["node_y"].cpu(), torch.tensor([0.1, 0.2, 0.3], dtype=torch.double))
+    io.add_node_attributes(pd.DataFrame({"index": [1, 0, 2], "z": [20, 10, 30]}), simple_graph)
+    assert simple_graph.data["node_z"].tolist() == [10, 20, 30]
+    with pytest.raises(ValueError, match="multiple attribute values for single node"):
+        io.add_node_attributes(pd.DataFrame({"v": ["a", "a", "b", "c"], "x": [1, 2, 3, 4]}), simple_graph)
+    with pytest.raises(ValueError, match="Mismatch between nodes"):
+        io.add_node_attributes(pd.DataFrame({"v": ["a", "b", "d"], "x": [1, 2, 3]}), simple_graph)
+    with pytest.raises(ValueError, match="must either have `index` or `v` column"):
+        io.add_node_attributes(pd.DataFrame({"foo": [1, 2, 3]}), simple_graph)
+
+    io.add_edge_attributes(pd.DataFrame({"v": ["a", "b", "a"], "w": ["b", "c", "c"], "weight": [1, 3, 2]}), simple_graph)
+    assert simple_graph.data["edge_weight"].tolist() == [1, 2, 3]
+    io.add_edge_attributes(pd.DataFrame({"v": ["a", "b", "a"], "w": ["b", "c", "c"], "edge_score": [5, 6, 7]}), simple_graph)
+    assert simple_graph.data["edge_score"].tolist() == [5, 7, 6]
+    with pytest.raises(ValueError, match="Please ensure all nodes in the DataFrame are present in the graph."):
+        io.add_edge_attributes(pd.DataFrame({"v": ["a", "x", "a"], "w": ["b", "c", "c"], "weight": [1.0, 2.0, 3.0]}), simple_graph)
+    with pytest.raises(ValueError, match="does not exist in the graph"):
+        io.add_edge_attributes(pd.DataFrame({"v": ["a", "b", "a"], "w": ["a", "c", "c"], "weight": [1.0, 2.0, 3.0]}), simple_graph)
+    tg = pp.TemporalGraph.from_edge_list([("a", "b", 1), ("b", "c", 5), ("c", "d", 9), ("c", "e", 9)])
+    io.add_edge_attributes(pd.DataFrame({"v": ["a", "b", "c", "c"], "w": ["b", "c", "e", "d"], "t": [1, 5, 9, 9], "weight": [1, 2, 4, 3]}),
+                           tg, time_attr="t")
+    assert tg.data["edge_weight"].tolist() == [1, 2, 3, 4]
+    with pytest.raises(ValueError, match="Please ensure the DataFrame matches the number of edges in the graph"):
+        io.add_edge_attributes(pd.DataFrame({"v": ["a"], "w": ["b"], "t": [99], "weight": [1.0]}), tg, time_attr="t")
+    with pytest.raises(ValueError, match="does not exist at time"):
+        io.add_edge_attributes(pd.DataFrame({"v": ["a", "b", "c", "c"], "w": ["b", "c", "d", "e"], "t": [1, 5, 9, 10],
+                                             "weight": [1.0, 2.0, 3.0, 4.0]}), tg, time_attr="t")
+
+    plain = pp.Graph.from_edge_list([("a", "b"), ("b", "c"), ("a", "c")])
+    df = io.graph_to_df(plain)
+    assert set(df.columns) == {"v", "w"} and len(df) == 3 and set(df["v"]) == {"a", "b"} and set(df["w"]) == {"b", "c"}
+    plain.data.edge_weight = torch.tensor([1.0, 2.0, 3.0])
+    plain.data.edge_label = torch.tensor([0, 1, 2])
+    df = io.graph_to_df(plain)
+    assert list(df["edge_weight"]) == [1.0, 2.0, 3.0] and list(df["edge_label"]) == [0, 1, 2]
+    assert set(io.graph_to_df(plain, node_indices=True)["v"]) == {0, 1}
+    path = tmp_path / "graph.csv"
+    io.write_csv(plain, path_or_buf=str(path))
+    back = io.read_csv_graph(str(path))
+    assert (back.n, back.m) == (3, 3) and back.data.edge_weight.tolist() == [1.0, 2.0, 3.0]
