@@ -145,6 +145,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
         f32x4 out[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) out[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(3);                    // a wave in its MFMA burst goes first: it frees the matrix pipe sooner (-2 %)
 #pragma unroll
         for (int c = 0; c < KQ / 4; ++c) {
             const float av[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
                 for (int ct = 0; ct < CT; ++ct) out[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[ct], out[ct], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_wave_barrier();
         float* yp = Y + (t * 16 + 4 * kq) * Q + i;
         const int rows_here = n_rows - (t * 16 + 4 * kq) < 4 ? (int)(n_rows - (t * 16 + 4 * kq)) : 4;
