@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_v4(const int32_t* __restrict__ 
             float4 o = acc[q];
             o.x += self_c[q] * self_row[q].x + b.x; o.y += self_c[q] * self_row[q].y + b.y;
             o.z += self_c[q] * self_row[q].z + b.z; o.w += self_c[q] * self_row[q].w + b.w;
-            if (act) { o.x = elu_fast(o.x); o.y = elu_fast(o.y); o.z = elu_fast(o.z); o.w = elu_fast(o.w); }
+            if (act) o = elu_fast4(o);
             *(float4*)(Y + (r0 + q) * F + c0) = o;
         }
     }

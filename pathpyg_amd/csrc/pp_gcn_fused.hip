@@ -51,13 +51,27 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
     const char* xb = (const char*)X;
     const int64_t n_tiles = (n_rows + 15) / 16;
     const int64_t step = (int64_t)gridDim.x * kGcnWaves;
+    int p_next[kRows + 1];                              // row pointers of the wave's NEXT tile: one round trip off the critical path
+    {
+        const int64_t t0 = (int64_t)blockIdx.x * kGcnWaves + wave;
+#pragma unroll
+        for (int q = 0; q <= kRows; ++q) {
+            const int64_t r = t0 * 16 + g * kRows + q;
+            p_next[q] = t0 < n_tiles ? ptr[r < n_rows ? r : n_rows] : 0;
+        }
+    }
     for (int64_t t = (int64_t)blockIdx.x * kGcnWaves + wave; t < n_tiles; t += step) {
         const int64_t r0 = t * 16 + g * kRows;
         int p[kRows + 1];
 #pragma unroll
-        for (int q = 0; q <= kRows; ++q) {
-            const int64_t r = r0 + q < n_rows ? r0 + q : n_rows;
-            p[q] = ptr[r];
+        for (int q = 0; q <= kRows; ++q) p[q] = p_next[q];
+        {
+            const int64_t tn = t + step;
+#pragma unroll
+            for (int q = 0; q <= kRows; ++q) {
+                const int64_t r = tn * 16 + g * kRows + q;
+                p_next[q] = tn < n_tiles ? ptr[r < n_rows ? r : n_rows] : 0;
+            }
         }
         int cj[kRows], pe[kRows], hs[kRows];
         float cv[kRows], sc[kRows];
@@ -166,10 +180,11 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float v = out[ct][reg] + bias_c[ct];
-                const float y = act ? elu_fast(v) : v;
-                if (reg < rows_here) yp[reg * Q + ct * 16] = y;
+            for (int reg = 0; reg < 4; reg += 2) {
+                pp_f32x2 y = {out[ct][reg] + bias_c[ct], out[ct][reg + 1] + bias_c[ct]};
+                if (act) y = elu_fast2(y);
+                if (reg < rows_here) yp[reg * Q + ct * 16] = y[0];
+                if (reg + 1 < rows_here) yp[(reg + 1) * Q + ct * 16] = y[1];
             }
     }
 }
