@@ -383,6 +383,7 @@ def main() -> int:
             "dbgnn_step_ms": ms_step - lift,
             "dbgnn_steps_per_s": 1e3 / max(ms_step - lift, 1e-9),
             "loss": float(loss.detach()),
+            "peak_hbm_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
             "roofline": {"bound": "hbm", "kernel": dominant[0], "launches": dominant[1],
                          "avg_launch_ms": dominant[2] / max(dominant[1], 1), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
