@@ -244,8 +244,8 @@ int pp_dense_backward_f32(const float* dH, const float* X, const float* W, int64
 /* A whole GCNConv layer (dbgnn.py:131-140) in one kernel, re-associated as (A_hat X) W^T so that the transformed matrix never
  * makes a round trip through HBM:
  *   Y[r, :Q] = act( (sum_e val[e] X[idx[e], :P] + self_coef[r] X[r, :P]) . W^T + bias ),   W is [Q,P] (Linear layout), act 0/1 (ELU)
- * over the destination-major CSR of a pp_gcn_plan (self_coef may be NULL: no self term); X has n_src rows and must stay below
- * 4 GiB (rows are addressed by 32-bit byte offsets; PP_ERR_TOO_LARGE otherwise).  P, Q in {16,32,64}.
+ * over the destination-major CSR of a pp_gcn_plan (self_coef may be NULL: no self term); X has n_src rows (rows are addressed by
+ * 32-bit byte offsets below 4 GiB, by 64-bit ones above).  P, Q in {16,32,64}.
  * agg_out [n_rows,P] or NULL: also store the aggregated input A_hat X; the weight gradient of a layer whose input needs no
  * gradient is then dW = dpre^T agg_out (pp_weight_grad_f32) without any backward aggregation. */
 int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
@@ -255,7 +255,7 @@ int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val,
 /* Backward of that layer in one kernel (pp_spmm_f32 over the source-major CSR + pp_dense_backward_f32 without the round trip of the
  * aggregated gradient through HBM):  G = A^T D + diag(self_coef) D with D = dpre [n_rows,M];
  *   d_in[n_rows,K] = (G . W) (*) ELU'(X) when fuse_act (X [n_rows,K] is then the stored activation of the layer below),
- *   colsum_in[K] (may be NULL) = column sums of d_in,  dW[M,K] = G^T X.   W is [M,K]; M, K in {16,32,64}; D below 4 GiB. */
+ *   colsum_in[K] (may be NULL) = column sums of d_in,  dW[M,K] = G^T X.   W is [M,K]; M, K in {16,32,64}. */
 size_t pp_gcn_backward_ws_bytes(int64_t n_rows);
 int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
                         const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,

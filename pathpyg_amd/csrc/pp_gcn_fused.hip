@@ -6,6 +6,8 @@
 // through HBM (write N*Q, gather it back).  (A_hat X) W^T is the same product re-associated: a wave aggregates a tile of 16
 // destination rows straight from X into LDS and multiplies the tile by W on v_mfma_f32_16x16x4_f32, so the only N-sized
 // traffic left is the gather itself and the store of Y.  W (<= 64x64 fp32) sits in LDS for the whole persistent workgroup.
+#include <type_traits>
+
 #include "pp_common.h"
 #include "pp_internal.h"
 
@@ -26,7 +28,7 @@ constexpr int kGcnWaves = kGcnThreads / kWave;
 // tiles' pointers, chunks and rows; 2 waves/SIMD) and a producer/consumer split (12 gather waves + 4 MFMA waves through an LDS
 // ring) both land on the same 2.0 ms: the kernel moves ~10 GB per launch through L2 at the ~5 TB/s this chip sustains for
 // 256-byte random rows, as do pp_dense_f32 + pp_spmm_f32 with their 12.6 GB in 2.4 ms.
-template <int P, int Q, bool kHeavy>      // kHeavy: the plan has hub rows (heavy.slot != nullptr); the common case pays nothing
+template <int P, int Q, bool kHeavy, bool kWide>   // kHeavy: the plan has hub rows; kWide: X is 4 GiB or larger (64-bit row offsets)
 __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                                  const float* __restrict__ val, int64_t n_rows, const float* __restrict__ X,
                                                                  const float* __restrict__ self_coef, const float* __restrict__ W,
@@ -34,6 +36,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
                                                                  float* __restrict__ agg_out, float* __restrict__ Y) {
     constexpr int kLanes = P / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = P / 4, CT = Q / 16, TS = P + 4;
     constexpr int kBatch = kRows < 2 ? kRows : 2;
+    using off_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;     // byte offset of a gathered row
     __shared__ __attribute__((aligned(16))) float s_b[P * 16 * CT];
     __shared__ __attribute__((aligned(16))) float s_tile[kGcnWaves][16 * TS];
     for (int e = threadIdx.x; e < P * Q; e += kGcnThreads) {
@@ -87,18 +90,18 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
         }
 #pragma unroll
         for (int b0 = 0; b0 < kRows; b0 += kBatch) {
-            uint32_t off[kBatch][kFirst], self_off[kBatch];
+            off_t off[kBatch][kFirst], self_off[kBatch];
 #pragma unroll
             for (int qq = 0; qq < kBatch; ++qq) {
                 const int q = b0 + qq;
                 const bool self_here = self_coef != nullptr && r0 + q < n_rows;
                 const int first = __shfl(cj[q], 0, kLanes);
                 const int dummy = p[q] < pe[q] ? first : (self_here ? (int)(r0 + q) : 0);
-                self_off[qq] = (uint32_t)(self_here ? (int)(r0 + q) : dummy) * (uint32_t)(P * 4) + (uint32_t)(16 * l);
+                self_off[qq] = (off_t)(uint32_t)(self_here ? (int)(r0 + q) : dummy) * (off_t)(P * 4) + (off_t)(16 * l);
 #pragma unroll
                 for (int u = 0; u < kFirst; ++u) {
                     const int j = u == 0 ? first : __shfl(cj[q], u, kLanes);
-                    off[qq][u] = (uint32_t)(p[q] + u < pe[q] ? j : dummy) * (uint32_t)(P * 4) + (uint32_t)(16 * l);
+                    off[qq][u] = (off_t)(uint32_t)(p[q] + u < pe[q] ? j : dummy) * (off_t)(P * 4) + (off_t)(16 * l);
                 }
             }
             float4 x[kBatch][kFirst], sr[kBatch];
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
                             const int src_lane = (e + u) < cnt ? e + u : e;
                             const int j = __shfl(my_j, src_lane, kLanes);
                             v[u] = (e + u) < cnt ? __shfl(my_v, src_lane, kLanes) : 0.f;
-                            y[u] = *(const float4*)(xb + (uint32_t)j * (uint32_t)(P * 4) + (uint32_t)(16 * l));
+                            y[u] = *(const float4*)(xb + (off_t)(uint32_t)j * (off_t)(P * 4) + (off_t)(16 * l));
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -192,13 +195,14 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
 // Persistent grid = exactly the workgroups that are resident at once (registers and LDS decide; asked from the runtime once).
 template <int P, int Q>
 static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                              const float* X, const float* self_coef, const float* W, const float* bias, int act, HeavyRows heavy, float* agg_out, float* Y) {
+                              const float* X, const float* self_coef, const float* W, const float* bias, int act, HeavyRows heavy, bool wide,
+                              float* agg_out, float* Y) {
     static int resident_of[2] = {0, 0};
     const int hv = heavy.slot != nullptr ? 1 : 0;
     if (resident_of[hv] == 0) {
         int per_cu = 0, dev = 0, cus = 0;
-        if (hv) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q, true>, kGcnThreads, 0));
-        else PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q, false>, kGcnThreads, 0));
+        if (hv) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q, true, false>, kGcnThreads, 0));
+        else PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q, false, false>, kGcnThreads, 0));
         PP_HIP(hipGetDevice(&dev));
         PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         resident_of[hv] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
@@ -206,21 +210,21 @@ static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const int32_t* pt
     const int resident = resident_of[hv];
     int64_t blocks = ceil_div(n_tiles, kGcnWaves);
     if (blocks > resident) blocks = resident;
-    if (heavy.slot != nullptr)
-        k_gcn_forward<P, Q, true><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y);
-    else
-        k_gcn_forward<P, Q, false><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y);
+#define PP_FWD(H, WIDE) k_gcn_forward<P, Q, H, WIDE><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y)
+    if (heavy.slot != nullptr) { if (wide) PP_FWD(true, true); else PP_FWD(true, false); }
+    else { if (wide) PP_FWD(false, true); else PP_FWD(false, false); }
+#undef PP_FWD
     return PP_OK;
 }
 
 template <int P>
 static int launch_gcn_forward_q(int Q, int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                                const float* X, const float* self_coef, const float* W, const float* bias, int act, HeavyRows heavy, float* agg_out,
-                                float* Y) {
+                                const float* X, const float* self_coef, const float* W, const float* bias, int act, HeavyRows heavy, bool wide,
+                                float* agg_out, float* Y) {
     switch (Q) {
-        case 16: return launch_gcn_forward<P, 16>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y);
-        case 32: return launch_gcn_forward<P, 32>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y);
-        case 64: return launch_gcn_forward<P, 64>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y);
+        case 16: return launch_gcn_forward<P, 16>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, wide, agg_out, Y);
+        case 32: return launch_gcn_forward<P, 32>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, wide, agg_out, Y);
+        case 64: return launch_gcn_forward<P, 64>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, wide, agg_out, Y);
         default: return PP_ERR_ARG;
     }
 }
@@ -231,7 +235,7 @@ static int launch_gcn_forward_q(int Q, int64_t n_tiles, hipStream_t st, const in
 //     d_in   = (G . W) (*) ELU'(x),  colsum_in = column sums    gradient w.r.t. the PRE-activation of the layer below + its bias gradient
 //     dW     = G^T x                                             contraction over the tile's rows on a second MFMA stream
 // Saves the write and the re-read of G (2 of the 7 N x 64 matrix passes of the two-kernel form).
-template <int M, int K, bool kHeavy>
+template <int M, int K, bool kHeavy, bool kWide>
 __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                              const float* __restrict__ val, int64_t n_rows, const float* __restrict__ D,
                                                              const float* __restrict__ self_coef, const float* __restrict__ X,
@@ -239,6 +243,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
                                                              float* __restrict__ colsum_in, float* __restrict__ partial_w) {
     constexpr int kLanes = M / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = M / 4, MT = M / 16, CT = K / 16, TS = M + 4;
     constexpr int kBatch = kRows < 2 ? kRows : 2;
+    using off_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;     // byte offset of a gathered row
     __shared__ __attribute__((aligned(16))) float s_b[M * 16 * CT];          // [k][i][ct] = W[k][ct*16 + i]
     __shared__ __attribute__((aligned(16))) float s_tile[kGcnWaves][16 * TS];
     __shared__ float s_fold[64 * 64];
@@ -293,18 +298,18 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
         }
 #pragma unroll
         for (int b0 = 0; b0 < kRows; b0 += kBatch) {
-            uint32_t off[kBatch][kFirst], self_off[kBatch];
+            off_t off[kBatch][kFirst], self_off[kBatch];
 #pragma unroll
             for (int qq = 0; qq < kBatch; ++qq) {
                 const int q = b0 + qq;
                 const bool self_here = self_coef != nullptr && r0 + q < n_rows;
                 const int first = __shfl(cj[q], 0, kLanes);
                 const int dummy = p[q] < pe[q] ? first : (self_here ? (int)(r0 + q) : 0);
-                self_off[qq] = (uint32_t)(self_here ? (int)(r0 + q) : dummy) * (uint32_t)(M * 4) + (uint32_t)(16 * l);
+                self_off[qq] = (off_t)(uint32_t)(self_here ? (int)(r0 + q) : dummy) * (off_t)(M * 4) + (off_t)(16 * l);
 #pragma unroll
                 for (int u = 0; u < kFirst; ++u) {
                     const int j = u == 0 ? first : __shfl(cj[q], u, kLanes);
-                    off[qq][u] = (uint32_t)(p[q] + u < pe[q] ? j : dummy) * (uint32_t)(M * 4) + (uint32_t)(16 * l);
+                    off[qq][u] = (off_t)(uint32_t)(p[q] + u < pe[q] ? j : dummy) * (off_t)(M * 4) + (off_t)(16 * l);
                 }
             }
             float4 x[kBatch][kFirst], sr[kBatch];
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
                             const int src_lane = (e + u) < cnt ? e + u : e;
                             const int j = __shfl(my_j, src_lane, kLanes);
                             v[u] = (e + u) < cnt ? __shfl(my_v, src_lane, kLanes) : 0.f;
-                            y[u] = *(const float4*)(db + (uint32_t)j * (uint32_t)(M * 4) + (uint32_t)(16 * l));
+                            y[u] = *(const float4*)(db + (off_t)(uint32_t)j * (off_t)(M * 4) + (off_t)(16 * l));
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -436,14 +441,14 @@ constexpr int64_t kGcnBackwardMaxBlocks = 256 * 4;
 
 template <int M, int K>
 static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                               const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy,
+                               const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy, bool wide,
                                float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out) {
     static int resident_of[2] = {0, 0};
     const int hv = heavy.slot != nullptr ? 1 : 0;
     if (resident_of[hv] == 0) {
         int per_cu = 0, dev = 0, cus = 0;
-        if (hv) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K, true>, kGcnThreads, 0));
-        else PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K, false>, kGcnThreads, 0));
+        if (hv) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K, true, false>, kGcnThreads, 0));
+        else PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K, false, false>, kGcnThreads, 0));
         PP_HIP(hipGetDevice(&dev));
         PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         resident_of[hv] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
@@ -453,21 +458,21 @@ static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* p
     int64_t blocks = ceil_div(n_tiles, kGcnWaves);
     if (blocks > resident) blocks = resident;
     *blocks_out = blocks;
-    if (heavy.slot != nullptr)
-        k_gcn_backward<M, K, true><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w);
-    else
-        k_gcn_backward<M, K, false><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w);
+#define PP_BWD(H, WIDE) k_gcn_backward<M, K, H, WIDE><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w)
+    if (heavy.slot != nullptr) { if (wide) PP_BWD(true, true); else PP_BWD(true, false); }
+    else { if (wide) PP_BWD(false, true); else PP_BWD(false, false); }
+#undef PP_BWD
     return PP_OK;
 }
 
 template <int M>
 static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                                 const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy,
+                                 const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy, bool wide,
                                  float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out) {
     switch (K) {
-        case 16: return launch_gcn_backward<M, 16>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w, blocks_out);
-        case 32: return launch_gcn_backward<M, 32>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w, blocks_out);
-        case 64: return launch_gcn_backward<M, 64>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w, blocks_out);
+        case 16: return launch_gcn_backward<M, 16>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out);
+        case 32: return launch_gcn_backward<M, 32>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out);
+        case 64: return launch_gcn_backward<M, 64>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out);
         default: return PP_ERR_ARG;
     }
 }
@@ -484,16 +489,16 @@ int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val,
     PP_REQUIRE(pp_dense_supported(P, Q), PP_ERR_ARG, "pp_gcn_forward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", P, Q);
     PP_REQUIRE(act == 0 || act == 1, PP_ERR_ARG, "pp_gcn_forward_f32: act must be 0 (none) or 1 (elu)");
     PP_REQUIRE(((uintptr_t)X | (uintptr_t)agg_out) % 16 == 0, PP_ERR_ARG, "pp_gcn_forward_f32: X and agg_out must be 16-byte aligned");
-    PP_REQUIRE(n_src >= 0 && (uint64_t)n_src * (uint64_t)P * 4 <= 0xffffffffull, PP_ERR_TOO_LARGE,
-               "pp_gcn_forward_f32: X must be smaller than 4 GiB (use pp_dense_f32 + pp_spmm_f32)");
+    PP_REQUIRE(n_src >= 0 && n_src < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_forward_f32: more than 2^31 source rows");
+    const bool wide = (uint64_t)n_src * (uint64_t)P * 4 > 0xffffffffull;          // 64-bit row offsets from 4 GiB on
     if (n_rows == 0) return PP_OK;
     const int64_t n_tiles = pp::ceil_div(n_rows, 16);
     const pp::HeavyRows heavy{heavy_slot, heavy_sum};
     int rc;
     switch (P) {
-        case 16: rc = pp::launch_gcn_forward_q<16>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, agg_out, Y); break;
-        case 32: rc = pp::launch_gcn_forward_q<32>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, agg_out, Y); break;
-        default: rc = pp::launch_gcn_forward_q<64>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, agg_out, Y); break;
+        case 16: rc = pp::launch_gcn_forward_q<16>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, wide, agg_out, Y); break;
+        case 32: rc = pp::launch_gcn_forward_q<32>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, wide, agg_out, Y); break;
+        default: rc = pp::launch_gcn_forward_q<64>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, wide, agg_out, Y); break;
     }
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();
@@ -514,8 +519,7 @@ int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val
     PP_REQUIRE(pp_dense_supported(M, K), PP_ERR_ARG, "pp_gcn_backward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", M, K);
     PP_REQUIRE(d_in != nullptr && dW != nullptr, PP_ERR_ARG, "pp_gcn_backward_f32: d_in and dW are required");
     PP_REQUIRE(((uintptr_t)D) % 16 == 0, PP_ERR_ARG, "pp_gcn_backward_f32: D must be 16-byte aligned");
-    PP_REQUIRE((uint64_t)n_rows * (uint64_t)M * 4 <= 0xffffffffull, PP_ERR_TOO_LARGE,
-               "pp_gcn_backward_f32: D must be smaller than 4 GiB (use pp_spmm_f32 + pp_dense_backward_f32)");
+    const bool wide = (uint64_t)n_rows * (uint64_t)M * 4 > 0xffffffffull;         // 64-bit row offsets from 4 GiB on
     PP_REQUIRE(ws_bytes >= pp_gcn_backward_ws_bytes(n_rows), PP_ERR_WORKSPACE, "pp_gcn_backward_f32: workspace too small");
     if (colsum_in) PP_HIP(hipMemsetAsync(colsum_in, 0, (size_t)K * sizeof(float), st));
     if (n_rows == 0) {
@@ -527,9 +531,9 @@ int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val
     int64_t blocks = 0;
     int rc;
     switch (M) {
-        case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, (float*)ws, &blocks); break;
-        case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, (float*)ws, &blocks); break;
-        default: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, (float*)ws, &blocks); break;
+        case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks); break;
+        case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks); break;
+        default: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks); break;
     }
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();

@@ -134,3 +134,37 @@ def test_config2_20m_scale_free_lift_properties(pp):
             key = key * n + ns[:, c]
         assert bool((key[1:] > key[:-1]).all())                         # unique rows in lexicographic order
     del ol
+
+
+def test_fused_gcn_kernels_with_matrices_beyond_4_gib(pp):
+    """1.7*10^7 rows x 64 floats = 4.35 GB per matrix: the fused layer kernels switch to 64-bit row offsets.  Checked against the
+    two-kernel path (pp_dense_f32 + pp_spmm_f32 / pp_spmm_f32 + pp_dense_backward_f32), whose addressing is 64-bit throughout; the
+    LAST rows (beyond the 4 GiB mark) are compared explicitly."""
+    from pathpyg_amd import _hip
+    n, f, e = 17_000_000, 64, 20_000_000
+    g = torch.Generator(device=DEV).manual_seed(5)
+    dst = torch.sort(torch.randint(0, n, (e,), generator=g, device=DEV)).values
+    ptr = torch.zeros(n + 1, dtype=torch.int32, device=DEV)
+    ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n), 0).to(torch.int32)
+    del dst
+    idx = torch.randint(0, n, (e,), generator=g, device=DEV, dtype=torch.int32)
+    idx[-1000:] = torch.randint(n - 1000, n, (1000,), generator=g, device=DEV, dtype=torch.int32)      # gathers from beyond 4 GiB
+    val = torch.rand(e, generator=g, device=DEV)
+    sc = torch.rand(n, generator=g, device=DEV)
+    x = torch.randn(n, f, generator=g, device=DEV)
+    w = torch.randn(f, f, generator=g, device=DEV) / 8
+    b = torch.randn(f, generator=g, device=DEV)
+    fused = _hip.gcn_forward(ptr, idx, val, n, x, sc, w, b, True)
+    split = _hip.spmm(ptr, idx, val, n, _hip.dense(x, w, True)[0], sc, None, b, True)
+    for rows in (slice(0, 100_000), slice(n - 100_000, n)):
+        torch.testing.assert_close(fused[rows], split[rows], rtol=1e-4, atol=1e-4)
+    assert float((fused - split).abs().max()) < 1e-3
+    del split
+    dpre = torch.randn(n, f, generator=g, device=DEV)
+    d_in, colsum, dw = _hip.gcn_backward(ptr, idx, val, n, dpre, sc, fused, w, True, True)
+    gsum = _hip.spmm(ptr, idx, val, n, dpre, sc, dpre)
+    want_in, want_sum, want_dw, _ = _hip.dense_backward(gsum, fused, w, True, True, True, False)
+    for rows in (slice(0, 100_000), slice(n - 100_000, n)):
+        torch.testing.assert_close(d_in[rows], want_in[rows], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dw, want_dw, rtol=1e-3, atol=1e-3 * float(want_dw.abs().max()))
+    torch.testing.assert_close(colsum, want_sum, rtol=1e-3, atol=1e-3 * float(want_sum.abs().max()))
