@@ -96,7 +96,9 @@ int pp_temporal_fill(int64_t m, int64_t num_nodes, int64_t total, int64_t id_off
 /* lift_order_edge_index(edge_index, num_nodes) -> [2,E'] int64, src/pathpyG/algorithms/lift_order.py:48-79.
  * edge_index must be grouped by source like the reference demands (:52,55). */
 size_t pp_linegraph_ws_bytes(int64_t n_edges, int64_t num_nodes);
-int pp_linegraph_count(const int64_t* edge_index, int64_t n_edges, int64_t num_nodes, void* ws, size_t ws_bytes, pp_stream_t stream);
+int pp_linegraph_count(const int64_t* edge_index, int64_t n_edges, int64_t e_begin, int64_t e_end, int64_t num_nodes, void* ws,
+                       size_t ws_bytes, pp_stream_t stream);   /* [e_begin, e_end): the source edges of this call (edge-range shard);
+                                                                 out-degrees / row pointers always come from all n_edges edges */
 int pp_linegraph_fill(int64_t n_edges, int64_t num_nodes, int64_t total, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream);
 const int64_t* pp_lift_result_ptr(void* ws); /* device pointer to {size, status} */
 

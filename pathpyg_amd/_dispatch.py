@@ -60,10 +60,10 @@ def temporal_betweenness(edge_index, time, num_nodes: int, delta):
     return _hip.temporal_betweenness(ei, num_nodes, event_graph)
 
 
-def linegraph_lift(edge_index, num_nodes: int):
+def linegraph_lift(edge_index, num_nodes: int, edge_range=None):
     dev = compute_device(edge_index)
     (ei,) = _stage(dev, edge_index)
-    return _back(edge_index, _hip.linegraph_lift(ei, num_nodes))
+    return _back(edge_index, _hip.linegraph_lift(ei, num_nodes, edge_range))
 
 
 def edge_attr(edge_index, attr, aggr: str):

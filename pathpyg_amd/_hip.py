@@ -169,14 +169,17 @@ def temporal_lift(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, 
     return out
 
 
-def linegraph_lift(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+def linegraph_lift(edge_index: torch.Tensor, num_nodes: int, edge_range: tuple[int, int] | None = None) -> torch.Tensor:
+    """Line-graph lift of a source-sorted edge list; ``edge_range = (lo, hi)``: edge-range shard — only the edges ``lo .. hi-1`` are
+    sources (the block of the global result that starts at the first pair of edge ``lo``), ids stay global."""
     ei = _edge_index(edge_index)
     dev = require_device(ei)
     e = ei.size(1)
+    lo, hi = (0, e) if edge_range is None else edge_range
     L = lib()
     with torch.cuda.device(dev):
         ws = _workspace(L.pp_linegraph_ws_bytes(e, num_nodes), dev)
-        check(L.pp_linegraph_count(_p(ei), e, num_nodes, _p(ws), ws.numel(), _stream()), "pp_linegraph_count")
+        check(L.pp_linegraph_count(_p(ei), e, lo, hi, num_nodes, _p(ws), ws.numel(), _stream()), "pp_linegraph_count")
         total, status = _result(ws)
         _bad_index(status, "lift_order_edge_index")
         out = torch.empty((2, total), dtype=torch.int64, device=dev)

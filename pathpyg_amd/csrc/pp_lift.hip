@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __rest
 __global__ __launch_bounds__(kBlock) void k_linegraph_count(const int64_t* __restrict__ head, int64_t n_edges, int64_t num_nodes,
                                                            const int32_t* __restrict__ outdeg, const uint32_t* __restrict__ rowptr,
                                                            uint32_t* __restrict__ first_pos, int32_t* __restrict__ count,
-                                                           int64_t* __restrict__ status) {
+                                                           int64_t e_begin, int64_t e_end, int64_t* __restrict__ status) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= n_edges) return;
     const int64_t v = head[e];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void k_linegraph_count(const int64_t* __res
     int32_t c = 0;
     if (v < 0 || v >= num_nodes) {
         atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex);
-    } else {
+    } else if (e >= e_begin && e < e_end) {          // edge-range shard: only the own edges are sources
         pos = rowptr[v];
         c = outdeg[v];
     }
@@ -595,9 +595,12 @@ int pp_temporal_fill(int64_t m, int64_t num_nodes, int64_t total, int64_t id_off
 // ---------------------------------------------------------------- line-graph lift
 size_t pp_linegraph_ws_bytes(int64_t n_edges, int64_t num_nodes) { return carve_lift(nullptr, n_edges, num_nodes, false).total_bytes; }
 
-int pp_linegraph_count(const int64_t* edge_index, int64_t n_edges, int64_t num_nodes, void* ws, size_t ws_bytes, pp_stream_t stream) {
+int pp_linegraph_count(const int64_t* edge_index, int64_t n_edges, int64_t e_begin, int64_t e_end, int64_t num_nodes, void* ws,
+                       size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_edges >= 0 && num_nodes >= 0, PP_ERR_ARG, "pp_linegraph_count: negative size");
+    PP_REQUIRE(e_begin >= 0 && e_begin <= e_end && e_end <= n_edges, PP_ERR_ARG, "pp_linegraph_count: edge range [%lld, %lld) outside [0, %lld]",
+               (long long)e_begin, (long long)e_end, (long long)n_edges);
     PP_REQUIRE(n_edges < (int64_t)0x7fffffff && num_nodes < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_linegraph_count: E or N >= 2^31");
     LiftWs w = carve_lift(ws, n_edges, num_nodes, false);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_linegraph_count: workspace too small");
@@ -609,7 +612,7 @@ int pp_linegraph_count(const int64_t* edge_index, int64_t n_edges, int64_t num_n
     rc = exclusive_scan<int32_t, int32_t>(outdeg, num_nodes, (int32_t*)w.rowptr, true, nullptr, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
     k_linegraph_count<<<(unsigned)ceil_div(n_edges, kBlock), kBlock, 0, st>>>(edge_index + n_edges, n_edges, num_nodes, outdeg, w.rowptr,
-                                                                             w.first_pos, w.count, w.result + 1);
+                                                                             w.first_pos, w.count, e_begin, e_end, w.result + 1);
     PP_LAUNCH_CHECK();
     return exclusive_scan<int32_t, int64_t>(w.count, n_edges, w.offset, true, w.result, w.scratch, w.scratch_bytes, st);
 }

@@ -94,6 +94,24 @@ def lift_order_temporal_sharded(g, delta=1, group=None, weights: torch.Tensor | 
     return local, sum(sizes[:rank]), sum(sizes)
 
 
+def lift_order_edge_index_sharded(edge_index: torch.Tensor, num_nodes: int, group=None, weights: torch.Tensor | None = None):
+    """Edge-range sharded line-graph lift of a source-sorted edge list replicated on every rank: rank r expands
+    the edges ``[lo_r, hi_r)``; out-degrees and row pointers are derived locally from the replicated list, so the only collective
+    is the all-gather of the per-rank pair counts.  Returns ``(local [2, E'_r] with global ids, ranges, total E')``; the rank-order
+    concatenation of the blocks is the single-process result."""
+    rank, world = _world(group)
+    ei = _dispatch.plain(edge_index)
+    ranges = event_ranges(ei.size(1), world, weights)
+    lo, hi = ranges[rank]
+    local = _dispatch.linegraph_lift(ei, num_nodes, (lo, hi))
+    total = local.size(1)
+    if world > 1:
+        counts = torch.tensor([total], dtype=torch.int64, device=local.device)
+        dist.all_reduce(counts, group=group)
+        total = int(counts.item())
+    return local, ranges, total
+
+
 def gather_lifted(local: torch.Tensor, group=None) -> torch.Tensor:
     """Concatenate the per-rank blocks (rank order) on every rank — for tests and small graphs only."""
     rank, world = _world(group)

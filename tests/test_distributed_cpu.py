@@ -72,6 +72,18 @@ def _worker(rank, world, port, seed, results):
             assert torch.equal(local, want[:, offset: offset + local.size(1)])      # my block of the global result
             full = pd.gather_lifted(local)
             assert torch.equal(full, want)
+        # edge-range sharded LINE-GRAPH lift of the (source-sorted) event graph: blocks concatenate to the single-process result
+        def oracle_range_lift(edge_index, num_nodes, edge_range=None):
+            full_lift = ol.line_graph_lift(edge_index, num_nodes)
+            lo_, hi_ = edge_range
+            return full_lift[:, (full_lift[0] >= lo_) & (full_lift[0] < hi_)]
+        _dispatch.linegraph_lift = oracle_range_lift
+        want3 = ol.line_graph_lift(want, m)
+        local3, ranges3, total3 = pd.lift_order_edge_index_sharded(want, m)
+        assert total3 == want3.size(1)
+        lo3, hi3 = ranges3[rank]
+        assert torch.equal(local3, want3[:, (want3[0] >= lo3) & (want3[0] < hi3)])
+        assert torch.equal(pd.gather_lifted(local3), want3)
         # gradient all-reduce: mean over ranks, one flattened collective
         net = pp.nn.DBGNN(num_classes=2, num_features=(3, 3), hidden_dims=[4, 4, 2])
         for i, p in enumerate(net.parameters()):

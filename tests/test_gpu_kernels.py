@@ -268,6 +268,21 @@ def test_temporal_lift_edge_range_shards_reassemble(hip):
         assert torch.equal(torch.cat(parts, dim=1), full)
 
 
+def test_linegraph_lift_edge_range_shards_reassemble(hip):
+    """Same for the line-graph lift (k -> k+1): every shard expands its own edge range against the degrees / row pointers of the
+    whole list; the blocks concatenate to the whole result."""
+    from pathpyg_amd.distributed import event_ranges
+    ei, t = _stream(12, 120_000, 500, 20_000)
+    ho = hip.temporal_lift(cu(ei), cu(t), 500, 300)                  # a source-sorted edge list over 120 000 "nodes" (events)
+    full = hip.linegraph_lift(ho, ei.size(1))
+    for world in (1, 3, 8):
+        parts = [hip.linegraph_lift(ho, ei.size(1), (lo, hi)) for lo, hi in event_ranges(ho.size(1), world)]
+        assert torch.equal(torch.cat(parts, dim=1), full)
+    assert hip.linegraph_lift(ho, ei.size(1), (5, 5)).shape == (2, 0)
+    with pytest.raises(ValueError):
+        hip.linegraph_lift(ho, ei.size(1), (10, ho.size(1) + 1))
+
+
 @pytest.mark.parametrize("case", ["all_same_time", "negative_delta", "huge_delta", "one_hub", "self_loops_only", "float_ties_exact_boundary"])
 def test_temporal_lift_adversarial_streams(hip, case):
     """Edge cases of the window logic against the oracle (which is pinned to the reference source on the golden vectors)."""
