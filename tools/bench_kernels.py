@@ -69,9 +69,9 @@ def main():
         e3 = _hip.linegraph_lift(ho, a.events).size(1)
         report(f"linegraph_lift of the event graph E3={e3}", lambda: _hip.linegraph_lift(ho, a.events), (16 * e2 + 16 * e3) / 1e9)
         ws2 = _hip._workspace(L.pp_linegraph_ws_bytes(e2, a.events), dev)
-        L.pp_linegraph_count(ho.data_ptr(), e2, a.events, ws2.data_ptr(), ws2.numel(), st)
+        L.pp_linegraph_count(ho.data_ptr(), e2, 0, e2, a.events, ws2.data_ptr(), ws2.numel(), st)
         out3 = torch.empty((2, e3), dtype=torch.int64, device=dev)
-        report("  pp_linegraph_count", lambda: L.pp_linegraph_count(ho.data_ptr(), e2, a.events, ws2.data_ptr(), ws2.numel(), st))
+        report("  pp_linegraph_count", lambda: L.pp_linegraph_count(ho.data_ptr(), e2, 0, e2, a.events, ws2.data_ptr(), ws2.numel(), st))
         report("  pp_linegraph_fill (k_expand, no list)", lambda: L.pp_linegraph_fill(e2, a.events, e3, out3.data_ptr(), ws2.data_ptr(), ws2.numel(), st), 16 * e3 / 1e9)
         big = torch.empty(e3 * 2, dtype=torch.int64, device=dev)
         report("  torch fill_ of the same bytes (write BW reference)", lambda: big.fill_(7), 16 * e3 / 1e9)
