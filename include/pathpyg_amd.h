@@ -168,8 +168,10 @@ int pp_ptr_from_sorted_i64(const int64_t* sorted, int64_t n, int64_t num_rows, i
  * pp_plan_result_ptr(ws)[1] = status (bit 0: index out of range). */
 size_t pp_gcn_plan_ws_bytes(int64_t n_edges, int64_t n_nodes);
 int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int row_sorted, int32_t* in_ptr,
-                int32_t* in_idx, float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, void* ws,
-                size_t ws_bytes, pp_stream_t stream);
+                int32_t* in_idx, float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, int32_t* dst_order,
+                void* ws, size_t ws_bytes, pp_stream_t stream);   /* dst_order [E] or NULL: the edge ids grouped by destination (the
+                                                                    permutation behind in_*); with in_ptr it IS the bipartite "last"
+                                                                    plan of an order-2 model, whose nodes are this graph's edges */
 
 /* CSR views of DBGNN's bipartite_edge_index [2,n_pairs] (row 0: higher-order node, row 1: first-order node),
  * src/pathpyG/nn/dbgnn.py:64-69: in_* grouped by first-order node (+ its in-degree as float), out_* by higher-order node.

@@ -394,7 +394,8 @@ def temporal_betweenness(edge_index: torch.Tensor, num_nodes: int, event_graph: 
 class CsrPlan:
     """CSR pair of one propagation: ``fwd`` rows are the destinations, ``bwd`` rows the sources (transposed)."""
 
-    __slots__ = ("n_dst", "n_src", "fwd_ptr", "fwd_idx", "fwd_val", "bwd_ptr", "bwd_idx", "bwd_val", "self_coef", "fwd_heavy", "bwd_heavy")
+    __slots__ = ("n_dst", "n_src", "fwd_ptr", "fwd_idx", "fwd_val", "bwd_ptr", "bwd_idx", "bwd_val", "self_coef", "fwd_heavy", "bwd_heavy",
+                 "dst_order")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -472,7 +473,7 @@ def _finish_plans(entries: list, what: str) -> None:
 
 
 def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nodes: int, row_sorted: bool | None = None,
-             status_out: list | None = None) -> CsrPlan:
+             status_out: list | None = None, want_dst_order: bool = False) -> CsrPlan:
     """GCN normalisation of a weighted graph, once per graph (see pp_gcn_plan in the C header).
     ``row_sorted=None`` checks on the device whether the sources are non-decreasing (one tiny kernel + 8-byte read).
     ``status_out``: append the device status word instead of reading it now (the caller checks several plans with ONE
@@ -495,13 +496,28 @@ def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nod
                        bwd_ptr=torch.empty(num_nodes + 1, **i32), bwd_idx=torch.empty(e, **i32), bwd_val=torch.empty(e, **f32),
                        self_coef=torch.empty(num_nodes, **f32))
         ws = _workspace(L.pp_gcn_plan_ws_bytes(e, num_nodes), dev)
+        if want_dst_order:
+            plan.dst_order = torch.empty(e, **i32)
         check(L.pp_gcn_plan(_p(ei), _p(edge_weight), e, num_nodes, 1 if row_sorted else 0, _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val), _p(plan.bwd_ptr),
-                            _p(plan.bwd_idx), _p(plan.bwd_val), _p(plan.self_coef), _p(ws), ws.numel(), _stream()), "pp_gcn_plan")
+                            _p(plan.bwd_idx), _p(plan.bwd_val), _p(plan.self_coef), _p(plan.dst_order), _p(ws), ws.numel(), _stream()), "pp_gcn_plan")
         entry = (ws[8:16].view(torch.int64).clone(), plan, _plan_row_lengths(plan))
         if status_out is None:
             _finish_plans([entry], "GCNConv")
         else:
             status_out.append(entry)
+    return plan
+
+
+def bipartite_plan_from_edge_grouping(plan_fo: CsrPlan, edge_dst: torch.Tensor, n_ho: int) -> CsrPlan:
+    """Bipartite "last" plan of an order-2 De Bruijn model WITHOUT another sort: the higher-order nodes are the first-order graph's
+    edges (same order), so "the higher-order nodes that end in node v" = "the edges into v" = the destination grouping the
+    first-order GCN plan already holds (``gcn_plan(..., want_dst_order=True)``).  ``edge_dst`` = ``edge_index[1]`` of that graph."""
+    dev = plan_fo.fwd_ptr.device
+    ptr = plan_fo.fwd_ptr
+    plan = CsrPlan(n_dst=plan_fo.n_dst, n_src=n_ho, fwd_ptr=ptr, fwd_idx=plan_fo.dst_order, fwd_val=None,
+                   bwd_ptr=torch.arange(n_ho + 1, dtype=torch.int32, device=dev), bwd_idx=edge_dst.to(torch.int32).contiguous(), bwd_val=None,
+                   self_coef=(ptr[1:] - ptr[:-1]).to(torch.float32))
+    plan.fwd_heavy = plan_fo.fwd_heavy              # same row pointers: the same hub rows
     return plan
 
 

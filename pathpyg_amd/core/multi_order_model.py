@@ -284,7 +284,12 @@ class MultiOrderModel:
             y=g.data.y,
         )
         # facts DBGNN.forward would otherwise have to verify on the device (every Graph's edge index is row-sorted)
-        object.__setattr__(out, "_pp_hints", {"rows_sorted": True, "bipartite_sources_sorted": mapping in ("last", "first")})
+        object.__setattr__(out, "_pp_hints", {
+            "rows_sorted": True, "bipartite_sources_sorted": mapping in ("last", "first"),
+            # temporal models: the order-2 nodes ARE the first-order graph's edges, in its edge order (_LiftChain.to_second_order) -
+            # DBGNN.forward then derives the "last" bipartite plan from the first-order plan's destination grouping, no extra sort
+            "bipartite_is_fo_edge_heads": bool(mapping == "last" and max_order == 2 and getattr(g_ho, "_nodes_are_fo_edges", False)
+                                               and n_ho == g.data.edge_index.size(1))})
         return out
 
 
@@ -330,6 +335,8 @@ class _LiftChain:
         merged = _dispatch.plain(self.graph.data.edge_index)
         blocks = _dispatch.successor_blocks(merged[0], self.unique_nodes.size(0), merged[1]) if save and merged.size(1) else None
         graph = _aggregate_with_known_nodes(ho_index, 2, None, unique_nodes, inv, ho_weight, "sum", col_block=blocks) if save else None
+        if graph is not None:
+            graph._nodes_are_fo_edges = True          # node u of this layer = edge u of layer 1 (same lexicographic order)
         return _LiftChain(ho_index, inv, _dispatch.plain(event_index)[1], unique_nodes, ho_weight, graph)
 
     def lift(self, aggr: str, save: bool):

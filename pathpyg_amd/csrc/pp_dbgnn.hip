@@ -496,8 +496,8 @@ extern "C" {
 size_t pp_gcn_plan_ws_bytes(int64_t n_edges, int64_t n_nodes) { return carve_plan(nullptr, n_edges, n_nodes).total_bytes; }
 
 int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int row_sorted, int32_t* in_ptr,
-                int32_t* in_idx, float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, void* ws,
-                size_t ws_bytes, pp_stream_t stream) {
+                int32_t* in_idx, float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, int32_t* dst_order,
+                void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_edges >= 0 && n_nodes >= 0, PP_ERR_ARG, "pp_gcn_plan: negative size");
     PP_REQUIRE(n_edges < (int64_t)0x7fffffff && n_nodes < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_plan: E or N >= 2^31");
@@ -524,6 +524,10 @@ int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_e
     if (n_edges > 0) {
         k_gather_by_dst<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, in_idx, in_val);
         PP_LAUNCH_CHECK();
+        if (dst_order) {       // edge ids grouped by destination: for an order-2 De Bruijn model this IS the bipartite "last" plan
+            k_u32_to_i32_ptr<<<egrid, kBlock, 0, st>>>(w.order, n_edges, dst_order);
+            PP_LAUNCH_CHECK();
+        }
     }
     k_gcn_degree_grouped<<<ngrid, kBlock, 0, st>>>(in_idx, in_val, w.ptr, w.last_loop, edge_weight, n_nodes, w.dinv, self_coef);
     PP_LAUNCH_CHECK();

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 from torch.nn import Linear, Module, ModuleList, Parameter
 
 from .. import _hip
+from .._dispatch import plain as _dispatch_plain
 
 
 class _Propagate(torch.autograd.Function):
@@ -292,14 +293,19 @@ class DBGNN(Module):
         hints = getattr(data, "_pp_hints", None) or {}
         rows_sorted = True if hints.get("rows_sorted") else None
         bip_sorted = True if hints.get("bipartite_sources_sorted") else None
+        from_edges = bool(hints.get("bipartite_is_fo_edge_heads"))     # order-2 temporal model, "last" mapping: no bipartite sort
         pending = []
         plan_fo = _cached(data, "fo", (data.edge_index, data.edge_weights),
-                          lambda: _hip.gcn_plan(data.edge_index, data.edge_weights, n_fo, rows_sorted, pending))
+                          lambda: _hip.gcn_plan(data.edge_index, data.edge_weights, n_fo, rows_sorted, pending, want_dst_order=from_edges))
         plan_ho = _cached(data, "ho", (data.edge_index_higher_order, data.edge_weights_higher_order),
                           lambda: _hip.gcn_plan(data.edge_index_higher_order, data.edge_weights_higher_order, n_ho, rows_sorted, pending))
-        plan_bi = _cached(data, "bi", (data.bipartite_edge_index,),
-                          lambda: _hip.bipartite_plan(data.bipartite_edge_index, n_ho, n_fo, None, bip_sorted, pending))
+        if not from_edges:
+            plan_bi = _cached(data, "bi", (data.bipartite_edge_index,),
+                              lambda: _hip.bipartite_plan(data.bipartite_edge_index, n_ho, n_fo, None, bip_sorted, pending))
         _hip.check_plan_status(pending)
+        if from_edges:
+            plan_bi = _cached(data, "bi", (data.edge_index, data.edge_weights),
+                              lambda: _hip.bipartite_plan_from_edge_grouping(plan_fo, _dispatch_plain(data.edge_index)[1], n_ho))
 
         if self.p_dropout > 0 and self.training:
             for layer in self.first_order_layers:                   # dropout -> GCNConv -> ELU (fused into the aggregation)
