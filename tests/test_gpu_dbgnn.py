@@ -402,3 +402,58 @@ def test_spmm_with_hub_rows(pp, f):
     got = _hip.spmm(ptr.to(DEV), idx.to(DEV), val.to(DEV), n, x.to(DEV), heavy=heavy).cpu().double()
     scale = float(want.abs().max())
     torch.testing.assert_close(got, want, rtol=1e-5, atol=2e-6 * scale)
+
+
+def test_fuzz_dbgnn_on_models_built_from_streams_and_paths(pp):
+    """End to end through the public API on 24 seeded configurations: temporal streams (the path with derived bipartite plans and
+    layer hints) and walk data, mappings last / first / both, one-hot default features and given ones, supported and unsupported
+    layer widths, order 2 and 3 as the higher order: logits, loss and every gradient against the oracle on the oracle's own layers."""
+    from oracle import dbgnn as od
+    from oracle import model as om
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        temporal = case % 3 != 2
+        order = 2 if case % 4 else 3
+        mapping = ("last", "first", "both")[case % 3] if order == 2 else "last"
+        n = int(rng.integers(4, 40))
+        if temporal:
+            m = int(rng.integers(30, 1500))
+            ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+            t = torch.from_numpy(rng.integers(0, 200, m))
+            delta = int(rng.integers(2, 30))
+            sei, st, _ = om.stable_time_sort(ei, t)
+            want = om.layers_from_temporal(sei, st, n, delta=delta, max_order=order)
+            if want[order]["edge_index"].size(1) == 0 and order == 3:
+                continue
+            g = pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=t.to(DEV), num_nodes=n))
+            model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=order)
+        else:
+            walks = [rng.integers(0, n, int(rng.integers(2, 7))).tolist() for _ in range(int(rng.integers(5, 120)))]
+            walks.append(list(range(n)))                             # every node occurs: dense first-order ids
+            weights = rng.integers(1, 4, len(walks)).astype(np.float32).tolist()
+            want = om.layers_from_paths(om.walks_to_path_tensors(walks, weights), max_order=order)
+            paths = pp.PathData(device=DEV)
+            paths.append_walks(walks, weights)
+            model = pp.MultiOrderModel.from_path_data(paths, max_order=order)
+        n_ho = want[order]["num_nodes"]
+        widths = [(16, 32, 8), (12, 20, 6), (64, 64, 16), (8, 8, 8)][case % 4]
+        one_hot = case % 5 == 0 and n_ho < 400
+        gen = torch.Generator().manual_seed(case)
+        fx, fh = (n, n_ho) if one_hot else (int(rng.integers(3, 20)), int(rng.integers(3, 20)))
+        x = None if one_hot else torch.randn(n, fx, generator=gen)
+        x_h = None if one_hot else torch.randn(n_ho, fh, generator=gen)
+        y = torch.randint(0, 3, (n,), generator=gen)
+        params = od.init_params(3, (fx, fh), list(widths), seed=case)
+        ref = om.dbgnn_inputs(want, order, mapping, x=x, x_h=x_h)
+        want_out, want_loss, want_grads = od.loss_and_grads(params, ref, y)
+        data = model.to_dbgnn_data(max_order=order, mapping=mapping, x=None if x is None else x.to(DEV), x_h=None if x_h is None else x_h.to(DEV))
+        net = _to_module(pp, params, 3, (fx, fh), list(widths))
+        out = net(data)
+        loss = F.cross_entropy(out, y.to(DEV))
+        loss.backward()
+        scale = float(want_out.abs().max()) + 1e-12
+        torch.testing.assert_close(out.detach().cpu(), want_out, rtol=RTOL * 10, atol=max(ATOL, 2e-6 * scale)), case
+        torch.testing.assert_close(loss.detach().cpu(), want_loss, rtol=RTOL * 10, atol=ATOL)
+        for name, p in net.named_parameters():
+            gs = float(want_grads[name].abs().max()) + 1e-12
+            torch.testing.assert_close(p.grad.cpu(), want_grads[name], rtol=1e-4, atol=max(ATOL, 5e-5 * gs)), (case, name)
