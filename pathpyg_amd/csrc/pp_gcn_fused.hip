@@ -39,9 +39,11 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
     using off_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;     // byte offset of a gathered row
     __shared__ __attribute__((aligned(16))) float s_b[P * 16 * CT];
     __shared__ __attribute__((aligned(16))) float s_tile[kGcnWaves][16 * TS];
+    // B[k][j] = W[j][k], stored [k][j]: lane i of output tile ct works on column CT*i + ct, so that a lane ends up with CT CONSECUTIVE
+    // output columns per row (one 16-byte store per row instead of four 4-byte ones) and reads its CT B values with one ds_read
     for (int e = threadIdx.x; e < P * Q; e += kGcnThreads) {
         const int j = e / P, k = e - j * P;
-        s_b[(k * 16 + (j & 15)) * CT + (j >> 4)] = W[e];
+        s_b[k * Q + j] = W[e];
     }
     __syncthreads();
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
     float* tile = s_tile[wave];
     float bias_c[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) bias_c[ct] = bias ? bias[ct * 16 + i] : 0.f;
+    for (int ct = 0; ct < CT; ++ct) bias_c[ct] = bias ? bias[CT * i + ct] : 0.f;
     const char* xb = (const char*)X;
     const int64_t n_tiles = (n_rows + 15) / 16;
     const int64_t step = (int64_t)gridDim.x * kGcnWaves;
@@ -178,17 +180,30 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_wave_barrier();
-        float* yp = Y + (t * 16 + 4 * kq) * Q + i;
+        // C/D layout: out[ct][reg] = row 4*kq + reg of the tile, column CT*i + ct: CT consecutive columns per lane and row
+        float* yp = Y + (t * 16 + 4 * kq) * Q + CT * i;
         const int rows_here = n_rows - (t * 16 + 4 * kq) < 4 ? (int)(n_rows - (t * 16 + 4 * kq)) : 4;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int reg = 0; reg < 4; ++reg) {
+            float y[CT];
 #pragma unroll
-            for (int reg = 0; reg < 4; reg += 2) {
-                pp_f32x2 y = {out[ct][reg] + bias_c[ct], out[ct][reg + 1] + bias_c[ct]};
-                if (act) y = elu_fast2(y);
-                if (reg < rows_here) yp[reg * Q + ct * 16] = y[0];
-                if (reg + 1 < rows_here) yp[(reg + 1) * Q + ct * 16] = y[1];
+            for (int ct = 0; ct < CT; ct += 2) {
+                if (ct + 1 < CT) {
+                    pp_f32x2 v = {out[ct][reg] + bias_c[ct], out[ct + 1][reg] + bias_c[ct + 1]};
+                    if (act) v = elu_fast2(v);
+                    y[ct] = v[0];
+                    y[ct + 1] = v[1];
+                } else {
+                    const float v = out[ct][reg] + bias_c[ct];
+                    y[ct] = act ? elu_fast(v) : v;
+                }
             }
+            if (reg < rows_here) {
+                if constexpr (CT == 4) *(float4*)(yp + reg * Q) = make_float4(y[0], y[1], y[2], y[3]);
+                else if constexpr (CT == 2) *(float2*)(yp + reg * Q) = make_float2(y[0], y[1]);
+                else yp[reg * Q] = y[0];
+            }
+        }
     }
 }
 
@@ -247,10 +262,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
     __shared__ __attribute__((aligned(16))) float s_b[M * 16 * CT];          // [k][i][ct] = W[k][ct*16 + i]
     __shared__ __attribute__((aligned(16))) float s_tile[kGcnWaves][16 * TS];
     __shared__ float s_fold[64 * 64];
-    for (int e = threadIdx.x; e < M * K; e += kGcnThreads) {
-        const int k = e / K, j = e - k * K;
-        s_b[(k * 16 + (j & 15)) * CT + (j >> 4)] = W[e];
-    }
+    for (int e = threadIdx.x; e < M * K; e += kGcnThreads) s_b[e] = W[e];       // [k][j]: lane i of tile ct works on column CT*i + ct
     for (int e = threadIdx.x; e < 64 * 64; e += kGcnThreads) s_fold[e] = 0.f;
     __syncthreads();
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -270,12 +282,19 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
     const int64_t step = (int64_t)gridDim.x * kGcnWaves;
     for (int64_t t = (int64_t)blockIdx.x * kGcnWaves + wave; t < n_tiles; t += step) {
         // natural-layout rows of the layer input: B operand of the dW stream and source of the ELU' epilogue (in flight during the gather)
+        // lane (i, kq) owns rows 4*kq .. 4*kq+3 of the tile and the CT consecutive columns CT*i ..: one vector load per row
         float xr[CT][4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t r = t * 16 + 4 * kq + reg;
+            const float* xp = X + r * K + CT * i;
+            if constexpr (CT == 4) {
+                const float4 v = r < n_rows ? *(const float4*)xp : make_float4(0.f, 0.f, 0.f, 0.f);
+                xr[0][reg] = v.x; xr[1][reg] = v.y; xr[2][reg] = v.z; xr[3][reg] = v.w;
+            } else {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) xr[ct][reg] = r < n_rows ? X[r * K + ct * 16 + i] : 0.f;
+                for (int ct = 0; ct < CT; ++ct) xr[ct][reg] = r < n_rows ? xp[ct] : 0.f;
+            }
         }
         const int64_t r0 = t * 16 + g * kRows;
         int p[kRows + 1];
@@ -367,11 +386,18 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
         float4 a[KQ / 4];
 #pragma unroll
         for (int c = 0; c < KQ / 4; ++c) a[c] = *(const float4*)(tile + i * TS + kq * KQ + 4 * c);
-        float hr[MT][4];                                              // G in the natural layout: A operand of the dW stream
+        float hr[MT][4];                                              // G rows 4*kq + s, columns MT*i ..: A operand of the dW stream
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
+        for (int reg = 0; reg < 4; ++reg) {
+            const float* gp = tile + (4 * kq + reg) * TS + MT * i;
+            if constexpr (MT == 4) {
+                const float4 v = *(const float4*)gp;
+                hr[0][reg] = v.x; hr[1][reg] = v.y; hr[2][reg] = v.z; hr[3][reg] = v.w;
+            } else {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hr[mt][reg] = tile[(4 * kq + reg) * TS + mt * 16 + i];
+                for (int mt = 0; mt < MT; ++mt) hr[mt][reg] = gp[mt];
+            }
+        }
         f32x4 out[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) out[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -380,7 +406,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
             const float av[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float* bp = s_b + ((kq * KQ + 4 * c + e) * 16 + i) * CT;
+                const float* bp = s_b + (kq * KQ + 4 * c + e) * K + CT * i;
                 float bv[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) bv[ct] = bp[ct];
@@ -388,7 +414,8 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
                 for (int ct = 0; ct < CT; ++ct) out[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[ct], out[ct], 0, 0, 0);
             }
         }
-        // ---------------------------------------------------------------- dW += G_tile^T x_tile (rows {reg, 4+reg, 8+reg, 12+reg} per step)
+        // ---------------------------------------------------------------- dW += G_tile^T x_tile: step `reg` contracts the rows 4*kq + reg
+        // (kq = the MFMA's k index); tile (mt, ct) holds dW[MT*row + mt][CT*col + ct]
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
@@ -397,20 +424,26 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
                 for (int ct = 0; ct < CT; ++ct)
                     acc_w[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[mt][reg], xr[ct][reg], acc_w[mt][ct], 0, 0, 0);
         __builtin_amdgcn_wave_barrier();
-        float* yp = d_in + (t * 16 + 4 * kq) * K + i;
+        float* yp = d_in + (t * 16 + 4 * kq) * K + CT * i;
         const int rows_here = n_rows - (t * 16 + 4 * kq) < 4 ? (int)(n_rows - (t * 16 + 4 * kq)) : 4;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int reg = 0; reg < 4; ++reg) {
+            float v[CT];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                float v = out[ct][reg];
+            for (int ct = 0; ct < CT; ++ct) {
+                v[ct] = out[ct][reg];
                 if (fuse_act) {
                     const float y = xr[ct][reg];
-                    v *= y > 0.f ? 1.f : y + 1.f;
+                    v[ct] *= y > 0.f ? 1.f : y + 1.f;
                 }
-                col_in[ct] += v;                                      // rows past the end aggregate nothing: v == 0 there
-                if (reg < rows_here) yp[reg * K + ct * 16] = v;
+                col_in[ct] += v[ct];                                  // rows past the end aggregate nothing: v == 0 there
             }
+            if (reg < rows_here) {
+                if constexpr (CT == 4) *(float4*)(yp + reg * K) = make_float4(v[0], v[1], v[2], v[3]);
+                else if constexpr (CT == 2) *(float2*)(yp + reg * K) = make_float2(v[0], v[1]);
+                else yp[reg * K] = v[0];
+            }
+        }
     }
     if (colsum_in) {
 #pragma unroll
@@ -418,7 +451,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
             float v = col_in[ct];
             v += __shfl_xor(v, 16, kWave);
             v += __shfl_xor(v, 32, kWave);
-            if (kq == 0) atomicAdd(&colsum_in[ct * 16 + i], v);
+            if (kq == 0) atomicAdd(&colsum_in[CT * i + ct], v);
         }
     }
     // fold the waves' dW through LDS in wave order: one partial [64][64] tile per workgroup (zero padded), summed by weight_grad_reduce
@@ -429,7 +462,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) s_fold[(mt * 16 + 4 * kq + reg) * 64 + ct * 16 + i] += acc_w[mt][ct][reg];
+                    for (int reg = 0; reg < 4; ++reg) s_fold[(MT * (4 * kq + reg) + mt) * 64 + CT * i + ct] += acc_w[mt][ct][reg];
         }
         __syncthreads();
     }
