@@ -823,6 +823,74 @@ __global__ __launch_bounds__(kBlock) void k_weight_grad(const float* __restrict_
 // Sums the per-workgroup partial tiles: 16 outputs x 16 interleaved slices of partials per workgroup, every slice
 // accumulated sequentially and the 16 slice sums folded in a fixed order => bitwise reproducible results.
 constexpr int kWgSlices = 16;
+// 64 x 64 layers: the same contraction on v_mfma_f32_16x16x4_f32 with 16-byte operand loads.  Lane (i, kq) reads the four
+// consecutive columns 4i .. 4i+3 of row n + kq of dH and of X (one dwordx4 each: a load instruction covers four whole rows), and the
+// 16 MFMAs of a step pair every dH component c with every X component c': tile (c, c') accumulates dW[4*row + c][4*col + c'].
+__global__ __launch_bounds__(kBlock) void k_weight_grad64(const float* __restrict__ dH, const float* __restrict__ X, int64_t n_rows,
+                                                         int64_t rows_per_wave, float* __restrict__ partial,
+                                                         float* __restrict__ partial_bias) {
+    constexpr int kSteps = 8;                              // 4-row steps in flight per iteration: 16 outstanding 16-byte loads per lane
+    const int lane = lane_id(), i = lane & 15, kq = lane >> 4;
+    const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
+    const int64_t n_begin = wave_global * rows_per_wave;
+    int64_t n_end = n_begin + rows_per_wave;
+    if (n_end > n_rows) n_end = n_rows;
+    using f32x4v = __attribute__((ext_vector_type(4))) float;
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[c][d] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float bias_acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t n0 = n_begin; n0 < n_end; n0 += 4 * kSteps) {
+        float4 a[kSteps], b[kSteps];
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) {
+            const int64_t n = n0 + 4 * u + kq;
+            const bool live = n < n_end;
+            a[u] = live ? *(const float4*)(dH + n * 64 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[u] = live ? *(const float4*)(X + n * 64 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) {
+            const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bias_acc[c] += av[c];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[d], acc[c][d], 0, 0, 0);
+            }
+        }
+    }
+    // fold the 4 waves through LDS in wave order; C/D layout of the 16x16 MFMA: row = 4*(lane>>4) + reg, col = lane&15
+    __shared__ float s_tile[64 * 64];
+    __shared__ float s_bias[64];
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        if (wave_id() == w) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int at = (4 * (4 * kq + reg) + c) * 64 + 4 * i + d;
+                        s_tile[at] = (w == 0 ? 0.f : s_tile[at]) + acc[c][d][reg];
+                    }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = bias_acc[c];
+                v += __shfl_xor(v, 16, kWave);
+                v += __shfl_xor(v, 32, kWave);
+                if (kq == 0) s_bias[4 * i + c] = (w == 0 ? 0.f : s_bias[4 * i + c]) + v;
+            }
+        }
+        __syncthreads();
+    }
+    float* out = partial + ((int64_t)blockIdx.x << 12);
+    for (int e = threadIdx.x; e < 64 * 64; e += kBlock) out[e] = s_tile[e];
+    if (partial_bias && threadIdx.x < 64) partial_bias[(int64_t)blockIdx.x * 64 + threadIdx.x] = s_bias[threadIdx.x];
+}
+
 __global__ __launch_bounds__(kBlock) void k_weight_grad_reduce(const float* __restrict__ partial, const float* __restrict__ partial_bias,
                                                               int64_t n_parts, int M, int K, float* __restrict__ dW, float* __restrict__ db) {
     __shared__ float s_sum[kWgSlices][kBlock / kWgSlices];
@@ -884,6 +952,17 @@ int pp_weight_grad_f32(const float* dH, const float* X, int64_t n_rows, int M, i
     const int64_t parts = waves / pp::kWavesPerBlock;
     float* partial_bias = (float*)((char*)ws + pp::align_up((size_t)parts * i_blocks * k_blocks * 4096 * sizeof(float)));
     dim3 grid((unsigned)(waves / pp::kWavesPerBlock), (unsigned)(i_blocks * k_blocks));
+    if (M == 64 && K == 64 && (((uintptr_t)dH | (uintptr_t)X) % 16 == 0)) {
+        const int64_t rows4 = pp::ceil_div(rows_per_wave, 4) * 4;          // a wave's range starts on a 4-row step
+        const int64_t waves4 = pp::ceil_div(pp::ceil_div(n_rows > 0 ? n_rows : 1, rows4), pp::kWavesPerBlock) * pp::kWavesPerBlock;
+        pp::k_weight_grad64<<<(unsigned)(waves4 / pp::kWavesPerBlock), pp::kBlock, 0, st>>>(dH, X, n_rows, rows4, partial, db ? partial_bias : nullptr);
+        PP_LAUNCH_CHECK();
+        const int outs64 = M * K + (db ? M : 0);
+        pp::k_weight_grad_reduce<<<(unsigned)pp::ceil_div(outs64, pp::kBlock / pp::kWgSlices), pp::kBlock, 0, st>>>(
+            partial, db ? partial_bias : nullptr, waves4 / pp::kWavesPerBlock, M, K, dW, db);
+        PP_LAUNCH_CHECK();
+        return PP_OK;
+    }
     pp::k_weight_grad<<<grid, pp::kBlock, 0, st>>>(dH, X, n_rows, M, K, rows_per_wave, partial, db ? partial_bias : nullptr);
     PP_LAUNCH_CHECK();
     const int outs = M * K + (db ? M : 0);
