@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guide: MI355X_MICROARCH.md); ~6300 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--events", type=int, default=10_000_000, help="temporal edges per GPU")
     ap.add_argument("--nodes", type=int, default=500_000)
     ap.add_argument("--span", type=int, default=10_000_000)
