@@ -838,10 +838,10 @@ constexpr int kWgSlices = 16;
 // 64 x 64 layers: the same contraction on v_mfma_f32_16x16x4_f32 with 16-byte operand loads.  Lane (i, kq) reads the four
 // consecutive columns 4i .. 4i+3 of row n + kq of dH and of X (one dwordx4 each: a load instruction covers four whole rows), and the
 // 16 MFMAs of a step pair every dH component c with every X component c': tile (c, c') accumulates dW[4*row + c][4*col + c'].
-__global__ __launch_bounds__(kBlock) void k_weight_grad64(const float* __restrict__ dH, const float* __restrict__ X, int64_t n_rows,
+__global__ __launch_bounds__(kBlock, 3) void k_weight_grad64(const float* __restrict__ dH, const float* __restrict__ X, int64_t n_rows,
                                                          int64_t rows_per_wave, float* __restrict__ partial,
                                                          float* __restrict__ partial_bias) {
-    constexpr int kSteps = 8;                              // 4-row steps in flight per iteration: 16 outstanding 16-byte loads per lane
+    constexpr int kSteps = 6;                              // 4-row steps per iteration, fetched in two half-batches
     const int lane = lane_id(), i = lane & 15, kq = lane >> 4;
     const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
     const int64_t n_begin = wave_global * rows_per_wave;
@@ -854,17 +854,21 @@ __global__ __launch_bounds__(kBlock) void k_weight_grad64(const float* __restric
 #pragma unroll
         for (int d = 0; d < 4; ++d) acc[c][d] = f32x4v{0.f, 0.f, 0.f, 0.f};
     float bias_acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t n0 = n_begin; n0 < n_end; n0 += 4 * kSteps) {
-        float4 a[kSteps], b[kSteps];
+    // two half-batches of kSteps/2 steps: while the MFMAs of one half run, the loads of the other are in flight
+    constexpr int kHalf = kSteps / 2;
+    float4 a[kSteps], b[kSteps];
+    auto fetch = [&](int h, int64_t n0) {
 #pragma unroll
-        for (int u = 0; u < kSteps; ++u) {
+        for (int u = h * kHalf; u < (h + 1) * kHalf; ++u) {
             const int64_t n = n0 + 4 * u + kq;
             const bool live = n < n_end;
             a[u] = live ? *(const float4*)(dH + n * 64 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
             b[u] = live ? *(const float4*)(X + n * 64 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    auto contract = [&](int h) {
 #pragma unroll
-        for (int u = 0; u < kSteps; ++u) {
+        for (int u = h * kHalf; u < (h + 1) * kHalf; ++u) {
             const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -873,6 +877,13 @@ __global__ __launch_bounds__(kBlock) void k_weight_grad64(const float* __restric
                 for (int d = 0; d < 4; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[d], acc[c][d], 0, 0, 0);
             }
         }
+    };
+    fetch(0, n_begin);
+    for (int64_t n0 = n_begin; n0 < n_end; n0 += 4 * kSteps) {
+        fetch(1, n0);
+        contract(0);
+        fetch(0, n0 + 4 * kSteps);
+        contract(1);
     }
     // fold the 4 waves through LDS in wave order; C/D layout of the 16x16 MFMA: row = 4*(lane>>4) + reg, col = lane&15
     __shared__ float s_tile[64 * 64];
@@ -901,6 +912,114 @@ __global__ __launch_bounds__(kBlock) void k_weight_grad64(const float* __restric
     float* out = partial + ((int64_t)blockIdx.x << 12);
     for (int e = threadIdx.x; e < 64 * 64; e += kBlock) out[e] = s_tile[e];
     if (partial_bias && threadIdx.x < 64) partial_bias[(int64_t)blockIdx.x * 64 + threadIdx.x] = s_bias[threadIdx.x];
+}
+
+// Wider layers (M = 64*MB, K = 64*KB, MB*KB <= 16 waves): the workgroup walks ONE row range and wave (bi, bj) owns output block (bi, bj),
+// contracted exactly like k_weight_grad64 from the 256-byte column slices bi of dH and bj of X.  The waves of a workgroup read the same
+// rows at the same time, so every slice comes from HBM once (the per-block launch of k_weight_grad re-read dH KB times and X MB times:
+// 9.4 ms for 2*10^7 rows of 128x128 - 2 x 20 GB - against the 20 GB a single pass needs).
+template <int MB, int KB>
+__global__ __launch_bounds__(64 * MB * KB, (MB * KB > 4 ? 4 : 3)) void k_weight_grad_blocks(const float* __restrict__ dH, const float* __restrict__ X, int64_t n_rows,
+                                                                     int64_t rows_per_group, float* __restrict__ partial,
+                                                                     float* __restrict__ partial_bias) {
+    constexpr int kSteps = MB * KB > 4 ? 2 : 6;            // 16 waves per workgroup leave 128 registers per lane
+    constexpr int M = 64 * MB, K = 64 * KB;
+    const int lane = lane_id(), i = lane & 15, kq = lane >> 4;
+    const int wave = threadIdx.x >> 6, bi = wave / KB, bj = wave % KB;
+    const int64_t n_begin = (int64_t)blockIdx.x * rows_per_group;
+    int64_t n_end = n_begin + rows_per_group;
+    if (n_end > n_rows) n_end = n_rows;
+    using f32x4v = __attribute__((ext_vector_type(4))) float;
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[c][d] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float bias_acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = dH + 64 * bi + 4 * i;
+    const float* bp = X + 64 * bj + 4 * i;
+    constexpr int kHalf = kSteps / 2;                       // half-batches: loads of one in flight under the MFMAs of the other
+    float4 a[kSteps], b[kSteps];
+    auto fetch = [&](int h, int64_t n0) {
+#pragma unroll
+        for (int u = h * kHalf; u < (h + 1) * kHalf; ++u) {
+            const int64_t n = n0 + 4 * u + kq;
+            const bool live = n < n_end;
+            a[u] = live ? *(const float4*)(ap + n * M) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[u] = live ? *(const float4*)(bp + n * K) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto contract = [&](int h) {
+#pragma unroll
+        for (int u = h * kHalf; u < (h + 1) * kHalf; ++u) {
+            const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bias_acc[c] += av[c];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[d], acc[c][d], 0, 0, 0);
+            }
+        }
+    };
+    fetch(0, n_begin);
+    for (int64_t n0 = n_begin; n0 < n_end; n0 += 4 * kSteps) {
+        fetch(1, n0);
+        contract(0);
+        fetch(0, n0 + 4 * kSteps);
+        contract(1);
+    }
+    // every wave owns its block: straight to partial[group][bi*KB + bj][64][64]; tile (c, d), register reg of lane (i, kq) is element
+    // [4*(4*kq + reg) + c][4*i + d] of the block (as in k_weight_grad64)
+    float* out = partial + (((int64_t)blockIdx.x * (MB * KB) + wave) << 12);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            *(float4*)(out + (4 * (4 * kq + reg) + c) * 64 + 4 * i) = make_float4(acc[c][0][reg], acc[c][1][reg], acc[c][2][reg], acc[c][3][reg]);
+    if (partial_bias && bj == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = bias_acc[c];
+            v += __shfl_xor(v, 16, kWave);
+            v += __shfl_xor(v, 32, kWave);
+            if (kq == 0) partial_bias[((int64_t)blockIdx.x * MB + bi) * 64 + 4 * i + c] = v;
+        }
+    }
+}
+
+// groups = workgroups resident at once (asked from the runtime once per shape), never more than the workspace formula provides
+template <int MB, int KB>
+static int launch_weight_grad_blocks(hipStream_t st, const float* dH, const float* X, int64_t n_rows, int64_t max_groups, float* partial,
+                                     float* partial_bias, int64_t* groups_out) {
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_weight_grad_blocks<MB, KB>, 64 * MB * KB, 0));
+        PP_HIP(hipGetDevice(&dev));
+        PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+    }
+    int64_t groups = ceil_div(n_rows > 0 ? n_rows : 1, 128);
+    if (groups > resident) groups = resident;
+    if (groups > max_groups) groups = max_groups;
+    const int64_t rows_per_group = ceil_div(ceil_div(n_rows > 0 ? n_rows : 1, groups), 4) * 4;
+    groups = ceil_div(n_rows > 0 ? n_rows : 1, rows_per_group);
+    k_weight_grad_blocks<MB, KB><<<(unsigned)groups, 64 * MB * KB, 0, st>>>(dH, X, n_rows, rows_per_group, partial, partial_bias);
+    *groups_out = groups;
+    return PP_OK;
+}
+
+static int launch_weight_grad_blocks_any(int mb, int kb, hipStream_t st, const float* dH, const float* X, int64_t n_rows, int64_t max_groups,
+                                         float* partial, float* partial_bias, int64_t* groups_out) {
+#define PP_WGB(A, B) if (mb == A && kb == B) return launch_weight_grad_blocks<A, B>(st, dH, X, n_rows, max_groups, partial, partial_bias, groups_out)
+    PP_WGB(1, 2); PP_WGB(2, 1); PP_WGB(2, 2); PP_WGB(1, 4); PP_WGB(4, 1); PP_WGB(2, 4); PP_WGB(4, 2); PP_WGB(4, 4);
+#undef PP_WGB
+    return PP_ERR_ARG;
+}
+
+static inline bool weight_grad_blocks_shape(int M, int K) {
+    const int mb = M / 64, kb = K / 64;
+    return M % 64 == 0 && K % 64 == 0 && mb * kb > 1 && (mb == 1 || mb == 2 || mb == 4) && (kb == 1 || kb == 2 || kb == 4);
 }
 
 __global__ __launch_bounds__(kBlock) void k_weight_grad_reduce(const float* __restrict__ partial, const float* __restrict__ partial_bias,
@@ -972,6 +1091,17 @@ int pp_weight_grad_f32(const float* dH, const float* X, int64_t n_rows, int M, i
         const int outs64 = M * K + (db ? M : 0);
         pp::k_weight_grad_reduce<<<(unsigned)pp::ceil_div(outs64, pp::kBlock / pp::kWgSlices), pp::kBlock, 0, st>>>(
             partial, db ? partial_bias : nullptr, waves4 / pp::kWavesPerBlock, M, K, dW, db);
+        PP_LAUNCH_CHECK();
+        return PP_OK;
+    }
+    if (pp::weight_grad_blocks_shape(M, K) && (((uintptr_t)dH | (uintptr_t)X) % 16 == 0)) {
+        int64_t groups = 0;
+        const int rc = pp::launch_weight_grad_blocks_any(M / 64, K / 64, st, dH, X, n_rows, parts, partial, db ? partial_bias : nullptr, &groups);
+        if (rc != PP_OK) return rc;
+        PP_LAUNCH_CHECK();
+        const int outs_b = M * K + (db ? M : 0);
+        pp::k_weight_grad_reduce<<<(unsigned)pp::ceil_div(outs_b, pp::kBlock / pp::kWgSlices), pp::kBlock, 0, st>>>(
+            partial, db ? partial_bias : nullptr, groups, M, K, dW, db);
         PP_LAUNCH_CHECK();
         return PP_OK;
     }

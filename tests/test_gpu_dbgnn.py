@@ -110,7 +110,8 @@ def test_reference_dbgnn_smoke(pp):
     torch.testing.assert_close(model(data).detach().cpu(), od.forward(params, cpu_data), rtol=RTOL, atol=ATOL)
 
 
-@pytest.mark.parametrize("n,m,k", [(1, 1, 1), (100, 8, 64), (5000, 64, 64), (70_001, 64, 64), (3000, 40, 100), (2000, 256, 128), (999, 3, 70)])
+@pytest.mark.parametrize("n,m,k", [(1, 1, 1), (100, 8, 64), (5000, 64, 64), (70_001, 64, 64), (3000, 40, 100), (2000, 256, 128), (999, 3, 70),
+                                   (40_003, 128, 128), (7, 128, 64), (1234, 64, 256), (9001, 256, 256), (513, 128, 256)])
 def test_weight_grad_kernel(pp, n, m, k):
     from pathpyg_amd import _hip
     g = torch.Generator().manual_seed(n + m + k)
