@@ -91,6 +91,39 @@ def _is_lexsorted(index):
     return bool(ok.all())
 
 
+def test_headline_10m_events_lift_matches_oracle_exactly(pp):
+    """The workload bench.py times (10^7 events, 5*10^5 nodes, delta = 10 % of the span): the k=2 event graph bit-for-bit against the
+    vectorised CPU oracle, and the aggregated layers through exact invariants (the CPU aggregation of 2*10^7 pairs takes minutes)."""
+    from oracle import lift as ol
+    from oracle import model as om
+    n, m, delta = 500_000, 10_000_000, 1_000_000
+    ei, t = _stream(1, m, n, 10_000_000)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=n))
+    sei, st, _ = om.stable_time_sort(ei.cpu(), t.cpu())
+    assert torch.equal(g.data.edge_index.cpu(), sei) and torch.equal(g.data.time.cpu(), st)
+    ho = pp.algorithms.lift_order_temporal(g, delta)
+    assert torch.equal(ho.cpu(), ol.temporal_lift_sorted(sei, st, delta, n))
+    model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=2, event_graph=ho)
+    d1, d2 = model.layers[1].data, model.layers[2].data
+    # layer 1 = distinct (u, v) pairs with multiplicities; layer 2 nodes = the same pairs, in the same (lexicographic) order
+    pair = sei[0] * n + sei[1]
+    uniq, counts = torch.unique(pair, return_counts=True)
+    assert torch.equal((d1.edge_index[0] * n + d1.edge_index[1]).cpu(), uniq)
+    assert torch.equal(d1.edge_weight.cpu(), counts.float())
+    assert torch.equal((d2.node_sequence[:, 0] * n + d2.node_sequence[:, 1]).cpu(), uniq)
+    assert torch.equal(d2.inverse_idx.cpu(), torch.searchsorted(uniq, pair))
+    assert _is_lexsorted(d2.edge_index) and float(d2.edge_weight.double().sum()) == float(ho.size(1))
+    # every aggregated second-order edge is the image of the instance pairs that map onto it: spot-check 2000 of them exactly
+    inv = d2.inverse_idx
+    key = inv[ho[0]] * d2.num_nodes + inv[ho[1]]
+    rng = np.random.default_rng(1)
+    pick = torch.from_numpy(rng.integers(0, d2.edge_index.size(1), 2000)).to(DEV)
+    want = d2.edge_index[0][pick] * d2.num_nodes + d2.edge_index[1][pick]
+    skey = key.sort().values
+    lo, hi = torch.searchsorted(skey, want), torch.searchsorted(skey, want, right=True)
+    assert torch.equal((hi - lo).float(), d2.edge_weight[pick])
+
+
 def test_config2_20m_scale_free_lift_properties(pp):
     from oracle import lift as ol
     n, m = 1_000_000, 20_000_000
