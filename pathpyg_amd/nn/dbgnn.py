@@ -116,12 +116,10 @@ class _GcnLayer(torch.autograd.Function):
 
     @staticmethod
     def supported(plan, x, weight) -> bool:
-        # The kernels take any size (64-bit row offsets from 4 GiB on), but on 10^8-row layers (25 GB matrices) the two-kernel path
-        # is the faster one: its gather kernel keeps twice the waves in flight under the long latencies of TLB-missing row
-        # gathers (measured: 255 vs 544 ms per step at 10^8 events) - the fused layer is used below 4 GiB per matrix.
+        # any size: from 4 GiB per matrix on the kernels switch to 64-bit row offsets (10^8-row layers, 25.6 GB matrices: 218 ms per
+        # step against 243 ms on the two-kernel path; 2*10^7 rows: 41 against 46 ms)
         return (plan.self_coef is not None and plan.n_dst == plan.n_src == x.size(0) and x.dtype == torch.float32
-                and _hip.dense_supported(weight.size(1), weight.size(0))
-                and x.size(0) * max(weight.size(0), weight.size(1)) * 4 < (1 << 32))
+                and _hip.dense_supported(weight.size(1), weight.size(0)))
 
     @staticmethod
     def forward(ctx, plan, x, weight, bias, fuse_act: bool, act_bias):

@@ -201,3 +201,24 @@ def test_fused_gcn_kernels_with_matrices_beyond_4_gib(pp):
         torch.testing.assert_close(d_in[rows], want_in[rows], rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(dw, want_dw, rtol=1e-3, atol=1e-3 * float(want_dw.abs().max()))
     torch.testing.assert_close(colsum, want_sum, rtol=1e-3, atol=1e-3 * float(want_sum.abs().max()))
+    # the same matrices with hub rows handed over (kHeavy + kWide kernel instances): rows of > 512 entries come from the chunked pre-pass
+    del d_in, want_in, gsum
+    deg = torch.bincount(torch.randint(0, n, (e - 6000,), generator=g, device=DEV), minlength=n)
+    deg[n - 7] += 4000                                                   # a hub beyond the 4 GiB mark
+    deg[12345] += 2000
+    ptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
+    del deg
+    heavy = _hip.HeavyRows(ptr, n)
+    assert heavy.n_heavy == 2
+    fused_h = _hip.gcn_forward(ptr, idx, val, n, x, sc, w, b, True, heavy=heavy)
+    split_h = _hip.spmm(ptr, idx, val, n, _hip.dense(x, w, True)[0], sc, None, b, True)
+    for rows in (slice(0, 100_000), slice(n - 100_000, n)):
+        torch.testing.assert_close(fused_h[rows], split_h[rows], rtol=1e-4, atol=1e-4)
+    assert float((fused_h - split_h).abs().max()) < 1e-3
+    del split_h
+    d_in, colsum, dw = _hip.gcn_backward(ptr, idx, val, n, dpre, sc, fused_h, w, True, True, heavy=heavy)
+    gsum = _hip.spmm(ptr, idx, val, n, dpre, sc, dpre)
+    want_in, want_sum, want_dw, _ = _hip.dense_backward(gsum, fused_h, w, True, True, True, False)
+    for rows in (slice(0, 100_000), slice(n - 100_000, n)):
+        torch.testing.assert_close(d_in[rows], want_in[rows], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dw, want_dw, rtol=1e-3, atol=1e-3 * float(want_dw.abs().max()))

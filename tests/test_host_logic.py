@@ -30,6 +30,11 @@ def test_library_exports_every_declared_symbol():
     assert handle.pp_sort_ws_bytes(4096, 4) >= 4096 * 8
     assert handle.pp_weight_grad_ws_bytes(1000, 64, 64) >= 64 * 64 * 4
     assert handle.pp_gcn_plan_ws_bytes(100, 10) > 0
+    # the {size, status} header of a workspace sits at its start: the accessors are host-side pointer casts
+    buf = ctypes.create_string_buffer(64)
+    for accessor in (handle.pp_lift_result_ptr, handle.pp_aggregate_result_ptr, handle.pp_plan_result_ptr):
+        got = accessor(ctypes.cast(buf, ctypes.c_void_p))
+        assert ctypes.cast(got, ctypes.c_void_p).value == ctypes.addressof(buf)
 
 
 def test_library_is_a_plain_c_abi_without_torch():
