@@ -249,9 +249,12 @@ int pp_dense_backward_f32(const float* dH, const float* X, const float* W, int64
  * makes a round trip through HBM:
  *   Y[r, :Q] = act( (sum_e val[e] X[idx[e], :P] + self_coef[r] X[r, :P]) . W^T + bias ),   W is [Q,P] (Linear layout), act 0/1 (ELU)
  * over the destination-major CSR of a pp_gcn_plan (self_coef may be NULL: no self term); X has n_src rows (rows are addressed by
- * 32-bit byte offsets below 4 GiB, by 64-bit ones above).  P, Q in {16,32,64}.
+ * 32-bit byte offsets below 4 GiB, by 64-bit ones above).  P, Q in {16,32,64}, and the 128-wide shapes 64x128, 128x64, 128x128 (W then
+ * fills 32-64 KB of LDS: one workgroup of 8 waves per CU).  pp_gcn_fused_supported(P, Q): 1 = forward + pp_gcn_backward_f32,
+ * 2 = forward + pp_gcn_input_grad_f32 (128-wide), 0 = unsupported shape.
  * agg_out [n_rows,P] or NULL: also store the aggregated input A_hat X; the weight gradient of a layer whose input needs no
  * gradient is then dW = dpre^T agg_out (pp_weight_grad_f32) without any backward aggregation. */
+int pp_gcn_fused_supported(int P, int Q);
 int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
                        const float* self_coef, const float* W, int Q, const float* bias, int act, const int32_t* heavy_slot, const float* heavy_sum,
                        float* agg_out, float* Y, pp_stream_t stream);
@@ -264,6 +267,15 @@ size_t pp_gcn_backward_ws_bytes(int64_t n_rows);
 int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
                         const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
                         const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, pp_stream_t stream);
+
+/* Input gradient of a 128-wide fused layer (GCNConv backward, reference nn/dbgnn.py:131-140 through autograd): the forward kernel over the
+ * source-major CSR with a gradient epilogue,  d_in[n_rows,K] = ((A^T D + diag(self_coef) D) . W) (*) ELU'(X_act) when fuse_act,
+ * colsum_in[K] (may be NULL) = column sums of d_in.  D = dpre [n_rows,M], W [M,K]; shapes 64x128, 128x64, 128x128.  The weight gradient
+ * of such a layer is dW = dpre^T (A_hat X) with the agg_out of its forward call (pp_weight_grad_f32): 64 accumulator registers per
+ * 64x64 block do not fit beside the gather here. */
+int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
+                          const float* self_coef, const float* W, int K, const float* X_act, int fuse_act, const int32_t* heavy_slot,
+                          const float* heavy_sum, float* d_in, float* colsum_in, pp_stream_t stream);
 
 /* All-pairs shortest time-respecting paths (temporal_shortest_paths, src/pathpyG/algorithms/temporal.py:57-107: scipy Dijkstra with
  * unit weights on the event DAG augmented by a virtual source and sink per node) as a frontier BFS per source node on the event graph:

@@ -700,6 +700,32 @@ def gcn_backward(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, x: t
     return d_in, colsum, dw
 
 
+def gcn_fused_supported(p: int, q: int) -> int:
+    """1: fused forward + one-kernel backward (widths 16/32/64); 2: fused forward + input-gradient kernel (128-wide shapes); 0: neither."""
+    return int(lib().pp_gcn_fused_supported(int(p), int(q)))
+
+
+def gcn_input_grad(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, weight: torch.Tensor, x_act: torch.Tensor | None,
+                   want_colsum: bool, heavy: HeavyRows | None = None):
+    """``((A^T dpre + diag(self_coef) dpre) @ weight) * elu'(x_act)`` (no activation factor when ``x_act`` is None) and optionally its
+    column sums, over the SOURCE-major CSR — the input gradient of a 128-wide fused layer."""
+    dev = require_device(ptr, idx, val, dpre, self_coef, weight, x_act)
+    dpre, weight = dpre.contiguous(), weight.contiguous()
+    m, k = weight.shape
+    if dpre.size(1) != m or dpre.size(0) != n_rows or (x_act is not None and tuple(x_act.shape) != (n_rows, k)):
+        raise ValueError("gcn_input_grad: shapes do not match")
+    if x_act is not None:
+        x_act = x_act.contiguous()
+    with torch.cuda.device(dev):
+        d_in = torch.empty((n_rows, k), dtype=torch.float32, device=dev)
+        colsum = torch.empty(k, dtype=torch.float32, device=dev) if want_colsum else None
+        slot, sums = _heavy_args(heavy, idx, val, dpre)
+        check(lib().pp_gcn_input_grad_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(dpre), m, _p(self_coef), _p(weight), k, _p(x_act),
+                                          1 if x_act is not None else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _stream()),
+              "pp_gcn_input_grad_f32")
+    return d_in, colsum
+
+
 def cross_entropy(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = True):
     """(mean cross-entropy [scalar tensor], d loss / d logits or None) in one pass; logits [N, C<=64] fp32, target int64 [N]."""
     dev = require_device(logits, target)

@@ -28,22 +28,32 @@ constexpr int kGcnWaves = kGcnThreads / kWave;
 // tiles' pointers, chunks and rows; 2 waves/SIMD) and a producer/consumer split (12 gather waves + 4 MFMA waves through an LDS
 // ring) both land on the same 2.0 ms: the kernel moves ~10 GB per launch through L2 at the ~5 TB/s this chip sustains for
 // 256-byte random rows, as do pp_dense_f32 + pp_spmm_f32 with their 12.6 GB in 2.4 ms.
-template <int P, int Q, bool kHeavy, bool kWide>   // kHeavy: the plan has hub rows; kWide: X is 4 GiB or larger (64-bit row offsets)
-__global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
-                                                                 const float* __restrict__ val, int64_t n_rows, const float* __restrict__ X,
-                                                                 const float* __restrict__ self_coef, const float* __restrict__ W,
-                                                                 const float* __restrict__ bias, int act, HeavyRows heavy,
-                                                                 float* __restrict__ agg_out, float* __restrict__ Y) {
+// kHeavy: the plan has hub rows; kWide: X is 4 GiB or larger (64-bit row offsets); kThreads: 256, or 512 for the 128-wide shapes (W alone
+// takes 64 KB of LDS there: one workgroup of 8 waves per CU).  kEpi 0: Y = act(tile . W^T + bias), W [Q,P] (the layer, forward).
+// kEpi 1: Y = (tile . W) (*) ELU'(act_in), W [P,Q], + column sums: the INPUT GRADIENT of a layer over the transposed graph (X = dpre) for
+// the widths whose weight gradient does not fit beside it in registers (pp_gcn_input_grad_f32).
+template <int P, int Q, bool kHeavy, bool kWide, int kThreads = kGcnThreads, int kEpi = 0>
+__global__ __launch_bounds__(kThreads) void k_gcn_forward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                              const float* __restrict__ val, int64_t n_rows, const float* __restrict__ X,
+                                                              const float* __restrict__ self_coef, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, int act, HeavyRows heavy,
+                                                              float* __restrict__ agg_out, float* __restrict__ Y,
+                                                              const float* __restrict__ act_in, float* __restrict__ colsum) {
     constexpr int kLanes = P / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = P / 4, CT = Q / 16, TS = P + 4;
-    constexpr int kBatch = kRows < 2 ? kRows : 2;
+    constexpr int kBatch = kRows < 2 ? kRows : (kRows >= 8 ? 4 : 2);      // 128-wide rows: 2 waves/SIMD, registers to spare for a deeper gather
+    constexpr int kWaves = kThreads / kWave;
     using off_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;     // byte offset of a gathered row
     __shared__ __attribute__((aligned(16))) float s_b[P * 16 * CT];
-    __shared__ __attribute__((aligned(16))) float s_tile[kGcnWaves][16 * TS];
-    // B[k][j] = W[j][k], stored [k][j]: lane i of output tile ct works on column CT*i + ct, so that a lane ends up with CT CONSECUTIVE
-    // output columns per row (one 16-byte store per row instead of four 4-byte ones) and reads its CT B values with one ds_read
-    for (int e = threadIdx.x; e < P * Q; e += kGcnThreads) {
-        const int j = e / P, k = e - j * P;
-        s_b[k * Q + j] = W[e];
+    __shared__ __attribute__((aligned(16))) float s_tile[kWaves][16 * TS];
+    // B[k][j] = W[j][k] (forward) or W[k][j] (input gradient), stored [k][j]: lane i of output tile ct works on column CT*i + ct, so that
+    // a lane ends up with CT CONSECUTIVE output columns per row (16-byte stores instead of 4-byte ones) and reads its CT B values at once
+    for (int e = threadIdx.x; e < P * Q; e += kThreads) {
+        if (kEpi == 0) {
+            const int j = e / P, k = e - j * P;
+            s_b[k * Q + j] = W[e];
+        } else {
+            s_b[e] = W[e];
+        }
     }
     __syncthreads();
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -55,17 +65,20 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
     for (int ct = 0; ct < CT; ++ct) bias_c[ct] = bias ? bias[CT * i + ct] : 0.f;
     const char* xb = (const char*)X;
     const int64_t n_tiles = (n_rows + 15) / 16;
-    const int64_t step = (int64_t)gridDim.x * kGcnWaves;
+    const int64_t step = (int64_t)gridDim.x * kWaves;
+    float col_in[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) col_in[ct] = 0.f;
     int p_next[kRows + 1];                              // row pointers of the wave's NEXT tile: one round trip off the critical path
     {
-        const int64_t t0 = (int64_t)blockIdx.x * kGcnWaves + wave;
+        const int64_t t0 = (int64_t)blockIdx.x * kWaves + wave;
 #pragma unroll
         for (int q = 0; q <= kRows; ++q) {
             const int64_t r = t0 * 16 + g * kRows + q;
             p_next[q] = t0 < n_tiles ? ptr[r < n_rows ? r : n_rows] : 0;
         }
     }
-    for (int64_t t = (int64_t)blockIdx.x * kGcnWaves + wave; t < n_tiles; t += step) {
+    for (int64_t t = (int64_t)blockIdx.x * kWaves + wave; t < n_tiles; t += step) {
         const int64_t r0 = t * 16 + g * kRows;
         int p[kRows + 1];
 #pragma unroll
@@ -158,6 +171,25 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
             }
         }
         __builtin_amdgcn_wave_barrier();
+        // input gradient: the activation rows of the epilogue (lane (i, kq): rows 4*kq .., columns CT*i ..) fly during the MFMAs
+        float xr[kEpi == 1 ? CT : 1][4];
+        if constexpr (kEpi == 1) if (act) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t r = t * 16 + 4 * kq + reg;
+                const float* xp = act_in + r * Q + CT * i;
+#pragma unroll
+                for (int c4 = 0; c4 < CT; c4 += 4) {
+                    if constexpr (CT >= 4) {
+                        const float4 v = r < n_rows ? *(const float4*)(xp + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        xr[c4][reg] = v.x; xr[c4 + 1][reg] = v.y; xr[c4 + 2][reg] = v.z; xr[c4 + 3][reg] = v.w;
+                    } else {
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) xr[ct][reg] = r < n_rows ? xp[ct] : 0.f;
+                    }
+                }
+            }
+        }
         float4 a[KQ / 4];
 #pragma unroll
         for (int c = 0; c < KQ / 4; ++c) a[c] = *(const float4*)(tile + i * TS + kq * KQ + 4 * c);
@@ -186,63 +218,109 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_forward(const int32_t* __re
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             float y[CT];
+            if constexpr (kEpi == 1) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ct += 2) {
-                if (ct + 1 < CT) {
-                    pp_f32x2 v = {out[ct][reg] + bias_c[ct], out[ct + 1][reg] + bias_c[ct + 1]};
-                    if (act) v = elu_fast2(v);
-                    y[ct] = v[0];
-                    y[ct + 1] = v[1];
-                } else {
-                    const float v = out[ct][reg] + bias_c[ct];
-                    y[ct] = act ? elu_fast(v) : v;
+                for (int ct = 0; ct < CT; ++ct) {
+                    y[ct] = out[ct][reg];
+                    if (act) {
+                        const float s = xr[ct][reg];
+                        y[ct] *= s > 0.f ? 1.f : s + 1.f;              // ELU'(pre) from the stored activation
+                    }
+                    col_in[ct] += y[ct];                               // rows past the end aggregate nothing: 0 there
+                }
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < CT; ct += 2) {
+                    if (ct + 1 < CT) {
+                        pp_f32x2 v = {out[ct][reg] + bias_c[ct], out[ct + 1][reg] + bias_c[ct + 1]};
+                        if (act) v = elu_fast2(v);
+                        y[ct] = v[0];
+                        y[ct + 1] = v[1];
+                    } else {
+                        const float v = out[ct][reg] + bias_c[ct];
+                        y[ct] = act ? elu_fast(v) : v;
+                    }
                 }
             }
             if (reg < rows_here) {
-                if constexpr (CT == 4) *(float4*)(yp + reg * Q) = make_float4(y[0], y[1], y[2], y[3]);
-                else if constexpr (CT == 2) *(float2*)(yp + reg * Q) = make_float2(y[0], y[1]);
+                if constexpr (CT >= 4) {
+#pragma unroll
+                    for (int c4 = 0; c4 < CT; c4 += 4) *(float4*)(yp + reg * Q + c4) = make_float4(y[c4], y[c4 + 1], y[c4 + 2], y[c4 + 3]);
+                } else if constexpr (CT == 2) *(float2*)(yp + reg * Q) = make_float2(y[0], y[1]);
                 else yp[reg * Q] = y[0];
             }
+        }
+    }
+    if (kEpi == 1) if (colsum != nullptr) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            float v = col_in[ct];
+            v += __shfl_xor(v, 16, kWave);
+            v += __shfl_xor(v, 32, kWave);
+            if (kq == 0) atomicAdd(&colsum[CT * i + ct], v);
         }
     }
 }
 
 // Persistent grid = exactly the workgroups that are resident at once (registers and LDS decide; asked from the runtime once).
-template <int P, int Q>
-static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                              const float* X, const float* self_coef, const float* W, const float* bias, int act, HeavyRows heavy, bool wide,
-                              float* agg_out, float* Y) {
+struct GcnArgs {
+    const int32_t *ptr, *idx;
+    const float* val;
+    int64_t n;
+    const float *X, *self_coef, *W, *bias;
+    int act;
+    HeavyRows heavy;
+    bool wide;
+    float *agg_out, *Y;
+    const float* act_in;
+    float* colsum;
+};
+
+template <int P, int Q, int kEpi>
+static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const GcnArgs& a) {
+    constexpr int kThreads = P * Q > 64 * 64 ? 512 : kGcnThreads;       // W of a 128-wide layer fills 32-64 KB of LDS: one workgroup per CU
     static int resident_of[2] = {0, 0};
-    const int hv = heavy.slot != nullptr ? 1 : 0;
+    const int hv = a.heavy.slot != nullptr ? 1 : 0;
     if (resident_of[hv] == 0) {
         int per_cu = 0, dev = 0, cus = 0;
-        if (hv) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q, true, false>, kGcnThreads, 0));
-        else PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q, false, false>, kGcnThreads, 0));
+        if (hv) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q, true, false, kThreads, kEpi>, kThreads, 0));
+        else PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward<P, Q, false, false, kThreads, kEpi>, kThreads, 0));
         PP_HIP(hipGetDevice(&dev));
         PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         resident_of[hv] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
     }
     const int resident = resident_of[hv];
-    int64_t blocks = ceil_div(n_tiles, kGcnWaves);
+    int64_t blocks = ceil_div(n_tiles, kThreads / kWave);
     if (blocks > resident) blocks = resident;
-#define PP_FWD(H, WIDE) k_gcn_forward<P, Q, H, WIDE><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, X, self_coef, W, bias, act, heavy, agg_out, Y)
-    if (heavy.slot != nullptr) { if (wide) PP_FWD(true, true); else PP_FWD(true, false); }
-    else { if (wide) PP_FWD(false, true); else PP_FWD(false, false); }
+#define PP_FWD(H, WIDE)                                                                                                                  \
+    k_gcn_forward<P, Q, H, WIDE, kThreads, kEpi><<<(unsigned)blocks, kThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n, a.X, a.self_coef, a.W, a.bias, \
+                                                                                         a.act, a.heavy, a.agg_out, a.Y, a.act_in, a.colsum)
+    if (a.heavy.slot != nullptr) { if (a.wide) PP_FWD(true, true); else PP_FWD(true, false); }
+    else { if (a.wide) PP_FWD(false, true); else PP_FWD(false, false); }
 #undef PP_FWD
     return PP_OK;
 }
 
 template <int P>
-static int launch_gcn_forward_q(int Q, int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
-                                const float* X, const float* self_coef, const float* W, const float* bias, int act, HeavyRows heavy, bool wide,
-                                float* agg_out, float* Y) {
+static int launch_gcn_forward_q(int Q, int64_t n_tiles, hipStream_t st, const GcnArgs& a) {
     switch (Q) {
-        case 16: return launch_gcn_forward<P, 16>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, wide, agg_out, Y);
-        case 32: return launch_gcn_forward<P, 32>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, wide, agg_out, Y);
-        case 64: return launch_gcn_forward<P, 64>(n_tiles, st, ptr, idx, val, n, X, self_coef, W, bias, act, heavy, wide, agg_out, Y);
+        case 16: return launch_gcn_forward<P, 16, 0>(n_tiles, st, a);
+        case 32: return launch_gcn_forward<P, 32, 0>(n_tiles, st, a);
+        case 64: return launch_gcn_forward<P, 64, 0>(n_tiles, st, a);
         default: return PP_ERR_ARG;
     }
 }
+
+// 128-wide shapes (64x128, 128x64, 128x128), forward (kEpi 0) and input gradient (kEpi 1)
+template <int kEpi>
+static int launch_gcn_wide(int P, int Q, int64_t n_tiles, hipStream_t st, const GcnArgs& a) {
+    if (P == 128 && Q == 128) return launch_gcn_forward<128, 128, kEpi>(n_tiles, st, a);
+    if (P == 64 && Q == 128) return launch_gcn_forward<64, 128, kEpi>(n_tiles, st, a);
+    if (P == 128 && Q == 64) return launch_gcn_forward<128, 64, kEpi>(n_tiles, st, a);
+    return PP_ERR_ARG;
+}
+
+static inline bool gcn_wide_shape(int P, int Q) { return (P == 128 && (Q == 64 || Q == 128)) || (P == 64 && Q == 128); }
 
 // =====================================================================================================
 // Backward of such a layer, again in one kernel (the math of pp_spmm_f32 on the transposed CSR + pp_dense_backward_f32):
@@ -514,25 +592,49 @@ static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const i
 
 extern "C" {
 
+int pp_gcn_fused_supported(int P, int Q) { return pp_dense_supported(P, Q) ? 1 : (pp::gcn_wide_shape(P, Q) ? 2 : 0); }
+
 int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
                        const float* self_coef, const float* W, int Q, const float* bias, int act, const int32_t* heavy_slot, const float* heavy_sum,
                        float* agg_out, float* Y, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_forward_f32: negative size");
-    PP_REQUIRE(pp_dense_supported(P, Q), PP_ERR_ARG, "pp_gcn_forward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", P, Q);
+    PP_REQUIRE(pp_gcn_fused_supported(P, Q), PP_ERR_ARG, "pp_gcn_forward_f32: unsupported layer shape %dx%d (supported: 16/32/64, 64/128 x 128, 128x64)", P, Q);
     PP_REQUIRE(act == 0 || act == 1, PP_ERR_ARG, "pp_gcn_forward_f32: act must be 0 (none) or 1 (elu)");
-    PP_REQUIRE(((uintptr_t)X | (uintptr_t)agg_out) % 16 == 0, PP_ERR_ARG, "pp_gcn_forward_f32: X and agg_out must be 16-byte aligned");
+    PP_REQUIRE(((uintptr_t)X | (uintptr_t)agg_out | (uintptr_t)Y) % 16 == 0, PP_ERR_ARG, "pp_gcn_forward_f32: X, Y and agg_out must be 16-byte aligned");
     PP_REQUIRE(n_src >= 0 && n_src < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_forward_f32: more than 2^31 source rows");
     const bool wide = (uint64_t)n_src * (uint64_t)P * 4 > 0xffffffffull;          // 64-bit row offsets from 4 GiB on
     if (n_rows == 0) return PP_OK;
     const int64_t n_tiles = pp::ceil_div(n_rows, 16);
-    const pp::HeavyRows heavy{heavy_slot, heavy_sum};
+    const pp::GcnArgs a{ptr, idx, val, n_rows, X, self_coef, W, bias, act, pp::HeavyRows{heavy_slot, heavy_sum}, wide, agg_out, Y, nullptr, nullptr};
     int rc;
-    switch (P) {
-        case 16: rc = pp::launch_gcn_forward_q<16>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, wide, agg_out, Y); break;
-        case 32: rc = pp::launch_gcn_forward_q<32>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, wide, agg_out, Y); break;
-        default: rc = pp::launch_gcn_forward_q<64>(Q, n_tiles, st, ptr, idx, val, n_rows, X, self_coef, W, bias, act, heavy, wide, agg_out, Y); break;
+    if (pp::gcn_wide_shape(P, Q)) rc = pp::launch_gcn_wide<0>(P, Q, n_tiles, st, a);
+    else switch (P) {
+        case 16: rc = pp::launch_gcn_forward_q<16>(Q, n_tiles, st, a); break;
+        case 32: rc = pp::launch_gcn_forward_q<32>(Q, n_tiles, st, a); break;
+        default: rc = pp::launch_gcn_forward_q<64>(Q, n_tiles, st, a); break;
     }
+    if (rc != PP_OK) return rc;
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
+                          const float* self_coef, const float* W, int K, const float* X_act, int fuse_act, const int32_t* heavy_slot,
+                          const float* heavy_sum, float* d_in, float* colsum_in, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_input_grad_f32: negative size");
+    PP_REQUIRE(pp::gcn_wide_shape(M, K), PP_ERR_ARG, "pp_gcn_input_grad_f32: unsupported layer shape %dx%d (64/128 x 128, 128x64)", M, K);
+    PP_REQUIRE(d_in != nullptr && (!fuse_act || X_act != nullptr), PP_ERR_ARG, "pp_gcn_input_grad_f32: d_in (and X_act with fuse_act) required");
+    PP_REQUIRE(((uintptr_t)D | (uintptr_t)X_act | (uintptr_t)d_in) % 16 == 0, PP_ERR_ARG, "pp_gcn_input_grad_f32: D, X_act and d_in must be 16-byte aligned");
+    PP_REQUIRE(n_rows < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_input_grad_f32: more than 2^31 rows");
+    const bool wide = (uint64_t)n_rows * (uint64_t)M * 4 > 0xffffffffull;
+    if (colsum_in) PP_HIP(hipMemsetAsync(colsum_in, 0, (size_t)K * sizeof(float), st));
+    if (n_rows == 0) return PP_OK;
+    const int64_t n_tiles = pp::ceil_div(n_rows, 16);
+    const pp::GcnArgs a{ptr, idx, val, n_rows, D, self_coef, W, nullptr, fuse_act ? 1 : 0, pp::HeavyRows{heavy_slot, heavy_sum}, wide, nullptr, d_in,
+                        X_act, colsum_in};
+    const int rc = pp::launch_gcn_wide<1>(M, K, n_tiles, st, a);
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();
     return PP_OK;

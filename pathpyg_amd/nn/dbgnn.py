@@ -119,7 +119,7 @@ class _GcnLayer(torch.autograd.Function):
         # any size: from 4 GiB per matrix on the kernels switch to 64-bit row offsets (10^8-row layers, 25.6 GB matrices: 218 ms per
         # step against 243 ms on the two-kernel path; 2*10^7 rows: 41 against 46 ms)
         return (plan.self_coef is not None and plan.n_dst == plan.n_src == x.size(0) and x.dtype == torch.float32
-                and _hip.dense_supported(weight.size(1), weight.size(0)))
+                and _hip.gcn_fused_supported(weight.size(1), weight.size(0)) > 0)
 
     @staticmethod
     def forward(ctx, plan, x, weight, bias, fuse_act: bool, act_bias):
@@ -127,24 +127,41 @@ class _GcnLayer(torch.autograd.Function):
         # first layer of a stack (its input needs no gradient): keep the aggregated input A x; the only gradient left is
         # dW = dpre^T (A x), so the backward pass needs no aggregation at all
         ctx.keep_agg = not ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
-        out = _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x, plan.self_coef, weight, bias, True, ctx.keep_agg,
+        # 128-wide layers: the 128 x 128 weight gradient does not fit in registers beside the gather, so A x is always kept for it and the
+        # input gradient comes from the forward kernel with a gradient epilogue (pp_gcn_input_grad_f32)
+        ctx.wide = _hip.gcn_fused_supported(weight.size(1), weight.size(0)) == 2
+        want_agg = ctx.keep_agg or (ctx.wide and ctx.needs_input_grad[2])
+        out = _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x, plan.self_coef, weight, bias, True, want_agg,
                                heavy=plan.fwd_heavy)
         if ctx.keep_agg:
             ctx.save_for_backward(out[1], weight)
             return out[0]
+        if ctx.wide:
+            y, agg = out if want_agg else (out, None)
+            ctx.save_for_backward(x, weight, agg)
+            return y
         ctx.save_for_backward(x, weight)
         return out
 
     @staticmethod
     def backward(ctx, dpre):
         plan = ctx.plan
-        x, weight = ctx.saved_tensors
         dpre = dpre.contiguous()
         dx = dw = dact = None
         if ctx.keep_agg:
-            dw, _ = _hip.weight_grad(dpre, x, want_bias=False)           # x is the stored A x here
+            agg, weight = ctx.saved_tensors
+            dw, _ = _hip.weight_grad(dpre, agg, want_bias=False)
             return None, None, dw, None, None, None
         want_sum = ctx.fuse_act and ctx.has_act_bias and ctx.needs_input_grad[5]
+        if ctx.wide:
+            x, weight, agg = ctx.saved_tensors
+            if ctx.needs_input_grad[2]:
+                dw, _ = _hip.weight_grad(dpre, agg, want_bias=False)
+            if ctx.needs_input_grad[1]:
+                dx, dact = _hip.gcn_input_grad(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, weight,
+                                               x if ctx.fuse_act else None, want_sum, heavy=plan.bwd_heavy)
+            return None, dx, dw, None, None, dact
+        x, weight = ctx.saved_tensors
         if ctx.needs_input_grad[1]:
             # aggregation over the transposed graph, input gradient (+ ELU' and the bias gradient of the layer below) and dW: one kernel
             dx, dact, dw = _hip.gcn_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, x, weight,

@@ -57,6 +57,8 @@ def _to_module(pp, params, num_classes, num_features, hidden):
     (2, 50, 20, 40, 0, (5, 7), [6, 10, 3], "first"),                # scalar-width kernels, empty higher-order graph
     (3, 120, 900, 500, 1500, (16, 16), [32, 16], "both"),            # single GCN layer per order
     (4, 3000, 40000, 20000, 60000, (64, 64), [128, 256, 64], "last"),
+    (5, 2500, 30000, 12000, 40000, (128, 128), [128, 128, 128], "last"),   # BASELINE configs[3] widths: 128-wide fused layers
+    (6, 800, 9000, 3000, 9000, (64, 128), [128, 64, 32], "last"),          # 64 -> 128 -> 64 stacks mix both kinds of fused layer
 ])
 def test_dbgnn_forward_backward_matches_oracle(pp, seed, n, e, n_ho, e_ho, f, hidden, mapping):
     from oracle import dbgnn as od
@@ -227,6 +229,8 @@ def test_dense_backward_kernel(pp, n, m, k):
     (1, 0, 16, 16, True, True), (17, 40, 64, 64, True, True), (1000, 5000, 32, 64, True, False), (4097, 9000, 64, 16, True, True),
     (70_001, 200_000, 64, 64, True, True), (300, 20_000, 64, 32, True, True),          # last: rows far longer than one index chunk
     (500, 700, 16, 32, False, True), (2000, 3000, 64, 64, False, False),
+    (17, 40, 128, 128, True, True), (5000, 30_000, 128, 128, True, True), (3000, 9000, 64, 128, True, False), (4097, 9000, 128, 64, True, True),
+    (1, 0, 128, 128, True, True), (900, 5000, 128, 128, False, True),             # 128-wide shapes: 8 waves per workgroup around one W in LDS
 ])
 def test_fused_gcn_layer_kernel(pp, n, e, p, q, with_self, weighted):
     """pp_gcn_forward_f32 (aggregate, then multiply on the matrix cores) against a float64 evaluation of the reference order
@@ -327,6 +331,41 @@ def test_fused_gcn_backward_kernel(pp, n, e, m, k, fuse):
     torch.testing.assert_close(got_w.cpu(), dw.float(), rtol=1e-4, atol=2e-6 * wscale)
 
 
+@pytest.mark.parametrize("n,e,m,k,fuse", [(1, 0, 128, 128, True), (17, 40, 128, 128, True), (5000, 30_000, 128, 128, True), (3000, 9000, 64, 128, False),
+                                          (4097, 9000, 128, 64, True), (300, 20_000, 128, 128, True)])
+def test_fused_gcn_input_grad_kernel(pp, n, e, m, k, fuse):
+    """pp_gcn_input_grad_f32 (128-wide layers) against float64: d_in = ((A^T dpre + self*dpre) W) * elu'(x) and its column sums."""
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(n + e + m + k)
+    row = torch.sort(torch.randint(0, n, (e,), generator=g)).values
+    if n > 10 and e > 100:
+        row[: min(e // 4, 2000)] = row[min(e // 4, 2000)]
+        row = torch.sort(row).values
+    ptr = torch.zeros(n + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.bincount(row, minlength=n), 0).int()
+    idx = torch.randint(0, n, (max(e, 1),), generator=g, dtype=torch.int32)[:e]
+    val = torch.rand(e, generator=g)
+    self_coef = torch.rand(n, generator=g)
+    dpre = torch.randn(n, m, generator=g)
+    x = F.elu(torch.randn(n, k, generator=g))
+    w = torch.randn(m, k, generator=g) / m ** 0.5
+    a = torch.zeros(n, n, dtype=torch.float64)
+    a.index_put_((row, idx.long()), val.double(), accumulate=True)
+    a += torch.diag(self_coef.double())
+    d_in = (a @ dpre.double()) @ w.double()
+    if fuse:
+        d_in = d_in * torch.where(x > 0, torch.ones_like(x), x + 1).double()
+    assert _hip.gcn_fused_supported(m, k) == 2 and _hip.gcn_fused_supported(64, 64) == 1 and _hip.gcn_fused_supported(48, 64) == 0
+    got_in, got_sum = _hip.gcn_input_grad(ptr.to(DEV), idx.to(DEV), val.to(DEV), n, dpre.to(DEV), self_coef.to(DEV), w.to(DEV),
+                                          x.to(DEV) if fuse else None, True)
+    scale = float(d_in.abs().max()) + 1e-12
+    torch.testing.assert_close(got_in.cpu(), d_in.float(), rtol=RTOL, atol=max(ATOL, 1e-6 * scale))
+    torch.testing.assert_close(got_sum.cpu(), d_in.sum(0).float(), rtol=1e-4, atol=1e-5 * float(d_in.abs().sum(0).max() + 1))
+    none_in, none_sum = _hip.gcn_input_grad(ptr.to(DEV), idx.to(DEV), val.to(DEV), n, dpre.to(DEV), self_coef.to(DEV), w.to(DEV),
+                                            x.to(DEV) if fuse else None, False)
+    assert none_sum is None and torch.equal(none_in, got_in)
+
+
 def _hub_bundle(seed, n, e, n_ho, e_ho, f, hub_share=0.4):
     """Like _bundle, but a large share of all edges points at (and leaves from) a handful of hub nodes: rows far beyond
     HEAVY_ROW_ENTRIES in both CSR directions of both graphs and of the bipartite map."""
@@ -352,7 +391,7 @@ def _hub_bundle(seed, n, e, n_ho, e_ho, f, hub_share=0.4):
     return data, torch.randint(0, 3, (n,), generator=g)
 
 
-@pytest.mark.parametrize("f,hidden", [(32, [32, 32, 16]), (20, [24, 40, 8])])        # fused kernels / generic SpMM + library GEMM
+@pytest.mark.parametrize("f,hidden", [(32, [32, 32, 16]), (20, [24, 40, 8]), (128, [128, 128, 64])])   # fused / generic SpMM + library GEMM / 128-wide fused
 def test_dbgnn_with_hub_rows_matches_float64_oracle(pp, f, hidden):
     """Scale-free shape: rows with 10^4 entries go through the chunked hub pre-pass (pp_spmm_heavy_f32) in every kernel that walks
     CSR rows.  fp32 sums of 10^4 terms in a different order: compared with the float64 oracle at 2e-5 of the largest entry."""

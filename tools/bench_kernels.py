@@ -105,18 +105,30 @@ def main():
         report("spmm fwd fo", lambda: _hip.spmm(p1.fwd_ptr, p1.fwd_idx, p1.fwd_val, a.nodes, x1, p1.self_coef, None, bias, True))
     if "gcn" in ops:
         wq = torch.randn(f, f, device=dev) / 8
+        narrow = _hip.gcn_fused_supported(f, f) == 1
+
+        def lin(m):
+            return _hip.dense(m, wq, True)[0] if narrow else m @ wq.t()
+
         fused = _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, x, plan.self_coef, wq, bias, True)
-        split = _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, _hip.dense(x, wq, True)[0], plan.self_coef, None, bias, True)
+        split = _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, lin(x), plan.self_coef, None, bias, True)
         print("gcn_forward fused vs dense+spmm: max abs diff", float((fused - split).abs().max()), "max abs", float(split.abs().max()))
+        del fused, split
         report("gcn_forward fused (gather + MFMA + ELU)", lambda: _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, x, plan.self_coef, wq, bias, True), alg)
+        report("gcn_forward fused, keeping A x (first layer / 128-wide layers)", lambda: _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, x, plan.self_coef, wq, bias, True, True), alg + 4 * f * n_ho / 1e9)
         zp = torch.zeros_like(plan.fwd_ptr)
         report("gcn_forward fused on an EMPTY graph (self rows only: MFMA stage cost)", lambda: _hip.gcn_forward(zp, plan.fwd_idx, plan.fwd_val, n_ho, x, plan.self_coef, wq, bias, True), 8 * f * n_ho / 1e9)
-        report("dense + spmm (what it replaces)", lambda: _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, _hip.dense(x, wq, True)[0], plan.self_coef, None, bias, True), alg)
-    if "gcn" in ops:
+        report("dense + spmm (what it replaces)", lambda: _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, n_ho, lin(x), plan.self_coef, None, bias, True), alg)
         dpre = torch.randn(n_ho, f, device=dev)
         xa = torch.nn.functional.elu(torch.randn(n_ho, f, device=dev))
-        report("gcn_backward fused (gather + d_in + ELU' + colsum + dW)", lambda: _hip.gcn_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, n_ho, dpre, plan.self_coef, xa, wq, True, True))
-        report("spmm bwd + dense_backward (what it replaces)", lambda: _hip.dense_backward(_hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, n_ho, dpre, plan.self_coef, dpre), xa, wq, True, True, True, False))
+        if narrow:
+            report("gcn_backward fused (gather + d_in + ELU' + colsum + dW)", lambda: _hip.gcn_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, n_ho, dpre, plan.self_coef, xa, wq, True, True))
+            report("spmm bwd + dense_backward (what it replaces)", lambda: _hip.dense_backward(_hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, n_ho, dpre, plan.self_coef, dpre), xa, wq, True, True, True, False))
+        else:
+            report("gcn_input_grad fused (gather + d_in + ELU' + colsum)", lambda: _hip.gcn_input_grad(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, n_ho, dpre, plan.self_coef, wq, xa, True), alg + 4 * f * n_ho / 1e9)
+            report("weight_grad(dpre, A x) (the other half of the 128-wide backward)", lambda: _hip.weight_grad(dpre, xa, False), 8 * f * n_ho / 1e9)
+            report("spmm bwd + library GEMM + act_backward (what they replace, without dW)", lambda: _hip.act_backward(_hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, n_ho, dpre, plan.self_coef, dpre) @ wq, xa, True, True, True))
+        del dpre, xa
     if "dense" in ops:
         w = torch.randn(f, f, device=dev)
         y = torch.randn(n_ho, f, device=dev)
