@@ -222,3 +222,40 @@ def test_fused_gcn_kernels_with_matrices_beyond_4_gib(pp):
     for rows in (slice(0, 100_000), slice(n - 100_000, n)):
         torch.testing.assert_close(d_in[rows], want_in[rows], rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(dw, want_dw, rtol=1e-3, atol=1e-3 * float(want_dw.abs().max()))
+
+
+def test_wide_fused_gcn_kernels_with_matrices_beyond_4_gib(pp):
+    """128-wide layers on 8.6*10^6 rows (4.4 GB per matrix): forward (keeping A x) and input gradient with 64-bit row offsets against
+    pp_spmm_f32 + a library GEMM; the last rows lie beyond the 4 GiB mark."""
+    from pathpyg_amd import _hip
+    n, f, e = 8_600_000, 128, 12_000_000
+    g = torch.Generator(device=DEV).manual_seed(6)
+    ptr = torch.zeros(n + 1, dtype=torch.int32, device=DEV)
+    ptr[1:] = torch.cumsum(torch.bincount(torch.randint(0, n, (e,), generator=g, device=DEV), minlength=n), 0).to(torch.int32)
+    idx = torch.randint(0, n, (e,), generator=g, device=DEV, dtype=torch.int32)
+    idx[-1000:] = torch.randint(n - 1000, n, (1000,), generator=g, device=DEV, dtype=torch.int32)
+    val = torch.rand(e, generator=g, device=DEV)
+    sc = torch.rand(n, generator=g, device=DEV)
+    x = torch.randn(n, f, generator=g, device=DEV)
+    w = torch.randn(f, f, generator=g, device=DEV) / 11
+    b = torch.randn(f, generator=g, device=DEV)
+    y, agg = _hip.gcn_forward(ptr, idx, val, n, x, sc, w, b, True, True)
+    want_agg = _hip.spmm(ptr, idx, val, n, x, sc, x)
+    for rows in (slice(0, 50_000), slice(n - 50_000, n)):
+        torch.testing.assert_close(agg[rows], want_agg[rows], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(y[rows], torch.nn.functional.elu(want_agg[rows] @ w.t() + b), rtol=1e-4, atol=2e-4)
+    assert float((agg - want_agg).abs().max()) < 1e-3
+    del agg, want_agg
+    dpre = torch.randn(n, f, generator=g, device=DEV)
+    d_in, colsum = _hip.gcn_input_grad(ptr, idx, val, n, dpre, sc, w, y, True)
+    gsum = _hip.spmm(ptr, idx, val, n, dpre, sc, dpre)
+    del dpre
+    total = torch.zeros(f, dtype=torch.float64, device=DEV)
+    for lo in range(0, n, 1_000_000):
+        rows = slice(lo, min(lo + 1_000_000, n))
+        want = (gsum[rows] @ w) * torch.where(y[rows] > 0, torch.ones_like(y[rows]), y[rows] + 1)
+        total += want.double().sum(0)
+        if lo == 0 or rows.stop == n:
+            torch.testing.assert_close(d_in[rows], want, rtol=1e-4, atol=2e-4)
+        assert float((d_in[rows] - want).abs().max()) < 2e-3
+    torch.testing.assert_close(colsum.double(), total, rtol=1e-3, atol=1e-3 * float(total.abs().max()))
