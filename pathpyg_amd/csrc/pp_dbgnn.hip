@@ -29,14 +29,6 @@ __global__ __launch_bounds__(kBlock) void k_index_key(const int64_t* __restrict_
     keys[i] = (uint32_t)v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_last_self_loop(const int64_t* __restrict__ edge_index, int64_t n_edges, int64_t n_nodes,
-                                                          int32_t* __restrict__ last_loop) {
-    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (e >= n_edges) return;
-    const int64_t r = edge_index[e];
-    if (r >= 0 && r < n_nodes && r == edge_index[n_edges + e]) atomicMax(&last_loop[r], (int32_t)e);
-}
-
 __global__ __launch_bounds__(kBlock) void k_gcn_coefficients(const int64_t* __restrict__ edge_index, int64_t n_edges, const float* __restrict__ w,
                                                             const uint32_t* __restrict__ order, const float* __restrict__ dinv,
                                                             int by_dst, int32_t* __restrict__ idx_out, float* __restrict__ val_out) {
@@ -48,15 +40,32 @@ __global__ __launch_bounds__(kBlock) void k_gcn_coefficients(const int64_t* __re
     val_out[p] = r == c ? 0.0f : dinv[r] * (w ? w[e] : 1.0f) * dinv[c];
 }
 
-// validation pass over the sources that also packs (source, weight) of every edge into 8 bytes: the destination grouping below then
-// needs ONE random 8-byte read per edge instead of an 8-byte and a 4-byte one in different arrays
-__global__ __launch_bounds__(kBlock) void k_pack_sources(const int64_t* __restrict__ edge_index, int64_t n_edges, int64_t n_nodes,
-                                                        const float* __restrict__ w, uint2* __restrict__ packed, int64_t* __restrict__ status) {
+// pp_gcn_plan's one pass over the edge list: both endpoints validated, (source, weight) packed, the destination written as the sort key
+// of the forward grouping and the last self loop of every node recorded (one read of the edge list instead of three)
+__global__ __launch_bounds__(kBlock) void k_plan_edges(const int64_t* __restrict__ edge_index, int64_t n_edges, int64_t n_nodes,
+                                                      const float* __restrict__ w, uint2* __restrict__ packed, uint32_t* __restrict__ dst_keys,
+                                                      int32_t* __restrict__ last_loop, int32_t* __restrict__ src_ptr,
+                                                      int64_t* __restrict__ status) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= n_edges) return;
-    int64_t v = edge_index[e];
-    if (v < 0 || v >= n_nodes) { atomicOr((unsigned long long*)status, 1ull); v = 0; }
-    packed[e] = make_uint2((uint32_t)v, __float_as_uint(w ? w[e] : 1.0f));
+    int64_t r = edge_index[e], c = edge_index[n_edges + e];
+    if (src_ptr) {          // row-sorted edge list: the source-major row pointer falls out of the same read (rows between two sources)
+        int64_t a = e == 0 ? -1 : edge_index[e - 1], b = r;
+        if (a < -1) a = -1;
+        if (b > n_nodes) b = n_nodes;
+        for (int64_t v = a + 1; v <= b; ++v) src_ptr[v] = (int32_t)e;
+        if (e == n_edges - 1) {
+            a = r < -1 ? -1 : r;
+            for (int64_t v = a + 1; v <= n_nodes; ++v) src_ptr[v] = (int32_t)n_edges;
+        }
+    }
+    const bool bad_r = r < 0 || r >= n_nodes, bad_c = c < 0 || c >= n_nodes;
+    if (bad_r || bad_c) atomicOr((unsigned long long*)status, 1ull);
+    if (!bad_r && r == c) atomicMax(&last_loop[r], (int32_t)e);
+    if (bad_r) r = 0;
+    if (bad_c) c = 0;
+    packed[e] = make_uint2((uint32_t)r, __float_as_uint(w ? w[e] : 1.0f));
+    dst_keys[e] = (uint32_t)c;
 }
 
 // destination-grouped copies: in_idx[p] = source of the p-th incoming edge, w_by_dst[p] = its weight
@@ -364,7 +373,6 @@ struct PlanWs {
     uint32_t* keys;        // [E]
     uint32_t* sorted;      // [E]
     uint32_t* order;       // [E]
-    uint32_t* ptr;         // [N+1]
     int32_t* last_loop;    // [N]
     float* dinv;           // [N]
     uint2* packed;         // [E] (source, weight bits) per edge
@@ -380,7 +388,6 @@ static PlanWs carve_plan(void* ws, int64_t e, int64_t n) {
     w.keys = a.take<uint32_t>(e);
     w.sorted = a.take<uint32_t>(e);
     w.order = a.take<uint32_t>(e);
-    w.ptr = a.take<uint32_t>(n + 1);
     w.last_loop = a.take<int32_t>(n);
     w.dinv = a.take<float>(n);
     w.packed = a.take<uint2>(e);
@@ -391,16 +398,18 @@ static PlanWs carve_plan(void* ws, int64_t e, int64_t n) {
 }
 
 // group edge ids by `index` (stable): order[p] = edge id, ptr = CSR pointer over [0, n_groups]
-static int group_by(const int64_t* index, int64_t e, int64_t n_groups, PlanWs& w, hipStream_t st) {
+static int group_by(const int64_t* index, int64_t e, int64_t n_groups, PlanWs& w, int32_t* ptr_out, hipStream_t st, bool keys_ready = false) {
     const unsigned grid = (unsigned)ceil_div(e > 0 ? e : 1, kBlock);
     if (e > 0) {
-        k_index_key<<<grid, kBlock, 0, st>>>(index, e, n_groups, w.keys, w.status + 1);
-        PP_LAUNCH_CHECK();
+        if (!keys_ready) {
+            k_index_key<<<grid, kBlock, 0, st>>>(index, e, n_groups, w.keys, w.status + 1);
+            PP_LAUNCH_CHECK();
+        }
         int rc = sort_pairs<uint32_t>(w.keys, nullptr, w.sorted, w.order, e, 0, bits_for((uint64_t)(n_groups > 0 ? n_groups - 1 : 0)),
                                       w.scratch, w.scratch_bytes, st);
         if (rc != PP_OK) return rc;
     }
-    k_ptr_from_sorted_u32<<<(unsigned)ceil_div(e + 1, kBlock), kBlock, 0, st>>>(w.sorted, e, n_groups, w.ptr);
+    k_ptr_from_sorted_u32<<<(unsigned)ceil_div(e + 1, kBlock), kBlock, 0, st>>>(w.sorted, e, n_groups, (uint32_t*)ptr_out);   // < 2^31: same bits
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
@@ -519,20 +528,15 @@ int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_e
     if (n_nodes == 0) return PP_OK;
     const unsigned egrid = (unsigned)ceil_div(n_edges > 0 ? n_edges : 1, kBlock);
     const unsigned ngrid = (unsigned)ceil_div(n_nodes, kBlock);
-    const unsigned pgrid = (unsigned)ceil_div(n_nodes + 1, kBlock);
     PP_HIP(hipMemsetAsync(w.last_loop, 0xff, (size_t)n_nodes * sizeof(int32_t), st));     // -1
     if (n_edges > 0) {
-        // validate the sources before they are used as indices (the destinations are validated by group_by)
-        k_pack_sources<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, n_nodes, edge_weight, w.packed, w.status + 1);
-        PP_LAUNCH_CHECK();
-        k_last_self_loop<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, n_nodes, w.last_loop);
+        k_plan_edges<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, n_nodes, edge_weight, w.packed, w.keys, w.last_loop,
+                                               row_sorted ? out_ptr : nullptr, w.status + 1);
         PP_LAUNCH_CHECK();
     }
     // edges grouped by destination (forward aggregation): order[p] = edge id, sorted[p] = its destination
-    int rc = group_by(edge_index + n_edges, n_edges, n_nodes, w, st);
+    int rc = group_by(edge_index + n_edges, n_edges, n_nodes, w, in_ptr, st, true);
     if (rc != PP_OK) return rc;
-    k_u32_to_i32_ptr<<<pgrid, kBlock, 0, st>>>(w.ptr, n_nodes + 1, in_ptr);
-    PP_LAUNCH_CHECK();
     if (n_edges > 0) {
         k_gather_by_dst<<<egrid, kBlock, 0, st>>>(w.packed, n_edges, w.order, in_idx, in_val);
         PP_LAUNCH_CHECK();
@@ -541,7 +545,7 @@ int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_e
             PP_LAUNCH_CHECK();
         }
     }
-    k_gcn_degree_grouped<<<ngrid, kBlock, 0, st>>>(in_idx, in_val, w.ptr, w.last_loop, edge_weight, n_nodes, w.dinv, self_coef);
+    k_gcn_degree_grouped<<<ngrid, kBlock, 0, st>>>(in_idx, in_val, (const uint32_t*)in_ptr, w.last_loop, edge_weight, n_nodes, w.dinv, self_coef);
     PP_LAUNCH_CHECK();
     if (n_edges > 0) {
         k_in_coefficients<<<egrid, kBlock, 0, st>>>(in_idx, w.sorted, w.dinv, n_edges, in_val);
@@ -549,18 +553,18 @@ int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_e
     }
     // edges grouped by source (backward = transposed aggregation)
     if (row_sorted) {       // De Bruijn layers come out of coalesce (row, col)-sorted: the edge order already is the grouping
-        k_ptr_from_sorted_i64_i32<<<(unsigned)ceil_div(n_edges + 1, kBlock), kBlock, 0, st>>>(edge_index, n_edges, n_nodes, out_ptr);
-        PP_LAUNCH_CHECK();
+        if (n_edges == 0) {  // (with edges, k_plan_edges wrote the row pointer)
+            k_ptr_from_sorted_i64_i32<<<1, kBlock, 0, st>>>(edge_index, 0, n_nodes, out_ptr);
+            PP_LAUNCH_CHECK();
+        }
         if (n_edges > 0) {
             k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, nullptr, w.dinv, 0, out_idx, out_val);
             PP_LAUNCH_CHECK();
         }
         return PP_OK;
     }
-    rc = group_by(edge_index, n_edges, n_nodes, w, st);
+    rc = group_by(edge_index, n_edges, n_nodes, w, out_ptr, st);
     if (rc != PP_OK) return rc;
-    k_u32_to_i32_ptr<<<pgrid, kBlock, 0, st>>>(w.ptr, n_nodes + 1, out_ptr);
-    PP_LAUNCH_CHECK();
     if (n_edges > 0) {
         k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, w.dinv, 0, out_idx, out_val);
         PP_LAUNCH_CHECK();
@@ -584,10 +588,8 @@ int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n
         k_index_key<<<egrid, kBlock, 0, st>>>(bipartite_index, n_pairs, n_ho, w.keys, w.status + 1);
         PP_LAUNCH_CHECK();
     }
-    int rc = group_by(bipartite_index + n_pairs, n_pairs, n_fo, w, st);           // by first-order destination
+    int rc = group_by(bipartite_index + n_pairs, n_pairs, n_fo, w, in_ptr, st);   // by first-order destination
     if (rc != PP_OK) return rc;
-    k_u32_to_i32_ptr<<<(unsigned)ceil_div(n_fo + 1, kBlock), kBlock, 0, st>>>(w.ptr, n_fo + 1, in_ptr);
-    PP_LAUNCH_CHECK();
     if (n_fo > 0) {
         k_ptr_diff_f32<<<(unsigned)ceil_div(n_fo, kBlock), kBlock, 0, st>>>(in_ptr, n_fo, in_degree);
         PP_LAUNCH_CHECK();
@@ -610,10 +612,8 @@ int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n
         }
         return PP_OK;
     }
-    rc = group_by(bipartite_index, n_pairs, n_ho, w, st);                        // by higher-order source
+    rc = group_by(bipartite_index, n_pairs, n_ho, w, out_ptr, st);               // by higher-order source
     if (rc != PP_OK) return rc;
-    k_u32_to_i32_ptr<<<(unsigned)ceil_div(n_ho + 1, kBlock), kBlock, 0, st>>>(w.ptr, n_ho + 1, out_ptr);
-    PP_LAUNCH_CHECK();
     if (n_pairs > 0) {
         k_gather_index<<<egrid, kBlock, 0, st>>>(bipartite_index + n_pairs, w.order, n_pairs, out_idx);
         PP_LAUNCH_CHECK();
