@@ -88,9 +88,24 @@ __global__ __launch_bounds__(kBlock) void k_gcn_degree_grouped(const int32_t* __
     const uint32_t p0 = live ? dst_ptr[i] : 0u, p1 = live ? dst_ptr[i + 1] : 0u;
     const bool is_long = p1 - p0 > 256u;                         // hub: summed by the whole wave below, not by this lane alone
     float deg = 0.0f;
-    if (!is_long)
-        for (uint32_t p = p0; p < p1; ++p)
-            if (in_idx[p] != (int32_t)i) deg += w_by_dst[p];
+    if (!is_long) {
+        // eight entries per round trip (an entry-by-entry walk pays one dependent load latency per entry: the longest row of the wave
+        // sets the pace); the sum stays strictly left to right
+        constexpr int kChunk = 8;
+        for (uint32_t p = p0; p < p1; p += kChunk) {
+            int32_t jj[kChunk];
+            float ww[kChunk];
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) {
+                const bool in = p + k < p1;
+                jj[k] = in ? in_idx[p + k] : (int32_t)i;
+                ww[k] = in ? w_by_dst[p + k] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+                if (jj[k] != (int32_t)i) deg += ww[k];
+        }
+    }
     // hub rows: the wave strides over the row with 8 independent loads in flight per lane (a lone lane needs ~1 us per entry: 3 ms for
     // a 10^5-entry row); waves work on different hubs in parallel, partial sums folded by a fixed-order butterfly
     for (uint64_t todo = __ballot(is_long); todo != 0; todo &= todo - 1) {
