@@ -321,17 +321,19 @@ static int coalesce_fill_impl(const void* weight, int dtype, int reduce, int64_t
 
 // ------------------------------------------------------------------ sortedness, argsort, CSR pointers
 __global__ __launch_bounds__(kBlock) void k_count_descents(const int64_t* __restrict__ a, int64_t n, int64_t* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    bool bad = i + 1 < n && a[i] > a[i + 1];
-    uint64_t vote = __ballot(bad);
-    if (lane_id() == 0 && vote) atomicAdd((unsigned long long*)out, (unsigned long long)__popcll(vote));
+    // grid-stride: at most one atomic per wave of a bounded grid (an unsorted 10^7-element input used to queue 1.6*10^5 of them on one word)
+    uint32_t mine = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i + 1 < n; i += (int64_t)gridDim.x * kBlock) mine += a[i] > a[i + 1] ? 1u : 0u;
+    const uint32_t total = wave_sum<uint32_t>(mine);
+    if (lane_id() == 0 && total) atomicAdd((unsigned long long*)out, (unsigned long long)total);
 }
 
 __global__ __launch_bounds__(kBlock) void k_count_descents_f64(const double* __restrict__ a, int64_t n, int64_t* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    bool bad = i + 1 < n && a[i] > a[i + 1];
-    uint64_t vote = __ballot(bad);
-    if (lane_id() == 0 && vote) atomicAdd((unsigned long long*)out, (unsigned long long)__popcll(vote));
+    // grid-stride: at most one atomic per wave of a bounded grid (an unsorted 10^7-element input used to queue 1.6*10^5 of them on one word)
+    uint32_t mine = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i + 1 < n; i += (int64_t)gridDim.x * kBlock) mine += a[i] > a[i + 1] ? 1u : 0u;
+    const uint32_t total = wave_sum<uint32_t>(mine);
+    if (lane_id() == 0 && total) atomicAdd((unsigned long long*)out, (unsigned long long)total);
 }
 
 // order-preserving map double -> uint64 (negative values: all bits flipped; others: sign bit set); -0.0 == +0.0
@@ -474,7 +476,7 @@ int pp_count_descents_i64(const int64_t* a, int64_t n, int64_t* descents, pp_str
     hipStream_t st = (hipStream_t)stream;
     PP_HIP(hipMemsetAsync(descents, 0, sizeof(int64_t), st));
     if (n < 2) return PP_OK;
-    k_count_descents<<<(unsigned)ceil_div(n, kBlock), kBlock, 0, st>>>(a, n, descents);
+    k_count_descents<<<(unsigned)(ceil_div(n, kBlock) < 2048 ? ceil_div(n, kBlock) : 2048), kBlock, 0, st>>>(a, n, descents);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
@@ -483,7 +485,7 @@ int pp_count_descents_f64(const double* a, int64_t n, int64_t* descents, pp_stre
     hipStream_t st = (hipStream_t)stream;
     PP_HIP(hipMemsetAsync(descents, 0, sizeof(int64_t), st));
     if (n < 2) return PP_OK;
-    k_count_descents_f64<<<(unsigned)ceil_div(n, kBlock), kBlock, 0, st>>>(a, n, descents);
+    k_count_descents_f64<<<(unsigned)(ceil_div(n, kBlock) < 2048 ? ceil_div(n, kBlock) : 2048), kBlock, 0, st>>>(a, n, descents);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
