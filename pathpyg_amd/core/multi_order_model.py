@@ -103,13 +103,13 @@ class MultiOrderModel:
         if max_order > 1:
             ho_index = lift_order_temporal(g, delta) if event_graph is None else event_graph
             chain = chain.to_second_order(edge_index, ho_index, aggregate_node_attributes(ho_index, edge_weight, "src"),
-                                          save=cached or max_order == 2)
+                                          save=cached or max_order == 2, want_edge_ids=max_order > 2)
             if cached or max_order == 2:
                 m.layers[2] = chain.graph
                 m.layers[2].mapping = IndexMap.from_node_sequence(g.mapping, chain.graph.data.node_sequence)
             for k in range(3, max_order + 1):
                 keep = cached or k == max_order
-                chain = chain.lift("src", save=keep)
+                chain = chain.lift("src", save=keep, want_edge_ids=k < max_order)
                 if keep:
                     m.layers[k] = chain.graph
                     m.layers[k].mapping = IndexMap.from_node_sequence(g.mapping, chain.graph.data.node_sequence)
@@ -130,12 +130,12 @@ class MultiOrderModel:
             edge_weight = edge_weight / aggregate_node_attributes(edge_index, outdeg, "src")
             aggr = "mul"
         chain = _LiftChain.first_order(edge_index, node_sequence, edge_weight, identity_nodes=False, num_first_order=None,
-                                       want_pairs=False)
+                                       want_pairs=max_order > 1)
         m.layers[1] = chain.graph
         m.layers[1].mapping = path_data.mapping
         for k in range(2, max_order + 1):
             keep = cached or k == max_order
-            chain = chain.lift(aggr, save=keep)
+            chain = chain.lift(aggr, save=keep, want_edge_ids=k < max_order)
             if keep:
                 m.layers[k] = chain.graph
                 m.layers[k].mapping = IndexMap.from_node_sequence(m.layers[1].mapping, chain.graph.data.node_sequence)
@@ -302,16 +302,22 @@ class _LiftChain:
     node.  An order-(k+1) instance is an edge (a -> b) of the order-k instance graph; its node sequence is
     ``seq(a) ++ last[b]``, so its lexicographic rank is the rank of the PAIR ``(inv[a], last[b])`` — a 2-column unique
     instead of a (k+1)-column one — and the distinct sequences are ``unique_k[first] ++ second`` for the distinct pairs.
+    When layer k has been aggregated even that sort is unnecessary: the pair ``(inv[a], last[b])`` determines and is determined by
+    the layer-k edge ``(inv[a], inv[b])``, so the order-(k+1) nodes are layer k's merged edges in coalesce order and the inverse map
+    of that coalesce (``edge_ids``) is the next ``inv``; the 2-column unique remains for ``cached=False`` (layer k not built).
     """
 
-    def __init__(self, index, inv, last, unique_nodes, weight, graph, pair_id=None):
+    def __init__(self, index, inv, last, unique_nodes, weight, graph, edge_ids=None):
         self.index = index              # [2, E_k] edges between order-k instances (source-sorted)
         self.inv = inv                  # [M_k] instance -> De Bruijn node id
         self.last = last                # [M_k] last first-order node of every instance
         self.unique_nodes = unique_nodes  # [U_k, k]
         self.weight = weight            # [E_k] or None
         self.graph = graph              # aggregated layer k (or None when not saved)
-        self.pair_id = pair_id          # first order only: id of each edge's distinct (src, dst) pair
+        # [E_k] position of every instance edge's merged edge in layer k (the inverse map of its coalesce) or None.  De Bruijn property:
+        # the order-(k+1) nodes ARE the merged edges of layer k, in the same lexicographic order - so this is the next order's `inv`,
+        # and the next order needs no unique over its node sequences at all (reference: torch.unique(dim=0), lift_order.py:133)
+        self.edge_ids = edge_ids
 
     @staticmethod
     def first_order(edge_index, node_sequence, edge_weight, identity_nodes: bool, num_first_order, want_pairs: bool):
@@ -322,24 +328,26 @@ class _LiftChain:
         else:
             unique_nodes, inv = _dispatch.unique_rows(node_sequence)
         out = _aggregate_with_known_nodes(edge_index, 1, node_sequence, unique_nodes, inv, edge_weight, "sum", want_inverse=want_pairs)
-        graph, pair_id = out if want_pairs else (out, None)
-        return _LiftChain(edge_index, inv, _dispatch.plain(node_sequence).reshape(-1), unique_nodes, edge_weight, graph, pair_id)
+        graph, edge_ids = out if want_pairs else (out, None)
+        return _LiftChain(edge_index, inv, _dispatch.plain(node_sequence).reshape(-1), unique_nodes, edge_weight, graph, edge_ids)
 
-    def to_second_order(self, event_index, ho_index, ho_weight, save: bool):
+    def to_second_order(self, event_index, ho_index, ho_weight, save: bool, want_edge_ids: bool = False):
         """Temporal special case: the order-2 instances are the events themselves, their distinct (src, dst) pairs are
-        layer 1's merged edges (already sorted), and ``pair_id`` from layer 1's coalesce is their inverse map."""
+        layer 1's merged edges (already sorted), and ``edge_ids`` from layer 1's coalesce is their inverse map."""
         from ..algorithms.lift_order import _aggregate_with_known_nodes
         unique_nodes = self.graph.data.edge_index.t().contiguous()
-        inv = self.pair_id
+        inv = self.edge_ids
         # a successor of node (a, b) is a node (b, c): all of them sit in the contiguous id block of the pairs that start with b
         merged = _dispatch.plain(self.graph.data.edge_index)
         blocks = _dispatch.successor_blocks(merged[0], self.unique_nodes.size(0), merged[1]) if save and merged.size(1) else None
-        graph = _aggregate_with_known_nodes(ho_index, 2, None, unique_nodes, inv, ho_weight, "sum", col_block=blocks) if save else None
-        if graph is not None:
+        graph = edge_ids = None
+        if save:
+            out = _aggregate_with_known_nodes(ho_index, 2, None, unique_nodes, inv, ho_weight, "sum", col_block=blocks, want_inverse=want_edge_ids)
+            graph, edge_ids = out if want_edge_ids else (out, None)
             graph._nodes_are_fo_edges = True          # node u of this layer = edge u of layer 1 (same lexicographic order)
-        return _LiftChain(ho_index, inv, _dispatch.plain(event_index)[1], unique_nodes, ho_weight, graph)
+        return _LiftChain(ho_index, inv, _dispatch.plain(event_index)[1], unique_nodes, ho_weight, graph, edge_ids)
 
-    def lift(self, aggr: str, save: bool):
+    def lift(self, aggr: str, save: bool, want_edge_ids: bool = False):
         from ..algorithms.lift_order import _aggregate_with_known_nodes
         num_instances = self.inv.numel()
         if self.weight is None:
@@ -348,19 +356,33 @@ class _LiftChain:
             ho_index, weight = lift_order_edge_index_weighted(self.index, self.weight, num_nodes=num_instances, aggr=aggr)
         last = aggregate_node_attributes(self.index, self.last, "dst")                 # last node of every new instance
         k = self.unique_nodes.size(1)
-        pairs = _dispatch.gather_concat(self.inv.unsqueeze(1), _dispatch.plain(self.index)[0], last)     # (inv[a], last[b])
-        hi = max(self.unique_nodes.size(0), int(_dispatch.minmax(self.unique_nodes)[1]) + 1 if self.unique_nodes.numel() else 1)
-        unique_pairs, inv = _dispatch.unique_rows(pairs, (0, max(hi - 1, 0)))
-        unique_nodes = _dispatch.gather_concat(self.unique_nodes, unique_pairs[:, 0], unique_pairs[:, 1])
-        blocks = None
-        if save and inv.numel():
-            # the new nodes are numbered by (order-k prefix node, last node); every successor of a new node P starts with P's
-            # order-k SUFFIX node, i.e. the order-k node of the second instance of any edge a -> b that realises P
-            suffix = torch.empty(unique_pairs.size(0), dtype=torch.int64, device=inv.device)
-            suffix[inv] = self.inv[_dispatch.plain(self.index)[1]]
-            blocks = _dispatch.successor_blocks(unique_pairs[:, 0].contiguous(), self.unique_nodes.size(0), suffix)
-        graph = _aggregate_with_known_nodes(ho_index, k + 1, None, unique_nodes, inv, weight, "sum", col_block=blocks) if save else None
-        return _LiftChain(ho_index, inv, last, unique_nodes, weight, graph)
+        if self.graph is not None and self.edge_ids is not None:
+            # the new nodes ARE layer k's merged edges (same lexicographic order): sequence = prefix node's sequence ++ last node of the
+            # suffix node; the coalesce inverse of layer k numbers the new instances - no sort of the instances' node sequences
+            merged = _dispatch.plain(self.graph.data.edge_index)
+            inv = self.edge_ids
+            prefix, suffix = merged[0].contiguous(), merged[1].contiguous()
+            tail = _dispatch.plain(self.unique_nodes)[:, -1].contiguous()
+            unique_nodes = _dispatch.gather_concat(self.unique_nodes, prefix, aggregate_node_attributes(merged, tail, "dst"))
+        else:
+            pairs = _dispatch.gather_concat(self.inv.unsqueeze(1), _dispatch.plain(self.index)[0], last)     # (inv[a], last[b])
+            hi = max(self.unique_nodes.size(0), int(_dispatch.minmax(self.unique_nodes)[1]) + 1 if self.unique_nodes.numel() else 1)
+            unique_pairs, inv = _dispatch.unique_rows(pairs, (0, max(hi - 1, 0)))
+            unique_nodes = _dispatch.gather_concat(self.unique_nodes, unique_pairs[:, 0], unique_pairs[:, 1])
+            prefix = unique_pairs[:, 0].contiguous()
+            suffix = None
+            if save and inv.numel():
+                # every successor of a new node P starts with P's order-k SUFFIX node, i.e. the order-k node of the second instance of
+                # any edge a -> b that realises P
+                suffix = torch.empty(unique_pairs.size(0), dtype=torch.int64, device=inv.device)
+                suffix[inv] = self.inv[_dispatch.plain(self.index)[1]]
+        graph = edge_ids = None
+        if save:
+            # the new nodes are numbered by (order-k prefix node, last node): all successors of P sit in the id block of P's suffix node
+            blocks = _dispatch.successor_blocks(prefix, self.unique_nodes.size(0), suffix) if inv.numel() else None
+            out = _aggregate_with_known_nodes(ho_index, k + 1, None, unique_nodes, inv, weight, "sum", col_block=blocks, want_inverse=want_edge_ids)
+            graph, edge_ids = out if want_edge_ids else (out, None)
+        return _LiftChain(ho_index, inv, last, unique_nodes, weight, graph, edge_ids)
 
 
 def _dispatch_degree(index: torch.Tensor, num_nodes: int) -> torch.Tensor:
