@@ -11,6 +11,3 @@ from .temporal import (  # noqa: F401
     temporal_closeness_centrality,
     temporal_shortest_paths,
 )
-
-from . import centrality  # noqa: E402,F401
-from .rolling_time_window import RollingTimeWindow  # noqa: E402,F401

@@ -285,6 +285,9 @@ class MultiOrderModel:
         )
         # facts DBGNN.forward would otherwise have to verify on the device (every Graph's edge index is row-sorted)
         object.__setattr__(out, "_pp_hints", {
+            # the hints describe exactly these tensor objects at these in-place versions; DBGNN.forward ignores them otherwise
+            "stamp": tuple((t, t._version) for t in (out.edge_index, out.edge_weights, out.edge_index_higher_order,
+                                                     out.edge_weights_higher_order, out.bipartite_edge_index) if t is not None),
             "rows_sorted": True, "bipartite_sources_sorted": mapping in ("last", "first"),
             # temporal models: the order-2 nodes ARE the first-order graph's edges, in its edge order (_LiftChain.to_second_order) -
             # DBGNN.forward then derives the "last" bipartite plan from the first-order plan's destination grouping, no extra sort

@@ -10,9 +10,10 @@ Same constructor, ``forward(data)`` contract and ``state_dict`` layout as the re
 
 so reference checkpoints load unchanged.  What differs is the execution: each graph's GCN normalisation is
 computed once and cached on the ``data`` object (PyG recomputes it on every call), every propagation is an
-atomics-free CSR segment reduction with bias + ELU fused into its epilogue, and the backward pass runs the
-same kernel over the transposed CSR.  The dense ``X @ W^T`` products are library GEMMs (rocBLAS / MFMA via
-``torch.nn.functional.linear``).  All tensors must live on the GPU; fp32 only.
+atomics-free CSR segment reduction, a whole GCN layer (aggregation + the dense product on ``v_mfma_f32_16x16x4_f32`` +
+bias + ELU) is ONE hand-written kernel for layer widths 16/32/64/128/256 (``csrc/pp_gcn_fused.hip``, ``csrc/pp_gcn_wide.hip``), and
+the backward pass runs the same structure over the transposed CSR.  No library GEMM is called for those widths; other
+widths fall back to ``torch.nn.functional.linear`` + the CSR kernel.  All tensors must live on the GPU; fp32 only.
 """
 from __future__ import annotations
 
@@ -230,14 +231,36 @@ def _plan_cache(data) -> dict:
     return cache
 
 
+def _stamp(tensors):
+    """Identity + in-place version of the tensors a cached object was derived from.  The tensors themselves are kept (not their
+    addresses: the caching allocator hands a freed block to the next tensor of the same size)."""
+    return tuple((t, t._version) for t in tensors if t is not None)
+
+
+def _stamp_matches(stamp, tensors) -> bool:
+    live = [t for t in tensors if t is not None]
+    return len(stamp) == len(live) and all(a is t and v == t._version for (a, v), t in zip(stamp, live))
+
+
 def _cached(data, key, tensors, build):
     cache = _plan_cache(data)
-    stamp = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors if t is not None)
     hit = cache.get(key)
-    if hit is None or hit[0] != stamp:
-        hit = (stamp, build())
+    if hit is None or not _stamp_matches(hit[0], tensors):
+        hit = (_stamp(tensors), build())
         cache[key] = hit
     return hit[1]
+
+
+def _valid_hints(data) -> dict:
+    """Hints attached by ``MultiOrderModel.to_dbgnn_data`` — honoured only while the tensors they describe are still the very
+    objects (and in-place versions) they were made for; a replaced or edited edge index falls back to the on-device checks."""
+    hints = getattr(data, "_pp_hints", None)
+    if not hints:
+        return {}
+    names = ("edge_index", "edge_weights", "edge_index_higher_order", "edge_weights_higher_order", "bipartite_edge_index")
+    if not _stamp_matches(hints.get("stamp", ()), [getattr(data, n, None) for n in names]):
+        return {}
+    return hints
 
 
 class GCNConv(Module):
@@ -277,6 +300,12 @@ class BipartiteGraphOperator(Module):
             plan = _hip.bipartite_plan(bipartite_index, n_ho, n_fo)
         return _Propagate.apply(plan, dense(x[0], self.lin1), dense(x[1], self.lin2), None, activation)
 
+    def message(self, x_i: torch.Tensor, x_j: torch.Tensor) -> torch.Tensor:
+        """Per-pair message of the reference's ``MessagePassing("add")`` operator (dbgnn.py:67-69): destination row + source row.
+        ``forward`` never materialises the per-pair tensor (the sum over pairs is a CSR segment reduction); kept for callers and
+        subclasses that use the reference's hook."""
+        return x_i + x_j
+
 
 class DBGNN(Module):
     """Time-aware GNN over a first-order graph, a higher-order De Bruijn graph and the bipartite map
@@ -305,7 +334,7 @@ class DBGNN(Module):
         n_fo, n_ho = int(data.num_nodes), int(data.num_ho_nodes)
         # bundles made by MultiOrderModel.to_dbgnn_data carry hints (every Graph's edge index is row-sorted, the bipartite
         # sources are arange) that save three device round trips; foreign bundles are checked on the device instead
-        hints = getattr(data, "_pp_hints", None) or {}
+        hints = _valid_hints(data)
         rows_sorted = True if hints.get("rows_sorted") else None
         bip_sorted = True if hints.get("bipartite_sources_sorted") else None
         from_edges = bool(hints.get("bipartite_is_fo_edge_heads"))     # order-2 temporal model, "last" mapping: no bipartite sort

@@ -172,14 +172,6 @@ def test_temporal_graph_derived_graphs(long_temporal_graph):
     assert isinstance(str(tg), str)
 
 
-def test_rolling_time_window(pp, long_temporal_graph):
-    """tests/algorithms/test_rolling_time_window.py: five 10-unit slices of the 20-event fixture."""
-    snapshots = list(pp.algorithms.RollingTimeWindow(long_temporal_graph, 10, 10, False))
-    assert [(g.n, g.m) for g in snapshots] == [(5, 4), (7, 3), (8, 6), (8, 3), (9, 4)]
-    g, window = next(iter(pp.algorithms.RollingTimeWindow(long_temporal_graph, 10, 10, return_window=True, weighted=False)))
-    assert window == (1, 11) and g.m == 4
-
-
 def test_static_graph_dataframe_io(pp, simple_graph, tmp_path):
     """tests/io/test_pandas.py:174-298,365-420: df_to_graph, add_node/edge_attributes, graph_to_df, csv round trip."""
     import pandas as pd

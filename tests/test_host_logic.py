@@ -170,18 +170,3 @@ def test_dbgnn_module_state_dict_layout():
     from oracle import dbgnn as od
     net.load_state_dict(od.init_params(3, (7, 9), [16, 32, 8]))          # oracle parameter dict == state_dict layout
     assert float(net.first_order_layers[0].bias.abs().sum()) == 0.0
-
-
-def test_path_traversal_statistics_match_reference_known_answers():
-    """tests/algorithms/test_centrality.py:21-42 (simple_walks fixture: C-B-D-F, A-B-D, D-E)."""
-    from pathpyg_amd.algorithms.centrality import map_to_nodes, path_node_traversals, path_visitation_probabilities
-    paths = pp.PathData(mapping=pp.IndexMap(["A", "B", "C", "D", "E", "F"]))
-    paths.append_walk(("C", "B", "D", "F"), weight=1.0)
-    paths.append_walk(("A", "B", "D"), weight=1.0)
-    paths.append_walk(("D", "E"), weight=1.0)
-    assert path_node_traversals(paths) == {"A": 1, "B": 2, "C": 1, "D": 3, "E": 1, "F": 1}
-    assert path_visitation_probabilities(paths) == {"A": 1 / 9, "B": 2 / 9, "C": 1 / 9, "D": 3 / 9, "E": 1 / 9, "F": 1 / 9}
-
-    class G:
-        mapping = pp.IndexMap(["a", "b", "c"])
-    assert map_to_nodes(G, {0: 0.5, 1: 2.7, 2: 0.3}) == {"a": 0.5, "b": 2.7, "c": 0.3}
