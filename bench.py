@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
-"""Headline benchmark: k=2 De Bruijn lift of a synthetic temporal edge stream + one DBGNN train step.
+"""Headline benchmark: k=2 De Bruijn lift of a synthetic temporal edge stream + one DBGNN train step, on 1..N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One STEP = one pass of the hot path over one batch of synthetic events that are already resident in HBM:
-    MultiOrderModel.from_temporal_graph(g, delta, max_order=2)      (event-graph lift + layers 1 and 2)
-    -> to_dbgnn_data(x, x_h) -> DBGNN forward, cross-entropy, backward, Adam step (plans rebuilt each step)
-Workload (SURVEY.md §8d "10M temporal edges" headline of BASELINE.json): temporal ER stream, m = 10^7 events,
-N = 5*10^5 nodes, int64 timestamps uniform in [0, 10^7), delta = 10^6 (E2 ~ 2*10^7), 64-dim features,
-hidden_dims [64, 64, 64], 8 classes, fp32.  The printed JSON line follows the driver's contract and adds
-`roofline` (dominant kernel, live HIP-event timing) and `cpu_baseline` (the CPU oracle on a bounded sample).
+``--gpus N`` with N > 1 and no RANK in the environment re-launches itself under ``torch.distributed.run`` (one process per GPU,
+backend nccl = RCCL over xGMI, rendezvous on 127.0.0.1); when the driver already started it that way the ranks are taken from the
+environment.  One STEP = one pass of the hot path over the synthetic events, which are already resident (replicated) in HBM:
+
+  partition (default, the north-star split; "scaling": "strong" — ONE global stream whatever N is):
+      layer 1 -> edge-range sharded event-graph lift -> lifted pairs to the owner of their destination (one all-to-all) -> coalesce
+      -> graph shards (halo, rectangular GCN plans) -> destination-partitioned DBGNN forward / loss / backward with one embedding
+      exchange per layer, reduce-scatter of the bipartite partial sums, all-reduce of the weight gradients -> Adam
+      (pathpyg_amd.distributed.build_dbgnn_shard + pathpyg_amd.nn.sharded.ShardedDBGNN; at N = 1 every collective is the identity)
+  streams (--mode streams; "scaling": "weak"): every rank runs the single-GPU API path
+      (MultiOrderModel.from_temporal_graph + to_dbgnn_data + DBGNN) on its own stream; only weight gradients are all-reduced.
+
+Workload (SURVEY.md §8d "10M temporal edges" headline of BASELINE.json): temporal ER stream, m = 10^7 events, N = 5*10^5 nodes,
+int64 timestamps uniform in [0, 10^7), delta = 10^6 (E2 ~ 1.9*10^7), 64-dim features, hidden_dims [64, 64, 64], 8 classes, fp32.
+The JSON line follows the driver's contract and adds `roofline` (the most expensive (kernel, graph) pair, live HIP-event timing),
+`kernel_rooflines` (every timed kernel per graph), `lift_roofline` / `aggregation_roofline` (SURVEY §8d bytes over the whole
+lift / aggregation incl. their sorts and scans) and `cpu_baseline` (BASELINE.md §3 protocol, bounded).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,19 +44,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--events", type=int, default=10_000_000, help="temporal edges per GPU")
+    ap.add_argument("--events", type=int, default=10_000_000, help="temporal edges of the stream (partition: global; streams: per GPU)")
     ap.add_argument("--nodes", type=int, default=500_000)
     ap.add_argument("--span", type=int, default=10_000_000)
     ap.add_argument("--delta", type=int, default=1_000_000)
     ap.add_argument("--features", type=int, default=64)
     ap.add_argument("--classes", type=int, default=8)
-    ap.add_argument("--mode", choices=("streams", "partition"), default="streams",
-                    help="N > 1: 'streams' (default) = every rank lifts and trains on its own event stream, only the weight gradients are "
-                         "all-reduced (weak scaling); 'partition' = ONE global stream: edge-range sharded lift + all-gather of the lifted "
-                         "pairs, DBGNN partitioned by destination rows with all-gather / reduce-scatter of the node embeddings over "
-                         "RCCL (strong scaling)")
+    ap.add_argument("--mode", choices=("partition", "streams"), default="partition")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: host-staged collectives (tests; several ranks may share one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (single-GPU test boxes, with --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-events", type=int, default=12_000, help="first size of the CPU-oracle sample (grows x1.5 until ~10 s)")
+    ap.add_argument("--cpu-loop-events", type=int, default=8_000, help="smallest of the three B-loop sizes (x2, x4 follow)")
+    ap.add_argument("--cpu-sample-events", type=int, default=2_000_000, help="size of the vectorised CPU pipeline sample (B-agg, B-dbgnn)")
     return ap.parse_args()
 
 
@@ -56,275 +67,374 @@ def synth_stream(events: int, nodes: int, span: int, seed: int, device):
     return edge_index, time_
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# live kernel timing: HIP events around C-ABI entry points on the stream they launch on
 class KernelClock:
-    """HIP events around every launch of one C-ABI entry point, on the stream it is launched on."""
+    """HIP events around every call of one C-ABI entry point (or from the start of `name` to the end of `until`)."""
 
-    def __init__(self, lib, name: str, bytes_of):
-        self.lib, self.name, self.bytes_of = lib, name, bytes_of
+    def __init__(self, lib, name: str, describe, until: str | None = None):
+        self.lib, self.name, self.describe, self.until = lib, name, describe, until
         self.orig = getattr(lib, name)
-        self.records = []
+        self.orig_until = getattr(lib, until) if until else None
+        self.records = []          # (start_event, end_event, key, bytes)
         self.enabled = False
+        self._open = None
 
     def __enter__(self):
         def wrapped(*args):
             if not self.enabled:
                 return self.orig(*args)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0 = torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
             rc = self.orig(*args)
-            e1.record(torch.cuda.current_stream())
-            self.records.append((e0, e1, self.bytes_of(*args)))
+            if self.until is None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(torch.cuda.current_stream())
+                self.records.append((e0, e1) + tuple(self.describe(*args)))
+            else:
+                self._open = (e0,) + tuple(self.describe(*args))
             return rc
         setattr(self.lib, self.name, wrapped)
+        if self.until:
+            def wrapped_until(*args):
+                rc = self.orig_until(*args)
+                if self.enabled and self._open is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(torch.cuda.current_stream())
+                    self.records.append((self._open[0], e1) + self._open[1:])
+                    self._open = None
+                return rc
+            setattr(self.lib, self.until, wrapped_until)
         return self
 
     def __exit__(self, *exc):
         setattr(self.lib, self.name, self.orig)
+        if self.until:
+            setattr(self.lib, self.until, self.orig_until)
 
-    def summary(self):
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
-        return len(self.records), ms, sum(b for _, _, b in self.records)
+    def groups(self) -> dict:
+        """{key: (launches, total ms, total algorithmic bytes)}"""
+        out = {}
+        for e0, e1, key, nbytes in self.records:
+            n, ms, b = out.get(key, (0, 0.0, 0))
+            out[key] = (n + 1, ms + e0.elapsed_time(e1), b + nbytes)
+        return out
 
 
-def spmm_bytes(ptr, idx, val, n_rows, x, f, self_coef, s, bias, act, heavy_slot, heavy_sum, y, stream):
-    """Algorithmic HBM bytes of one pp_spmm_f32 launch: CSR (ptr + idx + val) read once,
-    every source feature row read once, every output row written once (+ the self-term rows when separate)."""
-    nnz, n_src = spmm_bytes.shape_of[ptr]
-    total = 4 * (n_rows + 1) + nnz * (4 + (4 if val else 0)) + 4 * f * (n_src + n_rows)
+CSR_SHAPE = {}          # idx.data_ptr() of a CSR -> number of entries (registered when plans are built; the kernels only see pointers)
+
+
+def register_plan(plan) -> None:
+    for idx in (plan.fwd_idx, plan.bwd_idx):
+        if idx is not None:
+            CSR_SHAPE[idx.data_ptr()] = int(idx.numel())
+
+
+def _rows_label(n: int) -> str:
+    return f"{n:.2e} rows"
+
+
+def spmm_desc(ptr, idx, val, n_rows, x, f, self_coef, s, bias, act, heavy_slot, heavy_sum, y, stream):
+    """pp_spmm_f32: CSR once, every source row once (the bench registers the source-row count with the plan; at most one
+    row per CSR entry), every output row once (+ the self-term rows when they are a separate matrix)."""
+    nnz = CSR_SHAPE.get(idx, 0)
+    n_src = SRC_ROWS.get(idx, nnz)
+    total = 4 * (n_rows + 1) + nnz * (4 + (4 if val else 0)) + 4 * f * (min(n_src, nnz) + n_rows)
     if self_coef:
         total += 4 * n_rows + (4 * f * n_rows if (s and s != x) else 0)
-    return total
+    return (f"k_spmm_v4 (pp_spmm_f32) F={f}, {_rows_label(n_rows)}", total)
 
 
-spmm_bytes.shape_of = {}
+SRC_ROWS = {}           # idx.data_ptr() -> rows of the matrix the CSR gathers from
 
 
-def gcn_forward_bytes(ptr, idx, val, n_rows, n_src, x, p, self_coef, w, q, bias, act, heavy_slot, heavy_sum, agg_out, y, stream):
-    """Algorithmic HBM bytes of one fused GCN layer forward (pp_gcn_forward_f32): CSR once, every input row once (P wide), every
-    output row once (Q wide), the optional aggregated-input copy, the self coefficients and W."""
-    nnz, _ = spmm_bytes.shape_of[ptr]
-    return (4 * (n_rows + 1) + nnz * (4 + (4 if val else 0)) + 4 * p * n_src + 4 * q * n_rows + (4 * n_rows if self_coef else 0)
-            + (4 * p * n_rows if agg_out else 0) + 4 * p * q)
+def gcn_forward_desc(ptr, idx, val, n_rows, n_src, x, p, self_coef, w, q, bias, act, heavy_slot, heavy_sum, agg_out, y, stream):
+    """pp_gcn_forward_f32: CSR once, every input row once (P wide), every output row once (Q wide), the optional aggregated-input copy,
+    the self coefficients and W."""
+    nnz = CSR_SHAPE.get(idx, 0)
+    total = (4 * (n_rows + 1) + nnz * (4 + (4 if val else 0)) + 4 * p * n_src + 4 * q * n_rows + (4 * n_rows if self_coef else 0)
+             + (4 * p * n_rows if agg_out else 0) + 4 * p * q)
+    return (f"k_gcn_forward<{p},{q}> (pp_gcn_forward_f32), {_rows_label(n_rows)}", total)
 
 
-def gcn_backward_bytes(ptr, idx, val, n_rows, d, m, self_coef, x, k, w, fuse_act, heavy_slot, heavy_sum, d_in, colsum, dw, ws, ws_bytes,
-                       stream):
-    """Algorithmic HBM bytes of one fused GCN layer backward (pp_gcn_backward_f32): CSR, dpre (M wide) and the layer input (K wide)
-    read once, the input gradient (K wide) written once."""
-    nnz, _ = spmm_bytes.shape_of[ptr]
-    return 4 * (n_rows + 1) + nnz * (4 + (4 if val else 0)) + 4 * m * n_rows + 8 * k * n_rows + (4 * n_rows if self_coef else 0) + 8 * m * k
+def gcn_backward_desc(ptr, idx, val, n_rows, n_self, d, m, self_coef, x, k, w, fuse_act, heavy_slot, heavy_sum, d_in, colsum, dw, ws, ws_bytes,
+                      stream):
+    """pp_gcn_backward_f32: CSR, dpre (M wide) and the layer input (K wide) read once, the input gradient (K wide) written once."""
+    nnz = CSR_SHAPE.get(idx, 0)
+    total = 4 * (n_rows + 1) + nnz * (4 + (4 if val else 0)) + 4 * m * n_self + 8 * k * n_rows + (4 * n_self if self_coef else 0) + 8 * m * k
+    return (f"k_gcn_backward<{m},{k}> (pp_gcn_backward_f32), {_rows_label(n_rows)}", total)
 
 
 def pmc_traffic(kernel_key: str, args) -> float | None:
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/, separate FETCH_SIZE
-    and WRITE_SIZE runs of this same command, gfx950 FETCH correction applied).  Only valid for the default workload."""
+    """HBM bytes per launch of a (kernel, graph) pair from the committed rocprofv3 --pmc passes (profiles/, separate FETCH_SIZE and
+    WRITE_SIZE runs of this same command, gfx950 FETCH correction applied).  Only valid for the default workload at 1 GPU."""
     defaults = (10_000_000, 500_000, 10_000_000, 1_000_000, 64)
     if (args.events, args.nodes, args.span, args.delta, args.features) != defaults:
         return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            return float(json.load(fh)[kernel_key]["hbm_bytes_per_dispatch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                table = json.load(fh)
+            short = kernel_key.split(" ")[0].split("<")[0]
+            big = kernel_key.endswith("1.00e+07 rows")
+            for key in ((short + ("@ho" if big else "@fo")), short):
+                if key in table and (big or "@" in key):
+                    return float(table[key]["hbm_bytes_per_dispatch"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(args, seed: int) -> dict:
-    """The CPU oracle (port of the reference algorithm incl. its per-timestamp lift loop) on a bounded sample of the same
-    generator: events and nodes scaled down together (E2/m of the full workload is preserved), largest sample that keeps the
-    reference-style loop within ~10-30 s on this host (its cost grows faster than quadratically in m)."""
+    """BASELINE.md §3 / SURVEY §8(d) CPU protocol on this box's host cores, bounded to ~30-40 s:
+      B-loop   : the oracle's op-for-op port of the reference per-timestamp lift loop (temporal.py:33-53) at three sizes of the same
+                 generator (N and delta scaled with m so E2/m stays that of the workload), fitted a*T*m + b*E2, EXTRAPOLATED to the
+                 full workload (labelled as such; a direct run would take days);
+      B-sorted : vectorised CPU lift (sort + searchsorted + repeat_interleave, identical output; not in the reference), FULL size;
+      B-line   : lift_order_edge_index port (degree / cumsum / repeat_interleave) on the full-size event graph;
+      B-agg    : aggregate_edge_index port (torch.unique(dim=0) + stable sort + scatter-add) for layers 1+2 at `--cpu-sample-events`;
+      B-dbgnn  : pure-torch DBGNN train step (index_add_ message passing = what PyG dispatches on CPU) on that sample.
+    `value` = lifted k-edges/s of the reference algorithm end to end (loop lift + aggregation + 1 DBGNN train step) on the largest
+    B-loop sample."""
+    import numpy as np
     from oracle import dbgnn as od
+    from oracle import lift as ol
     from oracle import model as om
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(cores, 1))
+    cpu = torch.device("cpu")
 
-    def one_sample(m):
-        n = max(int(args.nodes * m / args.events), 16)
-        ei, t = synth_stream(m, n, args.span, seed, torch.device("cpu"))
-        t0 = time.perf_counter()
+    def sample(m, s):
+        scale = m / args.events
+        n = max(int(args.nodes * scale), 16)
+        ei, t = synth_stream(m, n, args.span, s, cpu)              # same span and delta: E2/m = m*delta/(n*span) is preserved
         ei, t, _ = om.stable_time_sort(ei, t)
-        layers = om.layers_from_temporal(ei, t, n, delta=args.delta, max_order=2, loop_lift=True)
-        t_lift = time.perf_counter() - t0
-        e2 = int(om.temporal_lift_sorted(ei, t, args.delta, n).size(1))
-        g = torch.Generator().manual_seed(seed + 1)
+        return ei, t, n
+
+    def train_step(layers, n, s):
+        g = torch.Generator().manual_seed(s)
         data = om.dbgnn_inputs(layers, 2, "last", x=torch.randn(n, args.features, generator=g),
                                x_h=torch.randn(layers[2]["num_nodes"], args.features, generator=g))
         y = torch.randint(0, args.classes, (n,), generator=g)
         params = {k: v.requires_grad_(True) for k, v in od.init_params(args.classes, (args.features, args.features),
-                                                                       [args.features] * 3, seed=seed).items()}
+                                                                       [args.features] * 3, seed=s).items()}
         opt = torch.optim.Adam(params.values(), lr=1e-3)
         t0 = time.perf_counter()
         opt.zero_grad()
-        loss = torch.nn.functional.cross_entropy(od.forward(params, data), y)
-        loss.backward()
+        torch.nn.functional.cross_entropy(od.forward(params, data), y).backward()
         opt.step()
-        return m, n, e2, t_lift, time.perf_counter() - t0
+        return time.perf_counter() - t0
 
-    best = None
-    m = min(args.cpu_events, args.events)
-    while True:
-        best = one_sample(m)
-        nxt = int(m * 1.5)
-        predicted = best[3] * (nxt / m) ** 3              # pessimistic growth law
-        if best[3] >= 8.0 or predicted > 40.0 or nxt > args.events or nxt > 30_000:
+    # ---- B-loop at three sizes
+    loop = []
+    m0 = min(args.cpu_loop_events, args.events)
+    for k, m in enumerate((m0, 2 * m0, 4 * m0)):
+        m = min(m, args.events)
+        ei, t, n = sample(m, seed + k)
+        t0 = time.perf_counter()
+        ho = ol.temporal_lift_per_timestamp(ei, t, args.delta)
+        dt = time.perf_counter() - t0
+        loop.append({"m": m, "N": n, "T": int(torch.unique(t).numel()), "E2": int(ho.size(1)), "seconds": dt})
+        if dt > 25.0:
             break
-        m = nxt
-    m, n, e2, t_lift, t_train = best
-    # vectorised CPU lift (sort + searchsorted + repeat_interleave: same output, a strong CPU algorithm the reference does not have)
-    # on the FULL workload, and the whole vectorised CPU step (that lift + aggregation + DBGNN train step) on a 10^6-event sample
-    m2 = args.events
-    n2 = args.nodes
-    ei2, t2 = synth_stream(m2, n2, args.span, seed + 2, torch.device("cpu"))
-    ei2, t2, _ = om.stable_time_sort(ei2, t2)
+    a_mat = np.array([[r["T"] * r["m"], r["E2"]] for r in loop], dtype=np.float64)
+    b_vec = np.array([r["seconds"] for r in loop], dtype=np.float64)
+    coef, *_ = np.linalg.lstsq(a_mat, b_vec, rcond=None)
+    coef = np.maximum(coef, 0.0)
+    # largest loop sample: the rest of the reference step on it (aggregation + train step)
+    big = loop[-1]
+    ei, t, n = sample(big["m"], seed + len(loop) - 1)
     t0 = time.perf_counter()
-    ho = om.temporal_lift_sorted(ei2, t2, args.delta, n2)
+    layers = om.layers_from_temporal(ei, t, n, delta=args.delta, max_order=2, loop_lift=True)
+    t_layers = time.perf_counter() - t0
+    t_train = train_step(layers, n, seed)
+    # ---- B-sorted and B-line at FULL size
+    ei_f, t_f = synth_stream(args.events, args.nodes, args.span, seed + 10, cpu)
+    ei_f, t_f, _ = om.stable_time_sort(ei_f, t_f)
+    t0 = time.perf_counter()
+    ho_f = ol.temporal_lift_sorted(ei_f, t_f, args.delta, args.nodes)
     t_sorted = time.perf_counter() - t0
-    m3 = min(args.events, 1_000_000)
-    n3 = max(int(args.nodes * m3 / args.events), 16)
-    ei3, t3 = synth_stream(m3, n3, args.span, seed + 3, torch.device("cpu"))
-    ei3, t3, _ = om.stable_time_sort(ei3, t3)
+    e2_full = int(ho_f.size(1))
+    t_total_full = float(coef[0] * torch.unique(t_f).numel() * args.events + coef[1] * e2_full)
     t0 = time.perf_counter()
-    layers3 = om.layers_from_temporal(ei3, t3, n3, delta=args.delta, max_order=2, loop_lift=False)
-    e2_3 = int(layers3[2]["inverse_idx"].numel() and om.temporal_lift_sorted(ei3, t3, args.delta, n3).size(1))
-    g3 = torch.Generator().manual_seed(seed + 4)
-    data3 = om.dbgnn_inputs(layers3, 2, "last", x=torch.randn(n3, args.features, generator=g3),
-                            x_h=torch.randn(layers3[2]["num_nodes"], args.features, generator=g3))
-    y3 = torch.randint(0, args.classes, (n3,), generator=g3)
-    params3 = {k: v.requires_grad_(True) for k, v in od.init_params(args.classes, (args.features, args.features),
-                                                                    [args.features] * 3, seed=seed).items()}
-    opt3 = torch.optim.Adam(params3.values(), lr=1e-3)
-    opt3.zero_grad()
-    torch.nn.functional.cross_entropy(od.forward(params3, data3), y3).backward()
-    opt3.step()
-    t_vec_step = time.perf_counter() - t0
+    e3 = int(ol.line_graph_lift(ho_f, args.events).size(1))
+    t_line = time.perf_counter() - t0
+    del ho_f, ei_f, t_f
+    # ---- B-agg + B-dbgnn on the vectorised pipeline sample
+    ms = min(args.cpu_sample_events, args.events)
+    ei_s, t_s, n_s = sample(ms, seed + 20)
+    t0 = time.perf_counter()
+    ho_s = ol.temporal_lift_sorted(ei_s, t_s, args.delta, n_s)
+    t_lift_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    layers_s = om.layers_from_temporal(ei_s, t_s, n_s, delta=args.delta, max_order=2, event_graph=ho_s)
+    t_agg_s = time.perf_counter() - t0
+    t_train_s = train_step(layers_s, n_s, seed + 1)
+    e2_s = int(ho_s.size(1))
     return {
-        "value": e2 / (t_lift + t_train),
+        "value": big["E2"] / (t_layers + t_train),
         "unit": "lifted k-edges/s",
-        "cores": torch.get_num_threads(),
+        "cores": cores,
         "kind": "port",
-        "sample": f"oracle (reference per-timestamp lift loop + aggregation + 1 DBGNN train step) on m={m} events, "
-                  f"N={n}, delta={args.delta}, E2={e2}: lift+aggregate {t_lift:.2f}s, train step {t_train:.2f}s",
-        "events_per_s": m / (t_lift + t_train),
-        "vectorised_lift_k_edges_per_s": ho.size(1) / t_sorted,
-        "vectorised_lift_sample": f"sort+searchsorted CPU lift only, FULL size m={m2}, E2={ho.size(1)}, {t_sorted:.2f}s",
-        "vectorised_step_k_edges_per_s": e2_3 / t_vec_step,
-        "vectorised_step_sample": f"vectorised CPU lift + aggregation + 1 DBGNN train step, m={m3}, N={n3}, E2={e2_3}, {t_vec_step:.2f}s",
+        "sample": f"oracle port of the reference algorithm (per-timestamp lift loop + aggregation + 1 DBGNN train step) on m={big['m']} events, "
+                  f"N={big['N']}, delta={args.delta}, E2={big['E2']}: lift+aggregate {t_layers:.2f}s, train step {t_train:.2f}s",
+        "b_loop": {"samples": loop, "model": "seconds = a*T*m + b*E2", "a": float(coef[0]), "b": float(coef[1]),
+                   "extrapolated_full_size_seconds": t_total_full,
+                   "extrapolated_full_size_k_edges_per_s": e2_full / t_total_full if t_total_full > 0 else None,
+                   "note": "EXTRAPOLATED from the three measured sizes to the full workload; not measured"},
+        "b_sorted": {"m": args.events, "E2": e2_full, "seconds": t_sorted, "k_edges_per_s": e2_full / t_sorted,
+                     "note": "vectorised CPU lift only (sort+searchsorted; not in the reference), FULL size"},
+        "b_line": {"E2": e2_full, "E3": e3, "seconds": t_line, "out_edges_per_s": e3 / t_line, "note": "lift_order_edge_index port, FULL size"},
+        "b_agg": {"m": ms, "N": n_s, "E2": e2_s, "seconds": t_agg_s,
+                  "note": "layers 1+2 via the aggregate_edge_index port (torch.unique(dim=0) + stable sort + scatter-add) of a precomputed "
+                          f"event graph (its vectorised lift took {t_lift_s:.2f}s)"},
+        "b_dbgnn": {"m": ms, "N": n_s, "U2": layers_s[2]["num_nodes"], "F": args.features, "seconds": t_train_s, "steps_per_s": 1.0 / t_train_s},
+        "vectorised_step_k_edges_per_s": e2_s / (t_lift_s + t_agg_s + t_train_s),
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def relaunch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run on this node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main() -> int:
     args = parse()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ          # started by torch.distributed.run
+    if args.gpus > 1 and not launched:
+        return relaunch(args)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ          # started by torch.distributed.run
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: pathpyg_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if not args.share_gpu and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (use --share-gpu --backend gloo to test)")
+    dev_index = 0 if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    import torch.distributed as dist
     if launched:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import pathpyg_amd as pp
     from pathpyg_amd import distributed as ppd
-    from pathpyg_amd import _hip
     from pathpyg_amd._lib import lib
 
-    # ---- inputs, resident in HBM before the timed region (each rank owns an independent stream: weak scaling)
     partition = args.mode == "partition"
+    comm = ppd.Comm()
+    # ---- inputs, resident in HBM before the timed region.  partition: ONE stream replicated on every rank; streams: one per rank
     ei, t = synth_stream(args.events, args.nodes, args.span, seed=1 + (0 if partition else rank), device=dev)
-    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=args.nodes))       # stable time sort (HIP radix sort)
+    pp.TemporalGraph(pp.Data(edge_index=ei[:, :1024].clone(), time=t[:1024].clone(), num_nodes=args.nodes))    # library load / first-launch costs
+    sort0, sort1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sort0.record()
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=args.nodes))       # a1: stable time sort (HIP radix sort) + permutation
+    sort1.record()
     del ei, t
-    model0 = pp.MultiOrderModel.from_temporal_graph(g, delta=args.delta, max_order=2)
-    n_ho = model0.layers[2].n
+    n_ho = int(pp.MultiOrderModel.from_temporal_graph(g, delta=1, max_order=1).layers[1].m)      # order-2 nodes = distinct (src, dst) pairs
     feat = torch.Generator(device=dev).manual_seed(7 + (0 if partition else rank))
     x = torch.randn(args.nodes, args.features, generator=feat, device=dev)
     x_h = torch.randn(n_ho, args.features, generator=feat, device=dev)
     y = torch.randint(0, args.classes, (args.nodes,), generator=feat, device=dev)
-    sizes = {"m": args.events, "N": args.nodes, "E2": int(pp.algorithms.lift_order_temporal(g, args.delta).size(1)),
-             "U2": n_ho, "A1": model0.layers[1].m, "A2": model0.layers[2].m}
-    del model0
     torch.manual_seed(0)                                    # identical initial weights on every rank
     net = pp.nn.DBGNN(num_classes=args.classes, num_features=(args.features, args.features),
                       hidden_dims=[args.features] * 3, p_dropout=0.0).to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    sharded = ppd.ShardedDBGNN(net, comm) if partition else None
     lift_ms = []
-    sharded = ppd.ShardedDBGNN(net) if partition else None
+    sizes = {}
 
     def step_partition(timed: bool):
-        """Strong-scaling form: every rank lifts its edge range of the ONE global stream (no exchange), the lifted pairs are
-        all-gathered (16 bytes per pair), the aggregation is replicated, and the DBGNN runs partitioned by destination rows."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        local, _, _ = ppd.lift_order_temporal_sharded(g, args.delta)
-        ho = ppd.gather_lifted(local)
-        mom = pp.MultiOrderModel.from_temporal_graph(g, delta=args.delta, max_order=2, event_graph=ho)
-        data = mom.to_dbgnn_data(max_order=2, mapping="last", x=x, x_h=x_h)
-        data.y = y
+        shard = ppd.build_dbgnn_shard(g, args.delta, x, x_h, y, comm)
         e1.record()
+        for gs in (shard.fo, shard.ho):
+            register_plan(gs.plan)
+        register_plan(shard.bip)
+        SRC_ROWS[shard.bip.fwd_idx.data_ptr()] = shard.ho.n_own
+        SRC_ROWS[shard.bip.bwd_idx.data_ptr()] = shard.bip.n_dst
         opt.zero_grad(set_to_none=True)
-        loss = sharded.loss(sharded.prepare(data))
+        loss = sharded.loss(shard)
         loss.backward()
         ppd.all_reduce_gradients(net, average=False)
         opt.step()
+        sizes.update(shard.sizes)
         if timed:
             lift_ms.append((e0, e1))
         return loss
 
-    def step(timed: bool):
+    def step_streams(timed: bool):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         mom = pp.MultiOrderModel.from_temporal_graph(g, delta=args.delta, max_order=2)
         data = mom.to_dbgnn_data(max_order=2, mapping="last", x=x, x_h=x_h)
         e1.record()
         opt.zero_grad(set_to_none=True)
-        out = net(data)
-        loss = pp.nn.cross_entropy(out, y)
+        loss = pp.nn.cross_entropy(net(data), y)
         loss.backward()
         if launched:        # data-parallel over independent streams: only the ~20 k weight gradients cross xGMI (one all-reduce)
             ppd.all_reduce_gradients(net)
         opt.step()
         if timed:
             lift_ms.append((e0, e1))
+        if not sizes:
+            sizes.update({"m": args.events, "N": args.nodes, "E2": int(pp.algorithms.lift_order_temporal(g, args.delta).size(1)),
+                          "U2": mom.layers[2].n, "A1": mom.layers[1].m, "A2": mom.layers[2].m})
         return loss
 
-    if partition:
-        step = step_partition
+    step = step_partition if partition else step_streams
+    if not partition:        # the API path builds its plans inside DBGNN.forward: register their shapes as they are made
+        from pathpyg_amd import _hip
+
+        def registering(fn, src_rows=None):
+            def wrapped(*a, **kw):
+                plan = fn(*a, **kw)
+                register_plan(plan)
+                SRC_ROWS[plan.fwd_idx.data_ptr()], SRC_ROWS[plan.bwd_idx.data_ptr()] = plan.n_src, plan.n_dst
+                return plan
+            return wrapped
+        _hip.gcn_plan, _hip.bipartite_plan = registering(_hip.gcn_plan), registering(_hip.bipartite_plan)
+        _hip.bipartite_plan_from_edge_grouping = registering(_hip.bipartite_plan_from_edge_grouping)
 
     def barrier():
         if launched:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     L = lib()
 
-    # shapes (nnz, source rows) of each CSR are recorded when the plan is built
-    orig_gcn_plan, orig_bip_plan = _hip.gcn_plan, _hip.bipartite_plan
+    def lift_desc(ei_p, t_p, tdt, m, n_own, *rest):
+        return ("temporal lift (pp_temporal_count .. pp_temporal_fill)", 24 * m)
 
-    def gcn_plan(edge_index, edge_weight, num_nodes, *a, **kw):
-        p = orig_gcn_plan(edge_index, edge_weight, num_nodes, *a, **kw)
-        spmm_bytes.shape_of[p.fwd_ptr.data_ptr()] = (p.fwd_idx.numel(), num_nodes)
-        spmm_bytes.shape_of[p.bwd_ptr.data_ptr()] = (p.bwd_idx.numel(), num_nodes)
-        return p
+    def coalesce_desc(ei_p, e, *rest):
+        return (f"aggregation (pp_coalesce_count .. pp_coalesce_fill), {e:.2e} instance edges", 20 * e)
 
-    def bip_plan(bip, n_ho_, n_fo_, *a, **kw):
-        p = orig_bip_plan(bip, n_ho_, n_fo_, *a, **kw)
-        spmm_bytes.shape_of[p.fwd_ptr.data_ptr()] = (p.fwd_idx.numel(), n_ho_)
-        spmm_bytes.shape_of[p.bwd_ptr.data_ptr()] = (p.bwd_idx.numel(), n_fo_)
-        return p
-
-    _hip.gcn_plan, _hip.bipartite_plan = gcn_plan, bip_plan
-
-    with KernelClock(L, "pp_spmm_f32", spmm_bytes) as spmm_clock, \
-            KernelClock(L, "pp_gcn_forward_f32", gcn_forward_bytes) as fwd_clock, \
-            KernelClock(L, "pp_gcn_backward_f32", gcn_backward_bytes) as bwd_clock, \
-            KernelClock(L, "pp_temporal_fill", lambda m, n, total, *r: 16 * total + 12 * m) as fill_clock:
-        clocks = (spmm_clock, fwd_clock, bwd_clock, fill_clock)
+    with KernelClock(L, "pp_spmm_f32", spmm_desc) as spmm_clock, \
+            KernelClock(L, "pp_gcn_forward_f32", gcn_forward_desc) as fwd_clock, \
+            KernelClock(L, "pp_gcn_backward_f32", gcn_backward_desc) as bwd_clock, \
+            KernelClock(L, "pp_temporal_fill", lambda m, n, total, *r: ("k_expand (pp_temporal_fill)", 16 * total + 12 * m)) as fill_clock, \
+            KernelClock(L, "pp_temporal_count", lift_desc, until="pp_temporal_fill") as lift_clock, \
+            KernelClock(L, "pp_coalesce_count", coalesce_desc, until="pp_coalesce_fill") as agg_clock:
+        clocks = (spmm_clock, fwd_clock, bwd_clock, fill_clock, lift_clock, agg_clock)
         for _ in range(args.warmup):
             step(False)
         barrier()
+        comm.sent_bytes = {k: 0 for k in comm.sent_bytes}
         for c in clocks:
             c.enabled = True
         t0 = time.perf_counter()
@@ -338,47 +448,58 @@ def main() -> int:
     k3 = None
     if rank == 0:
         ho = pp.algorithms.lift_order_temporal(g, args.delta)
-        with KernelClock(L, "pp_linegraph_fill", lambda e, n, total, *r: 16 * total + 12 * e) as lg_clock:
+        with KernelClock(L, "pp_linegraph_fill", lambda e, n, total, *r: ("k_expand<no list> (pp_linegraph_fill)", 16 * total + 12 * e)) as lg_clock:
             lg_clock.enabled = True
             for _ in range(3):
                 e3 = pp.algorithms.lift_order_edge_index(ho, num_nodes=args.events).size(1)
             torch.cuda.synchronize()
-        n_lg, lg_ms, lg_b = lg_clock.summary()
-        k3 = {"kernel": "k_tile_sources + k_expand<no list> (pp_linegraph_fill)", "E3": e3, "launches": n_lg,
-              "avg_launch_ms": lg_ms / max(n_lg, 1), "achieved": lg_b / (lg_ms * 1e-3) / 1e9 if lg_ms > 0 else 0.0,
-              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (lg_b / (lg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lg_ms > 0 else 0.0}
+        (key, (n_lg, lg_ms, lg_b)), = lg_clock.groups().items()
+        k3 = {"kernel": "k_tile_sources + " + key, "E3": e3, "launches": n_lg, "avg_launch_ms": lg_ms / max(n_lg, 1),
+              "achieved": lg_b / (lg_ms * 1e-3) / 1e9 if lg_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": (lg_b / (lg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lg_ms > 0 else 0.0}
         del ho
+    e2_total = float(sizes.get("E2", 0))
+    loss_total = loss.detach().to(torch.float64).reshape(1).clone()
+    if launched and partition:
+        comm.all_reduce_(loss_total)                             # every rank holds its share of the mean loss
     if launched:
-        import torch.distributed as dist
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        comm.all_reduce_(tmax, dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        e2_all = torch.tensor([sizes["E2"]], device=dev, dtype=torch.float64)
-        dist.all_reduce(e2_all)
-        e2_total = float(sizes["E2"]) if partition else float(e2_all.item())     # partition mode: ONE stream shared by all ranks
-    else:
-        e2_total = float(sizes["E2"])
+        if not partition:                                        # streams: every rank lifted its own stream
+            e2_all = torch.tensor([e2_total], device=dev, dtype=torch.float64)
+            comm.all_reduce_(e2_all)
+            e2_total = float(e2_all.item())
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         lift = sum(a.elapsed_time(b) for a, b in lift_ms) / len(lift_ms)
-        n_spmm, spmm_ms, spmm_b = spmm_clock.summary()
-        n_fill, fill_ms, fill_b = fill_clock.summary()
-        candidates = [("k_spmm_v4 (pp_spmm_f32)", "k_spmm_v4", n_spmm, spmm_ms, spmm_b),
-                      ("k_gcn_forward (pp_gcn_forward_f32)", "k_gcn_forward", *fwd_clock.summary()),
-                      ("k_gcn_backward (pp_gcn_backward_f32)", "k_gcn_backward", *bwd_clock.summary()),
-                      ("k_expand (pp_temporal_fill)", "k_expand", n_fill, fill_ms, fill_b)]
-        best = max(candidates, key=lambda c: c[3])          # the kernel with the most time in the timed region
-        dominant = (best[0], best[2], best[3], best[4])
-        traffic = pmc_traffic(best[1], args)
-        achieved = dominant[3] / (dominant[2] * 1e-3) / 1e9 if dominant[2] > 0 else 0.0
 
-        def side(c):
-            n_, ms_, b_ = c[2], c[3], c[4]
+        def entry(key, n_, ms_, b_, with_traffic=True):
             gbs = b_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
-            return {"kernel": c[0], "launches": n_, "avg_launch_ms": ms_ / max(n_, 1), "achieved": gbs, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(c[1], args),
-                    "algorithmic_bytes_per_launch": b_ / max(n_, 1)}
+            return {"kernel": key, "launches": n_, "avg_launch_ms": ms_ / max(n_, 1), "total_ms_per_step": ms_ / args.steps, "achieved": gbs,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic(key, args) if (with_traffic and world == 1) else None, "algorithmic_bytes_per_launch": b_ / max(n_, 1)}
+        per_kernel = []
+        for clock in (fwd_clock, bwd_clock, spmm_clock):
+            for key, (n_, ms_, b_) in clock.groups().items():
+                per_kernel.append(entry(key, n_, ms_, b_))
+        per_kernel.sort(key=lambda r: -r["total_ms_per_step"])
+        dominant = dict(per_kernel[0]) if per_kernel else None
+        if dominant:
+            dominant["bound"] = "hbm"
+        (fill_key, (n_fill, fill_ms, fill_b)), = fill_clock.groups().items() if fill_clock.records else (("k_expand", (0, 0.0, 0)),)
+        e2_rank = float(sizes.get("E2_local", sizes.get("E2", 0)))
+        m_rank = float(sizes.get("m", args.events))
+        lift_groups = lift_clock.groups()
+        lift_total_ms = sum(v[1] for v in lift_groups.values())
+        n_lift = sum(v[0] for v in lift_groups.values())
+        lift_bytes = 24.0 * m_rank / max(world if partition else 1, 1) + 16.0 * e2_rank     # read (src,dst,t) of the shard, write [2,E2]
+        lift_avg = lift_total_ms / max(n_lift, 1)
+        agg_total_ms = sum(v[1] for v in agg_clock.groups().values()) / args.steps
+        a1, a2, u2 = float(sizes.get("A1", 0)), float(sizes.get("A2_local", sizes.get("A2", 0))), float(sizes.get("U2", 0))
+        # 16 E_k + 4 E_k + 8 k U_k + 8 M_k + 20 A_k for layer 1 (instances = the m events, k = 1) and layer 2 (E2 pairs)
+        agg_bytes = (20.0 * m_rank + 8.0 * args.nodes + 8.0 * m_rank + 20.0 * a1) + (20.0 * e2_rank + 16.0 * u2 + 8.0 * m_rank + 20.0 * a2)
         line = {
             "metric": "lifted k-edges/s (k=2 De Bruijn lift + aggregation + 1 DBGNN train step per pass, 10M temporal edges)",
             "value": e2_total * args.steps / elapsed,
@@ -392,35 +513,38 @@ def main() -> int:
             "vs_baseline": None,
             "dtype": "int64 lift / f32 DBGNN",
             "data": "synthetic",
-            "config": {"workload": f"temporal ER stream per GPU: m={args.events} events, N={args.nodes} nodes, t~U[0,{args.span}), "
-                                   f"delta={args.delta}, k=2, F={args.features}, hidden=[{args.features}]*3, classes={args.classes}",
-                       "parallelism": (f"{world} GPU(s), one global stream: edge-range sharded lift + all-gather, destination-partitioned "
-                                       "DBGNN with embedding all-gather / reduce-scatter (RCCL)") if partition else
+            "config": {"workload": f"temporal ER stream{'' if partition else ' per GPU'}: m={args.events} events, N={args.nodes} nodes, "
+                                   f"t~U[0,{args.span}), delta={args.delta}, k=2, F={args.features}, hidden=[{args.features}]*3, classes={args.classes}",
+                       "parallelism": (f"{world} rank(s) over {comm.backend or 'no process group'}: ONE global stream, edge-range sharded lift, "
+                                       "destination-owner aggregation (all-to-all), destination-partitioned DBGNN with one embedding exchange per "
+                                       "layer (sparse all-to-all), bipartite reduce-scatter, weight-gradient all-reduce") if partition else
                                       ("1 GPU" if world == 1 else f"{world} independent streams, weight-gradient all-reduce (RCCL)"),
-                       **sizes},
-            "temporal_events_per_s": world * args.events * args.steps / elapsed,
+                       **{k: v for k, v in sizes.items() if not k.endswith("_cuts")}},
+            "temporal_events_per_s": (1 if partition else world) * args.events * args.steps / elapsed,
+            "time_sort_ms": sort0.elapsed_time(sort1),
             "lift_ms": lift,
-            "lift_k_edges_per_s": sizes["E2"] / (lift * 1e-3),
+            "lift_k_edges_per_s": sizes.get("E2", 0) / (lift * 1e-3),
             "dbgnn_step_ms": ms_step - lift,
             "dbgnn_steps_per_s": 1e3 / max(ms_step - lift, 1e-9),
-            "loss": float(loss.detach()),
+            "loss": float(loss_total),
             "peak_hbm_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
-            "roofline": {"bound": "hbm", "kernel": dominant[0], "launches": dominant[1],
-                         "avg_launch_ms": dominant[2] / max(dominant[1], 1), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dominant[3] / max(dominant[1], 1)},
-            "dbgnn_kernel_rooflines": [side(c) for c in candidates[:3] if c[2] > 0],
-            "lift_fill_roofline": {"kernel": "k_expand (pp_temporal_fill)", "launches": n_fill,
-                                   "avg_launch_ms": fill_ms / max(n_fill, 1),
-                                   "achieved": (fill_b / (fill_ms * 1e-3) / 1e9) if fill_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": (fill_b / (fill_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fill_ms > 0 else 0.0},
+            "comm_bytes_per_step_rank0": {k: v / args.steps for k, v in comm.sent_bytes.items()},
+            "roofline": dominant,
+            "kernel_rooflines": per_kernel,
+            "lift_roofline": {"what": "whole temporal lift of this rank: count + scans + tail sort + fill (24 m_shard + 16 E2_shard bytes, SURVEY §8d)",
+                              "avg_ms": lift_avg, "achieved": lift_bytes / (lift_avg * 1e-3) / 1e9 if lift_avg > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": (lift_bytes / (lift_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if lift_avg > 0 else 0.0},
+            "lift_fill_roofline": entry(fill_key, n_fill, fill_ms, fill_b),
+            "aggregation_roofline": {"what": "layers 1+2 of this rank: keys + radix sort + run heads + segment reduce (SURVEY §8d table bytes)",
+                                     "ms_per_step": agg_total_ms, "achieved": agg_bytes / (agg_total_ms * 1e-3) / 1e9 if agg_total_ms > 0 else 0.0,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": (agg_bytes / (agg_total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if agg_total_ms > 0 else 0.0},
+            "linegraph_fill_roofline": k3,
         }
-        line["linegraph_fill_roofline"] = k3
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, seed=11)
         print(json.dumps(line), flush=True)
     if launched:
-        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
     return 0

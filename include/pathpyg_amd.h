@@ -173,6 +173,23 @@ int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_e
                                                                     permutation behind in_*); with in_ptr it IS the bipartite "last"
                                                                     plan of an order-2 model, whose nodes are this graph's edges */
 
+/* The same plan for a DESTINATION-ROW PARTITION of the graph (multi-GPU DBGNN; the reference is single-process): this rank owns
+ * n_dst destination rows; its local source space has n_src >= n_dst rows, the first n_dst being the owned nodes themselves (source i ==
+ * destination i) and the rest halo rows owned by peers.  edge_index holds LOCAL ids (row 0 < n_src, row 1 < n_dst).  Two phases around
+ * the one exchange the normalisation needs:
+ *   pp_gcn_plan_begin : destination grouping, self loops, weighted in-degree -> dinv[0..n_dst), self_coef[n_dst]; with row_sorted
+ *                       also out_ptr [n_src+1]
+ *   (the caller fills dinv[n_dst..n_src) with the owners' values — one halo exchange of 4 bytes per halo row)
+ *   pp_gcn_plan_finish: coefficients dinv[src] w dinv[dst] of both groupings (in_val in place; out_*).
+ * The workspace (pp_gcn_plan_ws_bytes(n_edges, n_src)) carries the state between the two calls and must not be touched in between.
+ * pp_gcn_plan == begin + finish with n_src == n_dst. */
+int pp_gcn_plan_begin(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_src, int64_t n_dst, int row_sorted,
+                      int32_t* in_ptr, int32_t* in_idx, float* in_val, int32_t* out_ptr, float* self_coef, float* dinv, int32_t* dst_order,
+                      void* ws, size_t ws_bytes, pp_stream_t stream);
+int pp_gcn_plan_finish(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_src, int64_t n_dst, int row_sorted,
+                       const float* dinv, const int32_t* in_idx, float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, void* ws,
+                       size_t ws_bytes, pp_stream_t stream);
+
 /* CSR views of DBGNN's bipartite_edge_index [2,n_pairs] (row 0: higher-order node, row 1: first-order node),
  * src/pathpyG/nn/dbgnn.py:64-69: in_* grouped by first-order node (+ its in-degree as float), out_* by higher-order node.
  * src_sorted != 0: row 0 is non-decreasing (arange for the reference's "last"/"first" mappings): no source-major sort.
@@ -262,9 +279,11 @@ int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val,
 /* Backward of that layer in one kernel (pp_spmm_f32 over the source-major CSR + pp_dense_backward_f32 without the round trip of the
  * aggregated gradient through HBM):  G = A^T D + diag(self_coef) D with D = dpre [n_rows,M];
  *   d_in[n_rows,K] = (G . W) (*) ELU'(X) when fuse_act (X [n_rows,K] is then the stored activation of the layer below),
- *   colsum_in[K] (may be NULL) = column sums of d_in,  dW[M,K] = G^T X.   W is [M,K]; M, K in {16,32,64}. */
+ *   colsum_in[K] (may be NULL) = column sums of d_in,  dW[M,K] = G^T X.   W is [M,K]; M, K in {16,32,64}.
+ * n_self <= n_rows: only the first n_self rows carry the self term (D then has n_self rows).  n_self == n_rows for a whole graph;
+ * a destination-row partition (multi-GPU) has n_rows = owned + halo source rows and n_self = owned rows. */
 size_t pp_gcn_backward_ws_bytes(int64_t n_rows);
-int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
+int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
                         const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
                         const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, pp_stream_t stream);
 
@@ -273,7 +292,7 @@ int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val
  * colsum_in[K] (may be NULL) = column sums of d_in.  D = dpre [n_rows,M], W [M,K]; shapes 64x128, 128x64, 128x128.  The weight gradient
  * of such a layer is dW = dpre^T (A_hat X) with the agg_out of its forward call (pp_weight_grad_f32): 64 accumulator registers per
  * 64x64 block do not fit beside the gather here. */
-int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
+int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
                           const float* self_coef, const float* W, int K, const float* X_act, int fuse_act, const int32_t* heavy_slot,
                           const float* heavy_sum, float* d_in, float* colsum_in, pp_stream_t stream);
 

@@ -508,6 +508,47 @@ def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nod
     return plan
 
 
+def gcn_plan_partition(edge_index_local: torch.Tensor, edge_weight: torch.Tensor | None, n_src: int, n_dst: int, halo_dinv,
+                       row_sorted: bool = False, status_out: list | None = None, want_dst_order: bool = False) -> CsrPlan:
+    """GCN plan of a DESTINATION-ROW PARTITION (multi-GPU DBGNN): ``edge_index_local`` [2, E] holds local ids — row 0 (sources) below
+    ``n_src`` = owned + halo rows, row 1 (destinations) below ``n_dst`` = owned rows, owned node i is source i and destination i.
+    ``halo_dinv(dinv_own [n_dst]) -> dinv_halo [n_src - n_dst]`` is called between the two phases of the plan (pp_gcn_plan_begin /
+    pp_gcn_plan_finish) and returns the d^-1/2 of the halo rows from their owners (one 4-byte-per-row halo exchange)."""
+    ei = _edge_index(edge_index_local)
+    dev = require_device(ei, edge_weight)
+    e = ei.size(1)
+    if edge_weight is not None:
+        edge_weight = edge_weight.to(torch.float32).contiguous()
+        if edge_weight.numel() != e:
+            raise ValueError("edge_weights must hold one value per edge")
+    L = lib()
+    with torch.cuda.device(dev):
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        plan = CsrPlan(n_dst=n_dst, n_src=n_src,
+                       fwd_ptr=torch.empty(n_dst + 1, **i32), fwd_idx=torch.empty(e, **i32), fwd_val=torch.empty(e, **f32),
+                       bwd_ptr=torch.empty(n_src + 1, **i32), bwd_idx=torch.empty(e, **i32), bwd_val=torch.empty(e, **f32),
+                       self_coef=torch.empty(n_dst, **f32))
+        dinv = torch.empty(n_src, **f32)
+        ws = _workspace(L.pp_gcn_plan_ws_bytes(e, n_src), dev)
+        if want_dst_order:
+            plan.dst_order = torch.empty(e, **i32)
+        rs = 1 if row_sorted else 0
+        check(L.pp_gcn_plan_begin(_p(ei), _p(edge_weight), e, n_src, n_dst, rs, _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val),
+                                  _p(plan.bwd_ptr), _p(plan.self_coef), _p(dinv), _p(plan.dst_order), _p(ws), ws.numel(), _stream()),
+              "pp_gcn_plan_begin")
+        if n_src > n_dst:
+            dinv[n_dst:] = halo_dinv(dinv[:n_dst])
+        check(L.pp_gcn_plan_finish(_p(ei), _p(edge_weight), e, n_src, n_dst, rs, _p(dinv), _p(plan.fwd_idx), _p(plan.fwd_val), _p(plan.bwd_ptr),
+                                   _p(plan.bwd_idx), _p(plan.bwd_val), _p(ws), ws.numel(), _stream()), "pp_gcn_plan_finish")
+        entry = (ws[8:16].view(torch.int64).clone(), plan, _plan_row_lengths(plan))
+        if status_out is None:
+            _finish_plans([entry], "GCNConv (partition)")
+        else:
+            status_out.append(entry)
+    return plan
+
+
 def bipartite_plan_from_edge_grouping(plan_fo: CsrPlan, edge_dst: torch.Tensor, n_ho: int) -> CsrPlan:
     """Bipartite "last" plan of an order-2 De Bruijn model WITHOUT another sort: the higher-order nodes are the first-order graph's
     edges (same order), so "the higher-order nodes that end in node v" = "the edges into v" = the destination grouping the
@@ -658,9 +699,10 @@ def spmm_act_backward(ptr, idx, val, n_rows: int, d: torch.Tensor, z: torch.Tens
 
 def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, n_rows: int, x: torch.Tensor,
                 self_coef: torch.Tensor | None, weight: torch.Tensor, bias: torch.Tensor | None, act: bool, want_agg: bool = False,
-                heavy: HeavyRows | None = None):
+                heavy: HeavyRows | None = None, out: torch.Tensor | None = None):
     """``act((A x + diag(self_coef) x) @ weight.T + bias)`` in one kernel (aggregation fused with the MFMA product);
-    ``want_agg``: returns ``(y, A x + diag(self_coef) x)``."""
+    ``want_agg``: returns ``(y, A x + diag(self_coef) x)``.  ``out``: a contiguous ``[n_rows, Q]`` fp32 tensor to write ``y`` into
+    (e.g. the head of a buffer whose tail receives halo rows)."""
     dev = require_device(ptr, idx, val, x, self_coef, weight, bias)
     x, weight = x.contiguous(), weight.contiguous()
     q, p = weight.shape
@@ -669,7 +711,12 @@ def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, 
     if bias is not None:
         bias = bias.contiguous()
     with torch.cuda.device(dev):
-        y = torch.empty((n_rows, q), dtype=torch.float32, device=dev)
+        if out is None:
+            y = torch.empty((n_rows, q), dtype=torch.float32, device=dev)
+        else:
+            if tuple(out.shape) != (n_rows, q) or out.dtype != torch.float32 or not out.is_contiguous():
+                raise ValueError("gcn_forward: out must be a contiguous fp32 [n_rows, Q] tensor")
+            y = out
         agg = torch.empty((n_rows, p), dtype=torch.float32, device=dev) if want_agg else None
         slot, sums = _heavy_args(heavy, idx, val, x)
         check(lib().pp_gcn_forward_f32(_p(ptr), _p(idx), _p(val), n_rows, x.size(0), _p(x), p, _p(self_coef), _p(weight), q, _p(bias),
@@ -678,13 +725,15 @@ def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, 
 
 
 def gcn_backward(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, x: torch.Tensor, weight: torch.Tensor, fuse_act: bool,
-                 want_colsum: bool, heavy: HeavyRows | None = None):
+                 want_colsum: bool, heavy: HeavyRows | None = None, n_self: int | None = None):
     """Backward of :func:`gcn_forward` in one kernel: ``(d_in, colsum_in or None, dW)`` from the gradient ``dpre`` w.r.t. the
-    layer's pre-activation, over the SOURCE-major CSR (``ptr``/``idx``/``val`` = the plan's ``bwd_*`` arrays)."""
+    layer's pre-activation, over the SOURCE-major CSR (``ptr``/``idx``/``val`` = the plan's ``bwd_*`` arrays).
+    ``n_self`` (default ``n_rows``): partition plans — ``n_rows`` = owned + halo source rows, ``dpre`` has the ``n_self`` owned rows."""
     dev = require_device(ptr, idx, val, dpre, self_coef, x, weight)
     dpre, x, weight = dpre.contiguous(), x.contiguous(), weight.contiguous()
     m, k = weight.shape
-    if dpre.size(1) != m or x.size(1) != k or x.size(0) != n_rows or dpre.size(0) != n_rows:
+    n_self = n_rows if n_self is None else int(n_self)
+    if dpre.size(1) != m or x.size(1) != k or x.size(0) != n_rows or dpre.size(0) != n_self or n_self > n_rows:
         raise ValueError("gcn_backward: shapes do not match")
     L = lib()
     with torch.cuda.device(dev):
@@ -694,7 +743,7 @@ def gcn_backward(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, x: t
         dw = torch.empty((m, k), **f32)
         slot, sums = _heavy_args(heavy, idx, val, dpre)
         ws = _workspace(L.pp_gcn_backward_ws_bytes(n_rows), dev)
-        check(L.pp_gcn_backward_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(dpre), m, _p(self_coef), _p(x), k, _p(weight),
+        check(L.pp_gcn_backward_f32(_p(ptr), _p(idx), _p(val), n_rows, n_self, _p(dpre), m, _p(self_coef), _p(x), k, _p(weight),
                                     1 if fuse_act else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _p(dw), _p(ws), ws.numel(), _stream()),
               "pp_gcn_backward_f32")
     return d_in, colsum, dw
@@ -706,13 +755,14 @@ def gcn_fused_supported(p: int, q: int) -> int:
 
 
 def gcn_input_grad(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, weight: torch.Tensor, x_act: torch.Tensor | None,
-                   want_colsum: bool, heavy: HeavyRows | None = None):
+                   want_colsum: bool, heavy: HeavyRows | None = None, n_self: int | None = None):
     """``((A^T dpre + diag(self_coef) dpre) @ weight) * elu'(x_act)`` (no activation factor when ``x_act`` is None) and optionally its
     column sums, over the SOURCE-major CSR — the input gradient of a 128-wide fused layer."""
     dev = require_device(ptr, idx, val, dpre, self_coef, weight, x_act)
     dpre, weight = dpre.contiguous(), weight.contiguous()
     m, k = weight.shape
-    if dpre.size(1) != m or dpre.size(0) != n_rows or (x_act is not None and tuple(x_act.shape) != (n_rows, k)):
+    n_self = n_rows if n_self is None else int(n_self)
+    if dpre.size(1) != m or dpre.size(0) != n_self or n_self > n_rows or (x_act is not None and tuple(x_act.shape) != (n_rows, k)):
         raise ValueError("gcn_input_grad: shapes do not match")
     if x_act is not None:
         x_act = x_act.contiguous()
@@ -720,7 +770,7 @@ def gcn_input_grad(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, we
         d_in = torch.empty((n_rows, k), dtype=torch.float32, device=dev)
         colsum = torch.empty(k, dtype=torch.float32, device=dev) if want_colsum else None
         slot, sums = _heavy_args(heavy, idx, val, dpre)
-        check(lib().pp_gcn_input_grad_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(dpre), m, _p(self_coef), _p(weight), k, _p(x_act),
+        check(lib().pp_gcn_input_grad_f32(_p(ptr), _p(idx), _p(val), n_rows, n_self, _p(dpre), m, _p(self_coef), _p(weight), k, _p(x_act),
                                           1 if x_act is not None else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _stream()),
               "pp_gcn_input_grad_f32")
     return d_in, colsum

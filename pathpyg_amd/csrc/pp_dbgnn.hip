@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void k_gcn_coefficients(const int64_t* __re
 
 // pp_gcn_plan's one pass over the edge list: both endpoints validated, (source, weight) packed, the destination written as the sort key
 // of the forward grouping and the last self loop of every node recorded (one read of the edge list instead of three)
-__global__ __launch_bounds__(kBlock) void k_plan_edges(const int64_t* __restrict__ edge_index, int64_t n_edges, int64_t n_nodes,
+__global__ __launch_bounds__(kBlock) void k_plan_edges(const int64_t* __restrict__ edge_index, int64_t n_edges, int64_t n_nodes, int64_t n_dst,
                                                       const float* __restrict__ w, uint2* __restrict__ packed, uint32_t* __restrict__ dst_keys,
                                                       int32_t* __restrict__ last_loop, int32_t* __restrict__ src_ptr,
                                                       int64_t* __restrict__ status) {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void k_plan_edges(const int64_t* __restrict
             for (int64_t v = a + 1; v <= n_nodes; ++v) src_ptr[v] = (int32_t)n_edges;
         }
     }
-    const bool bad_r = r < 0 || r >= n_nodes, bad_c = c < 0 || c >= n_nodes;
+    const bool bad_r = r < 0 || r >= n_nodes, bad_c = c < 0 || c >= n_dst;       // n_nodes = source rows (owned + halo), n_dst = owned rows
     if (bad_r || bad_c) atomicOr((unsigned long long*)status, 1ull);
     if (!bad_r && r == c) atomicMax(&last_loop[r], (int32_t)e);
     if (bad_r) r = 0;
@@ -531,26 +531,29 @@ extern "C" {
 // ---------------------------------------------------------------- GCN plan
 size_t pp_gcn_plan_ws_bytes(int64_t n_edges, int64_t n_nodes) { return carve_plan(nullptr, n_edges, n_nodes).total_bytes; }
 
-int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int row_sorted, int32_t* in_ptr,
-                int32_t* in_idx, float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, int32_t* dst_order,
-                void* ws, size_t ws_bytes, pp_stream_t stream) {
+// Phase 1 (see the header): everything that needs no foreign data.  n_src >= n_dst; the first n_dst source rows ARE the destinations.
+int pp_gcn_plan_begin(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_src, int64_t n_dst, int row_sorted,
+                      int32_t* in_ptr, int32_t* in_idx, float* in_val, int32_t* out_ptr, float* self_coef, float* dinv, int32_t* dst_order,
+                      void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
-    PP_REQUIRE(n_edges >= 0 && n_nodes >= 0, PP_ERR_ARG, "pp_gcn_plan: negative size");
-    PP_REQUIRE(n_edges < (int64_t)0x7fffffff && n_nodes < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_plan: E or N >= 2^31");
-    PlanWs w = carve_plan(ws, n_edges, n_nodes);
+    PP_REQUIRE(n_edges >= 0 && n_dst >= 0 && n_src >= n_dst, PP_ERR_ARG, "pp_gcn_plan: bad sizes (need n_src >= n_dst >= 0)");
+    PP_REQUIRE(n_edges < (int64_t)0x7fffffff && n_src < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_plan: E or N >= 2^31");
+    PlanWs w = carve_plan(ws, n_edges, n_src);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_gcn_plan: workspace too small");
     PP_HIP(hipMemsetAsync(w.status, 0, 2 * sizeof(int64_t), st));
-    if (n_nodes == 0) return PP_OK;
+    if (n_src == 0) return PP_OK;
     const unsigned egrid = (unsigned)ceil_div(n_edges > 0 ? n_edges : 1, kBlock);
-    const unsigned ngrid = (unsigned)ceil_div(n_nodes, kBlock);
-    PP_HIP(hipMemsetAsync(w.last_loop, 0xff, (size_t)n_nodes * sizeof(int32_t), st));     // -1
+    if (n_dst > 0) PP_HIP(hipMemsetAsync(w.last_loop, 0xff, (size_t)n_dst * sizeof(int32_t), st));     // -1
     if (n_edges > 0) {
-        k_plan_edges<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, n_nodes, edge_weight, w.packed, w.keys, w.last_loop,
+        k_plan_edges<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, n_src, n_dst, edge_weight, w.packed, w.keys, w.last_loop,
                                                row_sorted ? out_ptr : nullptr, w.status + 1);
+        PP_LAUNCH_CHECK();
+    } else if (row_sorted) {
+        k_ptr_from_sorted_i64_i32<<<1, kBlock, 0, st>>>(edge_index, 0, n_src, out_ptr);
         PP_LAUNCH_CHECK();
     }
     // edges grouped by destination (forward aggregation): order[p] = edge id, sorted[p] = its destination
-    int rc = group_by(edge_index + n_edges, n_edges, n_nodes, w, in_ptr, st, true);
+    int rc = group_by(edge_index + n_edges, n_edges, n_dst, w, in_ptr, st, true);
     if (rc != PP_OK) return rc;
     if (n_edges > 0) {
         k_gather_by_dst<<<egrid, kBlock, 0, st>>>(w.packed, n_edges, w.order, in_idx, in_val);
@@ -560,31 +563,56 @@ int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_e
             PP_LAUNCH_CHECK();
         }
     }
-    k_gcn_degree_grouped<<<ngrid, kBlock, 0, st>>>(in_idx, in_val, (const uint32_t*)in_ptr, w.last_loop, edge_weight, n_nodes, w.dinv, self_coef);
-    PP_LAUNCH_CHECK();
+    if (n_dst > 0) {
+        k_gcn_degree_grouped<<<(unsigned)ceil_div(n_dst, kBlock), kBlock, 0, st>>>(in_idx, in_val, (const uint32_t*)in_ptr, w.last_loop, edge_weight,
+                                                                                  n_dst, dinv, self_coef);
+        PP_LAUNCH_CHECK();
+    }
+    return PP_OK;
+}
+
+// Phase 2: dinv[0..n_src) is complete (the halo part came from the owners) -> normalised coefficients in both groupings.
+int pp_gcn_plan_finish(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_src, int64_t n_dst, int row_sorted,
+                       const float* dinv, const int32_t* in_idx, float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, void* ws,
+                       size_t ws_bytes, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_edges >= 0 && n_dst >= 0 && n_src >= n_dst, PP_ERR_ARG, "pp_gcn_plan: bad sizes (need n_src >= n_dst >= 0)");
+    PlanWs w = carve_plan(ws, n_edges, n_src);
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_gcn_plan: workspace too small");
+    if (n_src == 0) return PP_OK;
+    const unsigned egrid = (unsigned)ceil_div(n_edges > 0 ? n_edges : 1, kBlock);
     if (n_edges > 0) {
-        k_in_coefficients<<<egrid, kBlock, 0, st>>>(in_idx, w.sorted, w.dinv, n_edges, in_val);
+        k_in_coefficients<<<egrid, kBlock, 0, st>>>(in_idx, w.sorted, dinv, n_edges, in_val);
         PP_LAUNCH_CHECK();
     }
     // edges grouped by source (backward = transposed aggregation)
     if (row_sorted) {       // De Bruijn layers come out of coalesce (row, col)-sorted: the edge order already is the grouping
-        if (n_edges == 0) {  // (with edges, k_plan_edges wrote the row pointer)
-            k_ptr_from_sorted_i64_i32<<<1, kBlock, 0, st>>>(edge_index, 0, n_nodes, out_ptr);
-            PP_LAUNCH_CHECK();
-        }
-        if (n_edges > 0) {
-            k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, nullptr, w.dinv, 0, out_idx, out_val);
+        if (n_edges > 0) {  // (k_plan_edges wrote the row pointer in phase 1)
+            k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, nullptr, dinv, 0, out_idx, out_val);
             PP_LAUNCH_CHECK();
         }
         return PP_OK;
     }
-    rc = group_by(edge_index, n_edges, n_nodes, w, out_ptr, st);
+    int rc = group_by(edge_index, n_edges, n_src, w, out_ptr, st);
     if (rc != PP_OK) return rc;
     if (n_edges > 0) {
-        k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, w.dinv, 0, out_idx, out_val);
+        k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, dinv, 0, out_idx, out_val);
         PP_LAUNCH_CHECK();
     }
     return PP_OK;
+}
+
+int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int row_sorted, int32_t* in_ptr,
+                int32_t* in_idx, float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, int32_t* dst_order,
+                void* ws, size_t ws_bytes, pp_stream_t stream) {
+    PP_REQUIRE(n_edges >= 0 && n_nodes >= 0, PP_ERR_ARG, "pp_gcn_plan: negative size");
+    PlanWs w = carve_plan(ws, n_edges, n_nodes);
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_gcn_plan: workspace too small");
+    int rc = pp_gcn_plan_begin(edge_index, edge_weight, n_edges, n_nodes, n_nodes, row_sorted, in_ptr, in_idx, in_val, out_ptr, self_coef, w.dinv,
+                               dst_order, ws, ws_bytes, stream);
+    if (rc != PP_OK) return rc;
+    return pp_gcn_plan_finish(edge_index, edge_weight, n_edges, n_nodes, n_nodes, row_sorted, w.dinv, in_idx, in_val, out_ptr, out_idx, out_val, ws,
+                              ws_bytes, stream);
 }
 
 // bipartite higher-order -> first-order projection plan: forward rows = first-order nodes, backward rows = higher-order nodes

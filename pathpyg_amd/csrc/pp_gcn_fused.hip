@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kThreads) void k_gcn_forward(const int32_t* __restr
                                                               const float* __restrict__ self_coef, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int act, HeavyRows heavy,
                                                               float* __restrict__ agg_out, float* __restrict__ Y,
-                                                              const float* __restrict__ act_in, float* __restrict__ colsum) {
+                                                              const float* __restrict__ act_in, float* __restrict__ colsum, int64_t n_self) {
     constexpr int kLanes = P / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = P / 4, CT = Q / 16, TS = P + 4;
     constexpr int kBatch = kRows < 2 ? kRows : (kRows >= 8 ? 4 : 2);      // 128-wide rows: 2 waves/SIMD, registers to spare for a deeper gather
     constexpr int kWaves = kThreads / kWave;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void k_gcn_forward(const int32_t* __restr
             const bool in = mine < pe[q];
             cj[q] = in ? idx[mine] : 0;
             cv[q] = in ? (val ? val[mine] : 1.f) : 0.f;
-            sc[q] = (self_coef != nullptr && r0 + q < n_rows) ? self_coef[r0 + q] : 0.f;
+            sc[q] = (self_coef != nullptr && r0 + q < n_self) ? self_coef[r0 + q] : 0.f;
         }
 #pragma unroll
         for (int b0 = 0; b0 < kRows; b0 += kBatch) {
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void k_gcn_forward(const int32_t* __restr
 #pragma unroll
             for (int qq = 0; qq < kBatch; ++qq) {
                 const int q = b0 + qq;
-                const bool self_here = self_coef != nullptr && r0 + q < n_rows;
+                const bool self_here = self_coef != nullptr && r0 + q < n_self;
                 const int first = __shfl(cj[q], 0, kLanes);
                 const int dummy = p[q] < pe[q] ? first : (self_here ? (int)(r0 + q) : 0);
                 self_off[qq] = (off_t)(uint32_t)(self_here ? (int)(r0 + q) : dummy) * (off_t)(P * 4) + (off_t)(16 * l);
@@ -274,6 +274,7 @@ struct GcnArgs {
     float *agg_out, *Y;
     const float* act_in;
     float* colsum;
+    int64_t n_self;          // rows with a self term (rectangular partition plans: the owned rows come first, halo rows have none)
 };
 
 template <int P, int Q, int kEpi>
@@ -294,7 +295,7 @@ static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const GcnArgs& a)
     if (blocks > resident) blocks = resident;
 #define PP_FWD(H, WIDE)                                                                                                                  \
     k_gcn_forward<P, Q, H, WIDE, kThreads, kEpi><<<(unsigned)blocks, kThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n, a.X, a.self_coef, a.W, a.bias, \
-                                                                                         a.act, a.heavy, a.agg_out, a.Y, a.act_in, a.colsum)
+                                                                                         a.act, a.heavy, a.agg_out, a.Y, a.act_in, a.colsum, a.n_self)
     if (a.heavy.slot != nullptr) { if (a.wide) PP_FWD(true, true); else PP_FWD(true, false); }
     else { if (a.wide) PP_FWD(false, true); else PP_FWD(false, false); }
 #undef PP_FWD
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
                                                              const float* __restrict__ val, int64_t n_rows, const float* __restrict__ D,
                                                              const float* __restrict__ self_coef, const float* __restrict__ X,
                                                              const float* __restrict__ W, int fuse_act, HeavyRows heavy, float* __restrict__ d_in,
-                                                             float* __restrict__ colsum_in, float* __restrict__ partial_w) {
+                                                             float* __restrict__ colsum_in, float* __restrict__ partial_w, int64_t n_self) {
     constexpr int kLanes = M / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = M / 4, MT = M / 16, CT = K / 16, TS = M + 4;
     constexpr int kBatch = kRows < 2 ? kRows : 2;
     using off_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;     // byte offset of a gathered row
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
             const bool in = mine < pe[q];
             cj[q] = in ? idx[mine] : 0;
             cv[q] = in ? (val ? val[mine] : 1.f) : 0.f;
-            sc[q] = (self_coef != nullptr && r0 + q < n_rows) ? self_coef[r0 + q] : 0.f;
+            sc[q] = (self_coef != nullptr && r0 + q < n_self) ? self_coef[r0 + q] : 0.f;
         }
 #pragma unroll
         for (int b0 = 0; b0 < kRows; b0 += kBatch) {
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
 #pragma unroll
             for (int qq = 0; qq < kBatch; ++qq) {
                 const int q = b0 + qq;
-                const bool self_here = self_coef != nullptr && r0 + q < n_rows;
+                const bool self_here = self_coef != nullptr && r0 + q < n_self;
                 const int first = __shfl(cj[q], 0, kLanes);
                 const int dummy = p[q] < pe[q] ? first : (self_here ? (int)(r0 + q) : 0);
                 self_off[qq] = (off_t)(uint32_t)(self_here ? (int)(r0 + q) : dummy) * (off_t)(M * 4) + (off_t)(16 * l);
@@ -553,7 +554,7 @@ constexpr int64_t kGcnBackwardMaxBlocks = 256 * 4;
 template <int M, int K>
 static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
                                const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy, bool wide,
-                               float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out) {
+                               float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out, int64_t n_self) {
     static int resident_of[2] = {0, 0};
     const int hv = heavy.slot != nullptr ? 1 : 0;
     if (resident_of[hv] == 0) {
@@ -569,7 +570,7 @@ static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* p
     int64_t blocks = ceil_div(n_tiles, kGcnWaves);
     if (blocks > resident) blocks = resident;
     *blocks_out = blocks;
-#define PP_BWD(H, WIDE) k_gcn_backward<M, K, H, WIDE><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w)
+#define PP_BWD(H, WIDE) k_gcn_backward<M, K, H, WIDE><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w, n_self)
     if (heavy.slot != nullptr) { if (wide) PP_BWD(true, true); else PP_BWD(true, false); }
     else { if (wide) PP_BWD(false, true); else PP_BWD(false, false); }
 #undef PP_BWD
@@ -579,11 +580,11 @@ static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* p
 template <int M>
 static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
                                  const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy, bool wide,
-                                 float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out) {
+                                 float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out, int64_t n_self) {
     switch (K) {
-        case 16: return launch_gcn_backward<M, 16>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out);
-        case 32: return launch_gcn_backward<M, 32>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out);
-        case 64: return launch_gcn_backward<M, 64>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out);
+        case 16: return launch_gcn_backward<M, 16>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self);
+        case 32: return launch_gcn_backward<M, 32>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self);
+        case 64: return launch_gcn_backward<M, 64>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self);
         default: return PP_ERR_ARG;
     }
 }
@@ -606,7 +607,7 @@ int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val,
     const bool wide = (uint64_t)n_src * (uint64_t)P * 4 > 0xffffffffull;          // 64-bit row offsets from 4 GiB on
     if (n_rows == 0) return PP_OK;
     const int64_t n_tiles = pp::ceil_div(n_rows, 16);
-    const pp::GcnArgs a{ptr, idx, val, n_rows, X, self_coef, W, bias, act, pp::HeavyRows{heavy_slot, heavy_sum}, wide, agg_out, Y, nullptr, nullptr};
+    const pp::GcnArgs a{ptr, idx, val, n_rows, X, self_coef, W, bias, act, pp::HeavyRows{heavy_slot, heavy_sum}, wide, agg_out, Y, nullptr, nullptr, n_rows};
     int rc;
     if (pp::gcn_wide_shape(P, Q)) rc = pp::launch_gcn_wide<0>(P, Q, n_tiles, st, a);
     else switch (P) {
@@ -619,11 +620,11 @@ int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val,
     return PP_OK;
 }
 
-int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
+int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
                           const float* self_coef, const float* W, int K, const float* X_act, int fuse_act, const int32_t* heavy_slot,
                           const float* heavy_sum, float* d_in, float* colsum_in, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
-    PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_input_grad_f32: negative size");
+    PP_REQUIRE(n_rows >= 0 && n_self >= 0 && n_self <= n_rows, PP_ERR_ARG, "pp_gcn_input_grad_f32: bad sizes");
     PP_REQUIRE(pp::gcn_wide_shape(M, K), PP_ERR_ARG, "pp_gcn_input_grad_f32: unsupported layer shape %dx%d (64/128 x 128, 128x64)", M, K);
     PP_REQUIRE(d_in != nullptr && (!fuse_act || X_act != nullptr), PP_ERR_ARG, "pp_gcn_input_grad_f32: d_in (and X_act with fuse_act) required");
     PP_REQUIRE(((uintptr_t)D | (uintptr_t)X_act | (uintptr_t)d_in) % 16 == 0, PP_ERR_ARG, "pp_gcn_input_grad_f32: D, X_act and d_in must be 16-byte aligned");
@@ -633,7 +634,7 @@ int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* v
     if (n_rows == 0) return PP_OK;
     const int64_t n_tiles = pp::ceil_div(n_rows, 16);
     const pp::GcnArgs a{ptr, idx, val, n_rows, D, self_coef, W, nullptr, fuse_act ? 1 : 0, pp::HeavyRows{heavy_slot, heavy_sum}, wide, nullptr, d_in,
-                        X_act, colsum_in};
+                        X_act, colsum_in, n_self};
     const int rc = pp::launch_gcn_wide<1>(M, K, n_tiles, st, a);
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();
@@ -646,11 +647,11 @@ size_t pp_gcn_backward_ws_bytes(int64_t n_rows) {
     return pp::align_up((size_t)blocks * 4096 * sizeof(float));
 }
 
-int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int M,
+int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
                         const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
                         const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
-    PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_backward_f32: negative size");
+    PP_REQUIRE(n_rows >= 0 && n_self >= 0 && n_self <= n_rows, PP_ERR_ARG, "pp_gcn_backward_f32: bad sizes");
     PP_REQUIRE(pp_dense_supported(M, K), PP_ERR_ARG, "pp_gcn_backward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", M, K);
     PP_REQUIRE(d_in != nullptr && dW != nullptr, PP_ERR_ARG, "pp_gcn_backward_f32: d_in and dW are required");
     PP_REQUIRE(((uintptr_t)D) % 16 == 0, PP_ERR_ARG, "pp_gcn_backward_f32: D must be 16-byte aligned");
@@ -666,9 +667,9 @@ int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val
     int64_t blocks = 0;
     int rc;
     switch (M) {
-        case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks); break;
-        case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks); break;
-        default: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks); break;
+        case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self); break;
+        case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self); break;
+        default: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self); break;
     }
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();

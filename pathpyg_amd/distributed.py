@@ -15,6 +15,8 @@ planner and the collectives on CPU with the ``gloo`` backend by substituting the
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -145,174 +147,318 @@ def all_reduce_gradients(module: torch.nn.Module, group=None, average: bool = Tr
 
 
 # =====================================================================================================
-# Destination-partitioned DBGNN: rank r owns a contiguous slice of the DESTINATION rows of the
-# first-order graph, of the higher-order graph and of the bipartite map, i.e. the rows of every feature matrix.
-# Per propagation: all-gather of the transformed features H (every rank needs the source rows its edges point
-# to), local atomics-free CSR aggregation of the owned rows, and in the backward pass a reduce-scatter of the
-# source-row gradients.  Weight gradients are averaged with one flattened all-reduce.  xGMI is point-to-point:
-# the row all-gather moves N*F*4 bytes per layer in total, each rank receiving (R-1)/R of it over its 7 links.
+# Collectives of the partitioned path.  RCCL ("nccl") moves device buffers directly over xGMI; any other backend (gloo in the CPU
+# tests, or gloo with several ranks sharing one GPU in the single-GPU hardware tests) is served by staging through host memory —
+# test transport only, the driver's multi-GPU runs use RCCL.
 # =====================================================================================================
-from . import _hip  # noqa: E402
+class Comm:
+    """Process-group handle with the five collectives the partitioned lift + DBGNN need, and a byte counter per kind."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = _world(group)
+        self.backend = dist.get_backend(group) if (self.world > 1 or (dist.is_available() and dist.is_initialized())) else None
+        self.native = self.backend == "nccl"
+        self.sent_bytes = {"exchange": 0, "all_gather": 0, "reduce_scatter": 0, "all_reduce": 0}
+
+    def _stage(self, t: torch.Tensor) -> torch.Tensor:
+        return t if (self.native or not t.is_cuda) else t.cpu()
+
+    def exchange_counts(self, send_counts: list[int], device) -> list[int]:
+        """counts[r] rows go to rank r -> how many rows come from each rank (one all-to-all of ``world`` integers)."""
+        if self.world == 1:
+            return list(send_counts)
+        dev = device if self.native else torch.device("cpu")
+        send = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        return [int(v) for v in recv.tolist()]
+
+    def exchange_rows(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int], out: torch.Tensor | None = None) -> torch.Tensor:
+        """Variable all-to-all along dim 0: ``send`` holds the rows for rank 0, 1, .. back to back; returns (or fills ``out`` with) the
+        rows received from rank 0, 1, .. back to back."""
+        n_recv = int(sum(recv_counts))
+        shape = (n_recv,) + tuple(send.shape[1:])
+        if self.world == 1:
+            if out is None:
+                return send
+            out.copy_(send)
+            return out
+        row_bytes = send.element_size() * math.prod(send.shape[1:])
+        self.sent_bytes["exchange"] += (int(sum(send_counts)) - int(send_counts[self.rank])) * row_bytes
+        if self.native:
+            if out is None:
+                out = torch.empty(shape, dtype=send.dtype, device=send.device)
+            dist.all_to_all_single(out, send.contiguous(), list(recv_counts), list(send_counts), group=self.group)
+            return out
+        staged = torch.empty(shape, dtype=send.dtype)
+        dist.all_to_all_single(staged, send.detach().cpu().contiguous(), list(recv_counts), list(send_counts), group=self.group)
+        if out is None:
+            return staged.to(send.device)
+        out.copy_(staged)
+        return out
+
+    def all_gather_rows(self, x_local: torch.Tensor) -> torch.Tensor:
+        """Equal-sized row blocks of all ranks, rank order: ``[world * rows, ...]``."""
+        if self.world == 1:
+            return x_local
+        self.sent_bytes["all_gather"] += (self.world - 1) * x_local.numel() * x_local.element_size()
+        src = self._stage(x_local.contiguous())
+        out = torch.empty((self.world * src.size(0),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(out, src, group=self.group)
+        return out.to(x_local.device)
+
+    def reduce_scatter_rows(self, x_full: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
+        """Sum ``[world * rows_per_rank, ...]`` over the ranks, keep this rank's block."""
+        if self.world == 1:
+            return x_full
+        self.sent_bytes["reduce_scatter"] += (self.world - 1) * rows_per_rank * x_full[0].numel() * x_full.element_size()
+        src = self._stage(x_full.contiguous())
+        out = torch.empty((rows_per_rank,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.reduce_scatter_tensor(out, src, group=self.group)
+        return out.to(x_full.device)
+
+    def all_reduce_(self, t: torch.Tensor, op=None) -> torch.Tensor:
+        if self.world == 1:
+            return t
+        self.sent_bytes["all_reduce"] += t.numel() * t.element_size()
+        op = dist.ReduceOp.SUM if op is None else op
+        if self.native or not t.is_cuda:
+            dist.all_reduce(t, op=op, group=self.group)
+            return t
+        staged = t.cpu()
+        dist.all_reduce(staged, op=op, group=self.group)
+        t.copy_(staged)
+        return t
+
+    def all_gather_ints(self, values: list[int], device) -> list[list[int]]:
+        """Every rank's small integer vector (same length everywhere): ``[world][len(values)]`` on the host."""
+        if self.world == 1:
+            return [list(values)]
+        dev = device if self.native else torch.device("cpu")
+        mine = torch.tensor(values, dtype=torch.int64, device=dev)
+        out = torch.empty(self.world * mine.numel(), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        return out.view(self.world, -1).tolist()
 
 
 def node_ranges(num_nodes: int, world_size: int) -> list[tuple[int, int]]:
     return [((num_nodes * r) // world_size, (num_nodes * (r + 1)) // world_size) for r in range(world_size)]
 
 
-def _gather_rows(x_local: torch.Tensor, ranges, group) -> torch.Tensor:
-    """Concatenate the row slices of all ranks (rank order) -> [N, F]."""
-    world = len(ranges)
+def _even_cuts(num_nodes: int, world: int) -> list[int]:
+    return [(num_nodes * r) // world for r in range(world + 1)]
+
+
+def _ops_default(ops):
+    if ops is not None:
+        return ops
+    from .nn.sharded import HipOps
+    return HipOps()
+
+
+# =====================================================================================================
+# Graph shards (see pathpyg_amd.nn.sharded for the layout): halo discovery, the request exchange, the rectangular GCN plan with its
+# one d^-1/2 halo exchange, and the CSR that folds returned gradient rows into the owned rows.
+# =====================================================================================================
+def build_graph_shard(src: torch.Tensor, dst: torch.Tensor, weight: torch.Tensor | None, num_nodes: int, cuts: list[int], comm: Comm,
+                      ops=None, row_sorted: bool = False, status_out: list | None = None, want_dst_order: bool = False):
+    """This rank's :class:`~pathpyg_amd.nn.sharded.GraphShard` of a graph with ``num_nodes`` nodes from the edges (GLOBAL ids) that
+    point into its destination range ``[cuts[rank], cuts[rank+1])`` — GCN normalisation with PyG ``gcn_norm`` semantics
+    (reference nn/dbgnn.py:104-114 through GCNConv): every in-edge of an owned node is local, so the weighted in-degree is too;
+    the d^-1/2 of the halo sources comes from their owners in one 4-byte-per-row exchange."""
+    from .nn.sharded import GraphShard
+    ops = _ops_default(ops)
+    rank, world = comm.rank, comm.world
+    lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+    n_own = hi - lo
+    dev = src.device
     if world == 1:
-        return x_local
-    cap = max(hi - lo for lo, hi in ranges)
-    padded = x_local.new_zeros((cap, x_local.size(1)))
-    padded[: x_local.size(0)] = x_local
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, ranges)], dim=0)
+        plan = ops.gcn_plan(torch.stack((src, dst)), weight, num_nodes, row_sorted, status_out, want_dst_order=want_dst_order)
+        return GraphShard(lo=0, hi=num_nodes, n_own=num_nodes, n_halo=0, n_src=num_nodes, num_nodes=num_nodes, cuts=list(cuts), plan=plan,
+                          send_counts=[0], recv_counts=[0])
+    # ---- halo = the distinct foreign sources, ascending (= grouped by owner: owners hold ascending id ranges)
+    need = torch.zeros(num_nodes, dtype=torch.bool, device=dev)
+    need[src] = True
+    need[lo:hi] = False
+    halo_ids = torch.nonzero(need).flatten()
+    n_halo = int(halo_ids.numel())
+    halo_rank = torch.cumsum(need, 0) - 1
+    foreign = (src < lo) | (src >= hi)
+    src_local = torch.where(foreign, halo_rank[src] + n_own, src - lo)
+    del need, halo_rank, foreign
+    cuts_t = torch.tensor(cuts, dtype=torch.int64, device=dev)
+    bounds = torch.searchsorted(halo_ids, cuts_t).tolist()
+    recv_counts = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
+    send_counts = comm.exchange_counts(recv_counts, dev)
+    requests = comm.exchange_rows(halo_ids, recv_counts, send_counts)             # the rows each peer wants from me (global ids)
+    send_idx = (requests - lo).contiguous()
+    if send_idx.numel() and (int(send_idx.min()) < 0 or int(send_idx.max()) >= n_own):
+        raise RuntimeError("build_graph_shard: a peer asked for a row this rank does not own (inconsistent cuts)")
+
+    def halo_dinv(dinv_own: torch.Tensor) -> torch.Tensor:
+        return comm.exchange_rows(dinv_own.index_select(0, send_idx), send_counts, recv_counts)
+
+    plan = ops.gcn_plan_partition(torch.stack((src_local, dst - lo)), weight, n_own + n_halo, n_own, halo_dinv, row_sorted=False,
+                                  status_out=status_out, want_dst_order=want_dst_order)
+    back_ptr, back_idx = ops.group_rows(send_idx, n_own) if send_idx.numel() else (torch.zeros(n_own + 1, dtype=torch.int32, device=dev),
+                                                                                   torch.zeros(0, dtype=torch.int32, device=dev))
+    return GraphShard(lo=lo, hi=hi, n_own=n_own, n_halo=n_halo, n_src=n_own + n_halo, num_nodes=num_nodes, cuts=list(cuts), plan=plan,
+                      halo_ids=halo_ids, send_idx=send_idx, send_counts=send_counts, recv_counts=recv_counts, back_ptr=back_ptr,
+                      back_idx=back_idx)
 
 
-def _reduce_scatter_rows(x_full: torch.Tensor, ranges, rank: int, group) -> torch.Tensor:
-    """Sum the [N, F] partials of all ranks and keep this rank's row slice."""
-    world = len(ranges)
-    lo, hi = ranges[rank]
+def _bipartite_shard(ho_local: torch.Tensor, fo_global: torch.Tensor, n_ho_own: int, fo_cuts: list[int], comm: Comm, ops, src_sorted: bool):
+    """Plan of the partial bipartite sums: sources = the owned higher-order rows (local ids), destinations = ALL first-order nodes in
+    rank-major padded layout (node v of rank r's range sits at ``r * cap + v - fo_cuts[r]``) so that the ``[world * cap, H]`` partials
+    reduce-scatter without a copy.  Returns ``(plan, cap)``."""
+    world = comm.world
+    cap = max(max(fo_cuts[r + 1] - fo_cuts[r] for r in range(world)), 1)
     if world == 1:
-        return x_full[lo:hi]
-    backend = dist.get_backend(group)
-    if backend == "nccl":
-        cap = max(b - a for a, b in ranges)
-        chunks = []
-        for a, b in ranges:
-            c = x_full.new_zeros((cap, x_full.size(1)))
-            c[: b - a] = x_full[a:b]
-            chunks.append(c)
-        out = torch.empty_like(chunks[0])
-        dist.reduce_scatter(out, chunks, group=group)
-        return out[: hi - lo].contiguous()
-    summed = x_full.clone()                      # gloo has no reduce_scatter: all-reduce and slice (tests only)
-    dist.all_reduce(summed, group=group)
-    return summed[lo:hi].contiguous()
+        padded = fo_global
+    else:
+        cuts_t = torch.tensor(fo_cuts, dtype=torch.int64, device=fo_global.device)
+        owner = torch.searchsorted(cuts_t[1:].contiguous(), fo_global, right=True).clamp_(max=world - 1)
+        padded = owner * cap + fo_global - cuts_t[owner]
+    plan = ops.bipartite_plan(torch.stack((ho_local, padded)), n_ho_own, world * cap, None, src_sorted)
+    return plan, cap
 
 
-class _AllGatherRows(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x_local, ranges, rank, group):
-        ctx.ranges, ctx.rank, ctx.group = ranges, rank, group
-        return _gather_rows(x_local, ranges, group)
+def shard_dbgnn_bundle(data, comm: Comm, ops=None, fo_cuts: list[int] | None = None, ho_cuts: list[int] | None = None):
+    """Partition a REPLICATED ``MultiOrderModel.to_dbgnn_data`` bundle (reference multi_order_model.py:511-554) for this rank: the edges
+    into its first-order / higher-order destination ranges, the bipartite pairs of its higher-order rows, its feature rows (owned +
+    halo, taken from the replicated inputs: no exchange for the first layer) and labels.  ``fo_cuts`` / ``ho_cuts``: row cuts
+    (default: equal node counts; for a De Bruijn layer cut the higher-order ids at first-order node boundaries to get the
+    one-peer-per-row exchange)."""
+    from .nn.sharded import DbgnnShard
+    ops = _ops_default(ops)
+    rank, world = comm.rank, comm.world
+    n_fo, n_ho = int(data.num_nodes), int(data.num_ho_nodes)
+    fo_cuts = _even_cuts(n_fo, world) if fo_cuts is None else [int(c) for c in fo_cuts]
+    ho_cuts = _even_cuts(n_ho, world) if ho_cuts is None else [int(c) for c in ho_cuts]
 
-    @staticmethod
-    def backward(ctx, d_full):
-        return _reduce_scatter_rows(d_full.contiguous(), ctx.ranges, ctx.rank, ctx.group), None, None, None
+    def in_edges(edge_index, weights, cuts):
+        ei = _dispatch.plain(edge_index)
+        if world == 1:
+            return ei[0], ei[1], weights
+        mine = (ei[1] >= cuts[rank]) & (ei[1] < cuts[rank + 1])
+        return ei[0][mine], ei[1][mine], (None if weights is None else weights[mine])
 
-
-class _LocalPropagate(torch.autograd.Function):
-    """y_local = act(A_local x_full + self_coef * s_local + bias): rows = this rank's destinations, columns = all sources."""
-
-    @staticmethod
-    def forward(ctx, plan, x_full, s_local, bias, act: bool):
-        y = _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x_full, plan.self_coef, s_local, bias, act, heavy=plan.fwd_heavy)
-        ctx.plan, ctx.act, ctx.has_bias = plan, act, bias is not None
-        ctx.save_for_backward(y if act else None)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        plan = ctx.plan
-        (y,) = ctx.saved_tensors
-        need_b = ctx.has_bias and ctx.needs_input_grad[3]
-        if ctx.act or need_b:
-            dpre, dbias = _hip.act_backward(dy, y, ctx.act, want_dpre=ctx.act, want_dbias=need_b)
-            if not ctx.act:
-                dpre = dy.contiguous()
-        else:
-            dpre, dbias = dy.contiguous(), None
-        dx_full = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, heavy=plan.bwd_heavy) if ctx.needs_input_grad[1] else None
-        ds = _hip.scale_rows(dpre, plan.self_coef) if ctx.needs_input_grad[2] else None
-        return None, dx_full, ds, dbias, None
-
-
-def _rect_plan(src_global, dst_local, value, n_src: int, n_dst: int, self_coef):
-    plan = _hip.bipartite_plan(torch.stack((src_global, dst_local)), n_src, n_dst, pair_value=value)
-    plan.self_coef = self_coef
-    return plan
+    pending = []
+    hints = getattr(data, "_pp_hints", None) or {}
+    sorted_rows = bool(world == 1 and hints.get("rows_sorted"))
+    fo = build_graph_shard(*in_edges(data.edge_index, data.edge_weights, fo_cuts), n_fo, fo_cuts, comm, ops, sorted_rows, pending)
+    ho = build_graph_shard(*in_edges(data.edge_index_higher_order, data.edge_weights_higher_order, ho_cuts), n_ho, ho_cuts, comm, ops,
+                           sorted_rows, pending)
+    bi = _dispatch.plain(data.bipartite_edge_index)
+    if world == 1:
+        bi_ho, bi_fo = bi[0], bi[1]
+    else:
+        mine = (bi[0] >= ho_cuts[rank]) & (bi[0] < ho_cuts[rank + 1])
+        bi_ho, bi_fo = bi[0][mine] - ho_cuts[rank], bi[1][mine]
+    bip, cap = _bipartite_shard(bi_ho, bi_fo, ho.n_own, fo_cuts, comm, ops, src_sorted=False)
+    ops.check_plan_status(pending)
+    indeg = torch.bincount(bi[1], minlength=n_fo)[fo_cuts[rank]: fo_cuts[rank + 1]].to(torch.float32)
+    x = data.x.index_select(0, fo.local_rows()) if world > 1 else data.x
+    x_h = data.x_h.index_select(0, ho.local_rows()) if world > 1 else data.x_h
+    y = None if data.y is None else data.y[fo_cuts[rank]: fo_cuts[rank + 1]]
+    return DbgnnShard(fo=fo, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x.contiguous(), x_h=x_h.contiguous(), y=y, n_fo=n_fo, n_ho=n_ho)
 
 
-def partition_gcn(edge_index: torch.Tensor, edge_weight: torch.Tensor, num_nodes: int, rank: int, world: int, group=None):
-    """This rank's share of the GCN propagation of one graph: the edges pointing into its destination rows with their
-    symmetric normalisation (PyG gcn_norm semantics: one self loop per node, weighted in-degree, d^-1/2)."""
-    ranges = node_ranges(num_nodes, world)
-    lo, hi = ranges[rank]
-    src, dst = edge_index[0], edge_index[1]
-    mine = (dst >= lo) & (dst < hi)
-    src, dst, w = src[mine], dst[mine], edge_weight[mine].to(torch.float32)
-    loop = src == dst
-    loop_w = torch.ones(hi - lo, dtype=torch.float32, device=w.device)
-    loop_w[dst[loop] - lo] = w[loop]                                     # an existing self loop keeps its weight
-    src, dst, w = src[~loop], dst[~loop], w[~loop]
-    deg = torch.zeros(hi - lo, dtype=torch.float32, device=w.device).index_add_(0, dst - lo, w) + loop_w
-    dinv_local = deg.pow(-0.5)
-    dinv_local[torch.isinf(dinv_local)] = 0
-    dinv = _gather_rows(dinv_local.unsqueeze(1), ranges, group).squeeze(1)       # every rank needs d^-1/2 of all sources
-    value = dinv[src] * w * dinv[dst]
-    plan = _rect_plan(src, dst - lo, value, num_nodes, hi - lo, (dinv_local * loop_w * dinv_local).contiguous())
-    return plan, ranges
+def build_dbgnn_shard(g, delta, x: torch.Tensor, x_h, y: torch.Tensor | None, comm: Comm, ops=None, weight: str = "edge_weight"):
+    """The north-star split, straight from a time-sorted event stream replicated on every rank (what it replaces on one process:
+    ``MultiOrderModel.from_temporal_graph(g, delta, max_order=2)`` + ``to_dbgnn_data`` + the plans of ``DBGNN.forward``; reference
+    multi_order_model.py:124-192, 511-554, algorithms/temporal.py:17-54, lift_order.py:109-152):
+
+    1. layer 1 (first-order graph = coalesce of the events, and the event -> order-2 node map) on every rank;
+    2. row cuts at first-order node boundaries, balanced by order-2 node count (an order-2 node (a, b) belongs to the owner of a);
+    3. EDGE-RANGE sharded event-graph lift (own events + forward halo, no exchange);
+    4. the lifted pairs (u, v) go to the OWNER OF THEIR DESTINATION v in one all-to-all (12 bytes per pair) and are coalesced there:
+       every rank ends up with exactly the in-edges of its order-2 rows — the layout the destination-partitioned DBGNN consumes.
+       Pairs arrive in (source rank, local) = global instance order, so merged weights are summed in the single-process order;
+    5. graph shards (halo, rectangular GCN plans) of both graphs, the bipartite "last" plan, local feature rows.
+
+    ``x`` [N, F] / ``x_h`` [U_2, F] (or a callable ``x_h(num_ho_nodes) -> tensor``) / ``y`` [N] are replicated inputs.
+    Returns a :class:`~pathpyg_amd.nn.sharded.DbgnnShard`; ``shard.sizes`` reports the global layer sizes."""
+    from .nn.sharded import DbgnnShard
+    ops = _ops_default(ops)
+    rank, world = comm.rank, comm.world
+    data = g.data
+    ei = _dispatch.plain(data.edge_index)
+    dev = ei.device
+    n, m = int(data.num_nodes), int(ei.size(1))
+    w = data[weight] if weight in data else torch.ones(m, device=dev)
+    # 1. layer 1
+    fo, fo_w, inv1 = ops.coalesce(ei, w, n, "sum", None, True)
+    n_ho = int(fo.size(1))
+    row_ptr = ops.ptr_from_sorted(fo[0], n)                                  # int64 [n+1]: order-2 nodes (a, .) = ids row_ptr[a] .. row_ptr[a+1]
+    # 2. cuts
+    if world == 1:
+        fo_cuts, ho_cuts = [0, n], [0, n_ho]
+        widest = int((row_ptr[1:] - row_ptr[:-1]).max().item()) if n > 0 else 1
+    else:
+        targets = torch.tensor([(n_ho * r) // world for r in range(1, world)], dtype=torch.int64, device=dev)
+        inner = torch.searchsorted(row_ptr, targets)
+        head = torch.cat((inner, (row_ptr[1:] - row_ptr[:-1]).max().reshape(1) if n > 0 else torch.ones(1, dtype=torch.int64, device=dev))).tolist()
+        widest = int(head[-1])
+        fo_cuts = [0] + [min(int(c), n) for c in head[:-1]] + [n]
+        for i in range(1, len(fo_cuts)):
+            fo_cuts[i] = max(fo_cuts[i], fo_cuts[i - 1])
+        ho_cuts = row_ptr[torch.tensor(fo_cuts, dtype=torch.int64, device=dev)].tolist()
+    col_block = (row_ptr[fo[1]], max(int(widest - 1).bit_length(), 1)) if n_ho else None     # successors of (a, b): the id block of b
+    # 3. edge-range lift
+    lo_e, hi_e = event_ranges(m, world)[rank]
+    end = halo_end(data.time, hi_e, delta) if hi_e > lo_e else lo_e
+    local = ops.temporal_lift(ei[:, lo_e:end].contiguous(), data.time[lo_e:end].contiguous(), n, delta, hi_e - lo_e, lo_e)
+    e2_local = int(local.size(1))
+    w_pairs = w.index_select(0, local[0])
+    # 4. aggregation at the destination owner
+    if world == 1:
+        ho_ei, ho_w = ops.coalesce(local, w_pairs, n_ho, "sum", inv1, False, col_block)
+    else:
+        u, v = inv1.index_select(0, local[0]), inv1.index_select(0, local[1])
+        cuts_t = torch.tensor(ho_cuts, dtype=torch.int64, device=dev)
+        owner = torch.searchsorted(cuts_t[1:].contiguous(), v, right=True).clamp_(max=world - 1)
+        ptr, order = ops.group_rows(owner, world)
+        counts = (ptr[1:] - ptr[:-1]).tolist()
+        order = order.long()
+        ids = torch.stack((u, v), dim=1).to(torch.int32).index_select(0, order)
+        recv_counts = comm.exchange_counts(counts, dev)
+        ids_r = comm.exchange_rows(ids, counts, recv_counts)
+        w_r = comm.exchange_rows(w_pairs.index_select(0, order), counts, recv_counts)
+        ho_ei, ho_w = ops.coalesce(ids_r.t().to(torch.int64).contiguous(), w_r, n_ho, "sum", None, False, col_block)
+        del u, v, owner, order, ids, ids_r, w_r
+    # 5. shards
+    pending = []
+    ho = build_graph_shard(ho_ei[0], ho_ei[1], ho_w.to(torch.float32), n_ho, ho_cuts, comm, ops, world == 1, pending)
+    if world == 1:
+        f_src, f_dst, f_w = fo[0], fo[1], fo_w
+    else:
+        mine = (fo[1] >= fo_cuts[rank]) & (fo[1] < fo_cuts[rank + 1])
+        f_src, f_dst, f_w = fo[0][mine], fo[1][mine], fo_w[mine]
+    fo_shard = build_graph_shard(f_src, f_dst, f_w.to(torch.float32), n, fo_cuts, comm, ops, world == 1, pending, want_dst_order=world == 1)
+    if world == 1:
+        bip, cap = ops.bipartite_from_grouping(fo_shard.plan, fo[1], n_ho), n
+    else:
+        own = torch.arange(ho.n_own, device=dev)
+        bip, cap = _bipartite_shard(own, fo[1][ho_cuts[rank]: ho_cuts[rank + 1]], ho.n_own, fo_cuts, comm, ops, src_sorted=True)
+    ops.check_plan_status(pending)
+    fptr = fo_shard.plan.fwd_ptr
+    indeg = (fptr[1:] - fptr[:-1]).to(torch.float32)                            # order-2 nodes (., b) per owned first-order node b
+    if callable(x_h):
+        x_h = x_h(n_ho)
+    x_loc = x if world == 1 else x.index_select(0, fo_shard.local_rows())
+    xh_loc = x_h if world == 1 else x_h.index_select(0, ho.local_rows())
+    totals = torch.tensor([e2_local, int(ho_ei.size(1))], dtype=torch.float64, device=dev)
+    comm.all_reduce_(totals)
+    e2, a2 = (int(v) for v in totals.tolist())
+    return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(),
+                      y=None if y is None else y[fo_cuts[rank]: fo_cuts[rank + 1]], n_fo=n, n_ho=n_ho,
+                      sizes={"m": m, "N": n, "E2": e2, "E2_local": e2_local, "U2": n_ho, "A1": n_ho, "A2": a2, "A2_local": int(ho_ei.size(1)),
+                             "fo_cuts": fo_cuts, "ho_cuts": ho_cuts, "fo_halo": fo_shard.n_halo, "ho_halo": ho.n_halo})
 
 
-def partition_bipartite(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, rank: int, world: int):
-    fo_ranges = node_ranges(n_fo, world)
-    lo, hi = fo_ranges[rank]
-    mine = (bipartite_index[1] >= lo) & (bipartite_index[1] < hi)
-    plan = _hip.bipartite_plan(torch.stack((bipartite_index[0][mine], bipartite_index[1][mine] - lo)), n_ho, hi - lo)
-    return plan
-
-
-class ShardedDBGNN(torch.nn.Module):
-    """Runs a :class:`pathpyg_amd.nn.DBGNN` with every graph partitioned by destination rows across the process group.
-
-    ``prepare(data)`` slices the (replicated) input bundle for this rank and builds the rectangular CSR plans;
-    ``forward(shard)`` returns the logits of the first-order nodes this rank owns.  Parameters are replicated; call
-    :func:`all_reduce_gradients` after ``backward``."""
-
-    def __init__(self, model, group=None):
-        super().__init__()
-        self.model = model
-        self.group = group
-        self.rank, self.world = _world(group)
-
-    def prepare(self, data) -> dict:
-        n_fo, n_ho = int(data.num_nodes), int(data.num_ho_nodes)
-        plan_fo, fo_ranges = partition_gcn(data.edge_index, data.edge_weights, n_fo, self.rank, self.world, self.group)
-        plan_ho, ho_ranges = partition_gcn(data.edge_index_higher_order, data.edge_weights_higher_order, n_ho, self.rank, self.world, self.group)
-        plan_bi = partition_bipartite(data.bipartite_edge_index, n_ho, n_fo, self.rank, self.world)
-        (flo, fhi), (hlo, hhi) = fo_ranges[self.rank], ho_ranges[self.rank]
-        return {"plan_fo": plan_fo, "plan_ho": plan_ho, "plan_bi": plan_bi, "fo_ranges": fo_ranges, "ho_ranges": ho_ranges,
-                "x": data.x[flo:fhi].contiguous(), "x_h": data.x_h[hlo:hhi].contiguous(),
-                "y": None if data.y is None else data.y[flo:fhi], "n_fo": n_fo}
-
-    def _gcn_stack(self, layers, x_local, plan, ranges):
-        from .nn.dbgnn import dense
-        for layer in layers:
-            h_local = dense(x_local, layer.lin)
-            h_full = _AllGatherRows.apply(h_local, ranges, self.rank, self.group)
-            x_local = _LocalPropagate.apply(plan, h_full, h_local, layer.bias, True)
-        return x_local
-
-    def forward(self, shard: dict) -> torch.Tensor:
-        from .nn.dbgnn import dense
-        m = self.model
-        x = self._gcn_stack(m.first_order_layers, shard["x"], shard["plan_fo"], shard["fo_ranges"])
-        x_h = self._gcn_stack(m.higher_order_layers, shard["x_h"], shard["plan_ho"], shard["ho_ranges"])
-        h_ho = _AllGatherRows.apply(dense(x_h, m.bipartite_layer.lin1), shard["ho_ranges"], self.rank, self.group)
-        h_fo = dense(x, m.bipartite_layer.lin2)
-        x = _LocalPropagate.apply(shard["plan_bi"], h_ho, h_fo, None, True)
-        return dense(x, m.lin)
-
-    def loss(self, shard: dict) -> torch.Tensor:
-        """Cross-entropy over ALL first-order nodes: local sum divided by the global node count, so that summing the
-        per-rank gradients (``all_reduce_gradients(..., average=False)``) reproduces the single-process gradient."""
-        out = self.forward(shard)
-        return torch.nn.functional.cross_entropy(out, shard["y"], reduction="sum") / shard["n_fo"]
-
+from .nn.sharded import ShardedDBGNN  # noqa: E402,F401  (historic import location)
 
 # =====================================================================================================
 # Distributed De Bruijn aggregation (SURVEY §8e, row a7): global lexicographic unique / coalesce = a distributed sort with ONE

@@ -111,44 +111,34 @@ def test_sharded_lift_and_gradient_allreduce_gloo(world):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# Destination-partitioned DBGNN: the sharding, the rectangular plans and the collectives run for real (gloo);
-# the four device kernels it calls are replaced by small torch-CPU equivalents (test-only stand-ins).
-class _CpuPlan:
-    fwd_heavy = bwd_heavy = None          # hub-row tables of the device plans: not needed by the CPU stand-in
+# Destination-partitioned DBGNN: the sharding, the halo exchange, the rectangular plans and the collectives run for real (gloo);
+# the device operations are the torch-CPU stand-ins of tests/cpu_ops.py (injected through the `ops` argument).
+def _spawn(target, world, *args, timeout=300):
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, results) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+        assert p.exitcode == 0
+    assert dict(results) == {r: "ok" for r in range(world)}
 
 
-def _cpu_bipartite_plan(bipartite_index, n_src, n_dst, pair_value=None):
-    src, dst = bipartite_index[0], bipartite_index[1]
-    plan = _CpuPlan()
-    plan.n_dst, plan.n_src = n_dst, n_src
-    by_dst = torch.sort(dst, stable=True).indices
-    by_src = torch.sort(src, stable=True).indices
-    plan.fwd_ptr = torch.zeros(n_dst + 1, dtype=torch.int32)
-    plan.fwd_ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_dst), 0)
-    plan.bwd_ptr = torch.zeros(n_src + 1, dtype=torch.int32)
-    plan.bwd_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=n_src), 0)
-    plan.fwd_idx, plan.bwd_idx = src[by_dst].int(), dst[by_src].int()
-    plan.fwd_val = None if pair_value is None else pair_value[by_dst].float()
-    plan.bwd_val = None if pair_value is None else pair_value[by_src].float()
-    plan.self_coef = torch.bincount(dst, minlength=n_dst).float()
-    return plan
-
-
-def _cpu_spmm(ptr, idx, val, n_rows, x, self_coef=None, s=None, bias=None, act=False, heavy=None):
-    counts = (ptr[1:] - ptr[:-1]).long()
-    rows = torch.repeat_interleave(torch.arange(n_rows), counts)
-    contrib = x[idx.long()] * (1.0 if val is None else val.unsqueeze(1))
-    y = torch.zeros(n_rows, x.size(1)).index_add_(0, rows, contrib)
-    if self_coef is not None:
-        y = y + self_coef.unsqueeze(1) * (x if s is None else s)
-    if bias is not None:
-        y = y + bias
-    return torch.nn.functional.elu(y) if act else y
-
-
-def _cpu_act_backward(dy, y, act, want_dpre=True, want_dbias=False):
-    g = dy * torch.where(y > 0, torch.ones_like(y), y + 1) if act else dy
-    return (g if want_dpre else None), (g.sum(0) if want_dbias else None)
+def _check_against_oracle(sharded, shard, net, want_out, want_loss, want_grads, lo, hi):
+    import pathpyg_amd.distributed as pd
+    out_local = sharded(shard)
+    torch.testing.assert_close(out_local.detach(), want_out[lo:hi], rtol=1e-4, atol=1e-5)
+    loss = sharded.loss(shard)
+    loss.backward()
+    pd.all_reduce_gradients(net, average=False)
+    total = loss.detach().clone()
+    dist.all_reduce(total)
+    torch.testing.assert_close(total, want_loss, rtol=1e-5, atol=1e-6)
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        torch.testing.assert_close(p.grad, want_grads[name], rtol=1e-3, atol=1e-5, msg=lambda m: f"{name}: {m}")
 
 
 def _dbgnn_worker(rank, world, port, results):
@@ -157,10 +147,9 @@ def _dbgnn_worker(rank, world, port, results):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import pathpyg_amd as pp
-        from pathpyg_amd import _hip, distributed as pd
+        from pathpyg_amd import distributed as pd
         from oracle import dbgnn as od
-        _hip.bipartite_plan, _hip.spmm, _hip.act_backward = _cpu_bipartite_plan, _cpu_spmm, _cpu_act_backward
-        _hip.scale_rows = lambda x, coef: x * coef.unsqueeze(1)
+        from tests.cpu_ops import CpuOps
         g = torch.Generator().manual_seed(0)
         n, n_ho, f = 37, 90, 8
 
@@ -171,27 +160,22 @@ def _dbgnn_worker(rank, world, port, results):
         ei, w = graph(n, 150)
         ei_h, w_h = graph(n_ho, 260)
         ns = torch.randint(0, n, (n_ho, 2), generator=g)
-        bundle = dict(num_nodes=n, num_ho_nodes=n_ho, x=torch.randn(n, f, generator=g), x_h=torch.randn(n_ho, f, generator=g),
-                      edge_index=ei, edge_weights=w, edge_index_higher_order=ei_h, edge_weights_higher_order=w_h,
-                      bipartite_edge_index=torch.stack((torch.arange(n_ho), ns[:, 1])), y=torch.randint(0, 3, (n,), generator=g))
-        params = od.init_params(3, (f, f), [12, 10, 6], seed=3)
-        want_out, want_loss, want_grads = od.loss_and_grads(params, bundle, bundle["y"])
-
-        net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=[12, 10, 6])
-        net.load_state_dict(params)
-        sharded = pd.ShardedDBGNN(net)
-        shard = sharded.prepare(pp.Data(**bundle))
-        out_local = sharded(shard)
-        lo, hi = shard["fo_ranges"][rank]
-        torch.testing.assert_close(out_local.detach(), want_out[lo:hi], rtol=1e-4, atol=1e-5)
-        loss = sharded.loss(shard)
-        loss.backward()
-        pd.all_reduce_gradients(net, average=False)
-        total = loss.detach().clone()
-        dist.all_reduce(total)
-        torch.testing.assert_close(total, want_loss, rtol=1e-5, atol=1e-6)
-        for name, p in net.named_parameters():
-            torch.testing.assert_close(p.grad, want_grads[name], rtol=1e-3, atol=1e-5), name
+        for mapping in ("last", "both"):
+            bip = torch.stack((torch.arange(n_ho), ns[:, 1]))
+            if mapping == "both":
+                bip = torch.cat((bip, torch.stack((torch.arange(n_ho), ns[:, 0]))), dim=1)
+            bundle = dict(num_nodes=n, num_ho_nodes=n_ho, x=torch.randn(n, f, generator=g), x_h=torch.randn(n_ho, f, generator=g),
+                          edge_index=ei, edge_weights=w, edge_index_higher_order=ei_h, edge_weights_higher_order=w_h,
+                          bipartite_edge_index=bip, y=torch.randint(0, 3, (n,), generator=g))
+            for dims in ([12, 10, 6], [12, 9, 10, 6]):                        # two and three GCN layers per stack
+                params = od.init_params(3, (f, f), dims, seed=3)
+                want = od.loss_and_grads(params, bundle, bundle["y"])
+                net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=dims)
+                net.load_state_dict(params)
+                sharded = pd.ShardedDBGNN(net, ops=CpuOps())
+                shard = sharded.prepare(pp.Data(**bundle))
+                assert shard.fo.n_own + 0 == shard.x.size(0) - shard.fo.n_halo
+                _check_against_oracle(sharded, shard, net, *want, shard.fo.lo, shard.fo.hi)
         results[rank] = "ok"
     finally:
         dist.destroy_process_group()
@@ -199,21 +183,61 @@ def _dbgnn_worker(rank, world, port, results):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_destination_partitioned_dbgnn_matches_single_process_oracle(world):
-    ctx = mp.get_context("spawn")
-    results = ctx.Manager().dict()
-    port = _free_port()
-    procs = [ctx.Process(target=_dbgnn_worker, args=(r, world, port, results)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(240)
-        assert p.exitcode == 0
-    assert dict(results) == {r: "ok" for r in range(world)}
+    _spawn(_dbgnn_worker, world)
+
+
+def _stream_worker(rank, world, port, results):
+    """The whole north-star split from the event stream: sharded lift -> destination-owner aggregation -> graph shards -> DBGNN."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pathpyg_amd as pp
+        from pathpyg_amd import distributed as pd
+        from oracle import dbgnn as od
+        from oracle import model as om
+        from tests.cpu_ops import CpuOps
+        rng = np.random.default_rng(23)
+        for m, n, delta, span in ((2500, 40, 9, 700), (600, 12, 30, 300), (40, 30, 2, 50)):
+            ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+            t = torch.from_numpy(np.sort(rng.integers(0, span, m)))
+            w = torch.from_numpy(rng.integers(1, 4, m).astype(np.float32))
+            layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2, edge_weight=w)
+            n_ho = layers[2]["num_nodes"]
+            gen = torch.Generator().manual_seed(4)
+            f = 8
+            x, x_h = torch.randn(n, f, generator=gen), torch.randn(n_ho, f, generator=gen)
+            y = torch.randint(0, 3, (n,), generator=gen)
+            params = od.init_params(3, (f, f), [12, 10, 6], seed=5)
+            want = od.loss_and_grads(params, om.dbgnn_inputs(layers, 2, "last", x=x, x_h=x_h), y)
+            tg = type("G", (), {})()
+            tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n, edge_weight=w)
+            comm = pd.Comm()
+            shard = pd.build_dbgnn_shard(tg, delta, x, x_h, y, comm, CpuOps())
+            sz = shard.sizes
+            assert sz["U2"] == n_ho and sz["A2"] == layers[2]["edge_index"].size(1) and \
+                sz["E2"] == om.temporal_lift_sorted(ei, t, delta, n).size(1)
+            # De Bruijn property of the aligned cuts: every higher-order row is requested by at most one peer
+            if shard.ho.n_send:
+                assert int(torch.bincount(shard.ho.send_idx).max()) == 1
+            assert sum(comm.all_gather_ints([shard.ho.n_own], ei.device)[r][0] for r in range(world)) == n_ho
+            net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=[12, 10, 6])
+            net.load_state_dict(params)
+            sharded = pd.ShardedDBGNN(net, comm, ops=CpuOps())
+            _check_against_oracle(sharded, shard, net, *want, shard.fo.lo, shard.fo.hi)
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_stream_to_sharded_dbgnn_matches_single_process_oracle(world):
+    _spawn(_stream_worker, world)
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # Distributed aggregation: range-partitioned keys, one exchange per layer (gloo; the local coalesce is the oracle's).
-def _oracle_coalesce(edge_index, weight, num_nodes, reduce="sum", remap=None, want_inverse=False):
+def _oracle_coalesce(edge_index, weight, num_nodes, reduce="sum", remap=None, want_inverse=False, col_block=None):
     from oracle import aggregate as oa
     assert remap is None and not want_inverse
     return oa.coalesce(edge_index, weight, num_nodes, reduce)

@@ -1,0 +1,172 @@
+"""GPU tests of the north-star split (edge-range sharded lift -> destination-owner aggregation -> destination-partitioned DBGNN) with
+the REAL HIP kernels:
+  * world size 1 (no process group): every collective is the identity — must agree with the oracle and with the single-GPU API path;
+  * 2 and 3 ranks SHARING cuda:0 under the gloo backend (collectives staged through the host — test transport only): exercises
+    halo exchange, rectangular plans (pp_gcn_plan_begin/_finish), n_self < n_rows in the fused backward kernels on hardware;
+  * bench.py end to end through RCCL at world size 1 and through gloo at world size 2.
+The GPU box has one GPU, so multi-rank RCCL itself cannot run here; its code path is the same Comm calls with device buffers."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL, ATOL = 1e-5, 2e-6
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _case(seed, m, n, delta, span, f, hidden, weighted):
+    from oracle import dbgnn as od
+    from oracle import model as om
+    rng = np.random.default_rng(seed)
+    ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+    t = torch.from_numpy(np.sort(rng.integers(0, span, m)))
+    w = torch.from_numpy(rng.integers(1, 4, m).astype(np.float32)) if weighted else None
+    layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2, edge_weight=w)
+    gen = torch.Generator().manual_seed(seed + 1)
+    x, x_h = torch.randn(n, f, generator=gen), torch.randn(layers[2]["num_nodes"], f, generator=gen)
+    y = torch.randint(0, 3, (n,), generator=gen)
+    params = od.init_params(3, (f, f), hidden, seed=seed + 2)
+    want = od.loss_and_grads(params, om.dbgnn_inputs(layers, 2, "last", x=x, x_h=x_h), y)
+    return ei, t, w, x, x_h, y, params, want, layers
+
+
+CASES = [
+    (3, 6000, 60, 12, 900, 16, [32, 32, 16], True),          # fused <=64-wide kernels
+    (4, 9000, 150, 40, 4000, 64, [64, 64, 64], False),       # the benchmark's widths
+    (5, 4000, 80, 25, 2000, 128, [128, 128, 64], True),      # 128-wide fused layers (pp_gcn_input_grad_f32 with n_self < n_rows)
+    (6, 1500, 40, 9, 500, 8, [12, 10, 6], True),             # widths without a fused kernel: library GEMM + CSR kernels
+    (7, 60, 50, 2, 80, 16, [16, 16, 16], False),             # nearly empty higher-order graph, ranks without edges
+]
+
+
+def _run_rank(rank, world, dev, comm, case):
+    import pathpyg_amd as pp
+    from pathpyg_amd import distributed as pd
+    ei, t, w, x, x_h, y, params, want, layers = _case(*case)
+    want_out, want_loss, want_grads = want
+    attrs = {} if w is None else {"edge_weight": w.to(dev)}
+    tg = pp.TemporalGraph(pp.Data(edge_index=ei.to(dev), time=t.to(dev), num_nodes=case[2], **attrs))
+    shard = pd.build_dbgnn_shard(tg, case[3], x.to(dev), x_h.to(dev), y.to(dev), comm)
+    assert shard.sizes["U2"] == layers[2]["num_nodes"] and shard.sizes["A2"] == layers[2]["edge_index"].size(1)
+    if shard.ho.n_send:
+        assert int(torch.bincount(shard.ho.send_idx).max()) == 1          # De Bruijn cuts: every row goes to at most one peer
+    net = pp.nn.DBGNN(num_classes=3, num_features=(case[5], case[5]), hidden_dims=case[6]).to(dev)
+    net.load_state_dict(params)
+    sharded = pd.ShardedDBGNN(net, comm)
+    out = sharded(shard)
+    torch.testing.assert_close(out.detach().cpu(), want_out[shard.fo.lo: shard.fo.hi], rtol=1e-4, atol=1e-5)
+    loss = sharded.loss(shard)
+    loss.backward()
+    pd.all_reduce_gradients(net, average=False)
+    total = loss.detach().clone().reshape(1)
+    comm.all_reduce_(total)
+    torch.testing.assert_close(total.cpu()[0], want_loss, rtol=RTOL, atol=ATOL)
+    for name, p in net.named_parameters():
+        scale = float(want_grads[name].abs().max()) + 1e-12
+        torch.testing.assert_close(p.grad.cpu(), want_grads[name], rtol=1e-4, atol=max(ATOL, 2e-5 * scale), msg=lambda s: f"{name}: {s}")
+    return shard, net
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"F{c[5]}_m{c[1]}" for c in CASES])
+def test_partition_path_world1_matches_oracle_and_api_path(case):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import pathpyg_amd as pp
+    from pathpyg_amd import distributed as pd
+    dev = torch.device("cuda:0")
+    comm = pd.Comm()
+    assert comm.world == 1
+    shard, net = _run_rank(0, 1, dev, comm, case)
+    # the same step through the single-GPU API (MultiOrderModel + DBGNN): identical kernels, identical numbers
+    ei, t, w, x, x_h, y, params, want, layers = _case(*case)
+    attrs = {} if w is None else {"edge_weight": w.to(dev)}
+    tg = pp.TemporalGraph(pp.Data(edge_index=ei.to(dev), time=t.to(dev), num_nodes=case[2], **attrs))
+    mom = pp.MultiOrderModel.from_temporal_graph(tg, delta=case[3], max_order=2)
+    data = mom.to_dbgnn_data(max_order=2, x=x.to(dev), x_h=x_h.to(dev))
+    net2 = pp.nn.DBGNN(num_classes=3, num_features=(case[5], case[5]), hidden_dims=case[6]).to(dev)
+    net2.load_state_dict(params)
+    loss2 = pp.nn.cross_entropy(net2(data), y.to(dev))
+    loss2.backward()
+    for (name, p), (_, q) in zip(net.named_parameters(), net2.named_parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-5, atol=1e-6, msg=lambda s: f"{name}: {s}")
+
+
+def _gloo_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from pathpyg_amd import distributed as pd
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        comm = pd.Comm()
+        assert comm.world == world and not comm.native
+        for case in CASES:
+            _run_rank(rank, world, dev, comm, case)
+        torch.cuda.synchronize()
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partition_path_ranks_sharing_one_gpu_match_oracle(world):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert dict(results) == {r: "ok" for r in range(world)}
+
+
+def _bench(extra, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    small = ["--events", "200000", "--nodes", "10000", "--span", "200000", "--delta", "20000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small + extra, capture_output=True, text=True, timeout=timeout, env=env,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_partition_default_and_rccl_world1_and_gloo_world2():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    one = _bench([])
+    assert one["n_gpus"] == 1 and one["scaling"] == "strong" and one["roofline"]["frac"] > 0 and one["lift_roofline"]["frac"] > 0
+    assert one["aggregation_roofline"]["frac"] > 0 and one["config"]["E2"] > 0
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    small = ["--events", "200000", "--nodes", "10000", "--span", "200000", "--delta", "20000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    for nproc, extra in ((1, []), (2, ["--backend", "gloo", "--share-gpu"])):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port + nproc), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + small + extra,
+                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert line["n_gpus"] == nproc and line["config"]["E2"] == one["config"]["E2"] and line["config"]["A2"] == one["config"]["A2"]
+        assert abs(line["loss"] - one["loss"]) < 1e-3 * max(1.0, abs(one["loss"]))
+        if nproc == 2:
+            assert line["comm_bytes_per_step_rank0"]["exchange"] > 0 and line["comm_bytes_per_step_rank0"]["reduce_scatter"] > 0
