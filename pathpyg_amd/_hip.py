@@ -537,7 +537,7 @@ def gcn_plan_partition(edge_index_local: torch.Tensor, edge_weight: torch.Tensor
         check(L.pp_gcn_plan_begin(_p(ei), _p(edge_weight), e, n_src, n_dst, rs, _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val),
                                   _p(plan.bwd_ptr), _p(plan.self_coef), _p(dinv), _p(plan.dst_order), _p(ws), ws.numel(), _stream()),
               "pp_gcn_plan_begin")
-        if n_src > n_dst:
+        if halo_dinv is not None:            # a collective: called even when this rank has no halo rows
             dinv[n_dst:] = halo_dinv(dinv[:n_dst])
         check(L.pp_gcn_plan_finish(_p(ei), _p(edge_weight), e, n_src, n_dst, rs, _p(dinv), _p(plan.fwd_idx), _p(plan.fwd_val), _p(plan.bwd_ptr),
                                    _p(plan.bwd_idx), _p(plan.bwd_val), _p(ws), ws.numel(), _stream()), "pp_gcn_plan_finish")

@@ -59,7 +59,7 @@ class CpuOps:
         deg = torch.zeros(n_dst).index_add_(0, dst[~loop], w[~loop]) + loop_w
         dinv_own = deg.pow(-0.5)
         dinv_own[torch.isinf(dinv_own)] = 0
-        dinv = torch.cat((dinv_own, halo_dinv(dinv_own))) if n_src > n_dst else dinv_own
+        dinv = torch.cat((dinv_own, halo_dinv(dinv_own))) if halo_dinv is not None else dinv_own
         val = torch.where(loop, torch.zeros_like(w), dinv[src] * w * dinv[dst])
         plan = _Plan()
         plan.n_dst, plan.n_src = n_dst, n_src
