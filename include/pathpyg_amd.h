@@ -82,7 +82,8 @@ int pp_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t
  *   delta      : as torch.tensor(delta) sees it: PP_DELTA_I64 -> delta_i; PP_DELTA_F32 / PP_DELTA_F64 -> delta_f
  *                (for PP_DELTA_F32 pass the float32-rounded value).  With float64 time only delta_f is used.
  * pp_temporal_count builds the per-node event lists, counts each event's continuations and scans them;
- * pp_lift_result_ptr(ws)[0] = E2, [1] = status (bit 0: node index outside [0,num_nodes)).
+ * pp_lift_result_ptr(ws)[0] = E2, [1] = status (bit 0: node index outside [0,num_nodes); bit 1: time is not ascending —
+ * the result is then meaningless; the reference's mask-based loop has no such precondition, temporal.py:37-43).
  * pp_temporal_fill writes out[0][p] = i, out[1][p] = j for all pairs in lexicographic (i,j) order.
  * Edge-range sharding (one shard per GPU): pass the shard's events followed by its forward halo (all later events
  * with t <= t_last_owned + delta); only the first n_own events act as sources (n_own = m, or < 0, for the whole

@@ -164,6 +164,9 @@ def temporal_lift(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, 
                                   _p(ws), ws.numel(), _stream()), "pp_temporal_count")
         total, status = _result(ws)
         _bad_index(status, "lift_order_temporal")
+        if status & 2:
+            raise ValueError("lift_order_temporal: the events are not sorted by time (TemporalGraph sorts them on construction; "
+                             "data.time / data.edge_index were modified afterwards)")
         out = torch.empty((2, total), dtype=torch.int64, device=dev)
         check(L.pp_temporal_fill(m, num_nodes, total, int(id_offset), _p(out), _p(ws), ws.numel(), _stream()), "pp_temporal_fill")
     return out

@@ -30,6 +30,7 @@ namespace pp {
 
 // status word bits reported next to the size (see pp_*_count)
 constexpr int64_t kBadIndex = 1;
+constexpr int64_t kUnsortedTime = 2;
 
 // ------------------------------------------------------------------ small element-wise kernels
 __global__ __launch_bounds__(kBlock) void k_tail_keys(const int64_t* __restrict__ tail, int64_t m, int64_t num_nodes,
@@ -89,51 +90,111 @@ __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __rest
                                                           uint32_t* __restrict__ head4, int64_t* __restrict__ status) {
     using W = Window<TimeT, kMode>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= m) return;
-    if (i >= n_own) {                 // halo event of an edge-range shard: a candidate, never a source
+    const bool live = i < m;
+    const bool source = live && i < n_own;         // (halo events of an edge-range shard are candidates, never sources)
+    const int64_t ic = live ? i : m - 1;           // lanes past the end mirror the last event: the wave-wide searches need all 64 lanes
+    const TimeT ti = time[ic];
+    const TimeT t_next = ic + 1 < m ? time[ic + 1] : ti;
+    // every search below relies on a time-sorted stream (the reference's mask-based loop does not, temporal.py:37-43): say so instead of
+    // returning a wrong event graph
+    if (live && t_next < ti) atomicOr((unsigned long long*)status, (unsigned long long)kUnsortedTime);
+    if (__ballot(source) == 0ull) {                // a wave of halo events only (edge-range shards): nothing to search
+        if (live) { first_pos[i] = 0; count[i] = 0; }
+        return;
+    }
+    // the head node's list bounds do not depend on the window: fetch them first so that this (random) miss overlaps the searches below
+    const int64_t v = source ? head[i] : 0;
+    const bool ok = v >= 0 && v < num_nodes;
+    const uint32_t s0 = (source && ok) ? rowptr[v] : 0u, s1 = (source && ok) ? rowptr[v + 1] : 0u;
+    // g_lo: first id with t > t_i.  Without timestamp ties this is i+1: probe, then gallop, then bisect.
+    int64_t g_lo = ic + 1;
+    if (g_lo < m && !(t_next > ti)) {
+        int64_t step = 2;
+        while (ic + step < m && !(time[ic + step] > ti)) step <<= 1;
+        int64_t hi = ic + step < m ? ic + step : m;
+        g_lo = upper_bound_dev<TimeT, int64_t>(time, ic + (step >> 1) + 1, hi, ti);
+    }
+    // g_hi: first id >= g_lo whose time is no longer admitted by the (promoted-dtype) threshold.  Plain per-lane bisection: the 64
+    // lanes of a wave walk almost the same path, so all but the last few levels are one broadcast cache line per wave.  (A
+    // wave-cooperative 64-ary search — 4 steps instead of 23 — was measured SLOWER, 0.97 -> 1.19 ms per count call: its first two
+    // steps touch 64 scattered lines per wave where the bisection touches one.)
+    const typename W::Thr thr = W::threshold(ti, delta_i, delta_f);
+    int64_t g_hi;
+    {
+        int64_t lo = g_lo < m ? g_lo : m, hi = m;
+        while (lo < hi) {
+            int64_t mid = lo + ((hi - lo) >> 1);
+            if (W::admits(time[mid], thr)) lo = mid + 1; else hi = mid;
+        }
+        g_hi = lo;
+    }
+    if (g_hi < g_lo) g_hi = g_lo;
+    if (!live) return;
+    if (!source) {
         first_pos[i] = 0;
         count[i] = 0;
         return;                       // its head4 row is never read (count 0)
     }
-    const TimeT ti = time[i];
-    // the head node's list bounds do not depend on the window: fetch them first so that this (random) miss overlaps the
-    // dependent loads of the time search below
-    const int64_t v = head[i];
-    const bool ok = v >= 0 && v < num_nodes;
-    const uint32_t s0 = ok ? rowptr[v] : 0u, s1 = ok ? rowptr[v + 1] : 0u;
-    // g_lo: first id with t > t_i.  Without timestamp ties this is i+1: probe, then gallop, then bisect.
-    int64_t g_lo = i + 1;
-    if (g_lo < m && !(time[g_lo] > ti)) {
-        int64_t step = 2;
-        while (i + step < m && !(time[i + step] > ti)) step <<= 1;
-        int64_t hi = i + step < m ? i + step : m;
-        g_lo = upper_bound_dev<TimeT, int64_t>(time, i + (step >> 1) + 1, hi, ti);
-    }
-    // g_hi: first id >= g_lo whose time is no longer admitted by the (promoted-dtype) threshold
-    const typename W::Thr thr = W::threshold(ti, delta_i, delta_f);
-    int64_t lo = g_lo, hi = m;
-    while (lo < hi) {
-        int64_t mid = lo + ((hi - lo) >> 1);
-        if (W::admits(time[mid], thr)) lo = mid + 1; else hi = mid;
-    }
-    const int64_t g_hi = lo;
     uint32_t pos = 0;
     int32_t c = 0;
+    uint4 h = make_uint4(0u, 0u, 0u, 0u);
     if (!ok) {
         atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex);
-    } else if (g_hi > g_lo) {
-        pos = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, s0, s1, (uint32_t)g_lo);
-        const uint32_t end = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, pos, s1, (uint32_t)g_hi);
-        c = (int32_t)(end - pos);
+    } else if (g_hi > g_lo && s1 > s0) {
+        // The head node's id list [s0, s1) is short (its out-degree) and sits in one or two cache lines that nothing else on this CU
+        // will touch again: fetch kChunks aligned 16-byte pieces of it with back-to-back loads (ONE round trip) and count the ids
+        // below g_lo / g_hi in registers — a binary search on memory costs ~10 dependent touches of a line that the other 2000
+        // lanes of the CU have evicted from L1 (and mostly from L2) in between (measured: 0.73 -> see DESIGN.md §5).
+        // The first 4 continuations fall out of the same registers (the fill kernel reads them in event order).
+        constexpr int kChunks = 12;
+        const uint32_t a0 = s0 & ~3u;
+        uint4 ch[kChunks];
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) {
+            const uint32_t at = a0 + 4u * k;
+            ch[k] = at < s1 ? *reinterpret_cast<const uint4*>(ids_by_tail + at) : make_uint4(0u, 0u, 0u, 0u);   // (the list array is padded to 4)
+        }
+        const uint32_t glo = (uint32_t)g_lo, ghi = (uint32_t)g_hi;
+        uint32_t below_lo = 0, below_hi = 0;
+        int taken = 0;
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) {
+            const uint32_t v4[4] = {ch[k].x, ch[k].y, ch[k].z, ch[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t at = a0 + 4u * k + e;
+                const bool in = at >= s0 && at < s1;
+                const uint32_t id = v4[e];
+                below_lo += (in && id < glo) ? 1u : 0u;
+                below_hi += (in && id < ghi) ? 1u : 0u;
+                const bool take = in && id >= glo && id < ghi;
+                h.x = (take && taken == 0) ? id : h.x;
+                h.y = (take && taken == 1) ? id : h.y;
+                h.z = (take && taken == 2) ? id : h.z;
+                h.w = (take && taken == 3) ? id : h.w;
+                taken += take ? 1 : 0;
+            }
+        }
+        pos = s0 + below_lo;
+        uint32_t end = s0 + below_hi;
+        const uint32_t covered = a0 + 4u * kChunks;
+        if (covered < s1) {          // longer list (hub node): finish both searches on memory, beyond the part already counted
+            if (pos == covered) pos = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, covered, s1, glo);
+            if (end == covered) end = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, pos > covered ? pos : covered, s1, ghi);
+            c = (int32_t)(end - pos);
+            if (c > taken) {         // some of the first 4 continuations lie beyond the register window
+                if (taken < 1 && c > 0) h.x = ids_by_tail[pos];
+                if (taken < 2 && c > 1) h.y = ids_by_tail[pos + 1];
+                if (taken < 3 && c > 2) h.z = ids_by_tail[pos + 2];
+                if (taken < 4 && c > 3) h.w = ids_by_tail[pos + 3];
+            }
+        } else {
+            c = (int32_t)(end - pos);
+        }
+        if (c == 0) pos = 0;
     }
     first_pos[i] = pos;
     count[i] = c;
-    // the first continuations sit in the cache lines the searches just touched: hand them to the fill kernel in event order
-    uint4 h = make_uint4(0u, 0u, 0u, 0u);
-    if (c > 0) h.x = ids_by_tail[pos];
-    if (c > 1) h.y = ids_by_tail[pos + 1];
-    if (c > 2) h.z = ids_by_tail[pos + 2];
-    if (c > 3) h.w = ids_by_tail[pos + 3];
     *reinterpret_cast<uint4*>(head4 + i * 4) = h;
 }
 
@@ -485,7 +546,7 @@ static LiftWs carve_lift(void* ws, int64_t n_src, int64_t num_nodes, bool tempor
     w.first_pos = a.take<uint32_t>(n_src);
     w.count = a.take<int32_t>(n_src);
     w.rowptr = a.take<uint32_t>(num_nodes + 1);
-    w.ids = temporal ? a.take<uint32_t>(n_src) : nullptr;
+    w.ids = temporal ? a.take<uint32_t>(n_src + 4) : nullptr;          // + 4: k_temporal_count reads it in aligned 16-byte pieces
     w.keys = a.take<uint32_t>(temporal ? n_src : num_nodes);
     w.sorted_keys = temporal ? a.take<uint32_t>(n_src) : nullptr;
     w.head4 = temporal ? a.take<uint32_t>(n_src * 4) : nullptr;

@@ -345,3 +345,14 @@ def test_coalesce_with_long_duplicate_runs(hip, dtype, reduce):
     got_index, got_w = _hip.coalesce(ei.to(DEV), w.to(DEV), n, reduce)
     assert torch.equal(got_index.cpu(), want_index)
     assert torch.equal(got_w.cpu(), want_w), (dtype, reduce)
+
+
+def test_temporal_lift_rejects_unsorted_time(hip):
+    """every search of the kernel assumes ascending timestamps; a stream modified after TemporalGraph sorted it must raise."""
+    g = torch.Generator().manual_seed(2)
+    ei = torch.randint(0, 20, (2, 500), generator=g).to(DEV)
+    t = torch.sort(torch.randint(0, 300, (500,), generator=g)).values.to(DEV)
+    assert hip.temporal_lift(ei, t, 20, 5).size(0) == 2
+    t[250] = 0                                                     # a descent in the middle of the stream
+    with pytest.raises(ValueError, match="not sorted by time"):
+        hip.temporal_lift(ei, t, 20, 5)
