@@ -246,10 +246,12 @@ int pp_weight_grad_f32(const float* dH, const float* X, int64_t n_rows, int M, i
  *   out[N,Q] = ( A[N,P] . B + bias ) (*) g'      B = W^T for w_transposed != 0 (W is [Q,P]: forward), W otherwise (W is [P,Q])
  *   grad_act : [N,Q] or NULL: the stored activation y = ELU(pre) of the layer below; the result is multiplied by
  *              ELU'(pre) = (y > 0 ? 1 : y + 1) and, with colsum [Q], its column sums (= that layer's bias gradient) accumulate.
- * fp32 on v_mfma_f32_16x16x4_f32.  Supported layer widths: P, Q in {16, 32, 64} (pp_dense_supported); others: library GEMM. */
+ * fp32 on v_mfma_f32_16x16x4_f32.  pp_dense_supported(P, Q): 1 = P, Q in {16, 32, 64} (weights in registers; also pp_dense_backward_f32),
+ * 2 = other widths up to 64 (zero-padded: pp_dense_narrow_f32), 3 = 64/128/256 with a side > 64 (pp_wide_layer_f32 in dense mode; with
+ * w_transposed == 0 it needs ws = pp_wide_layer_ws_bytes(P, Q) bytes), 0 = not supported (the Python side then uses the library GEMM). */
 int pp_dense_supported(int P, int Q);
 int pp_dense_f32(const float* A, const float* W, int w_transposed, int64_t n_rows, int P, int Q, const float* bias,
-                 const float* grad_act, float* colsum, float* out, pp_stream_t stream);
+                 const float* grad_act, float* colsum, float* out, void* ws, size_t ws_bytes, pp_stream_t stream);
 
 /* Mean softmax cross-entropy of logits [n,C] (C <= 64) against int64 targets [n] and its gradient dlogits [n,C] (may be NULL) in
  * one pass - the loss of the train step bench.py times (the reference ships no training loop). */
@@ -267,9 +269,10 @@ int pp_dense_backward_f32(const float* dH, const float* X, const float* W, int64
  * makes a round trip through HBM:
  *   Y[r, :Q] = act( (sum_e val[e] X[idx[e], :P] + self_coef[r] X[r, :P]) . W^T + bias ),   W is [Q,P] (Linear layout), act 0/1 (ELU)
  * over the destination-major CSR of a pp_gcn_plan (self_coef may be NULL: no self term); X has n_src rows (rows are addressed by
- * 32-bit byte offsets below 4 GiB, by 64-bit ones above).  P, Q in {16,32,64}, and the 128-wide shapes 64x128, 128x64, 128x128 (W then
- * fills 32-64 KB of LDS: one workgroup of 8 waves per CU).  pp_gcn_fused_supported(P, Q): 1 = forward + pp_gcn_backward_f32,
- * 2 = forward + pp_gcn_input_grad_f32 (128-wide), 0 = unsupported shape.
+ * 32-bit byte offsets below 4 GiB, by 64-bit ones above).  P, Q in {16,32,64}; the 128-wide shapes 64x128, 128x64, 128x128 (W then
+ * fills 32-64 KB of LDS: one workgroup of 8 waves per CU); every other combination of 64/128/256 goes to pp_wide_layer_f32 (weights
+ * streamed through LDS).  pp_gcn_fused_supported(P, Q): 1 = forward + pp_gcn_backward_f32, 2 = forward + pp_gcn_input_grad_f32
+ * (a side of 128 or 256), 0 = unsupported shape.
  * agg_out [n_rows,P] or NULL: also store the aggregated input A_hat X; the weight gradient of a layer whose input needs no
  * gradient is then dW = dpre^T agg_out (pp_weight_grad_f32) without any backward aggregation. */
 int pp_gcn_fused_supported(int P, int Q);
@@ -295,7 +298,30 @@ int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val
  * 64x64 block do not fit beside the gather here. */
 int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
                           const float* self_coef, const float* W, int K, const float* X_act, int fuse_act, const int32_t* heavy_slot,
-                          const float* heavy_sum, float* d_in, float* colsum_in, pp_stream_t stream);
+                          const float* heavy_sum, float* d_in, float* colsum_in, void* ws, size_t ws_bytes, pp_stream_t stream);
+                          /* ws: pp_wide_layer_ws_bytes(M, K) for the shapes served by pp_wide_layer_f32 (a side of 256), else unused */
+
+/* Layers too wide for a weight matrix in LDS (pp_gcn_wide.hip): P, Q in {64, 128, 256} with a side > 64 — DBGNN with 256-dim features
+ * (BASELINE configs[4]; GCNConv / Linear of nn/dbgnn.py:104-119 and their backward).  One kernel per layer:
+ *   Y[n, :Q] = epi( tile[n, :P] . B ),  tile[n] = sum_e val[e] X[idx[e]] + self_coef[n] X[n]  (rows >= n_self: no self term)
+ *                                       or X[n] when ptr == NULL (a dense layer; idx/val/self_coef ignored)
+ *   B = W^T with W [Q,P] (w_is_kq == 0: Linear layout, the forward) or B = W with W [P,Q] (w_is_kq == 1: the input gradient; transposed
+ *   once into ws, pp_wide_layer_ws_bytes(P, Q) bytes)
+ *   epilogue 0: Y = act(.. + bias), agg_out [n_rows,P] (optional) receives the aggregated tile;
+ *   epilogue 1: Y = (..) (*) ELU'(act_in) when act (act_in [n_rows,Q] = stored activation), colsum[Q] (optional) = column sums of Y.
+ * The 16 x P tile lives in registers in MFMA A layout, the weights stream through LDS 16 output columns at a time. */
+int pp_wide_layer_supported(int P, int Q);
+size_t pp_wide_layer_ws_bytes(int P, int Q);
+int pp_wide_layer_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, int64_t n_src, const float* X, int P,
+                      const float* self_coef, const float* W, int w_is_kq, int Q, const float* bias, int act, int epilogue, const float* act_in,
+                      const int32_t* heavy_slot, const float* heavy_sum, float* agg_out, float* Y, float* colsum, void* ws, size_t ws_bytes,
+                      pp_stream_t stream);
+
+/* Dense layers with widths in [1, 64] that are not 16/32/64 themselves (classifier head: 64 -> 8 classes; odd hidden widths): the
+ * pp_dense_f32 scheme with both sides zero-padded to 16/32/64 and guarded scalar I/O.  Same arguments as pp_dense_f32. */
+int pp_dense_narrow_supported(int P, int Q);
+int pp_dense_narrow_f32(const float* A, const float* W, int w_transposed, int64_t n_rows, int P, int Q, const float* bias, const float* grad_act,
+                        float* colsum, float* out, pp_stream_t stream);
 
 /* All-pairs shortest time-respecting paths (temporal_shortest_paths, src/pathpyG/algorithms/temporal.py:57-107: scipy Dijkstra with
  * unit weights on the event DAG augmented by a virtual source and sink per node) as a frontier BFS per source node on the event graph:

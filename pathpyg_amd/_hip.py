@@ -659,8 +659,10 @@ def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
     return dw, db
 
 
-def dense_supported(p: int, q: int) -> bool:
-    return bool(lib().pp_dense_supported(int(p), int(q)))
+def dense_supported(p: int, q: int) -> int:
+    """0: no HIP kernel for this layer shape (library GEMM); 1: widths 16/32/64 (also :func:`dense_backward`); 2: other widths up to 64
+    (zero-padded kernel); 3: 64/128/256 with a side > 64 (weights streamed through LDS)."""
+    return int(lib().pp_dense_supported(int(p), int(q)))
 
 
 def dense(a: torch.Tensor, weight: torch.Tensor, transposed: bool, bias: torch.Tensor | None = None,
@@ -678,11 +680,13 @@ def dense(a: torch.Tensor, weight: torch.Tensor, transposed: bool, bias: torch.T
         bias = bias.contiguous()
     if grad_act is not None:
         grad_act = grad_act.contiguous()
+    L = lib()
     with torch.cuda.device(dev):
         out = torch.empty((n, q), dtype=torch.float32, device=dev)
         colsum = torch.empty(q, dtype=torch.float32, device=dev) if want_colsum else None
-        check(lib().pp_dense_f32(_p(a), _p(weight), 1 if transposed else 0, n, p, q, _p(bias), _p(grad_act), _p(colsum), _p(out), _stream()),
-              "pp_dense_f32")
+        ws = _workspace(L.pp_wide_layer_ws_bytes(p, q), dev) if (not transposed and L.pp_dense_supported(p, q) == 3) else None
+        check(L.pp_dense_f32(_p(a), _p(weight), 1 if transposed else 0, n, p, q, _p(bias), _p(grad_act), _p(colsum), _p(out), _p(ws),
+                             0 if ws is None else ws.numel(), _stream()), "pp_dense_f32")
     return out, colsum
 
 
@@ -769,12 +773,14 @@ def gcn_input_grad(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, we
         raise ValueError("gcn_input_grad: shapes do not match")
     if x_act is not None:
         x_act = x_act.contiguous()
+    L = lib()
     with torch.cuda.device(dev):
         d_in = torch.empty((n_rows, k), dtype=torch.float32, device=dev)
         colsum = torch.empty(k, dtype=torch.float32, device=dev) if want_colsum else None
         slot, sums = _heavy_args(heavy, idx, val, dpre)
-        check(lib().pp_gcn_input_grad_f32(_p(ptr), _p(idx), _p(val), n_rows, n_self, _p(dpre), m, _p(self_coef), _p(weight), k, _p(x_act),
-                                          1 if x_act is not None else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _stream()),
+        ws = _workspace(L.pp_wide_layer_ws_bytes(m, k), dev)              # (only the shapes with a side of 256 use it: W^T)
+        check(L.pp_gcn_input_grad_f32(_p(ptr), _p(idx), _p(val), n_rows, n_self, _p(dpre), m, _p(self_coef), _p(weight), k, _p(x_act),
+                                      1 if x_act is not None else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _p(ws), ws.numel(), _stream()),
               "pp_gcn_input_grad_f32")
     return d_in, colsum
 

@@ -1278,13 +1278,32 @@ static int launch_dense_q(int Q, unsigned grid, hipStream_t st, const float* A, 
 
 extern "C" {
 
-int pp_dense_supported(int P, int Q) { return (P == 16 || P == 32 || P == 64) && (Q == 16 || Q == 32 || Q == 64); }
+static inline bool dense_exact(int P, int Q) { return (P == 16 || P == 32 || P == 64) && (Q == 16 || Q == 32 || Q == 64); }
+
+// 1: both widths in {16,32,64} (B in registers, also pp_dense_backward_f32); 2: other widths up to 64 (zero-padded, pp_dense_narrow_f32);
+// 3: 64/128/256 with a side > 64 (weights streamed through LDS, pp_wide_layer_f32); 0: library GEMM territory
+int pp_dense_supported(int P, int Q) {
+    if (dense_exact(P, Q)) return 1;
+    if (pp_dense_narrow_supported(P, Q)) return 2;
+    return pp_wide_layer_supported(P, Q) ? 3 : 0;
+}
 
 int pp_dense_f32(const float* A, const float* W, int w_transposed, int64_t n_rows, int P, int Q, const float* bias,
-                 const float* grad_act, float* colsum, float* out, pp_stream_t stream) {
+                 const float* grad_act, float* colsum, float* out, void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_dense_f32: negative size");
-    PP_REQUIRE(pp_dense_supported(P, Q), PP_ERR_ARG, "pp_dense_f32: unsupported layer shape %dx%d (supported: 16/32/64)", P, Q);
+    const int kind = pp_dense_supported(P, Q);
+    PP_REQUIRE(kind != 0, PP_ERR_ARG, "pp_dense_f32: unsupported layer shape %dx%d (supported: widths up to 64, and 64/128/256)", P, Q);
+    if (kind == 2) return pp_dense_narrow_f32(A, W, w_transposed, n_rows, P, Q, bias, grad_act, colsum, out, stream);
+    if (kind == 3) {
+        // forward (W [Q,P], one row per output column: as the kernel wants it) or input gradient (W [P,Q]: transposed into ws first)
+        if (grad_act == nullptr && colsum == nullptr)
+            return pp_wide_layer_f32(nullptr, nullptr, nullptr, n_rows, n_rows, n_rows, A, P, nullptr, W, w_transposed ? 0 : 1, Q, bias, 0, 0, nullptr, nullptr,
+                                     nullptr, nullptr, out, nullptr, ws, ws_bytes, stream);
+        PP_REQUIRE(bias == nullptr, PP_ERR_ARG, "pp_dense_f32: the gradient epilogue of a wide layer takes no bias");
+        return pp_wide_layer_f32(nullptr, nullptr, nullptr, n_rows, n_rows, n_rows, A, P, nullptr, W, w_transposed ? 0 : 1, Q, nullptr, grad_act ? 1 : 0, 1,
+                                 grad_act, nullptr, nullptr, nullptr, out, colsum, ws, ws_bytes, stream);
+    }
     PP_REQUIRE(((uintptr_t)A | (uintptr_t)out) % 16 == 0, PP_ERR_ARG, "pp_dense_f32: A and out must be 16-byte aligned");
     if (colsum) PP_HIP(hipMemsetAsync(colsum, 0, (size_t)Q * sizeof(float), st));
     if (n_rows == 0) return PP_OK;
@@ -1561,7 +1580,7 @@ int pp_dense_backward_f32(const float* dH, const float* X, const float* W, int64
                           float* colsum_in, float* dW, float* db, void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_dense_backward_f32: negative size");
-    PP_REQUIRE(pp_dense_supported(M, K), PP_ERR_ARG, "pp_dense_backward_f32: unsupported layer shape %dx%d", M, K);
+    PP_REQUIRE(pp_dense_supported(M, K) == 1, PP_ERR_ARG, "pp_dense_backward_f32: unsupported layer shape %dx%d (16/32/64 only)", M, K);
     PP_REQUIRE(ws_bytes >= pp_dense_backward_ws_bytes(n_rows), PP_ERR_WORKSPACE, "pp_dense_backward_f32: workspace too small");
     PP_REQUIRE(((uintptr_t)dH) % 16 == 0, PP_ERR_ARG, "pp_dense_backward_f32: dH must be 16-byte aligned");
     if (colsum_in) PP_HIP(hipMemsetAsync(colsum_in, 0, (size_t)K * sizeof(float), st));

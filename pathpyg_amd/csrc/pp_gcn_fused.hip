@@ -593,14 +593,19 @@ static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const i
 
 extern "C" {
 
-int pp_gcn_fused_supported(int P, int Q) { return pp_dense_supported(P, Q) ? 1 : (pp::gcn_wide_shape(P, Q) ? 2 : 0); }
+static inline bool dense_exact(int P, int Q) { return (P == 16 || P == 32 || P == 64) && (Q == 16 || Q == 32 || Q == 64); }
+
+int pp_gcn_fused_supported(int P, int Q) { return dense_exact(P, Q) ? 1 : ((pp::gcn_wide_shape(P, Q) || pp_wide_layer_supported(P, Q)) ? 2 : 0); }
 
 int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
                        const float* self_coef, const float* W, int Q, const float* bias, int act, const int32_t* heavy_slot, const float* heavy_sum,
                        float* agg_out, float* Y, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_forward_f32: negative size");
-    PP_REQUIRE(pp_gcn_fused_supported(P, Q), PP_ERR_ARG, "pp_gcn_forward_f32: unsupported layer shape %dx%d (supported: 16/32/64, 64/128 x 128, 128x64)", P, Q);
+    PP_REQUIRE(pp_gcn_fused_supported(P, Q), PP_ERR_ARG, "pp_gcn_forward_f32: unsupported layer shape %dx%d (supported: 16/32/64 and 64/128/256)", P, Q);
+    if (!dense_exact(P, Q) && !pp::gcn_wide_shape(P, Q))          // a side of 256: weights streamed through LDS (pp_gcn_wide.hip)
+        return pp_wide_layer_f32(ptr, idx, val, n_rows, n_rows, n_src, X, P, self_coef, W, 0, Q, bias, act, 0, nullptr, heavy_slot, heavy_sum, agg_out, Y,
+                                 nullptr, nullptr, 0, stream);
     PP_REQUIRE(act == 0 || act == 1, PP_ERR_ARG, "pp_gcn_forward_f32: act must be 0 (none) or 1 (elu)");
     PP_REQUIRE(((uintptr_t)X | (uintptr_t)agg_out | (uintptr_t)Y) % 16 == 0, PP_ERR_ARG, "pp_gcn_forward_f32: X, Y and agg_out must be 16-byte aligned");
     PP_REQUIRE(n_src >= 0 && n_src < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_forward_f32: more than 2^31 source rows");
@@ -622,10 +627,13 @@ int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val,
 
 int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
                           const float* self_coef, const float* W, int K, const float* X_act, int fuse_act, const int32_t* heavy_slot,
-                          const float* heavy_sum, float* d_in, float* colsum_in, pp_stream_t stream) {
+                          const float* heavy_sum, float* d_in, float* colsum_in, void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0 && n_self >= 0 && n_self <= n_rows, PP_ERR_ARG, "pp_gcn_input_grad_f32: bad sizes");
-    PP_REQUIRE(pp::gcn_wide_shape(M, K), PP_ERR_ARG, "pp_gcn_input_grad_f32: unsupported layer shape %dx%d (64/128 x 128, 128x64)", M, K);
+    PP_REQUIRE(pp_gcn_fused_supported(M, K) == 2, PP_ERR_ARG, "pp_gcn_input_grad_f32: unsupported layer shape %dx%d (64/128/256 with a side > 64)", M, K);
+    if (!pp::gcn_wide_shape(M, K))
+        return pp_wide_layer_f32(ptr, idx, val, n_rows, n_self, n_self, D, M, self_coef, W, 1, K, nullptr, fuse_act ? 1 : 0, 1, X_act, heavy_slot, heavy_sum,
+                                 nullptr, d_in, colsum_in, ws, ws_bytes, stream);
     PP_REQUIRE(d_in != nullptr && (!fuse_act || X_act != nullptr), PP_ERR_ARG, "pp_gcn_input_grad_f32: d_in (and X_act with fuse_act) required");
     PP_REQUIRE(((uintptr_t)D | (uintptr_t)X_act | (uintptr_t)d_in) % 16 == 0, PP_ERR_ARG, "pp_gcn_input_grad_f32: D, X_act and d_in must be 16-byte aligned");
     PP_REQUIRE(n_rows < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_input_grad_f32: more than 2^31 rows");

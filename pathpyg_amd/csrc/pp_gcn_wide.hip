@@ -1,0 +1,456 @@
+// pathpyg_amd — GCN / dense layers wider than the 160 KB LDS can hold a weight matrix for (64/128/256-wide, any combination with a
+// side > 64; BASELINE configs[4]: 256-dim features "MFMA feature GEMM"), still ONE kernel per layer:
+//
+//   out[n, :Q] = epi( tile[n, :P] . Wr[:Q, :P]^T )          Wr = the weight matrix with one ROW per output column
+//   tile[n]    = sum_e val[e] X[idx[e]] + self[n] X[n]       (CSR aggregation, as pp_gcn_fused.hip)   or   X[n]   (dense layer, ptr == NULL)
+//
+// Reference code replaced: GCNConv.lin + propagate + bias + F.elu and torch.nn.Linear of DBGNN.forward (nn/dbgnn.py:104-119,131-150) and
+// their autograd backward, for hidden widths up to 256.
+//
+// Structure (gfx950): a 256-thread workgroup = 4 waves, each wave owns a 16-row tile.  Phase 1 — every wave aggregates its tile
+// (gather stage of pp_gcn_fused.hip: kLanes = P/4 lanes per row, index/value chunks by one coalesced load + shuffles, 4 neighbour rows
+// + the row itself in flight per row) in batches of 4 rows per lane group, through a small wave-private LDS stage, into the A
+// operand layout of v_mfma_f32_16x16x4_f32 held in P/4 VGPRs per lane (the whole 16 x P tile lives in registers).  Phase 2 — the
+// weight matrix streams through LDS in chunks of 16 OUTPUT COLUMNS (16 rows of Wr = 16 x P floats, contiguous and coalesced in
+// HBM/L2; double buffered, one __syncthreads per chunk): per chunk a wave runs P/4 MFMAs into ONE accumulator tile, applies the
+// epilogue and stores 16 columns x 16 rows.  Chunking over output columns (not over k) keeps the accumulator at 4 registers, so the
+// register budget goes to the tile (64 VGPRs at P = 256) and the gathers; 2 workgroups per CU (50 KB LDS each) overlap one
+// workgroup's gather phase with the other's MFMA phase.  LDS rows are padded to P + 4 floats: the ds_read_b128 of lane (i, kq)
+// at row i, column kq*P/4 + 4c then hits 16 distinct bank quads inside each of the instruction's 16-lane groups.
+// The input gradient of such a layer is the same kernel over the transposed CSR with Wr = W^T (transposed once per call into the
+// caller's workspace, 256 KB at most) and the ELU' / column-sum epilogue; its weight gradient is dW = dpre^T (A_hat X) on
+// k_weight_grad_blocks (pp_dbgnn.hip) from the aggregated input the forward call stores.
+#include "pp_common.h"
+#include "pp_internal.h"
+
+namespace pp {
+
+using f32x4w = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kWideThreads = 256;
+constexpr int kWideWaves = kWideThreads / kWave;
+constexpr int kWideFirst = 4;                  // neighbours per row fetched in the first, fully overlapped, batch
+
+__global__ __launch_bounds__(kBlock) void k_transpose_f32(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= rows * cols) return;
+    const int r = e / cols, c = e - r * cols;
+    out[c * rows + r] = in[e];
+}
+
+// kEpi 0: Y = act(tile . Wr^T + bias)            (forward; optional copy of the aggregated tile to agg_out)
+// kEpi 1: Y = (tile . Wr^T) (*) ELU'(act_in)     (input gradient; act_in NULL = no factor) + column sums
+template <int P, int Q, int kEpi>
+__global__ __launch_bounds__(kWideThreads, 2) void k_wide_layer(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                                const float* __restrict__ val, int64_t n_rows, int64_t n_self,
+                                                                const float* __restrict__ X, const float* __restrict__ self_coef,
+                                                                const float* __restrict__ Wr, const float* __restrict__ bias, int act,
+                                                                HeavyRows heavy, float* __restrict__ agg_out, float* __restrict__ Y,
+                                                                const float* __restrict__ act_in, float* __restrict__ colsum) {
+    constexpr int kLanes = P / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = P / 4, TS = P + 4, NC = Q / 16;
+    constexpr int kBatch = P >= 256 ? 2 : (kRows < 4 ? kRows : 4);       // rows per lane group gathered at a time (register budget)
+    constexpr int kStageRows = kGroups * kBatch;
+    constexpr int kChunkVec = 16 * P / 4 / kWideThreads;          // float4 per thread and weight chunk
+    __shared__ __attribute__((aligned(16))) float s_w[2][16 * TS];
+    __shared__ __attribute__((aligned(16))) float s_stage[kWideWaves][kStageRows * TS];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int g = lane / kLanes, l = lane % kLanes;
+    const int i = lane & 15, kq = lane >> 4;
+    float* stage = s_stage[wave];
+    const char* xb = (const char*)X;
+    const bool dense = ptr == nullptr;
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    const int64_t n_groups = (n_tiles + kWideWaves - 1) / kWideWaves;
+    __shared__ float s_col[kEpi == 1 ? kWideWaves : 1][kEpi == 1 ? Q : 1];          // per-wave column sums of the gradient epilogue
+
+    // weight chunk loader: chunk c = rows 16c .. 16c+15 of Wr; thread e handles float4 number e, e + 256, ... of the chunk
+    // (row e / (P/4), quad e % (P/4)): fetched into registers one chunk ahead, written to the free LDS buffer after the MFMAs
+    float4 wnext[kChunkVec];
+#define PP_FETCH_CHUNK(C)                                                                                          \
+    _Pragma("unroll") for (int v = 0; v < kChunkVec; ++v)                                                          \
+        wnext[v] = *(const float4*)(Wr + (size_t)(C) * 16 * P + (size_t)(threadIdx.x + v * kWideThreads) * 4)
+#define PP_STORE_CHUNK(BUF)                                                                                        \
+    _Pragma("unroll") for (int v = 0; v < kChunkVec; ++v) {                                                        \
+        const int e_ = threadIdx.x + v * kWideThreads;                                                             \
+        const int r_ = e_ / (P / 4), q4_ = e_ - r_ * (P / 4);                                                      \
+        *(float4*)(&s_w[BUF][r_ * TS + 4 * q4_]) = wnext[v];                                                       \
+    }
+    static_assert(NC % 2 == 0, "the double buffer returns to slot 0 after every tile group");
+    PP_FETCH_CHUNK(0);
+    PP_STORE_CHUNK(0)
+    if constexpr (kEpi == 1) {
+        for (int e = lane; e < Q; e += kWave) s_col[wave][e] = 0.f;
+    }
+
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t t = grp * kWideWaves + wave;
+        const bool have_tile = t < n_tiles;
+        // ------------------------------------------------------------------ phase 1: aggregate the tile into the A operand registers
+        float4 a[KQ / 4];
+#pragma unroll
+        for (int c = 0; c < KQ / 4; ++c) a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have_tile) {
+            // one coalesced load each for the tile's 17 row pointers, its hub slots and self coefficients, then ONE load for the first 4
+            // (index, value) pairs of all 16 rows (lane 4*row + slot): the batches below take everything by shuffle and issue their
+            // row gathers without a dependent index load in between (rows with more than 4 neighbours continue chunk-wise)
+            const int64_t tr = t * 16;
+            const int64_t rl = tr + lane;
+            const int pv = (!dense && lane <= 16) ? ptr[rl < n_rows ? rl : n_rows] : 0;
+            const int hv = (heavy.slot != nullptr && lane < 16 && rl < n_rows) ? heavy.slot[rl] : -1;
+            const float scv = (lane < 16 && rl < n_self) ? (dense ? 1.f : (self_coef != nullptr ? self_coef[rl] : 0.f)) : 0.f;
+            int cj4;
+            float cv4;
+            {
+                const int rr = lane >> 2, slot = lane & 3;
+                const int pr = __shfl(pv, rr, kWave), pn = __shfl(pv, rr + 1, kWave);
+                const bool hub = __shfl(hv, rr, kWave) >= 0;
+                const int e = pr + slot;
+                const bool in = !hub && e < pn;
+                cj4 = in ? idx[e] : 0;
+                cv4 = in ? (val ? val[e] : 1.f) : 0.f;
+            }
+#pragma unroll 1
+            for (int b0 = 0; b0 < kRows; b0 += kBatch) {
+                int p0[kBatch], p1[kBatch], hs[kBatch], jrow[kBatch][kWideFirst], srow[kBatch];
+                float sc[kBatch];
+#pragma unroll
+                for (int q = 0; q < kBatch; ++q) {
+                    const int rt = g * kRows + b0 + q;                     // row of the tile this lane group works on
+                    const int64_t r = tr + rt;
+                    p0[q] = __shfl(pv, rt, kWave);
+                    hs[q] = __shfl(hv, rt, kWave);
+                    p1[q] = hs[q] >= 0 ? p0[q] : __shfl(pv, rt + 1, kWave);      // a hub row: its neighbour sum is already in heavy.sum
+                    sc[q] = __shfl(scv, rt, kWave);
+                    const bool self_here = r < n_self && (dense || self_coef != nullptr);
+                    const int first = __shfl(cj4, 4 * rt, kWave);
+                    const int dummy = p0[q] < p1[q] ? first : (self_here ? (int)r : 0);
+                    srow[q] = self_here ? (int)r : dummy;
+#pragma unroll
+                    for (int u = 0; u < kWideFirst; ++u) {
+                        const int j = __shfl(cj4, 4 * rt + u, kWave);
+                        jrow[q][u] = p0[q] + u < p1[q] ? j : dummy;
+                    }
+                }
+                float4 x[kBatch][kWideFirst], sr[kBatch];
+#pragma unroll
+                for (int q = 0; q < kBatch; ++q) {
+                    sr[q] = *(const float4*)(xb + (uint64_t)(uint32_t)srow[q] * (uint64_t)(P * 4) + (uint64_t)(16 * l));
+#pragma unroll
+                    for (int u = 0; u < kWideFirst; ++u)
+                        x[q][u] = *(const float4*)(xb + (uint64_t)(uint32_t)jrow[q][u] * (uint64_t)(P * 4) + (uint64_t)(16 * l));
+                }
+#pragma unroll
+                for (int q = 0; q < kBatch; ++q) {
+                    const int rt = g * kRows + b0 + q;
+                    const int64_t r = tr + rt;
+                    float4 acc = make_float4(sc[q] * sr[q].x, sc[q] * sr[q].y, sc[q] * sr[q].z, sc[q] * sr[q].w);
+#pragma unroll
+                    for (int u = 0; u < kWideFirst; ++u) {
+                        const float v = p0[q] + u < p1[q] ? __shfl(cv4, 4 * rt + u, kWave) : 0.f;
+                        acc.x += v * x[q][u].x; acc.y += v * x[q][u].y; acc.z += v * x[q][u].z; acc.w += v * x[q][u].w;
+                    }
+                    for (int base = p0[q] + kWideFirst; base < p1[q]; base += kLanes) {      // rows with more than kWideFirst neighbours
+                        const int mine = base + l;
+                        const int my_j = mine < p1[q] ? idx[mine] : 0;
+                        const float my_v = mine < p1[q] ? (val ? val[mine] : 1.f) : 0.f;
+                        const int cnt = p1[q] - base < kLanes ? p1[q] - base : kLanes;
+                        for (int e = 0; e < cnt; e += 4) {
+                            float4 y[4];
+                            float v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int src_lane = (e + u) < cnt ? e + u : e;
+                                const int j = __shfl(my_j, src_lane, kLanes);
+                                v[u] = (e + u) < cnt ? __shfl(my_v, src_lane, kLanes) : 0.f;
+                                y[u] = *(const float4*)(xb + (uint64_t)(uint32_t)j * (uint64_t)(P * 4) + (uint64_t)(16 * l));
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                acc.x += v[u] * y[u].x; acc.y += v[u] * y[u].y; acc.z += v[u] * y[u].z; acc.w += v[u] * y[u].w;
+                            }
+                        }
+                    }
+                    if (p0[q] == p1[q] && sc[q] == 0.f) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (hs[q] >= 0) {
+                        const float4 h = *(const float4*)(heavy.sum + (int64_t)hs[q] * P + 4 * l);
+                        acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
+                    }
+                    if (r >= n_rows) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *(float4*)(stage + (g * kBatch + q) * TS + 4 * l) = acc;
+                    if (kEpi == 0 && agg_out != nullptr && r < n_rows) *(float4*)(agg_out + r * P + 4 * l) = acc;
+                }
+                __builtin_amdgcn_wave_barrier();
+                // the lanes whose tile row i belongs to this batch pick up their quarter row (A layout: lane (i, kq) = row i, k-range kq)
+                const int within = (i % kRows) - b0;
+                if (within >= 0 && within < kBatch) {
+                    const float* sp = stage + ((i / kRows) * kBatch + within) * TS + kq * KQ;
+#pragma unroll
+                    for (int c = 0; c < KQ / 4; ++c) a[c] = *(const float4*)(sp + 4 * c);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // ------------------------------------------------------------------ phase 2: stream the weight chunks, 16 output columns at a time
+#pragma unroll 1
+        for (int c2 = 0; c2 < NC; c2 += 2) {
+#pragma unroll
+            for (int buf = 0; buf < 2; ++buf) {
+                const int c = c2 + buf;
+                __syncthreads();                                  // chunk c is complete in s_w[buf]; s_w[buf ^ 1] is free again
+                PP_FETCH_CHUNK(c + 1 < NC ? c + 1 : 0);           // (the chunk after the last one is chunk 0 of the next tile group)
+                float gp[4];
+                if constexpr (kEpi == 1) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int64_t r = t * 16 + 4 * kq + reg;
+                        gp[reg] = (act && have_tile && r < n_rows) ? act_in[r * Q + 16 * c + i] : 1.f;
+                    }
+                }
+                f32x4w out = {0.f, 0.f, 0.f, 0.f};
+                const float* wp = &s_w[buf][i * TS + kq * KQ];
+#pragma unroll
+                for (int cc = 0; cc < KQ / 4; ++cc) {
+                    const float4 b4 = *(const float4*)(wp + 4 * cc);
+                    out = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc].x, b4.x, out, 0, 0, 0);
+                    out = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc].y, b4.y, out, 0, 0, 0);
+                    out = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc].z, b4.z, out, 0, 0, 0);
+                    out = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc].w, b4.w, out, 0, 0, 0);
+                }
+                PP_STORE_CHUNK(buf ^ 1)
+                if (have_tile) {
+                    // C/D layout: out[reg] = row 4*kq + reg of the tile, column 16*c + i
+                    const float b = (kEpi == 0 && bias != nullptr) ? bias[16 * c + i] : 0.f;
+                    float csum = 0.f;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int64_t r = t * 16 + 4 * kq + reg;
+                        float v = out[reg];
+                        if constexpr (kEpi == 0) {
+                            v += b;
+                            if (act) v = elu_fast(v);
+                        } else {
+                            if (act) {
+                                const float sgn = gp[reg];
+                                v *= sgn > 0.f ? 1.f : sgn + 1.f;              // ELU'(pre) from the stored activation
+                            }
+                            if (r < n_rows) csum += v;
+                        }
+                        if (r < n_rows) Y[r * Q + 16 * c + i] = v;
+                    }
+                    if constexpr (kEpi == 1) {
+                        csum += __shfl_xor(csum, 16, kWave);
+                        csum += __shfl_xor(csum, 32, kWave);
+                        if (kq == 0) s_col[wave][16 * c + i] += csum;           // this wave's own row of s_col: no atomics needed
+                    }
+                }
+            }
+        }
+    }
+#undef PP_FETCH_CHUNK
+#undef PP_STORE_CHUNK
+    if constexpr (kEpi == 1) {
+        if (colsum != nullptr) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < Q; e += kWideThreads) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < kWideWaves; ++w) v += s_col[w][e];
+                atomicAdd(&colsum[e], v);
+            }
+        }
+    }
+}
+
+struct WideArgs {
+    const int32_t *ptr, *idx;
+    const float* val;
+    int64_t n_rows, n_self;
+    const float *X, *self_coef, *Wr, *bias;
+    int act;
+    HeavyRows heavy;
+    float *agg_out, *Y;
+    const float* act_in;
+    float* colsum;
+};
+
+template <int P, int Q, int kEpi>
+static int launch_wide(hipStream_t st, const WideArgs& a) {
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wide_layer<P, Q, kEpi>, kWideThreads, 0));
+        PP_HIP(hipGetDevice(&dev));
+        PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+    }
+    int64_t blocks = ceil_div(ceil_div(a.n_rows, 16), kWideWaves);
+    if (blocks > resident) blocks = resident;
+    k_wide_layer<P, Q, kEpi><<<(unsigned)blocks, kWideThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n_rows, a.n_self, a.X, a.self_coef, a.Wr, a.bias, a.act,
+                                                                         a.heavy, a.agg_out, a.Y, a.act_in, a.colsum);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+template <int P, int kEpi>
+static int launch_wide_q(int Q, hipStream_t st, const WideArgs& a) {
+    switch (Q) {
+        case 64: return launch_wide<P, 64, kEpi>(st, a);
+        case 128: return launch_wide<P, 128, kEpi>(st, a);
+        case 256: return launch_wide<P, 256, kEpi>(st, a);
+        default: return PP_ERR_ARG;
+    }
+}
+
+template <int kEpi>
+static int launch_wide_pq(int P, int Q, hipStream_t st, const WideArgs& a) {
+    switch (P) {
+        case 64: return launch_wide_q<64, kEpi>(Q, st, a);
+        case 128: return launch_wide_q<128, kEpi>(Q, st, a);
+        case 256: return launch_wide_q<256, kEpi>(Q, st, a);
+        default: return PP_ERR_ARG;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Narrow dense layers: widths that are not 16/32/64 themselves but fit in 64 (a classifier head with 8 classes, odd hidden widths):
+// the k_dense scheme (pp_dbgnn.hip) with both sides zero-padded to the next of 16/32/64 and guarded scalar I/O on the true widths.
+template <int P, int Q>
+__global__ __launch_bounds__(kBlock) void k_dense_narrow(const float* __restrict__ A, const float* __restrict__ W, int w_transposed, int64_t n_rows,
+                                                        int p_true, int q_true, const float* __restrict__ bias, const float* __restrict__ grad_act,
+                                                        float* __restrict__ colsum, float* __restrict__ out) {
+    constexpr int KQ = P / 4, CT = Q / 16;
+    const int lane = lane_id(), i = lane & 15, kq = lane >> 4;
+    float b[KQ][CT];
+#pragma unroll
+    for (int t = 0; t < KQ; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int k = kq * KQ + t, j = ct * 16 + i;
+            b[t][ct] = (k < p_true && j < q_true) ? (w_transposed ? W[j * p_true + k] : W[k * q_true + j]) : 0.f;
+        }
+    float bias_c[CT], col_acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        bias_c[ct] = (bias && ct * 16 + i < q_true) ? bias[ct * 16 + i] : 0.f;
+        col_acc[ct] = 0.f;
+    }
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave_id(); tile < n_tiles; tile += n_waves) {
+        const int64_t ra = tile * 16 + i;
+        float av[KQ];
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) {
+            const int k = kq * KQ + t;
+            av[t] = (ra < n_rows && k < p_true) ? A[ra * p_true + k] : 0.f;
+        }
+        f32x4w acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KQ; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b[t][ct], acc[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t r = tile * 16 + 4 * kq + reg;
+                const int j = ct * 16 + i;
+                if (r < n_rows && j < q_true) {
+                    float v = acc[ct][reg] + bias_c[ct];
+                    if (grad_act) {
+                        const float y = grad_act[r * q_true + j];
+                        v *= y > 0.f ? 1.f : y + 1.f;
+                        col_acc[ct] += v;
+                    }
+                    out[r * q_true + j] = v;
+                }
+            }
+    }
+    if (colsum) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            float v = col_acc[ct];
+            v += __shfl_xor(v, 16, kWave);
+            v += __shfl_xor(v, 32, kWave);
+            if (kq == 0 && ct * 16 + i < q_true) atomicAdd(&colsum[ct * 16 + i], v);
+        }
+    }
+}
+
+static inline int pad_width(int w) { return w <= 16 ? 16 : (w <= 32 ? 32 : 64); }
+
+template <int P>
+static int launch_narrow_q(int Qp, unsigned grid, hipStream_t st, const float* A, const float* W, int wt, int64_t n, int p, int q, const float* bias,
+                           const float* grad_act, float* colsum, float* out) {
+    switch (Qp) {
+        case 16: k_dense_narrow<P, 16><<<grid, kBlock, 0, st>>>(A, W, wt, n, p, q, bias, grad_act, colsum, out); break;
+        case 32: k_dense_narrow<P, 32><<<grid, kBlock, 0, st>>>(A, W, wt, n, p, q, bias, grad_act, colsum, out); break;
+        default: k_dense_narrow<P, 64><<<grid, kBlock, 0, st>>>(A, W, wt, n, p, q, bias, grad_act, colsum, out); break;
+    }
+    return PP_OK;
+}
+
+}  // namespace pp
+
+extern "C" {
+
+int pp_wide_layer_supported(int P, int Q) {
+    const bool p_ok = P == 64 || P == 128 || P == 256, q_ok = Q == 64 || Q == 128 || Q == 256;
+    return p_ok && q_ok && (P > 64 || Q > 64);
+}
+
+size_t pp_wide_layer_ws_bytes(int P, int Q) { return pp::align_up((size_t)(P > 0 ? P : 1) * (size_t)(Q > 0 ? Q : 1) * sizeof(float)); }
+
+int pp_wide_layer_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, int64_t n_src, const float* X, int P,
+                      const float* self_coef, const float* W, int w_is_kq, int Q, const float* bias, int act, int epilogue, const float* act_in,
+                      const int32_t* heavy_slot, const float* heavy_sum, float* agg_out, float* Y, float* colsum, void* ws, size_t ws_bytes,
+                      pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0 && n_self >= 0 && n_self <= n_rows && n_src >= 0, PP_ERR_ARG, "pp_wide_layer_f32: bad sizes");
+    PP_REQUIRE(n_rows == 0 || n_src >= 1, PP_ERR_ARG, "pp_wide_layer_f32: rows without any source row");
+    PP_REQUIRE(pp_wide_layer_supported(P, Q), PP_ERR_ARG, "pp_wide_layer_f32: unsupported layer shape %dx%d (64/128/256 with a side > 64)", P, Q);
+    PP_REQUIRE(epilogue == 0 || epilogue == 1, PP_ERR_ARG, "pp_wide_layer_f32: epilogue must be 0 (forward) or 1 (input gradient)");
+    PP_REQUIRE(act == 0 || act == 1, PP_ERR_ARG, "pp_wide_layer_f32: act must be 0 or 1");
+    PP_REQUIRE(epilogue == 0 || act == 0 || act_in != nullptr, PP_ERR_ARG, "pp_wide_layer_f32: act_in required for the ELU' epilogue");
+    PP_REQUIRE(((uintptr_t)X | (uintptr_t)agg_out | (uintptr_t)W) % 16 == 0, PP_ERR_ARG, "pp_wide_layer_f32: X, W and agg_out must be 16-byte aligned");
+    PP_REQUIRE(ptr != nullptr || (idx == nullptr && n_src >= n_rows), PP_ERR_ARG, "pp_wide_layer_f32: dense mode takes no CSR and n_src >= n_rows");
+    PP_REQUIRE(heavy_slot == nullptr || heavy_sum != nullptr, PP_ERR_ARG, "pp_wide_layer_f32: heavy_slot without heavy_sum");
+    if (colsum) PP_HIP(hipMemsetAsync(colsum, 0, (size_t)Q * sizeof(float), st));
+    if (n_rows == 0) return PP_OK;
+    const float* wr = W;
+    if (w_is_kq) {              // W is [P, Q] (k-major, the input-gradient case): the kernel wants one row per output column
+        PP_REQUIRE(ws != nullptr && ws_bytes >= pp_wide_layer_ws_bytes(P, Q), PP_ERR_WORKSPACE, "pp_wide_layer_f32: workspace too small");
+        pp::k_transpose_f32<<<(unsigned)pp::ceil_div((int64_t)P * Q, pp::kBlock), pp::kBlock, 0, st>>>(W, P, Q, (float*)ws);
+        PP_LAUNCH_CHECK();
+        wr = (const float*)ws;
+    }
+    const pp::WideArgs a{ptr, idx, val, n_rows, n_self, X, self_coef, wr, bias, act, pp::HeavyRows{heavy_slot, heavy_sum}, agg_out, Y, act_in, colsum};
+    return epilogue == 0 ? pp::launch_wide_pq<0>(P, Q, st, a) : pp::launch_wide_pq<1>(P, Q, st, a);
+}
+
+int pp_dense_narrow_supported(int P, int Q) { return P >= 1 && Q >= 1 && P <= 64 && Q <= 64; }
+
+int pp_dense_narrow_f32(const float* A, const float* W, int w_transposed, int64_t n_rows, int P, int Q, const float* bias, const float* grad_act,
+                        float* colsum, float* out, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_dense_narrow_f32: negative size");
+    PP_REQUIRE(pp_dense_narrow_supported(P, Q), PP_ERR_ARG, "pp_dense_narrow_f32: widths must lie in [1, 64], got %dx%d", P, Q);
+    if (colsum) PP_HIP(hipMemsetAsync(colsum, 0, (size_t)Q * sizeof(float), st));
+    if (n_rows == 0) return PP_OK;
+    int64_t blocks = pp::ceil_div(pp::ceil_div(n_rows, 16), pp::kWavesPerBlock);
+    if (blocks > 256 * 3) blocks = 256 * 3;
+    const int pp_ = pp::pad_width(P), qp = pp::pad_width(Q);
+    int rc;
+    switch (pp_) {
+        case 16: rc = pp::launch_narrow_q<16>(qp, (unsigned)blocks, st, A, W, w_transposed, n_rows, P, Q, bias, grad_act, colsum, out); break;
+        case 32: rc = pp::launch_narrow_q<32>(qp, (unsigned)blocks, st, A, W, w_transposed, n_rows, P, Q, bias, grad_act, colsum, out); break;
+        default: rc = pp::launch_narrow_q<64>(qp, (unsigned)blocks, st, A, W, w_transposed, n_rows, P, Q, bias, grad_act, colsum, out); break;
+    }
+    if (rc != PP_OK) return rc;
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // extern "C"

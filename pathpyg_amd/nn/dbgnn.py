@@ -66,7 +66,8 @@ class _Propagate(torch.autograd.Function):
 
 
 class _Dense(torch.autograd.Function):
-    """y = x W^T (+ b) on the matrix cores (hand-written fp32 MFMA kernels; library GEMM for unsupported layer widths).
+    """y = x W^T (+ b) on the matrix cores — hand-written fp32 MFMA kernels for every width up to 64 and for 64/128/256; only other
+    shapes (e.g. 100 -> 300) go to the library GEMM.
 
     ``fuse_act``: ``x`` is the stored activation ELU(pre) of the layer below and that layer was told ``grad_is_pre``: the
     input-gradient GEMM multiplies ELU'(pre) into its epilogue and accumulates the lower layer's bias gradient (returned as
@@ -76,7 +77,8 @@ class _Dense(torch.autograd.Function):
     def forward(ctx, x, weight, bias, fuse_act: bool, act_bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias, ctx.fuse_act, ctx.has_act_bias = bias is not None, fuse_act, act_bias is not None
-        ctx.fast = _hip.dense_supported(weight.size(1), weight.size(0))
+        kind = _hip.dense_supported(weight.size(1), weight.size(0))
+        ctx.fast, ctx.one_pass = kind > 0, kind == 1
         if ctx.fast:
             return _hip.dense(x, weight, True, bias)[0]
         return F.linear(x, weight, bias)
@@ -88,7 +90,7 @@ class _Dense(torch.autograd.Function):
         dx = dw = db = dact = None
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_sum = ctx.fuse_act and ctx.has_act_bias and ctx.needs_input_grad[4]
-        if ctx.fast and ctx.needs_input_grad[0] and need_w:
+        if ctx.one_pass and ctx.needs_input_grad[0] and need_w:
             # everything in one pass over dy and x: input gradient (+ fused ELU' and the lower layer's bias gradient), dW, db
             dx, dact, dw, db = _hip.dense_backward(dy, x, weight, ctx.fuse_act, True, want_sum, ctx.has_bias)
             return dx, dw, db, None, dact

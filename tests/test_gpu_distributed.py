@@ -48,6 +48,7 @@ CASES = [
     (3, 6000, 60, 12, 900, 16, [32, 32, 16], True),          # fused <=64-wide kernels
     (4, 9000, 150, 40, 4000, 64, [64, 64, 64], False),       # the benchmark's widths
     (5, 4000, 80, 25, 2000, 128, [128, 128, 64], True),      # 128-wide fused layers (pp_gcn_input_grad_f32 with n_self < n_rows)
+    (8, 3000, 70, 20, 1500, 256, [256, 256, 64], False),      # 256-wide layers (weights streamed through LDS) on rectangular plans
     (6, 1500, 40, 9, 500, 8, [12, 10, 6], True),             # widths without a fused kernel: library GEMM + CSR kernels
     (7, 60, 50, 2, 80, 16, [16, 16, 16], False),             # nearly empty higher-order graph, ranks without edges
 ]
