@@ -38,6 +38,34 @@ __global__ __launch_bounds__(kBlock) void k_transpose_f32(const float* __restric
     out[c * rows + r] = in[e];
 }
 
+// The epilogue of one 16-column chunk: out[reg] = row 4*kq + reg of the tile, column 16*c + i (C/D layout of the 16x16 MFMA).
+template <int Q, int kEpi>
+__device__ __forceinline__ void wide_epilogue(const f32x4w out, const float (&gp)[4], int c, int64_t t, int i, int kq, int64_t n_rows, int act,
+                                              const float* __restrict__ bias, float* __restrict__ Y, float* __restrict__ s_col_row) {
+    const float b = kEpi == 0 ? bias[16 * c + i] : 0.f;            // (bias: the kernel's LDS copy; zeros when the layer has none)
+    float csum = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int64_t r = t * 16 + 4 * kq + reg;
+        float v = out[reg];
+        if constexpr (kEpi == 0) {
+            v += b;
+            const float e = elu_fast(v);
+            v = act ? e : v;
+        } else {
+            const float sgn = gp[reg];
+            v *= (act && !(sgn > 0.f)) ? sgn + 1.f : 1.f;          // ELU'(pre) from the stored activation
+            if (r < n_rows) csum += v;
+        }
+        if (r < n_rows) Y[r * Q + 16 * c + i] = v;
+    }
+    if constexpr (kEpi == 1) {
+        csum += __shfl_xor(csum, 16, kWave);
+        csum += __shfl_xor(csum, 32, kWave);
+        if (kq == 0) s_col_row[16 * c + i] += csum;           // this wave's own row of the column sums: no atomics needed
+    }
+}
+
 // kEpi 0: Y = act(tile . Wr^T + bias)            (forward; optional copy of the aggregated tile to agg_out)
 // kEpi 1: Y = (tile . Wr^T) (*) ELU'(act_in)     (input gradient; act_in NULL = no factor) + column sums
 template <int P, int Q, int kEpi>
@@ -48,10 +76,13 @@ __global__ __launch_bounds__(kWideThreads, 2) void k_wide_layer(const int32_t* _
                                                                 HeavyRows heavy, float* __restrict__ agg_out, float* __restrict__ Y,
                                                                 const float* __restrict__ act_in, float* __restrict__ colsum) {
     constexpr int kLanes = P / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = P / 4, TS = P + 4, NC = Q / 16;
-    constexpr int kBatch = P >= 256 ? 2 : (kRows < 4 ? kRows : 4);       // rows per lane group gathered at a time (register budget)
+    constexpr int kBatch = kRows < 4 ? kRows : 4;                        // rows per lane group gathered at a time
     constexpr int kStageRows = kGroups * kBatch;
     constexpr int kChunkVec = 16 * P / 4 / kWideThreads;          // float4 per thread and weight chunk
-    __shared__ __attribute__((aligned(16))) float s_w[2][16 * TS];
+    // two separate LDS objects for the two weight buffers: the compiler orders every LDS read behind a pending LDS-DMA into the SAME
+    // object (s_waitcnt vmcnt(0) in the middle of the MFMA stream), but keeps distinct objects apart
+    __shared__ __attribute__((aligned(16))) float s_w0[16 * TS];
+    __shared__ __attribute__((aligned(16))) float s_w1[16 * TS];
     __shared__ __attribute__((aligned(16))) float s_stage[kWideWaves][kStageRows * TS];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int g = lane / kLanes, l = lane % kLanes;
@@ -62,21 +93,39 @@ __global__ __launch_bounds__(kWideThreads, 2) void k_wide_layer(const int32_t* _
     const int64_t n_tiles = (n_rows + 15) / 16;
     const int64_t n_groups = (n_tiles + kWideWaves - 1) / kWideWaves;
     __shared__ float s_col[kEpi == 1 ? kWideWaves : 1][kEpi == 1 ? Q : 1];          // per-wave column sums of the gradient epilogue
+    __shared__ float s_bias[kEpi == 0 ? Q : 1];                                     // LDS copy: no global load inside the chunk pipeline
+    if constexpr (kEpi == 0) {
+        for (int e = threadIdx.x; e < Q; e += kWideThreads) s_bias[e] = bias != nullptr ? bias[e] : 0.f;
+    }
 
-    // weight chunk loader: chunk c = rows 16c .. 16c+15 of Wr; thread e handles float4 number e, e + 256, ... of the chunk
-    // (row e / (P/4), quad e % (P/4)): fetched into registers one chunk ahead, written to the free LDS buffer after the MFMAs
-    float4 wnext[kChunkVec];
-#define PP_FETCH_CHUNK(C)                                                                                          \
-    _Pragma("unroll") for (int v = 0; v < kChunkVec; ++v)                                                          \
-        wnext[v] = *(const float4*)(Wr + (size_t)(C) * 16 * P + (size_t)(threadIdx.x + v * kWideThreads) * 4)
-#define PP_STORE_CHUNK(BUF)                                                                                        \
-    _Pragma("unroll") for (int v = 0; v < kChunkVec; ++v) {                                                        \
-        const int e_ = threadIdx.x + v * kWideThreads;                                                             \
-        const int r_ = e_ / (P / 4), q4_ = e_ - r_ * (P / 4);                                                      \
-        *(float4*)(&s_w[BUF][r_ * TS + 4 * q4_]) = wnext[v];                                                       \
+    // weight chunk loader: chunk c = rows 16c .. 16c+15 of Wr.
+    //  P == 256: one row = 1 KiB = one wave-wide global_load_lds_dwordx4 straight into the (padded) LDS row — no staging registers, no
+    //            ds_write, and nothing the compiler can sink into the MFMA stream; wave w moves rows w, w+4, w+8, w+12.  The DMA of
+    //            chunk c+1 is issued right after the barrier that publishes chunk c and lands while chunk c's MFMAs run.
+    //  P < 256:  thread e handles float4 number e, e + 256, ... of the chunk through registers (written to LDS after the MFMAs).
+    constexpr bool kDma = P == 256;
+    float4 wnext[kDma ? 1 : kChunkVec];
+#define PP_FETCH_CHUNK(C, BUF)                                                                                                     \
+    if constexpr (kDma) {                                                                                                          \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                                            \
+            const int row_ = wave + 4 * v;                                                                                         \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wr + ((size_t)(C) * 16 + row_) * P + 4 * lane), \
+                                             (__attribute__((address_space(3))) void*)(((BUF) == 0 ? s_w0 : s_w1) + row_ * TS), 16, 0, 0);           \
+        }                                                                                                                          \
+    } else {                                                                                                                       \
+        _Pragma("unroll") for (int v = 0; v < kChunkVec; ++v)                                                                      \
+            wnext[v] = *(const float4*)(Wr + (size_t)(C) * 16 * P + (size_t)(threadIdx.x + v * kWideThreads) * 4);                 \
+    }
+#define PP_STORE_CHUNK(BUF)                                                                                                        \
+    if constexpr (!kDma) {                                                                                                         \
+        _Pragma("unroll") for (int v = 0; v < kChunkVec; ++v) {                                                                    \
+            const int e_ = threadIdx.x + v * kWideThreads;                                                                         \
+            const int r_ = e_ / (P / 4), q4_ = e_ - r_ * (P / 4);                                                                  \
+            *(float4*)(((BUF) == 0 ? s_w0 : s_w1) + r_ * TS + 4 * q4_) = wnext[v];                                                                   \
+        }                                                                                                                          \
     }
     static_assert(NC % 2 == 0, "the double buffer returns to slot 0 after every tile group");
-    PP_FETCH_CHUNK(0);
+    PP_FETCH_CHUNK(0, 0)
     PP_STORE_CHUNK(0)
     if constexpr (kEpi == 1) {
         for (int e = lane; e < Q; e += kWave) s_col[wave][e] = 0.f;
@@ -191,61 +240,72 @@ __global__ __launch_bounds__(kWideThreads, 2) void k_wide_layer(const int32_t* _
             }
         }
         // ------------------------------------------------------------------ phase 2: stream the weight chunks, 16 output columns at a time
+        // Software pipeline over the chunks: [wait own DMA + older stores] barrier | DMA of chunk c+1 | epilogue (stores) of chunk c-1 |
+        // LDS reads + 64 MFMAs of chunk c.  Stores and DMA of one iteration are covered by the MFMAs of the same iteration.
+        // Two accumulator sets, one per LDS buffer: while chunk c accumulates into one, the other still holds chunk c-1 for its (deferred)
+        // epilogue — its registers are not rewritten for a whole chunk, so no MFMA ever waits for a pending store to read them.
+        f32x4w acc[2][2];
+        float gp[2][4];
+#pragma unroll
+        for (int sset = 0; sset < 2; ++sset) {
+            acc[sset][0] = f32x4w{0.f, 0.f, 0.f, 0.f};
+            acc[sset][1] = f32x4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) gp[sset][reg] = 1.f;
+        }
 #pragma unroll 1
         for (int c2 = 0; c2 < NC; c2 += 2) {
 #pragma unroll
             for (int buf = 0; buf < 2; ++buf) {
                 const int c = c2 + buf;
-                __syncthreads();                                  // chunk c is complete in s_w[buf]; s_w[buf ^ 1] is free again
-                PP_FETCH_CHUNK(c + 1 < NC ? c + 1 : 0);           // (the chunk after the last one is chunk 0 of the next tile group)
-                float gp[4];
+                __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): this wave's DMA rows of chunk c have landed (and its older stores are out)
+                __syncthreads();                                  // chunk c is complete in buffer `buf`; the other buffer is free again
+                PP_FETCH_CHUNK(c + 1 < NC ? c + 1 : 0, buf ^ 1)   // (the chunk after the last one is chunk 0 of the next tile group)
+                if (c > 0 && have_tile)
+                    wide_epilogue<Q, kEpi>(acc[buf ^ 1][0] + acc[buf ^ 1][1], gp[buf ^ 1], c - 1, t, i, kq, n_rows, act, s_bias, Y, s_col[kEpi == 1 ? wave : 0]);
                 if constexpr (kEpi == 1) {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int64_t r = t * 16 + 4 * kq + reg;
-                        gp[reg] = (act && have_tile && r < n_rows) ? act_in[r * Q + 16 * c + i] : 1.f;
+                        gp[buf][reg] = (act && have_tile && r < n_rows) ? act_in[r * Q + 16 * c + i] : 1.f;
                     }
                 }
-                f32x4w out = {0.f, 0.f, 0.f, 0.f};
-                const float* wp = &s_w[buf][i * TS + kq * KQ];
+                // two accumulators per chunk, alternating: a 16x16x4 fp32 MFMA issues every 32 cycles but its result is ready after 40 — a
+                // single dependent chain would idle the matrix pipe a fifth of the time
+                acc[buf][0] = f32x4w{0.f, 0.f, 0.f, 0.f};
+                acc[buf][1] = f32x4w{0.f, 0.f, 0.f, 0.f};
+                const float* wp = (buf == 0 ? s_w0 : s_w1) + i * TS + kq * KQ;
+                // register double buffer for the B operands: the LDS reads of the next 4 k-quads are issued BEFORE the 16 MFMAs of the
+                // current ones (the scheduling barriers pin that order; left alone the compiler reads two quads, waits out the LDS latency
+                // with an idle matrix pipe, and repeats)
+                constexpr int kQuads = KQ / 4, kStep = kQuads < 4 ? kQuads : 4;
+                float4 bc[kStep], bn[kStep];
 #pragma unroll
-                for (int cc = 0; cc < KQ / 4; ++cc) {
-                    const float4 b4 = *(const float4*)(wp + 4 * cc);
-                    out = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc].x, b4.x, out, 0, 0, 0);
-                    out = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc].y, b4.y, out, 0, 0, 0);
-                    out = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc].z, b4.z, out, 0, 0, 0);
-                    out = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc].w, b4.w, out, 0, 0, 0);
+                for (int u = 0; u < kStep; ++u) bc[u] = *(const float4*)(wp + 4 * u);
+#pragma unroll
+                for (int cc = 0; cc < kQuads; cc += kStep) {
+                    if (cc + kStep < kQuads) {
+#pragma unroll
+                        for (int u = 0; u < kStep; ++u) bn[u] = *(const float4*)(wp + 4 * (cc + kStep + u));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < kStep; ++u) {
+                        acc[buf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].x, bc[u].x, acc[buf][0], 0, 0, 0);
+                        acc[buf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].y, bc[u].y, acc[buf][1], 0, 0, 0);
+                        acc[buf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].z, bc[u].z, acc[buf][0], 0, 0, 0);
+                        acc[buf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].w, bc[u].w, acc[buf][1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < kStep; ++u) bc[u] = bn[u];
                 }
                 PP_STORE_CHUNK(buf ^ 1)
-                if (have_tile) {
-                    // C/D layout: out[reg] = row 4*kq + reg of the tile, column 16*c + i
-                    const float b = (kEpi == 0 && bias != nullptr) ? bias[16 * c + i] : 0.f;
-                    float csum = 0.f;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int64_t r = t * 16 + 4 * kq + reg;
-                        float v = out[reg];
-                        if constexpr (kEpi == 0) {
-                            v += b;
-                            if (act) v = elu_fast(v);
-                        } else {
-                            if (act) {
-                                const float sgn = gp[reg];
-                                v *= sgn > 0.f ? 1.f : sgn + 1.f;              // ELU'(pre) from the stored activation
-                            }
-                            if (r < n_rows) csum += v;
-                        }
-                        if (r < n_rows) Y[r * Q + 16 * c + i] = v;
-                    }
-                    if constexpr (kEpi == 1) {
-                        csum += __shfl_xor(csum, 16, kWave);
-                        csum += __shfl_xor(csum, 32, kWave);
-                        if (kq == 0) s_col[wave][16 * c + i] += csum;           // this wave's own row of s_col: no atomics needed
-                    }
-                }
             }
         }
+        if (have_tile) wide_epilogue<Q, kEpi>(acc[1][0] + acc[1][1], gp[1], NC - 1, t, i, kq, n_rows, act, s_bias, Y, s_col[kEpi == 1 ? wave : 0]);
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // (the DMA of the chunk nobody will use must not outlive the workgroup's LDS)
 #undef PP_FETCH_CHUNK
 #undef PP_STORE_CHUNK
     if constexpr (kEpi == 1) {
