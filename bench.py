@@ -54,8 +54,11 @@ def parse():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: host-staged collectives (tests; several ranks may share one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (single-GPU test boxes, with --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-loop-events", type=int, default=8_000, help="smallest of the three B-loop sizes (x2, x4 follow)")
+    ap.add_argument("--cpu-loop-events", type=int, default=6_000, help="smallest of the three B-loop sizes (x2, x4 follow; kept below torch's 32768-element parallel grain)")
     ap.add_argument("--cpu-sample-events", type=int, default=2_000_000, help="size of the vectorised CPU pipeline sample (B-agg, B-dbgnn)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU baseline and print its JSON (used by the main run, in a "
+                                                                      "subprocess with a hard time limit, so that it can never stall the bench line)")
+    ap.add_argument("--cpu-baseline-timeout", type=int, default=420)
     return ap.parse_args()
 
 
@@ -201,9 +204,16 @@ def cpu_baseline(args, seed: int) -> dict:
     from oracle import dbgnn as od
     from oracle import lift as ol
     from oracle import model as om
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(max(cores, 1))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # torch's intra-op pool: all host cores up to 64 (beyond that the fork/join of the many small ops of the reference loop costs more
+    # than it gains: measured on the 256-thread GPU host, m = 32000: > 6 min with 256 threads against seconds with the ops kept serial)
+    cores = max(min(avail, 64), 1)
+    torch.set_num_threads(cores)
     cpu = torch.device("cpu")
+    t_start = time.perf_counter()
+
+    def note(msg):
+        print(f"[cpu_baseline {time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
     def sample(m, s):
         scale = m / args.events
@@ -236,8 +246,11 @@ def cpu_baseline(args, seed: int) -> dict:
         ho = ol.temporal_lift_per_timestamp(ei, t, args.delta)
         dt = time.perf_counter() - t0
         loop.append({"m": m, "N": n, "T": int(torch.unique(t).numel()), "E2": int(ho.size(1)), "seconds": dt})
-        if dt > 25.0:
+        note(f"B-loop m={m}: {dt:.2f}s")
+        if dt * 8.0 > 60.0:                                  # the next size costs ~4-8x: stay inside the time budget
             break
+    if len(loop) < 2:
+        loop.append(dict(loop[0]))                            # degenerate fit (one size only): slope through that point
     a_mat = np.array([[r["T"] * r["m"], r["E2"]] for r in loop], dtype=np.float64)
     b_vec = np.array([r["seconds"] for r in loop], dtype=np.float64)
     coef, *_ = np.linalg.lstsq(a_mat, b_vec, rcond=None)
@@ -249,6 +262,7 @@ def cpu_baseline(args, seed: int) -> dict:
     layers = om.layers_from_temporal(ei, t, n, delta=args.delta, max_order=2, loop_lift=True)
     t_layers = time.perf_counter() - t0
     t_train = train_step(layers, n, seed)
+    note(f"reference step on the largest loop sample: layers {t_layers:.2f}s, train {t_train:.2f}s")
     # ---- B-sorted and B-line at FULL size
     ei_f, t_f = synth_stream(args.events, args.nodes, args.span, seed + 10, cpu)
     ei_f, t_f, _ = om.stable_time_sort(ei_f, t_f)
@@ -260,6 +274,7 @@ def cpu_baseline(args, seed: int) -> dict:
     t0 = time.perf_counter()
     e3 = int(ol.line_graph_lift(ho_f, args.events).size(1))
     t_line = time.perf_counter() - t0
+    note(f"B-sorted {t_sorted:.2f}s, B-line {t_line:.2f}s (full size)")
     del ho_f, ei_f, t_f
     # ---- B-agg + B-dbgnn on the vectorised pipeline sample
     ms = min(args.cpu_sample_events, args.events)
@@ -270,12 +285,15 @@ def cpu_baseline(args, seed: int) -> dict:
     t0 = time.perf_counter()
     layers_s = om.layers_from_temporal(ei_s, t_s, n_s, delta=args.delta, max_order=2, event_graph=ho_s)
     t_agg_s = time.perf_counter() - t0
+    note(f"B-agg {t_agg_s:.2f}s (m={ms})")
     t_train_s = train_step(layers_s, n_s, seed + 1)
+    note(f"B-dbgnn {t_train_s:.2f}s")
     e2_s = int(ho_s.size(1))
     return {
         "value": big["E2"] / (t_layers + t_train),
         "unit": "lifted k-edges/s",
         "cores": cores,
+        "host_threads_available": avail,
         "kind": "port",
         "sample": f"oracle port of the reference algorithm (per-timestamp lift loop + aggregation + 1 DBGNN train step) on m={big['m']} events, "
                   f"N={big['N']}, delta={args.delta}, E2={big['E2']}: lift+aggregate {t_layers:.2f}s, train step {t_train:.2f}s",
@@ -306,8 +324,28 @@ def relaunch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def cpu_baseline_isolated(args) -> dict:
+    """The CPU baseline in its own process (no HIP runtime threads beside the host cores it measures) and under a hard time limit."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"]
+    for k in ("events", "nodes", "span", "delta", "features", "classes", "cpu_loop_events", "cpu_sample_events"):
+        cmd += ["--" + k.replace("_", "-"), str(getattr(args, k))]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout)
+    except subprocess.TimeoutExpired as exc:
+        tail = (exc.stderr or b"")[-400:]
+        return {"value": None, "unit": "lifted k-edges/s", "cores": None, "kind": "port",
+                "sample": f"CPU baseline exceeded its {args.cpu_baseline_timeout}s limit and was stopped", "progress": tail.decode(errors="replace") if isinstance(tail, bytes) else str(tail)}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"value": None, "unit": "lifted k-edges/s", "cores": None, "kind": "port", "sample": "CPU baseline failed: " + r.stderr[-400:]}
+    return json.loads(lines[-1])
+
+
 def main() -> int:
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args, seed=11)), flush=True)
+        return 0
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ          # started by torch.distributed.run
     if args.gpus > 1 and not launched:
         return relaunch(args)
@@ -542,7 +580,7 @@ def main() -> int:
             "linegraph_fill_roofline": k3,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args, seed=11)
+            line["cpu_baseline"] = cpu_baseline_isolated(args)
         print(json.dumps(line), flush=True)
     if launched:
         dist.barrier()
