@@ -14,7 +14,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$C; rocprofv3 --pmc $C --kernel-trace -d /tmp/p_$C -o x -- $CMD > /tmp/log_$C.txt 2>&1
   python $R/tools/rocprof_pmc.py $(find /tmp/p_$C -name "*.db" | head -1) --top 40 --json /tmp/pmc_$C.json > $OUT/${TAG}_pmc_$C.txt 2>&1
 done
-python $R/bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_stderr.txt
+timeout 600 python $R/bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_stderr.txt
 python - <<PY
 import json
 f, w = json.load(open("/tmp/pmc_FETCH_SIZE.json")), json.load(open("/tmp/pmc_WRITE_SIZE.json"))
@@ -28,18 +28,21 @@ for key, pat in (("k_gcn_forward", "k_gcn_forward<64, 64"), ("k_gcn_backward", "
                  ("k_expand", "k_expand<true>"), ("k_temporal_count", "k_temporal_count"), ("k_spmm_act_backward", "k_spmm_act_backward<16>"),
                  ("k_weight_grad64", "k_weight_grad64")):
     fe, wr = pick(f, pat, "FETCH_SIZE"), pick(w, pat, "WRITE_SIZE")
-    if not fe or not wr:
+    if not fe or not wr or fe["dispatches"] != wr["dispatches"]:
         continue
-    fc, wc = fe["clusters"], wr["clusters"]
-    # clusters are sorted ascending: the last one is the 10^7-row higher-order graph (@ho), the first one the first-order graph (@fo)
-    for suffix, ci in (("@ho", -1), ("@fo", 0)) if len(fc) > 1 and len(wc) > 1 else (("", -1),):
-        out[key + suffix] = {"fetch_kib_per_dispatch": fc[ci]["mean"], "write_kib_per_dispatch": wc[ci]["mean"], "fetch_correction": 2.0,
-                             "hbm_bytes_per_dispatch": (2.0 * fc[ci]["mean"] + wc[ci]["mean"]) * 1024, "dispatches_in_profile": fc[ci]["count"]}
+    # the two passes run the same program: dispatch i of one pass is dispatch i of the other.  HBM bytes = 2 * FETCH + WRITE (KiB -> bytes)
+    fv, wv = fe["values_in_dispatch_order"], wr["values_in_dispatch_order"]
+    tot = [(2.0 * a + b) * 1024 for a, b in zip(fv, wv)]
+    big = [i for i, t_ in enumerate(tot) if t_ >= 0.4 * max(tot)]            # launches on the 10^7-row higher-order graph
+    small = [i for i, t_ in enumerate(tot) if t_ < 0.4 * max(tot)]           # launches on the 5*10^5-row first-order graph
+    for suffix, sel in ((("@ho", big), ("@fo", small)) if small else (("", big),)):
+        out[key + suffix] = {"fetch_kib_per_dispatch": sum(fv[i] for i in sel) / len(sel), "write_kib_per_dispatch": sum(wv[i] for i in sel) / len(sel),
+                             "fetch_correction": 2.0, "hbm_bytes_per_dispatch": sum(tot[i] for i in sel) / len(sel), "dispatches_in_profile": len(sel)}
 json.dump({"workload": "bench.py defaults (m=10^7, N=5*10^5, delta=10^6, F=64), partition mode at 1 GPU",
            "source": "${TAG}_pmc_FETCH_SIZE.txt + ${TAG}_pmc_WRITE_SIZE.txt (separate rocprofv3 --pmc passes); FETCH_SIZE doubled (gfx950); "
                      "@ho / @fo = the dispatch-size clusters of the 10^7-row higher-order and the 5*10^5-row first-order graph", **out},
           open("$OUT/${TAG}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
-python $R/tools/bench_kernels.py --ops lift,agg,plan,spmm,dense,gcn > $OUT/${TAG}_per_op_timings.txt 2>&1
+timeout 300 python $R/tools/bench_kernels.py --ops lift,agg,plan,spmm,dense,gcn > $OUT/${TAG}_per_op_timings.txt 2>&1
 tail -c 600 $OUT/${TAG}_bench_line.json

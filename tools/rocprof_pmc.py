@@ -39,7 +39,8 @@ def main():
     name = "kernel_name" if "kernel_name" in cols else "name"
     cname = "counter_name" if "counter_name" in cols else "pmc_name"
     val = "value" if "value" in cols else "counter_value"
-    rows = db.execute(f"select {name}, {cname}, dispatch_id, sum({val}) from counters_collection group by {name}, {cname}, dispatch_id").fetchall()
+    rows = db.execute(f"select {name}, {cname}, dispatch_id, sum({val}) from counters_collection group by {name}, {cname}, dispatch_id "
+                      f"order by dispatch_id").fetchall()
     per = {}
     for k, c, _, v in rows:
         per.setdefault((k, c), []).append(float(v))
@@ -50,7 +51,7 @@ def main():
         cl = clusters(vals)
         text = ", ".join(f"{len(g)} x {sum(g) / len(g):.1f}" for g in cl)
         print(f"{k[:68]:<70} {c:<12} {len(vals):>5} {sum(vals):>16.0f} {sum(vals) / len(vals):>16.1f}  {text}")
-        dump[f"{k}|{c}"] = {"dispatches": len(vals), "per_dispatch_mean": sum(vals) / len(vals),
+        dump[f"{k}|{c}"] = {"dispatches": len(vals), "per_dispatch_mean": sum(vals) / len(vals), "values_in_dispatch_order": vals,
                             "clusters": [{"count": len(g), "mean": sum(g) / len(g)} for g in cl]}
     if a.json:
         with open(a.json, "w") as fh:
