@@ -259,3 +259,152 @@ def test_wide_fused_gcn_kernels_with_matrices_beyond_4_gib(pp):
             torch.testing.assert_close(d_in[rows], want, rtol=1e-4, atol=2e-4)
         assert float((d_in[rows] - want).abs().max()) < 2e-3
     torch.testing.assert_close(colsum.double(), total, rtol=1e-3, atol=1e-3 * float(total.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] / configs[4] at full per-GPU size.  The CPU oracle cannot hold 2*10^7 x 128 float64 activations with autograd in
+# reasonable time, so the DBGNN step is compared with an independent float64 evaluation ON THE GPU made of stock torch ops only
+# (torch.sparse.mm on a COO adjacency built with the published gcn_norm rules, dense matmul, F.elu, F.cross_entropy): no code of
+# pathpyg_amd's kernels, float64 throughout, autograd for every gradient.
+def _gcn_norm_sparse(edge_index, edge_weight, n, dtype=torch.float64):
+    """diag(s) (A + loops)^T diag(s) as a sparse [dst, src] matrix — PyG gcn_norm: existing self loops keep their (last) weight, missing ones get
+    1, s = weighted in-degree ^ -1/2 with inf -> 0 (the rules oracle/dbgnn.py:gcn_norm restates)."""
+    dev = edge_index.device
+    row, col, w = edge_index[0], edge_index[1], edge_weight.to(dtype)
+    loop = row == col
+    loop_w = torch.ones(n, dtype=dtype, device=dev)
+    loop_w[row[loop]] = w[loop]
+    ids = torch.arange(n, device=dev)
+    r = torch.cat((row[~loop], ids))
+    c = torch.cat((col[~loop], ids))
+    v = torch.cat((w[~loop], loop_w))
+    deg = torch.zeros(n, dtype=dtype, device=dev).index_add_(0, c, v)
+    s = deg.pow(-0.5)
+    s[torch.isinf(s)] = 0
+    return torch.sparse_coo_tensor(torch.stack((c, r)), s[r] * v * s[c], (n, n)).coalesce()
+
+
+def _reference_step_float64(params, data, y):
+    """(logits, loss, {name: grad}) of one DBGNN step in float64 from stock torch ops on the device of `data`."""
+    import torch.nn.functional as F
+    dev = data["x"].device
+    p = {k: v.to(dev).double().requires_grad_(True) for k, v in params.items()}
+    a1 = _gcn_norm_sparse(data["edge_index"], data["edge_weights"], data["num_nodes"])
+    a2 = _gcn_norm_sparse(data["edge_index_higher_order"], data["edge_weights_higher_order"], data["num_ho_nodes"])
+    x, x_h = data["x"].double(), data["x_h"].double()
+    n_gcn = sum(1 for k in p if k.startswith("first_order_layers.") and k.endswith(".bias"))
+    for i in range(n_gcn):
+        x = F.elu(torch.sparse.mm(a1, x @ p[f"first_order_layers.{i}.lin.weight"].t()) + p[f"first_order_layers.{i}.bias"])
+    for i in range(n_gcn):
+        x_h = F.elu(torch.sparse.mm(a2, x_h @ p[f"higher_order_layers.{i}.lin.weight"].t()) + p[f"higher_order_layers.{i}.bias"])
+    bip = data["bipartite_edge_index"]
+    inc = torch.sparse_coo_tensor(torch.stack((bip[1], bip[0])), torch.ones(bip.size(1), dtype=torch.float64, device=dev),
+                                  (data["num_nodes"], data["num_ho_nodes"])).coalesce()
+    h_ho = x_h @ p["bipartite_layer.lin1.weight"].t() + p["bipartite_layer.lin1.bias"]
+    h_fo = x @ p["bipartite_layer.lin2.weight"].t() + p["bipartite_layer.lin2.bias"]
+    indeg = torch.zeros(data["num_nodes"], dtype=torch.float64, device=dev).index_add_(0, bip[1], torch.ones(bip.size(1), dtype=torch.float64, device=dev))
+    out = F.elu(torch.sparse.mm(inc, h_ho) + indeg.unsqueeze(1) * h_fo) @ p["lin.weight"].t() + p["lin.bias"]
+    loss = F.cross_entropy(out, y)
+    loss.backward()
+    return out.detach(), loss.detach(), {k: v.grad for k, v in p.items()}
+
+
+def _dbgnn_step_vs_float64(pp, m, n, span, delta, f, classes=8):
+    from oracle import dbgnn as od
+    ei, t = _stream(5, m, n, span)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=n))
+    del ei, t
+    model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=2)
+    n_ho = model.layers[2].n
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(n, f, generator=gen, device=DEV)
+    x_h = torch.randn(n_ho, f, generator=gen, device=DEV)
+    y = torch.randint(0, classes, (n,), generator=gen, device=DEV)
+    data = model.to_dbgnn_data(max_order=2, x=x, x_h=x_h)
+    params = od.init_params(classes, (f, f), [f, f, f], seed=4)
+    net = pp.nn.DBGNN(num_classes=classes, num_features=(f, f), hidden_dims=[f, f, f]).to(DEV)
+    net.load_state_dict(params)
+    out = net(data)
+    loss = pp.nn.dbgnn.cross_entropy(out, y)
+    loss.backward()
+    got_out, got_loss = out.detach().double(), loss.detach().double()
+    got_grads = {k: v.grad.detach().double() for k, v in net.named_parameters()}
+    sizes = (model.layers[2].n, model.layers[2].m)
+    ref_in = {key: data[key] for key in ("num_nodes", "num_ho_nodes", "x", "x_h", "edge_index", "edge_weights", "edge_index_higher_order",
+                                          "edge_weights_higher_order", "bipartite_edge_index")}
+    ref_in = {k: (pp._dispatch.plain(v) if isinstance(v, torch.Tensor) else v) for k, v in ref_in.items()}
+    del out, loss, net, data, model, g                                   # free the fp32 path's activations before the float64 pass
+    torch.cuda.empty_cache()
+    want_out, want_loss, want_grads = _reference_step_float64(params, ref_in, y)
+    scale = float(want_out.abs().max())
+    torch.testing.assert_close(got_out, want_out, rtol=1e-5, atol=1e-5 * scale)
+    torch.testing.assert_close(got_loss, want_loss, rtol=1e-5, atol=1e-6)
+    for name, grad in got_grads.items():
+        gs = float(want_grads[name].abs().max()) + 1e-30
+        torch.testing.assert_close(grad, want_grads[name], rtol=1e-4, atol=1e-4 * gs, msg=lambda s_: f"{name}: {s_}")
+    return sizes
+
+
+def test_config3_20m_events_f128_dbgnn_step_matches_float64_reference(pp):
+    """BASELINE configs[3] at its per-GPU size on ONE GPU: 20M-event temporal ER stream (1M nodes, E2 ~ 2m), k=2 DBGNN with 128-dim features and
+    hidden [128]*3 — the 128-wide fused layer kernels on a 2*10^7-row higher-order graph (10 GB matrices: 64-bit row offsets)."""
+    n_ho, a2 = _dbgnn_step_vs_float64(pp, m=20_000_000, n=1_000_000, span=10_000_000, delta=1_000_000, f=128)
+    assert n_ho > 19_000_000 and a2 > 35_000_000
+
+
+def test_config4_f256_dbgnn_step_matches_float64_reference(pp):
+    """BASELINE configs[4] DBGNN part ("256-dim features, MFMA feature GEMM") on one GPU at the largest stream whose float64 reference fits beside
+    it: the 10^7-event headline stream, hidden [256]*3 — every layer on the LDS-streamed 256-wide kernels (pp_gcn_wide.hip)."""
+    n_ho, a2 = _dbgnn_step_vs_float64(pp, m=10_000_000, n=500_000, span=10_000_000, delta=1_000_000, f=256)
+    assert n_ho > 9_900_000 and a2 > 18_000_000
+
+
+def test_config4_100m_events_k2_to_k5_lift_properties(pp):
+    """BASELINE configs[4] lift part on ONE GPU: 10^8-event stream (5*10^6 nodes), multi-order lift K = 2..5 with delta tuned so that E_k ~ m
+    at every order.  Exact invariants at full size: window / adjacency of every lifted pair, lexicographic order, the
+    line-graph edge-count identity at every order, weight conservation and lexicographic unique node sequences of every aggregated layer,
+    and the oracle's continuation sets on a sample of source events."""
+    from pathpyg_amd.algorithms.lift_order import lift_order_edge_index
+    n, m, span, delta = 5_000_000, 100_000_000, 100_000_000, 5_000_000
+    ei, t = _stream(7, m, n, span)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=n))
+    del ei, t
+    ei, t = g.data.edge_index, g.data.time
+    assert bool((t[1:] >= t[:-1]).all())
+    ho = pp.algorithms.lift_order_temporal(g, delta)
+    e2 = ho.size(1)
+    assert 0.8 * m < e2 < 1.2 * m and _is_lexsorted(ho)
+    i, j = ho[0], ho[1]
+    assert bool((ei[1][i] == ei[0][j]).all()) and bool(((t[j] > t[i]) & (t[j] <= t[i] + delta)).all())
+    rng = np.random.default_rng(2)
+    for i0 in rng.integers(0, m, 12).tolist():
+        cand = torch.nonzero((ei[0] == ei[1][i0]) & (t > t[i0]) & (t <= t[i0] + delta)).flatten()
+        lo = torch.searchsorted(i, torch.tensor(i0, device=DEV))
+        hi = torch.searchsorted(i, torch.tensor(i0, device=DEV), right=True)
+        assert torch.equal(j[lo:hi], cand)
+    # raw line-graph lifts k = 3, 4, 5: edge-count identity and middle-instance adjacency
+    totals = {1: m, 2: e2}
+    cur, n_inst = ho, m
+    for k in (3, 4, 5):
+        nxt = lift_order_edge_index(cur, num_nodes=n_inst)
+        outdeg = torch.bincount(cur[0], minlength=n_inst)
+        assert nxt.size(1) == int(outdeg[cur[1]].sum())
+        assert _is_lexsorted(nxt) and bool((cur[1][nxt[0]] == cur[0][nxt[1]]).all())
+        totals[k] = nxt.size(1)
+        n_inst, cur = cur.size(1), nxt
+        del outdeg
+    del cur, nxt
+    torch.cuda.empty_cache()
+    model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=5, event_graph=ho)
+    for k in (1, 2, 3, 4, 5):
+        d = model.layers[k].data
+        assert _is_lexsorted(d.edge_index)
+        assert float(d.edge_weight.double().sum()) == float(totals[k])
+        ns = d.node_sequence
+        assert ns.size(1) == k and ns.size(0) == d.num_nodes
+        later = torch.zeros(ns.size(0) - 1, dtype=torch.bool, device=DEV)          # row r+1 > row r lexicographically
+        equal = torch.ones_like(later)
+        for c in range(k):
+            later |= equal & (ns[1:, c] > ns[:-1, c])
+            equal &= ns[1:, c] == ns[:-1, c]
+        assert bool(later.all())

@@ -170,3 +170,21 @@ def test_dbgnn_module_state_dict_layout():
     from oracle import dbgnn as od
     net.load_state_dict(od.init_params(3, (7, 9), [16, 32, 8]))          # oracle parameter dict == state_dict layout
     assert float(net.first_order_layers[0].bias.abs().sum()) == 0.0
+
+
+def test_dbgnn_hints_are_bound_to_the_tensors_they_describe():
+    """hints of to_dbgnn_data must not survive a replaced or edited edge index."""
+    from pathpyg_amd.nn.dbgnn import _valid_hints
+    ei = torch.tensor([[0, 1], [1, 2]])
+    w = torch.ones(2)
+    d = pp.Data(num_nodes=3, num_ho_nodes=2, edge_index=ei, edge_weights=w, edge_index_higher_order=ei.clone(), edge_weights_higher_order=w.clone(),
+                bipartite_edge_index=ei.clone())
+    names = ("edge_index", "edge_weights", "edge_index_higher_order", "edge_weights_higher_order", "bipartite_edge_index")
+    object.__setattr__(d, "_pp_hints", {"stamp": tuple((d[k], d[k]._version) for k in names), "rows_sorted": True})
+    assert _valid_hints(d).get("rows_sorted") is True
+    d.edge_index_higher_order[0, 0] = 1                     # in-place edit: version changes
+    assert _valid_hints(d) == {}
+    object.__setattr__(d, "_pp_hints", {"stamp": tuple((d[k], d[k]._version) for k in names), "rows_sorted": True})
+    assert _valid_hints(d).get("rows_sorted") is True
+    d.edge_index = torch.tensor([[2, 0], [1, 1]])           # replaced tensor (not row-sorted any more)
+    assert _valid_hints(d) == {}
