@@ -332,6 +332,15 @@ class _LiftChain:
             unique_nodes, inv = _dispatch.unique_rows(node_sequence)
         out = _aggregate_with_known_nodes(edge_index, 1, node_sequence, unique_nodes, inv, edge_weight, "sum", want_inverse=want_pairs)
         graph, edge_ids = out if want_pairs else (out, None)
+        if not identity_nodes and edge_ids is not None:
+            # Layer 1 of a path model uses the walk node ids AS GIVEN (reference quirk, lift_order.py:135-136), while `unique_nodes` is
+            # indexed by RANK.  The shortcut of lift() (order-(k+1) nodes = layer k's merged edges) looks layer-1 edges up in
+            # `unique_nodes`, which is only right when id == rank, i.e. the ids are exactly 0..U-1; otherwise the next lift takes the
+            # 2-column unique over (rank of prefix, last node), which is id-agnostic.
+            u = unique_nodes.size(0)
+            ids = _dispatch.plain(unique_nodes).reshape(-1)
+            if u and not bool((ids == torch.arange(u, device=ids.device)).all()):
+                edge_ids = None
         return _LiftChain(edge_index, inv, _dispatch.plain(node_sequence).reshape(-1), unique_nodes, edge_weight, graph, edge_ids)
 
     def to_second_order(self, event_index, ho_index, ho_weight, save: bool, want_edge_ids: bool = False):

@@ -496,12 +496,14 @@ def coalesce_sharded(rows: torch.Tensor, cols: torch.Tensor, weight: torch.Tenso
     rank, world = _world(group)
     cuts = _owner_cuts(num_nodes, world).to(rows.device)
     owner = torch.searchsorted(cuts[1:].contiguous(), rows, right=True).clamp_(max=world - 1)
-    payload = torch.stack((rows, cols, weight.to(torch.float64).view(torch.int64) if weight.dtype == torch.float64
-                           else weight.to(torch.float32).view(torch.int32).to(torch.int64)), dim=1)
-    buckets = [payload[owner == r] for r in range(world)]
-    mine = _exchange(buckets, group)
-    ei = mine[:, :2].t().contiguous()
-    w = mine[:, 2].to(torch.int32).view(torch.float32) if weight.dtype != torch.float64 else mine[:, 2].view(torch.float64)
+    # ids and weights travel separately: the weights keep their dtype (integer weights stay exact beyond 2^24)
+    order = torch.sort(owner, stable=True).indices
+    counts = torch.bincount(owner, minlength=world).tolist()
+    ids = torch.stack((rows, cols), dim=1).index_select(0, order)
+    wsorted = weight.index_select(0, order)
+    mine = _exchange(list(ids.split(counts)), group)
+    w = _exchange(list(wsorted.split(counts)), group)
+    ei = mine.t().contiguous()
     merged_index, merged_weight = _dispatch.coalesce(ei, w.contiguous(), num_nodes, "sum")
     return merged_index, merged_weight, cuts.cpu()
 

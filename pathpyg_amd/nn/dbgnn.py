@@ -195,6 +195,44 @@ class _AggregateAct(torch.autograd.Function):
         return None, dpre, colsum
 
 
+class _ActBoundary(torch.autograd.Function):
+    """Identity on a stored activation ``y = ELU(pre)`` whose producer follows the ``grad_is_pre`` contract (:class:`_GcnLayer`): the
+    backward pass turns the gradient w.r.t. ``y`` into the gradient w.r.t. ``pre`` and hands the column sums to ``act_bias`` (one
+    ``pp_act_backward_f32`` pass).  Used where something that is not a fused consumer sits behind the activation — dropout."""
+
+    @staticmethod
+    def forward(ctx, y, act_bias):
+        ctx.has_bias = act_bias is not None
+        ctx.save_for_backward(y)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        want = ctx.has_bias and ctx.needs_input_grad[1]
+        dpre, dbias = _hip.act_backward(dy, y, True, want_dpre=True, want_dbias=want)
+        return dpre, dbias
+
+
+class _Aggregate(torch.autograd.Function):
+    """``A y`` over a CsrPlan without self term, bias or activation (the bipartite sum of already dropped-out rows)."""
+
+    @staticmethod
+    def forward(ctx, plan, y):
+        ctx.plan = plan
+        return _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, y, heavy=plan.fwd_heavy)
+
+    @staticmethod
+    def backward(ctx, d):
+        plan = ctx.plan
+        return None, _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d.contiguous(), heavy=plan.bwd_heavy)
+
+
+def _dropout(x: torch.Tensor, p: float) -> torch.Tensor:
+    """Training-mode dropout (module-level so that tests can substitute a reproducible mask)."""
+    return F.dropout(x, p=p, training=True)
+
+
 def dense(x, linear: Linear, fuse_act: bool = False, act_bias=None):
     if x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda:
         return _Dense.apply(x, linear.weight, linear.bias, fuse_act, act_bias)
@@ -217,8 +255,13 @@ class _CrossEntropy(torch.autograd.Function):
 def cross_entropy(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """Mean softmax cross-entropy (``F.cross_entropy`` semantics for class-index targets) with its gradient computed in the
     same HIP pass; falls back to torch for CPU tensors or more than 64 classes."""
-    if logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and logits.size(1) <= 64:
-        return _CrossEntropy.apply(logits, target)
+    if (logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and logits.size(1) <= 64 and logits.size(0) > 0
+            and target.dim() == 1 and target.dtype == torch.int64):
+        # the kernel has no ignore_index / out-of-range handling: check the class indices first (one tiny reduction + 16-byte read);
+        # anything else (soft labels, ignore_index = -100, empty batches) keeps torch's semantics through torch
+        lo, hi = _hip.minmax(target)
+        if lo >= 0 and hi < logits.size(1):
+            return _CrossEntropy.apply(logits, target)
     return F.cross_entropy(logits, target)
 
 
@@ -328,9 +371,6 @@ class DBGNN(Module):
         self.bipartite_layer = BipartiteGraphOperator(hidden_dims[-2], hidden_dims[-1])
         self.lin = Linear(hidden_dims[-1], num_classes)
 
-    def _dropout(self, x):
-        return F.dropout(x, p=self.p_dropout, training=self.training) if self.p_dropout > 0 else x
-
     def forward(self, data) -> torch.Tensor:
         x, x_h = data.x, data.x_h
         n_fo, n_ho = int(data.num_nodes), int(data.num_ho_nodes)
@@ -354,14 +394,31 @@ class DBGNN(Module):
                               lambda: _hip.bipartite_plan_from_edge_grouping(plan_fo, _dispatch_plain(data.edge_index)[1], n_ho))
 
         if self.p_dropout > 0 and self.training:
-            for layer in self.first_order_layers:                   # dropout -> GCNConv -> ELU (fused into the aggregation)
-                x = layer(self._dropout(x), data.edge_index, data.edge_weights, plan=plan_fo, activation=True)
-            x = self._dropout(x)
-            for layer in self.higher_order_layers:
-                x_h = layer(self._dropout(x_h), data.edge_index_higher_order, data.edge_weights_higher_order, plan=plan_ho, activation=True)
-            x_h = self._dropout(x_h)
-            x = self.bipartite_layer((x_h, x), data.bipartite_edge_index, n_ho=n_ho, n_fo=n_fo, plan=plan_bi, activation=True)
-            return dense(self._dropout(x), self.lin)
+            # dropout -> GCNConv -> ELU (reference dbgnn.py:131-146).  The layers stay on the fused kernels (aggregation + MFMA product + bias +
+            # ELU in one launch, one-kernel backward); the dropout itself and the ELU backward it separates from the next layer's
+            # input-gradient epilogue are element-wise passes (_dropout, _ActBoundary).
+            p = self.p_dropout
+
+            def stack_drop(layers, h, plan):
+                for layer in layers:
+                    h = _dropout(h, p)
+                    if _GcnLayer.supported(plan, h, layer.lin.weight):
+                        h = _ActBoundary.apply(_GcnLayer.apply(plan, h, layer.lin.weight, layer.bias, False, None), layer.bias)
+                    else:
+                        h = _Propagate.apply(plan, dense(h, layer.lin), None, layer.bias, True)
+                return _dropout(h, p)
+
+            x = stack_drop(self.first_order_layers, x, plan_fo)
+            x_h = stack_drop(self.higher_order_layers, x_h, plan_ho)
+            bl = self.bipartite_layer
+            if plan_bi.fwd_val is None and x_h.size(1) % 4 == 0 and x_h.size(1) <= 256:
+                # sum_j (W1 x_h[j] + b1) = W1 (sum_j x_h[j]) + deg * b1, as below: the dense layers run on the N first-order rows only
+                agg = _Aggregate.apply(plan_bi, x_h)
+                per_edge = dense(x, bl.lin2) + bl.lin1.bias
+                x = F.elu(torch.addcmul(_Dense.apply(agg, bl.lin1.weight, None, False, None), plan_bi.self_coef.unsqueeze(1), per_edge))
+            else:
+                x = self.bipartite_layer((x_h, x), data.bipartite_edge_index, n_ho=n_ho, n_fo=n_fo, plan=plan_bi, activation=True)
+            return dense(_dropout(x, p), self.lin)
 
         # No dropout between an activation and the dense layer that consumes it: every ELU backward is fused into the
         # epilogue of that dense layer's input-gradient GEMM (see _Dense / _Propagate.grad_is_pre).

@@ -382,3 +382,20 @@ def test_temporal_betweenness_vs_oracle(pp):
         got = _dispatch.temporal_betweenness(ei.to(DEV), t.to(DEV), n, delta).cpu().numpy()
         want = tp.temporal_betweenness_reference(ei, t, n, delta)
         np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-9, err_msg=str(trial))
+
+
+def test_path_model_with_node_id_gaps_below_used_ids_matches_oracle(pp):
+    """walk node ids with a gap BELOW ids that occur in edges but all < number of distinct ids (here {0, 2, 3} plus 7 in a
+    single-node walk: 4 distinct ids, edges only between ids < 4).  Layer 1 keeps the ids as given (reference quirk); layers >= 2 must
+    still be the reference's (instance sequences are extended with the raw ids), cached or not."""
+    from oracle import model as om
+    walks = [[0, 2, 3], [2, 3, 0, 2], [3, 2, 0], [7], [0, 2, 3, 2]]
+    weights = [1.0, 2.0, 1.0, 1.0, 3.0]
+    ref = om.walks_to_path_tensors(walks, weights)
+    want = om.layers_from_paths(ref, max_order=4)
+    for cached in (True, False):
+        paths = pp.PathData(device=DEV)
+        paths.append_walks(walks, weights)
+        model = pp.MultiOrderModel.from_path_data(paths, max_order=4, cached=cached)
+        for k in model.layers:
+            _layer_equal(model.layers[k], want[k])
