@@ -6,6 +6,8 @@
 // through HBM (write N*Q, gather it back).  (A_hat X) W^T is the same product re-associated: a wave aggregates a tile of 16
 // destination rows straight from X into LDS and multiplies the tile by W on v_mfma_f32_16x16x4_f32, so the only N-sized
 // traffic left is the gather itself and the store of Y.  W (<= 64x64 fp32) sits in LDS for the whole persistent workgroup.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "pp_common.h"
@@ -321,7 +323,10 @@ static int launch_gcn_wide(int P, int Q, int64_t n_tiles, hipStream_t st, const 
     return PP_ERR_ARG;
 }
 
-static inline bool gcn_wide_shape(int P, int Q) { return (P == 128 && (Q == 64 || Q == 128)) || (P == 64 && Q == 128); }
+static inline bool gcn_wide_shape(int P, int Q) {
+    static const bool stream_all = getenv("PP_WIDE_STREAMED") != nullptr;      // measurement switch: 128-wide shapes on pp_gcn_wide.hip too
+    return !stream_all && ((P == 128 && (Q == 64 || Q == 128)) || (P == 64 && Q == 128));
+}
 
 // =====================================================================================================
 // Backward of such a layer, again in one kernel (the math of pp_spmm_f32 on the transposed CSR + pp_dense_backward_f32):

@@ -262,11 +262,13 @@ def _ops_default(ops):
 # one d^-1/2 halo exchange, and the CSR that folds returned gradient rows into the owned rows.
 # =====================================================================================================
 def build_graph_shard(src: torch.Tensor, dst: torch.Tensor, weight: torch.Tensor | None, num_nodes: int, cuts: list[int], comm: Comm,
-                      ops=None, row_sorted: bool = False, status_out: list | None = None, want_dst_order: bool = False):
+                      ops=None, row_sorted: bool = False, status_out: list | None = None, want_dst_order: bool = False,
+                      edge_index: torch.Tensor | None = None):
     """This rank's :class:`~pathpyg_amd.nn.sharded.GraphShard` of a graph with ``num_nodes`` nodes from the edges (GLOBAL ids) that
     point into its destination range ``[cuts[rank], cuts[rank+1])`` — GCN normalisation with PyG ``gcn_norm`` semantics
     (reference nn/dbgnn.py:104-114 through GCNConv): every in-edge of an owned node is local, so the weighted in-degree is too;
-    the d^-1/2 of the halo sources comes from their owners in one 4-byte-per-row exchange."""
+    the d^-1/2 of the halo sources comes from their owners in one 4-byte-per-row exchange.  ``edge_index``: the same edges as one
+    contiguous [2, E] tensor when the caller has it (saves a copy at world size 1)."""
     from .nn.sharded import GraphShard
     ops = _ops_default(ops)
     rank, world = comm.rank, comm.world
@@ -274,7 +276,8 @@ def build_graph_shard(src: torch.Tensor, dst: torch.Tensor, weight: torch.Tensor
     n_own = hi - lo
     dev = src.device
     if world == 1:
-        plan = ops.gcn_plan(torch.stack((src, dst)), weight, num_nodes, row_sorted, status_out, want_dst_order=want_dst_order)
+        whole = edge_index if edge_index is not None else torch.stack((src, dst))
+        plan = ops.gcn_plan(whole, weight, num_nodes, row_sorted, status_out, want_dst_order=want_dst_order)
         return GraphShard(lo=0, hi=num_nodes, n_own=num_nodes, n_halo=0, n_src=num_nodes, num_nodes=num_nodes, cuts=list(cuts), plan=plan,
                           send_counts=[0], recv_counts=[0])
     # ---- halo = the distinct foreign sources, ascending (= grouped by owner: owners hold ascending id ranges)
@@ -387,7 +390,8 @@ def build_dbgnn_shard(g, delta, x: torch.Tensor, x_h, y: torch.Tensor | None, co
     ei = _dispatch.plain(data.edge_index)
     dev = ei.device
     n, m = int(data.num_nodes), int(ei.size(1))
-    w = data[weight] if weight in data else torch.ones(m, device=dev)
+    unit_weights = weight not in data
+    w = torch.ones(m, device=dev) if unit_weights else data[weight]
     # 1. layer 1
     fo, fo_w, inv1 = ops.coalesce(ei, w, n, "sum", None, True)
     n_ho = int(fo.size(1))
@@ -411,7 +415,7 @@ def build_dbgnn_shard(g, delta, x: torch.Tensor, x_h, y: torch.Tensor | None, co
     end = halo_end(data.time, hi_e, delta) if hi_e > lo_e else lo_e
     local = ops.temporal_lift(ei[:, lo_e:end].contiguous(), data.time[lo_e:end].contiguous(), n, delta, hi_e - lo_e, lo_e)
     e2_local = int(local.size(1))
-    w_pairs = w.index_select(0, local[0])
+    w_pairs = torch.ones(e2_local, device=dev) if unit_weights else w.index_select(0, local[0])   # lifted weight = weight of the source event
     # 4. aggregation at the destination owner
     if world == 1:
         ho_ei, ho_w = ops.coalesce(local, w_pairs, n_ho, "sum", inv1, False, col_block)
@@ -430,13 +434,14 @@ def build_dbgnn_shard(g, delta, x: torch.Tensor, x_h, y: torch.Tensor | None, co
         del u, v, owner, order, ids, ids_r, w_r
     # 5. shards
     pending = []
-    ho = build_graph_shard(ho_ei[0], ho_ei[1], ho_w.to(torch.float32), n_ho, ho_cuts, comm, ops, world == 1, pending)
+    ho = build_graph_shard(ho_ei[0], ho_ei[1], ho_w.to(torch.float32), n_ho, ho_cuts, comm, ops, world == 1, pending, edge_index=ho_ei)
     if world == 1:
         f_src, f_dst, f_w = fo[0], fo[1], fo_w
     else:
         mine = (fo[1] >= fo_cuts[rank]) & (fo[1] < fo_cuts[rank + 1])
         f_src, f_dst, f_w = fo[0][mine], fo[1][mine], fo_w[mine]
-    fo_shard = build_graph_shard(f_src, f_dst, f_w.to(torch.float32), n, fo_cuts, comm, ops, world == 1, pending, want_dst_order=world == 1)
+    fo_shard = build_graph_shard(f_src, f_dst, f_w.to(torch.float32), n, fo_cuts, comm, ops, world == 1, pending, want_dst_order=world == 1,
+                                 edge_index=fo if world == 1 else None)
     if world == 1:
         bip, cap = ops.bipartite_from_grouping(fo_shard.plan, fo[1], n_ho), n
     else:
