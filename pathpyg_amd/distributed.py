@@ -286,18 +286,16 @@ def build_graph_shard(src: torch.Tensor, dst: torch.Tensor, weight: torch.Tensor
     need[lo:hi] = False
     halo_ids = torch.nonzero(need).flatten()
     n_halo = int(halo_ids.numel())
-    halo_rank = torch.cumsum(need, 0) - 1
+    halo_rank = torch.cumsum(need, 0, dtype=torch.int32) - 1
     foreign = (src < lo) | (src >= hi)
-    src_local = torch.where(foreign, halo_rank[src] + n_own, src - lo)
+    src_local = torch.where(foreign, halo_rank[src].to(torch.int64) + n_own, src - lo)
     del need, halo_rank, foreign
     cuts_t = torch.tensor(cuts, dtype=torch.int64, device=dev)
     bounds = torch.searchsorted(halo_ids, cuts_t).tolist()
     recv_counts = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
     send_counts = comm.exchange_counts(recv_counts, dev)
     requests = comm.exchange_rows(halo_ids, recv_counts, send_counts)             # the rows each peer wants from me (global ids)
-    send_idx = (requests - lo).contiguous()
-    if send_idx.numel() and (int(send_idx.min()) < 0 or int(send_idx.max()) >= n_own):
-        raise RuntimeError("build_graph_shard: a peer asked for a row this rank does not own (inconsistent cuts)")
+    send_idx = (requests - lo).contiguous()        # (peers derive their requests from the same cuts: every id lies in [lo, hi))
 
     def halo_dinv(dinv_own: torch.Tensor) -> torch.Tensor:
         return comm.exchange_rows(dinv_own.index_select(0, send_idx), send_counts, recv_counts)
@@ -344,8 +342,8 @@ def shard_dbgnn_bundle(data, comm: Comm, ops=None, fo_cuts: list[int] | None = N
         ei = _dispatch.plain(edge_index)
         if world == 1:
             return ei[0], ei[1], weights
-        mine = (ei[1] >= cuts[rank]) & (ei[1] < cuts[rank + 1])
-        return ei[0][mine], ei[1][mine], (None if weights is None else weights[mine])
+        mine = torch.nonzero((ei[1] >= cuts[rank]) & (ei[1] < cuts[rank + 1])).flatten()
+        return ei[0].index_select(0, mine), ei[1].index_select(0, mine), (None if weights is None else weights.index_select(0, mine))
 
     pending = []
     hints = getattr(data, "_pp_hints", None) or {}
@@ -438,8 +436,8 @@ def build_dbgnn_shard(g, delta, x: torch.Tensor, x_h, y: torch.Tensor | None, co
     if world == 1:
         f_src, f_dst, f_w = fo[0], fo[1], fo_w
     else:
-        mine = (fo[1] >= fo_cuts[rank]) & (fo[1] < fo_cuts[rank + 1])
-        f_src, f_dst, f_w = fo[0][mine], fo[1][mine], fo_w[mine]
+        mine = torch.nonzero((fo[1] >= fo_cuts[rank]) & (fo[1] < fo_cuts[rank + 1])).flatten()      # one size read-back for all three gathers
+        f_src, f_dst, f_w = fo[0].index_select(0, mine), fo[1].index_select(0, mine), fo_w.index_select(0, mine)
     fo_shard = build_graph_shard(f_src, f_dst, f_w.to(torch.float32), n, fo_cuts, comm, ops, world == 1, pending, want_dst_order=world == 1,
                                  edge_index=fo if world == 1 else None)
     if world == 1:
