@@ -247,7 +247,7 @@ int pp_weight_grad_f32(const float* dH, const float* X, int64_t n_rows, int M, i
  *   grad_act : [N,Q] or NULL: the stored activation y = ELU(pre) of the layer below; the result is multiplied by
  *              ELU'(pre) = (y > 0 ? 1 : y + 1) and, with colsum [Q], its column sums (= that layer's bias gradient) accumulate.
  * fp32 on v_mfma_f32_16x16x4_f32.  pp_dense_supported(P, Q): 1 = P, Q in {16, 32, 64} (weights in registers; also pp_dense_backward_f32),
- * 2 = other widths up to 64 (zero-padded: pp_dense_narrow_f32), 3 = 64/128/256 with a side > 64 (pp_wide_layer_f32 in dense mode; with
+ * 2 = other widths whose padded product is <= 4096, e.g. anything up to 64 x 64 or 256 x 8 (zero-padded: pp_dense_narrow_f32), 3 = 64/128/256 with a side > 64 (pp_wide_layer_f32 in dense mode; with
  * w_transposed == 0 it needs ws = pp_wide_layer_ws_bytes(P, Q) bytes), 0 = not supported (the Python side then uses the library GEMM). */
 int pp_dense_supported(int P, int Q);
 int pp_dense_f32(const float* A, const float* W, int w_transposed, int64_t n_rows, int P, int Q, const float* bias,
@@ -317,8 +317,9 @@ int pp_wide_layer_f32(const int32_t* ptr, const int32_t* idx, const float* val, 
                       const int32_t* heavy_slot, const float* heavy_sum, float* agg_out, float* Y, float* colsum, void* ws, size_t ws_bytes,
                       pp_stream_t stream);
 
-/* Dense layers with widths in [1, 64] that are not 16/32/64 themselves (classifier head: 64 -> 8 classes; odd hidden widths): the
- * pp_dense_f32 scheme with both sides zero-padded to 16/32/64 and guarded scalar I/O.  Same arguments as pp_dense_f32. */
+/* Dense layers with one small side (classifier head: 64 -> 8 or 256 -> 8 classes and its input gradient; odd hidden widths): the
+ * pp_dense_f32 scheme with both sides zero-padded to 16/32/64/128/256 (padded P*Q <= 4096) and guarded scalar I/O on the true widths.
+ * Same arguments as pp_dense_f32. */
 int pp_dense_narrow_supported(int P, int Q);
 int pp_dense_narrow_f32(const float* A, const float* W, int w_transposed, int64_t n_rows, int P, int Q, const float* bias, const float* grad_act,
                         float* colsum, float* out, pp_stream_t stream);

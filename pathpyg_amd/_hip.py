@@ -660,8 +660,8 @@ def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
 
 
 def dense_supported(p: int, q: int) -> int:
-    """0: no HIP kernel for this layer shape (library GEMM); 1: widths 16/32/64 (also :func:`dense_backward`); 2: other widths up to 64
-    (zero-padded kernel); 3: 64/128/256 with a side > 64 (weights streamed through LDS)."""
+    """0: no HIP kernel for this layer shape (library GEMM); 1: widths 16/32/64 (also :func:`dense_backward`); 2: other widths whose
+    zero-padded product fits the register-resident kernel (anything up to 64 x 64, 256 x 8, 8 x 256, ...); 3: 64/128/256 with a side > 64 (weights streamed through LDS)."""
     return int(lib().pp_dense_supported(int(p), int(q)))
 
 

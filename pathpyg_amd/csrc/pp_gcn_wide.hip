@@ -372,8 +372,9 @@ static int launch_wide_pq(int P, int Q, hipStream_t st, const WideArgs& a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Narrow dense layers: widths that are not 16/32/64 themselves but fit in 64 (a classifier head with 8 classes, odd hidden widths):
-// the k_dense scheme (pp_dbgnn.hip) with both sides zero-padded to the next of 16/32/64 and guarded scalar I/O on the true widths.
+// Narrow dense layers: one side small (a classifier head: 64 -> 8 or 256 -> 8 classes and its input gradient 8 -> 256; odd hidden widths):
+// the k_dense scheme (pp_dbgnn.hip) with both sides zero-padded to the next of 16/32/64/128/256 (padded P*Q <= 4096: the weight block
+// lives in P*Q/64 registers per lane) and guarded scalar I/O on the true widths.
 template <int P, int Q>
 __global__ __launch_bounds__(kBlock) void k_dense_narrow(const float* __restrict__ A, const float* __restrict__ W, int w_transposed, int64_t n_rows,
                                                         int p_true, int q_true, const float* __restrict__ bias, const float* __restrict__ grad_act,
@@ -439,18 +440,35 @@ __global__ __launch_bounds__(kBlock) void k_dense_narrow(const float* __restrict
     }
 }
 
-static inline int pad_width(int w) { return w <= 16 ? 16 : (w <= 32 ? 32 : 64); }
+static inline int pad_width(int w) { return w <= 16 ? 16 : (w <= 32 ? 32 : (w <= 64 ? 64 : (w <= 128 ? 128 : 256))); }
 
-template <int P>
-static int launch_narrow_q(int Qp, unsigned grid, hipStream_t st, const float* A, const float* W, int wt, int64_t n, int p, int q, const float* bias,
-                           const float* grad_act, float* colsum, float* out) {
-    switch (Qp) {
-        case 16: k_dense_narrow<P, 16><<<grid, kBlock, 0, st>>>(A, W, wt, n, p, q, bias, grad_act, colsum, out); break;
-        case 32: k_dense_narrow<P, 32><<<grid, kBlock, 0, st>>>(A, W, wt, n, p, q, bias, grad_act, colsum, out); break;
-        default: k_dense_narrow<P, 64><<<grid, kBlock, 0, st>>>(A, W, wt, n, p, q, bias, grad_act, colsum, out); break;
+// padded shapes whose weight block (P*Q/64 registers per lane) and accumulators (Q/4 registers) fit beside each other: P*Q <= 4096
+static inline bool narrow_shape(int P, int Q) { return P >= 1 && Q >= 1 && P <= 256 && Q <= 256 && pad_width(P) * pad_width(Q) <= 4096; }
+
+#define PP_NARROW(PP_, QQ_) k_dense_narrow<PP_, QQ_><<<grid, kBlock, 0, st>>>(A, W, wt, n, p, q, bias, grad_act, colsum, out)
+static int launch_narrow(int Pp, int Qp, unsigned grid, hipStream_t st, const float* A, const float* W, int wt, int64_t n, int p, int q,
+                         const float* bias, const float* grad_act, float* colsum, float* out) {
+    switch (Pp * 1000 + Qp) {
+        case 16016: PP_NARROW(16, 16); break;
+        case 16032: PP_NARROW(16, 32); break;
+        case 16064: PP_NARROW(16, 64); break;
+        case 16128: PP_NARROW(16, 128); break;
+        case 16256: PP_NARROW(16, 256); break;
+        case 32016: PP_NARROW(32, 16); break;
+        case 32032: PP_NARROW(32, 32); break;
+        case 32064: PP_NARROW(32, 64); break;
+        case 32128: PP_NARROW(32, 128); break;
+        case 64016: PP_NARROW(64, 16); break;
+        case 64032: PP_NARROW(64, 32); break;
+        case 64064: PP_NARROW(64, 64); break;
+        case 128016: PP_NARROW(128, 16); break;
+        case 128032: PP_NARROW(128, 32); break;
+        case 256016: PP_NARROW(256, 16); break;
+        default: return PP_ERR_ARG;
     }
     return PP_OK;
 }
+#undef PP_NARROW
 
 }  // namespace pp
 
@@ -490,24 +508,18 @@ int pp_wide_layer_f32(const int32_t* ptr, const int32_t* idx, const float* val, 
     return epilogue == 0 ? pp::launch_wide_pq<0>(P, Q, st, a) : pp::launch_wide_pq<1>(P, Q, st, a);
 }
 
-int pp_dense_narrow_supported(int P, int Q) { return P >= 1 && Q >= 1 && P <= 64 && Q <= 64; }
+int pp_dense_narrow_supported(int P, int Q) { return pp::narrow_shape(P, Q) ? 1 : 0; }
 
 int pp_dense_narrow_f32(const float* A, const float* W, int w_transposed, int64_t n_rows, int P, int Q, const float* bias, const float* grad_act,
                         float* colsum, float* out, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_dense_narrow_f32: negative size");
-    PP_REQUIRE(pp_dense_narrow_supported(P, Q), PP_ERR_ARG, "pp_dense_narrow_f32: widths must lie in [1, 64], got %dx%d", P, Q);
+    PP_REQUIRE(pp_dense_narrow_supported(P, Q), PP_ERR_ARG, "pp_dense_narrow_f32: padded widths must satisfy P*Q <= 4096 (each <= 256), got %dx%d", P, Q);
     if (colsum) PP_HIP(hipMemsetAsync(colsum, 0, (size_t)Q * sizeof(float), st));
     if (n_rows == 0) return PP_OK;
     int64_t blocks = pp::ceil_div(pp::ceil_div(n_rows, 16), pp::kWavesPerBlock);
     if (blocks > 256 * 3) blocks = 256 * 3;
-    const int pp_ = pp::pad_width(P), qp = pp::pad_width(Q);
-    int rc;
-    switch (pp_) {
-        case 16: rc = pp::launch_narrow_q<16>(qp, (unsigned)blocks, st, A, W, w_transposed, n_rows, P, Q, bias, grad_act, colsum, out); break;
-        case 32: rc = pp::launch_narrow_q<32>(qp, (unsigned)blocks, st, A, W, w_transposed, n_rows, P, Q, bias, grad_act, colsum, out); break;
-        default: rc = pp::launch_narrow_q<64>(qp, (unsigned)blocks, st, A, W, w_transposed, n_rows, P, Q, bias, grad_act, colsum, out); break;
-    }
+    const int rc = pp::launch_narrow(pp::pad_width(P), pp::pad_width(Q), (unsigned)blocks, st, A, W, w_transposed, n_rows, P, Q, bias, grad_act, colsum, out);
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();
     return PP_OK;

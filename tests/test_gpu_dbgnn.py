@@ -172,6 +172,7 @@ def test_sharded_dbgnn_world1_matches_oracle_on_gpu(pp):
 
 @pytest.mark.parametrize("n,p,q", [(1, 16, 16), (15, 64, 64), (16, 32, 64), (1000, 64, 32), (70_001, 64, 64), (4097, 16, 64),
                                    (1000, 64, 8), (1000, 8, 64), (333, 12, 10), (5000, 3, 3), (70_001, 64, 13),       # zero-padded narrow widths
+                                   (3000, 256, 8), (3000, 8, 256), (500, 128, 32), (300, 200, 10), (300, 10, 200),   # one small side, up to 256
                                    (1, 256, 256), (17, 256, 256), (5000, 256, 256), (3000, 64, 256), (3000, 256, 64), (4097, 128, 256),
                                    (2000, 256, 128), (2000, 128, 128), (70_001, 128, 64)])                              # weights streamed through LDS
 def test_dense_mfma_kernel(pp, n, p, q):
@@ -194,7 +195,7 @@ def test_dense_mfma_kernel(pp, n, p, q):
     torch.testing.assert_close(out.cpu(), want, **tol)
     torch.testing.assert_close(colsum.cpu(), want.sum(0), rtol=1e-4, atol=1e-4 * float(want.abs().sum(0).max() + 1))
     assert _hip.dense_supported(8, 64) == 2 and _hip.dense_supported(64, 16) == 1 and _hip.dense_supported(256, 256) == 3
-    assert _hip.dense_supported(100, 300) == 0 and _hip.dense_supported(64, 96) == 0
+    assert _hip.dense_supported(100, 300) == 0 and _hip.dense_supported(64, 96) == 0 and _hip.dense_supported(256, 8) == 2
 
 
 @pytest.mark.parametrize("n,c", [(1, 2), (1000, 8), (100_003, 8), (5000, 13), (300, 64)])
