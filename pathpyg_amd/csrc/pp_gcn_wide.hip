@@ -38,32 +38,31 @@ __global__ __launch_bounds__(kBlock) void k_transpose_f32(const float* __restric
     out[c * rows + r] = in[e];
 }
 
-// The epilogue of one 16-column chunk: out[reg] = row 4*kq + reg of the tile, column 16*c + i (C/D layout of the 16x16 MFMA).
+// The epilogue of ONE ROW GROUP (reg) of a 64-column block.  The block's four chunks hold the weight rows 64*blk + 4*i' + c' (i' = MFMA column
+// index, c' = chunk), so after the four chunks lane (i, kq) owns, for each of its rows 4*kq + reg, the FOUR CONSECUTIVE output columns
+// 64*blk + 4*i .. + 3 (res[c'][reg]): 16-byte stores instead of four 4-byte ones.
 template <int Q, int kEpi>
-__device__ __forceinline__ void wide_epilogue(const f32x4w out, const float (&gp)[4], int c, int64_t t, int i, int kq, int64_t n_rows, int act,
-                                              const float* __restrict__ bias, float* __restrict__ Y, float* __restrict__ s_col_row) {
-    const float b = kEpi == 0 ? bias[16 * c + i] : 0.f;            // (bias: the kernel's LDS copy; zeros when the layer has none)
-    float csum = 0.f;
+__device__ __forceinline__ void wide_epilogue_row(const f32x4w (&res)[4], int reg, const float4 gp, int blk, int64_t t, int i, int kq, int64_t n_rows,
+                                                  int act, const float* __restrict__ bias, float* __restrict__ Y, float4& csum) {
+    const int64_t r = t * 16 + 4 * kq + reg;
+    float v[4] = {res[0][reg], res[1][reg], res[2][reg], res[3][reg]};
+    if constexpr (kEpi == 0) {
+        const float4 b = *(const float4*)(bias + 64 * blk + 4 * i);          // (the kernel's LDS copy; zeros when the layer has no bias)
+        const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int64_t r = t * 16 + 4 * kq + reg;
-        float v = out[reg];
-        if constexpr (kEpi == 0) {
-            v += b;
-            const float e = elu_fast(v);
-            v = act ? e : v;
-        } else {
-            const float sgn = gp[reg];
-            v *= (act && !(sgn > 0.f)) ? sgn + 1.f : 1.f;          // ELU'(pre) from the stored activation
-            if (r < n_rows) csum += v;
+        for (int e = 0; e < 4; e += 2) {
+            pp_f32x2 p = {v[e] + bb[e], v[e + 1] + bb[e + 1]};
+            const pp_f32x2 q = elu_fast2(p);
+            v[e] = act ? q[0] : p[0];
+            v[e + 1] = act ? q[1] : p[1];
         }
-        if (r < n_rows) Y[r * Q + 16 * c + i] = v;
+    } else {
+        const float g[4] = {gp.x, gp.y, gp.z, gp.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= (act && !(g[e] > 0.f)) ? g[e] + 1.f : 1.f;        // ELU'(pre) from the stored activation
+        if (r < n_rows) { csum.x += v[0]; csum.y += v[1]; csum.z += v[2]; csum.w += v[3]; }
     }
-    if constexpr (kEpi == 1) {
-        csum += __shfl_xor(csum, 16, kWave);
-        csum += __shfl_xor(csum, 32, kWave);
-        if (kq == 0) s_col_row[16 * c + i] += csum;           // this wave's own row of the column sums: no atomics needed
-    }
+    if (r < n_rows) *(float4*)(Y + r * Q + 64 * blk + 4 * i) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // kEpi 0: Y = act(tile . Wr^T + bias)            (forward; optional copy of the aggregated tile to agg_out)
@@ -105,27 +104,31 @@ __global__ __launch_bounds__(kWideThreads, 2) void k_wide_layer(const int32_t* _
     //  P < 256:  thread e handles float4 number e, e + 256, ... of the chunk through registers (written to LDS after the MFMAs).
     constexpr bool kDma = P == 256;
     float4 wnext[kDma ? 1 : kChunkVec];
-#define PP_FETCH_CHUNK(C, BUF)                                                                                                     \
+#define PP_FETCH_CHUNK(BLK, CP, BUF)   /* chunk CP of block BLK: LDS row r <- weight row 64*BLK + 4*r + CP */                       \
     if constexpr (kDma) {                                                                                                          \
         _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                                            \
             const int row_ = wave + 4 * v;                                                                                         \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wr + ((size_t)(C) * 16 + row_) * P + 4 * lane), \
-                                             (__attribute__((address_space(3))) void*)(((BUF) == 0 ? s_w0 : s_w1) + row_ * TS), 16, 0, 0);           \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wr + (size_t)(64 * (BLK) + 4 * row_ + (CP)) * P + 4 * lane), \
+                                             (__attribute__((address_space(3))) void*)(((BUF) == 0 ? s_w0 : s_w1) + row_ * TS), 16, 0, 0); \
         }                                                                                                                          \
     } else {                                                                                                                       \
-        _Pragma("unroll") for (int v = 0; v < kChunkVec; ++v)                                                                      \
-            wnext[v] = *(const float4*)(Wr + (size_t)(C) * 16 * P + (size_t)(threadIdx.x + v * kWideThreads) * 4);                 \
+        _Pragma("unroll") for (int v = 0; v < kChunkVec; ++v) {                                                                    \
+            const int e_ = threadIdx.x + v * kWideThreads;                                                                         \
+            const int r_ = e_ / (P / 4), q4_ = e_ - r_ * (P / 4);                                                                  \
+            wnext[v] = *(const float4*)(Wr + (size_t)(64 * (BLK) + 4 * r_ + (CP)) * P + 4 * q4_);                                  \
+        }                                                                                                                          \
     }
 #define PP_STORE_CHUNK(BUF)                                                                                                        \
     if constexpr (!kDma) {                                                                                                         \
         _Pragma("unroll") for (int v = 0; v < kChunkVec; ++v) {                                                                    \
             const int e_ = threadIdx.x + v * kWideThreads;                                                                         \
             const int r_ = e_ / (P / 4), q4_ = e_ - r_ * (P / 4);                                                                  \
-            *(float4*)(((BUF) == 0 ? s_w0 : s_w1) + r_ * TS + 4 * q4_) = wnext[v];                                                                   \
+            *(float4*)(((BUF) == 0 ? s_w0 : s_w1) + r_ * TS + 4 * q4_) = wnext[v];                                                 \
         }                                                                                                                          \
     }
-    static_assert(NC % 2 == 0, "the double buffer returns to slot 0 after every tile group");
-    PP_FETCH_CHUNK(0, 0)
+    static_assert(NC % 4 == 0, "output columns come in blocks of 64 = four 16-column chunks");
+    constexpr int NB = NC / 4;
+    PP_FETCH_CHUNK(0, 0, 0)
     PP_STORE_CHUNK(0)
     if constexpr (kEpi == 1) {
         for (int e = lane; e < Q; e += kWave) s_col[wave][e] = 0.f;
@@ -240,70 +243,106 @@ __global__ __launch_bounds__(kWideThreads, 2) void k_wide_layer(const int32_t* _
             }
         }
         // ------------------------------------------------------------------ phase 2: stream the weight chunks, 16 output columns at a time
-        // Software pipeline over the chunks: [wait own DMA + older stores] barrier | DMA of chunk c+1 | epilogue (stores) of chunk c-1 |
-        // LDS reads + 64 MFMAs of chunk c.  Stores and DMA of one iteration are covered by the MFMAs of the same iteration.
-        // Two accumulator sets, one per LDS buffer: while chunk c accumulates into one, the other still holds chunk c-1 for its (deferred)
-        // epilogue — its registers are not rewritten for a whole chunk, so no MFMA ever waits for a pending store to read them.
-        f32x4w acc[2][2];
-        float gp[2][4];
+        // Software pipeline over the chunks: [wait own DMA + older stores] barrier | DMA of the next chunk | one row group of the PREVIOUS
+        // block's epilogue (a 16-byte store per lane) | LDS reads + 64 MFMAs of this chunk.  Stores and DMA of one iteration are covered
+        // by the MFMAs of the same iteration; the results of a block wait in `res` (two sets: the block being accumulated and the one
+        // whose epilogue is being drained), so no MFMA ever waits for a pending store to read its registers.
+        f32x4w res[2][4];
+        float4 gpv[2][4];
+        float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int sset = 0; sset < 2; ++sset) {
-            acc[sset][0] = f32x4w{0.f, 0.f, 0.f, 0.f};
-            acc[sset][1] = f32x4w{0.f, 0.f, 0.f, 0.f};
+        for (int sset = 0; sset < 2; ++sset)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) gp[sset][reg] = 1.f;
-        }
+            for (int q = 0; q < 4; ++q) {
+                res[sset][q] = f32x4w{0.f, 0.f, 0.f, 0.f};
+                gpv[sset][q] = make_float4(1.f, 1.f, 1.f, 1.f);
+            }
 #pragma unroll 1
-        for (int c2 = 0; c2 < NC; c2 += 2) {
+        for (int blk2 = 0; blk2 < NB; blk2 += 2) {
 #pragma unroll
-            for (int buf = 0; buf < 2; ++buf) {
-                const int c = c2 + buf;
-                __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): this wave's DMA rows of chunk c have landed (and its older stores are out)
-                __syncthreads();                                  // chunk c is complete in buffer `buf`; the other buffer is free again
-                PP_FETCH_CHUNK(c + 1 < NC ? c + 1 : 0, buf ^ 1)   // (the chunk after the last one is chunk 0 of the next tile group)
-                if (c > 0 && have_tile)
-                    wide_epilogue<Q, kEpi>(acc[buf ^ 1][0] + acc[buf ^ 1][1], gp[buf ^ 1], c - 1, t, i, kq, n_rows, act, s_bias, Y, s_col[kEpi == 1 ? wave : 0]);
-                if constexpr (kEpi == 1) {
+            for (int sset = 0; sset < 2; ++sset) {
+                const int blk = blk2 + sset;
+                if (blk < NB) {
+                    if constexpr (kEpi == 1) {
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int64_t r = t * 16 + 4 * kq + reg;
-                        gp[buf][reg] = (act && have_tile && r < n_rows) ? act_in[r * Q + 16 * c + i] : 1.f;
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int64_t r = t * 16 + 4 * kq + reg;
+                            gpv[sset][reg] = (act && have_tile && r < n_rows) ? *(const float4*)(act_in + r * Q + 64 * blk + 4 * i)
+                                                                              : make_float4(1.f, 1.f, 1.f, 1.f);
+                        }
+                    }
+#pragma unroll
+                    for (int cp = 0; cp < 4; ++cp) {
+                        const int buf = cp & 1;
+                        __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): this wave's DMA rows of the chunk have landed (and its older stores are out)
+                        __syncthreads();                              // the chunk is complete in buffer `buf`; the other buffer is free again
+                        {
+                            const int nblk = cp < 3 ? blk : (blk + 1 < NB ? blk + 1 : 0);      // (after the last chunk: chunk 0 of the next tile group)
+                            PP_FETCH_CHUNK(nblk, (cp + 1) & 3, buf ^ 1)
+                        }
+                        if (blk > 0 && have_tile) {                   // drain one row group of the previous block
+                            wide_epilogue_row<Q, kEpi>(res[sset ^ 1], cp, gpv[sset ^ 1][cp], blk - 1, t, i, kq, n_rows, act, s_bias, Y, csum);
+                            if (kEpi == 1 && cp == 3) {
+                                float cs[4] = {csum.x, csum.y, csum.z, csum.w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    cs[e] += __shfl_xor(cs[e], 16, kWave);
+                                    cs[e] += __shfl_xor(cs[e], 32, kWave);
+                                    if (kq == 0) s_col[kEpi == 1 ? wave : 0][(kEpi == 1 ? 64 * (blk - 1) + 4 * i + e : 0)] += cs[e];
+                                }
+                                csum = make_float4(0.f, 0.f, 0.f, 0.f);
+                            }
+                        }
+                        // two accumulators per chunk, alternating: a 16x16x4 fp32 MFMA issues every 32 cycles but its result is ready after 40 —
+                        // a single dependent chain would idle the matrix pipe a fifth of the time
+                        f32x4w acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                        const float* wp = (buf == 0 ? s_w0 : s_w1) + i * TS + kq * KQ;
+                        // register double buffer for the B operands: the LDS reads of the next 4 k-quads are issued BEFORE the 16 MFMAs of the
+                        // current ones (the scheduling barriers pin that order; left alone the compiler reads two quads, waits out the LDS
+                        // latency with an idle matrix pipe, and repeats)
+                        constexpr int kQuads = KQ / 4, kStep = kQuads < 4 ? kQuads : 4;
+                        float4 bc[kStep], bn[kStep];
+#pragma unroll
+                        for (int u = 0; u < kStep; ++u) bc[u] = *(const float4*)(wp + 4 * u);
+#pragma unroll
+                        for (int cc = 0; cc < kQuads; cc += kStep) {
+                            if (cc + kStep < kQuads) {
+#pragma unroll
+                                for (int u = 0; u < kStep; ++u) bn[u] = *(const float4*)(wp + 4 * (cc + kStep + u));
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < kStep; ++u) {
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].x, bc[u].x, acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].y, bc[u].y, acc1, 0, 0, 0);
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].z, bc[u].z, acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].w, bc[u].w, acc1, 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < kStep; ++u) bc[u] = bn[u];
+                        }
+                        PP_STORE_CHUNK(buf ^ 1)
+                        res[sset][cp] = acc0 + acc1;
                     }
                 }
-                // two accumulators per chunk, alternating: a 16x16x4 fp32 MFMA issues every 32 cycles but its result is ready after 40 — a
-                // single dependent chain would idle the matrix pipe a fifth of the time
-                acc[buf][0] = f32x4w{0.f, 0.f, 0.f, 0.f};
-                acc[buf][1] = f32x4w{0.f, 0.f, 0.f, 0.f};
-                const float* wp = (buf == 0 ? s_w0 : s_w1) + i * TS + kq * KQ;
-                // register double buffer for the B operands: the LDS reads of the next 4 k-quads are issued BEFORE the 16 MFMAs of the
-                // current ones (the scheduling barriers pin that order; left alone the compiler reads two quads, waits out the LDS latency
-                // with an idle matrix pipe, and repeats)
-                constexpr int kQuads = KQ / 4, kStep = kQuads < 4 ? kQuads : 4;
-                float4 bc[kStep], bn[kStep];
-#pragma unroll
-                for (int u = 0; u < kStep; ++u) bc[u] = *(const float4*)(wp + 4 * u);
-#pragma unroll
-                for (int cc = 0; cc < kQuads; cc += kStep) {
-                    if (cc + kStep < kQuads) {
-#pragma unroll
-                        for (int u = 0; u < kStep; ++u) bn[u] = *(const float4*)(wp + 4 * (cc + kStep + u));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < kStep; ++u) {
-                        acc[buf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].x, bc[u].x, acc[buf][0], 0, 0, 0);
-                        acc[buf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].y, bc[u].y, acc[buf][1], 0, 0, 0);
-                        acc[buf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].z, bc[u].z, acc[buf][0], 0, 0, 0);
-                        acc[buf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc + u].w, bc[u].w, acc[buf][1], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < kStep; ++u) bc[u] = bn[u];
-                }
-                PP_STORE_CHUNK(buf ^ 1)
             }
         }
-        if (have_tile) wide_epilogue<Q, kEpi>(acc[1][0] + acc[1][1], gp[1], NC - 1, t, i, kq, n_rows, act, s_bias, Y, s_col[kEpi == 1 ? wave : 0]);
+        if (have_tile) {                                              // the last block's epilogue
+            constexpr int kLast = (NB - 1) & 1;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                wide_epilogue_row<Q, kEpi>(res[kLast], reg, gpv[kLast][reg], NB - 1, t, i, kq, n_rows, act, s_bias, Y, csum);
+            if constexpr (kEpi == 1) {
+                float cs[4] = {csum.x, csum.y, csum.z, csum.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cs[e] += __shfl_xor(cs[e], 16, kWave);
+                    cs[e] += __shfl_xor(cs[e], 32, kWave);
+                    if (kq == 0) s_col[wave][64 * (NB - 1) + 4 * i + e] += cs[e];
+                }
+            }
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                            // (the DMA of the chunk nobody will use must not outlive the workgroup's LDS)
 #undef PP_FETCH_CHUNK
