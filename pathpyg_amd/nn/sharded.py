@@ -112,6 +112,12 @@ class HipOps:
 
     # ---- dense layers of the head (first-order rows only) and the loss
     @staticmethod
+    def act_boundary(y, act_bias):
+        """Identity on an activation whose producer expects the gradient w.r.t. its PRE-activation (see dbgnn._ActBoundary)."""
+        from .dbgnn import _ActBoundary
+        return _ActBoundary.apply(y, act_bias)
+
+    @staticmethod
     def dense(x, linear, fuse_act: bool = False, act_bias=None):
         from .dbgnn import dense
         return dense(x, linear, fuse_act, act_bias)
@@ -170,6 +176,20 @@ def halo_reduce(shard: GraphShard, comm, ops, d_halo: torch.Tensor):
     return ops.spmm(shard.back_ptr, shard.back_idx, None, shard.n_own, recv)
 
 
+def dropout_mask(rows: torch.Tensor, width: int, p: float, seed: int, tag: int) -> torch.Tensor:
+    """Dropout factors ``[len(rows), width]`` in {0, 1/(1-p)} as a pure function of (seed, tag, GLOBAL row id, column): every rank —
+    whatever the world size — derives the same mask for the same row, so the halo copy of a row is dropped exactly like the owner's
+    row and a run is reproducible across partitionings.  Integer hash (two multiply-xorshift rounds on 32 bits) in int64 arithmetic."""
+    m32 = 0xFFFFFFFF
+    idx = rows.to(torch.int64).unsqueeze(1) * width + torch.arange(width, device=rows.device, dtype=torch.int64)
+    key = (seed * 0x9E3779B1 + tag * 0x85EBCA6B + 0x27D4EB2F) & m32
+    x = ((idx & m32) * 2654435761 + (idx >> 32) * 40503 + key) & m32
+    x = (((x >> 16) ^ x) * 0x45D9F3B) & m32
+    x = (((x >> 16) ^ x) * 0x45D9F3B) & m32
+    x = (x >> 16) ^ x
+    return (x >= int(p * 4294967296.0)).to(torch.float32) * (1.0 / (1.0 - p))
+
+
 class _ShardedGcnStack(torch.autograd.Function):
     """A stack of GCN layers ``h_{l+1} = ELU(A_hat h_l W_l^T + b_l)`` on this rank's destination rows.
 
@@ -178,11 +198,18 @@ class _ShardedGcnStack(torch.autograd.Function):
     w.r.t. the last layer's PRE-activation and computes that layer's bias gradient itself."""
 
     @staticmethod
-    def forward(ctx, shard: GraphShard, comm, ops, x_full: torch.Tensor, *params):
+    def forward(ctx, shard: GraphShard, comm, ops, drop, x_full: torch.Tensor, *params):
+        """``drop``: None, or ``(p, seed, tag)`` — training-mode dropout on the INPUT of every layer (reference dbgnn.py:131-140), with the
+        reproducible masks of :func:`dropout_mask`: the owner drops its rows before they are exchanged, the first layer's replicated input
+        rows are dropped locally (same mask on every rank)."""
         n_layers = len(params) // 2
         plan, n_own = shard.plan, shard.n_own
-        inputs, saved = [], []
+        inputs, saved, masks = [], [], []
         h = x_full
+        if drop is not None:
+            p_drop, seed, tag = drop
+            h = x_full * dropout_mask(shard.local_rows(), x_full.size(1), p_drop, seed, tag)
+            own_rows = torch.arange(shard.lo, shard.hi, device=x_full.device)
         for layer in range(n_layers):
             weight, bias = params[2 * layer], params[2 * layer + 1]
             last = layer == n_layers - 1
@@ -190,10 +217,15 @@ class _ShardedGcnStack(torch.autograd.Function):
             inputs.append(h)
             saved.append(ops.layer_forward(plan, h, weight, bias, layer == 0, buf[:n_own]))
             if not last:
+                if drop is not None:                     # the next layer's input dropout, applied by the owner before the exchange
+                    mask = dropout_mask(own_rows, weight.size(0), p_drop, seed, tag + layer + 1)
+                    masks.append(mask)
+                    buf[:n_own].mul_(mask)
                 halo_fill(shard, comm, buf)
             h = buf
         ctx.shard, ctx.comm, ctx.ops, ctx.n_layers = shard, comm, ops, n_layers
-        ctx.inputs, ctx.saved = inputs, saved
+        ctx.inputs, ctx.saved, ctx.masks = inputs, saved, masks
+        ctx.keep = None if drop is None else 1.0 - drop[0]
         ctx.save_for_backward(*params)
         return h
 
@@ -210,16 +242,22 @@ class _ShardedGcnStack(torch.autograd.Function):
             if layer == 0:
                 grads[0] = ops.layer_backward(plan, d, x_in, weight, ctx.saved[0], False, None)[2]
                 break
-            fuse_below = x_in if comm.world == 1 else None
+            fuse_below = x_in if (comm.world == 1 and ctx.keep is None) else None
             d_lin, colsum, grads[2 * layer] = ops.layer_backward(plan, d, x_in, weight, ctx.saved[layer], True, fuse_below)
-            if comm.world == 1:
+            if fuse_below is not None:
                 d = d_lin
             else:
                 extra = halo_reduce(shard, comm, ops, d_lin[n_own:])
-                d, colsum = ops.act_combine(d_lin[:n_own], extra, x_in[:n_own])
+                if ctx.keep is None:
+                    d, colsum = ops.act_combine(d_lin[:n_own], extra, x_in[:n_own])
+                else:
+                    # x_in holds the DROPPED activation y * mask / keep: the gradient passes the mask, and ELU' is taken at y = x_in * keep
+                    # (where the mask is 0 the gradient is 0 whatever ELU' says)
+                    d_own = d_lin[:n_own] if extra is None else d_lin[:n_own] + extra
+                    d, colsum = ops.act_combine(d_own * ctx.masks[layer - 1], None, x_in[:n_own] * ctx.keep)
             grads[2 * layer - 1] = colsum                      # bias gradient of the layer below
-        ctx.inputs = ctx.saved = None
-        return (None, None, None, None, *grads)
+        ctx.inputs = ctx.saved = ctx.masks = None
+        return (None, None, None, None, None, *grads)
 
 
 class _ShardedBipartite(torch.autograd.Function):
@@ -229,8 +267,10 @@ class _ShardedBipartite(torch.autograd.Function):
     layer's bias gradient in one kernel."""
 
     @staticmethod
-    def forward(ctx, plan, comm, ops, cap: int, n_own_fo: int, y_h: torch.Tensor, act_bias):
+    def forward(ctx, plan, comm, ops, cap: int, n_own_fo: int, y_h: torch.Tensor, act_bias, fuse_act: bool = True):
+        """``fuse_act=False``: ``y_h`` is not a raw ELU activation (dropout sits in between): plain transposed aggregation backward."""
         ctx.plan, ctx.comm, ctx.ops, ctx.cap, ctx.n_own_fo = plan, comm, ops, cap, n_own_fo
+        ctx.fuse_act = fuse_act
         ctx.has_bias = act_bias is not None
         ctx.save_for_backward(y_h)
         partial = ops.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, y_h, heavy=plan.fwd_heavy)       # [world * cap, H]
@@ -244,9 +284,11 @@ class _ShardedBipartite(torch.autograd.Function):
         if ctx.cap != ctx.n_own_fo:
             d_own = F.pad(d_own, (0, 0, 0, ctx.cap - ctx.n_own_fo))
         d_full = comm.all_gather_rows(d_own)                                                                     # [world * cap, H]
+        if not ctx.fuse_act:
+            return None, None, None, None, None, ops.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d_full, heavy=plan.bwd_heavy), None, None
         want = ctx.has_bias and ctx.needs_input_grad[6]
         dpre, colsum = ops.spmm_act_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d_full, y_h, want)
-        return None, None, None, None, None, dpre, colsum
+        return None, None, None, None, None, dpre, colsum, None
 
 
 class DbgnnShard:
@@ -283,18 +325,32 @@ class ShardedDBGNN(torch.nn.Module):
 
     def forward(self, shard: DbgnnShard) -> torch.Tensor:
         m, ops, comm = self.model, self.ops, self.comm
-        if m.p_dropout > 0 and m.training:
-            raise NotImplementedError("ShardedDBGNN: dropout is not supported on the partitioned path (use p_dropout=0 or eval())")
+        dropping = m.p_dropout > 0 and m.training
+        seed = 0
+        if dropping:            # one seed per forward pass, the same on every rank (the masks are functions of the global row id)
+            pick = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).to(shard.x.device)
+            seed = int(comm.all_reduce_(pick, torch.distributed.ReduceOp.MAX).item()) if comm.world > 1 else int(pick.item())
 
-        def stack(layers, graph_shard, x_full):
+        def stack(layers, graph_shard, x_full, tag):
             params = []
             for layer in layers:
                 params += [layer.lin.weight, layer.bias]
-            return _ShardedGcnStack.apply(graph_shard, comm, ops, x_full, *params), layers[-1].bias
+            drop = (m.p_dropout, seed, tag) if dropping else None
+            return _ShardedGcnStack.apply(graph_shard, comm, ops, drop, x_full, *params), layers[-1].bias
 
-        x, bias_fo = stack(m.first_order_layers, shard.fo, shard.x)
-        x_h, bias_ho = stack(m.higher_order_layers, shard.ho, shard.x_h)
+        x, bias_fo = stack(m.first_order_layers, shard.fo, shard.x, 0)
+        x_h, bias_ho = stack(m.higher_order_layers, shard.ho, shard.x_h, 64)
         bl = m.bipartite_layer
+        if dropping:            # dropout after both stacks and after the bipartite ELU (reference dbgnn.py:136,142,148): element-wise, masks as above
+            dev, p = shard.x.device, m.p_dropout
+            fo_rows = torch.arange(shard.fo.lo, shard.fo.hi, device=dev)
+            ho_rows = torch.arange(shard.ho.lo, shard.ho.hi, device=dev)
+            x = ops.act_boundary(x, bias_fo) * dropout_mask(fo_rows, x.size(1), p, seed, 32)
+            x_h = ops.act_boundary(x_h, bias_ho) * dropout_mask(ho_rows, x_h.size(1), p, seed, 96)
+            agg = _ShardedBipartite.apply(shard.bip, comm, ops, shard.cap, shard.fo.n_own, x_h, None, False)
+            per_edge = ops.dense(x, bl.lin2) + bl.lin1.bias
+            x = F.elu(torch.addcmul(ops.dense_nobias(agg, bl.lin1.weight), shard.indeg.unsqueeze(1), per_edge))
+            return ops.dense(x * dropout_mask(fo_rows, x.size(1), p, seed, 128), m.lin)
         # sum_j (W1 y_h[j] + b1) = W1 (sum_j y_h[j]) + deg * b1 (linearity, as in DBGNN.forward): only [N, H] partials cross xGMI
         agg = _ShardedBipartite.apply(shard.bip, comm, ops, shard.cap, shard.fo.n_own, x_h, bias_ho)
         per_edge = ops.dense(x, bl.lin2, True, bias_fo) + bl.lin1.bias

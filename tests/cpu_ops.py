@@ -179,6 +179,10 @@ class CpuOps:
 
     # ---- head
     @staticmethod
+    def act_boundary(y, act_bias):
+        return _ActGrad.apply(y, act_bias)
+
+    @staticmethod
     def dense(x, linear, fuse_act=False, act_bias=None):
         if fuse_act:
             x = _ActGrad.apply(x, act_bias)

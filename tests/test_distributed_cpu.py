@@ -235,6 +235,88 @@ def test_stream_to_sharded_dbgnn_matches_single_process_oracle(world):
     _spawn(_stream_worker, world)
 
 
+def _dropout_worker(rank, world, port, results):
+    """Training-mode dropout on the partitioned path: the masks are functions of (seed, tag, GLOBAL row, column), so every world size must
+    reproduce the single-process evaluation of the reference forward (dbgnn.py:131-150) with those masks — logits, loss, every gradient."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch.nn.functional as F
+        import pathpyg_amd as pp
+        from pathpyg_amd import distributed as pd
+        from pathpyg_amd.nn.sharded import dropout_mask
+        from oracle import dbgnn as od
+        from oracle import model as om
+        from tests.cpu_ops import CpuOps
+        rng = np.random.default_rng(31)
+        m, n, delta, span, f, p = 1800, 35, 10, 600, 8, 0.4
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        t = torch.from_numpy(np.sort(rng.integers(0, span, m)))
+        layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2)
+        n_ho = layers[2]["num_nodes"]
+        gen = torch.Generator().manual_seed(4)
+        x, x_h = torch.randn(n, f, generator=gen), torch.randn(n_ho, f, generator=gen)
+        y = torch.randint(0, 3, (n,), generator=gen)
+        for dims in ([12, 10, 6], [12, 9, 10, 6]):
+            params = od.init_params(3, (f, f), dims, seed=5)
+            params = {k: (v + 0.05 if k.endswith(".bias") else v) for k, v in params.items()}
+            # ---- reference: the whole graph in one process, masks by global row id
+            torch.manual_seed(77)
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).item())
+            data = om.dbgnn_inputs(layers, 2, "last", x=x, x_h=x_h)
+            leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+            n_gcn = len(dims) - 1
+
+            def run_stack(h, prefix, eidx, ew, tag):
+                rows = torch.arange(h.size(0))
+                for i in range(n_gcn):
+                    h = h * dropout_mask(rows, h.size(1), p, seed, tag + i)
+                    h = F.elu(od.gcn_conv(h, eidx, ew, leaves[f"{prefix}.{i}.lin.weight"], leaves[f"{prefix}.{i}.bias"]))
+                return h
+            hx = run_stack(x, "first_order_layers", data["edge_index"], data["edge_weights"], 0)
+            hh = run_stack(x_h, "higher_order_layers", data["edge_index_higher_order"], data["edge_weights_higher_order"], 64)
+            hx = hx * dropout_mask(torch.arange(n), hx.size(1), p, seed, 32)
+            hh = hh * dropout_mask(torch.arange(n_ho), hh.size(1), p, seed, 96)
+            z = F.elu(od.bipartite_op(hh, hx, data["bipartite_edge_index"], n, leaves["bipartite_layer.lin1.weight"], leaves["bipartite_layer.lin1.bias"],
+                                      leaves["bipartite_layer.lin2.weight"], leaves["bipartite_layer.lin2.bias"]))
+            want_out = (z * dropout_mask(torch.arange(n), z.size(1), p, seed, 128)) @ leaves["lin.weight"].t() + leaves["lin.bias"]
+            want_loss = F.cross_entropy(want_out, y)
+            want_loss.backward()
+            # ---- partitioned
+            tg = type("G", (), {})()
+            tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n)
+            comm = pd.Comm()
+            shard = pd.build_dbgnn_shard(tg, delta, x, x_h, y, comm, CpuOps())
+            net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=dims, p_dropout=p)
+            net.load_state_dict(params)
+            net.train()
+            sharded = pd.ShardedDBGNN(net, comm, ops=CpuOps())
+            torch.manual_seed(77)
+            _check_against_oracle_train(sharded, shard, net, want_out.detach(), want_loss.detach(), {k: v.grad for k, v in leaves.items()})
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_against_oracle_train(sharded, shard, net, want_out, want_loss, want_grads):
+    import pathpyg_amd.distributed as pd
+    loss = sharded.loss(shard)
+    loss.backward()
+    pd.all_reduce_gradients(net, average=False)
+    total = loss.detach().clone()
+    dist.all_reduce(total)
+    torch.testing.assert_close(total, want_loss, rtol=1e-5, atol=1e-6)
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        torch.testing.assert_close(p.grad, want_grads[name], rtol=1e-3, atol=1e-5, msg=lambda m: f"{name}: {m}")
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_partitioned_dropout_is_reproducible_across_world_sizes(world):
+    _spawn(_dropout_worker, world)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # Distributed aggregation: range-partitioned keys, one exchange per layer (gloo; the local coalesce is the oracle's).
 def _oracle_coalesce(edge_index, weight, num_nodes, reduce="sum", remap=None, want_inverse=False, col_block=None):

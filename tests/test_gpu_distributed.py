@@ -174,3 +174,60 @@ def test_bench_partition_default_and_rccl_world1_and_gloo_world2():
     # the driver's command shape without a launcher: `python bench.py --gpus N` starts its own ranks
     self_launched = _bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"])
     assert self_launched["n_gpus"] == 2 and self_launched["config"]["E2"] == one["config"]["E2"] and self_launched["scaling"] == "strong"
+
+
+def _masked_reference(case, p, seed):
+    """Single-process torch-CPU evaluation of the reference forward with the partition path's reproducible dropout masks."""
+    import torch.nn.functional as F
+    from oracle import dbgnn as od
+    from oracle import model as om
+    from pathpyg_amd.nn.sharded import dropout_mask
+    ei, t, w, x, x_h, y, params, want, layers = _case(*case)
+    data = om.dbgnn_inputs(layers, 2, "last", x=x, x_h=x_h)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    n, n_ho, n_gcn = data["num_nodes"], data["num_ho_nodes"], len(case[6]) - 1
+
+    def run_stack(h, prefix, eidx, ew, tag):
+        rows = torch.arange(h.size(0))
+        for i in range(n_gcn):
+            h = F.elu(od.gcn_conv(h * dropout_mask(rows, h.size(1), p, seed, tag + i), eidx, ew, leaves[f"{prefix}.{i}.lin.weight"], leaves[f"{prefix}.{i}.bias"]))
+        return h
+    hx = run_stack(x, "first_order_layers", data["edge_index"], data["edge_weights"], 0) * 1.0
+    hh = run_stack(x_h, "higher_order_layers", data["edge_index_higher_order"], data["edge_weights_higher_order"], 64)
+    hx = hx * dropout_mask(torch.arange(n), hx.size(1), p, seed, 32)
+    hh = hh * dropout_mask(torch.arange(n_ho), hh.size(1), p, seed, 96)
+    z = F.elu(od.bipartite_op(hh, hx, data["bipartite_edge_index"], n, leaves["bipartite_layer.lin1.weight"], leaves["bipartite_layer.lin1.bias"],
+                              leaves["bipartite_layer.lin2.weight"], leaves["bipartite_layer.lin2.bias"]))
+    out = (z * dropout_mask(torch.arange(n), z.size(1), p, seed, 128)) @ leaves["lin.weight"].t() + leaves["lin.bias"]
+    loss = F.cross_entropy(out, y)
+    loss.backward()
+    return loss.detach(), {k: v.grad for k, v in leaves.items()}
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2]], ids=["F16", "F64", "F128"])
+def test_partition_path_dropout_matches_masked_reference(case):
+    """Training-mode dropout on the partitioned path with the HIP kernels (world size 1): loss and every gradient against the reference forward
+    evaluated on the CPU with the same (seed, tag, global row, column) masks."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import pathpyg_amd as pp
+    from pathpyg_amd import distributed as pd
+    dev, p = torch.device("cuda:0"), 0.4
+    ei, t, w, x, x_h, y, params, want, layers = _case(*case)
+    attrs = {} if w is None else {"edge_weight": w.to(dev)}
+    tg = pp.TemporalGraph(pp.Data(edge_index=ei.to(dev), time=t.to(dev), num_nodes=case[2], **attrs))
+    comm = pd.Comm()
+    shard = pd.build_dbgnn_shard(tg, case[3], x.to(dev), x_h.to(dev), y.to(dev), comm)
+    net = pp.nn.DBGNN(num_classes=3, num_features=(case[5], case[5]), hidden_dims=case[6], p_dropout=p).to(dev)
+    net.load_state_dict(params)
+    net.train()
+    torch.manual_seed(5)
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).item())
+    torch.manual_seed(5)
+    loss = pd.ShardedDBGNN(net, comm).loss(shard)
+    loss.backward()
+    want_loss, want_grads = _masked_reference(case, p, seed)
+    torch.testing.assert_close(loss.detach().cpu(), want_loss, rtol=RTOL, atol=ATOL)
+    for name, prm in net.named_parameters():
+        scale = float(want_grads[name].abs().max()) + 1e-12
+        torch.testing.assert_close(prm.grad.cpu(), want_grads[name], rtol=1e-4, atol=max(ATOL, 2e-5 * scale), msg=lambda s: f"{name}: {s}")
