@@ -398,15 +398,16 @@ def main() -> int:
 
     def step_partition(timed: bool):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        opt.zero_grad(set_to_none=True)
         e0.record()
         shard = ppd.build_dbgnn_shard(g, args.delta, x, x_h, y, comm)
         e1.record()
-        for gs in (shard.fo, shard.ho):
-            register_plan(gs.plan)
-        register_plan(shard.bip)
-        SRC_ROWS[shard.bip.fwd_idx.data_ptr()] = shard.ho.n_own
-        SRC_ROWS[shard.bip.bwd_idx.data_ptr()] = shard.bip.n_dst
-        opt.zero_grad(set_to_none=True)
+        if timed:                                   # (bookkeeping of the live rooflines: pointers -> CSR sizes)
+            for gs in (shard.fo, shard.ho):
+                register_plan(gs.plan)
+            register_plan(shard.bip)
+            SRC_ROWS[shard.bip.fwd_idx.data_ptr()] = shard.ho.n_own
+            SRC_ROWS[shard.bip.bwd_idx.data_ptr()] = shard.bip.n_dst
         loss = sharded.loss(shard)
         loss.backward()
         ppd.all_reduce_gradients(net, average=False)

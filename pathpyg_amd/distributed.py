@@ -452,9 +452,12 @@ def build_dbgnn_shard(g, delta, x: torch.Tensor, x_h, y: torch.Tensor | None, co
         x_h = x_h(n_ho)
     x_loc = x if world == 1 else x.index_select(0, fo_shard.local_rows())
     xh_loc = x_h if world == 1 else x_h.index_select(0, ho.local_rows())
-    totals = torch.tensor([e2_local, int(ho_ei.size(1))], dtype=torch.float64, device=dev)
-    comm.all_reduce_(totals)
-    e2, a2 = (int(v) for v in totals.tolist())
+    if world == 1:
+        e2, a2 = e2_local, int(ho_ei.size(1))
+    else:
+        totals = torch.tensor([e2_local, int(ho_ei.size(1))], dtype=torch.float64, device=dev)
+        comm.all_reduce_(totals)
+        e2, a2 = (int(v) for v in totals.tolist())
     return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(),
                       y=None if y is None else y[fo_cuts[rank]: fo_cuts[rank + 1]], n_fo=n, n_ho=n_ho,
                       sizes={"m": m, "N": n, "E2": e2, "E2_local": e2_local, "U2": n_ho, "A1": n_ho, "A2": a2, "A2_local": int(ho_ei.size(1)),

@@ -259,7 +259,22 @@ def cross_entropy(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
             and target.dim() == 1 and target.dtype == torch.int64):
         # the kernel has no ignore_index / out-of-range handling: check the class indices first (one tiny reduction + 16-byte read);
         # anything else (soft labels, ignore_index = -100, empty batches) keeps torch's semantics through torch
-        lo, hi = _hip.minmax(target)
+        # validated once per (storage, slice, in-place version) — the record lives on the base tensor, so the per-step views of one label
+        # vector do not cost a read-back each
+        holder = target._base if target._base is not None else target
+        key = (target.storage_offset(), target.numel(), target._version)
+        seen = getattr(holder, "_pp_class_range", None)
+        if not isinstance(seen, dict):
+            seen = {}
+            try:
+                holder._pp_class_range = seen
+            except Exception:
+                pass
+        if key not in seen:
+            if len(seen) > 64:
+                seen.clear()
+            seen[key] = tuple(_hip.minmax(target))
+        lo, hi = seen[key]
         if lo >= 0 and hi < logits.size(1):
             return _CrossEntropy.apply(logits, target)
     return F.cross_entropy(logits, target)
