@@ -180,8 +180,8 @@ def pmc_traffic(kernel_key: str, args) -> float | None:
                 table = json.load(fh)
             short = kernel_key.split(" ")[0].split("<")[0]
             big = kernel_key.endswith("1.00e+07 rows")
-            for key in ((short + ("@ho" if big else "@fo")), short):
-                if key in table and (big or "@" in key):
+            for key in ((short + ("@ho" if big else "@fo")), short):          # (kernels launched on one graph only have no @ split)
+                if key in table:
                     return float(table[key]["hbm_bytes_per_dispatch"])
         except (OSError, KeyError, ValueError):
             continue
