@@ -235,6 +235,17 @@ int pp_act_backward_f32(const float* dY, const float* Y, int64_t n_rows, int F, 
 /* out[r,:] = coef[r] * X[r,:] (gradient of the bipartite self term) */
 int pp_scale_rows_f32(const float* X, const float* coef, int64_t n_rows, int F, float* out, pp_stream_t stream);
 
+/* F.dropout(x, p, training=True) of DBGNN.forward (nn/dbgnn.py:132,136,138,142,148) with COUNTER-BASED masks: element (r, c) of a [n_rows, F] matrix
+ * is kept iff hash(seed, tag, global row, c) >= p * 2^32 (two multiply-xorshift rounds on 32 bits), global row = rows[r] if rows != NULL else
+ * row0 + r.  No mask tensor: the backward pass regenerates it, and the ranks of a partitioned run agree on every row.
+ *   pp_dropout_f32               out = x * keep / (1 - p)                                   (out may alias x)
+ *   pp_dropout_act_backward_f32  dpre = dY * keep / (1 - p) * (act ? ELU'(y) : 1), y = Ydrop * (1 - p) where kept;  dbias[F] (optional) = column sums
+ * i.e. the backward of dropout and the ELU backward of the layer underneath in one pass over (dY, Ydrop). */
+int pp_dropout_f32(const float* X, int64_t n_rows, int F, double p, int64_t seed, int64_t tag, int64_t row0, const int64_t* rows, float* out,
+                   pp_stream_t stream);
+int pp_dropout_act_backward_f32(const float* dY, const float* Ydrop, int64_t n_rows, int F, double p, int64_t seed, int64_t tag, int64_t row0,
+                                const int64_t* rows, int act, float* dpre, float* dbias, pp_stream_t stream);
+
 /* Weight gradient of a dense layer of the DBGNN (autograd of lin / lin1 / lin2 / GCNConv.lin, dbgnn.py:64,133,139,149):
  * dW[M,K] = dH[N,M]^T X[N,K] and, when db != NULL, db[M] = column sums of dH.  fp32 on the matrix cores
  * (v_mfma_f32_32x32x2_f32, operands read straight from the row-major inputs), deterministic two-stage reduction. */

@@ -635,6 +635,38 @@ def act_backward(dy: torch.Tensor, y: torch.Tensor | None, act: bool, want_dpre:
     return dpre, dbias
 
 
+def dropout(x: torch.Tensor, p: float, seed: int, tag: int, row0: int = 0, rows: torch.Tensor | None = None, out: torch.Tensor | None = None):
+    """Training-mode dropout with counter-based masks (see pp_dropout_f32): ``x * keep / (1 - p)``; ``out`` may be ``x`` itself."""
+    dev = require_device(x, rows)
+    x = x.contiguous()
+    n, f = x.shape
+    if rows is not None:
+        rows = rows.to(torch.int64).contiguous()
+    with torch.cuda.device(dev):
+        if out is None:
+            out = torch.empty_like(x)
+        check(lib().pp_dropout_f32(_p(x), n, f, float(p), int(seed), int(tag), int(row0), _p(rows), _p(out), _stream()), "pp_dropout_f32")
+    return out
+
+
+def dropout_act_backward(dy: torch.Tensor, y_dropped: torch.Tensor | None, p: float, seed: int, tag: int, row0: int = 0,
+                         rows: torch.Tensor | None = None, act: bool = True, want_dbias: bool = False):
+    """``(dpre, dbias or None)``: backward of :func:`dropout` fused with the ELU backward of the activation underneath (``act``)."""
+    dev = require_device(dy, y_dropped, rows)
+    dy = dy.contiguous()
+    n, f = dy.shape
+    if y_dropped is not None:
+        y_dropped = y_dropped.contiguous()
+    if rows is not None:
+        rows = rows.to(torch.int64).contiguous()
+    with torch.cuda.device(dev):
+        dpre = torch.empty_like(dy)
+        dbias = torch.empty(f, dtype=torch.float32, device=dev) if want_dbias else None
+        check(lib().pp_dropout_act_backward_f32(_p(dy), _p(y_dropped), n, f, float(p), int(seed), int(tag), int(row0), _p(rows), 1 if act else 0,
+                                                _p(dpre), _p(dbias), _stream()), "pp_dropout_act_backward_f32")
+    return dpre, dbias
+
+
 def scale_rows(x: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
     dev = require_device(x, coef)
     x = x.contiguous()

@@ -332,6 +332,65 @@ __global__ __launch_bounds__(kBlock) void k_act_backward(const float* __restrict
         for (int c = threadIdx.x; c < F; c += kBlock) atomicAdd(&dbias[c], s_col[c]);
 }
 
+// ------------------------------------------------------------------ dropout with counter-based masks
+// keep(row, col) is a pure function of (seed, tag, GLOBAL row id, column): two multiply-xorshift rounds on 32 bits (the same arithmetic as
+// pathpyg_amd.nn.sharded.dropout_mask, bit for bit).  No mask tensor exists: the backward pass regenerates it, and every rank of a
+// partitioned run derives the same decision for the same row.
+__device__ __forceinline__ bool dropout_keep(int64_t row, int col, int width, uint32_t key, uint32_t threshold) {
+    const uint64_t idx = (uint64_t)row * (uint64_t)width + (uint64_t)col;
+    uint32_t x = (uint32_t)idx * 2654435761u + (uint32_t)(idx >> 32) * 40503u + key;
+    x = ((x >> 16) ^ x) * 0x45D9F3Bu;
+    x = ((x >> 16) ^ x) * 0x45D9F3Bu;
+    x = (x >> 16) ^ x;
+    return x >= threshold;
+}
+
+// out = x * keep / (1 - p)      (x may alias out)
+__global__ __launch_bounds__(kBlock) void k_dropout(const float* __restrict__ X, int64_t n_rows, int F, uint32_t key, uint32_t threshold, float scale,
+                                                   int64_t row0, const int64_t* __restrict__ rows, float* __restrict__ out) {
+    const int64_t total = n_rows * (int64_t)F;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / F;
+        const int c = (int)(i - r * F);
+        const int64_t gr = rows ? rows[r] : row0 + r;
+        out[i] = dropout_keep(gr, c, F, key, threshold) ? X[i] * scale : 0.f;
+    }
+}
+
+// dpre = dY * keep / (1 - p) * (act ? ELU'(y) : 1) with y = Ydrop * (1 - p) where kept; column sums of dpre (optional)
+template <bool kFixedColumn>
+__global__ __launch_bounds__(kBlock) void k_dropout_act_backward(const float* __restrict__ dY, const float* __restrict__ Ydrop, int64_t n_rows, int F,
+                                                                uint32_t key, uint32_t threshold, float scale, float keep_prob, int64_t row0,
+                                                                const int64_t* __restrict__ rows, int act, float* __restrict__ dpre,
+                                                                float* __restrict__ dbias) {
+    extern __shared__ float s_col[];
+    for (int c = threadIdx.x; c < F; c += kBlock) s_col[c] = 0.f;
+    __syncthreads();
+    const int64_t total = n_rows * (int64_t)F;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t first = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    float mine = 0.f;
+    for (int64_t i = first; i < total; i += stride) {
+        const int64_t r = i / F;
+        const int c = (int)(i - r * F);
+        const int64_t gr = rows ? rows[r] : row0 + r;
+        float g = 0.f;
+        if (dropout_keep(gr, c, F, key, threshold)) {
+            g = dY[i] * scale;
+            if (act) { const float y = Ydrop[i] * keep_prob; g *= (y > 0.f ? 1.f : y + 1.f); }
+        }
+        dpre[i] = g;
+        if (dbias) {
+            if (kFixedColumn) mine += g;
+            else atomicAdd(&s_col[c], g);
+        }
+    }
+    if (dbias && kFixedColumn && first < total) atomicAdd(&s_col[(int)(first % F)], mine);
+    __syncthreads();
+    if (dbias)
+        for (int c = threadIdx.x; c < F; c += kBlock) atomicAdd(&dbias[c], s_col[c]);
+}
+
 __global__ __launch_bounds__(kBlock) void k_scale_rows(const float* __restrict__ X, const float* __restrict__ coef, int64_t n_rows, int F,
                                                       float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -774,6 +833,45 @@ int pp_scale_rows_f32(const float* X, const float* coef, int64_t n_rows, int F, 
     const int64_t total = n_rows * (int64_t)F;
     if (total <= 0) return PP_OK;
     k_scale_rows<<<(unsigned)ceil_div(total, kBlock), kBlock, 0, st>>>(X, coef, n_rows, F, out);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+static inline uint32_t dropout_key(int64_t seed, int64_t tag) {
+    return (uint32_t)(((uint64_t)seed * 0x9E3779B1ull + (uint64_t)tag * 0x85EBCA6Bull + 0x27D4EB2Full) & 0xFFFFFFFFull);
+}
+
+int pp_dropout_f32(const float* X, int64_t n_rows, int F, double p, int64_t seed, int64_t tag, int64_t row0, const int64_t* rows, float* out,
+                   pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0 && F >= 1, PP_ERR_ARG, "pp_dropout_f32: bad shape");
+    PP_REQUIRE(p >= 0.0 && p < 1.0, PP_ERR_ARG, "pp_dropout_f32: p must lie in [0, 1)");
+    const int64_t total = n_rows * (int64_t)F;
+    if (total == 0) return PP_OK;
+    int64_t g = ceil_div(total, kBlock * 8);
+    if (g > kMaxGrid) g = kMaxGrid;
+    k_dropout<<<(unsigned)g, kBlock, 0, st>>>(X, n_rows, F, dropout_key(seed, tag), (uint32_t)(p * 4294967296.0), (float)(1.0 / (1.0 - p)), row0, rows, out);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+int pp_dropout_act_backward_f32(const float* dY, const float* Ydrop, int64_t n_rows, int F, double p, int64_t seed, int64_t tag, int64_t row0,
+                                const int64_t* rows, int act, float* dpre, float* dbias, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0 && F >= 1, PP_ERR_ARG, "pp_dropout_act_backward_f32: bad shape");
+    PP_REQUIRE(p >= 0.0 && p < 1.0, PP_ERR_ARG, "pp_dropout_act_backward_f32: p must lie in [0, 1)");
+    PP_REQUIRE(dpre != nullptr && (!act || Ydrop != nullptr), PP_ERR_ARG, "pp_dropout_act_backward_f32: dpre (and Ydrop with act) required");
+    if (dbias) PP_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), st));
+    const int64_t total = n_rows * (int64_t)F;
+    if (total == 0) return PP_OK;
+    int64_t g = ceil_div(total, kBlock * 8);
+    if (g > kMaxGrid) g = kMaxGrid;
+    const uint32_t key = dropout_key(seed, tag), thr = (uint32_t)(p * 4294967296.0);
+    const float scale = (float)(1.0 / (1.0 - p)), keep = (float)(1.0 - p);
+    if ((g * kBlock) % F == 0)
+        k_dropout_act_backward<true><<<(unsigned)g, kBlock, (size_t)F * sizeof(float), st>>>(dY, Ydrop, n_rows, F, key, thr, scale, keep, row0, rows, act, dpre, dbias);
+    else
+        k_dropout_act_backward<false><<<(unsigned)g, kBlock, (size_t)F * sizeof(float), st>>>(dY, Ydrop, n_rows, F, key, thr, scale, keep, row0, rows, act, dpre, dbias);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

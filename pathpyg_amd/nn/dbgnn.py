@@ -228,9 +228,37 @@ class _Aggregate(torch.autograd.Function):
         return None, _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d.contiguous(), heavy=plan.bwd_heavy)
 
 
-def _dropout(x: torch.Tensor, p: float) -> torch.Tensor:
-    """Training-mode dropout (module-level so that tests can substitute a reproducible mask)."""
-    return F.dropout(x, p=p, training=True)
+class _DropAct(torch.autograd.Function):
+    """Training-mode dropout of a matrix whose rows are the GLOBAL rows ``row0 .. row0 + n`` (or ``rows``), with the counter-based masks of
+    ``pp_dropout_f32`` (no mask tensor; the same decision for the same (seed, tag, row, column) on every rank of a partitioned run).
+    ``act=True``: the input is a stored activation ``ELU(pre)`` whose producer follows the ``grad_is_pre`` contract — the backward pass
+    returns the gradient w.r.t. ``pre`` (dropout backward and ELU backward in ONE pass, ``pp_dropout_act_backward_f32``) and hands the
+    column sums to ``act_bias``."""
+
+    @staticmethod
+    def forward(ctx, y, act_bias, p: float, seed: int, tag: int, row0: int, rows, act: bool):
+        out = _hip.dropout(y, p, seed, tag, row0, rows)
+        ctx.args = (p, seed, tag, row0, rows, act)
+        ctx.has_bias = act_bias is not None
+        ctx.save_for_backward(out if act else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        p, seed, tag, row0, rows, act = ctx.args
+        (dropped,) = ctx.saved_tensors
+        want = act and ctx.has_bias and ctx.needs_input_grad[1]
+        dpre, dbias = _hip.dropout_act_backward(d_out, dropped, p, seed, tag, row0, rows, act, want)
+        return dpre, dbias, None, None, None, None, None, None
+
+
+def _draw_seed() -> int:
+    """One dropout seed per forward pass (from torch's CPU generator, so ``torch.manual_seed`` makes a run reproducible)."""
+    return int(torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).item())
+
+
+# dropout call sites of DBGNN.forward -> mask tags (shared with the partitioned model: both paths drop the same elements for a given seed)
+TAG_FO, TAG_FO_OUT, TAG_HO, TAG_HO_OUT, TAG_HEAD = 0, 32, 64, 96, 128
 
 
 def dense(x, linear: Linear, fuse_act: bool = False, act_bias=None):
@@ -410,21 +438,22 @@ class DBGNN(Module):
 
         if self.p_dropout > 0 and self.training:
             # dropout -> GCNConv -> ELU (reference dbgnn.py:131-146).  The layers stay on the fused kernels (aggregation + MFMA product + bias +
-            # ELU in one launch, one-kernel backward); the dropout itself and the ELU backward it separates from the next layer's
-            # input-gradient epilogue are element-wise passes (_dropout, _ActBoundary).
-            p = self.p_dropout
+            # ELU in one launch, one-kernel backward); each dropout is one pass forward and one pass backward that also carries the ELU
+            # backward of the layer underneath (_DropAct: counter-based masks, no mask tensor).
+            p, seed = self.p_dropout, _draw_seed()
 
-            def stack_drop(layers, h, plan):
-                for layer in layers:
-                    h = _dropout(h, p)
+            def stack_drop(layers, h, plan, tag, out_tag):
+                pending_bias, contract = None, False              # `h` is raw input first, then a fused layer's activation (grad_is_pre contract)
+                for i, layer in enumerate(layers):
+                    h = _DropAct.apply(h, pending_bias, p, seed, tag + i, 0, None, contract)
                     if _GcnLayer.supported(plan, h, layer.lin.weight):
-                        h = _ActBoundary.apply(_GcnLayer.apply(plan, h, layer.lin.weight, layer.bias, False, None), layer.bias)
+                        h, pending_bias, contract = _GcnLayer.apply(plan, h, layer.lin.weight, layer.bias, False, None), layer.bias, True
                     else:
-                        h = _Propagate.apply(plan, dense(h, layer.lin), None, layer.bias, True)
-                return _dropout(h, p)
+                        h, pending_bias, contract = _Propagate.apply(plan, dense(h, layer.lin), None, layer.bias, True), None, False
+                return _DropAct.apply(h, pending_bias, p, seed, out_tag, 0, None, contract)
 
-            x = stack_drop(self.first_order_layers, x, plan_fo)
-            x_h = stack_drop(self.higher_order_layers, x_h, plan_ho)
+            x = stack_drop(self.first_order_layers, x, plan_fo, TAG_FO, TAG_FO_OUT)
+            x_h = stack_drop(self.higher_order_layers, x_h, plan_ho, TAG_HO, TAG_HO_OUT)
             bl = self.bipartite_layer
             if plan_bi.fwd_val is None and x_h.size(1) % 4 == 0 and x_h.size(1) <= 256:
                 # sum_j (W1 x_h[j] + b1) = W1 (sum_j x_h[j]) + deg * b1, as below: the dense layers run on the N first-order rows only
@@ -433,7 +462,7 @@ class DBGNN(Module):
                 x = F.elu(torch.addcmul(_Dense.apply(agg, bl.lin1.weight, None, False, None), plan_bi.self_coef.unsqueeze(1), per_edge))
             else:
                 x = self.bipartite_layer((x_h, x), data.bipartite_edge_index, n_ho=n_ho, n_fo=n_fo, plan=plan_bi, activation=True)
-            return dense(_dropout(x, p), self.lin)
+            return dense(_DropAct.apply(x, None, p, seed, TAG_HEAD, 0, None, False), self.lin)
 
         # No dropout between an activation and the dense layer that consumes it: every ELU backward is fused into the
         # epilogue of that dense layer's input-gradient GEMM (see _Dense / _Propagate.grad_is_pre).

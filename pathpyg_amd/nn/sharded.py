@@ -23,6 +23,8 @@ import torch.nn.functional as F
 
 from .. import _hip
 
+TAG_FO, TAG_FO_OUT, TAG_HO, TAG_HO_OUT, TAG_HEAD = 0, 32, 64, 96, 128          # dropout call sites (same numbering as nn.dbgnn)
+
 
 class HipOps:
     """The device operations of the sharded DBGNN, all HIP (see the module docstring for why this is an object)."""
@@ -111,11 +113,16 @@ class HipOps:
         return _hip.act_backward(_hip.spmm(ptr, idx, val, n_rows, d), z, True, want_dpre=True, want_dbias=want_colsum)   # odd widths: two kernels
 
     # ---- dense layers of the head (first-order rows only) and the loss
+    # ---- dropout (counter-based masks keyed by the global row id: pp_dropout_f32 / pp_dropout_act_backward_f32)
+    dropout = staticmethod(_hip.dropout)
+    dropout_act_backward = staticmethod(_hip.dropout_act_backward)
+
     @staticmethod
-    def act_boundary(y, act_bias):
-        """Identity on an activation whose producer expects the gradient w.r.t. its PRE-activation (see dbgnn._ActBoundary)."""
-        from .dbgnn import _ActBoundary
-        return _ActBoundary.apply(y, act_bias)
+    def drop_act(y, act_bias, p, seed, tag, row0, act: bool):
+        """Autograd dropout of the owned rows ``row0 ..``; ``act``: ``y`` is a stored activation whose producer expects the gradient w.r.t. its
+        pre-activation (see dbgnn._DropAct)."""
+        from .dbgnn import _DropAct
+        return _DropAct.apply(y, act_bias, p, seed, tag, row0, None, act)
 
     @staticmethod
     def dense(x, linear, fuse_act: bool = False, act_bias=None):
@@ -204,12 +211,11 @@ class _ShardedGcnStack(torch.autograd.Function):
         rows are dropped locally (same mask on every rank)."""
         n_layers = len(params) // 2
         plan, n_own = shard.plan, shard.n_own
-        inputs, saved, masks = [], [], []
+        inputs, saved = [], []
         h = x_full
         if drop is not None:
             p_drop, seed, tag = drop
-            h = x_full * dropout_mask(shard.local_rows(), x_full.size(1), p_drop, seed, tag)
-            own_rows = torch.arange(shard.lo, shard.hi, device=x_full.device)
+            h = ops.dropout(x_full, p_drop, seed, tag, 0, shard.local_rows() if shard.n_halo or shard.lo else None)
         for layer in range(n_layers):
             weight, bias = params[2 * layer], params[2 * layer + 1]
             last = layer == n_layers - 1
@@ -217,15 +223,12 @@ class _ShardedGcnStack(torch.autograd.Function):
             inputs.append(h)
             saved.append(ops.layer_forward(plan, h, weight, bias, layer == 0, buf[:n_own]))
             if not last:
-                if drop is not None:                     # the next layer's input dropout, applied by the owner before the exchange
-                    mask = dropout_mask(own_rows, weight.size(0), p_drop, seed, tag + layer + 1)
-                    masks.append(mask)
-                    buf[:n_own].mul_(mask)
+                if drop is not None:                     # the next layer's input dropout, applied (in place) by the owner before the exchange
+                    ops.dropout(buf[:n_own], p_drop, seed, tag + layer + 1, shard.lo, None, buf[:n_own])
                 halo_fill(shard, comm, buf)
             h = buf
         ctx.shard, ctx.comm, ctx.ops, ctx.n_layers = shard, comm, ops, n_layers
-        ctx.inputs, ctx.saved, ctx.masks = inputs, saved, masks
-        ctx.keep = None if drop is None else 1.0 - drop[0]
+        ctx.inputs, ctx.saved, ctx.drop = inputs, saved, drop
         ctx.save_for_backward(*params)
         return h
 
@@ -242,21 +245,22 @@ class _ShardedGcnStack(torch.autograd.Function):
             if layer == 0:
                 grads[0] = ops.layer_backward(plan, d, x_in, weight, ctx.saved[0], False, None)[2]
                 break
-            fuse_below = x_in if (comm.world == 1 and ctx.keep is None) else None
+            fuse_below = x_in if (comm.world == 1 and ctx.drop is None) else None
             d_lin, colsum, grads[2 * layer] = ops.layer_backward(plan, d, x_in, weight, ctx.saved[layer], True, fuse_below)
             if fuse_below is not None:
                 d = d_lin
             else:
                 extra = halo_reduce(shard, comm, ops, d_lin[n_own:])
-                if ctx.keep is None:
+                if ctx.drop is None:
                     d, colsum = ops.act_combine(d_lin[:n_own], extra, x_in[:n_own])
                 else:
-                    # x_in holds the DROPPED activation y * mask / keep: the gradient passes the mask, and ELU' is taken at y = x_in * keep
-                    # (where the mask is 0 the gradient is 0 whatever ELU' says)
+                    # x_in holds the DROPPED activation y * keep / (1 - p): the gradient passes the mask, and ELU' is taken at y = x_in * (1 - p)
+                    # (where the mask is 0 the gradient is 0 whatever ELU' says) — one pass (pp_dropout_act_backward_f32)
                     d_own = d_lin[:n_own] if extra is None else d_lin[:n_own] + extra
-                    d, colsum = ops.act_combine(d_own * ctx.masks[layer - 1], None, x_in[:n_own] * ctx.keep)
+                    p_drop, seed, tag = ctx.drop
+                    d, colsum = ops.dropout_act_backward(d_own, x_in[:n_own], p_drop, seed, tag + layer, shard.lo, None, True, True)
             grads[2 * layer - 1] = colsum                      # bias gradient of the layer below
-        ctx.inputs = ctx.saved = ctx.masks = None
+        ctx.inputs = ctx.saved = None
         return (None, None, None, None, None, *grads)
 
 
@@ -338,19 +342,17 @@ class ShardedDBGNN(torch.nn.Module):
             drop = (m.p_dropout, seed, tag) if dropping else None
             return _ShardedGcnStack.apply(graph_shard, comm, ops, drop, x_full, *params), layers[-1].bias
 
-        x, bias_fo = stack(m.first_order_layers, shard.fo, shard.x, 0)
-        x_h, bias_ho = stack(m.higher_order_layers, shard.ho, shard.x_h, 64)
+        x, bias_fo = stack(m.first_order_layers, shard.fo, shard.x, TAG_FO)
+        x_h, bias_ho = stack(m.higher_order_layers, shard.ho, shard.x_h, TAG_HO)
         bl = m.bipartite_layer
-        if dropping:            # dropout after both stacks and after the bipartite ELU (reference dbgnn.py:136,142,148): element-wise, masks as above
-            dev, p = shard.x.device, m.p_dropout
-            fo_rows = torch.arange(shard.fo.lo, shard.fo.hi, device=dev)
-            ho_rows = torch.arange(shard.ho.lo, shard.ho.hi, device=dev)
-            x = ops.act_boundary(x, bias_fo) * dropout_mask(fo_rows, x.size(1), p, seed, 32)
-            x_h = ops.act_boundary(x_h, bias_ho) * dropout_mask(ho_rows, x_h.size(1), p, seed, 96)
+        if dropping:            # dropout after both stacks and after the bipartite ELU (reference dbgnn.py:136,142,148), masks as above
+            p = m.p_dropout
+            x = ops.drop_act(x, bias_fo, p, seed, TAG_FO_OUT, shard.fo.lo, True)
+            x_h = ops.drop_act(x_h, bias_ho, p, seed, TAG_HO_OUT, shard.ho.lo, True)
             agg = _ShardedBipartite.apply(shard.bip, comm, ops, shard.cap, shard.fo.n_own, x_h, None, False)
             per_edge = ops.dense(x, bl.lin2) + bl.lin1.bias
             x = F.elu(torch.addcmul(ops.dense_nobias(agg, bl.lin1.weight), shard.indeg.unsqueeze(1), per_edge))
-            return ops.dense(x * dropout_mask(fo_rows, x.size(1), p, seed, 128), m.lin)
+            return ops.dense(ops.drop_act(x, None, p, seed, TAG_HEAD, shard.fo.lo, False), m.lin)
         # sum_j (W1 y_h[j] + b1) = W1 (sum_j y_h[j]) + deg * b1 (linearity, as in DBGNN.forward): only [N, H] partials cross xGMI
         agg = _ShardedBipartite.apply(shard.bip, comm, ops, shard.cap, shard.fo.n_own, x_h, bias_ho)
         per_edge = ops.dense(x, bl.lin2, True, bias_fo) + bl.lin1.bias

@@ -177,10 +177,34 @@ class CpuOps:
         d = (d_lin_own if extra is None else d_lin_own + extra) * _elu_grad(y_below)
         return d, d.sum(0)
 
-    # ---- head
+    # ---- dropout (the torch evaluation of the same counter-based masks)
     @staticmethod
-    def act_boundary(y, act_bias):
-        return _ActGrad.apply(y, act_bias)
+    def _mask(n, f, p, seed, tag, row0, rows):
+        from pathpyg_amd.nn.sharded import dropout_mask
+        return dropout_mask(torch.arange(row0, row0 + n) if rows is None else rows, f, p, seed, tag)
+
+    @staticmethod
+    def dropout(x, p, seed, tag, row0=0, rows=None, out=None):
+        y = x * CpuOps._mask(x.size(0), x.size(1), p, seed, tag, row0, rows)
+        if out is None:
+            return y
+        out.copy_(y)
+        return out
+
+    @staticmethod
+    def dropout_act_backward(dy, y_dropped, p, seed, tag, row0=0, rows=None, act=True, want_dbias=False):
+        g = dy * CpuOps._mask(dy.size(0), dy.size(1), p, seed, tag, row0, rows)
+        if act:
+            g = g * _elu_grad(y_dropped * (1.0 - p))
+        return g, (g.sum(0) if want_dbias else None)
+
+    @staticmethod
+    def drop_act(y, act_bias, p, seed, tag, row0, act):
+        if act:
+            y = _ActGrad.apply(y, act_bias)
+        return y * CpuOps._mask(y.size(0), y.size(1), p, seed, tag, row0, None)
+
+    # ---- head
 
     @staticmethod
     def dense(x, linear, fuse_act=False, act_bias=None):

@@ -513,46 +513,44 @@ def test_fuzz_dbgnn_on_models_built_from_streams_and_paths(pp):
 
 
 @pytest.mark.parametrize("f,hidden", [((16, 16), [32, 16, 8]), ((64, 64), [64, 64, 64]), ((128, 64), [128, 128, 64]), ((5, 7), [6, 10, 3])])
-def test_dbgnn_training_with_dropout_matches_masked_reference(pp, monkeypatch, f, hidden):
-    """p_dropout > 0 in training mode (reference dbgnn.py:131-150; its own test uses 0.4): the layers stay on the fused kernels, dropout and
-    the ELU backward behind it are element-wise passes.  With the random masks replaced by a reproducible sequence on both sides, logits, loss
-    and every gradient must match a torch-CPU evaluation of the reference forward with the same masks."""
+def test_dbgnn_training_with_dropout_matches_masked_reference(pp, f, hidden):
+    """p_dropout > 0 in training mode (reference dbgnn.py:131-150; its own test uses 0.4): the layers stay on the fused kernels; dropout and
+    the dropout + ELU backward are one element-wise kernel each (pp_dropout_f32 / pp_dropout_act_backward_f32) whose keep decision is a pure
+    function of (seed, call site, row, column).  Logits, loss and every gradient must match a torch-CPU evaluation of the reference forward
+    with the same masks (pathpyg_amd.nn.sharded.dropout_mask is the torch statement of the hash)."""
     from oracle import dbgnn as od
     import pathpyg_amd.nn.dbgnn as mod
+    from pathpyg_amd.nn.sharded import dropout_mask
     p = 0.4
     data, y = _bundle(11, 300, 4000, 1200, 5000, f, "last")
     params = od.init_params(3, f, hidden, seed=2)
-
-    def make_masker():
-        g = torch.Generator().manual_seed(123)
-        return lambda shape: (torch.rand(shape, generator=g) >= p).float() / (1 - p)
-
-    gpu_mask = make_masker()
-    monkeypatch.setattr(mod, "_dropout", lambda x, p_: x * gpu_mask(tuple(x.shape)).to(x.device))
     model = _to_module(pp, params, 3, f, hidden)
     model.p_dropout = p
     model.train()
+    torch.manual_seed(77)
+    seed = mod._draw_seed()
+    torch.manual_seed(77)                      # the model's forward draws the same seed
     gdata = pp.Data(**{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in data.items()})
     out = model(gdata)
     loss = F.cross_entropy(out, y.to(DEV))
     loss.backward()
 
-    ref_mask = make_masker()
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    drop = lambda t: t * ref_mask(tuple(t.shape))
+    site = {"fo": mod.TAG_FO, "ho": mod.TAG_HO}
+    drop = lambda t, tag: t * dropout_mask(torch.arange(t.size(0)), t.size(1), p, seed, tag)
     x, x_h = data["x"], data["x_h"]
     n_gcn = len(hidden) - 1
     for i in range(n_gcn):
-        x = F.elu(od.gcn_conv(drop(x), data["edge_index"], data["edge_weights"], leaves[f"first_order_layers.{i}.lin.weight"],
+        x = F.elu(od.gcn_conv(drop(x, site["fo"] + i), data["edge_index"], data["edge_weights"], leaves[f"first_order_layers.{i}.lin.weight"],
                               leaves[f"first_order_layers.{i}.bias"]))
-    x = drop(x)
+    x = drop(x, mod.TAG_FO_OUT)
     for i in range(n_gcn):
-        x_h = F.elu(od.gcn_conv(drop(x_h), data["edge_index_higher_order"], data["edge_weights_higher_order"],
+        x_h = F.elu(od.gcn_conv(drop(x_h, site["ho"] + i), data["edge_index_higher_order"], data["edge_weights_higher_order"],
                                 leaves[f"higher_order_layers.{i}.lin.weight"], leaves[f"higher_order_layers.{i}.bias"]))
-    x_h = drop(x_h)
+    x_h = drop(x_h, mod.TAG_HO_OUT)
     x = F.elu(od.bipartite_op(x_h, x, data["bipartite_edge_index"], data["num_nodes"], leaves["bipartite_layer.lin1.weight"],
                               leaves["bipartite_layer.lin1.bias"], leaves["bipartite_layer.lin2.weight"], leaves["bipartite_layer.lin2.bias"]))
-    want_out = drop(x) @ leaves["lin.weight"].t() + leaves["lin.bias"]
+    want_out = drop(x, mod.TAG_HEAD) @ leaves["lin.weight"].t() + leaves["lin.bias"]
     want_loss = F.cross_entropy(want_out, y)
     want_loss.backward()
     scale = float(want_out.detach().abs().max()) + 1e-12

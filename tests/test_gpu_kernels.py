@@ -356,3 +356,37 @@ def test_temporal_lift_rejects_unsorted_time(hip):
     t[250] = 0                                                     # a descent in the middle of the stream
     with pytest.raises(ValueError, match="not sorted by time"):
         hip.temporal_lift(ei, t, 20, 5)
+
+
+@pytest.mark.parametrize("n,f", [(1, 1), (37, 5), (1000, 16), (4097, 64), (300, 250)])
+def test_dropout_kernels_match_the_integer_hash(hip, n, f):
+    """pp_dropout_f32 / pp_dropout_act_backward_f32 against the torch statement of the same counter-based mask (nn.sharded.dropout_mask):
+    bit-identical keep decisions for consecutive rows (row0), explicit global row ids (rows), in place, and the fused ELU backward +
+    column sums."""
+    from pathpyg_amd.nn.sharded import dropout_mask
+    g = torch.Generator().manual_seed(n * 131 + f)
+    x = torch.randn(n, f, generator=g)
+    p, seed, tag = 0.4, 123456789, 65
+    row0 = 2 ** 33 + 11                                               # the row * width product crosses 32 bits
+    want = x * dropout_mask(torch.arange(row0, row0 + n), f, p, seed, tag)
+    got = hip.dropout(x.to(DEV), p, seed, tag, row0)
+    assert torch.equal(got.cpu(), want)
+    rows = torch.randint(0, 2 ** 40, (n,), generator=g)
+    want_rows = x * dropout_mask(rows, f, p, seed, tag)
+    buf = x.to(DEV)
+    assert hip.dropout(buf, p, seed, tag, 0, rows.to(DEV), buf) is buf
+    assert torch.equal(buf.cpu(), want_rows)
+    assert 0.5 < float((want != 0).float().mean()) < 0.7 or n * f < 500   # about 1 - p of the elements survive
+    # backward: dy * mask * ELU'(y) with y recovered from the dropped activation
+    y = torch.nn.functional.elu(torch.randn(n, f, generator=g))
+    mask = dropout_mask(torch.arange(row0, row0 + n), f, p, seed, tag)
+    dy = torch.randn(n, f, generator=g)
+    for act in (True, False):
+        want_g = dy * mask * (torch.where(y > 0, torch.ones_like(y), y + 1) if act else 1.0)
+        got_g, got_b = hip.dropout_act_backward(dy.to(DEV), (y * mask).to(DEV) if act else None, p, seed, tag, row0, None, act, True)
+        torch.testing.assert_close(got_g.cpu(), want_g, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(got_b.cpu(), want_g.sum(0), rtol=1e-4, atol=1e-4 * max(1.0, n ** 0.5))
+    # p = 0 keeps everything; bad p is refused
+    assert torch.equal(hip.dropout(x.to(DEV), 0.0, seed, tag).cpu(), x)
+    with pytest.raises(Exception):
+        hip.dropout(x.to(DEV), 1.0, seed, tag)
