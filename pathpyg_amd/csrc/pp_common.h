@@ -129,6 +129,22 @@ __device__ __forceinline__ T block_exclusive_sum(T v, T* scratch, T* total) {
     return wave_base + inc - v;
 }
 
+// Streaming accesses (data touched once per kernel): the `nt` cache policy keeps them from evicting the small tables the same kernel
+// reads at random (row pointers, degree^-1/2) out of the 4 MB L2 of its XCD.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ T load_stream(const T* p) { return __builtin_nontemporal_load(p); }
+template <typename T>
+__device__ __forceinline__ void store_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ uint4 load_stream_u4(const uint32_t* p) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_stream_u4(uint32_t* p, uint4 v) {
+    u32x4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
+}
+
 // Rows of a CSR with very many entries (hubs of a scale-free graph) are not walked by the lane group that owns the row: a pre-pass
 // (pp_spmm_heavy_f32) sums them chunk-wise with whole workgroups; the row kernels read the finished sum instead.
 struct HeavyRows {

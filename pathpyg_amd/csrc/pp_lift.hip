@@ -82,19 +82,41 @@ struct Window<int64_t, 2> {
     __device__ static bool admits(int64_t tj, Thr thr) { return (double)tj <= thr; }
 };
 
+// marks[w] = first event id whose time the window of event 64*w (the first lane of wave w of k_temporal_count) no longer admits, over the
+// whole stream; marks[n_waves] = m.  The stream is time-sorted, so the window end of every event of wave w lies in
+// [marks[w], marks[w + 1]]: the count kernel bisects ~6 levels inside one or two cache lines shared by the wave instead of 23 levels
+// over the stream.  One thread per wave: m/64 full bisections, 47 us at m = 10^7 (neighbouring threads share the lines of the upper
+// levels; a 17-ary search with 16 lanes per mark — 6 round trips instead of 23 — took 94 us: every round touches 16 scattered lines per
+// mark, and scattered lines per load instruction, not round trips, are what these searches pay for).
+template <typename TimeT, int kMode>
+__global__ __launch_bounds__(kBlock) void k_window_marks(const TimeT* __restrict__ time, int64_t m, int64_t n_waves, int64_t delta_i, double delta_f,
+                                                        uint32_t* __restrict__ marks) {
+    using W = Window<TimeT, kMode>;
+    const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (w > n_waves) return;
+    if (w == n_waves) { marks[w] = (uint32_t)m; return; }
+    const typename W::Thr thr = W::threshold(time[w * kWave], delta_i, delta_f);
+    int64_t lo = w * kWave, hi = m;
+    while (lo < hi) {
+        int64_t mid = lo + ((hi - lo) >> 1);
+        if (W::admits(time[mid], thr)) lo = mid + 1; else hi = mid;
+    }
+    marks[w] = (uint32_t)lo;
+}
+
 template <typename TimeT, int kMode>
 __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __restrict__ head, const TimeT* __restrict__ time, int64_t m,
                                                           int64_t n_own, int64_t num_nodes, int64_t delta_i, double delta_f,
                                                           const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids_by_tail,
-                                                          uint32_t* __restrict__ first_pos, int32_t* __restrict__ count,
-                                                          uint32_t* __restrict__ head4, int64_t* __restrict__ status) {
+                                                          const uint32_t* __restrict__ marks, uint32_t* __restrict__ first_pos,
+                                                          int32_t* __restrict__ count, uint32_t* __restrict__ head4, int64_t* __restrict__ status) {
     using W = Window<TimeT, kMode>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < m;
     const bool source = live && i < n_own;         // (halo events of an edge-range shard are candidates, never sources)
     const int64_t ic = live ? i : m - 1;           // lanes past the end mirror the last event: the wave-wide searches need all 64 lanes
     const TimeT ti = time[ic];
-    const TimeT t_next = ic + 1 < m ? time[ic + 1] : ti;
+    const TimeT t_next = ic + 1 < m ? time[ic + 1] : ti;      // (cached loads: the bisections below revisit these lines)
     // every search below relies on a time-sorted stream (the reference's mask-based loop does not, temporal.py:37-43): say so instead of
     // returning a wrong event graph
     if (live && t_next < ti) atomicOr((unsigned long long*)status, (unsigned long long)kUnsortedTime);
@@ -103,9 +125,14 @@ __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __rest
         return;
     }
     // the head node's list bounds do not depend on the window: fetch them first so that this (random) miss overlaps the searches below
-    const int64_t v = source ? head[i] : 0;
+    const int64_t v = source ? load_stream(head + i) : 0;
     const bool ok = v >= 0 && v < num_nodes;
-    const uint32_t s0 = (source && ok) ? rowptr[v] : 0u, s1 = (source && ok) ? rowptr[v + 1] : 0u;
+    // (one 8-byte load at a 4-byte aligned address: what a load instruction costs here is the number of distinct lines its 64 lanes
+    //  touch, and rowptr[v], rowptr[v + 1] as two instructions touch the same 64 random lines twice)
+    struct __attribute__((packed, aligned(4))) Bounds { uint32_t begin, end; };
+    Bounds bounds = {0u, 0u};
+    if (source && ok) bounds = *reinterpret_cast<const Bounds*>(rowptr + v);
+    const uint32_t s0 = bounds.begin, s1 = bounds.end;
     // g_lo: first id with t > t_i.  Without timestamp ties this is i+1: probe, then gallop, then bisect.
     int64_t g_lo = ic + 1;
     if (g_lo < m && !(t_next > ti)) {
@@ -114,14 +141,21 @@ __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __rest
         int64_t hi = ic + step < m ? ic + step : m;
         g_lo = upper_bound_dev<TimeT, int64_t>(time, ic + (step >> 1) + 1, hi, ti);
     }
-    // g_hi: first id >= g_lo whose time is no longer admitted by the (promoted-dtype) threshold.  Plain per-lane bisection: the 64
-    // lanes of a wave walk almost the same path, so all but the last few levels are one broadcast cache line per wave.  (A
-    // wave-cooperative 64-ary search — 4 steps instead of 23 — was measured SLOWER, 0.97 -> 1.19 ms per count call: its first two
-    // steps touch 64 scattered lines per wave where the bisection touches one.)
+    // g_hi: first id >= g_lo whose time is no longer admitted by the (promoted-dtype) threshold.  k_window_marks bracketed it for the
+    // whole wave: the bisection runs over [marks[wave], marks[wave + 1]] — about as many events as the wave itself holds on a stream of
+    // even density, ~6 levels inside one or two cache lines that all 64 lanes share, instead of 23 dependent levels over the stream
+    // (0.635 -> 0.466 ms per launch).  Measured and rejected on top of this: a wave-cooperative 64-ary search over the
+    // whole stream (1.19 instead of 0.97 ms per count call: its first two steps touch 64 scattered lines per wave); staging the
+    // bracketed times in LDS and bisecting there with all loads issued as unconditional batches (0.53 ms: 98 VGPRs, 5 waves/SIMD);
+    // `nt` loads of the id lists (0.82 ms: the six 16-byte pieces of a line are six memory reads once the line is not kept).
     const typename W::Thr thr = W::threshold(ti, delta_i, delta_f);
     int64_t g_hi;
     {
-        int64_t lo = g_lo < m ? g_lo : m, hi = m;
+        const int64_t wv = i >> 6;                 // == the wave's index over the stream (kBlock is a multiple of the wave size)
+        int64_t lo = marks[wv], hi = marks[wv + 1];
+        if (lo < g_lo) lo = g_lo;
+        if (lo > m) lo = m;
+        if (hi > m) hi = m;
         while (lo < hi) {
             int64_t mid = lo + ((hi - lo) >> 1);
             if (W::admits(time[mid], thr)) lo = mid + 1; else hi = mid;
@@ -193,14 +227,16 @@ __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __rest
         }
         if (c == 0) pos = 0;
     }
-    first_pos[i] = pos;
-    count[i] = c;
-    *reinterpret_cast<uint4*>(head4 + i * 4) = h;
+    store_stream(first_pos + i, pos);
+    store_stream(count + i, c);
+    store_stream_u4(head4 + i * 4, h);
 }
 
 // ------------------------------------------------------------------ line-graph count
+// (the out-degree of the head node is read as rowptr[v + 1] - rowptr[v] with ONE load: a separate degree array is a second random
+//  line per edge — 0.38 -> 0.17 ms per launch at 1.9e7 edges)
 __global__ __launch_bounds__(kBlock) void k_linegraph_count(const int64_t* __restrict__ head, int64_t n_edges, int64_t num_nodes,
-                                                           const int32_t* __restrict__ outdeg, const uint32_t* __restrict__ rowptr,
+                                                           const uint32_t* __restrict__ rowptr,
                                                            uint32_t* __restrict__ first_pos, int32_t* __restrict__ count,
                                                            int64_t e_begin, int64_t e_end, int64_t* __restrict__ status) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -211,8 +247,10 @@ __global__ __launch_bounds__(kBlock) void k_linegraph_count(const int64_t* __res
     if (v < 0 || v >= num_nodes) {
         atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex);
     } else if (e >= e_begin && e < e_end) {          // edge-range shard: only the own edges are sources
-        pos = rowptr[v];
-        c = outdeg[v];
+        struct __attribute__((packed, aligned(4))) Bounds { uint32_t begin, end; };
+        const Bounds bounds = *reinterpret_cast<const Bounds*>(rowptr + v);       // one 8-byte load at a 4-byte aligned address
+        pos = bounds.begin;
+        c = (int32_t)(bounds.end - bounds.begin);
     }
     first_pos[e] = pos;
     count[e] = c;
@@ -531,6 +569,7 @@ struct LiftWs {
     uint32_t* keys;         // temporal: tail keys [n_src];  line graph: outdeg (as int32) [num_nodes]
     uint32_t* sorted_keys;  // temporal only [n_src]
     uint32_t* head4;        // temporal only [n_src * 4]: the first 4 continuations of every event
+    uint32_t* marks;        // temporal only [n_src / 64 + 2]: window end of the first event of every wave (k_window_marks)
     int64_t* tile_src;      // first source of every 512-slot output tile (k_tile_sources) [tile_cap + 1]
     int64_t tile_cap;
     void* scratch;          // sort / scan workspace
@@ -550,6 +589,7 @@ static LiftWs carve_lift(void* ws, int64_t n_src, int64_t num_nodes, bool tempor
     w.keys = a.take<uint32_t>(temporal ? n_src : num_nodes);
     w.sorted_keys = temporal ? a.take<uint32_t>(n_src) : nullptr;
     w.head4 = temporal ? a.take<uint32_t>(n_src * 4) : nullptr;
+    w.marks = temporal ? a.take<uint32_t>(n_src / kWave + 2) : nullptr;
     w.tile_cap = n_src / 16 > 65536 ? n_src / 16 : 65536;       // covers results up to 32x the number of sources
     w.tile_src = a.take<int64_t>(w.tile_cap + 1);
     size_t sb = scan_ws_bytes(n_src > num_nodes ? n_src : num_nodes);
@@ -578,6 +618,18 @@ static int launch_expand(const LiftWs& w, int64_t n_src, int64_t total, int64_t 
     return PP_OK;
 }
 
+template <typename TimeT, int kMode>
+static int launch_temporal_count_mode(unsigned grid, hipStream_t st, const int64_t* head, const TimeT* time, int64_t m, int64_t n_own, int64_t n,
+                                      int64_t di, double df, const LiftWs& w) {
+    const int64_t n_waves = ceil_div(m, kWave);
+    k_window_marks<TimeT, kMode><<<(unsigned)ceil_div(n_waves + 1, kBlock), kBlock, 0, st>>>(time, m, n_waves, di, df, w.marks);
+    PP_LAUNCH_CHECK();
+    k_temporal_count<TimeT, kMode><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.marks, w.first_pos, w.count,
+                                                            w.head4, w.result + 1);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
 template <typename TimeT>
 static int launch_temporal_count(int delta_kind, unsigned grid, hipStream_t st, const int64_t* head, const TimeT* time, int64_t m,
                                  int64_t n_own, int64_t n, int64_t di, double df, const LiftWs& w);
@@ -585,21 +637,14 @@ static int launch_temporal_count(int delta_kind, unsigned grid, hipStream_t st, 
 template <>
 int launch_temporal_count<int64_t>(int delta_kind, unsigned grid, hipStream_t st, const int64_t* head, const int64_t* time, int64_t m,
                                    int64_t n_own, int64_t n, int64_t di, double df, const LiftWs& w) {
-    if (delta_kind == PP_DELTA_I64)
-        k_temporal_count<int64_t, 0><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.head4, w.result + 1);
-    else if (delta_kind == PP_DELTA_F32)
-        k_temporal_count<int64_t, 1><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.head4, w.result + 1);
-    else
-        k_temporal_count<int64_t, 2><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.head4, w.result + 1);
-    PP_LAUNCH_CHECK();
-    return PP_OK;
+    if (delta_kind == PP_DELTA_I64) return launch_temporal_count_mode<int64_t, 0>(grid, st, head, time, m, n_own, n, di, df, w);
+    if (delta_kind == PP_DELTA_F32) return launch_temporal_count_mode<int64_t, 1>(grid, st, head, time, m, n_own, n, di, df, w);
+    return launch_temporal_count_mode<int64_t, 2>(grid, st, head, time, m, n_own, n, di, df, w);
 }
 template <>
 int launch_temporal_count<double>(int, unsigned grid, hipStream_t st, const int64_t* head, const double* time, int64_t m, int64_t n_own,
                                   int64_t n, int64_t di, double df, const LiftWs& w) {
-    k_temporal_count<double, 0><<<grid, kBlock, 0, st>>>(head, time, m, n_own, n, di, df, w.rowptr, w.ids, w.first_pos, w.count, w.head4, w.result + 1);
-    PP_LAUNCH_CHECK();
-    return PP_OK;
+    return launch_temporal_count_mode<double, 0>(grid, st, head, time, m, n_own, n, di, df, w);
 }
 
 }  // namespace pp
@@ -672,7 +717,7 @@ int pp_linegraph_count(const int64_t* edge_index, int64_t n_edges, int64_t e_beg
     if (rc != PP_OK) return rc;
     rc = exclusive_scan<int32_t, int32_t>(outdeg, num_nodes, (int32_t*)w.rowptr, true, nullptr, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
-    k_linegraph_count<<<(unsigned)ceil_div(n_edges, kBlock), kBlock, 0, st>>>(edge_index + n_edges, n_edges, num_nodes, outdeg, w.rowptr,
+    k_linegraph_count<<<(unsigned)ceil_div(n_edges, kBlock), kBlock, 0, st>>>(edge_index + n_edges, n_edges, num_nodes, w.rowptr,
                                                                              w.first_pos, w.count, e_begin, e_end, w.result + 1);
     PP_LAUNCH_CHECK();
     return exclusive_scan<int32_t, int64_t>(w.count, n_edges, w.offset, true, w.result, w.scratch, w.scratch_bytes, st);

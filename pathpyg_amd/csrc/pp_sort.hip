@@ -24,6 +24,7 @@ constexpr int kRadix = 1 << kRadixBits;             // 256 digits == kBlock thre
 constexpr int kSortItems = 16;                      // keys per lane
 constexpr int kSortTile = kBlock * kSortItems;      // 4096 keys per workgroup
 constexpr int kWaveSpan = kWave * kSortItems;       // 1024 consecutive keys per wave
+constexpr int kXcds = 8;                            // accelerator dies of an MI355X (workgroup i runs on die i % 8)
 
 static_assert(kRadix == kBlock, "one thread per digit in the table steps");
 
@@ -83,7 +84,13 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KeyT* __restrict__ key
 
     const int lane = lane_id();
     const int wave = wave_id();
-    const int64_t tile_base = (int64_t)blockIdx.x * kSortTile;
+    // Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2.  Tile t and tile t+1 extend the same 256 digit runs,
+    // i.e. they write the two halves of the same cache lines: give every XCD a CONTIGUOUS range of tiles so that those partial-line
+    // writes meet in one L2 instead of reaching the memory side as masked writes from two.
+    const int64_t per_xcd = (ntiles + kXcds - 1) / kXcds;
+    const int64_t tile = (int64_t)(blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+    if (tile >= ntiles) return;
+    const int64_t tile_base = tile * kSortTile;
     const int64_t wave_base = tile_base + (int64_t)wave * kWaveSpan;
 
 #pragma unroll
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KeyT* __restrict__ key
         unsigned start = block_exclusive_sum<unsigned>(run, s_scratch, &total);
         unsigned digit_base = block_exclusive_sum<unsigned>(totals[d], s_scratch, &total);   // keys with a smaller digit, all tiles
         s_dstart[d] = start;
-        s_gofs[d] = digit_base + table[(int64_t)d * ntiles + blockIdx.x] - start;   // modular arithmetic on purpose
+        s_gofs[d] = digit_base + table[(int64_t)d * ntiles + tile] - start;   // modular arithmetic on purpose
     }
     __syncthreads();
 
@@ -209,6 +216,7 @@ int sort_pairs(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uin
 
     const KeyT* src_k = keys_in;
     const uint32_t* src_v = vals_in;
+    const unsigned scatter_grid = (unsigned)(ceil_div(ntiles, kXcds) * kXcds);
     for (int p = 0; p < passes; ++p) {
         const int shift = begin_bit + p * kRadixBits;
         const int nbits = (end_bit - shift) < kRadixBits ? (end_bit - shift) : kRadixBits;
@@ -222,9 +230,9 @@ int sort_pairs(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uin
         k_scan_digit_rows<<<kRadix, kBlock, 0, st>>>(table, ntiles, totals);
         PP_LAUNCH_CHECK();
         if (p == 0 && src_v == nullptr) {
-            k_scatter<KeyT, true><<<(unsigned)ntiles, kBlock, 0, st>>>(src_k, nullptr, dst_k, dst_v, n, shift, mask, table, totals, ntiles);
+            k_scatter<KeyT, true><<<scatter_grid, kBlock, 0, st>>>(src_k, nullptr, dst_k, dst_v, n, shift, mask, table, totals, ntiles);
         } else {
-            k_scatter<KeyT, false><<<(unsigned)ntiles, kBlock, 0, st>>>(src_k, src_v, dst_k, dst_v, n, shift, mask, table, totals, ntiles);
+            k_scatter<KeyT, false><<<scatter_grid, kBlock, 0, st>>>(src_k, src_v, dst_k, dst_v, n, shift, mask, table, totals, ntiles);
         }
         PP_LAUNCH_CHECK();
         src_k = dst_k;
