@@ -377,7 +377,8 @@ def main() -> int:
     comm = ppd.Comm()
     # ---- inputs, resident in HBM before the timed region.  partition: ONE stream replicated on every rank; streams: one per rank
     ei, t = synth_stream(args.events, args.nodes, args.span, seed=1 + (0 if partition else rank), device=dev)
-    pp.TemporalGraph(pp.Data(edge_index=ei[:, :1024].clone(), time=t[:1024].clone(), num_nodes=args.nodes))    # library load / first-launch costs
+    # library load, first-launch costs and the sort workspace (allocator growth) are paid by an untimed pass over the same stream
+    pp.TemporalGraph(pp.Data(edge_index=ei.clone(), time=t.clone(), num_nodes=args.nodes))
     sort0, sort1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     sort0.record()
     g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=args.nodes))       # a1: stable time sort (HIP radix sort) + permutation

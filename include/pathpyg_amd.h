@@ -156,6 +156,13 @@ int pp_argsort_i64(const int64_t* keys, int64_t n, int64_t min_value, int64_t ma
 /* stable replacement of torch.argsort(time) for float64 timestamps, src/pathpyG/core/temporal_graph.py:58 */
 int pp_argsort_f64(const double* keys, int64_t n, int64_t* perm_out, void* ws, size_t ws_bytes, pp_stream_t stream);
 int pp_ptr_from_sorted_i64(const int64_t* sorted, int64_t n, int64_t num_rows, int64_t* ptr, pp_stream_t stream);
+/* TemporalGraph.__init__, src/pathpyG/core/temporal_graph.py:58-63 (argsort of the timestamps, then edge_index / time indexed by it):
+ * out3 = {descents, min, max} of the timestamps in one device buffer (float64: descents only) — one read-back says whether a sort is
+ * needed and how many key bits it takes; pp_gather_events applies the permutation to the three 8-byte columns of every event in one
+ * pass (time_dtype PP_I64 or PP_F64; status bit 1: permutation entry out of range). */
+int pp_time_stats(const void* time, int time_dtype, int64_t n, int64_t* out3, pp_stream_t stream);
+int pp_gather_events(const int64_t* edge_index, const void* time, const int64_t* perm, int64_t m, int64_t* edge_index_out, void* time_out,
+                     int64_t* status, pp_stream_t stream);
 
 /* ------------------------------------------------------------------ DBGNN message passing (pp_dbgnn.hip) */
 

@@ -124,6 +124,18 @@ def is_sorted(a) -> bool:
     return _hip.is_sorted(x)
 
 
+def time_stats(time):
+    dev = compute_device(time)
+    (t,) = _stage(dev, time)
+    return _hip.time_stats(t)
+
+
+def gather_events(edge_index, time, perm):
+    dev = compute_device(edge_index, time, perm)
+    ei, t, p = _stage(dev, edge_index, time, perm)
+    return _back(edge_index, *_hip.gather_events(ei, t, p))
+
+
 def stable_argsort(keys, value_range=None):
     dev = compute_device(keys)
     (k,) = _stage(dev, keys)

@@ -324,6 +324,32 @@ def is_sorted(a: torch.Tensor) -> bool:
         return int(out.item()) == 0
 
 
+def time_stats(time: torch.Tensor) -> tuple[int, int, int]:
+    """``(descents, min, max)`` of a timestamp vector with ONE read-back (float64: min = max = 0)."""
+    time = _ordered_dtype(time)
+    dev = require_device(time)
+    with torch.cuda.device(dev):
+        out = torch.empty(3, dtype=torch.int64, device=dev)
+        check(lib().pp_time_stats(_p(time), _DTYPE_CODE[time.dtype], time.numel(), _p(out), _stream()), "pp_time_stats")
+        descents, lo, hi = out.tolist()
+    return descents, lo, hi
+
+
+def gather_events(edge_index: torch.Tensor, time: torch.Tensor, perm: torch.Tensor):
+    """``(edge_index[:, perm], time[perm])`` in one pass (time int64 or float64)."""
+    ei = _edge_index(edge_index)
+    dev = require_device(ei, time, perm)
+    if time.dtype not in (torch.int64, torch.float64):
+        raise TypeError("gather_events: timestamps must be int64 or float64")
+    time, perm = time.contiguous(), perm.to(torch.int64).contiguous()
+    m = ei.size(1)
+    with torch.cuda.device(dev):
+        out_ei, out_t = torch.empty_like(ei), torch.empty_like(time)
+        status = torch.empty(1, dtype=torch.int64, device=dev)
+        check(lib().pp_gather_events(_p(ei), _p(time), _p(perm), m, _p(out_ei), _p(out_t), _p(status), _stream()), "pp_gather_events")
+    return out_ei, out_t
+
+
 def argsort(keys: torch.Tensor, value_range: tuple[int, int] | None = None) -> torch.Tensor:
     """Stable argsort of an integer or floating-point vector -> int64 permutation."""
     keys = _ordered_dtype(keys)

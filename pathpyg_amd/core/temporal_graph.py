@@ -33,18 +33,30 @@ class TemporalGraph(Graph):
         if "num_nodes" not in data:
             data.num_nodes = (_dispatch.minmax(data.edge_index)[1] + 1) if data.edge_index.numel() else 0
 
-        # time-sort the events and every per-event attribute (temporal_graph.py:58-63), stably
-        if data.time.numel() > 1 and not _dispatch.is_sorted(data.time):
-            per_event = set(data.edge_attrs()) | {"time"}
-            perm = _dispatch.stable_argsort(data.time)
-            for key in per_event:
-                value = data[key]
-                if key == "edge_index":
-                    data.edge_index = value[:, perm.to(value.device)].contiguous()
-                elif isinstance(value, torch.Tensor):
-                    data[key] = value[perm.to(value.device)]
-                elif isinstance(value, np.ndarray):
-                    data[key] = value[perm.cpu().numpy()]
+        # time-sort the events and every per-event attribute (temporal_graph.py:58-63), stably.  One read-back ({descents, min, max})
+        # decides whether to sort at all and sizes the radix keys; edge_index and time are permuted in one pass.
+        if data.time.numel() > 1:
+            ordered = data.time if data.time.dtype in (torch.int64, torch.float64) else None
+            if ordered is None:
+                descents, value_range = (0 if _dispatch.is_sorted(data.time) else 1), None
+            else:
+                descents, lo, hi = _dispatch.time_stats(ordered)
+                value_range = (lo, hi) if ordered.dtype == torch.int64 else None
+            if descents:
+                perm = _dispatch.stable_argsort(data.time, value_range)
+                fused = ordered is not None and data.time.device == data.edge_index.device
+                if fused:
+                    data.edge_index, data.time = _dispatch.gather_events(data.edge_index, data.time, perm)
+                for key in set(data.edge_attrs()) | {"time"}:
+                    value = data[key]
+                    if key in ("edge_index", "time") and fused:
+                        continue
+                    if key == "edge_index":
+                        data.edge_index = value[:, perm.to(value.device)].contiguous()
+                    elif isinstance(value, torch.Tensor):
+                        data[key] = value[perm.to(value.device)]
+                    elif isinstance(value, np.ndarray):
+                        data[key] = value[perm.cpu().numpy()]
 
         self._edge_to_index = None
         self._tedge_to_index = None

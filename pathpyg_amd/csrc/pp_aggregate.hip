@@ -352,6 +352,20 @@ __global__ __launch_bounds__(kBlock) void k_keys_from_i64(const int64_t* __restr
     if (i < n) keys[i] = (KeyT)(uint64_t)(a[i] - bias);
 }
 
+// the time sort of a whole event stream (TemporalGraph.__init__): one pass reads the permutation once and gathers the three 8-byte
+// columns of every event (source, destination, time bits) — instead of one indexing launch per column
+__global__ __launch_bounds__(kBlock) void k_gather_events(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ time_bits,
+                                                         const int64_t* __restrict__ perm, int64_t m, int64_t* __restrict__ edge_index_out,
+                                                         int64_t* __restrict__ time_out, int64_t* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    int64_t p = perm[i];
+    if (p < 0 || p >= m) { atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex); p = 0; }
+    edge_index_out[i] = edge_index[p];
+    edge_index_out[m + i] = edge_index[m + p];
+    time_out[i] = time_bits[p];
+}
+
 __global__ __launch_bounds__(kBlock) void k_widen_u32(const uint32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[i] = (int64_t)in[i];
@@ -486,6 +500,33 @@ int pp_count_descents_f64(const double* a, int64_t n, int64_t* descents, pp_stre
     PP_HIP(hipMemsetAsync(descents, 0, sizeof(int64_t), st));
     if (n < 2) return PP_OK;
     k_count_descents_f64<<<(unsigned)(ceil_div(n, kBlock) < 2048 ? ceil_div(n, kBlock) : 2048), kBlock, 0, st>>>(a, n, descents);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+// {descents, min, max} of a timestamp vector in one device buffer: ONE read-back decides whether TemporalGraph.__init__ has to sort
+// and how many key bits the sort needs (float64: min / max are not used and left 0)
+int pp_time_stats(const void* time, int time_dtype, int64_t n, int64_t* out3, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(time_dtype == PP_I64 || time_dtype == PP_F64, PP_ERR_ARG, "pp_time_stats: time must be int64 or float64");
+    PP_REQUIRE(n >= 0, PP_ERR_ARG, "pp_time_stats: negative length");
+    PP_HIP(hipMemsetAsync(out3, 0, 3 * sizeof(int64_t), st));
+    if (n == 0) return PP_OK;
+    if (time_dtype == PP_F64) return pp_count_descents_f64((const double*)time, n, out3, stream);
+    int rc = pp_count_descents_i64((const int64_t*)time, n, out3, stream);
+    if (rc != PP_OK) return rc;
+    return minmax_i64((const int64_t*)time, n, out3 + 1, st);
+}
+
+// edge_index_out[:, i] = edge_index[:, perm[i]], time_out[i] = time[perm[i]] (8-byte timestamps of either dtype); status bit 1: perm out of range
+int pp_gather_events(const int64_t* edge_index, const void* time, const int64_t* perm, int64_t m, int64_t* edge_index_out, void* time_out,
+                     int64_t* status, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(m >= 0, PP_ERR_ARG, "pp_gather_events: negative length");
+    PP_HIP(hipMemsetAsync(status, 0, sizeof(int64_t), st));
+    if (m == 0) return PP_OK;
+    k_gather_events<<<(unsigned)ceil_div(m, kBlock), kBlock, 0, st>>>(edge_index, (const int64_t*)time, perm, m, edge_index_out, (int64_t*)time_out,
+                                                                     status);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

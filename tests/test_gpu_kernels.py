@@ -390,3 +390,23 @@ def test_dropout_kernels_match_the_integer_hash(hip, n, f):
     assert torch.equal(hip.dropout(x.to(DEV), 0.0, seed, tag).cpu(), x)
     with pytest.raises(Exception):
         hip.dropout(x.to(DEV), 1.0, seed, tag)
+
+
+@pytest.mark.parametrize("dtype", [torch.int64, torch.float64])
+def test_time_stats_and_fused_event_gather(hip, dtype):
+    """pp_time_stats (one read-back: descents, min, max) and pp_gather_events (edge_index and time permuted in one pass) against torch."""
+    g = torch.Generator().manual_seed(3)
+    m = 100_003
+    t = torch.randint(-50, 10_000, (m,), generator=g).to(dtype)
+    ei = torch.randint(0, 5000, (2, m), generator=g)
+    descents, lo, hi = hip.time_stats(t.to(DEV))
+    assert descents == int((t[1:] < t[:-1]).sum())
+    if dtype == torch.int64:
+        assert (lo, hi) == (int(t.min()), int(t.max()))
+    perm = hip.argsort(t.to(DEV), (lo, hi) if dtype == torch.int64 else None)
+    want = torch.sort(t, stable=True)
+    assert torch.equal(perm.cpu(), want.indices)
+    got_ei, got_t = hip.gather_events(ei.to(DEV), t.to(DEV), perm)
+    assert torch.equal(got_t.cpu(), want.values) and torch.equal(got_ei.cpu(), ei[:, want.indices])
+    assert hip.time_stats(want.values.to(DEV))[0] == 0
+    assert hip.time_stats(torch.empty(0, dtype=dtype, device=DEV))[0] == 0
