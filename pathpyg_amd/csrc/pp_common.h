@@ -145,6 +145,27 @@ __device__ __forceinline__ void store_stream_u4(uint32_t* p, uint4 v) {
     __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
 }
 
+// Raw buffer access (buffer_load_* with a 32-bit byte offset): the address arithmetic of a gather is ONE 32-bit VALU add instead of a 64-bit
+// multiply-add, and an offset at or above kBufOob reads as zeros WITHOUT touching memory — absent neighbours, rows past the end and masked
+// lanes need neither a branch around the load nor a select behind it.  (On this chip the VALU and the matrix pipe of a SIMD do not
+// overlap across waves — tools/probes/mfma/overlap.hip — so every VALU instruction of the gather stage is paid in full.)
+// Arrays addressed this way must be smaller than kBufOob bytes.
+constexpr uint32_t kBufOob = 0xFFFFF000u;
+using buf_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ buf_t buf_of(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)kBufOob, 0x00020000); }
+__device__ __forceinline__ float4 buf_load_f4(buf_t r, uint32_t off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);      // (a 16-byte GCC vector: copy it out, do not convert it)
+    static_assert(sizeof(v) == 16, "b128");
+    float4 out;
+    __builtin_memcpy(&out, &v, 16);
+    return out;
+}
+__device__ __forceinline__ uint32_t buf_load_u32(buf_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0); }
+__device__ __forceinline__ float buf_load_f32(buf_t r, uint32_t off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0)); }
+// value of `v` in the lane whose byte address (4 * lane) is `addr4` — constant parts of the address fold into the instruction's offset field
+__device__ __forceinline__ int lane_read_i(int addr4, int v) { return __builtin_amdgcn_ds_bpermute(addr4, v); }
+__device__ __forceinline__ float lane_read_f(int addr4, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr4, __builtin_bit_cast(int, v))); }
+
 // Rows of a CSR with very many entries (hubs of a scale-free graph) are not walked by the lane group that owns the row: a pre-pass
 // (pp_spmm_heavy_f32) sums them chunk-wise with whole workgroups; the row kernels read the finished sum instead.
 struct HeavyRows {
