@@ -469,6 +469,21 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
     for (int ct = 0; ct < CT; ++ct) col_in[ct] = 0.f;
     const int64_t n_tiles = (n_rows + 15) / 16;
     const int64_t step = (int64_t)gridDim.x * kGcnWaves;
+    // gather stage as in k_gcn_forward: buffer loads + ds_bpermute unless D is 4 GiB or larger (kWide)
+    [[maybe_unused]] int pv_next = 0, hv_next = -1;
+    [[maybe_unused]] float scv_next = 0.f;
+    constexpr int kShift = M == 16 ? 6 : (M == 32 ? 7 : (M == 64 ? 8 : 9));     // log2(row bytes)
+    const buf_t rs_x = buf_of(D), rs_ptr = buf_of(ptr), rs_self = buf_of(self_coef), rs_slot = buf_of(heavy.slot);
+    const uint32_t l16 = 16u * l;
+    const int a_rr = (lane >> 2) * 4, a_row = g * kRows * 4, a_pair = g * kRows * 16;      // ds_bpermute addresses: lane = row / row / 4*row + slot
+    auto fetch_pointers = [&](int64_t tile) {
+        const int64_t rl = tile * 16 + lane;
+        const bool live = tile < n_tiles;
+        pv_next = (int)buf_load_u32(rs_ptr, (live && lane <= 16) ? (uint32_t)(rl < n_rows ? rl : n_rows) * 4u : kBufOob);
+        scv_next = self_coef != nullptr ? buf_load_f32(rs_self, (live && lane < 16 && rl < n_self) ? (uint32_t)rl * 4u : kBufOob) : 0.f;
+        if constexpr (kHeavy) hv_next = (live && lane < 16 && rl < n_rows) ? (int)buf_load_u32(rs_slot, (uint32_t)rl * 4u) : -1;
+    };
+    if constexpr (!kWide) fetch_pointers((int64_t)blockIdx.x * kGcnWaves + wave);
     for (int64_t t = (int64_t)blockIdx.x * kGcnWaves + wave; t < n_tiles; t += step) {
         // natural-layout rows of the layer input: B operand of the dW stream and source of the ELU' epilogue (in flight during the gather)
         // lane (i, kq) owns rows 4*kq .. 4*kq+3 of the tile and the CT consecutive columns CT*i ..: one vector load per row
@@ -485,89 +500,169 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
                 for (int ct = 0; ct < CT; ++ct) xr[ct][reg] = r < n_rows ? xp[ct] : 0.f;
             }
         }
-        const int64_t r0 = t * 16 + g * kRows;
-        int p[kRows + 1];
+        if constexpr (kWide) {
+            const int64_t r0 = t * 16 + g * kRows;
+            int p[kRows + 1];
 #pragma unroll
-        for (int q = 0; q <= kRows; ++q) {
-            const int64_t r = r0 + q < n_rows ? r0 + q : n_rows;
-            p[q] = ptr[r];
-        }
-        int cj[kRows], pe[kRows], hs[kRows];
-        float cv[kRows], sc[kRows];
-#pragma unroll
-        for (int q = 0; q < kRows; ++q) {
-            hs[q] = (kHeavy && r0 + q < n_rows) ? heavy.slot[r0 + q] : -1;
-            pe[q] = (kHeavy && hs[q] >= 0) ? p[q] : p[q + 1];                   // a hub row: its neighbour sum is already in heavy.sum
-            const int mine = p[q] + l;
-            const bool in = mine < pe[q];
-            cj[q] = in ? idx[mine] : 0;
-            cv[q] = in ? (val ? val[mine] : 1.f) : 0.f;
-            sc[q] = (self_coef != nullptr && r0 + q < n_self) ? self_coef[r0 + q] : 0.f;
-        }
-#pragma unroll
-        for (int b0 = 0; b0 < kRows; b0 += kBatch) {
-            off_t off[kBatch][kFirst], self_off[kBatch];
-#pragma unroll
-            for (int qq = 0; qq < kBatch; ++qq) {
-                const int q = b0 + qq;
-                const bool self_here = self_coef != nullptr && r0 + q < n_self;
-                const int first = __shfl(cj[q], 0, kLanes);
-                const int dummy = p[q] < pe[q] ? first : (self_here ? (int)(r0 + q) : 0);
-                self_off[qq] = (off_t)(uint32_t)(self_here ? (int)(r0 + q) : dummy) * (off_t)(M * 4) + (off_t)(16 * l);
-#pragma unroll
-                for (int u = 0; u < kFirst; ++u) {
-                    const int j = u == 0 ? first : __shfl(cj[q], u, kLanes);
-                    off[qq][u] = (off_t)(uint32_t)(p[q] + u < pe[q] ? j : dummy) * (off_t)(M * 4) + (off_t)(16 * l);
-                }
+            for (int q = 0; q <= kRows; ++q) {
+                const int64_t r = r0 + q < n_rows ? r0 + q : n_rows;
+                p[q] = ptr[r];
             }
-            float4 x[kBatch][kFirst], sr[kBatch];
+            int cj[kRows], pe[kRows], hs[kRows];
+            float cv[kRows], sc[kRows];
 #pragma unroll
-            for (int qq = 0; qq < kBatch; ++qq) {
-                sr[qq] = *(const float4*)(db + self_off[qq]);
-#pragma unroll
-                for (int u = 0; u < kFirst; ++u) x[qq][u] = *(const float4*)(db + off[qq][u]);
+            for (int q = 0; q < kRows; ++q) {
+                hs[q] = (kHeavy && r0 + q < n_rows) ? heavy.slot[r0 + q] : -1;
+                pe[q] = (kHeavy && hs[q] >= 0) ? p[q] : p[q + 1];                   // a hub row: its neighbour sum is already in heavy.sum
+                const int mine = p[q] + l;
+                const bool in = mine < pe[q];
+                cj[q] = in ? idx[mine] : 0;
+                cv[q] = in ? (val ? val[mine] : 1.f) : 0.f;
+                sc[q] = (self_coef != nullptr && r0 + q < n_self) ? self_coef[r0 + q] : 0.f;
             }
 #pragma unroll
-            for (int qq = 0; qq < kBatch; ++qq) {
-                const int q = b0 + qq;
-                float4 acc = make_float4(sc[q] * sr[qq].x, sc[q] * sr[qq].y, sc[q] * sr[qq].z, sc[q] * sr[qq].w);
+            for (int b0 = 0; b0 < kRows; b0 += kBatch) {
+                off_t off[kBatch][kFirst], self_off[kBatch];
 #pragma unroll
-                for (int u = 0; u < kFirst; ++u) {
-                    const float v = __shfl(cv[q], u, kLanes);
-                    acc.x += v * x[qq][u].x; acc.y += v * x[qq][u].y; acc.z += v * x[qq][u].z; acc.w += v * x[qq][u].w;
+                for (int qq = 0; qq < kBatch; ++qq) {
+                    const int q = b0 + qq;
+                    const bool self_here = self_coef != nullptr && r0 + q < n_self;
+                    const int first = __shfl(cj[q], 0, kLanes);
+                    const int dummy = p[q] < pe[q] ? first : (self_here ? (int)(r0 + q) : 0);
+                    self_off[qq] = (off_t)(uint32_t)(self_here ? (int)(r0 + q) : dummy) * (off_t)(M * 4) + (off_t)(16 * l);
+#pragma unroll
+                    for (int u = 0; u < kFirst; ++u) {
+                        const int j = u == 0 ? first : __shfl(cj[q], u, kLanes);
+                        off[qq][u] = (off_t)(uint32_t)(p[q] + u < pe[q] ? j : dummy) * (off_t)(M * 4) + (off_t)(16 * l);
+                    }
                 }
-                int my_j = cj[q];
-                float my_v = cv[q];
-                const int p0 = p[q], p1 = pe[q];
-                for (int base = p0; base < p1; base += kLanes) {      // rows with more than kFirst neighbours
-                    if (base != p0) {
+                float4 x[kBatch][kFirst], sr[kBatch];
+#pragma unroll
+                for (int qq = 0; qq < kBatch; ++qq) {
+                    sr[qq] = *(const float4*)(db + self_off[qq]);
+#pragma unroll
+                    for (int u = 0; u < kFirst; ++u) x[qq][u] = *(const float4*)(db + off[qq][u]);
+                }
+#pragma unroll
+                for (int qq = 0; qq < kBatch; ++qq) {
+                    const int q = b0 + qq;
+                    float4 acc = make_float4(sc[q] * sr[qq].x, sc[q] * sr[qq].y, sc[q] * sr[qq].z, sc[q] * sr[qq].w);
+#pragma unroll
+                    for (int u = 0; u < kFirst; ++u) {
+                        const float v = __shfl(cv[q], u, kLanes);
+                        acc.x += v * x[qq][u].x; acc.y += v * x[qq][u].y; acc.z += v * x[qq][u].z; acc.w += v * x[qq][u].w;
+                    }
+                    int my_j = cj[q];
+                    float my_v = cv[q];
+                    const int p0 = p[q], p1 = pe[q];
+                    for (int base = p0; base < p1; base += kLanes) {      // rows with more than kFirst neighbours
+                        if (base != p0) {
+                            const int mine = base + l;
+                            my_j = mine < p1 ? idx[mine] : 0;
+                            my_v = mine < p1 ? (val ? val[mine] : 1.f) : 0.f;
+                        }
+                        const int cnt = p1 - base < kLanes ? p1 - base : kLanes;
+                        for (int e = base == p0 ? kFirst : 0; e < cnt; e += 4) {
+                            float4 y[4];
+                            float v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int src_lane = (e + u) < cnt ? e + u : e;
+                                const int j = __shfl(my_j, src_lane, kLanes);
+                                v[u] = (e + u) < cnt ? __shfl(my_v, src_lane, kLanes) : 0.f;
+                                y[u] = *(const float4*)(db + (off_t)(uint32_t)j * (off_t)(M * 4) + (off_t)(16 * l));
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                acc.x += v[u] * y[u].x; acc.y += v[u] * y[u].y; acc.z += v[u] * y[u].z; acc.w += v[u] * y[u].w;
+                            }
+                        }
+                    }
+                    if (p0 == p1 && sc[q] == 0.f) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (kHeavy && hs[q] >= 0) {
+                        const float4 h = *(const float4*)(heavy.sum + (int64_t)hs[q] * M + 4 * l);
+                        acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
+                    }
+                    *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc;
+                }
+            }
+        } else {
+            const int pv = pv_next, hv = hv_next;
+            const float scv = scv_next;
+            fetch_pointers(t + step);
+            // the first 4 (index, value) pairs of every row: lane 4*row + slot
+            uint32_t jo4;
+            float cv4;
+            // (entry offsets are taken relative to the tile's first entry: the index / value arrays may exceed 4 GiB, one tile's share cannot)
+            const int p_first = __builtin_amdgcn_readfirstlane(pv);
+            const buf_t rs_idx = buf_of(idx + p_first), rs_val = buf_of(val != nullptr ? val + p_first : nullptr);
+            {
+                const int pr = lane_read_i(a_rr, pv), pn = lane_read_i(a_rr + 4, pv);
+                const bool hub = kHeavy && lane_read_i(a_rr, hv) >= 0;
+                const int e = pr + (lane & 3);
+                const bool in = !hub && e < pn;
+                const uint32_t eo = in ? (uint32_t)(e - p_first) * 4u : kBufOob;
+                const uint32_t j = buf_load_u32(rs_idx, eo);
+                cv4 = val != nullptr ? buf_load_f32(rs_val, eo) : (in ? 1.f : 0.f);
+                jo4 = in ? (j << kShift) : kBufOob;
+            }
+            const uint32_t row_base = ((uint32_t)(t * 16) + (uint32_t)(g * kRows)) << kShift;        // (< 4 GiB: not kWide)
+#pragma unroll
+            for (int b0 = 0; b0 < kRows; b0 += kBatch) {
+                float4 x[kBatch][kFirst], sr[kBatch];
+                float v[kBatch][kFirst], sc[kBatch];
+#pragma unroll
+                for (int qq = 0; qq < kBatch; ++qq) {
+                    const int q = b0 + qq;
+                    sc[qq] = lane_read_f(a_row + 4 * q, scv);
+                    const bool self_here = t * 16 + g * kRows + q < n_self;
+                    sr[qq] = buf_load_f4(rs_x, self_here ? row_base + ((uint32_t)q << kShift) + l16 : kBufOob);
+#pragma unroll
+                    for (int u = 0; u < kFirst; ++u) {
+                        const uint32_t jo = (uint32_t)lane_read_i(a_pair + 16 * q + 4 * u, (int)jo4);
+                        v[qq][u] = lane_read_f(a_pair + 16 * q + 4 * u, cv4);
+                        x[qq][u] = buf_load_f4(rs_x, jo + l16);
+                    }
+                }
+#pragma unroll
+                for (int qq = 0; qq < kBatch; ++qq) {
+                    const int q = b0 + qq;
+                    float4 acc = make_float4(sc[qq] * sr[qq].x, sc[qq] * sr[qq].y, sc[qq] * sr[qq].z, sc[qq] * sr[qq].w);
+#pragma unroll
+                    for (int u = 0; u < kFirst; ++u) {
+                        acc.x += v[qq][u] * x[qq][u].x; acc.y += v[qq][u] * x[qq][u].y; acc.z += v[qq][u] * x[qq][u].z; acc.w += v[qq][u] * x[qq][u].w;
+                    }
+                    const int p0 = lane_read_i(a_row + 4 * q, pv);
+                    const int hs = kHeavy ? lane_read_i(a_row + 4 * q, hv) : -1;
+                    const int p_end = lane_read_i(a_row + 4 * q + 4, pv);                  // (every lane takes part: ds_bpermute reads active lanes only)
+                    const int p1 = hs >= 0 ? p0 : p_end;                                  // a hub row: its neighbour sum is already in heavy.sum
+                    for (int base = p0 + kFirst; base < p1; base += kLanes) {             // rows with more than kFirst neighbours
                         const int mine = base + l;
-                        my_j = mine < p1 ? idx[mine] : 0;
-                        my_v = mine < p1 ? (val ? val[mine] : 1.f) : 0.f;
-                    }
-                    const int cnt = p1 - base < kLanes ? p1 - base : kLanes;
-                    for (int e = base == p0 ? kFirst : 0; e < cnt; e += 4) {
-                        float4 y[4];
-                        float v[4];
+                        const uint32_t eo = mine < p1 ? (uint32_t)(mine - p_first) * 4u : kBufOob;
+                        const uint32_t my_jo = mine < p1 ? (buf_load_u32(rs_idx, eo) << kShift) : kBufOob;
+                        const float my_v = val != nullptr ? buf_load_f32(rs_val, eo) : (mine < p1 ? 1.f : 0.f);
+                        const int cnt = p1 - base < kLanes ? p1 - base : kLanes;
+                        for (int e = 0; e < cnt; e += 4) {
+                            float4 y[4];
+                            float w4[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int src_lane = (e + u) < cnt ? e + u : e;
-                            const int j = __shfl(my_j, src_lane, kLanes);
-                            v[u] = (e + u) < cnt ? __shfl(my_v, src_lane, kLanes) : 0.f;
-                            y[u] = *(const float4*)(db + (off_t)(uint32_t)j * (off_t)(M * 4) + (off_t)(16 * l));
-                        }
+                            for (int u = 0; u < 4; ++u) {
+                                const uint32_t jo = (uint32_t)__shfl((int)my_jo, e + u, kLanes);
+                                w4[u] = __shfl(my_v, e + u, kLanes);
+                                y[u] = buf_load_f4(rs_x, jo + l16);
+                            }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            acc.x += v[u] * y[u].x; acc.y += v[u] * y[u].y; acc.z += v[u] * y[u].z; acc.w += v[u] * y[u].w;
+                            for (int u = 0; u < 4; ++u) {
+                                acc.x += w4[u] * y[u].x; acc.y += w4[u] * y[u].y; acc.z += w4[u] * y[u].z; acc.w += w4[u] * y[u].w;
+                            }
                         }
                     }
+                    if (kHeavy && hs >= 0) {
+                        const float4 h = *(const float4*)(heavy.sum + (int64_t)hs * M + 4 * l);
+                        acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
+                    }
+                    *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc;
                 }
-                if (p0 == p1 && sc[q] == 0.f) acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kHeavy && hs[q] >= 0) {
-                    const float4 h = *(const float4*)(heavy.sum + (int64_t)hs[q] * M + 4 * l);
-                    acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
-                }
-                *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -748,7 +843,7 @@ int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* v
     PP_REQUIRE(d_in != nullptr && (!fuse_act || X_act != nullptr), PP_ERR_ARG, "pp_gcn_input_grad_f32: d_in (and X_act with fuse_act) required");
     PP_REQUIRE(((uintptr_t)D | (uintptr_t)X_act | (uintptr_t)d_in) % 16 == 0, PP_ERR_ARG, "pp_gcn_input_grad_f32: D, X_act and d_in must be 16-byte aligned");
     PP_REQUIRE(n_rows < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_input_grad_f32: more than 2^31 rows");
-    const bool wide = (uint64_t)n_rows * (uint64_t)M * 4 > 0xffffffffull;
+    const bool wide = (uint64_t)n_rows * (uint64_t)M * 4 >= (uint64_t)pp::kBufOob || n_rows >= ((int64_t)1 << 30) - 64;
     if (colsum_in) PP_HIP(hipMemsetAsync(colsum_in, 0, (size_t)K * sizeof(float), st));
     if (n_rows == 0) return PP_OK;
     const int64_t n_tiles = pp::ceil_div(n_rows, 16);
@@ -774,7 +869,7 @@ int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val
     PP_REQUIRE(pp_dense_supported(M, K), PP_ERR_ARG, "pp_gcn_backward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", M, K);
     PP_REQUIRE(d_in != nullptr && dW != nullptr, PP_ERR_ARG, "pp_gcn_backward_f32: d_in and dW are required");
     PP_REQUIRE(((uintptr_t)D) % 16 == 0, PP_ERR_ARG, "pp_gcn_backward_f32: D must be 16-byte aligned");
-    const bool wide = (uint64_t)n_rows * (uint64_t)M * 4 > 0xffffffffull;         // 64-bit row offsets from 4 GiB on
+    const bool wide = (uint64_t)n_rows * (uint64_t)M * 4 >= (uint64_t)pp::kBufOob || n_rows >= ((int64_t)1 << 30) - 64;      // 64-bit row addresses
     PP_REQUIRE(ws_bytes >= pp_gcn_backward_ws_bytes(n_rows), PP_ERR_WORKSPACE, "pp_gcn_backward_f32: workspace too small");
     if (colsum_in) PP_HIP(hipMemsetAsync(colsum_in, 0, (size_t)K * sizeof(float), st));
     if (n_rows == 0) {
