@@ -21,6 +21,168 @@ constexpr int kGcnThreads = 256;                 // 4 waves share one copy of W
 constexpr int kFirst = 4;                        // neighbours per row fetched in the first, fully overlapped, batch
 constexpr int kGcnWaves = kGcnThreads / kWave;
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Gather stage shared by the layer kernels (the form for matrices below 4 GiB): aggregates one 16-row tile
+//     tile[r] = self[r] * X[r] + sum_e val[e] * X[idx[e]]
+// into a wave-private LDS buffer (row stride P + 4 floats).  kLanes = P/4 lanes own a row (one float4 each), a lane group walks its kRows
+// rows kBatch at a time.  Everything is read with buffer loads (32-bit offsets; an offset >= kBufOob reads as zeros without touching
+// memory, so absent neighbours and rows past the end need no branch around a load and no select behind it — on this chip the VALU and
+// the matrix pipe of a SIMD do not overlap across waves, tools/probes/mfma/overlap.hip, so the gather's VALU instructions are paid in
+// full).  Per tile ONE coalesced load each brings the 17 row pointers, the 16 self coefficients (both one tile ahead) and the first 4 and
+// the next 4 (index, value) pairs of all 16 rows (lane 4*row + slot); the lane groups take them with ds_bpermute.  Rows with more than 8
+// neighbours continue chunk-wise.
+template <int P, bool kHeavy>
+struct TileGather {
+    static constexpr int kLanes = P / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, TS = P + 4;
+    static constexpr int kBatch = kRows < 2 ? kRows : (kRows >= 8 ? 4 : 2);      // 128-wide rows: registers to spare for a deeper gather
+    static constexpr int kShift = P == 16 ? 6 : (P == 32 ? 7 : (P == 64 ? 8 : 9));      // log2(row bytes)
+    buf_t rs_x, rs_ptr, rs_self, rs_slot;
+    const int32_t* idx;
+    const float* val;
+    const float* self_coef;
+    HeavyRows heavy;
+    int64_t n_rows, n_self, n_tiles;
+    int lane, g, l, a_rr, a_row, a_pair;
+    uint32_t l16;
+    int pv_next, hv_next;
+    float scv_next;
+
+    __device__ __forceinline__ TileGather(const float* X, const int32_t* ptr, const int32_t* idx_, const float* val_, const float* self_coef_,
+                                          HeavyRows heavy_, int64_t n_rows_, int64_t n_self_)
+        : rs_x(buf_of(X)), rs_ptr(buf_of(ptr)), rs_self(buf_of(self_coef_)), rs_slot(buf_of(heavy_.slot)), idx(idx_), val(val_),
+          self_coef(self_coef_), heavy(heavy_), n_rows(n_rows_), n_self(n_self_), n_tiles((n_rows_ + 15) / 16), lane(lane_id()),
+          g(lane_id() / kLanes), l(lane_id() % kLanes), pv_next(0), hv_next(-1), scv_next(0.f) {
+        a_rr = (lane >> 2) * 4;            // ds_bpermute byte addresses: lane = row of this lane's (row, slot) pair ..
+        a_row = g * kRows * 4;             // .. lane = first row of this lane group ..
+        a_pair = g * kRows * 16;           // .. lane = 4 * (first row of this lane group)
+        l16 = 16u * l;
+    }
+
+    // row pointers, self coefficients and hub slots of `tile` (one round trip off the critical path when called a tile ahead)
+    __device__ __forceinline__ void prefetch(int64_t tile) {
+        const int64_t rl = tile * 16 + lane;
+        const bool live = tile < n_tiles;
+        pv_next = (int)buf_load_u32(rs_ptr, (live && lane <= 16) ? (uint32_t)(rl < n_rows ? rl : n_rows) * 4u : kBufOob);
+        scv_next = self_coef != nullptr ? buf_load_f32(rs_self, (live && lane < 16 && rl < n_self) ? (uint32_t)rl * 4u : kBufOob) : 0.f;
+        if constexpr (kHeavy) hv_next = (live && lane < 16 && rl < n_rows) ? (int)buf_load_u32(rs_slot, (uint32_t)rl * 4u) : -1;
+    }
+
+    // aggregates tile t (whose pointers the last prefetch() fetched) and prefetches tile t_next
+    __device__ __forceinline__ void run(int64_t t, int64_t t_next, float* __restrict__ tile, float* __restrict__ agg_out) {
+        const int pv = pv_next, hv = hv_next;
+        const float scv = scv_next;
+        prefetch(t_next);
+        // (entry offsets are taken relative to the tile's first entry: the index / value arrays may exceed 4 GiB, one tile's share cannot)
+        const int p_first = __builtin_amdgcn_readfirstlane(pv);
+        const buf_t rs_idx = buf_of(idx + p_first), rs_val = buf_of(val != nullptr ? val + p_first : nullptr);
+        uint32_t jo_a, jo_b;               // byte offsets of the source rows of pairs 0..3 / 4..7 of row lane >> 2 (slot lane & 3)
+        float cv_a, cv_b;
+        bool more;                         // some row of the tile has more than 4 neighbours (wave-uniform)
+        {
+            const int pr = lane_read_i(a_rr, pv), pn = lane_read_i(a_rr + 4, pv);
+            const bool hub = kHeavy && lane_read_i(a_rr, hv) >= 0;
+            const int e = pr + (lane & 3);
+            const bool in_a = !hub && e < pn, in_b = !hub && e + 4 < pn;
+            more = __ballot(in_b) != 0ull;
+            const uint32_t eo_a = in_a ? (uint32_t)(e - p_first) * 4u : kBufOob, eo_b = in_b ? (uint32_t)(e + 4 - p_first) * 4u : kBufOob;
+            const uint32_t j_a = buf_load_u32(rs_idx, eo_a);
+            cv_a = val != nullptr ? buf_load_f32(rs_val, eo_a) : (in_a ? 1.f : 0.f);
+            uint32_t j_b = 0u;
+            cv_b = 0.f;
+            if (more) {
+                j_b = buf_load_u32(rs_idx, eo_b);
+                cv_b = val != nullptr ? buf_load_f32(rs_val, eo_b) : (in_b ? 1.f : 0.f);
+            }
+            jo_a = in_a ? (j_a << kShift) : kBufOob;
+            jo_b = in_b ? (j_b << kShift) : kBufOob;
+        }
+        const uint32_t row_base = ((uint32_t)(t * 16) + (uint32_t)(g * kRows)) << kShift;        // (below 4 GiB by the caller's choice of this form)
+#pragma unroll
+        for (int b0 = 0; b0 < kRows; b0 += kBatch) {
+            float4 x[kBatch][kFirst], sr[kBatch];
+            float v[kBatch][kFirst], sc[kBatch];
+#pragma unroll
+            for (int qq = 0; qq < kBatch; ++qq) {
+                const int q = b0 + qq;
+                sc[qq] = lane_read_f(a_row + 4 * q, scv);
+                const bool self_here = t * 16 + g * kRows + q < n_self;
+                sr[qq] = buf_load_f4(rs_x, self_here ? row_base + ((uint32_t)q << kShift) + l16 : kBufOob);
+#pragma unroll
+                for (int u = 0; u < kFirst; ++u) {
+                    const uint32_t jo = (uint32_t)lane_read_i(a_pair + 16 * q + 4 * u, (int)jo_a);
+                    v[qq][u] = lane_read_f(a_pair + 16 * q + 4 * u, cv_a);
+                    x[qq][u] = buf_load_f4(rs_x, jo + l16);
+                }
+            }
+            float4 acc[kBatch];
+#pragma unroll
+            for (int qq = 0; qq < kBatch; ++qq) {
+                acc[qq] = make_float4(sc[qq] * sr[qq].x, sc[qq] * sr[qq].y, sc[qq] * sr[qq].z, sc[qq] * sr[qq].w);
+#pragma unroll
+                for (int u = 0; u < kFirst; ++u) {
+                    acc[qq].x += v[qq][u] * x[qq][u].x; acc[qq].y += v[qq][u] * x[qq][u].y;
+                    acc[qq].z += v[qq][u] * x[qq][u].z; acc[qq].w += v[qq][u] * x[qq][u].w;
+                }
+            }
+            if (more) {                    // pairs 4..7 (every lane takes part: ds_bpermute reads active lanes only; absent pairs read zeros)
+#pragma unroll
+                for (int qq = 0; qq < kBatch; ++qq) {
+                    const int q = b0 + qq;
+#pragma unroll
+                    for (int u = 0; u < kFirst; ++u) {
+                        const uint32_t jo = (uint32_t)lane_read_i(a_pair + 16 * q + 4 * u, (int)jo_b);
+                        v[qq][u] = lane_read_f(a_pair + 16 * q + 4 * u, cv_b);
+                        x[qq][u] = buf_load_f4(rs_x, jo + l16);
+                    }
+                }
+#pragma unroll
+                for (int qq = 0; qq < kBatch; ++qq)
+#pragma unroll
+                    for (int u = 0; u < kFirst; ++u) {
+                        acc[qq].x += v[qq][u] * x[qq][u].x; acc[qq].y += v[qq][u] * x[qq][u].y;
+                        acc[qq].z += v[qq][u] * x[qq][u].z; acc[qq].w += v[qq][u] * x[qq][u].w;
+                    }
+            }
+#pragma unroll
+            for (int qq = 0; qq < kBatch; ++qq) {
+                const int q = b0 + qq;
+                const int64_t r = t * 16 + g * kRows + q;
+                const int p0 = lane_read_i(a_row + 4 * q, pv);
+                const int hs = kHeavy ? lane_read_i(a_row + 4 * q, hv) : -1;
+                const int p_end = lane_read_i(a_row + 4 * q + 4, pv);                  // (every lane takes part, see above)
+                const int p1 = hs >= 0 ? p0 : p_end;                                  // a hub row: its neighbour sum is already in heavy.sum
+                for (int base = p0 + 2 * kFirst; base < p1; base += kLanes) {         // rows with more than 8 neighbours
+                    const int mine = base + l;
+                    const uint32_t eo = mine < p1 ? (uint32_t)(mine - p_first) * 4u : kBufOob;
+                    const uint32_t my_jo = mine < p1 ? (buf_load_u32(rs_idx, eo) << kShift) : kBufOob;
+                    const float my_v = val != nullptr ? buf_load_f32(rs_val, eo) : (mine < p1 ? 1.f : 0.f);
+                    const int cnt = p1 - base < kLanes ? p1 - base : kLanes;
+                    for (int e = 0; e < cnt; e += 4) {
+                        float4 y[4];
+                        float w4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t jo = (uint32_t)__shfl((int)my_jo, e + u, kLanes);
+                            w4[u] = __shfl(my_v, e + u, kLanes);
+                            y[u] = buf_load_f4(rs_x, jo + l16);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc[qq].x += w4[u] * y[u].x; acc[qq].y += w4[u] * y[u].y; acc[qq].z += w4[u] * y[u].z; acc[qq].w += w4[u] * y[u].w;
+                        }
+                    }
+                }
+                if (kHeavy && hs >= 0) {
+                    const float4 h = *(const float4*)(heavy.sum + (int64_t)hs * P + 4 * l);
+                    acc[qq].x += h.x; acc[qq].y += h.y; acc[qq].z += h.z; acc[qq].w += h.w;
+                }
+                *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc[qq];
+                if (agg_out != nullptr && r < n_rows) *(float4*)(agg_out + r * P + 4 * l) = acc[qq];
+            }
+        }
+    }
+};
+
 // One wave per 16-row tile, persistent workgroups of 4 waves.  Gather stage: kLanes = P/4 lanes own a row (one float4 each), a lane
 // group walks its kRows rows kBatch at a time and issues the first kFirst neighbour rows of the batch plus the rows themselves
 // back to back (index / weight chunks come by one coalesced load per row and are handed round by shuffle); longer rows continue
@@ -76,19 +238,7 @@ __global__ __launch_bounds__(kThreads) void k_gcn_forward(const int32_t* __restr
     // come by ONE coalesced load each (lane 4*row + slot) and are handed round with ds_bpermute; absent neighbours / rows past the end carry
     // the out-of-range offset and read as zeros.  The pointers are fetched one tile ahead.
     [[maybe_unused]] int p_next[kRows + 1];
-    [[maybe_unused]] int pv_next = 0, hv_next = -1;
-    [[maybe_unused]] float scv_next = 0.f;
-    constexpr int kShift = P == 16 ? 6 : (P == 32 ? 7 : (P == 64 ? 8 : 9));     // log2(row bytes)
-    const buf_t rs_x = buf_of(X), rs_ptr = buf_of(ptr), rs_self = buf_of(self_coef), rs_slot = buf_of(heavy.slot);
-    const uint32_t l16 = 16u * l;
-    const int a_rr = (lane >> 2) * 4, a_row = g * kRows * 4, a_pair = g * kRows * 16;      // ds_bpermute addresses: lane = row / row / 4*row + slot
-    auto fetch_pointers = [&](int64_t tile) {
-        const int64_t rl = tile * 16 + lane;
-        const bool live = tile < n_tiles;
-        pv_next = (int)buf_load_u32(rs_ptr, (live && lane <= 16) ? (uint32_t)(rl < n_rows ? rl : n_rows) * 4u : kBufOob);
-        scv_next = self_coef != nullptr ? buf_load_f32(rs_self, (live && lane < 16 && rl < n_self) ? (uint32_t)rl * 4u : kBufOob) : 0.f;
-        if constexpr (kHeavy) hv_next = (live && lane < 16 && rl < n_rows) ? (int)buf_load_u32(rs_slot, (uint32_t)rl * 4u) : -1;
-    };
+    [[maybe_unused]] TileGather<P, kHeavy> gather(X, ptr, idx, val, self_coef, heavy, n_rows, n_self);
     if constexpr (kWide) {
         {
             const int64_t t0 = (int64_t)blockIdx.x * kWaves + wave;
@@ -100,7 +250,7 @@ __global__ __launch_bounds__(kThreads) void k_gcn_forward(const int32_t* __restr
         }
 
     } else {
-        fetch_pointers((int64_t)blockIdx.x * kWaves + wave);
+        gather.prefetch((int64_t)blockIdx.x * kWaves + wave);
     }
     for (int64_t t = (int64_t)blockIdx.x * kWaves + wave; t < n_tiles; t += step) {
         if constexpr (kWide) {
@@ -197,85 +347,7 @@ __global__ __launch_bounds__(kThreads) void k_gcn_forward(const int32_t* __restr
             }
 
         } else {
-            const int pv = pv_next, hv = hv_next;
-            const float scv = scv_next;
-            fetch_pointers(t + step);
-            // the first 4 (index, value) pairs of every row: lane 4*row + slot
-            uint32_t jo4;
-            float cv4;
-            // (entry offsets are taken relative to the tile's first entry: the index / value arrays may exceed 4 GiB, one tile's share cannot)
-            const int p_first = __builtin_amdgcn_readfirstlane(pv);
-            const buf_t rs_idx = buf_of(idx + p_first), rs_val = buf_of(val != nullptr ? val + p_first : nullptr);
-            {
-                const int pr = lane_read_i(a_rr, pv), pn = lane_read_i(a_rr + 4, pv);
-                const bool hub = kHeavy && lane_read_i(a_rr, hv) >= 0;
-                const int e = pr + (lane & 3);
-                const bool in = !hub && e < pn;
-                const uint32_t eo = in ? (uint32_t)(e - p_first) * 4u : kBufOob;
-                const uint32_t j = buf_load_u32(rs_idx, eo);
-                cv4 = val != nullptr ? buf_load_f32(rs_val, eo) : (in ? 1.f : 0.f);
-                jo4 = in ? (j << kShift) : kBufOob;
-            }
-            const uint32_t row_base = ((uint32_t)(t * 16) + (uint32_t)(g * kRows)) << kShift;        // (< 4 GiB: not kWide)
-#pragma unroll
-            for (int b0 = 0; b0 < kRows; b0 += kBatch) {
-                float4 x[kBatch][kFirst], sr[kBatch];
-                float v[kBatch][kFirst], sc[kBatch];
-#pragma unroll
-                for (int qq = 0; qq < kBatch; ++qq) {
-                    const int q = b0 + qq;
-                    sc[qq] = lane_read_f(a_row + 4 * q, scv);
-                    const bool self_here = t * 16 + g * kRows + q < n_self;
-                    sr[qq] = buf_load_f4(rs_x, self_here ? row_base + ((uint32_t)q << kShift) + l16 : kBufOob);
-#pragma unroll
-                    for (int u = 0; u < kFirst; ++u) {
-                        const uint32_t jo = (uint32_t)lane_read_i(a_pair + 16 * q + 4 * u, (int)jo4);
-                        v[qq][u] = lane_read_f(a_pair + 16 * q + 4 * u, cv4);
-                        x[qq][u] = buf_load_f4(rs_x, jo + l16);
-                    }
-                }
-#pragma unroll
-                for (int qq = 0; qq < kBatch; ++qq) {
-                    const int q = b0 + qq;
-                    const int64_t r = t * 16 + g * kRows + q;
-                    float4 acc = make_float4(sc[qq] * sr[qq].x, sc[qq] * sr[qq].y, sc[qq] * sr[qq].z, sc[qq] * sr[qq].w);
-#pragma unroll
-                    for (int u = 0; u < kFirst; ++u) {
-                        acc.x += v[qq][u] * x[qq][u].x; acc.y += v[qq][u] * x[qq][u].y; acc.z += v[qq][u] * x[qq][u].z; acc.w += v[qq][u] * x[qq][u].w;
-                    }
-                    const int p0 = lane_read_i(a_row + 4 * q, pv);
-                    const int hs = kHeavy ? lane_read_i(a_row + 4 * q, hv) : -1;
-                    const int p_end = lane_read_i(a_row + 4 * q + 4, pv);                  // (every lane takes part: ds_bpermute reads active lanes only)
-                    const int p1 = hs >= 0 ? p0 : p_end;                                  // a hub row: its neighbour sum is already in heavy.sum
-                    for (int base = p0 + kFirst; base < p1; base += kLanes) {             // rows with more than kFirst neighbours
-                        const int mine = base + l;
-                        const uint32_t eo = mine < p1 ? (uint32_t)(mine - p_first) * 4u : kBufOob;
-                        const uint32_t my_jo = mine < p1 ? (buf_load_u32(rs_idx, eo) << kShift) : kBufOob;
-                        const float my_v = val != nullptr ? buf_load_f32(rs_val, eo) : (mine < p1 ? 1.f : 0.f);
-                        const int cnt = p1 - base < kLanes ? p1 - base : kLanes;
-                        for (int e = 0; e < cnt; e += 4) {
-                            float4 y[4];
-                            float w4[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const uint32_t jo = (uint32_t)__shfl((int)my_jo, e + u, kLanes);
-                                w4[u] = __shfl(my_v, e + u, kLanes);
-                                y[u] = buf_load_f4(rs_x, jo + l16);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                acc.x += w4[u] * y[u].x; acc.y += w4[u] * y[u].y; acc.z += w4[u] * y[u].z; acc.w += w4[u] * y[u].w;
-                            }
-                        }
-                    }
-                    if (kHeavy && hs >= 0) {
-                        const float4 h = *(const float4*)(heavy.sum + (int64_t)hs * P + 4 * l);
-                        acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
-                    }
-                    *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc;
-                    if (agg_out != nullptr && r < n_rows) *(float4*)(agg_out + r * P + 4 * l) = acc;
-                }
-            }
+            gather.run(t, t + step, tile, agg_out);
         }
         __builtin_amdgcn_wave_barrier();
         // input gradient: the activation rows of the epilogue (lane (i, kq): rows 4*kq .., columns CT*i ..) fly during the MFMAs
@@ -469,21 +541,9 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
     for (int ct = 0; ct < CT; ++ct) col_in[ct] = 0.f;
     const int64_t n_tiles = (n_rows + 15) / 16;
     const int64_t step = (int64_t)gridDim.x * kGcnWaves;
-    // gather stage as in k_gcn_forward: buffer loads + ds_bpermute unless D is 4 GiB or larger (kWide)
-    [[maybe_unused]] int pv_next = 0, hv_next = -1;
-    [[maybe_unused]] float scv_next = 0.f;
-    constexpr int kShift = M == 16 ? 6 : (M == 32 ? 7 : (M == 64 ? 8 : 9));     // log2(row bytes)
-    const buf_t rs_x = buf_of(D), rs_ptr = buf_of(ptr), rs_self = buf_of(self_coef), rs_slot = buf_of(heavy.slot);
-    const uint32_t l16 = 16u * l;
-    const int a_rr = (lane >> 2) * 4, a_row = g * kRows * 4, a_pair = g * kRows * 16;      // ds_bpermute addresses: lane = row / row / 4*row + slot
-    auto fetch_pointers = [&](int64_t tile) {
-        const int64_t rl = tile * 16 + lane;
-        const bool live = tile < n_tiles;
-        pv_next = (int)buf_load_u32(rs_ptr, (live && lane <= 16) ? (uint32_t)(rl < n_rows ? rl : n_rows) * 4u : kBufOob);
-        scv_next = self_coef != nullptr ? buf_load_f32(rs_self, (live && lane < 16 && rl < n_self) ? (uint32_t)rl * 4u : kBufOob) : 0.f;
-        if constexpr (kHeavy) hv_next = (live && lane < 16 && rl < n_rows) ? (int)buf_load_u32(rs_slot, (uint32_t)rl * 4u) : -1;
-    };
-    if constexpr (!kWide) fetch_pointers((int64_t)blockIdx.x * kGcnWaves + wave);
+    // gather stage as in k_gcn_forward: buffer loads + ds_bpermute (TileGather) unless D is 4 GiB or larger (kWide)
+    [[maybe_unused]] TileGather<M, kHeavy> gather(D, ptr, idx, val, self_coef, heavy, n_rows, n_self);
+    if constexpr (!kWide) gather.prefetch((int64_t)blockIdx.x * kGcnWaves + wave);
     for (int64_t t = (int64_t)blockIdx.x * kGcnWaves + wave; t < n_tiles; t += step) {
         // natural-layout rows of the layer input: B operand of the dW stream and source of the ELU' epilogue (in flight during the gather)
         // lane (i, kq) owns rows 4*kq .. 4*kq+3 of the tile and the CT consecutive columns CT*i ..: one vector load per row
@@ -587,83 +647,7 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
                 }
             }
         } else {
-            const int pv = pv_next, hv = hv_next;
-            const float scv = scv_next;
-            fetch_pointers(t + step);
-            // the first 4 (index, value) pairs of every row: lane 4*row + slot
-            uint32_t jo4;
-            float cv4;
-            // (entry offsets are taken relative to the tile's first entry: the index / value arrays may exceed 4 GiB, one tile's share cannot)
-            const int p_first = __builtin_amdgcn_readfirstlane(pv);
-            const buf_t rs_idx = buf_of(idx + p_first), rs_val = buf_of(val != nullptr ? val + p_first : nullptr);
-            {
-                const int pr = lane_read_i(a_rr, pv), pn = lane_read_i(a_rr + 4, pv);
-                const bool hub = kHeavy && lane_read_i(a_rr, hv) >= 0;
-                const int e = pr + (lane & 3);
-                const bool in = !hub && e < pn;
-                const uint32_t eo = in ? (uint32_t)(e - p_first) * 4u : kBufOob;
-                const uint32_t j = buf_load_u32(rs_idx, eo);
-                cv4 = val != nullptr ? buf_load_f32(rs_val, eo) : (in ? 1.f : 0.f);
-                jo4 = in ? (j << kShift) : kBufOob;
-            }
-            const uint32_t row_base = ((uint32_t)(t * 16) + (uint32_t)(g * kRows)) << kShift;        // (< 4 GiB: not kWide)
-#pragma unroll
-            for (int b0 = 0; b0 < kRows; b0 += kBatch) {
-                float4 x[kBatch][kFirst], sr[kBatch];
-                float v[kBatch][kFirst], sc[kBatch];
-#pragma unroll
-                for (int qq = 0; qq < kBatch; ++qq) {
-                    const int q = b0 + qq;
-                    sc[qq] = lane_read_f(a_row + 4 * q, scv);
-                    const bool self_here = t * 16 + g * kRows + q < n_self;
-                    sr[qq] = buf_load_f4(rs_x, self_here ? row_base + ((uint32_t)q << kShift) + l16 : kBufOob);
-#pragma unroll
-                    for (int u = 0; u < kFirst; ++u) {
-                        const uint32_t jo = (uint32_t)lane_read_i(a_pair + 16 * q + 4 * u, (int)jo4);
-                        v[qq][u] = lane_read_f(a_pair + 16 * q + 4 * u, cv4);
-                        x[qq][u] = buf_load_f4(rs_x, jo + l16);
-                    }
-                }
-#pragma unroll
-                for (int qq = 0; qq < kBatch; ++qq) {
-                    const int q = b0 + qq;
-                    float4 acc = make_float4(sc[qq] * sr[qq].x, sc[qq] * sr[qq].y, sc[qq] * sr[qq].z, sc[qq] * sr[qq].w);
-#pragma unroll
-                    for (int u = 0; u < kFirst; ++u) {
-                        acc.x += v[qq][u] * x[qq][u].x; acc.y += v[qq][u] * x[qq][u].y; acc.z += v[qq][u] * x[qq][u].z; acc.w += v[qq][u] * x[qq][u].w;
-                    }
-                    const int p0 = lane_read_i(a_row + 4 * q, pv);
-                    const int hs = kHeavy ? lane_read_i(a_row + 4 * q, hv) : -1;
-                    const int p_end = lane_read_i(a_row + 4 * q + 4, pv);                  // (every lane takes part: ds_bpermute reads active lanes only)
-                    const int p1 = hs >= 0 ? p0 : p_end;                                  // a hub row: its neighbour sum is already in heavy.sum
-                    for (int base = p0 + kFirst; base < p1; base += kLanes) {             // rows with more than kFirst neighbours
-                        const int mine = base + l;
-                        const uint32_t eo = mine < p1 ? (uint32_t)(mine - p_first) * 4u : kBufOob;
-                        const uint32_t my_jo = mine < p1 ? (buf_load_u32(rs_idx, eo) << kShift) : kBufOob;
-                        const float my_v = val != nullptr ? buf_load_f32(rs_val, eo) : (mine < p1 ? 1.f : 0.f);
-                        const int cnt = p1 - base < kLanes ? p1 - base : kLanes;
-                        for (int e = 0; e < cnt; e += 4) {
-                            float4 y[4];
-                            float w4[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const uint32_t jo = (uint32_t)__shfl((int)my_jo, e + u, kLanes);
-                                w4[u] = __shfl(my_v, e + u, kLanes);
-                                y[u] = buf_load_f4(rs_x, jo + l16);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                acc.x += w4[u] * y[u].x; acc.y += w4[u] * y[u].y; acc.z += w4[u] * y[u].z; acc.w += w4[u] * y[u].w;
-                            }
-                        }
-                    }
-                    if (kHeavy && hs >= 0) {
-                        const float4 h = *(const float4*)(heavy.sum + (int64_t)hs * M + 4 * l);
-                        acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
-                    }
-                    *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc;
-                }
-            }
+            gather.run(t, t + step, tile, nullptr);
         }
         __builtin_amdgcn_wave_barrier();
         // ---------------------------------------------------------------- G . W  ->  d_in tile
