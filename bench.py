@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--span", type=int, default=10_000_000)
     ap.add_argument("--delta", type=int, default=1_000_000)
     ap.add_argument("--features", type=int, default=64)
+    ap.add_argument("--dropout", type=float, default=0.0, help="p_dropout of the model (the headline number is quoted at 0; the reference's own test uses 0.4)")
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--mode", choices=("partition", "streams"), default="partition")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: host-staged collectives (tests; several ranks may share one GPU)")
@@ -391,7 +392,7 @@ def main() -> int:
     y = torch.randint(0, args.classes, (args.nodes,), generator=feat, device=dev)
     torch.manual_seed(0)                                    # identical initial weights on every rank
     net = pp.nn.DBGNN(num_classes=args.classes, num_features=(args.features, args.features),
-                      hidden_dims=[args.features] * 3, p_dropout=0.0).to(dev)
+                      hidden_dims=[args.features] * 3, p_dropout=args.dropout).to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     sharded = ppd.ShardedDBGNN(net, comm) if partition else None
     lift_ms = []
@@ -554,7 +555,8 @@ def main() -> int:
             "dtype": "int64 lift / f32 DBGNN",
             "data": "synthetic",
             "config": {"workload": f"temporal ER stream{'' if partition else ' per GPU'}: m={args.events} events, N={args.nodes} nodes, "
-                                   f"t~U[0,{args.span}), delta={args.delta}, k=2, F={args.features}, hidden=[{args.features}]*3, classes={args.classes}",
+                                   f"t~U[0,{args.span}), delta={args.delta}, k=2, F={args.features}, hidden=[{args.features}]*3, classes={args.classes}"
+                                   + (f", p_dropout={args.dropout}" if args.dropout else ""),
                        "parallelism": (f"{world} rank(s) over {comm.backend or 'no process group'}: ONE global stream, edge-range sharded lift, "
                                        "destination-owner aggregation (all-to-all), destination-partitioned DBGNN with one embedding exchange per "
                                        "layer (sparse all-to-all), bipartite reduce-scatter, weight-gradient all-reduce") if partition else

@@ -234,6 +234,11 @@ int pp_spmm_heavy_f32(const int32_t* idx, const float* val, const float* X, int 
  * bipartite aggregation sum_j x_h[j] (dbgnn.py:50-69 re-associated: lin1 is applied AFTER the sum over the higher-order nodes). */
 int pp_spmm_act_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int F, const float* Z,
                              float* colsum, float* dX, pp_stream_t stream);
+/* the same with Z stored DROPPED (F.dropout between the last higher-order layer and the bipartite layer, dbgnn.py:142; masks of pp_dropout_f32):
+ * dX = (A D) * mask / (1 - p) * ELU'(Z * (1 - p)) */
+int pp_spmm_act_backward_drop_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int F, const float* Z,
+                                  float* colsum, float* dX, double drop_p, int64_t drop_seed, int64_t drop_tag, int64_t drop_row0,
+                                  pp_stream_t stream);
 
 /* dpre = dY * elu'(.) from the stored OUTPUT y (1 if y > 0 else y + 1); act 0: dpre = dY; dbias[F] = column sums of dpre.
  * dpre or dbias may be NULL. */
@@ -317,6 +322,25 @@ int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val
 int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
                           const float* self_coef, const float* W, int K, const float* X_act, int fuse_act, const int32_t* heavy_slot,
                           const float* heavy_sum, float* d_in, float* colsum_in, void* ws, size_t ws_bytes, pp_stream_t stream);
+/* The same three calls with the reference's training-mode F.dropout (src/pathpyG/nn/dbgnn.py:132,138,142) fused into their epilogues
+ * (counter-based masks, see pp_dropout_f32; drop_p == 0: exactly the calls above; pp_gcn_drop_supported(P, Q): the 16/32/64 and 128-wide
+ * kernels).  forward: Y is dropped — mask(drop_seed, drop_tag, drop_row0 + row, column) — before it is stored, i.e. the NEXT layer's input
+ * dropout costs no pass.  backward / input_grad (with fuse_act): X / X_act is the dropped activation of the layer below (site drop_tag);
+ * d_in becomes the gradient w.r.t. that layer's pre-activation, (G W) * mask / (1 - p) * ELU'(X * (1 - p)). */
+int pp_gcn_drop_supported(int P, int Q);
+int pp_gcn_forward_drop_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
+                            const float* self_coef, const float* W, int Q, const float* bias, int act, const int32_t* heavy_slot,
+                            const float* heavy_sum, float* agg_out, float* Y, double drop_p, int64_t drop_seed, int64_t drop_tag, int64_t drop_row0,
+                            pp_stream_t stream);
+int pp_gcn_backward_drop_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
+                             const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
+                             const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, double drop_p,
+                             int64_t drop_seed, int64_t drop_tag, int64_t drop_row0, pp_stream_t stream);
+int pp_gcn_input_grad_drop_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
+                               const float* self_coef, const float* W, int K, const float* X_act, int fuse_act, const int32_t* heavy_slot,
+                               const float* heavy_sum, float* d_in, float* colsum_in, void* ws, size_t ws_bytes, double drop_p, int64_t drop_seed,
+                               int64_t drop_tag, int64_t drop_row0, pp_stream_t stream);
+
                           /* ws: pp_wide_layer_ws_bytes(M, K) for the shapes served by pp_wide_layer_f32 (a side of 256), else unused */
 
 /* Layers too wide for a weight matrix in LDS (pp_gcn_wide.hip): P, Q in {64, 128, 256} with a side > 64 — DBGNN with 256-dim features

@@ -748,27 +748,42 @@ def dense(a: torch.Tensor, weight: torch.Tensor, transposed: bool, bias: torch.T
     return out, colsum
 
 
-def spmm_act_backward(ptr, idx, val, n_rows: int, d: torch.Tensor, z: torch.Tensor, want_colsum: bool):
+def spmm_act_backward(ptr, idx, val, n_rows: int, d: torch.Tensor, z: torch.Tensor, want_colsum: bool, drop: tuple | None = None):
     """``dx = (A d) * elu'(z)`` with ``elu'`` from the stored activation ``z`` (``z > 0 ? 1 : z + 1``) and, optionally, the
-    column sums of ``dx`` — one pass."""
+    column sums of ``dx`` — one pass.  ``drop = (p, seed, tag, row0)``: ``z`` is stored dropped; mask and ``1 / (1 - p)`` go into ``dx``."""
     dev = require_device(d, z)
+    dp, dseed, dtag, drow0 = _drop_args(drop)
     d, z = d.contiguous(), z.contiguous()
     f = d.size(1)
     with torch.cuda.device(dev):
         dx = torch.empty((n_rows, f), dtype=torch.float32, device=dev)
         colsum = torch.empty(f, dtype=torch.float32, device=dev) if want_colsum else None
-        check(lib().pp_spmm_act_backward_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(d), f, _p(z), _p(colsum), _p(dx), _stream()),
-              "pp_spmm_act_backward_f32")
+        check(lib().pp_spmm_act_backward_drop_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(d), f, _p(z), _p(colsum), _p(dx), dp, dseed, dtag, drow0,
+                                                  _stream()), "pp_spmm_act_backward_drop_f32")
     return dx, colsum
+
+
+def _drop_args(drop):
+    if drop is None:
+        return 0.0, 0, 0, 0
+    p, seed, tag, row0 = drop
+    return float(p), int(seed), int(tag), int(row0)
+
+
+def gcn_drop_supported(p: int, q: int) -> bool:
+    """Layer shapes whose fused kernels take the ``drop`` argument (16/32/64 and the 128-wide shapes)."""
+    return bool(lib().pp_gcn_drop_supported(int(p), int(q)))
 
 
 def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, n_rows: int, x: torch.Tensor,
                 self_coef: torch.Tensor | None, weight: torch.Tensor, bias: torch.Tensor | None, act: bool, want_agg: bool = False,
-                heavy: HeavyRows | None = None, out: torch.Tensor | None = None):
+                heavy: HeavyRows | None = None, out: torch.Tensor | None = None, drop: tuple | None = None):
     """``act((A x + diag(self_coef) x) @ weight.T + bias)`` in one kernel (aggregation fused with the MFMA product);
     ``want_agg``: returns ``(y, A x + diag(self_coef) x)``.  ``out``: a contiguous ``[n_rows, Q]`` fp32 tensor to write ``y`` into
-    (e.g. the head of a buffer whose tail receives halo rows)."""
+    (e.g. the head of a buffer whose tail receives halo rows).  ``drop = (p, seed, tag, row0)``: training-mode dropout of ``y`` fused into
+    the epilogue (counter-based mask of :func:`dropout`; needs :func:`gcn_drop_supported`)."""
     dev = require_device(ptr, idx, val, x, self_coef, weight, bias)
+    dp, dseed, dtag, drow0 = _drop_args(drop)
     x, weight = x.contiguous(), weight.contiguous()
     q, p = weight.shape
     if x.size(1) != p:
@@ -784,17 +799,21 @@ def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, 
             y = out
         agg = torch.empty((n_rows, p), dtype=torch.float32, device=dev) if want_agg else None
         slot, sums = _heavy_args(heavy, idx, val, x)
-        check(lib().pp_gcn_forward_f32(_p(ptr), _p(idx), _p(val), n_rows, x.size(0), _p(x), p, _p(self_coef), _p(weight), q, _p(bias),
-                                       1 if act else 0, _p(slot), _p(sums), _p(agg), _p(y), _stream()), "pp_gcn_forward_f32")
+        check(lib().pp_gcn_forward_drop_f32(_p(ptr), _p(idx), _p(val), n_rows, x.size(0), _p(x), p, _p(self_coef), _p(weight), q, _p(bias),
+                                            1 if act else 0, _p(slot), _p(sums), _p(agg), _p(y), dp, dseed, dtag, drow0, _stream()),
+              "pp_gcn_forward_drop_f32")
     return (y, agg) if want_agg else y
 
 
 def gcn_backward(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, x: torch.Tensor, weight: torch.Tensor, fuse_act: bool,
-                 want_colsum: bool, heavy: HeavyRows | None = None, n_self: int | None = None):
+                 want_colsum: bool, heavy: HeavyRows | None = None, n_self: int | None = None, drop: tuple | None = None):
     """Backward of :func:`gcn_forward` in one kernel: ``(d_in, colsum_in or None, dW)`` from the gradient ``dpre`` w.r.t. the
     layer's pre-activation, over the SOURCE-major CSR (``ptr``/``idx``/``val`` = the plan's ``bwd_*`` arrays).
-    ``n_self`` (default ``n_rows``): partition plans — ``n_rows`` = owned + halo source rows, ``dpre`` has the ``n_self`` owned rows."""
+    ``n_self`` (default ``n_rows``): partition plans — ``n_rows`` = owned + halo source rows, ``dpre`` has the ``n_self`` owned rows.
+    ``drop = (p, seed, tag, row0)`` (with ``fuse_act``): ``x`` is the DROPPED activation of the layer below; its mask and ``1 / (1 - p)`` go
+    into ``d_in`` together with the ELU'."""
     dev = require_device(ptr, idx, val, dpre, self_coef, x, weight)
+    dp, dseed, dtag, drow0 = _drop_args(drop)
     dpre, x, weight = dpre.contiguous(), x.contiguous(), weight.contiguous()
     m, k = weight.shape
     n_self = n_rows if n_self is None else int(n_self)
@@ -808,9 +827,9 @@ def gcn_backward(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, x: t
         dw = torch.empty((m, k), **f32)
         slot, sums = _heavy_args(heavy, idx, val, dpre)
         ws = _workspace(L.pp_gcn_backward_ws_bytes(n_rows), dev)
-        check(L.pp_gcn_backward_f32(_p(ptr), _p(idx), _p(val), n_rows, n_self, _p(dpre), m, _p(self_coef), _p(x), k, _p(weight),
-                                    1 if fuse_act else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _p(dw), _p(ws), ws.numel(), _stream()),
-              "pp_gcn_backward_f32")
+        check(L.pp_gcn_backward_drop_f32(_p(ptr), _p(idx), _p(val), n_rows, n_self, _p(dpre), m, _p(self_coef), _p(x), k, _p(weight),
+                                         1 if fuse_act else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _p(dw), _p(ws), ws.numel(), dp, dseed, dtag,
+                                         drow0, _stream()), "pp_gcn_backward_drop_f32")
     return d_in, colsum, dw
 
 
@@ -820,10 +839,11 @@ def gcn_fused_supported(p: int, q: int) -> int:
 
 
 def gcn_input_grad(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, weight: torch.Tensor, x_act: torch.Tensor | None,
-                   want_colsum: bool, heavy: HeavyRows | None = None, n_self: int | None = None):
+                   want_colsum: bool, heavy: HeavyRows | None = None, n_self: int | None = None, drop: tuple | None = None):
     """``((A^T dpre + diag(self_coef) dpre) @ weight) * elu'(x_act)`` (no activation factor when ``x_act`` is None) and optionally its
-    column sums, over the SOURCE-major CSR — the input gradient of a 128-wide fused layer."""
+    column sums, over the SOURCE-major CSR — the input gradient of a 128-wide fused layer (``drop``: as in :func:`gcn_backward`)."""
     dev = require_device(ptr, idx, val, dpre, self_coef, weight, x_act)
+    dp, dseed, dtag, drow0 = _drop_args(drop)
     dpre, weight = dpre.contiguous(), weight.contiguous()
     m, k = weight.shape
     n_self = n_rows if n_self is None else int(n_self)
@@ -837,9 +857,9 @@ def gcn_input_grad(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, we
         colsum = torch.empty(k, dtype=torch.float32, device=dev) if want_colsum else None
         slot, sums = _heavy_args(heavy, idx, val, dpre)
         ws = _workspace(L.pp_wide_layer_ws_bytes(m, k), dev)              # (only the shapes with a side of 256 use it: W^T)
-        check(L.pp_gcn_input_grad_f32(_p(ptr), _p(idx), _p(val), n_rows, n_self, _p(dpre), m, _p(self_coef), _p(weight), k, _p(x_act),
-                                      1 if x_act is not None else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _p(ws), ws.numel(), _stream()),
-              "pp_gcn_input_grad_f32")
+        check(L.pp_gcn_input_grad_drop_f32(_p(ptr), _p(idx), _p(val), n_rows, n_self, _p(dpre), m, _p(self_coef), _p(weight), k, _p(x_act),
+                                           1 if x_act is not None else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _p(ws), ws.numel(), dp, dseed,
+                                           dtag, drow0, _stream()), "pp_gcn_input_grad_drop_f32")
     return d_in, colsum
 
 

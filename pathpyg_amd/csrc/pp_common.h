@@ -166,6 +166,31 @@ __device__ __forceinline__ float buf_load_f32(buf_t r, uint32_t off) { return __
 __device__ __forceinline__ int lane_read_i(int addr4, int v) { return __builtin_amdgcn_ds_bpermute(addr4, v); }
 __device__ __forceinline__ float lane_read_f(int addr4, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr4, __builtin_bit_cast(int, v))); }
 
+// Counter-based dropout (pp_dropout_f32 and the fused layer epilogues): keep(row, col) is a pure function of (seed, call site, GLOBAL row id,
+// column) — two multiply-xorshift rounds on 32 bits, the same arithmetic as pathpyg_amd.nn.sharded.dropout_mask, bit for bit.  No mask
+// tensor exists: the backward pass regenerates the decision, and every rank of a partitioned run derives the same one for the same row.
+struct DropSite {
+    uint32_t key, thr;       // thr == 0: no dropout at this site
+    float scale, keep;       // 1 / (1 - p), 1 - p
+    int64_t row0;            // global id of the matrix's first row
+};
+__device__ __forceinline__ bool dropout_keep(int64_t row, int col, int width, uint32_t key, uint32_t threshold) {
+    const uint64_t idx = (uint64_t)row * (uint64_t)width + (uint64_t)col;
+    uint32_t x = (uint32_t)idx * 2654435761u + (uint32_t)(idx >> 32) * 40503u + key;
+    x = ((x >> 16) ^ x) * 0x45D9F3Bu;
+    x = ((x >> 16) ^ x) * 0x45D9F3Bu;
+    x = (x >> 16) ^ x;
+    return x >= threshold;
+}
+static inline uint32_t dropout_key(int64_t seed, int64_t tag) {
+    return (uint32_t)(((uint64_t)seed * 0x9E3779B1ull + (uint64_t)tag * 0x85EBCA6Bull + 0x27D4EB2Full) & 0xFFFFFFFFull);
+}
+static inline DropSite drop_site(double p, int64_t seed, int64_t tag, int64_t row0) {
+    DropSite d{0u, 0u, 1.f, 1.f, row0};
+    if (p > 0.0) { d.key = dropout_key(seed, tag); d.thr = (uint32_t)(p * 4294967296.0); d.scale = (float)(1.0 / (1.0 - p)); d.keep = (float)(1.0 - p); }
+    return d;
+}
+
 // Rows of a CSR with very many entries (hubs of a scale-free graph) are not walked by the lane group that owns the row: a pre-pass
 // (pp_spmm_heavy_f32) sums them chunk-wise with whole workgroups; the row kernels read the finished sum instead.
 struct HeavyRows {

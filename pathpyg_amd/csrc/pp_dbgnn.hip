@@ -333,18 +333,6 @@ __global__ __launch_bounds__(kBlock) void k_act_backward(const float* __restrict
 }
 
 // ------------------------------------------------------------------ dropout with counter-based masks
-// keep(row, col) is a pure function of (seed, tag, GLOBAL row id, column): two multiply-xorshift rounds on 32 bits (the same arithmetic as
-// pathpyg_amd.nn.sharded.dropout_mask, bit for bit).  No mask tensor exists: the backward pass regenerates it, and every rank of a
-// partitioned run derives the same decision for the same row.
-__device__ __forceinline__ bool dropout_keep(int64_t row, int col, int width, uint32_t key, uint32_t threshold) {
-    const uint64_t idx = (uint64_t)row * (uint64_t)width + (uint64_t)col;
-    uint32_t x = (uint32_t)idx * 2654435761u + (uint32_t)(idx >> 32) * 40503u + key;
-    x = ((x >> 16) ^ x) * 0x45D9F3Bu;
-    x = ((x >> 16) ^ x) * 0x45D9F3Bu;
-    x = (x >> 16) ^ x;
-    return x >= threshold;
-}
-
 // out = x * keep / (1 - p)      (x may alias out)
 __global__ __launch_bounds__(kBlock) void k_dropout(const float* __restrict__ X, int64_t n_rows, int F, uint32_t key, uint32_t threshold, float scale,
                                                    int64_t row0, const int64_t* __restrict__ rows, float* __restrict__ out) {
@@ -402,11 +390,12 @@ __global__ __launch_bounds__(kBlock) void k_scale_rows(const float* __restrict__
 // gradient of the layer that produced it: one pass (gather D, read Z, write dX) instead of SpMM + a three-pass ELU backward.
 // Persistent lane groups (kLanes = F/4 lanes per row, one float4 each) keep their column sums in registers; one LDS fold and
 // F atomics per workgroup at the end.
-template <int kLanes>
+// kDrop: Z is the DROPPED activation (dropout site `drop`): the mask, 1 / (1 - p) and ELU' at Z * (1 - p) go into dX.
+template <int kLanes, bool kDrop = false>
 __global__ __launch_bounds__(kBlock) void k_spmm_act_backward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                              const float* __restrict__ val, int64_t n_rows, const float* __restrict__ D,
                                                              int F, const float* __restrict__ Z, float* __restrict__ colsum,
-                                                             float* __restrict__ dX) {
+                                                             float* __restrict__ dX, DropSite drop) {
     constexpr int kGroups = kBlock / kLanes;
     __shared__ float s_col[kGroups][kLanes * 4 + 4];
     const int g = threadIdx.x / kLanes, l = threadIdx.x % kLanes;
@@ -426,8 +415,17 @@ __global__ __launch_bounds__(kBlock) void k_spmm_act_backward(const int32_t* __r
             acc.x += v0 * x0.x + v1 * x1.x; acc.y += v0 * x0.y + v1 * x1.y;
             acc.z += v0 * x0.z + v1 * x1.z; acc.w += v0 * x0.w + v1 * x1.w;
         }
-        acc.x *= z.x > 0.f ? 1.f : z.x + 1.f; acc.y *= z.y > 0.f ? 1.f : z.y + 1.f;
-        acc.z *= z.z > 0.f ? 1.f : z.z + 1.f; acc.w *= z.w > 0.f ? 1.f : z.w + 1.f;
+        float4 zz = z;
+        if constexpr (kDrop) {
+            const int64_t gr = drop.row0 + r;
+            acc.x = dropout_keep(gr, 4 * l, F, drop.key, drop.thr) ? acc.x * drop.scale : 0.f;
+            acc.y = dropout_keep(gr, 4 * l + 1, F, drop.key, drop.thr) ? acc.y * drop.scale : 0.f;
+            acc.z = dropout_keep(gr, 4 * l + 2, F, drop.key, drop.thr) ? acc.z * drop.scale : 0.f;
+            acc.w = dropout_keep(gr, 4 * l + 3, F, drop.key, drop.thr) ? acc.w * drop.scale : 0.f;
+            zz = make_float4(z.x * drop.keep, z.y * drop.keep, z.z * drop.keep, z.w * drop.keep);
+        }
+        acc.x *= zz.x > 0.f ? 1.f : zz.x + 1.f; acc.y *= zz.y > 0.f ? 1.f : zz.y + 1.f;
+        acc.z *= zz.z > 0.f ? 1.f : zz.z + 1.f; acc.w *= zz.w > 0.f ? 1.f : zz.w + 1.f;
         part.x += acc.x; part.y += acc.y; part.z += acc.z; part.w += acc.w;
         *(float4*)(dX + r * F + 4 * l) = acc;
     }
@@ -803,10 +801,18 @@ int pp_act_backward_f32(const float* dY, const float* Y, int64_t n_rows, int F, 
 
 int pp_spmm_act_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int F, const float* Z,
                              float* colsum, float* dX, pp_stream_t stream) {
+    return pp_spmm_act_backward_drop_f32(ptr, idx, val, n_rows, D, F, Z, colsum, dX, 0.0, 0, 0, 0, stream);
+}
+
+int pp_spmm_act_backward_drop_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, const float* D, int F, const float* Z,
+                                  float* colsum, float* dX, double drop_p, int64_t drop_seed, int64_t drop_tag, int64_t drop_row0,
+                                  pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_spmm_act_backward_f32: negative size");
     PP_REQUIRE(F >= 4 && F % 4 == 0 && F <= 256, PP_ERR_ARG, "pp_spmm_act_backward_f32: F must be a multiple of 4 in [4, 256]");
     PP_REQUIRE(((uintptr_t)D | (uintptr_t)Z | (uintptr_t)dX) % 16 == 0, PP_ERR_ARG, "pp_spmm_act_backward_f32: 16-byte alignment");
+    PP_REQUIRE(drop_p >= 0.0 && drop_p < 1.0, PP_ERR_ARG, "pp_spmm_act_backward_drop_f32: p must lie in [0, 1)");
+    const DropSite drop = drop_site(drop_p, drop_seed, drop_tag, drop_row0);
     if (colsum) PP_HIP(hipMemsetAsync(colsum, 0, (size_t)F * sizeof(float), st));
     if (n_rows == 0) return PP_OK;
     const int q = F / 4;
@@ -814,7 +820,8 @@ int pp_spmm_act_backward_f32(const int32_t* ptr, const int32_t* idx, const float
     do {                                                                                                                \
         int64_t blocks = ceil_div(n_rows, kBlock / L);                                                                  \
         if (blocks > kMaxGrid) blocks = kMaxGrid;                                                                       \
-        k_spmm_act_backward<L><<<(unsigned)blocks, kBlock, 0, st>>>(ptr, idx, val, n_rows, D, F, Z, colsum, dX);        \
+        if (drop.thr != 0u) k_spmm_act_backward<L, true><<<(unsigned)blocks, kBlock, 0, st>>>(ptr, idx, val, n_rows, D, F, Z, colsum, dX, drop);  \
+        else k_spmm_act_backward<L, false><<<(unsigned)blocks, kBlock, 0, st>>>(ptr, idx, val, n_rows, D, F, Z, colsum, dX, drop);                \
     } while (0)
     if (q <= 1) PP_SAB(1);
     else if (q <= 2) PP_SAB(2);
@@ -835,10 +842,6 @@ int pp_scale_rows_f32(const float* X, const float* coef, int64_t n_rows, int F, 
     k_scale_rows<<<(unsigned)ceil_div(total, kBlock), kBlock, 0, st>>>(X, coef, n_rows, F, out);
     PP_LAUNCH_CHECK();
     return PP_OK;
-}
-
-static inline uint32_t dropout_key(int64_t seed, int64_t tag) {
-    return (uint32_t)(((uint64_t)seed * 0x9E3779B1ull + (uint64_t)tag * 0x85EBCA6Bull + 0x27D4EB2Full) & 0xFFFFFFFFull);
 }
 
 int pp_dropout_f32(const float* X, int64_t n_rows, int F, double p, int64_t seed, int64_t tag, int64_t row0, const int64_t* rows, float* out,

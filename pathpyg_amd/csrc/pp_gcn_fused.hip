@@ -196,13 +196,14 @@ struct TileGather {
 // takes 64 KB of LDS there: one workgroup of 8 waves per CU).  kEpi 0: Y = act(tile . W^T + bias), W [Q,P] (the layer, forward).
 // kEpi 1: Y = (tile . W) (*) ELU'(act_in), W [P,Q], + column sums: the INPUT GRADIENT of a layer over the transposed graph (X = dpre) for
 // the widths whose weight gradient does not fit beside it in registers (pp_gcn_input_grad_f32).
-template <int P, int Q, bool kHeavy, bool kWide, int kThreads = kGcnThreads, int kEpi = 0>
+template <int P, int Q, bool kHeavy, bool kWide, int kThreads = kGcnThreads, int kEpi = 0, bool kDrop = false>
 __global__ __launch_bounds__(kThreads) void k_gcn_forward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                               const float* __restrict__ val, int64_t n_rows, const float* __restrict__ X,
                                                               const float* __restrict__ self_coef, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int act, HeavyRows heavy,
                                                               float* __restrict__ agg_out, float* __restrict__ Y,
-                                                              const float* __restrict__ act_in, float* __restrict__ colsum, int64_t n_self) {
+                                                              const float* __restrict__ act_in, float* __restrict__ colsum, int64_t n_self,
+                                                              DropSite drop) {
     constexpr int kLanes = P / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = P / 4, CT = Q / 16, TS = P + 4;
     constexpr int kBatch = kRows < 2 ? kRows : (kRows >= 8 ? 4 : 2);      // 128-wide rows: 2 waves/SIMD, registers to spare for a deeper gather
     constexpr int kWaves = kThreads / kWave;
@@ -402,7 +403,12 @@ __global__ __launch_bounds__(kThreads) void k_gcn_forward(const int32_t* __restr
                 for (int ct = 0; ct < CT; ++ct) {
                     y[ct] = out[ct][reg];
                     if (act) {
-                        const float s = xr[ct][reg];
+                        float s = xr[ct][reg];
+                        if constexpr (kDrop) {                         // act_in is the DROPPED activation: y = act_in * (1 - p) where kept
+                            const bool kept = dropout_keep(drop.row0 + t * 16 + 4 * kq + reg, CT * i + ct, Q, drop.key, drop.thr);
+                            s *= drop.keep;
+                            y[ct] *= kept ? drop.scale : 0.f;
+                        }
                         y[ct] *= s > 0.f ? 1.f : s + 1.f;              // ELU'(pre) from the stored activation
                     }
                     col_in[ct] += y[ct];                               // rows past the end aggregate nothing: 0 there
@@ -419,6 +425,13 @@ __global__ __launch_bounds__(kThreads) void k_gcn_forward(const int32_t* __restr
                         const float v = out[ct][reg] + bias_c[ct];
                         y[ct] = act ? elu_fast(v) : v;
                     }
+                }
+            }
+            if constexpr (kEpi == 0 && kDrop) {
+                {                                                      // dropout of the layer OUTPUT (the next layer's input dropout), fused
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        y[ct] = dropout_keep(drop.row0 + t * 16 + 4 * kq + reg, CT * i + ct, Q, drop.key, drop.thr) ? y[ct] * drop.scale : 0.f;
                 }
             }
             if (reg < rows_here) {
@@ -454,6 +467,7 @@ struct GcnArgs {
     const float* act_in;
     float* colsum;
     int64_t n_self;          // rows with a self term (rectangular partition plans: the owned rows come first, halo rows have none)
+    DropSite drop;           // kEpi 0: dropout of Y; kEpi 1: the dropout that produced act_in (thr == 0: none)
 };
 
 template <int P, int Q, int kEpi>
@@ -473,8 +487,14 @@ static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const GcnArgs& a)
     int64_t blocks = ceil_div(n_tiles, kThreads / kWave);
     if (blocks > resident) blocks = resident;
 #define PP_FWD(H, WIDE)                                                                                                                  \
-    k_gcn_forward<P, Q, H, WIDE, kThreads, kEpi><<<(unsigned)blocks, kThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n, a.X, a.self_coef, a.W, a.bias, \
-                                                                                         a.act, a.heavy, a.agg_out, a.Y, a.act_in, a.colsum, a.n_self)
+    do {                                                                                                                                  \
+        if (a.drop.thr != 0u)                                                                                                             \
+            k_gcn_forward<P, Q, H, WIDE, kThreads, kEpi, true><<<(unsigned)blocks, kThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n, a.X, a.self_coef, a.W, \
+                a.bias, a.act, a.heavy, a.agg_out, a.Y, a.act_in, a.colsum, a.n_self, a.drop);                                           \
+        else                                                                                                                              \
+            k_gcn_forward<P, Q, H, WIDE, kThreads, kEpi, false><<<(unsigned)blocks, kThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n, a.X, a.self_coef, a.W, \
+                a.bias, a.act, a.heavy, a.agg_out, a.Y, a.act_in, a.colsum, a.n_self, a.drop);                                           \
+    } while (0)
     if (a.heavy.slot != nullptr) { if (a.wide) PP_FWD(true, true); else PP_FWD(true, false); }
     else { if (a.wide) PP_FWD(false, true); else PP_FWD(false, false); }
 #undef PP_FWD
@@ -511,12 +531,12 @@ static inline bool gcn_wide_shape(int P, int Q) {
 //     d_in   = (G . W) (*) ELU'(x),  colsum_in = column sums    gradient w.r.t. the PRE-activation of the layer below + its bias gradient
 //     dW     = G^T x                                             contraction over the tile's rows on a second MFMA stream
 // Saves the write and the re-read of G (2 of the 7 N x 64 matrix passes of the two-kernel form).
-template <int M, int K, bool kHeavy, bool kWide>
+template <int M, int K, bool kHeavy, bool kWide, bool kDrop = false>
 __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                              const float* __restrict__ val, int64_t n_rows, const float* __restrict__ D,
                                                              const float* __restrict__ self_coef, const float* __restrict__ X,
                                                              const float* __restrict__ W, int fuse_act, HeavyRows heavy, float* __restrict__ d_in,
-                                                             float* __restrict__ colsum_in, float* __restrict__ partial_w, int64_t n_self) {
+                                                             float* __restrict__ colsum_in, float* __restrict__ partial_w, int64_t n_self, DropSite drop) {
     constexpr int kLanes = M / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, KQ = M / 4, MT = M / 16, CT = K / 16, TS = M + 4;
     constexpr int kBatch = kRows < 2 ? kRows : 2;
     using off_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;     // byte offset of a gathered row
@@ -701,7 +721,12 @@ __global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __r
             for (int ct = 0; ct < CT; ++ct) {
                 v[ct] = out[ct][reg];
                 if (fuse_act) {
-                    const float y = xr[ct][reg];
+                    float y = xr[ct][reg];
+                    if constexpr (kDrop) {                             // X is the DROPPED activation of the layer below: y = X * (1 - p) where kept
+                        const bool kept = dropout_keep(drop.row0 + t * 16 + 4 * kq + reg, CT * i + ct, K, drop.key, drop.thr);
+                        y *= drop.keep;
+                        v[ct] *= kept ? drop.scale : 0.f;
+                    }
                     v[ct] *= y > 0.f ? 1.f : y + 1.f;
                 }
                 col_in[ct] += v[ct];                                  // rows past the end aggregate nothing: v == 0 there
@@ -743,7 +768,7 @@ constexpr int64_t kGcnBackwardMaxBlocks = 256 * 4;
 template <int M, int K>
 static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
                                const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy, bool wide,
-                               float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out, int64_t n_self) {
+                               float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out, int64_t n_self, DropSite drop) {
     static int resident_of[2] = {0, 0};
     const int hv = heavy.slot != nullptr ? 1 : 0;
     if (resident_of[hv] == 0) {
@@ -759,7 +784,15 @@ static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* p
     int64_t blocks = ceil_div(n_tiles, kGcnWaves);
     if (blocks > resident) blocks = resident;
     *blocks_out = blocks;
-#define PP_BWD(H, WIDE) k_gcn_backward<M, K, H, WIDE><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, colsum_in, partial_w, n_self)
+#define PP_BWD(H, WIDE)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (drop.thr != 0u)                                                                                                               \
+            k_gcn_backward<M, K, H, WIDE, true><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, \
+                                                                                          colsum_in, partial_w, n_self, drop);          \
+        else                                                                                                                              \
+            k_gcn_backward<M, K, H, WIDE, false><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, \
+                                                                                           colsum_in, partial_w, n_self, drop);         \
+    } while (0)
     if (heavy.slot != nullptr) { if (wide) PP_BWD(true, true); else PP_BWD(true, false); }
     else { if (wide) PP_BWD(false, true); else PP_BWD(false, false); }
 #undef PP_BWD
@@ -769,11 +802,11 @@ static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* p
 template <int M>
 static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
                                  const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy, bool wide,
-                                 float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out, int64_t n_self) {
+                                 float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out, int64_t n_self, DropSite drop) {
     switch (K) {
-        case 16: return launch_gcn_backward<M, 16>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self);
-        case 32: return launch_gcn_backward<M, 32>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self);
-        case 64: return launch_gcn_backward<M, 64>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self);
+        case 16: return launch_gcn_backward<M, 16>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self, drop);
+        case 32: return launch_gcn_backward<M, 32>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self, drop);
+        case 64: return launch_gcn_backward<M, 64>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self, drop);
         default: return PP_ERR_ARG;
     }
 }
@@ -786,11 +819,22 @@ static inline bool dense_exact(int P, int Q) { return (P == 16 || P == 32 || P =
 
 int pp_gcn_fused_supported(int P, int Q) { return dense_exact(P, Q) ? 1 : ((pp::gcn_wide_shape(P, Q) || pp_wide_layer_supported(P, Q)) ? 2 : 0); }
 
+int pp_gcn_drop_supported(int P, int Q) { return (dense_exact(P, Q) || pp::gcn_wide_shape(P, Q)) ? 1 : 0; }
+
 int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
                        const float* self_coef, const float* W, int Q, const float* bias, int act, const int32_t* heavy_slot, const float* heavy_sum,
                        float* agg_out, float* Y, pp_stream_t stream) {
+    return pp_gcn_forward_drop_f32(ptr, idx, val, n_rows, n_src, X, P, self_coef, W, Q, bias, act, heavy_slot, heavy_sum, agg_out, Y, 0.0, 0, 0, 0, stream);
+}
+
+int pp_gcn_forward_drop_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
+                            const float* self_coef, const float* W, int Q, const float* bias, int act, const int32_t* heavy_slot,
+                            const float* heavy_sum, float* agg_out, float* Y, double drop_p, int64_t drop_seed, int64_t drop_tag, int64_t drop_row0,
+                            pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_forward_f32: negative size");
+    PP_REQUIRE(drop_p >= 0.0 && drop_p < 1.0, PP_ERR_ARG, "pp_gcn_forward_drop_f32: p must lie in [0, 1)");
+    PP_REQUIRE(drop_p == 0.0 || pp_gcn_drop_supported(P, Q), PP_ERR_ARG, "pp_gcn_forward_drop_f32: no fused dropout for layer shape %dx%d", P, Q);
     PP_REQUIRE(pp_gcn_fused_supported(P, Q), PP_ERR_ARG, "pp_gcn_forward_f32: unsupported layer shape %dx%d (supported: 16/32/64 and 64/128/256)", P, Q);
     if (!dense_exact(P, Q) && !pp::gcn_wide_shape(P, Q))          // a side of 256: weights streamed through LDS (pp_gcn_wide.hip)
         return pp_wide_layer_f32(ptr, idx, val, n_rows, n_rows, n_src, X, P, self_coef, W, 0, Q, bias, act, 0, nullptr, heavy_slot, heavy_sum, agg_out, Y,
@@ -802,7 +846,8 @@ int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val,
     const bool wide = (uint64_t)n_src * (uint64_t)P * 4 >= (uint64_t)pp::kBufOob || n_rows >= ((int64_t)1 << 30) - 64;
     if (n_rows == 0) return PP_OK;
     const int64_t n_tiles = pp::ceil_div(n_rows, 16);
-    const pp::GcnArgs a{ptr, idx, val, n_rows, X, self_coef, W, bias, act, pp::HeavyRows{heavy_slot, heavy_sum}, wide, agg_out, Y, nullptr, nullptr, n_rows};
+    const pp::GcnArgs a{ptr, idx, val, n_rows, X, self_coef, W, bias, act, pp::HeavyRows{heavy_slot, heavy_sum}, wide, agg_out, Y, nullptr, nullptr, n_rows,
+                        pp::drop_site(drop_p, drop_seed, drop_tag, drop_row0)};
     int rc;
     if (pp::gcn_wide_shape(P, Q)) rc = pp::launch_gcn_wide<0>(P, Q, n_tiles, st, a);
     else switch (P) {
@@ -818,7 +863,17 @@ int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val,
 int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
                           const float* self_coef, const float* W, int K, const float* X_act, int fuse_act, const int32_t* heavy_slot,
                           const float* heavy_sum, float* d_in, float* colsum_in, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    return pp_gcn_input_grad_drop_f32(ptr, idx, val, n_rows, n_self, D, M, self_coef, W, K, X_act, fuse_act, heavy_slot, heavy_sum, d_in, colsum_in, ws,
+                                      ws_bytes, 0.0, 0, 0, 0, stream);
+}
+
+int pp_gcn_input_grad_drop_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
+                               const float* self_coef, const float* W, int K, const float* X_act, int fuse_act, const int32_t* heavy_slot,
+                               const float* heavy_sum, float* d_in, float* colsum_in, void* ws, size_t ws_bytes, double drop_p, int64_t drop_seed,
+                               int64_t drop_tag, int64_t drop_row0, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(drop_p >= 0.0 && drop_p < 1.0, PP_ERR_ARG, "pp_gcn_input_grad_drop_f32: p must lie in [0, 1)");
+    PP_REQUIRE(drop_p == 0.0 || (fuse_act && pp::gcn_wide_shape(M, K)), PP_ERR_ARG, "pp_gcn_input_grad_drop_f32: fused dropout needs fuse_act and a 128-wide shape");
     PP_REQUIRE(n_rows >= 0 && n_self >= 0 && n_self <= n_rows, PP_ERR_ARG, "pp_gcn_input_grad_f32: bad sizes");
     PP_REQUIRE(pp_gcn_fused_supported(M, K) == 2, PP_ERR_ARG, "pp_gcn_input_grad_f32: unsupported layer shape %dx%d (64/128/256 with a side > 64)", M, K);
     if (!pp::gcn_wide_shape(M, K))
@@ -832,7 +887,7 @@ int pp_gcn_input_grad_f32(const int32_t* ptr, const int32_t* idx, const float* v
     if (n_rows == 0) return PP_OK;
     const int64_t n_tiles = pp::ceil_div(n_rows, 16);
     const pp::GcnArgs a{ptr, idx, val, n_rows, D, self_coef, W, nullptr, fuse_act ? 1 : 0, pp::HeavyRows{heavy_slot, heavy_sum}, wide, nullptr, d_in,
-                        X_act, colsum_in, n_self};
+                        X_act, colsum_in, n_self, pp::drop_site(drop_p, drop_seed, drop_tag, drop_row0)};
     const int rc = pp::launch_gcn_wide<1>(M, K, n_tiles, st, a);
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();
@@ -848,7 +903,18 @@ size_t pp_gcn_backward_ws_bytes(int64_t n_rows) {
 int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
                         const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
                         const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    return pp_gcn_backward_drop_f32(ptr, idx, val, n_rows, n_self, D, M, self_coef, X, K, W, fuse_act, heavy_slot, heavy_sum, d_in, colsum_in, dW, ws,
+                                    ws_bytes, 0.0, 0, 0, 0, stream);
+}
+
+int pp_gcn_backward_drop_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
+                             const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
+                             const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, double drop_p,
+                             int64_t drop_seed, int64_t drop_tag, int64_t drop_row0, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(drop_p >= 0.0 && drop_p < 1.0, PP_ERR_ARG, "pp_gcn_backward_drop_f32: p must lie in [0, 1)");
+    PP_REQUIRE(drop_p == 0.0 || fuse_act, PP_ERR_ARG, "pp_gcn_backward_drop_f32: the fused dropout belongs to the activation below (fuse_act)");
+    const pp::DropSite drop = pp::drop_site(drop_p, drop_seed, drop_tag, drop_row0);
     PP_REQUIRE(n_rows >= 0 && n_self >= 0 && n_self <= n_rows, PP_ERR_ARG, "pp_gcn_backward_f32: bad sizes");
     PP_REQUIRE(pp_dense_supported(M, K), PP_ERR_ARG, "pp_gcn_backward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", M, K);
     PP_REQUIRE(d_in != nullptr && dW != nullptr, PP_ERR_ARG, "pp_gcn_backward_f32: d_in and dW are required");
@@ -865,9 +931,9 @@ int pp_gcn_backward_f32(const int32_t* ptr, const int32_t* idx, const float* val
     int64_t blocks = 0;
     int rc;
     switch (M) {
-        case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self); break;
-        case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self); break;
-        default: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self); break;
+        case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop); break;
+        case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop); break;
+        default: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop); break;
     }
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();

@@ -125,8 +125,12 @@ class _GcnLayer(torch.autograd.Function):
                 and _hip.gcn_fused_supported(weight.size(1), weight.size(0)) > 0)
 
     @staticmethod
-    def forward(ctx, plan, x, weight, bias, fuse_act: bool, act_bias):
+    def forward(ctx, plan, x, weight, bias, fuse_act: bool, act_bias, drop_in=None, drop_out=None):
+        """``drop_out = (p, seed, tag, row0)``: the dropout that follows this layer's ELU, applied in the kernel's epilogue (``y`` leaves
+        the kernel dropped).  ``drop_in`` (with ``fuse_act``): ``x`` is the DROPPED activation of the layer below; the backward kernel puts
+        its mask, ``1 / (1 - p)`` and the ELU' at ``x * (1 - p)`` into the gradient it hands down."""
         ctx.plan, ctx.fuse_act, ctx.has_act_bias = plan, fuse_act, act_bias is not None
+        ctx.drop_in = drop_in if fuse_act else None
         # first layer of a stack (its input needs no gradient): keep the aggregated input A x; the only gradient left is
         # dW = dpre^T (A x), so the backward pass needs no aggregation at all
         ctx.keep_agg = not ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
@@ -135,7 +139,7 @@ class _GcnLayer(torch.autograd.Function):
         ctx.wide = _hip.gcn_fused_supported(weight.size(1), weight.size(0)) == 2
         want_agg = ctx.keep_agg or (ctx.wide and ctx.needs_input_grad[2])
         out = _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x, plan.self_coef, weight, bias, True, want_agg,
-                               heavy=plan.fwd_heavy)
+                               heavy=plan.fwd_heavy, drop=drop_out)
         if ctx.keep_agg:
             ctx.save_for_backward(out[1], weight)
             return out[0]
@@ -154,7 +158,7 @@ class _GcnLayer(torch.autograd.Function):
         if ctx.keep_agg:
             agg, weight = ctx.saved_tensors
             dw, _ = _hip.weight_grad(dpre, agg, want_bias=False)
-            return None, None, dw, None, None, None
+            return None, None, dw, None, None, None, None, None
         want_sum = ctx.fuse_act and ctx.has_act_bias and ctx.needs_input_grad[5]
         if ctx.wide:
             x, weight, agg = ctx.saved_tensors
@@ -162,17 +166,17 @@ class _GcnLayer(torch.autograd.Function):
                 dw, _ = _hip.weight_grad(dpre, agg, want_bias=False)
             if ctx.needs_input_grad[1]:
                 dx, dact = _hip.gcn_input_grad(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, weight,
-                                               x if ctx.fuse_act else None, want_sum, heavy=plan.bwd_heavy)
-            return None, dx, dw, None, None, dact
+                                               x if ctx.fuse_act else None, want_sum, heavy=plan.bwd_heavy, drop=ctx.drop_in)
+            return None, dx, dw, None, None, dact, None, None
         x, weight = ctx.saved_tensors
         if ctx.needs_input_grad[1]:
             # aggregation over the transposed graph, input gradient (+ ELU' and the bias gradient of the layer below) and dW: one kernel
             dx, dact, dw = _hip.gcn_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, x, weight,
-                                             ctx.fuse_act, want_sum, heavy=plan.bwd_heavy)
+                                             ctx.fuse_act, want_sum, heavy=plan.bwd_heavy, drop=ctx.drop_in)
         elif ctx.needs_input_grad[2]:
             g = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, dpre, heavy=plan.bwd_heavy)
             dw, _ = _hip.weight_grad(g, x, want_bias=False)
-        return None, dx, dw, None, None, dact
+        return None, dx, dw, None, None, dact, None, None
 
 
 class _AggregateAct(torch.autograd.Function):
@@ -181,8 +185,9 @@ class _AggregateAct(torch.autograd.Function):
     gradient of ``act_bias``) from one kernel (``pp_spmm_act_backward_f32``)."""
 
     @staticmethod
-    def forward(ctx, plan, y, act_bias):
-        ctx.plan, ctx.has_act_bias = plan, act_bias is not None
+    def forward(ctx, plan, y, act_bias, drop=None):
+        """``drop = (p, seed, tag, row0)``: ``y`` was stored DROPPED by its producer's epilogue; the backward kernel applies the mask too."""
+        ctx.plan, ctx.has_act_bias, ctx.drop = plan, act_bias is not None, drop
         ctx.save_for_backward(y)
         return _hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, y, heavy=plan.fwd_heavy)
 
@@ -191,8 +196,8 @@ class _AggregateAct(torch.autograd.Function):
         plan = ctx.plan
         (y,) = ctx.saved_tensors
         want_sum = ctx.has_act_bias and ctx.needs_input_grad[2]
-        dpre, colsum = _hip.spmm_act_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d_agg.contiguous(), y, want_sum)
-        return None, dpre, colsum
+        dpre, colsum = _hip.spmm_act_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d_agg.contiguous(), y, want_sum, ctx.drop)
+        return None, dpre, colsum, None
 
 
 class _ActBoundary(torch.autograd.Function):
@@ -236,8 +241,9 @@ class _DropAct(torch.autograd.Function):
     column sums to ``act_bias``."""
 
     @staticmethod
-    def forward(ctx, y, act_bias, p: float, seed: int, tag: int, row0: int, rows, act: bool):
-        out = _hip.dropout(y, p, seed, tag, row0, rows)
+    def forward(ctx, y, act_bias, p: float, seed: int, tag: int, row0: int, rows, act: bool, applied: bool = False):
+        # applied: the producing kernel dropped `y` already (fused epilogue): identity forward, the same backward
+        out = y.view_as(y) if applied else _hip.dropout(y, p, seed, tag, row0, rows)
         ctx.args = (p, seed, tag, row0, rows, act)
         ctx.has_bias = act_bias is not None
         ctx.save_for_backward(out if act else None)
@@ -249,7 +255,7 @@ class _DropAct(torch.autograd.Function):
         (dropped,) = ctx.saved_tensors
         want = act and ctx.has_bias and ctx.needs_input_grad[1]
         dpre, dbias = _hip.dropout_act_backward(d_out, dropped, p, seed, tag, row0, rows, act, want)
-        return dpre, dbias, None, None, None, None, None, None
+        return dpre, dbias, None, None, None, None, None, None, None
 
 
 def _draw_seed() -> int:
@@ -442,25 +448,43 @@ class DBGNN(Module):
             # backward of the layer underneath (_DropAct: counter-based masks, no mask tensor).
             p, seed = self.p_dropout, _draw_seed()
 
-            def stack_drop(layers, h, plan, tag, out_tag):
-                pending_bias, contract = None, False              # `h` is raw input first, then a fused layer's activation (grad_is_pre contract)
+            def stack_drop(layers, h, plan, tag, out_tag, finish=True):
+                # `h` is raw input first, then a layer's activation.  contract: its producer wants the gradient w.r.t. its pre-activation;
+                # applied: the producer's epilogue dropped `h` already (site tag + i), so the dropout costs no pass in either direction
+                pending_bias, contract, applied = None, False, False
                 for i, layer in enumerate(layers):
-                    h = _DropAct.apply(h, pending_bias, p, seed, tag + i, 0, None, contract)
-                    if _GcnLayer.supported(plan, h, layer.lin.weight):
-                        h, pending_bias, contract = _GcnLayer.apply(plan, h, layer.lin.weight, layer.bias, False, None), layer.bias, True
+                    weight = layer.lin.weight
+                    site_in = (p, seed, tag + i, 0)
+                    site_out = (p, seed, tag + i + 1 if i + 1 < len(layers) else out_tag, 0)
+                    fused = _GcnLayer.supported(plan, h, weight)
+                    in_kernel = fused and _hip.gcn_drop_supported(weight.size(1), weight.size(0))
+                    if applied and in_kernel:
+                        h = _GcnLayer.apply(plan, h, weight, layer.bias, True, pending_bias, site_in, site_out)
+                        pending_bias, contract, applied = layer.bias, True, True
+                        continue
+                    h = _DropAct.apply(h, pending_bias, *site_in, None, contract, applied)
+                    if fused:
+                        h = _GcnLayer.apply(plan, h, weight, layer.bias, False, None, None, site_out if in_kernel else None)
+                        pending_bias, contract, applied = layer.bias, True, in_kernel
                     else:
-                        h, pending_bias, contract = _Propagate.apply(plan, dense(h, layer.lin), None, layer.bias, True), None, False
-                return _DropAct.apply(h, pending_bias, p, seed, out_tag, 0, None, contract)
+                        h, pending_bias, contract, applied = _Propagate.apply(plan, dense(h, layer.lin), None, layer.bias, True), None, False, False
+                if not finish and contract and applied:            # the consumer's backward kernel takes the out_tag mask itself
+                    return h, pending_bias
+                return _DropAct.apply(h, pending_bias, p, seed, out_tag, 0, None, contract, applied), None
 
-            x = stack_drop(self.first_order_layers, x, plan_fo, TAG_FO, TAG_FO_OUT)
-            x_h = stack_drop(self.higher_order_layers, x_h, plan_ho, TAG_HO, TAG_HO_OUT)
+            x, _ = stack_drop(self.first_order_layers, x, plan_fo, TAG_FO, TAG_FO_OUT)
             bl = self.bipartite_layer
-            if plan_bi.fwd_val is None and x_h.size(1) % 4 == 0 and x_h.size(1) <= 256:
+            if plan_bi.fwd_val is None and self.higher_order_layers[-1].lin.weight.size(0) % 4 == 0 and self.higher_order_layers[-1].lin.weight.size(0) <= 256:
                 # sum_j (W1 x_h[j] + b1) = W1 (sum_j x_h[j]) + deg * b1, as below: the dense layers run on the N first-order rows only
-                agg = _Aggregate.apply(plan_bi, x_h)
+                x_h, pending_ho = stack_drop(self.higher_order_layers, x_h, plan_ho, TAG_HO, TAG_HO_OUT, finish=False)
+                if pending_ho is not None:
+                    agg = _AggregateAct.apply(plan_bi, x_h, pending_ho, (p, seed, TAG_HO_OUT, 0))
+                else:
+                    agg = _Aggregate.apply(plan_bi, x_h)
                 per_edge = dense(x, bl.lin2) + bl.lin1.bias
                 x = F.elu(torch.addcmul(_Dense.apply(agg, bl.lin1.weight, None, False, None), plan_bi.self_coef.unsqueeze(1), per_edge))
             else:
+                x_h, _ = stack_drop(self.higher_order_layers, x_h, plan_ho, TAG_HO, TAG_HO_OUT)
                 x = self.bipartite_layer((x_h, x), data.bipartite_edge_index, n_ho=n_ho, n_fo=n_fo, plan=plan_bi, activation=True)
             return dense(_DropAct.apply(x, None, p, seed, TAG_HEAD, 0, None, False), self.lin)
 

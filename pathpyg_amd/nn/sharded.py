@@ -54,24 +54,37 @@ class HipOps:
 
     # ---- one GCN layer on a (possibly rectangular) plan
     @staticmethod
-    def layer_forward(plan, x_full: torch.Tensor, weight: torch.Tensor, bias, first: bool, out: torch.Tensor):
+    def drop_fusable(weight: torch.Tensor) -> bool:
+        """Layer shapes whose fused kernels apply dropout in their epilogues (no extra pass)."""
+        k = weight.size(1)
+        return k % 4 == 0 and _hip.gcn_fused_supported(k, weight.size(0)) > 0 and _hip.gcn_drop_supported(k, weight.size(0))
+
+    @staticmethod
+    def layer_forward(plan, x_full: torch.Tensor, weight: torch.Tensor, bias, first: bool, out: torch.Tensor, drop=None):
         """``out[:] = ELU((A x_full + diag(self) x_full[:n_dst]) W^T + b)`` for the plan's ``n_dst`` destination rows; returns what
-        :meth:`layer_backward` wants to see again."""
+        :meth:`layer_backward` wants to see again.  ``drop = (p, seed, tag, row0)``: ``out`` leaves dropped (in the kernel's epilogue where
+        the shape allows, by one in-place pass otherwise)."""
         kind = _hip.gcn_fused_supported(weight.size(1), weight.size(0)) if x_full.size(1) % 4 == 0 else 0
+        in_kernel = drop is not None and HipOps.drop_fusable(weight)
         if kind:
             want_agg = first or kind == 2
             res = _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x_full, plan.self_coef, weight, bias, True, want_agg,
-                                   heavy=plan.fwd_heavy, out=out)
-            return res[1] if want_agg else None
-        t = F.linear(x_full, weight)                                   # widths without a fused kernel: library GEMM + CSR kernel
-        out.copy_(_hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, t, plan.self_coef, t, bias, True, heavy=plan.fwd_heavy))
-        return None
+                                   heavy=plan.fwd_heavy, out=out, drop=drop if in_kernel else None)
+            saved = res[1] if want_agg else None
+        else:
+            t = F.linear(x_full, weight)                               # widths without a fused kernel: library GEMM + CSR kernel
+            out.copy_(_hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, t, plan.self_coef, t, bias, True, heavy=plan.fwd_heavy))
+            saved = None
+        if drop is not None and not in_kernel:
+            _hip.dropout(out, drop[0], drop[1], drop[2], drop[3], None, out)
+        return saved
 
     @staticmethod
-    def layer_backward(plan, dpre: torch.Tensor, x_full: torch.Tensor, weight: torch.Tensor, saved, need_input_grad: bool, fuse_below):
+    def layer_backward(plan, dpre: torch.Tensor, x_full: torch.Tensor, weight: torch.Tensor, saved, need_input_grad: bool, fuse_below, drop=None):
         """Backward of :meth:`layer_forward` from the gradient w.r.t. its pre-activation: ``(d_lin [n_src, K] or None, colsum or None,
         dW)`` with ``d_lin = (A^T dpre + diag(self) dpre) W``.  ``fuse_below`` (world size 1 only): the layer input IS the stored
-        activation of the layer below — its ELU' and bias gradient are folded into the same kernel and ``d_lin`` is final."""
+        activation of the layer below — its ELU' and bias gradient are folded into the same kernel and ``d_lin`` is final; with
+        ``drop`` (needs :meth:`drop_fusable`) that activation was stored DROPPED and the mask goes into the same epilogue."""
         m, k = weight.shape
         kind = _hip.gcn_fused_supported(k, m) if k % 4 == 0 else 0
         fuse = fuse_below is not None
@@ -79,12 +92,12 @@ class HipOps:
             return None, None, _hip.weight_grad(dpre, saved, want_bias=False)[0]
         if kind == 1:
             d_lin, colsum, dw = _hip.gcn_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, x_full, weight,
-                                                  fuse, fuse, heavy=plan.bwd_heavy, n_self=plan.n_dst)
+                                                  fuse, fuse, heavy=plan.bwd_heavy, n_self=plan.n_dst, drop=drop if fuse else None)
             return (d_lin if need_input_grad else None), colsum, dw
         if kind == 2:
             dw = _hip.weight_grad(dpre, saved, want_bias=False)[0]
             d_lin, colsum = _hip.gcn_input_grad(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, plan.self_coef, weight,
-                                                fuse_below, fuse, heavy=plan.bwd_heavy, n_self=plan.n_dst)
+                                                fuse_below, fuse, heavy=plan.bwd_heavy, n_self=plan.n_dst, drop=drop if fuse else None)
             return d_lin, colsum, dw
         g = _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, heavy=plan.bwd_heavy)
         g[: plan.n_dst].addcmul_(dpre, plan.self_coef.unsqueeze(1))
@@ -107,10 +120,13 @@ class HipOps:
     spmm = staticmethod(_hip.spmm)
 
     @staticmethod
-    def spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum):
+    def spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum, drop=None):
         if d.size(1) % 4 == 0 and d.size(1) <= 256:
-            return _hip.spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum)
-        return _hip.act_backward(_hip.spmm(ptr, idx, val, n_rows, d), z, True, want_dpre=True, want_dbias=want_colsum)   # odd widths: two kernels
+            return _hip.spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum, drop)
+        g = _hip.spmm(ptr, idx, val, n_rows, d)                                                                          # odd widths: two kernels
+        if drop is not None:
+            return _hip.dropout_act_backward(g, z, drop[0], drop[1], drop[2], drop[3], None, True, want_colsum)
+        return _hip.act_backward(g, z, True, want_dpre=True, want_dbias=want_colsum)
 
     # ---- dense layers of the head (first-order rows only) and the loss
     # ---- dropout (counter-based masks keyed by the global row id: pp_dropout_f32 / pp_dropout_act_backward_f32)
@@ -118,11 +134,11 @@ class HipOps:
     dropout_act_backward = staticmethod(_hip.dropout_act_backward)
 
     @staticmethod
-    def drop_act(y, act_bias, p, seed, tag, row0, act: bool):
+    def drop_act(y, act_bias, p, seed, tag, row0, act: bool, applied: bool = False):
         """Autograd dropout of the owned rows ``row0 ..``; ``act``: ``y`` is a stored activation whose producer expects the gradient w.r.t. its
         pre-activation (see dbgnn._DropAct)."""
         from .dbgnn import _DropAct
-        return _DropAct.apply(y, act_bias, p, seed, tag, row0, None, act)
+        return _DropAct.apply(y, act_bias, p, seed, tag, row0, None, act, applied)
 
     @staticmethod
     def dense(x, linear, fuse_act: bool = False, act_bias=None):
@@ -206,7 +222,8 @@ class _ShardedGcnStack(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, shard: GraphShard, comm, ops, drop, x_full: torch.Tensor, *params):
-        """``drop``: None, or ``(p, seed, tag)`` — training-mode dropout on the INPUT of every layer (reference dbgnn.py:131-140), with the
+        """``drop``: None, or ``(p, seed, tag, out_tag)`` — training-mode dropout on the INPUT of every layer (sites tag + layer) and, with
+        ``out_tag``, on the stack's output (the consumer's backward then owns that mask) — the former was: dropout on the INPUT of every layer (reference dbgnn.py:131-140), with the
         reproducible masks of :func:`dropout_mask`: the owner drops its rows before they are exchanged, the first layer's replicated input
         rows are dropped locally (same mask on every rank)."""
         n_layers = len(params) // 2
@@ -214,17 +231,19 @@ class _ShardedGcnStack(torch.autograd.Function):
         inputs, saved = [], []
         h = x_full
         if drop is not None:
-            p_drop, seed, tag = drop
+            p_drop, seed, tag, out_tag = drop
             h = ops.dropout(x_full, p_drop, seed, tag, 0, shard.local_rows() if shard.n_halo or shard.lo else None)
         for layer in range(n_layers):
             weight, bias = params[2 * layer], params[2 * layer + 1]
             last = layer == n_layers - 1
             buf = torch.empty((n_own if last else shard.n_src, weight.size(0)), dtype=torch.float32, device=x_full.device)
             inputs.append(h)
-            saved.append(ops.layer_forward(plan, h, weight, bias, layer == 0, buf[:n_own]))
+            # the next layer's input dropout is applied by the owner before the exchange — in the layer kernel's epilogue where the shape allows
+            site_out = None
+            if drop is not None and (not last or out_tag is not None):      # (the last layer's output: the dropout in front of the bipartite layer)
+                site_out = (p_drop, seed, out_tag if last else tag + layer + 1, shard.lo)
+            saved.append(ops.layer_forward(plan, h, weight, bias, layer == 0, buf[:n_own], site_out))
             if not last:
-                if drop is not None:                     # the next layer's input dropout, applied (in place) by the owner before the exchange
-                    ops.dropout(buf[:n_own], p_drop, seed, tag + layer + 1, shard.lo, None, buf[:n_own])
                 halo_fill(shard, comm, buf)
             h = buf
         ctx.shard, ctx.comm, ctx.ops, ctx.n_layers = shard, comm, ops, n_layers
@@ -245,8 +264,11 @@ class _ShardedGcnStack(torch.autograd.Function):
             if layer == 0:
                 grads[0] = ops.layer_backward(plan, d, x_in, weight, ctx.saved[0], False, None)[2]
                 break
-            fuse_below = x_in if (comm.world == 1 and ctx.drop is None) else None
-            d_lin, colsum, grads[2 * layer] = ops.layer_backward(plan, d, x_in, weight, ctx.saved[layer], True, fuse_below)
+            # world size 1: the input IS the stored (possibly dropped) activation of the layer below, its backward rides in the same kernel
+            fuse_below = x_in if (comm.world == 1 and (ctx.drop is None or ops.drop_fusable(weight))) else None
+            site_in = None if ctx.drop is None else (ctx.drop[0], ctx.drop[1], ctx.drop[2] + layer, shard.lo)
+            d_lin, colsum, grads[2 * layer] = ops.layer_backward(plan, d, x_in, weight, ctx.saved[layer], True, fuse_below,
+                                                                 site_in if fuse_below is not None else None)
             if fuse_below is not None:
                 d = d_lin
             else:
@@ -257,7 +279,7 @@ class _ShardedGcnStack(torch.autograd.Function):
                     # x_in holds the DROPPED activation y * keep / (1 - p): the gradient passes the mask, and ELU' is taken at y = x_in * (1 - p)
                     # (where the mask is 0 the gradient is 0 whatever ELU' says) — one pass (pp_dropout_act_backward_f32)
                     d_own = d_lin[:n_own] if extra is None else d_lin[:n_own] + extra
-                    p_drop, seed, tag = ctx.drop
+                    p_drop, seed, tag = ctx.drop[:3]
                     d, colsum = ops.dropout_act_backward(d_own, x_in[:n_own], p_drop, seed, tag + layer, shard.lo, None, True, True)
             grads[2 * layer - 1] = colsum                      # bias gradient of the layer below
         ctx.inputs = ctx.saved = None
@@ -271,10 +293,10 @@ class _ShardedBipartite(torch.autograd.Function):
     layer's bias gradient in one kernel."""
 
     @staticmethod
-    def forward(ctx, plan, comm, ops, cap: int, n_own_fo: int, y_h: torch.Tensor, act_bias, fuse_act: bool = True):
+    def forward(ctx, plan, comm, ops, cap: int, n_own_fo: int, y_h: torch.Tensor, act_bias, fuse_act: bool = True, drop=None):
         """``fuse_act=False``: ``y_h`` is not a raw ELU activation (dropout sits in between): plain transposed aggregation backward."""
         ctx.plan, ctx.comm, ctx.ops, ctx.cap, ctx.n_own_fo = plan, comm, ops, cap, n_own_fo
-        ctx.fuse_act = fuse_act
+        ctx.fuse_act, ctx.drop = fuse_act, drop          # drop: y_h is stored dropped (site (p, seed, tag, first global row))
         ctx.has_bias = act_bias is not None
         ctx.save_for_backward(y_h)
         partial = ops.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, y_h, heavy=plan.fwd_heavy)       # [world * cap, H]
@@ -289,10 +311,10 @@ class _ShardedBipartite(torch.autograd.Function):
             d_own = F.pad(d_own, (0, 0, 0, ctx.cap - ctx.n_own_fo))
         d_full = comm.all_gather_rows(d_own)                                                                     # [world * cap, H]
         if not ctx.fuse_act:
-            return None, None, None, None, None, ops.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d_full, heavy=plan.bwd_heavy), None, None
+            return None, None, None, None, None, ops.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d_full, heavy=plan.bwd_heavy), None, None, None
         want = ctx.has_bias and ctx.needs_input_grad[6]
-        dpre, colsum = ops.spmm_act_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d_full, y_h, want)
-        return None, None, None, None, None, dpre, colsum, None
+        dpre, colsum = ops.spmm_act_backward(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d_full, y_h, want, ctx.drop)
+        return None, None, None, None, None, dpre, colsum, None, None
 
 
 class DbgnnShard:
@@ -335,21 +357,22 @@ class ShardedDBGNN(torch.nn.Module):
             pick = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).to(shard.x.device)
             seed = int(comm.all_reduce_(pick, torch.distributed.ReduceOp.MAX).item()) if comm.world > 1 else int(pick.item())
 
-        def stack(layers, graph_shard, x_full, tag):
+        def stack(layers, graph_shard, x_full, tag, out_tag):
             params = []
             for layer in layers:
                 params += [layer.lin.weight, layer.bias]
-            drop = (m.p_dropout, seed, tag) if dropping else None
+            drop = (m.p_dropout, seed, tag, out_tag) if dropping else None
             return _ShardedGcnStack.apply(graph_shard, comm, ops, drop, x_full, *params), layers[-1].bias
 
-        x, bias_fo = stack(m.first_order_layers, shard.fo, shard.x, TAG_FO)
-        x_h, bias_ho = stack(m.higher_order_layers, shard.ho, shard.x_h, TAG_HO)
+        x, bias_fo = stack(m.first_order_layers, shard.fo, shard.x, TAG_FO, TAG_FO_OUT)
+        x_h, bias_ho = stack(m.higher_order_layers, shard.ho, shard.x_h, TAG_HO, TAG_HO_OUT)
         bl = m.bipartite_layer
         if dropping:            # dropout after both stacks and after the bipartite ELU (reference dbgnn.py:136,142,148), masks as above
             p = m.p_dropout
-            x = ops.drop_act(x, bias_fo, p, seed, TAG_FO_OUT, shard.fo.lo, True)
-            x_h = ops.drop_act(x_h, bias_ho, p, seed, TAG_HO_OUT, shard.ho.lo, True)
-            agg = _ShardedBipartite.apply(shard.bip, comm, ops, shard.cap, shard.fo.n_own, x_h, None, False)
+            # both stacks hand their outputs over DROPPED (last layer's epilogue); what is left of those two sites is their backward: one
+            # element-wise pass on the first-order rows, nothing on the higher-order ones (the bipartite backward kernel takes the mask)
+            x = ops.drop_act(x, bias_fo, p, seed, TAG_FO_OUT, shard.fo.lo, True, True)
+            agg = _ShardedBipartite.apply(shard.bip, comm, ops, shard.cap, shard.fo.n_own, x_h, bias_ho, True, (p, seed, TAG_HO_OUT, shard.ho.lo))
             per_edge = ops.dense(x, bl.lin2) + bl.lin1.bias
             x = F.elu(torch.addcmul(ops.dense_nobias(agg, bl.lin1.weight), shard.indeg.unsqueeze(1), per_edge))
             return ops.dense(ops.drop_act(x, None, p, seed, TAG_HEAD, shard.fo.lo, False), m.lin)

@@ -43,6 +43,24 @@ class _ActGrad(torch.autograd.Function):
         return d, (d.sum(0) if ctx.has_bias else None)
 
 
+class _DroppedGrad(torch.autograd.Function):
+    """Identity on an activation its producer stored DROPPED (site (p, seed, tag, row0)): the backward pass returns the gradient w.r.t. the
+    producer's pre-activation, g * mask / (1 - p) * ELU'(y_dropped * (1 - p)), and the column sums for ``act_bias``."""
+
+    @staticmethod
+    def forward(ctx, y, act_bias, p, seed, tag, row0):
+        ctx.save_for_backward(y)
+        ctx.site, ctx.has_bias = (p, seed, tag, row0), act_bias is not None
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        p, seed, tag, row0 = ctx.site
+        d = g * CpuOps._mask(y.size(0), y.size(1), p, seed, tag, row0, None) * _elu_grad(y * (1.0 - p))
+        return d, (d.sum(0) if ctx.has_bias else None), None, None, None, None
+
+
 class CpuOps:
     name = "cpu-test-standin"
 
@@ -146,19 +164,30 @@ class CpuOps:
         return F.elu(y) if act else y
 
     @staticmethod
-    def spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum):
-        g = CpuOps.spmm(ptr, idx, val, n_rows, d) * _elu_grad(z)
+    def spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum, drop=None):
+        g = CpuOps.spmm(ptr, idx, val, n_rows, d)
+        if drop is not None:
+            g = g * CpuOps._mask(g.size(0), g.size(1), drop[0], drop[1], drop[2], drop[3], None) * _elu_grad(z * (1.0 - drop[0]))
+        else:
+            g = g * _elu_grad(z)
         return g, (g.sum(0) if want_colsum else None)
 
     # ---- one GCN layer on a rectangular plan
     @staticmethod
-    def layer_forward(plan, x_full, weight, bias, first, out):
+    def drop_fusable(weight):
+        return True
+
+    @staticmethod
+    def layer_forward(plan, x_full, weight, bias, first, out, drop=None):
         agg = CpuOps.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, x_full, plan.self_coef, x_full)
-        out.copy_(F.elu(agg @ weight.t() + bias))
+        y = F.elu(agg @ weight.t() + bias)
+        if drop is not None:
+            y = y * CpuOps._mask(y.size(0), y.size(1), drop[0], drop[1], drop[2], drop[3], None)
+        out.copy_(y)
         return agg if first else None
 
     @staticmethod
-    def layer_backward(plan, dpre, x_full, weight, saved, need_input_grad, fuse_below):
+    def layer_backward(plan, dpre, x_full, weight, saved, need_input_grad, fuse_below, drop=None):
         if not need_input_grad and saved is not None:
             return None, None, dpre.t() @ saved
         g = CpuOps.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre)
@@ -168,7 +197,10 @@ class CpuOps:
             return None, None, dw
         d_lin = g @ weight
         if fuse_below is not None:
-            d_lin = d_lin * _elu_grad(fuse_below)
+            if drop is not None:                       # fuse_below is the dropped activation: mask / (1 - p), ELU' at y = dropped * (1 - p)
+                d_lin = d_lin * CpuOps._mask(d_lin.size(0), d_lin.size(1), drop[0], drop[1], drop[2], drop[3], None) * _elu_grad(fuse_below * (1.0 - drop[0]))
+            else:
+                d_lin = d_lin * _elu_grad(fuse_below)
             return d_lin, d_lin.sum(0), dw
         return d_lin, None, dw
 
@@ -199,7 +231,9 @@ class CpuOps:
         return g, (g.sum(0) if want_dbias else None)
 
     @staticmethod
-    def drop_act(y, act_bias, p, seed, tag, row0, act):
+    def drop_act(y, act_bias, p, seed, tag, row0, act, applied=False):
+        if applied:
+            return _DroppedGrad.apply(y, act_bias, p, seed, tag, row0)
         if act:
             y = _ActGrad.apply(y, act_bias)
         return y * CpuOps._mask(y.size(0), y.size(1), p, seed, tag, row0, None)

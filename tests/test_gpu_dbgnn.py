@@ -563,3 +563,41 @@ def test_dbgnn_training_with_dropout_matches_masked_reference(pp, f, hidden):
     if f[0] % 16 == 0:
         assert mod._GcnLayer.supported(mod._hip.gcn_plan(gdata.edge_index, gdata.edge_weights, data["num_nodes"]), gdata.x,
                                        model.first_order_layers[0].lin.weight)
+
+
+@pytest.mark.parametrize("n,e,p_in,q_out", [(17, 40, 16, 32), (3001, 9000, 64, 64), (4097, 20_000, 32, 16), (2000, 9000, 128, 128), (1500, 6000, 64, 128)])
+def test_fused_layer_kernels_with_dropout_in_their_epilogues(pp, n, e, p_in, q_out):
+    """pp_gcn_forward_drop_f32 / pp_gcn_backward_drop_f32 / pp_gcn_input_grad_drop_f32: the dropout fused into the epilogue drops exactly the
+    elements pp_dropout_f32 drops (same counter-based mask, bit-identical values), and the backward kernels' d_in equals the unfused
+    composition (linear input gradient, then pp_dropout_act_backward_f32)."""
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(n + e + p_in)
+    row = torch.sort(torch.randint(0, n, (e,), generator=g)).values
+    ptr = torch.zeros(n + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.bincount(row, minlength=n), 0).int()
+    idx = torch.randint(0, n, (e,), generator=g, dtype=torch.int32)
+    val = torch.rand(e, generator=g)
+    sc = torch.rand(n, generator=g)
+    x = torch.randn(n, p_in, generator=g)
+    w = torch.randn(q_out, p_in, generator=g) / p_in ** 0.5
+    b = torch.randn(q_out, generator=g)
+    site = (0.4, 987654321, 65, 2 ** 33 + 5)
+    assert _hip.gcn_drop_supported(p_in, q_out) and not _hip.gcn_drop_supported(256, 256)
+    dev = lambda t: t.to(DEV)
+    y0 = _hip.gcn_forward(dev(ptr), dev(idx), dev(val), n, dev(x), dev(sc), dev(w), dev(b), True)
+    y1 = _hip.gcn_forward(dev(ptr), dev(idx), dev(val), n, dev(x), dev(sc), dev(w), dev(b), True, drop=site)
+    assert torch.equal(y1, _hip.dropout(y0, *site))
+    # backward of a layer [q_out -> p_in here: weight m x k] whose INPUT is the dropped activation y1 (k = q_out columns)
+    m, k = p_in, q_out
+    dpre = torch.randn(n, m, generator=g)
+    wb = torch.randn(m, k, generator=g) / m ** 0.5
+    if _hip.gcn_fused_supported(k, m) == 1:
+        lin, _, dw0 = _hip.gcn_backward(dev(ptr), dev(idx), dev(val), n, dev(dpre), dev(sc), y1, dev(wb), False, False)
+        got, colsum, dw1 = _hip.gcn_backward(dev(ptr), dev(idx), dev(val), n, dev(dpre), dev(sc), y1, dev(wb), True, True, drop=site)
+        torch.testing.assert_close(dw1, dw0, rtol=1e-6, atol=1e-6)
+    else:
+        lin, _ = _hip.gcn_input_grad(dev(ptr), dev(idx), dev(val), n, dev(dpre), dev(sc), dev(wb), None, False)
+        got, colsum = _hip.gcn_input_grad(dev(ptr), dev(idx), dev(val), n, dev(dpre), dev(sc), dev(wb), y1, True, drop=site)
+    want, want_sum = _hip.dropout_act_backward(lin, y1, *site, None, True, True)
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(colsum, want_sum, rtol=1e-4, atol=1e-4 * float(want.abs().sum(0).max() + 1))
