@@ -141,11 +141,47 @@ def resolve_delta(time_dtype: torch.dtype, delta) -> tuple[int, int, float]:
     return DELTA_I64, int(d), 0.0
 
 
+def _drive(gen):
+    """Runs a count -> read-back -> fill generator on its own: the generator yields its workspace after the count launch and is sent
+    ``(size, status)``."""
+    ws = next(gen)
+    try:
+        gen.send(_result(ws))
+    except StopIteration as done:
+        return done.value
+    raise RuntimeError("count/fill generator yielded twice")
+
+
+def run_together(*gens):
+    """Launches the COUNT phases of several independent count -> fill operations back to back, reads all their {size, status} pairs with
+    ONE device-to-host copy (instead of one synchronising read-back each), then runs the fills.  Returns the results in order."""
+    workspaces = [next(g) for g in gens]
+    if len(workspaces) == 1:
+        heads = [_result(workspaces[0])]
+    else:
+        flat = torch.cat([ws[:16] for ws in workspaces]).view(torch.int64).tolist()
+        heads = [(flat[2 * i], flat[2 * i + 1]) for i in range(len(workspaces))]
+    results = []
+    for g, head in zip(gens, heads):
+        try:
+            g.send(head)
+        except StopIteration as done:
+            results.append(done.value)
+        else:
+            raise RuntimeError("count/fill generator yielded twice")
+    return results
+
+
 def temporal_lift(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, n_own: int | None = None,
                   id_offset: int = 0) -> torch.Tensor:
     """Second-order event graph of a TIME-SORTED event list: all (i, j) with head(i) == tail(j) and
     t_i < t_j <= t_i + delta, lexicographic, int64 [2, E2].  ``n_own`` / ``id_offset``: edge-range shard —
     only the first ``n_own`` events are sources and ``id_offset`` is added to every id of the result."""
+    return _drive(temporal_lift_steps(edge_index, time, num_nodes, delta, n_own, id_offset))
+
+
+def temporal_lift_steps(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, n_own: int | None = None, id_offset: int = 0):
+    """:func:`temporal_lift` as a count -> fill generator for :func:`run_together`."""
     ei = _edge_index(edge_index)
     dev = require_device(ei, time)
     if time.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
@@ -162,7 +198,7 @@ def temporal_lift(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, 
         ws = _workspace(L.pp_temporal_ws_bytes(m, num_nodes), dev)
         check(L.pp_temporal_count(_p(ei), _p(time), _DTYPE_CODE[time.dtype], m, m if n_own is None else int(n_own), num_nodes, kind, di, df,
                                   _p(ws), ws.numel(), _stream()), "pp_temporal_count")
-        total, status = _result(ws)
+        total, status = yield ws
         _bad_index(status, "lift_order_temporal")
         if status & 2:
             raise ValueError("lift_order_temporal: the events are not sorted by time (TemporalGraph sorts them on construction; "
@@ -265,6 +301,12 @@ def coalesce(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: i
     ``want_inverse`` additionally returns, per input edge, the index of the merged edge it went into.
     ``col_block = (col_base [num_nodes] int64, col_bits)``: every column of row r lies in ``[col_base[r], col_base[r] + 2**col_bits)``
     (De Bruijn layers): shorter sort keys, same result."""
+    return _drive(coalesce_steps(edge_index, weight, num_nodes, reduce, remap, want_inverse, col_block))
+
+
+def coalesce_steps(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: int, reduce: str = "sum",
+                   remap: torch.Tensor | None = None, want_inverse: bool = False, col_block: tuple | None = None):
+    """:func:`coalesce` as a count -> fill generator for :func:`run_together`."""
     if reduce not in _REDUCE:
         raise ValueError(f"unknown reduce {reduce}")
     ei = _edge_index(edge_index)
@@ -286,7 +328,7 @@ def coalesce(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: i
         ws = _workspace(L.pp_coalesce_ws_bytes(e), dev)
         check(L.pp_coalesce_count(_p(ei), e, _p(remap), 0 if remap is None else remap.numel(), num_nodes, _p(col_base), col_bits,
                                   _p(ws), ws.numel(), _stream()), "pp_coalesce_count")
-        n_out, status = _result(ws)
+        n_out, status = yield ws
         # the reference fails in EdgeIndex.validate() with a ValueError when an index exceeds the number of distinct nodes
         # (lift_order.py:133-147: layer-1 quirk, node ids are used as given while num_nodes counts the distinct ones)
         _bad_index(status, "aggregate_edge_index (an edge refers to a node id >= number of distinct nodes)", ValueError)

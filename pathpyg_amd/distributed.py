@@ -390,8 +390,13 @@ def build_dbgnn_shard(g, delta, x: torch.Tensor, x_h, y: torch.Tensor | None, co
     n, m = int(data.num_nodes), int(ei.size(1))
     unit_weights = weight not in data
     w = torch.ones(m, device=dev) if unit_weights else data[weight]
-    # 1. layer 1
-    fo, fo_w, inv1 = ops.coalesce(ei, w, n, "sum", None, True)
+    # 1. layer 1 — and 3. the edge-range lift of the same stream: independent of each other, so their count phases are queued together and
+    #    their sizes cost ONE read-back
+    lo_e, hi_e = event_ranges(m, world)[rank]
+    end = halo_end(data.time, hi_e, delta) if hi_e > lo_e else lo_e
+    (fo, fo_w, inv1), local = ops.coalesce_and_lift(
+        (ei, w, n, "sum", None, True),
+        (ei[:, lo_e:end].contiguous(), data.time[lo_e:end].contiguous(), n, delta, hi_e - lo_e, lo_e))
     n_ho = int(fo.size(1))
     row_ptr = ops.ptr_from_sorted(fo[0], n)                                  # int64 [n+1]: order-2 nodes (a, .) = ids row_ptr[a] .. row_ptr[a+1]
     # 2. cuts
@@ -408,10 +413,6 @@ def build_dbgnn_shard(g, delta, x: torch.Tensor, x_h, y: torch.Tensor | None, co
             fo_cuts[i] = max(fo_cuts[i], fo_cuts[i - 1])
         ho_cuts = row_ptr[torch.tensor(fo_cuts, dtype=torch.int64, device=dev)].tolist()
     col_block = (row_ptr[fo[1]], max(int(widest - 1).bit_length(), 1)) if n_ho else None     # successors of (a, b): the id block of b
-    # 3. edge-range lift
-    lo_e, hi_e = event_ranges(m, world)[rank]
-    end = halo_end(data.time, hi_e, delta) if hi_e > lo_e else lo_e
-    local = ops.temporal_lift(ei[:, lo_e:end].contiguous(), data.time[lo_e:end].contiguous(), n, delta, hi_e - lo_e, lo_e)
     e2_local = int(local.size(1))
     w_pairs = torch.ones(e2_local, device=dev) if unit_weights else w.index_select(0, local[0])   # lifted weight = weight of the source event
     # 4. aggregation at the destination owner

@@ -41,6 +41,12 @@ class HipOps:
     # ---- lift + aggregation
     temporal_lift = staticmethod(_hip.temporal_lift)
     coalesce = staticmethod(_hip.coalesce)
+
+    @staticmethod
+    def coalesce_and_lift(coalesce_args: tuple, lift_args: tuple):
+        """Layer-1 coalesce and the temporal lift of the same stream are independent: their count phases are launched back to back and their
+        sizes come back with one read (``(coalesce result, lift result)``)."""
+        return tuple(_hip.run_together(_hip.coalesce_steps(*coalesce_args), _hip.temporal_lift_steps(*lift_args)))
     ptr_from_sorted = staticmethod(_hip.ptr_from_sorted)
 
     @staticmethod

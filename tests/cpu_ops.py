@@ -134,6 +134,10 @@ class CpuOps:
         return out + id_offset
 
     @staticmethod
+    def coalesce_and_lift(coalesce_args, lift_args):
+        return CpuOps.coalesce(*coalesce_args), CpuOps.temporal_lift(*lift_args)
+
+    @staticmethod
     def coalesce(edge_index, weight, num_nodes, reduce="sum", remap=None, want_inverse=False, col_block=None):
         ei = edge_index if remap is None else remap[edge_index]
         if ei.numel() and int(ei.max()) >= num_nodes:
