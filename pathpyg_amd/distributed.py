@@ -58,19 +58,17 @@ def halo_end(time: torch.Tensor, hi: int, delta) -> int:
     m = int(time.numel())
     if hi <= 0 or hi >= m:
         return m if hi > 0 else 0
-    last = time[hi - 1].cpu()
-    thr = last + torch.tensor(delta)
-    cmp_dtype = torch.result_type(time, thr)
-    # searchsorted on a tiny CPU copy would need the whole array; a bisection with O(log m) scalar reads is enough
-    lo, up = hi, m
-    thr_c = thr.to(cmp_dtype)
-    while lo < up:
-        mid = (lo + up) // 2
-        if bool(time[mid].to(cmp_dtype).cpu() <= thr_c):
-            lo = mid + 1
-        else:
-            up = mid
-    return lo
+    # one searchsorted on the device and ONE read-back (this used to be a host bisection: ~log2(m) scalar reads per step and rank)
+    delta_t = delta.to(time.device) if isinstance(delta, torch.Tensor) else torch.as_tensor(delta, device=time.device)
+    thr = time[hi - 1] + delta_t                                     # promoted like the reference's comparison
+    if thr.dtype != time.dtype and not time.dtype.is_floating_point:
+        # a float threshold over integer times: float(t) <= thr admits no integer above ceil(thr) + one rounding step of the float type
+        t64 = thr.double()
+        step = t64.abs() * (2.0 ** -23 if thr.dtype == torch.float32 else 2.0 ** -52) + 1.0
+        bound = torch.ceil(t64 + step).clamp(max=float(2 ** 62)).to(torch.int64)
+    else:
+        bound = thr.to(time.dtype)
+    return hi + int(torch.searchsorted(time[hi:], bound, right=True).item())
 
 
 def lift_order_temporal_sharded(g, delta=1, group=None, weights: torch.Tensor | None = None):

@@ -188,3 +188,27 @@ def test_dbgnn_hints_are_bound_to_the_tensors_they_describe():
     assert _valid_hints(d).get("rows_sorted") is True
     d.edge_index = torch.tensor([[2, 0], [1, 1]])           # replaced tensor (not row-sorted any more)
     assert _valid_hints(d) == {}
+
+
+def test_halo_end_is_a_tight_conservative_bound_for_every_delta_dtype():
+    """distributed.halo_end (one searchsorted + one read-back): never smaller than the first event the promoted comparison of
+    temporal.py:43 rejects, and at most a rounding step of the float type beyond it."""
+    import torch
+    from pathpyg_amd.distributed import halo_end
+    g = torch.Generator().manual_seed(4)
+    for span in (50, 10_000, 2 ** 40):
+        t = torch.sort(torch.randint(0, span, (3000,), generator=g)).values
+        for delta in (0, 7, span // 10, 3.5, torch.tensor(2.25, dtype=torch.float32), torch.tensor(float(span // 7), dtype=torch.float32),
+                      torch.tensor(1e3, dtype=torch.float64)):
+            for hi in (1, 17, 1500, 2999):
+                thr = t[hi - 1] + (delta if isinstance(delta, torch.Tensor) else torch.as_tensor(delta))
+                admitted = t.to(torch.result_type(t, thr)) <= thr
+                exact = hi + int(admitted[hi:].to(torch.int64).cumprod(0).sum())          # first id >= hi that is not admitted
+                got = halo_end(t, hi, delta)
+                assert exact <= got <= t.numel()
+                if got > exact:          # extra events lie within the float rounding slack of the threshold
+                    slack = float(thr.double().abs()) * 2.0 ** -22 + 2.0
+                    assert float(t[got - 1]) <= float(thr.double()) + slack
+        tf = torch.sort(torch.rand(500, generator=g, dtype=torch.float64)).values
+        assert halo_end(tf, 100, 0.1) == 100 + int((tf[100:] <= tf[99] + 0.1).sum())
+    assert halo_end(t, 0, 5) == 0 and halo_end(t, t.numel(), 5) == t.numel()
