@@ -74,39 +74,44 @@ def synth_stream(events: int, nodes: int, span: int, seed: int, device):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # live kernel timing: HIP events around C-ABI entry points on the stream they launch on
 class KernelClock:
-    """HIP events around every call of one C-ABI entry point (or from the start of `name` to the end of `until`)."""
+    """HIP events around every call of one C-ABI entry point; with `until`: around the call of `name` (the count phase) AND around the
+    following call of `until` (the fill phase) — two intervals, because count phases of independent operations are queued together and
+    other kernels run between an operation's count and its fill."""
 
     def __init__(self, lib, name: str, describe, until: str | None = None):
         self.lib, self.name, self.describe, self.until = lib, name, describe, until
         self.orig = getattr(lib, name)
         self.orig_until = getattr(lib, until) if until else None
-        self.records = []          # (start_event, end_event, key, bytes)
+        self.records = []          # (start_event, end_event, start2 | None, end2 | None, key, bytes)
         self.enabled = False
         self._open = None
+
+    @staticmethod
+    def _timed(fn, args):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        rc = fn(*args)
+        e1.record(torch.cuda.current_stream())
+        return rc, e0, e1
 
     def __enter__(self):
         def wrapped(*args):
             if not self.enabled:
                 return self.orig(*args)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream())
-            rc = self.orig(*args)
+            rc, e0, e1 = self._timed(self.orig, args)
             if self.until is None:
-                e1 = torch.cuda.Event(enable_timing=True)
-                e1.record(torch.cuda.current_stream())
-                self.records.append((e0, e1) + tuple(self.describe(*args)))
+                self.records.append((e0, e1, None, None) + tuple(self.describe(*args)))
             else:
-                self._open = (e0,) + tuple(self.describe(*args))
+                self._open = (e0, e1) + tuple(self.describe(*args))
             return rc
         setattr(self.lib, self.name, wrapped)
         if self.until:
             def wrapped_until(*args):
-                rc = self.orig_until(*args)
-                if self.enabled and self._open is not None:
-                    e1 = torch.cuda.Event(enable_timing=True)
-                    e1.record(torch.cuda.current_stream())
-                    self.records.append((self._open[0], e1) + self._open[1:])
-                    self._open = None
+                if not (self.enabled and self._open is not None):
+                    return self.orig_until(*args)
+                rc, f0, f1 = self._timed(self.orig_until, args)
+                self.records.append((self._open[0], self._open[1], f0, f1) + self._open[2:])
+                self._open = None
                 return rc
             setattr(self.lib, self.until, wrapped_until)
         return self
@@ -119,9 +124,9 @@ class KernelClock:
     def groups(self) -> dict:
         """{key: (launches, total ms, total algorithmic bytes)}"""
         out = {}
-        for e0, e1, key, nbytes in self.records:
+        for e0, e1, f0, f1, key, nbytes in self.records:
             n, ms, b = out.get(key, (0, 0.0, 0))
-            out[key] = (n + 1, ms + e0.elapsed_time(e1), b + nbytes)
+            out[key] = (n + 1, ms + e0.elapsed_time(e1) + (f0.elapsed_time(f1) if f0 is not None else 0.0), b + nbytes)
         return out
 
 
@@ -152,7 +157,7 @@ def spmm_desc(ptr, idx, val, n_rows, x, f, self_coef, s, bias, act, heavy_slot, 
 SRC_ROWS = {}           # idx.data_ptr() -> rows of the matrix the CSR gathers from
 
 
-def gcn_forward_desc(ptr, idx, val, n_rows, n_src, x, p, self_coef, w, q, bias, act, heavy_slot, heavy_sum, agg_out, y, stream):
+def gcn_forward_desc(ptr, idx, val, n_rows, n_src, x, p, self_coef, w, q, bias, act, heavy_slot, heavy_sum, agg_out, y, *drop_and_stream):
     """pp_gcn_forward_f32: CSR once, every input row once (P wide), every output row once (Q wide), the optional aggregated-input copy,
     the self coefficients and W."""
     nnz = CSR_SHAPE.get(idx, 0)
@@ -162,7 +167,7 @@ def gcn_forward_desc(ptr, idx, val, n_rows, n_src, x, p, self_coef, w, q, bias, 
 
 
 def gcn_backward_desc(ptr, idx, val, n_rows, n_self, d, m, self_coef, x, k, w, fuse_act, heavy_slot, heavy_sum, d_in, colsum, dw, ws, ws_bytes,
-                      stream):
+                      *drop_and_stream):
     """pp_gcn_backward_f32: CSR, dpre (M wide) and the layer input (K wide) read once, the input gradient (K wide) written once."""
     nnz = CSR_SHAPE.get(idx, 0)
     total = 4 * (n_rows + 1) + nnz * (4 + (4 if val else 0)) + 4 * m * n_self + 8 * k * n_rows + (4 * n_self if self_coef else 0) + 8 * m * k
@@ -466,8 +471,8 @@ def main() -> int:
         return (f"aggregation (pp_coalesce_count .. pp_coalesce_fill), {e:.2e} instance edges", 20 * e)
 
     with KernelClock(L, "pp_spmm_f32", spmm_desc) as spmm_clock, \
-            KernelClock(L, "pp_gcn_forward_f32", gcn_forward_desc) as fwd_clock, \
-            KernelClock(L, "pp_gcn_backward_f32", gcn_backward_desc) as bwd_clock, \
+            KernelClock(L, "pp_gcn_forward_drop_f32", gcn_forward_desc) as fwd_clock, \
+            KernelClock(L, "pp_gcn_backward_drop_f32", gcn_backward_desc) as bwd_clock, \
             KernelClock(L, "pp_temporal_fill", lambda m, n, total, *r: ("k_expand (pp_temporal_fill)", 16 * total + 12 * m)) as fill_clock, \
             KernelClock(L, "pp_temporal_count", lift_desc, until="pp_temporal_fill") as lift_clock, \
             KernelClock(L, "pp_coalesce_count", coalesce_desc, until="pp_coalesce_fill") as agg_clock:
