@@ -36,17 +36,34 @@ __device__ __forceinline__ unsigned digit_of(KeyT k, int shift, unsigned mask) {
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_digit_hist(const KeyT* __restrict__ keys, int64_t n, int shift, unsigned mask,
                                                       uint32_t* __restrict__ table, int64_t ntiles) {
-    __shared__ unsigned bins[kRadix];
-    bins[threadIdx.x] = 0;
+    // one private histogram per wave (LDS atomics of different waves never meet), 16-byte key loads; summed at the end
+    __shared__ unsigned bins[kWavesPerBlock][kRadix];
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) bins[w][threadIdx.x] = 0;
     __syncthreads();
     const int64_t tile_base = (int64_t)blockIdx.x * kSortTile;
+    unsigned* mine = bins[wave_id()];
+    constexpr int kVec = 16 / sizeof(KeyT);                   // keys per 16-byte load
+    struct alignas(16) Chunk { KeyT k[kVec]; };
+    if (tile_base + kSortTile <= n && ((uintptr_t)keys & 15) == 0) {
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-        int64_t i = tile_base + (int64_t)r * kBlock + threadIdx.x;
-        if (i < n) atomicAdd(&bins[digit_of(keys[i], shift, mask)], 1u);
+        for (int r = 0; r < kSortItems / kVec; ++r) {
+            const Chunk c = *reinterpret_cast<const Chunk*>(keys + tile_base + ((int64_t)r * kBlock + threadIdx.x) * kVec);
+#pragma unroll
+            for (int e = 0; e < kVec; ++e) atomicAdd(&mine[digit_of(c.k[e], shift, mask)], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            int64_t i = tile_base + (int64_t)r * kBlock + threadIdx.x;
+            if (i < n) atomicAdd(&mine[digit_of(keys[i], shift, mask)], 1u);
+        }
     }
     __syncthreads();
-    table[(int64_t)threadIdx.x * ntiles + blockIdx.x] = bins[threadIdx.x];
+    unsigned total = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) total += bins[w][threadIdx.x];
+    table[(int64_t)threadIdx.x * ntiles + blockIdx.x] = total;
 }
 
 // One workgroup per digit: exclusive scan of that digit's row of the table (its counts over the tiles, a few thousand entries) in
