@@ -398,8 +398,13 @@ def build_dbgnn_shard(g, delta, x: torch.Tensor, x_h, y: torch.Tensor | None, co
     n_ho = int(fo.size(1))
     row_ptr = ops.ptr_from_sorted(fo[0], n)                                  # int64 [n+1]: order-2 nodes (a, .) = ids row_ptr[a] .. row_ptr[a+1]
     # 2. cuts
+    pending = []
+    fo_shard = None
     if world == 1:
         fo_cuts, ho_cuts = [0, n], [0, n_ho]
+        # the first-order graph needs nothing that follows: its plan kernels are queued NOW, in front of the size read-backs below, so the
+        # GPU has ~1 ms of work while the host waits for them
+        fo_shard = build_graph_shard(fo[0], fo[1], fo_w.to(torch.float32), n, fo_cuts, comm, ops, True, pending, want_dst_order=True, edge_index=fo)
         widest = int((row_ptr[1:] - row_ptr[:-1]).max().item()) if n > 0 else 1
     else:
         targets = torch.tensor([(n_ho * r) // world for r in range(1, world)], dtype=torch.int64, device=dev)
@@ -430,15 +435,11 @@ def build_dbgnn_shard(g, delta, x: torch.Tensor, x_h, y: torch.Tensor | None, co
         ho_ei, ho_w = ops.coalesce(ids_r.t().to(torch.int64).contiguous(), w_r, n_ho, "sum", None, False, col_block)
         del u, v, owner, order, ids, ids_r, w_r
     # 5. shards
-    pending = []
     ho = build_graph_shard(ho_ei[0], ho_ei[1], ho_w.to(torch.float32), n_ho, ho_cuts, comm, ops, world == 1, pending, edge_index=ho_ei)
-    if world == 1:
-        f_src, f_dst, f_w = fo[0], fo[1], fo_w
-    else:
+    if fo_shard is None:
         mine = torch.nonzero((fo[1] >= fo_cuts[rank]) & (fo[1] < fo_cuts[rank + 1])).flatten()      # one size read-back for all three gathers
         f_src, f_dst, f_w = fo[0].index_select(0, mine), fo[1].index_select(0, mine), fo_w.index_select(0, mine)
-    fo_shard = build_graph_shard(f_src, f_dst, f_w.to(torch.float32), n, fo_cuts, comm, ops, world == 1, pending, want_dst_order=world == 1,
-                                 edge_index=fo if world == 1 else None)
+        fo_shard = build_graph_shard(f_src, f_dst, f_w.to(torch.float32), n, fo_cuts, comm, ops, False, pending)
     if world == 1:
         bip, cap = ops.bipartite_from_grouping(fo_shard.plan, fo[1], n_ho), n
     else:
