@@ -155,21 +155,27 @@ def _drive(gen):
 def run_together(*gens):
     """Launches the COUNT phases of several independent count -> fill operations back to back, reads all their {size, status} pairs with
     ONE device-to-host copy (instead of one synchronising read-back each), then runs the fills.  Returns the results in order."""
-    workspaces = [next(g) for g in gens]
-    if len(workspaces) == 1:
-        heads = [_result(workspaces[0])]
-    else:
-        flat = torch.cat([ws[:16] for ws in workspaces]).view(torch.int64).tolist()
-        heads = [(flat[2 * i], flat[2 * i + 1]) for i in range(len(workspaces))]
-    results = []
-    for g, head in zip(gens, heads):
-        try:
-            g.send(head)
-        except StopIteration as done:
-            results.append(done.value)
+    try:
+        workspaces = [next(g) for g in gens]
+        if len({ws.device for ws in workspaces}) > 1:
+            raise RuntimeError("run_together: the operations live on different devices")
+        if len(workspaces) == 1:
+            heads = [_result(workspaces[0])]
         else:
-            raise RuntimeError("count/fill generator yielded twice")
-    return results
+            flat = torch.cat([ws[:16] for ws in workspaces]).view(torch.int64).tolist()
+            heads = [(flat[2 * i], flat[2 * i + 1]) for i in range(len(workspaces))]
+        results = []
+        for g, head in zip(gens, heads):
+            try:
+                g.send(head)
+            except StopIteration as done:
+                results.append(done.value)
+            else:
+                raise RuntimeError("count/fill generator yielded twice")
+        return results
+    finally:
+        for g in gens:          # an error in one operation must not leave the others suspended
+            g.close()
 
 
 def temporal_lift(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, n_own: int | None = None,
@@ -194,15 +200,17 @@ def temporal_lift_steps(edge_index: torch.Tensor, time: torch.Tensor, num_nodes:
         raise ValueError("time and edge_index disagree on the number of events")
     kind, di, df = resolve_delta(time.dtype, delta)
     L = lib()
+    # (the device guard is NOT held across the yield: interleaved generators would exit their guards out of order)
     with torch.cuda.device(dev):
         ws = _workspace(L.pp_temporal_ws_bytes(m, num_nodes), dev)
         check(L.pp_temporal_count(_p(ei), _p(time), _DTYPE_CODE[time.dtype], m, m if n_own is None else int(n_own), num_nodes, kind, di, df,
                                   _p(ws), ws.numel(), _stream()), "pp_temporal_count")
-        total, status = yield ws
-        _bad_index(status, "lift_order_temporal")
-        if status & 2:
-            raise ValueError("lift_order_temporal: the events are not sorted by time (TemporalGraph sorts them on construction; "
-                             "data.time / data.edge_index were modified afterwards)")
+    total, status = yield ws
+    _bad_index(status, "lift_order_temporal")
+    if status & 2:
+        raise ValueError("lift_order_temporal: the events are not sorted by time (TemporalGraph sorts them on construction; "
+                         "data.time / data.edge_index were modified afterwards)")
+    with torch.cuda.device(dev):
         out = torch.empty((2, total), dtype=torch.int64, device=dev)
         check(L.pp_temporal_fill(m, num_nodes, total, int(id_offset), _p(out), _p(ws), ws.numel(), _stream()), "pp_temporal_fill")
     return out
@@ -328,10 +336,11 @@ def coalesce_steps(edge_index: torch.Tensor, weight: torch.Tensor | None, num_no
         ws = _workspace(L.pp_coalesce_ws_bytes(e), dev)
         check(L.pp_coalesce_count(_p(ei), e, _p(remap), 0 if remap is None else remap.numel(), num_nodes, _p(col_base), col_bits,
                                   _p(ws), ws.numel(), _stream()), "pp_coalesce_count")
-        n_out, status = yield ws
-        # the reference fails in EdgeIndex.validate() with a ValueError when an index exceeds the number of distinct nodes
-        # (lift_order.py:133-147: layer-1 quirk, node ids are used as given while num_nodes counts the distinct ones)
-        _bad_index(status, "aggregate_edge_index (an edge refers to a node id >= number of distinct nodes)", ValueError)
+    n_out, status = yield ws
+    # the reference fails in EdgeIndex.validate() with a ValueError when an index exceeds the number of distinct nodes
+    # (lift_order.py:133-147: layer-1 quirk, node ids are used as given while num_nodes counts the distinct ones)
+    _bad_index(status, "aggregate_edge_index (an edge refers to a node id >= number of distinct nodes)", ValueError)
+    with torch.cuda.device(dev):
         out_index = torch.empty((2, n_out), dtype=torch.int64, device=dev)
         out_weight = None if weight is None else torch.empty(n_out, dtype=weight.dtype, device=dev)
         check(L.pp_coalesce_fill(_p(weight), 2 if weight is None else _DTYPE_CODE[weight.dtype], _REDUCE[reduce], e, n_out, num_nodes,

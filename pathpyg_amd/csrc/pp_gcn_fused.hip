@@ -916,7 +916,7 @@ int pp_gcn_backward_drop_f32(const int32_t* ptr, const int32_t* idx, const float
     PP_REQUIRE(drop_p == 0.0 || fuse_act, PP_ERR_ARG, "pp_gcn_backward_drop_f32: the fused dropout belongs to the activation below (fuse_act)");
     const pp::DropSite drop = pp::drop_site(drop_p, drop_seed, drop_tag, drop_row0);
     PP_REQUIRE(n_rows >= 0 && n_self >= 0 && n_self <= n_rows, PP_ERR_ARG, "pp_gcn_backward_f32: bad sizes");
-    PP_REQUIRE(pp_dense_supported(M, K), PP_ERR_ARG, "pp_gcn_backward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", M, K);
+    PP_REQUIRE(pp_dense_supported(M, K) == 1, PP_ERR_ARG, "pp_gcn_backward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", M, K);
     PP_REQUIRE(d_in != nullptr && dW != nullptr, PP_ERR_ARG, "pp_gcn_backward_f32: d_in and dW are required");
     PP_REQUIRE(((uintptr_t)D) % 16 == 0, PP_ERR_ARG, "pp_gcn_backward_f32: D must be 16-byte aligned");
     const bool wide = (uint64_t)n_rows * (uint64_t)M * 4 >= (uint64_t)pp::kBufOob || n_rows >= ((int64_t)1 << 30) - 64;      // 64-bit row addresses
@@ -933,7 +933,8 @@ int pp_gcn_backward_drop_f32(const int32_t* ptr, const int32_t* idx, const float
     switch (M) {
         case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop); break;
         case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop); break;
-        default: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop); break;
+        case 64: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop); break;
+        default: rc = PP_ERR_ARG; break;
     }
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();

@@ -344,8 +344,9 @@ def shard_dbgnn_bundle(data, comm: Comm, ops=None, fo_cuts: list[int] | None = N
         return ei[0].index_select(0, mine), ei[1].index_select(0, mine), (None if weights is None else weights.index_select(0, mine))
 
     pending = []
-    hints = getattr(data, "_pp_hints", None) or {}
-    sorted_rows = bool(world == 1 and hints.get("rows_sorted"))
+    from .nn.dbgnn import _valid_hints
+    hints = _valid_hints(data)             # honoured only while they still describe these very tensors; None -> checked on the device
+    sorted_rows = True if (world == 1 and hints.get("rows_sorted")) else (None if world == 1 else False)
     fo = build_graph_shard(*in_edges(data.edge_index, data.edge_weights, fo_cuts), n_fo, fo_cuts, comm, ops, sorted_rows, pending)
     ho = build_graph_shard(*in_edges(data.edge_index_higher_order, data.edge_weights_higher_order, ho_cuts), n_ho, ho_cuts, comm, ops,
                            sorted_rows, pending)

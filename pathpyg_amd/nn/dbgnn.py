@@ -296,7 +296,7 @@ def cross_entropy(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         # validated once per (storage, slice, in-place version) — the record lives on the base tensor, so the per-step views of one label
         # vector do not cost a read-back each
         holder = target._base if target._base is not None else target
-        key = (target.storage_offset(), target.numel(), target._version)
+        key = (target.storage_offset(), target.numel(), tuple(target.stride()), target._version)
         seen = getattr(holder, "_pp_class_range", None)
         if not isinstance(seen, dict):
             seen = {}
