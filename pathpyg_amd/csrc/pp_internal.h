@@ -8,7 +8,7 @@ namespace pp {
 size_t scan_ws_bytes(int64_t n);
 template <typename InT, typename OutT>
 int exclusive_scan(const InT* in, int64_t n, OutT* out, bool with_total, int64_t* total_dev, void* ws, size_t ws_bytes,
-                   hipStream_t st);
+                   hipStream_t st, int64_t* slot_owner = nullptr, int64_t slot_stride = 1, int64_t slot_cap = 0);
 template <typename IdxT>
 int histogram(const IdxT* idx, int64_t n, int64_t nbins, int32_t* bins, hipStream_t st);
 int minmax_i64(const int64_t* a, int64_t n, int64_t* out2, hipStream_t st);

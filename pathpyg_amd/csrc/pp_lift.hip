@@ -104,36 +104,73 @@ __global__ __launch_bounds__(kBlock) void k_window_marks(const TimeT* __restrict
     marks[w] = (uint32_t)lo;
 }
 
+// Tail of the list search for lists longer than the part `covered` that was counted in registers (hub nodes): finish both searches on
+// memory beyond it and fetch the head continuations that lie there.  In: pos / end = s0 + (ids below g_lo / g_hi among the covered part),
+// `taken` = head slots already filled.  Out: the final position, the count, the completed head slots.
+constexpr int kHeadSlots = 4;
+__device__ __forceinline__ void list_tail(const uint32_t* __restrict__ ids_by_tail, uint32_t covered, uint32_t s1, uint32_t glo, uint32_t ghi,
+                                          int taken, uint32_t& pos, uint32_t& end, int32_t& c, uint4& h) {
+    if (covered < s1) {
+        if (pos == covered) pos = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, covered, s1, glo);
+        if (end == covered) end = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, pos > covered ? pos : covered, s1, ghi);
+        c = (int32_t)(end - pos);
+        if (c > taken) {         // some of the first 4 continuations lie beyond the register window
+            if (taken < 1 && c > 0) h.x = ids_by_tail[pos];
+            if (taken < 2 && c > 1) h.y = ids_by_tail[pos + 1];
+            if (taken < 3 && c > 2) h.z = ids_by_tail[pos + 2];
+            if (taken < 4 && c > 3) h.w = ids_by_tail[pos + 3];
+        }
+    } else {
+        c = (int32_t)(end - pos);
+    }
+    if (c == 0) pos = 0;
+}
+
+// Per event i: the admissible id window [g_lo, g_hi) and, inside the id list of head(i), (first position, count) of the ids in that window
+// + the first 4 of them.
+// Phase A, one lane per event: times, list bounds (ONE 8-byte load at a 4-byte aligned address: rowptr[v], rowptr[v + 1] as two
+//   instructions touch the same 64 random lines twice), g_lo (= i + 1 without timestamp ties: probe, gallop, bisect), g_hi by bisection
+//   between the two window marks of the wave (k_window_marks: ~6 levels inside one or two cache lines all 64 lanes share instead of 23
+//   dependent levels over the stream; 0.635 -> 0.466 ms).  Every search relies on a time-sorted stream (the reference's mask loop does
+//   not, temporal.py:37-43): a descent sets a status bit instead of returning a wrong event graph.
+// Phase B, EIGHT LANES PER EVENT: the list is short (the node's out-degree) and sits in one or two cache lines nothing else on this CU
+//   touches again.  A group of 8 lanes reads ONE aligned 128-byte line of its event's list per instruction (the wave covers 8 events at
+//   a time, 8 rounds), counts the ids below g_lo / g_hi in registers, sums over the group with 3 xor-shuffles; the first 4 continuations
+//   and (position, end) go back to the owning lane through a wave-private LDS row.  Lists longer than 3 lines (hubs) finish on memory.
+// History (same-box A/B): two bisections per event on memory 0.74 ms; one lane per event fetching 12 sixteen-byte pieces
+//   back to back 0.447 ms; this form 0.43 ms.  The kernel moves ~3 GB over the fabric per launch (1.6 random 128-byte lines per event
+//   out of a 40 MB array that lives in the Infinity Cache, 10 % of it in an XCD's L2): ~7 TB/s, the same rate the row gathers of the
+//   GCN kernels reach from that cache — it is bound by that traffic, not by instruction issue.  Measured and rejected: a wave-cooperative
+//   64-ary search (first steps touch 64 scattered lines per wave), LDS-staged bisection (98 VGPRs), `nt` loads of the lists.
+constexpr int kGroupLanes = 8;
+constexpr int kLineIds = 32;                   // ids per aligned 128-byte line
+constexpr int kGroupLines = 3;                 // lines a group reads before the (hub) fallback on memory: >= 65 ids from s0
+
 template <typename TimeT, int kMode>
 __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __restrict__ head, const TimeT* __restrict__ time, int64_t m,
-                                                          int64_t n_own, int64_t num_nodes, int64_t delta_i, double delta_f,
-                                                          const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids_by_tail,
-                                                          const uint32_t* __restrict__ marks, uint32_t* __restrict__ first_pos,
-                                                          int32_t* __restrict__ count, uint32_t* __restrict__ head4, int64_t* __restrict__ status) {
+                                                             int64_t n_own, int64_t num_nodes, int64_t delta_i, double delta_f,
+                                                             const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids_by_tail,
+                                                             const uint32_t* __restrict__ marks, uint32_t* __restrict__ first_pos,
+                                                             int32_t* __restrict__ count, uint32_t* __restrict__ head4, int64_t* __restrict__ status) {
     using W = Window<TimeT, kMode>;
+    __shared__ __attribute__((aligned(16))) uint32_t s_head[kWavesPerBlock][kWave][4];
+    __shared__ uint2 s_pc[kWavesPerBlock][kWave];
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < m;
-    const bool source = live && i < n_own;         // (halo events of an edge-range shard are candidates, never sources)
-    const int64_t ic = live ? i : m - 1;           // lanes past the end mirror the last event: the wave-wide searches need all 64 lanes
+    const bool source = live && i < n_own;
+    const int64_t ic = live ? i : m - 1;
     const TimeT ti = time[ic];
-    const TimeT t_next = ic + 1 < m ? time[ic + 1] : ti;      // (cached loads: the bisections below revisit these lines)
-    // every search below relies on a time-sorted stream (the reference's mask-based loop does not, temporal.py:37-43): say so instead of
-    // returning a wrong event graph
+    const TimeT t_next = ic + 1 < m ? time[ic + 1] : ti;
     if (live && t_next < ti) atomicOr((unsigned long long*)status, (unsigned long long)kUnsortedTime);
-    if (__ballot(source) == 0ull) {                // a wave of halo events only (edge-range shards): nothing to search
+    if (__ballot(source) == 0ull) {
         if (live) { first_pos[i] = 0; count[i] = 0; }
         return;
     }
-    // the head node's list bounds do not depend on the window: fetch them first so that this (random) miss overlaps the searches below
     const int64_t v = source ? load_stream(head + i) : 0;
     const bool ok = v >= 0 && v < num_nodes;
-    // (one 8-byte load at a 4-byte aligned address: what a load instruction costs here is the number of distinct lines its 64 lanes
-    //  touch, and rowptr[v], rowptr[v + 1] as two instructions touch the same 64 random lines twice)
     struct __attribute__((packed, aligned(4))) Bounds { uint32_t begin, end; };
     Bounds bounds = {0u, 0u};
     if (source && ok) bounds = *reinterpret_cast<const Bounds*>(rowptr + v);
-    const uint32_t s0 = bounds.begin, s1 = bounds.end;
-    // g_lo: first id with t > t_i.  Without timestamp ties this is i+1: probe, then gallop, then bisect.
     int64_t g_lo = ic + 1;
     if (g_lo < m && !(t_next > ti)) {
         int64_t step = 2;
@@ -141,17 +178,10 @@ __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __rest
         int64_t hi = ic + step < m ? ic + step : m;
         g_lo = upper_bound_dev<TimeT, int64_t>(time, ic + (step >> 1) + 1, hi, ti);
     }
-    // g_hi: first id >= g_lo whose time is no longer admitted by the (promoted-dtype) threshold.  k_window_marks bracketed it for the
-    // whole wave: the bisection runs over [marks[wave], marks[wave + 1]] — about as many events as the wave itself holds on a stream of
-    // even density, ~6 levels inside one or two cache lines that all 64 lanes share, instead of 23 dependent levels over the stream
-    // (0.635 -> 0.466 ms per launch).  Measured and rejected on top of this: a wave-cooperative 64-ary search over the
-    // whole stream (1.19 instead of 0.97 ms per count call: its first two steps touch 64 scattered lines per wave); staging the
-    // bracketed times in LDS and bisecting there with all loads issued as unconditional batches (0.53 ms: 98 VGPRs, 5 waves/SIMD);
-    // `nt` loads of the id lists (0.82 ms: the six 16-byte pieces of a line are six memory reads once the line is not kept).
     const typename W::Thr thr = W::threshold(ti, delta_i, delta_f);
     int64_t g_hi;
     {
-        const int64_t wv = i >> 6;                 // == the wave's index over the stream (kBlock is a multiple of the wave size)
+        const int64_t wv = i >> 6;
         int64_t lo = marks[wv], hi = marks[wv + 1];
         if (lo < g_lo) lo = g_lo;
         if (lo > m) lo = m;
@@ -163,73 +193,72 @@ __global__ __launch_bounds__(kBlock) void k_temporal_count(const int64_t* __rest
         g_hi = lo;
     }
     if (g_hi < g_lo) g_hi = g_lo;
-    if (!live) return;
-    if (!source) {
-        first_pos[i] = 0;
-        count[i] = 0;
-        return;                       // its head4 row is never read (count 0)
+    if (source && !ok) atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex);
+    const bool need = source && ok && g_hi > g_lo && bounds.end > bounds.begin;
+    // ---- phase B: 8 lanes per event
+    const int l = lane_id(), w = wave_id();
+    const int grp = l >> 3, q = l & 7;
+    const uint32_t my_s0 = need ? bounds.begin : 0u, my_s1 = need ? bounds.end : 0u;
+    const uint32_t my_glo = (uint32_t)g_lo, my_ghi = (uint32_t)g_hi;
+    *reinterpret_cast<uint4*>(s_head[w][l]) = make_uint4(0u, 0u, 0u, 0u);
+    s_pc[w][l] = make_uint2(0u, 0u);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int round = 0; round < kWave / kGroupLanes; ++round) {
+        const int e = round * kGroupLanes + grp;            // the event (lane) this group serves in this round
+        const uint32_t s0 = (uint32_t)__shfl((int)my_s0, e, kWave), s1 = (uint32_t)__shfl((int)my_s1, e, kWave);
+        if (__ballot(s1 > s0) == 0ull) continue;            // (wave-uniform)
+        const uint32_t glo = (uint32_t)__shfl((int)my_glo, e, kWave), ghi = (uint32_t)__shfl((int)my_ghi, e, kWave);
+        const uint32_t a0 = s0 & ~(uint32_t)(kLineIds - 1);
+        uint4 ch[kGroupLines];
+#pragma unroll
+        for (int k = 0; k < kGroupLines; ++k) {
+            const uint32_t at = a0 + (uint32_t)(k * kLineIds + 4 * q);
+            ch[k] = at < s1 ? *reinterpret_cast<const uint4*>(ids_by_tail + at) : make_uint4(0u, 0u, 0u, 0u);   // (the list array is padded to 4)
+        }
+        uint32_t below = 0;                                  // below_lo in the low half, below_hi in the high half
+#pragma unroll
+        for (int k = 0; k < kGroupLines; ++k) {
+            const uint32_t v4[4] = {ch[k].x, ch[k].y, ch[k].z, ch[k].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t at = a0 + (uint32_t)(k * kLineIds + 4 * q + t);
+                const bool in = at >= s0 && at < s1;
+                below += ((in && v4[t] < glo) ? 1u : 0u) + ((in && v4[t] < ghi) ? 0x10000u : 0u);
+            }
+        }
+        below += (uint32_t)__shfl_xor((int)below, 1, kWave);
+        below += (uint32_t)__shfl_xor((int)below, 2, kWave);
+        below += (uint32_t)__shfl_xor((int)below, 4, kWave);
+        const uint32_t pos = s0 + (below & 0xffffu), end = s0 + (below >> 16);
+        // the first 4 continuations are the list entries pos .. pos+3 (below `end`): whoever holds one writes it to the owner's LDS row
+#pragma unroll
+        for (int k = 0; k < kGroupLines; ++k) {
+            const uint32_t v4[4] = {ch[k].x, ch[k].y, ch[k].z, ch[k].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t at = a0 + (uint32_t)(k * kLineIds + 4 * q + t);
+                if (at >= pos && at < end && at - pos < (uint32_t)kHeadSlots && at < s1) s_head[w][e][at - pos] = v4[t];
+            }
+        }
+        if (q == 0 && s1 > s0) s_pc[w][e] = make_uint2(pos, end);
     }
+    __builtin_amdgcn_wave_barrier();
+    if (!live) return;
     uint32_t pos = 0;
     int32_t c = 0;
     uint4 h = make_uint4(0u, 0u, 0u, 0u);
-    if (!ok) {
-        atomicOr((unsigned long long*)status, (unsigned long long)kBadIndex);
-    } else if (g_hi > g_lo && s1 > s0) {
-        // The head node's id list [s0, s1) is short (its out-degree) and sits in one or two cache lines that nothing else on this CU
-        // will touch again: fetch kChunks aligned 16-byte pieces of it with back-to-back loads (ONE round trip) and count the ids
-        // below g_lo / g_hi in registers — a binary search on memory costs ~10 dependent touches of a line that the other 2000
-        // lanes of the CU have evicted from L1 (and mostly from L2) in between (measured: 0.73 -> see DESIGN.md §5).
-        // The first 4 continuations fall out of the same registers (the fill kernel reads them in event order).
-        constexpr int kChunks = 12;
-        const uint32_t a0 = s0 & ~3u;
-        uint4 ch[kChunks];
-#pragma unroll
-        for (int k = 0; k < kChunks; ++k) {
-            const uint32_t at = a0 + 4u * k;
-            ch[k] = at < s1 ? *reinterpret_cast<const uint4*>(ids_by_tail + at) : make_uint4(0u, 0u, 0u, 0u);   // (the list array is padded to 4)
-        }
-        const uint32_t glo = (uint32_t)g_lo, ghi = (uint32_t)g_hi;
-        uint32_t below_lo = 0, below_hi = 0;
-        int taken = 0;
-#pragma unroll
-        for (int k = 0; k < kChunks; ++k) {
-            const uint32_t v4[4] = {ch[k].x, ch[k].y, ch[k].z, ch[k].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t at = a0 + 4u * k + e;
-                const bool in = at >= s0 && at < s1;
-                const uint32_t id = v4[e];
-                below_lo += (in && id < glo) ? 1u : 0u;
-                below_hi += (in && id < ghi) ? 1u : 0u;
-                const bool take = in && id >= glo && id < ghi;
-                h.x = (take && taken == 0) ? id : h.x;
-                h.y = (take && taken == 1) ? id : h.y;
-                h.z = (take && taken == 2) ? id : h.z;
-                h.w = (take && taken == 3) ? id : h.w;
-                taken += take ? 1 : 0;
-            }
-        }
-        pos = s0 + below_lo;
-        uint32_t end = s0 + below_hi;
-        const uint32_t covered = a0 + 4u * kChunks;
-        if (covered < s1) {          // longer list (hub node): finish both searches on memory, beyond the part already counted
-            if (pos == covered) pos = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, covered, s1, glo);
-            if (end == covered) end = lower_bound_dev<uint32_t, uint32_t>(ids_by_tail, pos > covered ? pos : covered, s1, ghi);
-            c = (int32_t)(end - pos);
-            if (c > taken) {         // some of the first 4 continuations lie beyond the register window
-                if (taken < 1 && c > 0) h.x = ids_by_tail[pos];
-                if (taken < 2 && c > 1) h.y = ids_by_tail[pos + 1];
-                if (taken < 3 && c > 2) h.z = ids_by_tail[pos + 2];
-                if (taken < 4 && c > 3) h.w = ids_by_tail[pos + 3];
-            }
-        } else {
-            c = (int32_t)(end - pos);
-        }
-        if (c == 0) pos = 0;
+    if (need) {
+        const uint2 pe = s_pc[w][l];
+        h = *reinterpret_cast<const uint4*>(s_head[w][l]);
+        pos = pe.x;
+        uint32_t end = pe.y;
+        const int have = (int)(end - pos) < kHeadSlots ? (int)(end - pos) : kHeadSlots;      // head slots filled from the lines read above
+        list_tail(ids_by_tail, (my_s0 & ~(uint32_t)(kLineIds - 1)) + (uint32_t)(kGroupLines * kLineIds), my_s1, my_glo, my_ghi, have, pos, end, c, h);
     }
     store_stream(first_pos + i, pos);
     store_stream(count + i, c);
-    store_stream_u4(head4 + i * 4, h);
+    if (source) store_stream_u4(head4 + i * 4, h);
 }
 
 // ------------------------------------------------------------------ line-graph count
@@ -262,7 +291,8 @@ __global__ __launch_bounds__(kBlock) void k_linegraph_count(const int64_t* __res
 //
 // The unit of work is ONE WAVE and 512 consecutive output slots; waves never wait for each other (no workgroup
 // barrier: measured 2x faster than a 2048-slot workgroup tile, whose five barriers serialised on the slowest wave).
-//   k_tile_sources  one thread per tile: the source owning the tile's first slot (binary search on `offset`).
+//   (scan)          the offset scan of the count phase also records, per tile, the source owning the tile's first slot
+//                   (pp_scan.hip, `slot_owner`): no separate search kernel.
 //   k_expand        the wave loads the boundaries + first positions of its <= 513 sources with 9 back-to-back
 //                   coalesced loads (a run-time loop here costs one HBM round trip per iteration), marks every
 //                   non-empty source at its first slot in an LDS slot array, spreads the marks with an inclusive
@@ -271,14 +301,6 @@ __global__ __launch_bounds__(kBlock) void k_linegraph_count(const int64_t* __res
 constexpr int kWaveTile = 512;                       // output slots per wave
 constexpr int kWaveCap = kWaveTile + 1;              // sources whose boundaries are staged (else: per-slot search)
 constexpr int kStageIters = (kWaveCap + 1 + kWave - 1) / kWave;
-
-__global__ __launch_bounds__(kBlock) void k_tile_sources(const int64_t* __restrict__ offset, int64_t n_src, int64_t total, int64_t n_tiles,
-                                                        int64_t* __restrict__ tile_src) {
-    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (b > n_tiles) return;
-    const int64_t p = b * kWaveTile;
-    tile_src[b] = p < total ? upper_bound_dev<int64_t, int64_t>(offset, 0, n_src + 1, p) - 1 : n_src - 1;
-}
 
 struct alignas(16) I64x2 { int64_t a, b; };
 struct alignas(16) I32x4 { int32_t x, y, z, w; };
@@ -570,7 +592,7 @@ struct LiftWs {
     uint32_t* sorted_keys;  // temporal only [n_src]
     uint32_t* head4;        // temporal only [n_src * 4]: the first 4 continuations of every event
     uint32_t* marks;        // temporal only [n_src / 64 + 2]: window end of the first event of every wave (k_window_marks)
-    int64_t* tile_src;      // first source of every 512-slot output tile (k_tile_sources) [tile_cap + 1]
+    int64_t* tile_src;      // first source of every 512-slot output tile (written by the offset scan) [tile_cap + 1]
     int64_t tile_cap;
     void* scratch;          // sort / scan workspace
     size_t scratch_bytes;
@@ -600,17 +622,12 @@ static LiftWs carve_lift(void* ws, int64_t n_src, int64_t num_nodes, bool tempor
     return w;
 }
 
-// the per-tile start sources are precomputed when the result is at most 32x the source count; beyond that every
+// the per-tile start sources come from the count phase's scan when the result is at most 32x the source count; beyond that every
 // wave searches for its own start (amortised by the amount of output per source)
 template <bool kList>
 static int launch_expand(const LiftWs& w, int64_t n_src, int64_t total, int64_t id_offset, int64_t* out, hipStream_t st) {
     const int64_t n_tiles = ceil_div(total, kWaveTile);
-    int64_t* tile_src = nullptr;
-    if (n_tiles <= w.tile_cap) {
-        tile_src = w.tile_src;
-        k_tile_sources<<<(unsigned)ceil_div(n_tiles + 1, kBlock), kBlock, 0, st>>>(w.offset, n_src, total, n_tiles, tile_src);
-        PP_LAUNCH_CHECK();
-    }
+    int64_t* tile_src = n_tiles <= w.tile_cap ? w.tile_src : nullptr;          // (written by the count phase's scan)
     k_expand<kList><<<(unsigned)ceil_div(n_tiles, kWavesPerBlock), kBlock, 0, st>>>(w.offset, w.first_pos, kList ? w.ids : nullptr,
                                                                                        kList ? w.head4 : nullptr, n_src, total, id_offset,
                                                                                        tile_src, out);
@@ -686,7 +703,7 @@ int pp_temporal_count(const int64_t* edge_index, const void* time, int time_dtyp
         rc = launch_temporal_count<double>(delta_kind, grid, st, head, (const double*)time, m, n_own, num_nodes, delta_i, delta_f, w);
     if (rc != PP_OK) return rc;
     // 3. offsets + total
-    return exclusive_scan<int32_t, int64_t>(w.count, m, w.offset, true, w.result, w.scratch, w.scratch_bytes, st);
+    return exclusive_scan<int32_t, int64_t>(w.count, m, w.offset, true, w.result, w.scratch, w.scratch_bytes, st, w.tile_src, kWaveTile, w.tile_cap);
 }
 
 int pp_temporal_fill(int64_t m, int64_t num_nodes, int64_t total, int64_t id_offset, int64_t* out, void* ws, size_t ws_bytes,
@@ -720,7 +737,7 @@ int pp_linegraph_count(const int64_t* edge_index, int64_t n_edges, int64_t e_beg
     k_linegraph_count<<<(unsigned)ceil_div(n_edges, kBlock), kBlock, 0, st>>>(edge_index + n_edges, n_edges, num_nodes, w.rowptr,
                                                                              w.first_pos, w.count, e_begin, e_end, w.result + 1);
     PP_LAUNCH_CHECK();
-    return exclusive_scan<int32_t, int64_t>(w.count, n_edges, w.offset, true, w.result, w.scratch, w.scratch_bytes, st);
+    return exclusive_scan<int32_t, int64_t>(w.count, n_edges, w.offset, true, w.result, w.scratch, w.scratch_bytes, st, w.tile_src, kWaveTile, w.tile_cap);
 }
 
 int pp_linegraph_fill(int64_t n_edges, int64_t num_nodes, int64_t total, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream) {

@@ -82,9 +82,14 @@ __global__ __launch_bounds__(kBlock) void k_scan_tile_sums(int64_t* __restrict__
 }
 
 // ---- pass 3: rescan every tile with its base ------------------------------------------------------
+// `slot_owner` (the lift fills): out[] are the output offsets of n sources; slot_owner[b] = the source that owns output slot
+// b * slot_stride (the last source s with out[s] <= b * slot_stride), for every b <= slot_cap whose slot exists, and
+// slot_owner[ceil(total / slot_stride)] = n - 1.  The expansion kernel reads its tile's first / last source from it: the scan has every
+// (offset, count) pair in registers anyway, a separate kernel would bisect the finished offsets once per tile.
 template <typename InT, typename OutT>
 __global__ __launch_bounds__(kBlock) void k_scan_tiles(const InT* __restrict__ in, int64_t n, const int64_t* __restrict__ tile_base,
-                                                      OutT* __restrict__ out, int write_total) {
+                                                      OutT* __restrict__ out, int write_total, int64_t* __restrict__ slot_owner,
+                                                      int64_t slot_stride, int64_t slot_cap) {
     __shared__ int64_t scratch[kWavesPerBlock + 1];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     int64_t v[kScanItems];
@@ -94,6 +99,22 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(const InT* __restrict__ i
     for (int k = 0; k < kScanItems; ++k) s += v[k];
     int64_t tot;
     int64_t run = tile_base[blockIdx.x] + block_exclusive_sum(s, scratch, &tot);
+    if (slot_owner) {
+        int64_t at = run;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            const int64_t i = base + k;
+            if (i < n) {
+                const int64_t end = at + v[k];
+                for (int64_t b = (at + slot_stride - 1) / slot_stride; b * slot_stride < end && b <= slot_cap; ++b) slot_owner[b] = i;
+                if (i == n - 1) {
+                    const int64_t b = (end + slot_stride - 1) / slot_stride;
+                    if (b <= slot_cap) slot_owner[b] = i;
+                }
+                at = end;
+            }
+        }
+    }
     if (base + kScanItems < n && ((uintptr_t)out & 15) == 0) {     // whole chunk inside the array (and not its last item): 16-byte stores
         constexpr int kVec = 16 / sizeof(OutT);
         struct alignas(16) Chunk { OutT x[kVec]; };
@@ -123,11 +144,12 @@ size_t scan_ws_bytes(int64_t n) { return align_up((size_t)(ceil_div(n > 0 ? n : 
 // out[i] = sum(in[0..i)), i in [0,n]; out[n] (= total) is written when `with_total`; *total_dev optional.
 template <typename InT, typename OutT>
 int exclusive_scan(const InT* in, int64_t n, OutT* out, bool with_total, int64_t* total_dev, void* ws, size_t ws_bytes,
-                   hipStream_t st) {
+                   hipStream_t st, int64_t* slot_owner, int64_t slot_stride, int64_t slot_cap) {
     PP_REQUIRE(n >= 0, PP_ERR_ARG, "exclusive_scan: negative length");
     PP_REQUIRE(ws_bytes >= scan_ws_bytes(n), PP_ERR_WORKSPACE, "exclusive_scan: workspace too small");
     int64_t* tile_sum = (int64_t*)ws;
     if (n == 0) {
+        if (slot_owner) PP_HIP(hipMemsetAsync(slot_owner, 0, sizeof(int64_t), st));
         if (with_total) PP_HIP(hipMemsetAsync(out, 0, sizeof(OutT), st));
         if (total_dev) PP_HIP(hipMemsetAsync(total_dev, 0, sizeof(int64_t), st));
         return PP_OK;
@@ -137,15 +159,15 @@ int exclusive_scan(const InT* in, int64_t n, OutT* out, bool with_total, int64_t
     PP_LAUNCH_CHECK();
     k_scan_tile_sums<<<1, kBlock, 0, st>>>(tile_sum, ntiles, total_dev);
     PP_LAUNCH_CHECK();
-    k_scan_tiles<InT, OutT><<<(unsigned)ntiles, kBlock, 0, st>>>(in, n, tile_sum, out, with_total ? 1 : 0);
+    k_scan_tiles<InT, OutT><<<(unsigned)ntiles, kBlock, 0, st>>>(in, n, tile_sum, out, with_total ? 1 : 0, slot_owner, slot_stride, slot_cap);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
 
-template int exclusive_scan<int32_t, int64_t>(const int32_t*, int64_t, int64_t*, bool, int64_t*, void*, size_t, hipStream_t);
-template int exclusive_scan<int32_t, int32_t>(const int32_t*, int64_t, int32_t*, bool, int64_t*, void*, size_t, hipStream_t);
-template int exclusive_scan<int64_t, int64_t>(const int64_t*, int64_t, int64_t*, bool, int64_t*, void*, size_t, hipStream_t);
-template int exclusive_scan<uint32_t, uint32_t>(const uint32_t*, int64_t, uint32_t*, bool, int64_t*, void*, size_t, hipStream_t);
+template int exclusive_scan<int32_t, int64_t>(const int32_t*, int64_t, int64_t*, bool, int64_t*, void*, size_t, hipStream_t, int64_t*, int64_t, int64_t);
+template int exclusive_scan<int32_t, int32_t>(const int32_t*, int64_t, int32_t*, bool, int64_t*, void*, size_t, hipStream_t, int64_t*, int64_t, int64_t);
+template int exclusive_scan<int64_t, int64_t>(const int64_t*, int64_t, int64_t*, bool, int64_t*, void*, size_t, hipStream_t, int64_t*, int64_t, int64_t);
+template int exclusive_scan<uint32_t, uint32_t>(const uint32_t*, int64_t, uint32_t*, bool, int64_t*, void*, size_t, hipStream_t, int64_t*, int64_t, int64_t);
 
 // ---- histogram of an index vector (PyG degree) ---------------------------------------------------
 // Runs of equal values inside a wave (the common case: the line-graph lift's input is source-sorted)
@@ -234,10 +256,10 @@ const char* pp_last_error(void) { return pp::g_err; }
 size_t pp_scan_ws_bytes(int64_t n) { return pp::scan_ws_bytes(n); }
 
 int pp_exclusive_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream) {
-    return pp::exclusive_scan<int32_t, int64_t>(in, n, out, true, nullptr, ws, ws_bytes, (hipStream_t)stream);
+    return pp::exclusive_scan<int32_t, int64_t>(in, n, out, true, nullptr, ws, ws_bytes, (hipStream_t)stream, nullptr, 1, 0);
 }
 int pp_exclusive_scan_i64(const int64_t* in, int64_t n, int64_t* out, void* ws, size_t ws_bytes, pp_stream_t stream) {
-    return pp::exclusive_scan<int64_t, int64_t>(in, n, out, true, nullptr, ws, ws_bytes, (hipStream_t)stream);
+    return pp::exclusive_scan<int64_t, int64_t>(in, n, out, true, nullptr, ws, ws_bytes, (hipStream_t)stream, nullptr, 1, 0);
 }
 int pp_degree_i64(const int64_t* index, int64_t n, int64_t num_bins, int32_t* bins, pp_stream_t stream) {
     return pp::histogram<int64_t>(index, n, num_bins, bins, (hipStream_t)stream);
