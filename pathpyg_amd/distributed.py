@@ -229,6 +229,16 @@ class Comm:
         t.copy_(staged)
         return t
 
+    def all_gather_ints_dev(self, mine: torch.Tensor) -> list[list[int]]:
+        """Every rank's small int64 DEVICE vector (same length everywhere) -> ``[world][len]`` on the host: one collective + one read-back."""
+        if self.world == 1:
+            return [mine.tolist()]
+        src = mine.to(torch.int64).contiguous()
+        src = src if (self.native or not src.is_cuda) else src.cpu()
+        out = torch.empty(self.world * src.numel(), dtype=torch.int64, device=src.device)
+        dist.all_gather_into_tensor(out, src, group=self.group)
+        return out.view(self.world, -1).tolist()
+
     def all_gather_ints(self, values: list[int], device) -> list[list[int]]:
         """Every rank's small integer vector (same length everywhere): ``[world][len(values)]`` on the host."""
         if self.world == 1:
@@ -259,14 +269,32 @@ def _ops_default(ops):
 # Graph shards (see pathpyg_amd.nn.sharded for the layout): halo discovery, the request exchange, the rectangular GCN plan with its
 # one d^-1/2 halo exchange, and the CSR that folds returned gradient rows into the owned rows.
 # =====================================================================================================
+def sorted_halo(src: torch.Tensor, lo: int, hi: int, cuts_t: torch.Tensor):
+    """Halo of an edge list whose global source ids ``src`` are ASCENDING (what the exchanges of :func:`build_dbgnn_shard` deliver): the
+    distinct sources outside ``[lo, hi)`` are the run heads of the list — no flag array over all nodes, no sort.  Returns ``(src_local
+    int64 [E] in the local source space [owned | halo], halo_ids int64 ascending, rows needed from every rank)``."""
+    world = int(cuts_t.numel()) - 1
+    e = int(src.numel())
+    if e == 0:
+        return src, src.new_empty(0), [0] * world
+    foreign = (src < lo) | (src >= hi)
+    head = foreign.clone()
+    head[1:] &= src[1:] != src[:-1]
+    slot = torch.cumsum(head, 0) - 1                                       # halo slot of every foreign edge
+    src_local = torch.where(foreign, slot + (hi - lo), src - lo)
+    halo_ids = src[head]                                                   # (one size read-back)
+    bounds = torch.searchsorted(halo_ids, cuts_t.to(halo_ids.device)).tolist()
+    return src_local, halo_ids, [int(bounds[r + 1] - bounds[r]) for r in range(world)]
+
+
 def build_graph_shard(src: torch.Tensor, dst: torch.Tensor, weight: torch.Tensor | None, num_nodes: int, cuts: list[int], comm: Comm,
                       ops=None, row_sorted: bool = False, status_out: list | None = None, want_dst_order: bool = False,
-                      edge_index: torch.Tensor | None = None):
+                      edge_index: torch.Tensor | None = None, src_sorted: bool = False):
     """This rank's :class:`~pathpyg_amd.nn.sharded.GraphShard` of a graph with ``num_nodes`` nodes from the edges (GLOBAL ids) that
     point into its destination range ``[cuts[rank], cuts[rank+1])`` — GCN normalisation with PyG ``gcn_norm`` semantics
     (reference nn/dbgnn.py:104-114 through GCNConv): every in-edge of an owned node is local, so the weighted in-degree is too;
     the d^-1/2 of the halo sources comes from their owners in one 4-byte-per-row exchange.  ``edge_index``: the same edges as one
-    contiguous [2, E] tensor when the caller has it (saves a copy at world size 1)."""
+    contiguous [2, E] tensor when the caller has it (saves a copy at world size 1); ``src_sorted``: ``src`` ascends (:func:`sorted_halo`)."""
     from .nn.sharded import GraphShard
     ops = _ops_default(ops)
     rank, world = comm.rank, comm.world
@@ -278,33 +306,50 @@ def build_graph_shard(src: torch.Tensor, dst: torch.Tensor, weight: torch.Tensor
         plan = ops.gcn_plan(whole, weight, num_nodes, row_sorted, status_out, want_dst_order=want_dst_order)
         return GraphShard(lo=0, hi=num_nodes, n_own=num_nodes, n_halo=0, n_src=num_nodes, num_nodes=num_nodes, cuts=list(cuts), plan=plan,
                           send_counts=[0], recv_counts=[0])
-    # ---- halo = the distinct foreign sources, ascending (= grouped by owner: owners hold ascending id ranges)
-    need = torch.zeros(num_nodes, dtype=torch.bool, device=dev)
-    need[src] = True
-    need[lo:hi] = False
-    halo_ids = torch.nonzero(need).flatten()
-    n_halo = int(halo_ids.numel())
-    halo_rank = torch.cumsum(need, 0, dtype=torch.int32) - 1
-    foreign = (src < lo) | (src >= hi)
-    src_local = torch.where(foreign, halo_rank[src].to(torch.int64) + n_own, src - lo)
-    del need, halo_rank, foreign
     cuts_t = torch.tensor(cuts, dtype=torch.int64, device=dev)
-    bounds = torch.searchsorted(halo_ids, cuts_t).tolist()
-    recv_counts = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
+    if src_sorted:
+        src_local, halo_ids, recv_counts = sorted_halo(src, lo, hi, cuts_t)
+    else:
+        # halo = the distinct foreign sources, ascending (= grouped by owner: owners hold ascending id ranges)
+        need = torch.zeros(num_nodes, dtype=torch.bool, device=dev)
+        need[src] = True
+        need[lo:hi] = False
+        halo_ids = torch.nonzero(need).flatten()
+        halo_rank = torch.cumsum(need, 0, dtype=torch.int32) - 1
+        foreign = (src < lo) | (src >= hi)
+        src_local = torch.where(foreign, halo_rank[src].to(torch.int64) + n_own, src - lo)
+        del need, halo_rank, foreign
+        bounds = torch.searchsorted(halo_ids, cuts_t).tolist()
+        recv_counts = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
     send_counts = comm.exchange_counts(recv_counts, dev)
     requests = comm.exchange_rows(halo_ids, recv_counts, send_counts)             # the rows each peer wants from me (global ids)
     send_idx = (requests - lo).contiguous()        # (peers derive their requests from the same cuts: every id lies in [lo, hi))
+    return _finish_graph_shard(torch.stack((src_local, dst - lo)), weight, lo, hi, num_nodes, cuts, halo_ids, send_idx, send_counts, recv_counts,
+                               comm, ops, status_out, unique_send=False, want_dst_order=want_dst_order)
+
+
+def _finish_graph_shard(ei_local: torch.Tensor, weight, lo: int, hi: int, num_nodes: int, cuts: list[int], halo_ids: torch.Tensor,
+                        send_idx: torch.Tensor, send_counts: list[int], recv_counts: list[int], comm: Comm, ops, status_out,
+                        unique_send: bool, want_dst_order: bool = False):
+    """Rectangular GCN plan over the local source space ``[owned | halo]`` (one d^-1/2 exchange between its two phases) + the bookkeeping of
+    the layer exchanges.  ``unique_send``: every owned row goes to at most one peer (De Bruijn layers): returned gradient rows are added in
+    place, no CSR over the send list is needed."""
+    from .nn.sharded import GraphShard
+    n_own, n_halo = hi - lo, int(halo_ids.numel())
+    dev = ei_local.device
 
     def halo_dinv(dinv_own: torch.Tensor) -> torch.Tensor:
         return comm.exchange_rows(dinv_own.index_select(0, send_idx), send_counts, recv_counts)
 
-    plan = ops.gcn_plan_partition(torch.stack((src_local, dst - lo)), weight, n_own + n_halo, n_own, halo_dinv, row_sorted=False,
-                                  status_out=status_out, want_dst_order=want_dst_order)
-    back_ptr, back_idx = ops.group_rows(send_idx, n_own) if send_idx.numel() else (torch.zeros(n_own + 1, dtype=torch.int32, device=dev),
-                                                                                   torch.zeros(0, dtype=torch.int32, device=dev))
+    plan = ops.gcn_plan_partition(ei_local, weight, n_own + n_halo, n_own, halo_dinv, row_sorted=False, status_out=status_out,
+                                  want_dst_order=want_dst_order)
+    back_ptr = back_idx = None
+    if not unique_send:
+        back_ptr, back_idx = ops.group_rows(send_idx, n_own) if send_idx.numel() else (torch.zeros(n_own + 1, dtype=torch.int32, device=dev),
+                                                                                       torch.zeros(0, dtype=torch.int32, device=dev))
     return GraphShard(lo=lo, hi=hi, n_own=n_own, n_halo=n_halo, n_src=n_own + n_halo, num_nodes=num_nodes, cuts=list(cuts), plan=plan,
                       halo_ids=halo_ids, send_idx=send_idx, send_counts=send_counts, recv_counts=recv_counts, back_ptr=back_ptr,
-                      back_idx=back_idx)
+                      back_idx=back_idx, send_unique=unique_send)
 
 
 def _bipartite_shard(ho_local: torch.Tensor, fo_global: torch.Tensor, n_ho_own: int, fo_cuts: list[int], comm: Comm, ops, src_sorted: bool):
@@ -365,104 +410,277 @@ def shard_dbgnn_bundle(data, comm: Comm, ops=None, fo_cuts: list[int] | None = N
     return DbgnnShard(fo=fo, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x.contiguous(), x_h=x_h.contiguous(), y=y, n_fo=n_fo, n_ho=n_ho)
 
 
-def build_dbgnn_shard(g, delta, x: torch.Tensor, x_h, y: torch.Tensor | None, comm: Comm, ops=None, weight: str = "edge_weight"):
+ROW_COST = 2          # cost of a higher-order row relative to one of its in-edges when the cuts are balanced (a row is read and written once)
+
+
+def _rows_of(source, rows: torch.Tensor | None, lo: int = 0, hi: int = 0):
+    """Feature / label rows from a replicated tensor or from a ROW LOADER ``source(rows int64) -> tensor`` (a rank of a partitioned run only
+    ever touches its owned + halo rows: a 10^8 x 256 feature matrix need not exist on any single GPU)."""
+    if source is None:
+        return None
+    if callable(source):
+        return source(rows if rows is not None else torch.arange(lo, hi))
+    return source.index_select(0, rows) if rows is not None else source[lo:hi]
+
+
+def _window_ends(time: torch.Tensor, his: torch.Tensor, delta) -> torch.Tensor:
+    """:func:`halo_end` for a vector of range ends ``his`` (device tensor), without a host read-back."""
+    m = int(time.numel())
+    idx = (his - 1).clamp(min=0, max=max(m - 1, 0))
+    delta_t = delta.to(time.device) if isinstance(delta, torch.Tensor) else torch.as_tensor(delta, device=time.device)
+    thr = time[idx] + delta_t
+    if thr.dtype != time.dtype and not time.dtype.is_floating_point:
+        t64 = thr.double()
+        step = t64.abs() * (2.0 ** -23 if thr.dtype == torch.float32 else 2.0 ** -52) + 1.0
+        bound = torch.ceil(t64 + step).clamp(max=float(2 ** 62)).to(torch.int64)
+    else:
+        bound = thr.to(time.dtype)
+    ends = torch.searchsorted(time, bound.contiguous(), right=True)
+    ends = torch.maximum(ends, his)
+    return torch.where(his <= 0, torch.zeros_like(his), torch.where(his >= m, torch.full_like(his, m), ends))
+
+
+def _balanced_cuts(weights: torch.Tensor, world: int) -> torch.Tensor:
+    """Device int64 ``[world + 1]``: cut positions over ``len(weights)`` items so that every part carries about the same weight (exact integer
+    arithmetic: every rank derives the SAME cuts from the same replicated input, no collective)."""
+    n = int(weights.numel())
+    prefix = torch.cumsum(weights.to(torch.int64), 0)
+    total = prefix[-1] if n else torch.zeros((), dtype=torch.int64, device=weights.device)
+    targets = (total * torch.arange(1, world, device=weights.device, dtype=torch.int64)) // world
+    inner = torch.searchsorted(prefix, targets, right=True).clamp_(max=n) if n else torch.zeros(world - 1, dtype=torch.int64, device=weights.device)
+    inner = torch.cummax(inner, 0).values if world > 1 else inner
+    ends = torch.tensor([0, n], dtype=torch.int64, device=weights.device)
+    return torch.cat((ends[:1], inner, ends[1:]))
+
+
+def partition_plan(ei: torch.Tensor, time: torch.Tensor, n: int, delta, world: int, ops):
+    """Everything the ranks must agree on BEFORE they split up, derived from the replicated stream with exact integer arithmetic (identical on
+    every rank, no collective) and read back with ONE device-to-host copy:
+
+    * ``fo_cuts``: first-order node ranges.  Rank r owns the nodes ``[fo_cuts[r], fo_cuts[r+1])``, the order-2 nodes ``(a, .)`` of its nodes a
+      and runs layer 1 on the events that START in its range.  Balanced by estimated work: a node b costs ``ROW_COST`` per outgoing event
+      (its rows ``(b, .)``) plus its expected in-edges ``in(b) * out(b) * delta / span`` (SURVEY §8e "balanced by nnz");
+    * ``ev_cuts``: source-event ranges of the edge-range lift, balanced by the expected OUTPUT of an event (the out-degree of its head node;
+      SURVEY §8e "balanced by output count") and ``ev_ends``: where each range's forward halo ends;
+    * ``order`` / ``owner_ptr``: the event ids grouped by the owner of their START node (stable: ascending inside a group) — rank r's layer-1
+      events are ``order[owner_ptr[r]:owner_ptr[r+1]]``, and every rank knows every other rank's list (needed to place the gathered
+      event -> order-2 node maps)."""
+    dev = ei.device
+    m = int(ei.size(1))
+    outdeg, indeg = ops.degree(ei[0], n).to(torch.int64), ops.degree(ei[1], n).to(torch.int64)
+    if m > 0:
+        span = (time[-1] - time[0]).to(torch.float64).clamp(min=1e-300)
+        delta_t = (delta.to(dev) if isinstance(delta, torch.Tensor) else torch.as_tensor(delta, device=dev)).to(torch.float64)
+        frac_q = torch.floor((delta_t / span).clamp(min=0.0, max=1.0) * 1024.0).to(torch.int64)      # window share of the stream, in 1/1024
+    else:
+        frac_q = torch.zeros((), dtype=torch.int64, device=dev)
+    node_w = outdeg * (ROW_COST * 1024 + indeg * frac_q) + 1                                          # (+1: empty nodes still get spread)
+    fo_cuts_t = _balanced_cuts(node_w, world)
+    ev_w = outdeg.index_select(0, ei[1]) + 1 if m else torch.zeros(0, dtype=torch.int64, device=dev)
+    ev_cuts_t = _balanced_cuts(ev_w, world)
+    ev_ends_t = _window_ends(time, ev_cuts_t[1:], delta) if m else torch.zeros(world, dtype=torch.int64, device=dev)
+    owner = torch.searchsorted(fo_cuts_t[1:-1].contiguous(), ei[0].contiguous(), right=True) if world > 1 else torch.zeros(m, dtype=torch.int64, device=dev)
+    owner_ptr_t, order = ops.group_rows(owner, world)
+    host = torch.cat((fo_cuts_t, ev_cuts_t, ev_ends_t, owner_ptr_t.to(torch.int64))).tolist()
+    w1 = world + 1
+    return {"fo_cuts": host[:w1], "ev_cuts": host[w1: 2 * w1], "ev_ends": host[2 * w1: 2 * w1 + world], "owner_ptr": host[2 * w1 + world:],
+            "fo_cuts_t": fo_cuts_t, "order": order}
+
+
+def _route(keys_owner: torch.Tensor, world: int, ops):
+    """Stable grouping of items by destination rank: ``(ptr device int32 [world+1], order int64 [n])``."""
+    ptr, order = ops.group_rows(keys_owner, world)
+    return ptr, order.long()
+
+
+def build_dbgnn_shard(g, delta, x, x_h, y, comm: Comm, ops=None, weight: str = "edge_weight"):
     """The north-star split, straight from a time-sorted event stream replicated on every rank (what it replaces on one process:
     ``MultiOrderModel.from_temporal_graph(g, delta, max_order=2)`` + ``to_dbgnn_data`` + the plans of ``DBGNN.forward``; reference
-    multi_order_model.py:124-192, 511-554, algorithms/temporal.py:17-54, lift_order.py:109-152):
+    multi_order_model.py:124-192, 511-554, algorithms/temporal.py:17-54, lift_order.py:109-152).
 
-    1. layer 1 (first-order graph = coalesce of the events, and the event -> order-2 node map) on every rank;
-    2. row cuts at first-order node boundaries, balanced by order-2 node count (an order-2 node (a, b) belongs to the owner of a);
-    3. EDGE-RANGE sharded event-graph lift (own events + forward halo, no exchange);
-    4. the lifted pairs (u, v) go to the OWNER OF THEIR DESTINATION v in one all-to-all (12 bytes per pair) and are coalesced there:
-       every rank ends up with exactly the in-edges of its order-2 rows — the layout the destination-partitioned DBGNN consumes.
-       Pairs arrive in (source rank, local) = global instance order, so merged weights are summed in the single-process order;
-    5. graph shards (halo, rectangular GCN plans) of both graphs, the bipartite "last" plan, local feature rows.
+    World size 1: the single-GPU kernels back to back (layer-1 coalesce and the lift share one size read-back).  World size R > 1
+    (:func:`_build_partitioned`): every stage is sharded —
 
-    ``x`` [N, F] / ``x_h`` [U_2, F] (or a callable ``x_h(num_ho_nodes) -> tensor``) / ``y`` [N] are replicated inputs.
+    0. :func:`partition_plan`: node ranges balanced by estimated nnz, event ranges balanced by expected output, no collective;
+    1. LAYER 1 BY START-NODE RANGE: rank r coalesces the events that start in its node range — they yield exactly the order-2 nodes
+       ``(a, .)`` it owns, in global lexicographic order.  Two all-gathers make the result global: the per-node block sizes (N ints: global
+       ids, ``row_ptr``) and the event -> order-2 node map (m ints);
+    2. EDGE-RANGE LIFT with a forward halo, no exchange (``pp_temporal_count/_fill`` with ``n_own`` / ``id_offset``);
+    3. the lifted pairs (u, v) go to the OWNER OF THEIR DESTINATION v in one all-to-all (8 bytes per pair, + the weight when the stream is
+       weighted) and are coalesced there: every rank ends up with exactly the in-edges of its order-2 rows.  Pairs arrive in (source
+       rank, local) = global instance order, so merged weights are summed in the single-process order;
+    4. the order-2 nodes ``(a, b)`` — which ARE the first-order edges — go to the owner of b in one all-to-all (16 bytes per node): the
+       receiver gets the in-edges of its first-order rows and, by the De Bruijn property, exactly the higher-order rows its layers will
+       gather from (``(a, b)`` feeds only rows ``(b, .)``): the higher-order halo needs no request round, every owned row has ONE consumer;
+    5. graph shards (rectangular GCN plans with one d^-1/2 halo exchange each), the bipartite "last" plan, local feature rows.
+
+    ``x`` [N, F] / ``x_h`` [U_2, F] / ``y`` [N]: replicated tensors, or ROW LOADERS ``f(rows int64) -> tensor`` (``x_h`` may also be a
+    callable of the node count, the round-2 form, when it takes an ``int``) — a rank only ever reads its owned + halo rows.
     Returns a :class:`~pathpyg_amd.nn.sharded.DbgnnShard`; ``shard.sizes`` reports the global layer sizes."""
-    from .nn.sharded import DbgnnShard
     ops = _ops_default(ops)
-    rank, world = comm.rank, comm.world
+    if comm.world > 1:
+        return _build_partitioned(g, delta, x, x_h, y, comm, ops, weight)
+    from .nn.sharded import DbgnnShard
     data = g.data
     ei = _dispatch.plain(data.edge_index)
     dev = ei.device
     n, m = int(data.num_nodes), int(ei.size(1))
     unit_weights = weight not in data
     w = torch.ones(m, device=dev) if unit_weights else data[weight]
-    # 1. layer 1 — and 3. the edge-range lift of the same stream: independent of each other, so their count phases are queued together and
-    #    their sizes cost ONE read-back
-    lo_e, hi_e = event_ranges(m, world)[rank]
-    end = halo_end(data.time, hi_e, delta) if hi_e > lo_e else lo_e
-    (fo, fo_w, inv1), local = ops.coalesce_and_lift(
-        (ei, w, n, "sum", None, True),
-        (ei[:, lo_e:end].contiguous(), data.time[lo_e:end].contiguous(), n, delta, hi_e - lo_e, lo_e))
+    # layer 1 and the lift of the same stream are independent: their count phases are queued together, their sizes cost ONE read-back
+    (fo, fo_w, inv1), local = ops.coalesce_and_lift((ei, w, n, "sum", None, True), (ei, data.time.contiguous(), n, delta, m, 0))
     n_ho = int(fo.size(1))
     row_ptr = ops.ptr_from_sorted(fo[0], n)                                  # int64 [n+1]: order-2 nodes (a, .) = ids row_ptr[a] .. row_ptr[a+1]
-    # 2. cuts
     pending = []
-    fo_shard = None
-    if world == 1:
-        fo_cuts, ho_cuts = [0, n], [0, n_ho]
-        # the first-order graph needs nothing that follows: its plan kernels are queued NOW, in front of the size read-backs below, so the
-        # GPU has ~1 ms of work while the host waits for them
-        fo_shard = build_graph_shard(fo[0], fo[1], fo_w.to(torch.float32), n, fo_cuts, comm, ops, True, pending, want_dst_order=True, edge_index=fo)
-        widest = int((row_ptr[1:] - row_ptr[:-1]).max().item()) if n > 0 else 1
-    else:
-        targets = torch.tensor([(n_ho * r) // world for r in range(1, world)], dtype=torch.int64, device=dev)
-        inner = torch.searchsorted(row_ptr, targets)
-        head = torch.cat((inner, (row_ptr[1:] - row_ptr[:-1]).max().reshape(1) if n > 0 else torch.ones(1, dtype=torch.int64, device=dev))).tolist()
-        widest = int(head[-1])
-        fo_cuts = [0] + [min(int(c), n) for c in head[:-1]] + [n]
-        for i in range(1, len(fo_cuts)):
-            fo_cuts[i] = max(fo_cuts[i], fo_cuts[i - 1])
-        ho_cuts = row_ptr[torch.tensor(fo_cuts, dtype=torch.int64, device=dev)].tolist()
+    fo_cuts, ho_cuts = [0, n], [0, n_ho]
+    # the first-order graph needs nothing that follows: its plan kernels are queued NOW, in front of the size read-backs below, so the
+    # GPU has ~1 ms of work while the host waits for them
+    fo_shard = build_graph_shard(fo[0], fo[1], fo_w.to(torch.float32), n, fo_cuts, comm, ops, True, pending, want_dst_order=True, edge_index=fo)
+    widest = int((row_ptr[1:] - row_ptr[:-1]).max().item()) if n > 0 else 1
     col_block = (row_ptr[fo[1]], max(int(widest - 1).bit_length(), 1)) if n_ho else None     # successors of (a, b): the id block of b
+    e2 = int(local.size(1))
+    w_pairs = torch.ones(e2, device=dev) if unit_weights else w.index_select(0, local[0])   # lifted weight = weight of the source event
+    ho_ei, ho_w = ops.coalesce(local, w_pairs, n_ho, "sum", inv1, False, col_block)
+    ho = build_graph_shard(ho_ei[0], ho_ei[1], ho_w.to(torch.float32), n_ho, ho_cuts, comm, ops, True, pending, edge_index=ho_ei)
+    bip = ops.bipartite_from_grouping(fo_shard.plan, fo[1], n_ho)
+    ops.check_plan_status(pending)
+    fptr = fo_shard.plan.fwd_ptr
+    indeg = (fptr[1:] - fptr[:-1]).to(torch.float32)                            # order-2 nodes (., b) per first-order node b
+    x_loc = _rows_of(x, None, 0, n)
+    xh_loc = x_h(n_ho) if (callable(x_h) and _takes_count(x_h)) else _rows_of(x_h, None, 0, n_ho)
+    a2 = int(ho_ei.size(1))
+    return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=n, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(), y=_rows_of(y, None, 0, n),
+                      n_fo=n, n_ho=n_ho,
+                      sizes={"m": m, "N": n, "E2": e2, "E2_local": e2, "U2": n_ho, "A1": n_ho, "A2": a2, "A2_local": a2, "fo_cuts": fo_cuts,
+                             "ho_cuts": ho_cuts, "fo_halo": 0, "ho_halo": 0})
+
+
+def _takes_count(fn) -> bool:
+    """Round-2 form of the ``x_h`` argument: ``x_h(num_ho_nodes) -> [U, F]`` (marked by the attribute ``takes_count``, or by a parameter
+    named ``num_ho_nodes`` / ``n_ho``)."""
+    if getattr(fn, "takes_count", False):
+        return True
+    try:
+        import inspect
+        names = list(inspect.signature(fn).parameters)
+    except (TypeError, ValueError):
+        return False
+    return bool(names) and names[0] in ("num_ho_nodes", "n_ho", "num_nodes")
+
+
+def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
+    """World size > 1 branch of :func:`build_dbgnn_shard` (see there for the scheme)."""
+    from .nn.sharded import DbgnnShard, GraphShard
+    rank, world = comm.rank, comm.world
+    data = g.data
+    ei = _dispatch.plain(data.edge_index)
+    dev = ei.device
+    time = data.time.contiguous()
+    n, m = int(data.num_nodes), int(ei.size(1))
+    unit_weights = weight not in data
+    w_all = None if unit_weights else data[weight]
+    i64 = dict(dtype=torch.int64, device=dev)
+    # ---- 0. the plan every rank derives for itself (one read-back)
+    plan = partition_plan(ei, time, n, delta, world, ops)
+    fo_cuts, owner_ptr = plan["fo_cuts"], plan["owner_ptr"]
+    fo_cuts_t, order = plan["fo_cuts_t"], plan["order"]
+    lo_n, hi_n = fo_cuts[rank], fo_cuts[rank + 1]
+    n_fo_own = hi_n - lo_n
+    lo_e, hi_e = plan["ev_cuts"][rank], plan["ev_cuts"][rank + 1]
+    end_e = max(plan["ev_ends"][rank], hi_e) if hi_e > lo_e else lo_e
+    # ---- 1. layer 1 on the events that start in my node range  +  2. the edge-range lift (count phases queued together: one read-back)
+    mine = order[owner_ptr[rank]: owner_ptr[rank + 1]].long()
+    ei_r = ei.index_select(1, mine)
+    w_r = torch.ones(mine.numel(), device=dev) if unit_weights else w_all.index_select(0, mine)
+    (fo_r, fo_w_r, inv_r), local = ops.coalesce_and_lift(
+        (ei_r, w_r, n, "sum", None, True),
+        (ei[:, lo_e:end_e].contiguous(), time[lo_e:end_e].contiguous(), n, delta, hi_e - lo_e, lo_e))
+    n_ho_own = int(fo_r.size(1))
+    # global ids: per-node block sizes of all ranks (N ints over the wire) -> row_ptr; event -> order-2 node map of all ranks (m ints)
+    cap_n = max(max(fo_cuts[r + 1] - fo_cuts[r] for r in range(world)), 1)
+    cap_m = max(max(owner_ptr[r + 1] - owner_ptr[r] for r in range(world)), 1)
+    ptr_r = ops.ptr_from_sorted(fo_r[0] - lo_n, n_fo_own)                                       # int64 [n_fo_own + 1], local
+    blocks_pad = torch.zeros(cap_n, **i64)
+    blocks_pad[:n_fo_own] = ptr_r[1:] - ptr_r[:-1]
+    inv_pad = torch.zeros(cap_m, dtype=torch.int32, device=dev)
+    inv_pad[: mine.numel()] = inv_r.to(torch.int32)
+    blocks_all = comm.all_gather_rows(blocks_pad.to(torch.int32)).view(world, cap_n)
+    inv_all = comm.all_gather_rows(inv_pad).view(world, cap_m)
+    blocks = torch.cat([blocks_all[r, : fo_cuts[r + 1] - fo_cuts[r]] for r in range(world)]).to(torch.int64)      # [n]
+    row_ptr = torch.zeros(n + 1, **i64)
+    torch.cumsum(blocks, 0, out=row_ptr[1:])
+    ho_cuts_t = row_ptr.index_select(0, fo_cuts_t)                                              # order-2 id ranges = blocks of the node ranges
     e2_local = int(local.size(1))
-    w_pairs = torch.ones(e2_local, device=dev) if unit_weights else w.index_select(0, local[0])   # lifted weight = weight of the source event
-    # 4. aggregation at the destination owner
-    if world == 1:
-        ho_ei, ho_w = ops.coalesce(local, w_pairs, n_ho, "sum", inv1, False, col_block)
+    totals = torch.tensor([e2_local], **i64)
+    head = torch.cat((ho_cuts_t, totals)).tolist()                                              # (read-back: global order-2 ids)
+    ho_cuts = head[: world + 1]
+    n_ho = ho_cuts[-1]
+    lo_h, hi_h = ho_cuts[rank], ho_cuts[rank + 1]
+    assert hi_h - lo_h == n_ho_own, "partition_plan: the ranks disagree on the order-2 node ranges"
+    inv1 = torch.empty(m, dtype=torch.int64, device=dev)                                          # event -> global order-2 node id
+    vals = torch.cat([inv_all[r, : owner_ptr[r + 1] - owner_ptr[r]].to(torch.int64) + ho_cuts[r] for r in range(world)])
+    inv1.index_copy_(0, order.long(), vals)
+    del vals, inv_all, blocks_all
+    # ---- 3. lifted pairs to the owner of their destination  +  4. order-2 nodes (= first-order edges) to the owner of their head node:
+    #         both send-count vectors travel in ONE all-gather, one read-back
+    u, v = inv1.index_select(0, local[0]), inv1.index_select(0, local[1])
+    p_ptr, p_order = _route(torch.searchsorted(ho_cuts_t[1:-1].contiguous(), v, right=True), world, ops)
+    f_ptr, f_order = _route(torch.searchsorted(fo_cuts_t[1:-1].contiguous(), fo_r[1].contiguous(), right=True), world, ops)
+    counts = comm.all_gather_ints_dev(torch.cat((p_ptr[1:] - p_ptr[:-1], f_ptr[1:] - f_ptr[:-1])).to(torch.int64))      # [world][2 * world]
+    p_send, f_send = counts[rank][:world], counts[rank][world:]
+    p_recv, f_recv = [counts[r][rank] for r in range(world)], [counts[r][world + rank] for r in range(world)]
+    pairs = torch.stack((u, v), dim=1).to(torch.int32).index_select(0, p_order)
+    pairs_in = comm.exchange_rows(pairs, p_send, p_recv)
+    if unit_weights:
+        w_in = torch.ones(pairs_in.size(0), device=dev)
     else:
-        u, v = inv1.index_select(0, local[0]), inv1.index_select(0, local[1])
-        cuts_t = torch.tensor(ho_cuts, dtype=torch.int64, device=dev)
-        owner = torch.searchsorted(cuts_t[1:].contiguous(), v, right=True).clamp_(max=world - 1)
-        ptr, order = ops.group_rows(owner, world)
-        counts = (ptr[1:] - ptr[:-1]).tolist()
-        order = order.long()
-        ids = torch.stack((u, v), dim=1).to(torch.int32).index_select(0, order)
-        recv_counts = comm.exchange_counts(counts, dev)
-        ids_r = comm.exchange_rows(ids, counts, recv_counts)
-        w_r = comm.exchange_rows(w_pairs.index_select(0, order), counts, recv_counts)
-        ho_ei, ho_w = ops.coalesce(ids_r.t().to(torch.int64).contiguous(), w_r, n_ho, "sum", None, False, col_block)
-        del u, v, owner, order, ids, ids_r, w_r
-    # 5. shards
-    ho = build_graph_shard(ho_ei[0], ho_ei[1], ho_w.to(torch.float32), n_ho, ho_cuts, comm, ops, world == 1, pending, edge_index=ho_ei)
-    if fo_shard is None:
-        mine = torch.nonzero((fo[1] >= fo_cuts[rank]) & (fo[1] < fo_cuts[rank + 1])).flatten()      # one size read-back for all three gathers
-        f_src, f_dst, f_w = fo[0].index_select(0, mine), fo[1].index_select(0, mine), fo_w.index_select(0, mine)
-        fo_shard = build_graph_shard(f_src, f_dst, f_w.to(torch.float32), n, fo_cuts, comm, ops, False, pending)
-    if world == 1:
-        bip, cap = ops.bipartite_from_grouping(fo_shard.plan, fo[1], n_ho), n
-    else:
-        own = torch.arange(ho.n_own, device=dev)
-        bip, cap = _bipartite_shard(own, fo[1][ho_cuts[rank]: ho_cuts[rank + 1]], ho.n_own, fo_cuts, comm, ops, src_sorted=True)
+        w_in = comm.exchange_rows(w_all.index_select(0, local[0]).index_select(0, p_order), p_send, p_recv)     # weight of the source event
+    own_ids = torch.arange(lo_h, hi_h, **i64)
+    nodes = torch.stack((fo_r[0], fo_r[1], own_ids, fo_w_r.to(torch.float32).view(torch.int32).to(torch.int64)), dim=1).to(torch.int32)
+    nodes_out = nodes.index_select(0, f_order)
+    nodes_in = comm.exchange_rows(nodes_out, f_send, f_recv)                                     # (a, b, global id, weight bits), sorted by id
+    del u, v, pairs, nodes
+    # ---- layer 2: the in-edges of my order-2 rows
+    ho_ei, ho_w = ops.coalesce(pairs_in.t().to(torch.int64).contiguous(), w_in, n_ho, "sum", None, False, None)
+    # ---- 5. shards.  Higher-order graph: the halo is structural — the order-2 nodes (a, b) with b in my node range that other ranks own
+    pending = []
+    f_off = [0]
+    for c in f_recv:
+        f_off.append(f_off[-1] + c)
+    foreign = torch.cat((nodes_in[: f_off[rank]], nodes_in[f_off[rank + 1]:]))
+    ho_halo_ids = foreign[:, 2].to(torch.int64).contiguous()                                      # ascending (senders hold ascending id ranges)
+    keep = torch.ones(int(f_order.numel()), dtype=torch.bool, device=dev)
+    s_off = [0]
+    for c in f_send:
+        s_off.append(s_off[-1] + c)
+    ho_send_idx = torch.cat((f_order[: s_off[rank]], f_order[s_off[rank + 1]:])).contiguous()     # my rows, grouped by the rank that gathers them
+    del keep
+    ho_send = [0 if r == rank else f_send[r] for r in range(world)]
+    ho_recv = [0 if r == rank else f_recv[r] for r in range(world)]
+    src = ho_ei[0]
+    own = (src >= lo_h) & (src < hi_h)
+    src_local = torch.where(own, src - lo_h, n_ho_own + torch.searchsorted(ho_halo_ids, src.contiguous())) if ho_halo_ids.numel() else src - lo_h
+    ho = _finish_graph_shard(torch.stack((src_local, ho_ei[1] - lo_h)), ho_w.to(torch.float32), lo_h, hi_h, n_ho, ho_cuts, ho_halo_ids, ho_send_idx,
+                             ho_send, ho_recv, comm, ops, pending, unique_send=True)
+    # first-order graph: my in-edges (a -> b, b in my range) arrived sorted by a; its halo = the distinct foreign a (request round)
+    fo_shard = build_graph_shard(nodes_in[:, 0].to(torch.int64), nodes_in[:, 1].to(torch.int64), nodes_in[:, 3].contiguous().view(torch.float32), n, fo_cuts,
+                                 comm, ops, False, pending, src_sorted=True)
+    bip, cap = _bipartite_shard(torch.arange(n_ho_own, **i64), fo_r[1], n_ho_own, fo_cuts, comm, ops, src_sorted=True)
     ops.check_plan_status(pending)
     fptr = fo_shard.plan.fwd_ptr
     indeg = (fptr[1:] - fptr[:-1]).to(torch.float32)                            # order-2 nodes (., b) per owned first-order node b
-    if callable(x_h):
+    x_loc = _rows_of(x, fo_shard.local_rows())
+    if callable(x_h) and _takes_count(x_h):
         x_h = x_h(n_ho)
-    x_loc = x if world == 1 else x.index_select(0, fo_shard.local_rows())
-    xh_loc = x_h if world == 1 else x_h.index_select(0, ho.local_rows())
-    if world == 1:
-        e2, a2 = e2_local, int(ho_ei.size(1))
-    else:
-        totals = torch.tensor([e2_local, int(ho_ei.size(1))], dtype=torch.float64, device=dev)
-        comm.all_reduce_(totals)
-        e2, a2 = (int(v) for v in totals.tolist())
+    xh_loc = _rows_of(x_h, ho.local_rows())
+    sums = torch.tensor([e2_local, int(ho_ei.size(1))], dtype=torch.float64, device=dev)
+    comm.all_reduce_(sums)
+    e2, a2 = (int(t) for t in sums.tolist())
     return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(),
-                      y=None if y is None else y[fo_cuts[rank]: fo_cuts[rank + 1]], n_fo=n, n_ho=n_ho,
+                      y=_rows_of(y, None, lo_n, hi_n), n_fo=n, n_ho=n_ho,
                       sizes={"m": m, "N": n, "E2": e2, "E2_local": e2_local, "U2": n_ho, "A1": n_ho, "A2": a2, "A2_local": int(ho_ei.size(1)),
-                             "fo_cuts": fo_cuts, "ho_cuts": ho_cuts, "fo_halo": fo_shard.n_halo, "ho_halo": ho.n_halo})
+                             "fo_cuts": fo_cuts, "ho_cuts": ho_cuts, "ev_cuts": plan["ev_cuts"], "fo_halo": fo_shard.n_halo, "ho_halo": ho.n_halo,
+                             "lift_events_local": end_e - lo_e, "layer1_events_local": int(mine.numel())})
 
 
 from .nn.sharded import ShardedDBGNN  # noqa: E402,F401  (historic import location)

@@ -48,6 +48,7 @@ class HipOps:
         sizes come back with one read (``(coalesce result, lift result)``)."""
         return tuple(_hip.run_together(_hip.coalesce_steps(*coalesce_args), _hip.temporal_lift_steps(*lift_args)))
     ptr_from_sorted = staticmethod(_hip.ptr_from_sorted)
+    degree = staticmethod(_hip.degree)
 
     @staticmethod
     def group_rows(keys: torch.Tensor, num_rows: int):
@@ -168,10 +169,11 @@ class GraphShard:
     ``plan``: rectangular CsrPlan over local ids (destinations ``[0, n_own)``, sources ``[0, n_own + n_halo)``, owned node i is
     both source i and destination i); ``halo_ids``: global ids of the halo rows (ascending, hence grouped by owner);
     ``send_idx`` / ``send_counts``: owned rows each peer asked for; ``recv_counts``: halo rows coming from each peer;
-    ``back_ptr`` / ``back_idx``: CSR over the owned rows into the ``[n_send]`` buffer of returned gradient rows."""
+    ``back_ptr`` / ``back_idx``: CSR over the owned rows into the ``[n_send]`` buffer of returned gradient rows; ``send_unique``: every
+    owned row is sent to at most one peer (De Bruijn layers cut at first-order node boundaries): returned rows are added in place."""
 
     __slots__ = ("lo", "hi", "n_own", "n_halo", "n_src", "num_nodes", "cuts", "plan", "halo_ids", "send_idx", "send_counts", "recv_counts",
-                 "back_ptr", "back_idx")
+                 "back_ptr", "back_idx", "send_unique")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -195,13 +197,19 @@ def halo_fill(shard: GraphShard, comm, buf: torch.Tensor) -> None:
     comm.exchange_rows(send, shard.send_counts, shard.recv_counts, out=buf[shard.n_own:])
 
 
-def halo_reduce(shard: GraphShard, comm, ops, d_halo: torch.Tensor):
-    """Return the halo rows' gradient contributions to their owners; result: ``[n_own, K]`` sums of what the peers sent (or None)."""
+def halo_reduce(shard: GraphShard, comm, ops, d_halo: torch.Tensor, d_own: torch.Tensor | None = None):
+    """Return the halo rows' gradient contributions to their owners; result: ``[n_own, K]`` sums of what the peers sent (or None).
+    ``send_unique`` shards with ``d_own`` given: the returned rows are added to ``d_own`` in place (every row has one consumer) -> None."""
     if comm.world == 1:
         return None
     recv = comm.exchange_rows(d_halo.contiguous(), shard.recv_counts, shard.send_counts)
     if recv.size(0) == 0:
         return None
+    if shard.send_unique:
+        if d_own is not None:
+            d_own.index_add_(0, shard.send_idx, recv)
+            return None
+        return torch.zeros((shard.n_own, recv.size(1)), dtype=recv.dtype, device=recv.device).index_add_(0, shard.send_idx, recv)
     return ops.spmm(shard.back_ptr, shard.back_idx, None, shard.n_own, recv)
 
 
@@ -278,7 +286,7 @@ class _ShardedGcnStack(torch.autograd.Function):
             if fuse_below is not None:
                 d = d_lin
             else:
-                extra = halo_reduce(shard, comm, ops, d_lin[n_own:])
+                extra = halo_reduce(shard, comm, ops, d_lin[n_own:], d_lin[:n_own])
                 if ctx.drop is None:
                     d, colsum = ops.act_combine(d_lin[:n_own], extra, x_in[:n_own])
                 else:

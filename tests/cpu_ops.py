@@ -149,6 +149,10 @@ class CpuOps:
         return merged_index, merged_weight, torch.searchsorted(keys.contiguous(), (ei[0] * num_nodes + ei[1]).contiguous())
 
     @staticmethod
+    def degree(index, num_bins):
+        return torch.bincount(index, minlength=num_bins).to(torch.int32)
+
+    @staticmethod
     def ptr_from_sorted(sorted_index, num_rows):
         ptr = torch.zeros(num_rows + 1, dtype=torch.int64)
         ptr[1:] = torch.cumsum(torch.bincount(sorted_index, minlength=num_rows), 0)

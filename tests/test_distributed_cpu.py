@@ -235,6 +235,87 @@ def test_stream_to_sharded_dbgnn_matches_single_process_oracle(world):
     _spawn(_stream_worker, world)
 
 
+def zipf_stream(rng, m, n, span, alpha=1.2):
+    """Scale-free temporal stream (SURVEY §8d C3 generator): destinations ~ Zipf(alpha) truncated to n nodes, sources uniform."""
+    p = 1.0 / np.arange(1, n + 1) ** alpha
+    dst = rng.choice(n, size=m, p=p / p.sum())
+    ei = torch.from_numpy(np.stack((rng.integers(0, n, m), rng.permutation(n)[dst])))
+    return ei, torch.from_numpy(np.sort(rng.integers(0, span, m)))
+
+
+def _world8_worker(rank, world, port, results):
+    """Eight ranks on an ER and on a Zipf stream: the fully sharded build (layer 1 by start-node range, edge-range lift, destination-owner
+    aggregation, structural higher-order halo) + the partitioned DBGNN against the single-process oracle; features and labels through ROW
+    LOADERS (no rank may ask for the whole matrix); the plan's cuts must balance the estimated work."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        import pathpyg_amd as pp
+        from pathpyg_amd import distributed as pd
+        from oracle import dbgnn as od
+        from oracle import model as om
+        from tests.cpu_ops import CpuOps
+        rng = np.random.default_rng(41)
+        for kind, m, n, delta, span in (("er", 4000, 64, 12, 900), ("zipf", 4000, 64, 12, 900), ("er", 30, 9, 3, 40)):
+            if kind == "er":
+                ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+                t = torch.from_numpy(np.sort(rng.integers(0, span, m)))
+            else:
+                ei, t = zipf_stream(rng, m, n, span)
+            w = torch.from_numpy(rng.integers(1, 4, m).astype(np.float32)) if kind == "zipf" else None
+            layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2, edge_weight=w)
+            n_ho = layers[2]["num_nodes"]
+            gen = torch.Generator().manual_seed(4)
+            f = 8
+            x, x_h = torch.randn(n, f, generator=gen), torch.randn(n_ho, f, generator=gen)
+            y = torch.randint(0, 3, (n,), generator=gen)
+            params = od.init_params(3, (f, f), [12, 10, 6], seed=5)
+            want = od.loss_and_grads(params, om.dbgnn_inputs(layers, 2, "last", x=x, x_h=x_h), y)
+            tg = type("G", (), {})()
+            tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n, **({} if w is None else {"edge_weight": w}))
+            comm = pd.Comm()
+            asked = {"x": 0, "x_h": 0}
+
+            def load_x(rows):
+                asked["x"] += int(rows.numel())
+                return x.index_select(0, rows)
+
+            def load_xh(rows):
+                asked["x_h"] += int(rows.numel())
+                return x_h.index_select(0, rows)
+            shard = pd.build_dbgnn_shard(tg, delta, load_x, load_xh, lambda rows: y.index_select(0, rows), comm, CpuOps())
+            sz = shard.sizes
+            assert sz["U2"] == n_ho and sz["A2"] == layers[2]["edge_index"].size(1) and sz["E2"] == om.temporal_lift_sorted(ei, t, delta, n).size(1)
+            assert asked["x"] == shard.fo.n_src and asked["x_h"] == shard.ho.n_src            # owned + halo rows, nothing else
+            assert shard.ho.send_unique and (shard.ho.n_send == 0 or int(torch.bincount(shard.ho.send_idx).max()) == 1)
+            # every stage is sharded: the ranks' layer-1 events partition the stream, their lift ranges tile it
+            gathered = comm.all_gather_ints([sz["layer1_events_local"], shard.ho.n_own, shard.fo.n_own, sz["E2_local"]], ei.device)
+            assert sum(r[0] for r in gathered) == m and sum(r[1] for r in gathered) == n_ho and sum(r[2] for r in gathered) == n
+            assert sum(r[3] for r in gathered) == sz["E2"]
+            assert sz["ev_cuts"][0] == 0 and sz["ev_cuts"][-1] == m and sz["fo_cuts"][0] == 0 and sz["fo_cuts"][-1] == n
+            if m >= 1000:
+                # balance: no rank carries more than twice the mean of the quantity its cut is meant to equalise
+                assert max(r[3] for r in gathered) <= 2.0 * sz["E2"] / world + 50, [r[3] for r in gathered]
+                work = comm.all_gather_ints([ROW_COST_ * shard.ho.n_own + sz["A2_local"]], ei.device)
+                assert max(r[0] for r in work) <= 2.0 * sum(r[0] for r in work) / world + 50, work
+            net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=[12, 10, 6])
+            net.load_state_dict(params)
+            sharded = pd.ShardedDBGNN(net, comm, ops=CpuOps())
+            _check_against_oracle(sharded, shard, net, *want, shard.fo.lo, shard.fo.hi)
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+ROW_COST_ = 2
+
+
+def test_world8_er_and_zipf_streams_match_oracle_and_balance():
+    _spawn(_world8_worker, 8, timeout=600)
+
+
 def _dropout_worker(rank, world, port, results):
     """Training-mode dropout on the partitioned path: the masks are functions of (seed, tag, GLOBAL row, column), so every world size must
     reproduce the single-process evaluation of the reference forward (dbgnn.py:131-150) with those masks — logits, loss, every gradient."""
