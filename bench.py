@@ -54,6 +54,11 @@ def parse():
     ap.add_argument("--mode", choices=("partition", "streams"), default="partition")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: host-staged collectives (tests; several ranks may share one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (single-GPU test boxes, with --backend gloo)")
+    ap.add_argument("--emulate-ranks", type=int, default=0, help="run R ranks of the partition path on ONE GPU, taking turns (gloo transport): per-rank compute "
+                                                                 "time + bytes per xGMI link of every collective -> a LABELLED PROJECTION of the R-GPU step "
+                                                                 "(not a measurement of R GPUs; prints its own JSON report)")
+    ap.add_argument("--serialize", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-overlap", action="store_true", help="partition path without the interleaved exchange schedule (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-loop-events", type=int, default=6_000, help="smallest of the three B-loop sizes (x2, x4 follow; kept below torch's 32768-element parallel grain)")
     ap.add_argument("--cpu-sample-events", type=int, default=2_000_000, help="size of the vectorised CPU pipeline sample (B-agg, B-dbgnn)")
@@ -320,14 +325,40 @@ def cpu_baseline(args, seed: int) -> dict:
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 def relaunch(args) -> int:
-    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run on this node."""
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run on this node.
+    `--emulate-ranks R`: R ranks sharing cuda:0 over gloo, taking turns (Comm(serialize=True))."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    nproc, extra = args.gpus, []
+    if args.emulate_ranks > 1:
+        nproc, extra = args.emulate_ranks, ["--backend", "gloo", "--share-gpu", "--serialize", "--no-cpu-baseline"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
     return subprocess.call(cmd, env=env)
+
+
+# ---- xGMI link model of the projection (bench.py --emulate-ranks): every pair of the 8 GPUs of a node has its own link; "7 links x ~153 GB/s
+# per GPU" is the bidirectional figure, i.e. 76.8 GB/s per direction and link.  A collective is priced at its busiest link.
+XGMI_GBS_PER_DIRECTION = 76.8
+XGMI_EFFICIENCY = 0.8            # share of the link rate a large RCCL transfer sustains (assumption, stated in the report)
+COLLECTIVE_LATENCY_US = 15.0     # launch + synchronisation cost of one collective (assumption)
+
+
+def price_collectives(events, steps: int) -> dict:
+    """Per-step cost of the logged collectives of ONE rank on the link model above: each costs latency + bytes-on-its-busiest-link / rate;
+    `overlapped` ones were issued asynchronously with independent kernels queued behind them (pathpyg_amd.nn.sharded._ShardedTrunk)."""
+    rate = XGMI_GBS_PER_DIRECTION * XGMI_EFFICIENCY * 1e9
+    out = {"exposed_ms": 0.0, "overlapped_ms": 0.0, "collectives_per_step": len(events) / max(steps, 1), "by_kind": {}}
+    for kind, nbytes, overlapped in events:
+        ms = (COLLECTIVE_LATENCY_US * 1e-6 + nbytes / rate) * 1e3 / max(steps, 1)
+        out["overlapped_ms" if overlapped else "exposed_ms"] += ms
+        k = out["by_kind"].setdefault(kind + (" (async)" if overlapped else ""), {"count_per_step": 0.0, "busiest_link_bytes_per_step": 0.0, "ms_per_step": 0.0})
+        k["count_per_step"] += 1.0 / max(steps, 1)
+        k["busiest_link_bytes_per_step"] += nbytes / max(steps, 1)
+        k["ms_per_step"] += ms
+    return out
 
 
 def cpu_baseline_isolated(args) -> dict:
@@ -347,13 +378,58 @@ def cpu_baseline_isolated(args) -> dict:
     return json.loads(lines[-1])
 
 
+def emulation_report(args, comm, sizes, build_s, loss, dev, dist) -> int:
+    """`--emulate-ranks R`: the R ranks shared ONE GPU and took turns, so a rank's turns add up to the compute time it would need on a GPU
+    of its own; the collectives are priced on the xGMI link model.  Prints a PROJECTION of the R-GPU step, labelled as such."""
+    world = comm.world
+    mine = torch.tensor([int(comm.compute_s * 1e6), int(build_s * 1e6), sizes.get("E2_local", 0), sizes.get("A2_local", 0),
+                         sizes.get("lift_events_local", 0), sizes.get("layer1_events_local", 0), sizes.get("ho_halo", 0), sizes.get("fo_halo", 0)],
+                        dtype=torch.int64)
+    every = torch.empty(world * mine.numel(), dtype=torch.int64)
+    dist.all_gather_into_tensor(every, mine)
+    every = every.view(world, -1).tolist()
+    loss_total = loss.detach().to(torch.float64).reshape(1).cpu()
+    dist.all_reduce(loss_total)
+    if comm.rank == 0:
+        steps = args.steps
+        compute_ms = [r[0] / 1e3 / steps for r in every]
+        build_ms = [r[1] / 1e3 / steps for r in every]
+        priced = price_collectives(comm.events, steps)
+        slowest = max(compute_ms)
+        dbgnn_ms = max(c - b for c, b in zip(compute_ms, build_ms))
+        hidden = min(priced["overlapped_ms"], dbgnn_ms)
+        report = {
+            "what": f"PROJECTION of the {world}-GPU partition step from {world} ranks taking turns on ONE MI355X (NOT a measurement of {world} GPUs)",
+            "emulated_ranks": world, "steps": steps, "warmup": args.warmup,
+            "workload": f"m={args.events}, N={args.nodes}, span={args.span}, delta={args.delta}, F={args.features}",
+            "per_rank_compute_ms": compute_ms, "per_rank_graph_build_ms": build_ms,
+            "max_rank_compute_ms": slowest, "mean_rank_compute_ms": sum(compute_ms) / world,
+            "per_rank": {"E2_local": [r[2] for r in every], "A2_local": [r[3] for r in every], "lift_events_local": [r[4] for r in every],
+                         "layer1_events_local": [r[5] for r in every], "ho_halo_rows": [r[6] for r in every], "fo_halo_rows": [r[7] for r in every]},
+            "collectives_rank0": priced,
+            "link_model": {"GB_per_s_per_direction_and_link": XGMI_GBS_PER_DIRECTION, "efficiency": XGMI_EFFICIENCY,
+                           "latency_us_per_collective": COLLECTIVE_LATENCY_US,
+                           "note": "every GPU pair has its own xGMI link; a collective costs latency + bytes on its busiest link / rate"},
+            "comm_bytes_per_step_rank0": {k: v / steps for k, v in comm.sent_bytes.items()},
+            "projected_ms_per_step_no_overlap": slowest + priced["exposed_ms"] + priced["overlapped_ms"],
+            "projected_ms_per_step": slowest + priced["exposed_ms"] + priced["overlapped_ms"] - hidden,
+            "amdahl_terms_ms": {"slowest_rank_compute": slowest, "of_which_graph_build": max(build_ms), "collectives_exposed": priced["exposed_ms"],
+                                "collectives_async": priced["overlapped_ms"], "async_hidden_behind_dbgnn_kernels": hidden},
+            "loss": float(loss_total), "E2": sizes.get("E2"), "U2": sizes.get("U2"), "A2": sizes.get("A2"),
+        }
+        print(json.dumps(report), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main() -> int:
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args, seed=11)), flush=True)
         return 0
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ          # started by torch.distributed.run
-    if args.gpus > 1 and not launched:
+    if (args.gpus > 1 or args.emulate_ranks > 1) and not launched:
         return relaunch(args)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -380,7 +456,8 @@ def main() -> int:
     from pathpyg_amd._lib import lib
 
     partition = args.mode == "partition"
-    comm = ppd.Comm()
+    comm = ppd.Comm(serialize=args.serialize)
+    emulating = comm.serialize
     # ---- inputs, resident in HBM before the timed region.  partition: ONE stream replicated on every rank; streams: one per rank
     ei, t = synth_stream(args.events, args.nodes, args.span, seed=1 + (0 if partition else rank), device=dev)
     # library load, first-launch costs and the sort workspace (allocator growth) are paid by an untimed pass over the same stream
@@ -399,7 +476,11 @@ def main() -> int:
     net = pp.nn.DBGNN(num_classes=args.classes, num_features=(args.features, args.features),
                       hidden_dims=[args.features] * 3, p_dropout=args.dropout).to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
-    sharded = ppd.ShardedDBGNN(net, comm) if partition else None
+    sharded = ppd.ShardedDBGNN(net, comm, overlap=not args.no_overlap) if partition else None
+    # world size > 1: a rank reads only its owned + halo rows of the (resident) inputs
+    x_in, xh_in, y_in = (x, x_h, y) if world == 1 else ((lambda rows: x.index_select(0, rows)), (lambda rows: x_h.index_select(0, rows)),
+                                                        (lambda rows: y.index_select(0, rows)))
+    build_s = [0.0]
     lift_ms = []
     sizes = {}
 
@@ -407,8 +488,13 @@ def main() -> int:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         opt.zero_grad(set_to_none=True)
         e0.record()
-        shard = ppd.build_dbgnn_shard(g, args.delta, x, x_h, y, comm)
+        c0 = comm.compute_s
+        shard = ppd.build_dbgnn_shard(g, args.delta, x_in, xh_in, y_in, comm)
         e1.record()
+        if emulating and timed:
+            torch.cuda.synchronize()
+            import time as _t
+            build_s[0] += comm.compute_s - c0 + (_t.perf_counter() - comm._turn_start if comm._turn_start is not None else 0.0)
         if timed:                                   # (bookkeeping of the live rooflines: pointers -> CSR sizes)
             for gs in (shard.fo, shard.ho):
                 register_plan(gs.plan)
@@ -417,7 +503,7 @@ def main() -> int:
             SRC_ROWS[shard.bip.bwd_idx.data_ptr()] = shard.bip.n_dst
         loss = sharded.loss(shard)
         loss.backward()
-        ppd.all_reduce_gradients(net, average=False)
+        ppd.all_reduce_gradients(net, average=False, comm=comm)
         opt.step()
         sizes.update(shard.sizes)
         if timed:
@@ -478,21 +564,29 @@ def main() -> int:
             KernelClock(L, "pp_coalesce_count", coalesce_desc, until="pp_coalesce_fill") as agg_clock:
         clocks = (spmm_clock, fwd_clock, bwd_clock, fill_clock, lift_clock, agg_clock)
         for _ in range(args.warmup):
+            if emulating:
+                comm.barrier()
             step(False)
+        if emulating:
+            comm.end_turns()
         barrier()
-        comm.sent_bytes = {k: 0 for k in comm.sent_bytes}
+        comm.reset_counters()
         for c in clocks:
-            c.enabled = True
+            c.enabled = not emulating
         t0 = time.perf_counter()
         for _ in range(args.steps):
+            if emulating:
+                comm.barrier()           # (opens this rank's first turn of the step; the turns of a step add up to its compute time)
             loss = step(True)
+        if emulating:
+            comm.end_turns()
         barrier()
         elapsed = time.perf_counter() - t0
         for c in clocks:
             c.enabled = False
     # untimed extra: the k=2 -> k=3 line-graph lift of the same event graph (the lift kernel WITHOUT the continuation-list gather)
     k3 = None
-    if rank == 0:
+    if rank == 0 and not emulating:
         ho = pp.algorithms.lift_order_temporal(g, args.delta)
         with KernelClock(L, "pp_linegraph_fill", lambda e, n, total, *r: ("k_expand<no list> (pp_linegraph_fill)", 16 * total + 12 * e)) as lg_clock:
             lg_clock.enabled = True
@@ -505,6 +599,8 @@ def main() -> int:
               "frac": (lg_b / (lg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lg_ms > 0 else 0.0}
         del ho
     e2_total = float(sizes.get("E2", 0))
+    if emulating:
+        return emulation_report(args, comm, sizes, build_s[0], loss, dev, dist)
     loss_total = loss.detach().to(torch.float64).reshape(1).clone()
     if launched and partition:
         comm.all_reduce_(loss_total)                             # every rank holds its share of the mean loss

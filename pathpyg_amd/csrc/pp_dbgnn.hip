@@ -863,7 +863,7 @@ int pp_dropout_act_backward_f32(const float* dY, const float* Ydrop, int64_t n_r
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n_rows >= 0 && F >= 1, PP_ERR_ARG, "pp_dropout_act_backward_f32: bad shape");
     PP_REQUIRE(p >= 0.0 && p < 1.0, PP_ERR_ARG, "pp_dropout_act_backward_f32: p must lie in [0, 1)");
-    PP_REQUIRE(dpre != nullptr && (!act || Ydrop != nullptr), PP_ERR_ARG, "pp_dropout_act_backward_f32: dpre (and Ydrop with act) required");
+    PP_REQUIRE(n_rows == 0 || (dpre != nullptr && (!act || Ydrop != nullptr)), PP_ERR_ARG, "pp_dropout_act_backward_f32: dpre (and Ydrop with act) required");
     if (dbias) PP_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), st));
     const int64_t total = n_rows * (int64_t)F;
     if (total == 0) return PP_OK;

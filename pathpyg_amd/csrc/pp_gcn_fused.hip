@@ -879,7 +879,7 @@ int pp_gcn_input_grad_drop_f32(const int32_t* ptr, const int32_t* idx, const flo
     if (!pp::gcn_wide_shape(M, K))
         return pp_wide_layer_f32(ptr, idx, val, n_rows, n_self, n_self, D, M, self_coef, W, 1, K, nullptr, fuse_act ? 1 : 0, 1, X_act, heavy_slot, heavy_sum,
                                  nullptr, d_in, colsum_in, ws, ws_bytes, stream);
-    PP_REQUIRE(d_in != nullptr && (!fuse_act || X_act != nullptr), PP_ERR_ARG, "pp_gcn_input_grad_f32: d_in (and X_act with fuse_act) required");
+    PP_REQUIRE(n_rows == 0 || (d_in != nullptr && (!fuse_act || X_act != nullptr)), PP_ERR_ARG, "pp_gcn_input_grad_f32: d_in (and X_act with fuse_act) required");
     PP_REQUIRE(((uintptr_t)D | (uintptr_t)X_act | (uintptr_t)d_in) % 16 == 0, PP_ERR_ARG, "pp_gcn_input_grad_f32: D, X_act and d_in must be 16-byte aligned");
     PP_REQUIRE(n_rows < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_input_grad_f32: more than 2^31 rows");
     const bool wide = (uint64_t)n_rows * (uint64_t)M * 4 >= (uint64_t)pp::kBufOob || n_rows >= ((int64_t)1 << 30) - 64;
@@ -917,7 +917,7 @@ int pp_gcn_backward_drop_f32(const int32_t* ptr, const int32_t* idx, const float
     const pp::DropSite drop = pp::drop_site(drop_p, drop_seed, drop_tag, drop_row0);
     PP_REQUIRE(n_rows >= 0 && n_self >= 0 && n_self <= n_rows, PP_ERR_ARG, "pp_gcn_backward_f32: bad sizes");
     PP_REQUIRE(pp_dense_supported(M, K) == 1, PP_ERR_ARG, "pp_gcn_backward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", M, K);
-    PP_REQUIRE(d_in != nullptr && dW != nullptr, PP_ERR_ARG, "pp_gcn_backward_f32: d_in and dW are required");
+    PP_REQUIRE((n_rows == 0 || d_in != nullptr) && dW != nullptr, PP_ERR_ARG, "pp_gcn_backward_f32: d_in and dW are required");
     PP_REQUIRE(((uintptr_t)D) % 16 == 0, PP_ERR_ARG, "pp_gcn_backward_f32: D must be 16-byte aligned");
     const bool wide = (uint64_t)n_rows * (uint64_t)M * 4 >= (uint64_t)pp::kBufOob || n_rows >= ((int64_t)1 << 30) - 64;      // 64-bit row addresses
     PP_REQUIRE(ws_bytes >= pp_gcn_backward_ws_bytes(n_rows), PP_ERR_WORKSPACE, "pp_gcn_backward_f32: workspace too small");

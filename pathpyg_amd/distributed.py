@@ -127,15 +127,19 @@ def gather_lifted(local: torch.Tensor, group=None) -> torch.Tensor:
     return torch.cat([p[:, : int(s.item())] for p, s in zip(parts, sizes)], dim=1)
 
 
-def all_reduce_gradients(module: torch.nn.Module, group=None, average: bool = True) -> None:
+def all_reduce_gradients(module: torch.nn.Module, group=None, average: bool = True, comm: "Comm | None" = None) -> None:
     """Sum (``average=False``) or average the (small) DBGNN weight gradients across ranks in ONE flattened all-reduce
-    (latency-bound: ~20 k floats; per-tensor calls would pay the xGMI launch latency 14 times)."""
-    _, world = _world(group)
+    (latency-bound: ~20 k floats; per-tensor calls would pay the xGMI launch latency 14 times).  ``comm``: count the bytes on (and take
+    turns through) this :class:`Comm`."""
+    _, world = _world(group) if comm is None else (comm.rank, comm.world)
     grads = [p.grad for p in module.parameters() if p.grad is not None]
     if world == 1 or not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, group=group)
+    if comm is not None:
+        comm.all_reduce_(flat)
+    else:
+        dist.all_reduce(flat, group=group)
     if average:
         flat /= world
     at = 0
@@ -150,14 +154,75 @@ def all_reduce_gradients(module: torch.nn.Module, group=None, average: bool = Tr
 # test transport only, the driver's multi-GPU runs use RCCL.
 # =====================================================================================================
 class Comm:
-    """Process-group handle with the five collectives the partitioned lift + DBGNN need, and a byte counter per kind."""
+    """Process-group handle with the collectives the partitioned lift + DBGNN need, byte counters per kind, and a per-collective log
+    (``events``: kind, bytes to the busiest peer, overlapped or not) from which ``bench.py`` prices a step on xGMI.
 
-    def __init__(self, group=None):
+    ``serialize=True`` (host-staged backends only; ``bench.py --emulate-ranks``): R ranks SHARE one GPU and take turns — a rank computes
+    from one collective to the next while the others wait (a token travels rank 0 -> 1 -> .. between collectives), and the wall time of
+    its turns (GPU drained at the end of each) accumulates in ``compute_s``: the per-rank compute time of a real R-GPU run, measured on
+    one GPU."""
+
+    def __init__(self, group=None, serialize: bool = False):
         self.group = group
         self.rank, self.world = _world(group)
         self.backend = dist.get_backend(group) if (self.world > 1 or (dist.is_available() and dist.is_initialized())) else None
         self.native = self.backend == "nccl"
         self.sent_bytes = {"exchange": 0, "all_gather": 0, "reduce_scatter": 0, "all_reduce": 0}
+        self.events = []               # (kind, bytes to / from the busiest peer, issued asynchronously)
+        self.serialize = bool(serialize) and self.world > 1 and not self.native
+        self.compute_s = 0.0
+        self._turn_start = None
+        self._token = torch.zeros(1, dtype=torch.int64)
+
+    # ---- emulation turns
+    def _enter(self):
+        """Called at the start of every collective."""
+        if not self.serialize:
+            return
+        import time as _time
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if self._turn_start is not None:
+            self.compute_s += _time.perf_counter() - self._turn_start
+            self._turn_start = None
+        if self.rank + 1 < self.world:
+            dist.send(self._token, self.rank + 1, group=self.group)
+
+    def _exit(self):
+        """Called at the end of every collective: wait for my turn."""
+        if not self.serialize:
+            return
+        import time as _time
+        if self.rank > 0:
+            dist.recv(self._token, self.rank - 1, group=self.group)
+        self._turn_start = _time.perf_counter()
+
+    def barrier(self):
+        """A collective without payload (step boundaries of the bench; closes / opens a turn in the emulation)."""
+        if self.world == 1:
+            return
+        self._enter()
+        dist.barrier(group=self.group)
+        self._exit()
+
+    def end_turns(self):
+        """Emulation: close this rank's turn and pass the token on WITHOUT waiting for it again (before code that talks to the process
+        group directly, e.g. the bench's own barriers)."""
+        self._enter()
+
+    def reset_counters(self):
+        self.sent_bytes = {k: 0 for k in self.sent_bytes}
+        self.events = []
+        self.compute_s = 0.0
+
+    def _count_exchange(self, send_counts, row_bytes: int, recv_counts=None, overlapped: bool = False):
+        self.sent_bytes["exchange"] += (int(sum(send_counts)) - int(send_counts[self.rank])) * row_bytes
+        out_peer = max([int(c) for r, c in enumerate(send_counts) if r != self.rank] or [0])
+        in_peer = max([int(c) for r, c in enumerate(recv_counts) if r != self.rank] or [0]) if recv_counts is not None else 0
+        self.events.append(("exchange", max(out_peer, in_peer) * row_bytes, overlapped))
+
+    def _peer_bytes(self, kind: str, block_bytes: int, overlapped: bool = False):
+        self.events.append((kind, int(block_bytes), overlapped))
 
     def _stage(self, t: torch.Tensor) -> torch.Tensor:
         return t if (self.native or not t.is_cuda) else t.cpu()
@@ -166,11 +231,15 @@ class Comm:
         """counts[r] rows go to rank r -> how many rows come from each rank (one all-to-all of ``world`` integers)."""
         if self.world == 1:
             return list(send_counts)
+        self._enter()
         dev = device if self.native else torch.device("cpu")
         send = torch.tensor(send_counts, dtype=torch.int64, device=dev)
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)
-        return [int(v) for v in recv.tolist()]
+        out = [int(v) for v in recv.tolist()]
+        self.events.append(("counts", 8, False))
+        self._exit()
+        return out
 
     def exchange_rows(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int], out: torch.Tensor | None = None) -> torch.Tensor:
         """Variable all-to-all along dim 0: ``send`` holds the rows for rank 0, 1, .. back to back; returns (or fills ``out`` with) the
@@ -182,72 +251,164 @@ class Comm:
                 return send
             out.copy_(send)
             return out
+        self._enter()
         row_bytes = send.element_size() * math.prod(send.shape[1:])
-        self.sent_bytes["exchange"] += (int(sum(send_counts)) - int(send_counts[self.rank])) * row_bytes
+        self._count_exchange(send_counts, row_bytes, recv_counts)
         if self.native:
             if out is None:
                 out = torch.empty(shape, dtype=send.dtype, device=send.device)
             dist.all_to_all_single(out, send.contiguous(), list(recv_counts), list(send_counts), group=self.group)
+            self._exit()
             return out
         staged = torch.empty(shape, dtype=send.dtype)
         dist.all_to_all_single(staged, send.detach().cpu().contiguous(), list(recv_counts), list(send_counts), group=self.group)
         if out is None:
-            return staged.to(send.device)
-        out.copy_(staged)
+            out = staged.to(send.device)
+        else:
+            out.copy_(staged)
+        self._exit()
         return out
+
+    # ---- asynchronous forms: the collective is queued behind the work already on the current stream and runs beside what is launched next
+    # (RCCL executes on its own stream; `wait()` makes the current stream wait for it).  Host-staged backends complete eagerly — the log
+    # still marks them as overlapped: the schedule, not the transport, decides what can hide behind what.
+    class _Done:
+        def __init__(self, value):
+            self.value = value
+
+        def wait(self):
+            return self.value
+
+    class _Pending:
+        def __init__(self, work, value, keep=()):
+            self.work, self.value, self.keep = work, value, keep
+
+        def wait(self):
+            self.work.wait()
+            self.keep = ()
+            return self.value
+
+    def _mark_overlapped(self):
+        if self.events:
+            kind, nbytes, _ = self.events[-1]
+            self.events[-1] = (kind, nbytes, True)
+
+    def exchange_rows_async(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int], out: torch.Tensor | None = None):
+        """:meth:`exchange_rows` as a handle whose ``wait()`` returns the received rows."""
+        if not self.native or self.world == 1:
+            done = Comm._Done(self.exchange_rows(send, send_counts, recv_counts, out))
+            if self.world > 1:
+                self._mark_overlapped()
+            return done
+        row_bytes = send.element_size() * math.prod(send.shape[1:])
+        self._count_exchange(send_counts, row_bytes, recv_counts, overlapped=True)
+        if out is None:
+            out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        src = send.contiguous()
+        work = dist.all_to_all_single(out, src, list(recv_counts), list(send_counts), group=self.group, async_op=True)
+        return Comm._Pending(work, out, (src,))
+
+    def reduce_scatter_rows_async(self, x_full: torch.Tensor, rows_per_rank: int):
+        if not self.native or self.world == 1:
+            done = Comm._Done(self.reduce_scatter_rows(x_full, rows_per_rank))
+            if self.world > 1:
+                self._mark_overlapped()
+            return done
+        block = rows_per_rank * x_full[0].numel() * x_full.element_size()
+        self.sent_bytes["reduce_scatter"] += (self.world - 1) * block
+        self._peer_bytes("reduce_scatter", block, overlapped=True)
+        src = x_full.contiguous()
+        out = torch.empty((rows_per_rank,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        work = dist.reduce_scatter_tensor(out, src, group=self.group, async_op=True)
+        return Comm._Pending(work, out, (src,))
+
+    def all_gather_rows_async(self, x_local: torch.Tensor):
+        if not self.native or self.world == 1:
+            done = Comm._Done(self.all_gather_rows(x_local))
+            if self.world > 1:
+                self._mark_overlapped()
+            return done
+        block = x_local.numel() * x_local.element_size()
+        self.sent_bytes["all_gather"] += (self.world - 1) * block
+        self._peer_bytes("all_gather", block, overlapped=True)
+        src = x_local.contiguous()
+        out = torch.empty((self.world * src.size(0),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        work = dist.all_gather_into_tensor(out, src, group=self.group, async_op=True)
+        return Comm._Pending(work, out, (src,))
 
     def all_gather_rows(self, x_local: torch.Tensor) -> torch.Tensor:
         """Equal-sized row blocks of all ranks, rank order: ``[world * rows, ...]``."""
         if self.world == 1:
             return x_local
-        self.sent_bytes["all_gather"] += (self.world - 1) * x_local.numel() * x_local.element_size()
+        self._enter()
+        block = x_local.numel() * x_local.element_size()
+        self.sent_bytes["all_gather"] += (self.world - 1) * block
+        self._peer_bytes("all_gather", block)
         src = self._stage(x_local.contiguous())
         out = torch.empty((self.world * src.size(0),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
         dist.all_gather_into_tensor(out, src, group=self.group)
-        return out.to(x_local.device)
+        out = out.to(x_local.device)
+        self._exit()
+        return out
 
     def reduce_scatter_rows(self, x_full: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
         """Sum ``[world * rows_per_rank, ...]`` over the ranks, keep this rank's block."""
         if self.world == 1:
             return x_full
-        self.sent_bytes["reduce_scatter"] += (self.world - 1) * rows_per_rank * x_full[0].numel() * x_full.element_size()
+        self._enter()
+        block = rows_per_rank * x_full[0].numel() * x_full.element_size()
+        self.sent_bytes["reduce_scatter"] += (self.world - 1) * block
+        self._peer_bytes("reduce_scatter", block)
         src = self._stage(x_full.contiguous())
         out = torch.empty((rows_per_rank,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
         dist.reduce_scatter_tensor(out, src, group=self.group)
-        return out.to(x_full.device)
+        out = out.to(x_full.device)
+        self._exit()
+        return out
 
     def all_reduce_(self, t: torch.Tensor, op=None) -> torch.Tensor:
         if self.world == 1:
             return t
+        self._enter()
         self.sent_bytes["all_reduce"] += t.numel() * t.element_size()
+        self._peer_bytes("all_reduce", t.numel() * t.element_size())
         op = dist.ReduceOp.SUM if op is None else op
         if self.native or not t.is_cuda:
             dist.all_reduce(t, op=op, group=self.group)
-            return t
-        staged = t.cpu()
-        dist.all_reduce(staged, op=op, group=self.group)
-        t.copy_(staged)
+        else:
+            staged = t.cpu()
+            dist.all_reduce(staged, op=op, group=self.group)
+            t.copy_(staged)
+        self._exit()
         return t
 
     def all_gather_ints_dev(self, mine: torch.Tensor) -> list[list[int]]:
         """Every rank's small int64 DEVICE vector (same length everywhere) -> ``[world][len]`` on the host: one collective + one read-back."""
         if self.world == 1:
             return [mine.tolist()]
+        self._enter()
         src = mine.to(torch.int64).contiguous()
         src = src if (self.native or not src.is_cuda) else src.cpu()
         out = torch.empty(self.world * src.numel(), dtype=torch.int64, device=src.device)
         dist.all_gather_into_tensor(out, src, group=self.group)
-        return out.view(self.world, -1).tolist()
+        host = out.view(self.world, -1).tolist()
+        self.events.append(("counts", 8 * src.numel(), False))
+        self._exit()
+        return host
 
     def all_gather_ints(self, values: list[int], device) -> list[list[int]]:
         """Every rank's small integer vector (same length everywhere): ``[world][len(values)]`` on the host."""
         if self.world == 1:
             return [list(values)]
+        self._enter()
         dev = device if self.native else torch.device("cpu")
         mine = torch.tensor(values, dtype=torch.int64, device=dev)
         out = torch.empty(self.world * mine.numel(), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(out, mine, group=self.group)
-        return out.view(self.world, -1).tolist()
+        host = out.view(self.world, -1).tolist()
+        self.events.append(("counts", 8 * mine.numel(), False))
+        self._exit()
+        return host
 
 
 def node_ranges(num_nodes: int, world_size: int) -> list[tuple[int, int]]:
@@ -413,13 +574,13 @@ def shard_dbgnn_bundle(data, comm: Comm, ops=None, fo_cuts: list[int] | None = N
 ROW_COST = 2          # cost of a higher-order row relative to one of its in-edges when the cuts are balanced (a row is read and written once)
 
 
-def _rows_of(source, rows: torch.Tensor | None, lo: int = 0, hi: int = 0):
+def _rows_of(source, rows: torch.Tensor | None, lo: int = 0, hi: int = 0, device=None):
     """Feature / label rows from a replicated tensor or from a ROW LOADER ``source(rows int64) -> tensor`` (a rank of a partitioned run only
     ever touches its owned + halo rows: a 10^8 x 256 feature matrix need not exist on any single GPU)."""
     if source is None:
         return None
     if callable(source):
-        return source(rows if rows is not None else torch.arange(lo, hi))
+        return source(rows if rows is not None else torch.arange(lo, hi, device=device))
     return source.index_select(0, rows) if rows is not None else source[lo:hi]
 
 
@@ -546,10 +707,10 @@ def build_dbgnn_shard(g, delta, x, x_h, y, comm: Comm, ops=None, weight: str = "
     ops.check_plan_status(pending)
     fptr = fo_shard.plan.fwd_ptr
     indeg = (fptr[1:] - fptr[:-1]).to(torch.float32)                            # order-2 nodes (., b) per first-order node b
-    x_loc = _rows_of(x, None, 0, n)
-    xh_loc = x_h(n_ho) if (callable(x_h) and _takes_count(x_h)) else _rows_of(x_h, None, 0, n_ho)
+    x_loc = _rows_of(x, None, 0, n, dev)
+    xh_loc = x_h(n_ho) if (callable(x_h) and _takes_count(x_h)) else _rows_of(x_h, None, 0, n_ho, dev)
     a2 = int(ho_ei.size(1))
-    return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=n, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(), y=_rows_of(y, None, 0, n),
+    return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=n, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(), y=_rows_of(y, None, 0, n, dev),
                       n_fo=n, n_ho=n_ho,
                       sizes={"m": m, "N": n, "E2": e2, "E2_local": e2, "U2": n_ho, "A1": n_ho, "A2": a2, "A2_local": a2, "fo_cuts": fo_cuts,
                              "ho_cuts": ho_cuts, "fo_halo": 0, "ho_halo": 0})
@@ -677,7 +838,7 @@ def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
     comm.all_reduce_(sums)
     e2, a2 = (int(t) for t in sums.tolist())
     return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(),
-                      y=_rows_of(y, None, lo_n, hi_n), n_fo=n, n_ho=n_ho,
+                      y=_rows_of(y, None, lo_n, hi_n, dev), n_fo=n, n_ho=n_ho,
                       sizes={"m": m, "N": n, "E2": e2, "E2_local": e2_local, "U2": n_ho, "A1": n_ho, "A2": a2, "A2_local": int(ho_ei.size(1)),
                              "fo_cuts": fo_cuts, "ho_cuts": ho_cuts, "ev_cuts": plan["ev_cuts"], "fo_halo": fo_shard.n_halo, "ho_halo": ho.n_halo,
                              "lift_events_local": end_e - lo_e, "layer1_events_local": int(mine.numel())})

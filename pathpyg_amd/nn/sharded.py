@@ -331,6 +331,120 @@ class _ShardedBipartite(torch.autograd.Function):
         return None, None, None, None, None, dpre, colsum, None, None
 
 
+class _ShardedTrunk(torch.autograd.Function):
+    """Both GCN stacks and the bipartite sum of a partitioned DBGNN as ONE schedule (world size > 1, no dropout), so that every exchange has
+    independent kernels to hide behind — the layer functions above run a stack at a time and wait for each exchange where it is issued:
+
+    forward   per layer l:  [wait the higher-order halo of layer l]  HIGHER-ORDER layer l  -> its halo exchange starts
+                            [wait the first-order halo of layer l]   FIRST-ORDER layer l   -> its halo exchange starts
+              (the first-order layer runs under the higher-order exchange, the next higher-order layer under the first-order one);
+              after the last higher-order layer: bipartite partial sums -> reduce-scatter starts, the last first-order layer runs under it;
+    backward  the mirror image: all-gather of the bipartite gradient rows under the last first-order layer's backward kernel, every
+              stack's halo-gradient exchange under the other stack's backward kernel.
+
+    Inputs: the shard, then the first-order stack's (weight, bias) pairs, then the higher-order stack's.  Outputs ``(y_fo, agg)``: the
+    first-order stack's activation and the reduce-scattered bipartite sums on the owned first-order rows.  Contract as the layer functions:
+    the consumer of ``y_fo`` hands back the gradient w.r.t. the last first-order PRE-activation and owns that layer's bias gradient; the
+    last higher-order layer's bias gradient comes out of the bipartite backward kernel here."""
+
+    @staticmethod
+    def forward(ctx, shard, comm, ops, n_layers: int, *params):
+        fo, ho = shard.fo, shard.ho
+        p_fo, p_ho = params[: 2 * n_layers], params[2 * n_layers:]
+        state = {}
+        for name, gs, x_full, prm in (("ho", ho, shard.x_h, p_ho), ("fo", fo, shard.x, p_fo)):
+            state[name] = {"gs": gs, "h": x_full, "prm": prm, "inputs": [], "saved": [], "pending": None}
+        agg_pending = None
+
+        def layer(name, l):
+            st = state[name]
+            gs, prm = st["gs"], st["prm"]
+            last = l == n_layers - 1
+            if st["pending"] is not None:
+                st["pending"].wait()
+                st["pending"] = None
+            weight, bias = prm[2 * l], prm[2 * l + 1]
+            buf = torch.empty((gs.n_own if last else gs.n_src, weight.size(0)), dtype=torch.float32, device=st["h"].device)
+            st["inputs"].append(st["h"])
+            st["saved"].append(ops.layer_forward(gs.plan, st["h"], weight, bias, l == 0, buf[: gs.n_own], None))
+            if not last:
+                send = buf[: gs.n_own].index_select(0, gs.send_idx)
+                st["pending"] = comm.exchange_rows_async(send, gs.send_counts, gs.recv_counts, out=buf[gs.n_own:])
+            st["h"] = buf
+
+        for l in range(n_layers):
+            layer("ho", l)
+            if l == n_layers - 1:
+                bip = shard.bip
+                partial = ops.spmm(bip.fwd_ptr, bip.fwd_idx, bip.fwd_val, bip.n_dst, state["ho"]["h"], heavy=bip.fwd_heavy)      # [world * cap, H]
+                agg_pending = comm.reduce_scatter_rows_async(partial, shard.cap)
+            layer("fo", l)
+        agg = agg_pending.wait()[: fo.n_own]
+        y_fo, y_ho = state["fo"]["h"], state["ho"]["h"]
+        ctx.shard, ctx.comm, ctx.ops, ctx.n_layers = shard, comm, ops, n_layers
+        ctx.state = {k: (v["inputs"], v["saved"]) for k, v in state.items()}
+        ctx.y_ho = y_ho
+        ctx.save_for_backward(*params)
+        return y_fo, agg
+
+    @staticmethod
+    def backward(ctx, dpre_fo, d_agg):
+        shard, comm, ops, n_layers = ctx.shard, ctx.comm, ctx.ops, ctx.n_layers
+        params = ctx.saved_tensors
+        fo, ho, bip = shard.fo, shard.ho, shard.bip
+        grads_fo, grads_ho = [None] * (2 * n_layers), [None] * (2 * n_layers)
+        st = {"fo": {"gs": fo, "prm": params[: 2 * n_layers], "grads": grads_fo, "d": dpre_fo.contiguous(), "pending": None},
+              "ho": {"gs": ho, "prm": params[2 * n_layers:], "grads": grads_ho, "d": None, "pending": None}}
+        # the bipartite gradient rows of all ranks travel while the first-order stack starts its backward pass
+        d_own = d_agg.contiguous()
+        if shard.cap != fo.n_own:
+            d_own = F.pad(d_own, (0, 0, 0, shard.cap - fo.n_own))
+        full_pending = comm.all_gather_rows_async(d_own)
+
+        def finish_exchange(name, l):
+            """Halo-gradient rows of layer l are back: fold them into the owned rows, ELU' of the layer below, its bias gradient."""
+            s = st[name]
+            gs = s["gs"]
+            d_lin, x_in = s["pending"]
+            recv = s["handle"].wait()
+            own = d_lin[: gs.n_own]
+            if recv.size(0):
+                if gs.send_unique:
+                    own.index_add_(0, gs.send_idx, recv)
+                else:
+                    own = own + ops.spmm(gs.back_ptr, gs.back_idx, None, gs.n_own, recv)
+            s["d"], colsum = ops.act_combine(own, None, x_in[: gs.n_own])
+            s["grads"][2 * l - 1] = colsum
+            s["pending"] = None
+
+        def layer_backward(name, l):
+            s = st[name]
+            gs = s["gs"]
+            inputs, saved = ctx.state[name]
+            weight, x_in = s["prm"][2 * l], inputs[l]
+            if l == 0:
+                s["grads"][0] = ops.layer_backward(gs.plan, s["d"], x_in, weight, saved[0], False, None)[2]
+                return
+            d_lin, _, s["grads"][2 * l] = ops.layer_backward(gs.plan, s["d"], x_in, weight, saved[l], True, None)
+            s["pending"] = (d_lin, x_in)
+            s["handle"] = comm.exchange_rows_async(d_lin[gs.n_own:].contiguous(), gs.recv_counts, gs.send_counts)
+
+        for l in range(n_layers - 1, -1, -1):
+            if l < n_layers - 1:
+                finish_exchange("fo", l + 1)
+            layer_backward("fo", l)
+            if l == n_layers - 1:
+                d_full = full_pending.wait()
+                want = ctx.needs_input_grad[4 + 2 * n_layers + 2 * n_layers - 1]
+                st["ho"]["d"], colsum_h = ops.spmm_act_backward(bip.bwd_ptr, bip.bwd_idx, bip.bwd_val, bip.n_src, d_full, ctx.y_ho, want, None)
+                grads_ho[2 * n_layers - 1] = colsum_h
+            else:
+                finish_exchange("ho", l + 1)
+            layer_backward("ho", l)
+        ctx.state = ctx.y_ho = None
+        return (None, None, None, None, *grads_fo, *grads_ho)
+
+
 class DbgnnShard:
     """Everything one rank needs for DBGNN steps on its partition: the two graph shards, the bipartite plan, the local input features
     (owned + halo rows) and the labels of the owned first-order nodes."""
@@ -351,10 +465,11 @@ class ShardedDBGNN(torch.nn.Module):
     :func:`pathpyg_amd.distributed.shard_dbgnn_bundle` (a replicated ``to_dbgnn_data`` bundle) or
     :func:`pathpyg_amd.distributed.build_dbgnn_shard` (straight from the event stream: sharded lift + aggregation)."""
 
-    def __init__(self, model, group=None, ops=None):
+    def __init__(self, model, group=None, ops=None, overlap: bool = True):
         super().__init__()
         from ..distributed import Comm
         self.model = model
+        self.overlap = overlap          # world size > 1 without dropout: the interleaved schedule of _ShardedTrunk
         self.comm = group if isinstance(group, Comm) else Comm(group)
         self.ops = ops if ops is not None else HipOps()
         self.rank, self.world = self.comm.rank, self.comm.world
@@ -378,9 +493,19 @@ class ShardedDBGNN(torch.nn.Module):
             drop = (m.p_dropout, seed, tag, out_tag) if dropping else None
             return _ShardedGcnStack.apply(graph_shard, comm, ops, drop, x_full, *params), layers[-1].bias
 
+        bl = m.bipartite_layer
+        if comm.world > 1 and not dropping and len(m.first_order_layers) == len(m.higher_order_layers) and self.overlap:
+            # one schedule for both stacks + the bipartite sum: every exchange runs beside kernels of the other stack (_ShardedTrunk)
+            params = []
+            for layers in (m.first_order_layers, m.higher_order_layers):
+                for layer in layers:
+                    params += [layer.lin.weight, layer.bias]
+            x, agg = _ShardedTrunk.apply(shard, comm, ops, len(m.first_order_layers), *params)
+            per_edge = ops.dense(x, bl.lin2, True, m.first_order_layers[-1].bias) + bl.lin1.bias
+            x = F.elu(torch.addcmul(ops.dense_nobias(agg, bl.lin1.weight), shard.indeg.unsqueeze(1), per_edge))
+            return ops.dense(x, m.lin)
         x, bias_fo = stack(m.first_order_layers, shard.fo, shard.x, TAG_FO, TAG_FO_OUT)
         x_h, bias_ho = stack(m.higher_order_layers, shard.ho, shard.x_h, TAG_HO, TAG_HO_OUT)
-        bl = m.bipartite_layer
         if dropping:            # dropout after both stacks and after the bipartite ELU (reference dbgnn.py:136,142,148), masks as above
             p = m.p_dropout
             # both stacks hand their outputs over DROPPED (last layer's epilogue); what is left of those two sites is their backward: one
