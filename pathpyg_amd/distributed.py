@@ -172,7 +172,7 @@ class Comm:
         self.serialize = bool(serialize) and self.world > 1 and not self.native
         self.compute_s = 0.0
         self._turn_start = None
-        self._token = torch.zeros(1, dtype=torch.int64)
+        self._seq, self._kv = 0, None
 
     # ---- emulation turns
     def _enter(self):
@@ -185,17 +185,23 @@ class Comm:
         if self._turn_start is not None:
             self.compute_s += _time.perf_counter() - self._turn_start
             self._turn_start = None
-        if self.rank + 1 < self.world:
-            dist.send(self._token, self.rank + 1, group=self.group)
+        if self.rank + 1 < self.world:          # the token travels through the rendezvous store (point-to-point sends beside collectives
+            self._store().set(f"pp_turn/{self._seq}/{self.rank + 1}", b"1")     # upset the gloo transport)
 
     def _exit(self):
         """Called at the end of every collective: wait for my turn."""
         if not self.serialize:
             return
         import time as _time
+        self._seq += 1          # (index of the next collective: rank - 1 passes the token on when IT enters that one)
         if self.rank > 0:
-            dist.recv(self._token, self.rank - 1, group=self.group)
+            self._store().wait([f"pp_turn/{self._seq}/{self.rank}"])
         self._turn_start = _time.perf_counter()
+
+    def _store(self):
+        if self._kv is None:
+            self._kv = dist.distributed_c10d._get_default_store()
+        return self._kv
 
     def barrier(self):
         """A collective without payload (step boundaries of the bench; closes / opens a turn in the emulation)."""
@@ -209,6 +215,7 @@ class Comm:
         """Emulation: close this rank's turn and pass the token on WITHOUT waiting for it again (before code that talks to the process
         group directly, e.g. the bench's own barriers)."""
         self._enter()
+        self._seq += 1
 
     def reset_counters(self):
         self.sent_bytes = {k: 0 for k in self.sent_bytes}

@@ -312,6 +312,60 @@ def _world8_worker(rank, world, port, results):
 ROW_COST_ = 2
 
 
+def _turns_worker(rank, world, port, results):
+    """Comm(serialize=True) — the turn-taking of `bench.py --emulate-ranks`: same numbers as the free-running path, a compute time per rank,
+    a log entry per collective with the asynchronous ones marked."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pathpyg_amd as pp
+        from pathpyg_amd import distributed as pd
+        from oracle import dbgnn as od
+        from oracle import model as om
+        from tests.cpu_ops import CpuOps
+        rng = np.random.default_rng(29)
+        m, n, delta, span, f = 1500, 30, 9, 500, 8
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        t = torch.from_numpy(np.sort(rng.integers(0, span, m)))
+        layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2)
+        gen = torch.Generator().manual_seed(4)
+        x, x_h = torch.randn(n, f, generator=gen), torch.randn(layers[2]["num_nodes"], f, generator=gen)
+        y = torch.randint(0, 3, (n,), generator=gen)
+        params = od.init_params(3, (f, f), [12, 10, 6], seed=5)
+        want = od.loss_and_grads(params, om.dbgnn_inputs(layers, 2, "last", x=x, x_h=x_h), y)
+        tg = type("G", (), {})()
+        tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n)
+        comm = pd.Comm(serialize=True)
+        assert comm.serialize
+        net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=[12, 10, 6])
+        net.load_state_dict(params)
+        sharded = pd.ShardedDBGNN(net, comm, ops=CpuOps())
+        for _ in range(2):
+            comm.barrier()
+            net.zero_grad()
+            shard = pd.build_dbgnn_shard(tg, delta, x, x_h, y, comm, CpuOps())
+            loss = sharded.loss(shard)
+            loss.backward()
+            pd.all_reduce_gradients(net, average=False, comm=comm)
+        comm.end_turns()
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        torch.testing.assert_close(total, want[1], rtol=1e-5, atol=1e-6)
+        for name, p in net.named_parameters():
+            torch.testing.assert_close(p.grad, want[2][name], rtol=1e-3, atol=1e-5, msg=lambda s_: f"{name}: {s_}")
+        kinds = {k for k, _, _ in comm.events}
+        assert comm.compute_s > 0 and {"exchange", "all_gather", "reduce_scatter", "all_reduce", "counts"} <= kinds
+        assert any(o for _, _, o in comm.events) and any(not o for _, _, o in comm.events)        # the trunk's exchanges are the overlapped ones
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_turn_taking_emulation_gives_the_same_numbers_and_a_collective_log():
+    _spawn(_turns_worker, 3)
+
+
 def test_world8_er_and_zipf_streams_match_oracle_and_balance():
     _spawn(_world8_worker, 8, timeout=600)
 
