@@ -54,10 +54,9 @@ def parse():
     ap.add_argument("--mode", choices=("partition", "streams"), default="partition")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: host-staged collectives (tests; several ranks may share one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (single-GPU test boxes, with --backend gloo)")
-    ap.add_argument("--emulate-ranks", type=int, default=0, help="run R ranks of the partition path on ONE GPU, taking turns (gloo transport): per-rank compute "
-                                                                 "time + bytes per xGMI link of every collective -> a LABELLED PROJECTION of the R-GPU step "
-                                                                 "(not a measurement of R GPUs; prints its own JSON report)")
-    ap.add_argument("--serialize", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--emulate-ranks", type=int, default=0, help="run R ranks of the partition path as R threads on ONE GPU, taking turns: per-rank "
+                                                                 "compute time + bytes per xGMI link of every collective -> a LABELLED PROJECTION of the "
+                                                                 "R-GPU step (not a measurement of R GPUs; prints its own JSON report)")
     ap.add_argument("--no-overlap", action="store_true", help="partition path without the interleaved exchange schedule (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-loop-events", type=int, default=6_000, help="smallest of the three B-loop sizes (x2, x4 follow; kept below torch's 32768-element parallel grain)")
@@ -325,17 +324,13 @@ def cpu_baseline(args, seed: int) -> dict:
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 def relaunch(args) -> int:
-    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run on this node.
-    `--emulate-ranks R`: R ranks sharing cuda:0 over gloo, taking turns (Comm(serialize=True))."""
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run on this node."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    nproc, extra = args.gpus, []
-    if args.emulate_ranks > 1:
-        nproc, extra = args.emulate_ranks, ["--backend", "gloo", "--share-gpu", "--serialize", "--no-cpu-baseline"]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
@@ -378,48 +373,87 @@ def cpu_baseline_isolated(args) -> dict:
     return json.loads(lines[-1])
 
 
-def emulation_report(args, comm, sizes, build_s, loss, dev, dist) -> int:
-    """`--emulate-ranks R`: the R ranks shared ONE GPU and took turns, so a rank's turns add up to the compute time it would need on a GPU
-    of its own; the collectives are priced on the xGMI link model.  Prints a PROJECTION of the R-GPU step, labelled as such."""
-    world = comm.world
-    mine = torch.tensor([int(comm.compute_s * 1e6), int(build_s * 1e6), sizes.get("E2_local", 0), sizes.get("A2_local", 0),
-                         sizes.get("lift_events_local", 0), sizes.get("layer1_events_local", 0), sizes.get("ho_halo", 0), sizes.get("fo_halo", 0)],
-                        dtype=torch.int64)
-    every = torch.empty(world * mine.numel(), dtype=torch.int64)
-    dist.all_gather_into_tensor(every, mine)
-    every = every.view(world, -1).tolist()
-    loss_total = loss.detach().to(torch.float64).reshape(1).cpu()
-    dist.all_reduce(loss_total)
-    if comm.rank == 0:
-        steps = args.steps
-        compute_ms = [r[0] / 1e3 / steps for r in every]
-        build_ms = [r[1] / 1e3 / steps for r in every]
-        priced = price_collectives(comm.events, steps)
-        slowest = max(compute_ms)
-        dbgnn_ms = max(c - b for c, b in zip(compute_ms, build_ms))
-        hidden = min(priced["overlapped_ms"], dbgnn_ms)
-        report = {
-            "what": f"PROJECTION of the {world}-GPU partition step from {world} ranks taking turns on ONE MI355X (NOT a measurement of {world} GPUs)",
-            "emulated_ranks": world, "steps": steps, "warmup": args.warmup,
-            "workload": f"m={args.events}, N={args.nodes}, span={args.span}, delta={args.delta}, F={args.features}",
-            "per_rank_compute_ms": compute_ms, "per_rank_graph_build_ms": build_ms,
-            "max_rank_compute_ms": slowest, "mean_rank_compute_ms": sum(compute_ms) / world,
-            "per_rank": {"E2_local": [r[2] for r in every], "A2_local": [r[3] for r in every], "lift_events_local": [r[4] for r in every],
-                         "layer1_events_local": [r[5] for r in every], "ho_halo_rows": [r[6] for r in every], "fo_halo_rows": [r[7] for r in every]},
-            "collectives_rank0": priced,
-            "link_model": {"GB_per_s_per_direction_and_link": XGMI_GBS_PER_DIRECTION, "efficiency": XGMI_EFFICIENCY,
-                           "latency_us_per_collective": COLLECTIVE_LATENCY_US,
-                           "note": "every GPU pair has its own xGMI link; a collective costs latency + bytes on its busiest link / rate"},
-            "comm_bytes_per_step_rank0": {k: v / steps for k, v in comm.sent_bytes.items()},
-            "projected_ms_per_step_no_overlap": slowest + priced["exposed_ms"] + priced["overlapped_ms"],
-            "projected_ms_per_step": slowest + priced["exposed_ms"] + priced["overlapped_ms"] - hidden,
-            "amdahl_terms_ms": {"slowest_rank_compute": slowest, "of_which_graph_build": max(build_ms), "collectives_exposed": priced["exposed_ms"],
-                                "collectives_async": priced["overlapped_ms"], "async_hidden_behind_dbgnn_kernels": hidden},
-            "loss": float(loss_total), "E2": sizes.get("E2"), "U2": sizes.get("U2"), "A2": sizes.get("A2"),
-        }
-        print(json.dumps(report), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+def emulate(args) -> int:
+    """`--emulate-ranks R`: the R ranks of the partition step as R THREADS on cuda:0 (pathpyg_amd.distributed.ThreadWorld): they take
+    turns, so a rank's turns add up to the compute time it would need on a GPU of its own (kernels + launches + its read-backs; the copies
+    that stand in for the collectives are not counted); every collective is logged with the bytes on its busiest link and priced on the
+    xGMI link model.  Prints a PROJECTION of the R-GPU step, labelled as such — not a measurement of R GPUs."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: pathpyg_amd has no CPU path")
+    import pathpyg_amd as pp
+    from pathpyg_amd import distributed as ppd
+    world = args.emulate_ranks
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ei, t = synth_stream(args.events, args.nodes, args.span, seed=1, device=dev)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=args.nodes))
+    del ei, t
+    n_ho = int(pp.MultiOrderModel.from_temporal_graph(g, delta=1, max_order=1).layers[1].m)
+    feat = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(args.nodes, args.features, generator=feat, device=dev)          # resident inputs, shared by the emulated ranks
+    x_h = torch.randn(n_ho, args.features, generator=feat, device=dev)
+    y = torch.randint(0, args.classes, (args.nodes,), generator=feat, device=dev)
+    loaders = ((lambda rows: x.index_select(0, rows)), (lambda rows: x_h.index_select(0, rows)), (lambda rows: y.index_select(0, rows)))
+
+    def body(comm):
+        torch.manual_seed(0)
+        net = pp.nn.DBGNN(num_classes=args.classes, num_features=(args.features, args.features), hidden_dims=[args.features] * 3,
+                          p_dropout=args.dropout).to(dev)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        sharded = ppd.ShardedDBGNN(net, comm, overlap=not args.no_overlap)
+        build_s, sizes, loss = 0.0, {}, None
+        for it in range(args.warmup + args.steps):
+            if it == args.warmup:
+                comm.end_turns()
+                comm.tw.plain_barrier.wait()
+                comm.reset_counters()
+            comm.barrier()                          # (step boundary: opens this rank's first turn of the step)
+            opt.zero_grad(set_to_none=True)
+            c0 = comm.lap()
+            shard = ppd.build_dbgnn_shard(g, args.delta, *loaders, comm)
+            build_s += comm.lap() - c0 if it >= args.warmup else 0.0
+            loss = sharded.loss(shard)
+            loss.backward()
+            ppd.all_reduce_gradients(net, average=False, comm=comm)
+            opt.step()
+            sizes = shard.sizes
+        comm.end_turns()
+        total = loss.detach().to(torch.float64).reshape(1).clone()
+        comm.all_reduce_(total)
+        return {"compute_s": comm.compute_s, "build_s": build_s, "events": list(comm.events), "sent": dict(comm.sent_bytes), "sizes": sizes,
+                "loss": float(total)}
+
+    results = ppd.run_thread_world(world, body, dev)
+    steps = args.steps
+    compute_ms = [r["compute_s"] * 1e3 / steps for r in results]
+    build_ms = [r["build_s"] * 1e3 / steps for r in results]
+    # the rank with the costliest collectives sets the pace of every collective
+    priced_all = [price_collectives(r["events"], steps) for r in results]
+    priced = max(priced_all, key=lambda p_: p_["exposed_ms"] + p_["overlapped_ms"])
+    slowest = max(compute_ms)
+    dbgnn_ms = max(c - b for c, b in zip(compute_ms, build_ms))
+    hidden = min(priced["overlapped_ms"], dbgnn_ms)
+    sz = results[0]["sizes"]
+    report = {
+        "what": f"PROJECTION of the {world}-GPU partition step from {world} ranks taking turns on ONE MI355X (threads of one process; NOT a measurement of "
+                f"{world} GPUs)",
+        "emulated_ranks": world, "steps": steps, "warmup": args.warmup, "overlap_schedule": not args.no_overlap,
+        "workload": f"m={args.events}, N={args.nodes}, span={args.span}, delta={args.delta}, F={args.features}",
+        "per_rank_compute_ms": compute_ms, "per_rank_graph_build_ms": build_ms,
+        "max_rank_compute_ms": slowest, "mean_rank_compute_ms": sum(compute_ms) / world,
+        "per_rank": {k: [r["sizes"].get(k) for r in results] for k in ("E2_local", "A2_local", "lift_events_local", "layer1_events_local", "ho_halo", "fo_halo")},
+        "collectives_costliest_rank": priced,
+        "link_model": {"GB_per_s_per_direction_and_link": XGMI_GBS_PER_DIRECTION, "efficiency": XGMI_EFFICIENCY,
+                       "latency_us_per_collective": COLLECTIVE_LATENCY_US,
+                       "note": "every GPU pair of a node has its own xGMI link; a collective costs latency + bytes on its busiest link / rate"},
+        "comm_bytes_per_step_rank0": {k: v / steps for k, v in results[0]["sent"].items()},
+        "projected_ms_per_step_no_overlap": slowest + priced["exposed_ms"] + priced["overlapped_ms"],
+        "projected_ms_per_step": slowest + priced["exposed_ms"] + priced["overlapped_ms"] - hidden,
+        "amdahl_terms_ms": {"slowest_rank_compute": slowest, "of_which_graph_build": max(build_ms), "collectives_exposed": priced["exposed_ms"],
+                            "collectives_async": priced["overlapped_ms"], "async_hidden_behind_dbgnn_kernels": hidden},
+        "loss": results[0]["loss"], "E2": sz.get("E2"), "U2": sz.get("U2"), "A2": sz.get("A2"),
+    }
+    print(json.dumps(report), flush=True)
     return 0
 
 
@@ -429,7 +463,9 @@ def main() -> int:
         print(json.dumps(cpu_baseline(args, seed=11)), flush=True)
         return 0
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ          # started by torch.distributed.run
-    if (args.gpus > 1 or args.emulate_ranks > 1) and not launched:
+    if args.emulate_ranks > 1:
+        return emulate(args)
+    if args.gpus > 1 and not launched:
         return relaunch(args)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -456,8 +492,7 @@ def main() -> int:
     from pathpyg_amd._lib import lib
 
     partition = args.mode == "partition"
-    comm = ppd.Comm(serialize=args.serialize)
-    emulating = comm.serialize
+    comm = ppd.Comm()
     # ---- inputs, resident in HBM before the timed region.  partition: ONE stream replicated on every rank; streams: one per rank
     ei, t = synth_stream(args.events, args.nodes, args.span, seed=1 + (0 if partition else rank), device=dev)
     # library load, first-launch costs and the sort workspace (allocator growth) are paid by an untimed pass over the same stream
@@ -480,7 +515,6 @@ def main() -> int:
     # world size > 1: a rank reads only its owned + halo rows of the (resident) inputs
     x_in, xh_in, y_in = (x, x_h, y) if world == 1 else ((lambda rows: x.index_select(0, rows)), (lambda rows: x_h.index_select(0, rows)),
                                                         (lambda rows: y.index_select(0, rows)))
-    build_s = [0.0]
     lift_ms = []
     sizes = {}
 
@@ -488,13 +522,8 @@ def main() -> int:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         opt.zero_grad(set_to_none=True)
         e0.record()
-        c0 = comm.compute_s
         shard = ppd.build_dbgnn_shard(g, args.delta, x_in, xh_in, y_in, comm)
         e1.record()
-        if emulating and timed:
-            torch.cuda.synchronize()
-            import time as _t
-            build_s[0] += comm.compute_s - c0 + (_t.perf_counter() - comm._turn_start if comm._turn_start is not None else 0.0)
         if timed:                                   # (bookkeeping of the live rooflines: pointers -> CSR sizes)
             for gs in (shard.fo, shard.ho):
                 register_plan(gs.plan)
@@ -564,29 +593,21 @@ def main() -> int:
             KernelClock(L, "pp_coalesce_count", coalesce_desc, until="pp_coalesce_fill") as agg_clock:
         clocks = (spmm_clock, fwd_clock, bwd_clock, fill_clock, lift_clock, agg_clock)
         for _ in range(args.warmup):
-            if emulating:
-                comm.barrier()
             step(False)
-        if emulating:
-            comm.end_turns()
         barrier()
         comm.reset_counters()
         for c in clocks:
-            c.enabled = not emulating
+            c.enabled = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            if emulating:
-                comm.barrier()           # (opens this rank's first turn of the step; the turns of a step add up to its compute time)
             loss = step(True)
-        if emulating:
-            comm.end_turns()
         barrier()
         elapsed = time.perf_counter() - t0
         for c in clocks:
             c.enabled = False
     # untimed extra: the k=2 -> k=3 line-graph lift of the same event graph (the lift kernel WITHOUT the continuation-list gather)
     k3 = None
-    if rank == 0 and not emulating:
+    if rank == 0:
         ho = pp.algorithms.lift_order_temporal(g, args.delta)
         with KernelClock(L, "pp_linegraph_fill", lambda e, n, total, *r: ("k_expand<no list> (pp_linegraph_fill)", 16 * total + 12 * e)) as lg_clock:
             lg_clock.enabled = True
@@ -599,8 +620,6 @@ def main() -> int:
               "frac": (lg_b / (lg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lg_ms > 0 else 0.0}
         del ho
     e2_total = float(sizes.get("E2", 0))
-    if emulating:
-        return emulation_report(args, comm, sizes, build_s[0], loss, dev, dist)
     loss_total = loss.detach().to(torch.float64).reshape(1).clone()
     if launched and partition:
         comm.all_reduce_(loss_total)                             # every rank holds its share of the mean loss

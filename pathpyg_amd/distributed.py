@@ -153,69 +153,168 @@ def all_reduce_gradients(module: torch.nn.Module, group=None, average: bool = Tr
 # tests, or gloo with several ranks sharing one GPU in the single-GPU hardware tests) is served by staging through host memory —
 # test transport only, the driver's multi-GPU runs use RCCL.
 # =====================================================================================================
+class ThreadWorld:
+    """R ranks as R THREADS of one process on ONE GPU (``bench.py --emulate-ranks``, tests): the transport of a :class:`Comm` whose collectives
+    are device-to-device copies between the ranks' tensors.  The ranks take turns: a baton travels rank 0 -> 1 -> .. -> R-1 between
+    collectives, so a rank computes from one collective to the next while the others wait, and the wall time of its turns (GPU drained at
+    the end of each, copies of the collectives excluded) is the compute time it would need on a GPU of its own.  One process = one HIP
+    context: turns cost no context switch (R processes sharing a GPU pay ~1 ms per switch — measured: 130 ms per step of pure overhead).
+    Needs ``torch.autograd.set_multithreading_enabled(False)`` (backward functions then run on the calling thread; the engine's one
+    device thread would otherwise block in the first rank's collective)."""
+
+    def __init__(self, world: int):
+        import threading
+        self.world = world
+        self.cv = threading.Condition()
+        self.baton = 0
+        self.slots = [[None] * world, [None] * world]
+        self.arrived = {}                 # collective sequence number -> ranks that deposited
+        self.plain_barrier = threading.Barrier(world)
+        self.failed = None
+
+    def fail(self, exc):
+        with self.cv:
+            self.failed = exc
+            self.cv.notify_all()
+        self.plain_barrier.abort()
+
+    def _wait(self, cond):
+        while not cond():
+            if self.failed is not None:
+                raise RuntimeError(f"another emulated rank failed: {self.failed!r}")
+            self.cv.wait(timeout=1.0)
+
+    def take_turn(self, comm):
+        """Block until this rank holds the baton (start of its first turn)."""
+        with self.cv:
+            self._wait(lambda: self.baton == comm.rank)
+        comm._holding = True
+        comm._clock_start()
+
+    def collective(self, comm, payload, collect):
+        """Deposit ``payload``, hand the baton on, wait until every rank has deposited and the baton is back, then ``collect(slots)``."""
+        rank, world = comm.rank, self.world
+        if not comm._holding:
+            self.take_turn(comm)
+        comm._clock_stop()
+        seq = comm._seq
+        comm._seq += 1
+        with self.cv:
+            self.slots[seq % 2][rank] = payload
+            self.arrived[seq] = self.arrived.get(seq, 0) + 1
+            self.baton = (rank + 1) % world
+            comm._holding = False
+            self.cv.notify_all()
+            self._wait(lambda: self.arrived.get(seq, 0) == world and self.baton == rank)
+            slots = list(self.slots[seq % 2])
+        comm._holding = True
+        out = collect(slots) if collect is not None else None
+        if rank == world - 1:
+            with self.cv:
+                self.arrived.pop(seq - 1, None)
+        comm._clock_start()
+        return out
+
+    def release(self, comm):
+        """End this rank's turn without a collective (before a plain barrier)."""
+        if comm._holding:
+            comm._clock_stop()
+            with self.cv:
+                self.baton = (comm.rank + 1) % self.world
+                comm._holding = False
+                self.cv.notify_all()
+
+
+def run_thread_world(world: int, body, device=None):
+    """Run ``body(comm) -> result`` on ``world`` emulated ranks (threads of this process, :class:`ThreadWorld`); returns the results in rank
+    order.  An exception in one rank stops the others and is re-raised."""
+    import threading
+    tw = ThreadWorld(world)
+    results, errors = [None] * world, [None] * world
+    previous = torch.autograd.is_multithreading_enabled() if hasattr(torch.autograd, "is_multithreading_enabled") else True
+    torch.autograd.set_multithreading_enabled(False)
+
+    def run(rank):
+        try:
+            if device is not None and torch.device(device).type == "cuda":
+                torch.cuda.set_device(device)
+            comm = Comm(thread_world=tw, rank=rank)
+            results[rank] = body(comm)
+            tw.release(comm)
+        except BaseException as exc:          # noqa: BLE001 - handed to the caller
+            errors[rank] = exc
+            tw.fail(exc)
+
+    threads = [threading.Thread(target=run, args=(r,), name=f"pp-rank-{r}") for r in range(world)]
+    try:
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        torch.autograd.set_multithreading_enabled(previous)
+    first = next((e for e in errors if e is not None and not isinstance(e, RuntimeError)), None) or next((e for e in errors if e is not None), None)
+    if first is not None:
+        raise first
+    return results
+
+
 class Comm:
     """Process-group handle with the collectives the partitioned lift + DBGNN need, byte counters per kind, and a per-collective log
     (``events``: kind, bytes to the busiest peer, overlapped or not) from which ``bench.py`` prices a step on xGMI.
 
-    ``serialize=True`` (host-staged backends only; ``bench.py --emulate-ranks``): R ranks SHARE one GPU and take turns — a rank computes
-    from one collective to the next while the others wait (a token travels rank 0 -> 1 -> .. between collectives), and the wall time of
-    its turns (GPU drained at the end of each) accumulates in ``compute_s``: the per-rank compute time of a real R-GPU run, measured on
-    one GPU."""
+    ``thread_world`` / ``rank``: this rank is a THREAD of an emulated world (:class:`ThreadWorld`; ``bench.py --emulate-ranks``): collectives
+    are copies between the ranks' device tensors, the ranks take turns, ``compute_s`` accumulates the wall time of this rank's turns."""
 
-    def __init__(self, group=None, serialize: bool = False):
+    def __init__(self, group=None, thread_world: "ThreadWorld | None" = None, rank: int | None = None):
         self.group = group
-        self.rank, self.world = _world(group)
-        self.backend = dist.get_backend(group) if (self.world > 1 or (dist.is_available() and dist.is_initialized())) else None
-        self.native = self.backend == "nccl"
+        self.tw = thread_world
+        if thread_world is not None:          # R ranks as threads of this process (ThreadWorld): device-to-device collectives, timed turns
+            self.rank, self.world, self.backend, self.native = int(rank), thread_world.world, "threads", False
+        else:
+            self.rank, self.world = _world(group)
+            self.backend = dist.get_backend(group) if (self.world > 1 or (dist.is_available() and dist.is_initialized())) else None
+            self.native = self.backend == "nccl"
+        self._holding = False
         self.sent_bytes = {"exchange": 0, "all_gather": 0, "reduce_scatter": 0, "all_reduce": 0}
         self.events = []               # (kind, bytes to / from the busiest peer, issued asynchronously)
-        self.serialize = bool(serialize) and self.world > 1 and not self.native
         self.compute_s = 0.0
         self._turn_start = None
-        self._seq, self._kv = 0, None
+        self._seq = 0
 
     # ---- emulation turns
-    def _enter(self):
-        """Called at the start of every collective."""
-        if not self.serialize:
-            return
+    def _clock_start(self):
+        import time as _time
+        self._turn_start = _time.perf_counter()
+
+    def _clock_stop(self):
         import time as _time
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         if self._turn_start is not None:
             self.compute_s += _time.perf_counter() - self._turn_start
             self._turn_start = None
-        if self.rank + 1 < self.world:          # the token travels through the rendezvous store (point-to-point sends beside collectives
-            self._store().set(f"pp_turn/{self._seq}/{self.rank + 1}", b"1")     # upset the gloo transport)
 
-    def _exit(self):
-        """Called at the end of every collective: wait for my turn."""
-        if not self.serialize:
-            return
-        import time as _time
-        self._seq += 1          # (index of the next collective: rank - 1 passes the token on when IT enters that one)
-        if self.rank > 0:
-            self._store().wait([f"pp_turn/{self._seq}/{self.rank}"])
-        self._turn_start = _time.perf_counter()
-
-    def _store(self):
-        if self._kv is None:
-            self._kv = dist.distributed_c10d._get_default_store()
-        return self._kv
+    def lap(self) -> float:
+        """Emulation: fold the running turn into ``compute_s`` (GPU drained) and return it."""
+        if self._turn_start is not None:
+            self._clock_stop()
+            self._clock_start()
+        return self.compute_s
 
     def barrier(self):
         """A collective without payload (step boundaries of the bench; closes / opens a turn in the emulation)."""
         if self.world == 1:
             return
-        self._enter()
+        if self.tw is not None:
+            self.tw.collective(self, None, None)
+            return
         dist.barrier(group=self.group)
-        self._exit()
 
     def end_turns(self):
-        """Emulation: close this rank's turn and pass the token on WITHOUT waiting for it again (before code that talks to the process
-        group directly, e.g. the bench's own barriers)."""
-        self._enter()
-        self._seq += 1
+        """Emulation: close this rank's turn and pass the baton on without waiting for it again."""
+        if self.tw is not None:
+            self.tw.release(self)
 
     def reset_counters(self):
         self.sent_bytes = {k: 0 for k in self.sent_bytes}
@@ -238,14 +337,15 @@ class Comm:
         """counts[r] rows go to rank r -> how many rows come from each rank (one all-to-all of ``world`` integers)."""
         if self.world == 1:
             return list(send_counts)
-        self._enter()
+        if self.tw is not None:
+            self.events.append(("counts", 8, False))
+            return self.tw.collective(self, [int(c) for c in send_counts], lambda slots: [slots[q][self.rank] for q in range(self.world)])
         dev = device if self.native else torch.device("cpu")
         send = torch.tensor(send_counts, dtype=torch.int64, device=dev)
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)
         out = [int(v) for v in recv.tolist()]
         self.events.append(("counts", 8, False))
-        self._exit()
         return out
 
     def exchange_rows(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int], out: torch.Tensor | None = None) -> torch.Tensor:
@@ -258,14 +358,25 @@ class Comm:
                 return send
             out.copy_(send)
             return out
-        self._enter()
         row_bytes = send.element_size() * math.prod(send.shape[1:])
         self._count_exchange(send_counts, row_bytes, recv_counts)
+        if self.tw is not None:
+            offs = [0]
+            for c in send_counts:
+                offs.append(offs[-1] + int(c))
+
+            def collect(slots):
+                pieces = [slots[q][0][slots[q][1][self.rank]: slots[q][1][self.rank + 1]] for q in range(self.world)]
+                got = torch.cat(pieces) if pieces else send.new_empty(shape)
+                if out is None:
+                    return got
+                out.copy_(got)
+                return out
+            return self.tw.collective(self, (send.detach().contiguous(), offs), collect)
         if self.native:
             if out is None:
                 out = torch.empty(shape, dtype=send.dtype, device=send.device)
             dist.all_to_all_single(out, send.contiguous(), list(recv_counts), list(send_counts), group=self.group)
-            self._exit()
             return out
         staged = torch.empty(shape, dtype=send.dtype)
         dist.all_to_all_single(staged, send.detach().cpu().contiguous(), list(recv_counts), list(send_counts), group=self.group)
@@ -273,7 +384,6 @@ class Comm:
             out = staged.to(send.device)
         else:
             out.copy_(staged)
-        self._exit()
         return out
 
     # ---- asynchronous forms: the collective is queued behind the work already on the current stream and runs beside what is launched next
@@ -347,74 +457,89 @@ class Comm:
         """Equal-sized row blocks of all ranks, rank order: ``[world * rows, ...]``."""
         if self.world == 1:
             return x_local
-        self._enter()
         block = x_local.numel() * x_local.element_size()
         self.sent_bytes["all_gather"] += (self.world - 1) * block
         self._peer_bytes("all_gather", block)
+        if self.tw is not None:
+            return self.tw.collective(self, x_local.detach().contiguous(), lambda slots: torch.cat(slots))
         src = self._stage(x_local.contiguous())
         out = torch.empty((self.world * src.size(0),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
         dist.all_gather_into_tensor(out, src, group=self.group)
         out = out.to(x_local.device)
-        self._exit()
         return out
 
     def reduce_scatter_rows(self, x_full: torch.Tensor, rows_per_rank: int) -> torch.Tensor:
         """Sum ``[world * rows_per_rank, ...]`` over the ranks, keep this rank's block."""
         if self.world == 1:
             return x_full
-        self._enter()
         block = rows_per_rank * x_full[0].numel() * x_full.element_size()
         self.sent_bytes["reduce_scatter"] += (self.world - 1) * block
         self._peer_bytes("reduce_scatter", block)
+        if self.tw is not None:
+            lo_, hi_ = self.rank * rows_per_rank, (self.rank + 1) * rows_per_rank
+
+            def collect(slots):
+                acc = slots[0][lo_:hi_].clone()
+                for q in range(1, self.world):          # rank order: the same sum on every run
+                    acc += slots[q][lo_:hi_]
+                return acc
+            return self.tw.collective(self, x_full.detach().contiguous(), collect)
         src = self._stage(x_full.contiguous())
         out = torch.empty((rows_per_rank,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
         dist.reduce_scatter_tensor(out, src, group=self.group)
         out = out.to(x_full.device)
-        self._exit()
         return out
 
     def all_reduce_(self, t: torch.Tensor, op=None) -> torch.Tensor:
         if self.world == 1:
             return t
-        self._enter()
         self.sent_bytes["all_reduce"] += t.numel() * t.element_size()
         self._peer_bytes("all_reduce", t.numel() * t.element_size())
         op = dist.ReduceOp.SUM if op is None else op
+        if self.tw is not None:
+            def collect(slots):
+                acc = slots[0].clone()
+                for q in range(1, self.world):
+                    acc = torch.maximum(acc, slots[q]) if op == dist.ReduceOp.MAX else acc + slots[q]
+                t.copy_(acc)
+                return t
+            return self.tw.collective(self, t.detach().clone(), collect)
         if self.native or not t.is_cuda:
             dist.all_reduce(t, op=op, group=self.group)
         else:
             staged = t.cpu()
             dist.all_reduce(staged, op=op, group=self.group)
             t.copy_(staged)
-        self._exit()
         return t
 
     def all_gather_ints_dev(self, mine: torch.Tensor) -> list[list[int]]:
         """Every rank's small int64 DEVICE vector (same length everywhere) -> ``[world][len]`` on the host: one collective + one read-back."""
         if self.world == 1:
             return [mine.tolist()]
-        self._enter()
+        if self.tw is not None:
+            self.events.append(("counts", 8 * mine.numel(), False))
+            return self.tw.collective(self, mine.tolist(), lambda slots: [list(v) for v in slots])
         src = mine.to(torch.int64).contiguous()
         src = src if (self.native or not src.is_cuda) else src.cpu()
         out = torch.empty(self.world * src.numel(), dtype=torch.int64, device=src.device)
         dist.all_gather_into_tensor(out, src, group=self.group)
         host = out.view(self.world, -1).tolist()
         self.events.append(("counts", 8 * src.numel(), False))
-        self._exit()
         return host
 
     def all_gather_ints(self, values: list[int], device) -> list[list[int]]:
         """Every rank's small integer vector (same length everywhere): ``[world][len(values)]`` on the host."""
         if self.world == 1:
             return [list(values)]
-        self._enter()
+        if self.tw is not None:
+            self.events.append(("counts", 8 * len(values), False))
+            return self.tw.collective(self, [int(v) for v in values], lambda slots: [list(v) for v in slots])
         dev = device if self.native else torch.device("cpu")
         mine = torch.tensor(values, dtype=torch.int64, device=dev)
         out = torch.empty(self.world * mine.numel(), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(out, mine, group=self.group)
         host = out.view(self.world, -1).tolist()
         self.events.append(("counts", 8 * mine.numel(), False))
-        self._exit()
         return host
 
 

@@ -312,58 +312,54 @@ def _world8_worker(rank, world, port, results):
 ROW_COST_ = 2
 
 
-def _turns_worker(rank, world, port, results):
-    """Comm(serialize=True) — the turn-taking of `bench.py --emulate-ranks`: same numbers as the free-running path, a compute time per rank,
-    a log entry per collective with the asynchronous ones marked."""
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        import pathpyg_amd as pp
-        from pathpyg_amd import distributed as pd
-        from oracle import dbgnn as od
-        from oracle import model as om
-        from tests.cpu_ops import CpuOps
-        rng = np.random.default_rng(29)
-        m, n, delta, span, f = 1500, 30, 9, 500, 8
-        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
-        t = torch.from_numpy(np.sort(rng.integers(0, span, m)))
-        layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2)
-        gen = torch.Generator().manual_seed(4)
-        x, x_h = torch.randn(n, f, generator=gen), torch.randn(layers[2]["num_nodes"], f, generator=gen)
-        y = torch.randint(0, 3, (n,), generator=gen)
-        params = od.init_params(3, (f, f), [12, 10, 6], seed=5)
-        want = od.loss_and_grads(params, om.dbgnn_inputs(layers, 2, "last", x=x, x_h=x_h), y)
-        tg = type("G", (), {})()
-        tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n)
-        comm = pd.Comm(serialize=True)
-        assert comm.serialize
+@pytest.mark.parametrize("world", [2, 8])
+def test_thread_world_ranks_match_oracle(world):
+    """ThreadWorld — R ranks as threads of ONE process (what `bench.py --emulate-ranks` runs on the one GPU): collectives are copies between
+    the ranks' tensors, the ranks take turns.  Same numbers as the oracle, a compute time and a collective log per rank."""
+    import pathpyg_amd as pp
+    from pathpyg_amd import distributed as pd
+    from oracle import dbgnn as od
+    from oracle import model as om
+    from tests.cpu_ops import CpuOps
+    rng = np.random.default_rng(37)
+    m, n, delta, span, f = 3000, 48, 10, 800, 8
+    ei, t = zipf_stream(rng, m, n, span)
+    w = torch.from_numpy(rng.integers(1, 4, m).astype(np.float32))
+    layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2, edge_weight=w)
+    gen = torch.Generator().manual_seed(4)
+    x, x_h = torch.randn(n, f, generator=gen), torch.randn(layers[2]["num_nodes"], f, generator=gen)
+    y = torch.randint(0, 3, (n,), generator=gen)
+    params = od.init_params(3, (f, f), [12, 10, 6], seed=5)
+    want_out, want_loss, want_grads = od.loss_and_grads(params, om.dbgnn_inputs(layers, 2, "last", x=x, x_h=x_h), y)
+    tg = type("G", (), {})()
+    tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n, edge_weight=w)
+
+    def body(comm):
         net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=[12, 10, 6])
         net.load_state_dict(params)
         sharded = pd.ShardedDBGNN(net, comm, ops=CpuOps())
         for _ in range(2):
             comm.barrier()
             net.zero_grad()
-            shard = pd.build_dbgnn_shard(tg, delta, x, x_h, y, comm, CpuOps())
+            shard = pd.build_dbgnn_shard(tg, delta, lambda r: x.index_select(0, r), lambda r: x_h.index_select(0, r), lambda r: y.index_select(0, r),
+                                         comm, CpuOps())
+            out = sharded(shard)
             loss = sharded.loss(shard)
             loss.backward()
             pd.all_reduce_gradients(net, average=False, comm=comm)
-        comm.end_turns()
-        total = loss.detach().clone()
-        dist.all_reduce(total)
-        torch.testing.assert_close(total, want[1], rtol=1e-5, atol=1e-6)
-        for name, p in net.named_parameters():
-            torch.testing.assert_close(p.grad, want[2][name], rtol=1e-3, atol=1e-5, msg=lambda s_: f"{name}: {s_}")
-        kinds = {k for k, _, _ in comm.events}
-        assert comm.compute_s > 0 and {"exchange", "all_gather", "reduce_scatter", "all_reduce", "counts"} <= kinds
-        assert any(o for _, _, o in comm.events) and any(not o for _, _, o in comm.events)        # the trunk's exchanges are the overlapped ones
-        results[rank] = "ok"
-    finally:
-        dist.destroy_process_group()
+        total = loss.detach().clone().reshape(1)
+        comm.all_reduce_(total)
+        return {"out": out.detach(), "lo": shard.fo.lo, "hi": shard.fo.hi, "loss": total[0], "grads": {k: p.grad.clone() for k, p in net.named_parameters()},
+                "compute_s": comm.compute_s, "events": list(comm.events), "sizes": shard.sizes}
 
-
-def test_turn_taking_emulation_gives_the_same_numbers_and_a_collective_log():
-    _spawn(_turns_worker, 3)
+    results = pd.run_thread_world(world, body)
+    assert sum(r["hi"] - r["lo"] for r in results) == n
+    for r in results:
+        torch.testing.assert_close(r["out"], want_out[r["lo"]: r["hi"]], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(r["loss"], want_loss, rtol=1e-5, atol=1e-6)
+        for name, gr in r["grads"].items():
+            torch.testing.assert_close(gr, want_grads[name], rtol=1e-3, atol=1e-5, msg=lambda s_: f"{name}: {s_}")
+        assert r["compute_s"] > 0 and any(o for _, _, o in r["events"]) and r["sizes"]["U2"] == layers[2]["num_nodes"]
 
 
 def test_world8_er_and_zipf_streams_match_oracle_and_balance():
