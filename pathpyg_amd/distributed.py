@@ -178,10 +178,14 @@ class ThreadWorld:
             self.cv.notify_all()
         self.plain_barrier.abort()
 
-    def _wait(self, cond):
+    def _wait(self, cond, limit_s: float = 300.0):
+        import time as _time
+        t0 = _time.monotonic()
         while not cond():
             if self.failed is not None:
                 raise RuntimeError(f"another emulated rank failed: {self.failed!r}")
+            if _time.monotonic() - t0 > limit_s:
+                raise RuntimeError("ThreadWorld: a rank waited for its turn for more than 5 minutes (the ranks no longer call the same collectives?)")
             self.cv.wait(timeout=1.0)
 
     def take_turn(self, comm):
@@ -236,6 +240,7 @@ def run_thread_world(world: int, body, device=None):
 
     def run(rank):
         try:
+            torch.autograd.set_multithreading_enabled(False)       # (thread-local, like the grad mode: every rank thread sets it for itself)
             if device is not None and torch.device(device).type == "cuda":
                 torch.cuda.set_device(device)
             comm = Comm(thread_world=tw, rank=rank)
