@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--emulate-ranks", type=int, default=0, help="run R ranks of the partition path as R threads on ONE GPU, taking turns: per-rank "
                                                                  "compute time + bytes per xGMI link of every collective -> a LABELLED PROJECTION of the "
                                                                  "R-GPU step (not a measurement of R GPUs; prints its own JSON report)")
+    ap.add_argument("--trace", action="store_true", help="--emulate-ranks: per-phase compute time of rank 1 in the report")
     ap.add_argument("--no-overlap", action="store_true", help="partition path without the interleaved exchange schedule (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-loop-events", type=int, default=6_000, help="smallest of the three B-loop sizes (x2, x4 follow; kept below torch's 32768-element parallel grain)")
@@ -401,6 +402,8 @@ def emulate(args) -> int:
                           p_dropout=args.dropout).to(dev)
         opt = torch.optim.Adam(net.parameters(), lr=1e-3)
         sharded = ppd.ShardedDBGNN(net, comm, overlap=not args.no_overlap)
+        if args.trace:
+            comm.trace = {}
         build_s, sizes, loss = 0.0, {}, None
         for it in range(args.warmup + args.steps):
             if it == args.warmup:
@@ -416,12 +419,14 @@ def emulate(args) -> int:
             loss.backward()
             ppd.all_reduce_gradients(net, average=False, comm=comm)
             opt.step()
+            comm.mark("step: gradient all-reduce + Adam")
             sizes = shard.sizes
         comm.end_turns()
+        sizes = ppd.global_sizes(shard, comm)
         total = loss.detach().to(torch.float64).reshape(1).clone()
         comm.all_reduce_(total)
         return {"compute_s": comm.compute_s, "build_s": build_s, "events": list(comm.events), "sent": dict(comm.sent_bytes), "sizes": sizes,
-                "loss": float(total)}
+                "loss": float(total), "trace": comm.trace}
 
     results = ppd.run_thread_world(world, body, dev)
     steps = args.steps
@@ -453,6 +458,8 @@ def emulate(args) -> int:
                             "collectives_async": priced["overlapped_ms"], "async_hidden_behind_dbgnn_kernels": hidden},
         "loss": results[0]["loss"], "E2": sz.get("E2"), "U2": sz.get("U2"), "A2": sz.get("A2"),
     }
+    if args.trace:
+        report["phase_ms_rank1"] = {k: v * 1e3 / steps for k, v in (results[min(1, world - 1)]["trace"] or {}).items()}
     print(json.dumps(report), flush=True)
     return 0
 
@@ -535,6 +542,7 @@ def main() -> int:
         ppd.all_reduce_gradients(net, average=False, comm=comm)
         opt.step()
         sizes.update(shard.sizes)
+        step_partition.last_shard = shard
         if timed:
             lift_ms.append((e0, e1))
         return loss
@@ -619,6 +627,8 @@ def main() -> int:
               "achieved": lg_b / (lg_ms * 1e-3) / 1e9 if lg_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
               "frac": (lg_b / (lg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lg_ms > 0 else 0.0}
         del ho
+    if partition:
+        sizes.update(ppd.global_sizes(step_partition.last_shard, comm))       # (A2 over all ranks: a collective, outside the timed region)
     e2_total = float(sizes.get("E2", 0))
     loss_total = loss.detach().to(torch.float64).reshape(1).clone()
     if launched and partition:

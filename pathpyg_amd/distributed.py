@@ -286,6 +286,7 @@ class Comm:
         self.compute_s = 0.0
         self._turn_start = None
         self._seq = 0
+        self.trace, self._mark_at = None, 0.0
 
     # ---- emulation turns
     def _clock_start(self):
@@ -299,6 +300,14 @@ class Comm:
         if self._turn_start is not None:
             self.compute_s += _time.perf_counter() - self._turn_start
             self._turn_start = None
+
+    def mark(self, label: str) -> None:
+        """Emulation only (``trace`` enabled by bench.py --emulate-ranks --trace): compute time since the previous mark, under ``label``."""
+        if self.trace is None or self.tw is None:
+            return
+        now = self.lap()
+        self.trace[label] = self.trace.get(label, 0.0) + (now - self._mark_at)
+        self._mark_at = now
 
     def lap(self) -> float:
         """Emulation: fold the running turn into ``compute_s`` (GPU drained) and return it."""
@@ -325,6 +334,9 @@ class Comm:
         self.sent_bytes = {k: 0 for k in self.sent_bytes}
         self.events = []
         self.compute_s = 0.0
+        self._mark_at = 0.0
+        if self.trace is not None:
+            self.trace = {}
 
     def _count_exchange(self, send_counts, row_bytes: int, recv_counts=None, overlapped: bool = False):
         self.sent_bytes["exchange"] += (int(sum(send_counts)) - int(send_counts[self.rank])) * row_bytes
@@ -853,6 +865,17 @@ def build_dbgnn_shard(g, delta, x, x_h, y, comm: Comm, ops=None, weight: str = "
                              "ho_cuts": ho_cuts, "fo_halo": 0, "ho_halo": 0})
 
 
+def global_sizes(shard, comm: Comm) -> dict:
+    """``shard.sizes`` with the global number of aggregated order-2 edges ``A2`` (a collective: every rank calls it; kept out of
+    :func:`build_dbgnn_shard` so that a step pays no all-reduce for a number only reports need)."""
+    sizes = dict(shard.sizes)
+    if "A2" not in sizes:
+        total = torch.tensor([sizes["A2_local"]], dtype=torch.float64, device=shard.x.device)
+        comm.all_reduce_(total)
+        sizes["A2"] = int(total.item())
+    return sizes
+
+
 def _takes_count(fn) -> bool:
     """Round-2 form of the ``x_h`` argument: ``x_h(num_ho_nodes) -> [U, F]`` (marked by the attribute ``takes_count``, or by a parameter
     named ``num_ho_nodes`` / ``n_ho``)."""
@@ -866,93 +889,136 @@ def _takes_count(fn) -> bool:
     return bool(names) and names[0] in ("num_ho_nodes", "n_ho", "num_nodes")
 
 
-def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
-    """World size > 1 branch of :func:`build_dbgnn_shard` (see there for the scheme)."""
-    from .nn.sharded import DbgnnShard, GraphShard
-    rank, world = comm.rank, comm.world
+class StreamShard:
+    """One rank's share of a time-sorted event stream under :func:`partition_plan` — what a multi-GPU deployment holds after it has
+    DISTRIBUTED the stream (done once per stream, like the time sort of ``TemporalGraph.__init__``; every step then starts from resident,
+    already distributed inputs): the events that start in its node range (layer 1), its edge range + forward halo (lift), and where the
+    events of its lift slice sit in the all-gathered event -> order-2 node maps."""
+
+    __slots__ = ("plan", "world", "rank", "n", "m", "ei_l1", "w_l1", "ei_lift", "time_lift", "w_lift", "n_own_lift", "slot", "slot_owner",
+                 "cap_n", "cap_m", "stamp", "delta")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+def distribute_stream(g, delta, comm: Comm, ops=None, weight: str = "edge_weight") -> StreamShard:
+    """Partition plan + this rank's slices of the (replicated) stream ``g``.  Cached on ``g`` for as long as its tensors, ``delta`` and the
+    world stay the same; :func:`build_dbgnn_shard` calls it on first use."""
+    ops = _ops_default(ops)
     data = g.data
     ei = _dispatch.plain(data.edge_index)
+    w_all = data[weight] if weight in data else None
+    stamp = (comm.world, comm.rank, repr(delta), tuple((t_, t_._version) for t_ in (data.edge_index, data.time, w_all) if t_ is not None))
+    cached = getattr(g, "_pp_stream_shard", None)
+    if cached is not None and len(cached.stamp) == len(stamp) and cached.stamp[:3] == stamp[:3] and \
+            all(a is b and va == vb for (a, va), (b, vb) in zip(cached.stamp[3], stamp[3])):
+        return cached
+    rank, world = comm.rank, comm.world
     dev = ei.device
     time = data.time.contiguous()
     n, m = int(data.num_nodes), int(ei.size(1))
-    unit_weights = weight not in data
-    w_all = None if unit_weights else data[weight]
-    i64 = dict(dtype=torch.int64, device=dev)
-    # ---- 0. the plan every rank derives for itself (one read-back)
     plan = partition_plan(ei, time, n, delta, world, ops)
-    fo_cuts, owner_ptr = plan["fo_cuts"], plan["owner_ptr"]
-    fo_cuts_t, order = plan["fo_cuts_t"], plan["order"]
-    lo_n, hi_n = fo_cuts[rank], fo_cuts[rank + 1]
-    n_fo_own = hi_n - lo_n
+    owner_ptr, order = plan["owner_ptr"], plan["order"].long()
     lo_e, hi_e = plan["ev_cuts"][rank], plan["ev_cuts"][rank + 1]
     end_e = max(plan["ev_ends"][rank], hi_e) if hi_e > lo_e else lo_e
-    # ---- 1. layer 1 on the events that start in my node range  +  2. the edge-range lift (count phases queued together: one read-back)
-    mine = order[owner_ptr[rank]: owner_ptr[rank + 1]].long()
-    ei_r = ei.index_select(1, mine)
-    w_r = torch.ones(mine.numel(), device=dev) if unit_weights else w_all.index_select(0, mine)
-    (fo_r, fo_w_r, inv_r), local = ops.coalesce_and_lift(
-        (ei_r, w_r, n, "sum", None, True),
-        (ei[:, lo_e:end_e].contiguous(), time[lo_e:end_e].contiguous(), n, delta, hi_e - lo_e, lo_e))
-    n_ho_own = int(fo_r.size(1))
-    # global ids: per-node block sizes of all ranks (N ints over the wire) -> row_ptr; event -> order-2 node map of all ranks (m ints)
-    cap_n = max(max(fo_cuts[r + 1] - fo_cuts[r] for r in range(world)), 1)
+    mine = order[owner_ptr[rank]: owner_ptr[rank + 1]]
+    cap_n = max(max(plan["fo_cuts"][r + 1] - plan["fo_cuts"][r] for r in range(world)), 1)
     cap_m = max(max(owner_ptr[r + 1] - owner_ptr[r] for r in range(world)), 1)
+    # where the events of my lift slice sit in the [world, cap_m] buffer of all-gathered (event -> local order-2 node) maps
+    pos_of_event = torch.empty(m, dtype=torch.int64, device=dev)
+    pos_of_event[order] = torch.arange(m, dtype=torch.int64, device=dev)
+    k = pos_of_event[lo_e:end_e]
+    ptr_t = torch.tensor(owner_ptr, dtype=torch.int64, device=dev)
+    q = torch.searchsorted(ptr_t[1:-1].contiguous(), k.contiguous(), right=True) if world > 1 else torch.zeros_like(k)
+    shard = StreamShard(plan=plan, world=world, rank=rank, n=n, m=m, ei_l1=ei.index_select(1, mine).contiguous(),
+                        w_l1=None if w_all is None else w_all.index_select(0, mine).contiguous(), ei_lift=ei[:, lo_e:end_e].contiguous(),
+                        time_lift=time[lo_e:end_e].contiguous(), w_lift=None if w_all is None else w_all[lo_e:end_e].contiguous(),
+                        n_own_lift=hi_e - lo_e, slot=(q * cap_m + (k - ptr_t[q])).contiguous(), slot_owner=q.contiguous(), cap_n=cap_n, cap_m=cap_m,
+                        stamp=stamp, delta=delta)
+    try:
+        object.__setattr__(g, "_pp_stream_shard", shard)
+    except Exception:          # exotic containers: no caching, still correct
+        pass
+    return shard
+
+
+def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
+    """World size > 1 branch of :func:`build_dbgnn_shard` (see there for the scheme)."""
+    from .nn.sharded import DbgnnShard
+    rank, world = comm.rank, comm.world
+    ss = distribute_stream(g, delta, comm, ops, weight)              # (cached: the stream is distributed once, not once per step)
+    comm.mark("build: 0 stream distribution (first step only)")
+    plan = ss.plan
+    n, m = ss.n, ss.m
+    dev = ss.ei_l1.device
+    unit_weights = ss.w_l1 is None
+    i64 = dict(dtype=torch.int64, device=dev)
+    fo_cuts, owner_ptr, fo_cuts_t = plan["fo_cuts"], plan["owner_ptr"], plan["fo_cuts_t"]
+    lo_n, hi_n = fo_cuts[rank], fo_cuts[rank + 1]
+    n_fo_own = hi_n - lo_n
+    m_l1 = int(ss.ei_l1.size(1))
+    # ---- 1. layer 1 on the events that start in my node range  +  2. the edge-range lift (count phases queued together: one read-back)
+    w_r = torch.ones(m_l1, device=dev) if unit_weights else ss.w_l1
+    (fo_r, fo_w_r, inv_r), local = ops.coalesce_and_lift((ss.ei_l1, w_r, n, "sum", None, True),
+                                                         (ss.ei_lift, ss.time_lift, n, delta, ss.n_own_lift, 0))       # (ids relative to my slice)
+    n_ho_own = int(fo_r.size(1))
+    comm.mark("build: 1+2 layer-1 coalesce + lift")
+    # global ids: per-node block sizes of all ranks (N ints over the wire) -> row_ptr; event -> order-2 node map of all ranks (m ints)
     ptr_r = ops.ptr_from_sorted(fo_r[0] - lo_n, n_fo_own)                                       # int64 [n_fo_own + 1], local
-    blocks_pad = torch.zeros(cap_n, **i64)
+    blocks_pad = torch.zeros(ss.cap_n, dtype=torch.int32, device=dev)
     blocks_pad[:n_fo_own] = ptr_r[1:] - ptr_r[:-1]
-    inv_pad = torch.zeros(cap_m, dtype=torch.int32, device=dev)
-    inv_pad[: mine.numel()] = inv_r.to(torch.int32)
-    blocks_all = comm.all_gather_rows(blocks_pad.to(torch.int32)).view(world, cap_n)
-    inv_all = comm.all_gather_rows(inv_pad).view(world, cap_m)
-    blocks = torch.cat([blocks_all[r, : fo_cuts[r + 1] - fo_cuts[r]] for r in range(world)]).to(torch.int64)      # [n]
-    row_ptr = torch.zeros(n + 1, **i64)
-    torch.cumsum(blocks, 0, out=row_ptr[1:])
-    ho_cuts_t = row_ptr.index_select(0, fo_cuts_t)                                              # order-2 id ranges = blocks of the node ranges
+    inv_pad = torch.zeros(ss.cap_m, dtype=torch.int32, device=dev)
+    inv_pad[:m_l1] = inv_r
+    blocks_all = comm.all_gather_rows(blocks_pad).view(world, ss.cap_n)
+    inv_all = comm.all_gather_rows(inv_pad)                                                     # [world * cap_m]
+    own_blocks = blocks_all.sum(dim=1, dtype=torch.int64)                                       # order-2 nodes per rank
+    ho_cuts_t = torch.zeros(world + 1, **i64)
+    torch.cumsum(own_blocks, 0, out=ho_cuts_t[1:])
     e2_local = int(local.size(1))
-    totals = torch.tensor([e2_local], **i64)
-    head = torch.cat((ho_cuts_t, totals)).tolist()                                              # (read-back: global order-2 ids)
-    ho_cuts = head[: world + 1]
+    ho_cuts = ho_cuts_t.tolist()                                                                # (read-back: global order-2 id ranges)
     n_ho = ho_cuts[-1]
     lo_h, hi_h = ho_cuts[rank], ho_cuts[rank + 1]
     assert hi_h - lo_h == n_ho_own, "partition_plan: the ranks disagree on the order-2 node ranges"
-    inv1 = torch.empty(m, dtype=torch.int64, device=dev)                                          # event -> global order-2 node id
-    vals = torch.cat([inv_all[r, : owner_ptr[r + 1] - owner_ptr[r]].to(torch.int64) + ho_cuts[r] for r in range(world)])
-    inv1.index_copy_(0, order.long(), vals)
-    del vals, inv_all, blocks_all
+    inv_slice = inv_all.index_select(0, ss.slot).to(torch.int64) + ho_cuts_t.index_select(0, ss.slot_owner)     # event of my lift slice -> global node id
+    del inv_all
+    comm.mark("build: global ids (2 all-gathers, event->node map of my slice)")
     # ---- 3. lifted pairs to the owner of their destination  +  4. order-2 nodes (= first-order edges) to the owner of their head node:
     #         both send-count vectors travel in ONE all-gather, one read-back
-    u, v = inv1.index_select(0, local[0]), inv1.index_select(0, local[1])
+    u, v = inv_slice.index_select(0, local[0]), inv_slice.index_select(0, local[1])
     p_ptr, p_order = _route(torch.searchsorted(ho_cuts_t[1:-1].contiguous(), v, right=True), world, ops)
     f_ptr, f_order = _route(torch.searchsorted(fo_cuts_t[1:-1].contiguous(), fo_r[1].contiguous(), right=True), world, ops)
-    counts = comm.all_gather_ints_dev(torch.cat((p_ptr[1:] - p_ptr[:-1], f_ptr[1:] - f_ptr[:-1])).to(torch.int64))      # [world][2 * world]
-    p_send, f_send = counts[rank][:world], counts[rank][world:]
+    counts = comm.all_gather_ints_dev(torch.cat((p_ptr[1:] - p_ptr[:-1], f_ptr[1:] - f_ptr[:-1], torch.tensor([e2_local], dtype=torch.int32, device=dev)))
+                                      .to(torch.int64))                                                                  # [world][2 * world + 1]
+    e2 = sum(counts[r][2 * world] for r in range(world))
+    p_send, f_send = counts[rank][:world], counts[rank][world: 2 * world]
     p_recv, f_recv = [counts[r][rank] for r in range(world)], [counts[r][world + rank] for r in range(world)]
     pairs = torch.stack((u, v), dim=1).to(torch.int32).index_select(0, p_order)
     pairs_in = comm.exchange_rows(pairs, p_send, p_recv)
     if unit_weights:
         w_in = torch.ones(pairs_in.size(0), device=dev)
     else:
-        w_in = comm.exchange_rows(w_all.index_select(0, local[0]).index_select(0, p_order), p_send, p_recv)     # weight of the source event
+        w_in = comm.exchange_rows(ss.w_lift.index_select(0, local[0]).index_select(0, p_order), p_send, p_recv)     # weight of the source event
     own_ids = torch.arange(lo_h, hi_h, **i64)
     nodes = torch.stack((fo_r[0], fo_r[1], own_ids, fo_w_r.to(torch.float32).view(torch.int32).to(torch.int64)), dim=1).to(torch.int32)
     nodes_out = nodes.index_select(0, f_order)
     nodes_in = comm.exchange_rows(nodes_out, f_send, f_recv)                                     # (a, b, global id, weight bits), sorted by id
     del u, v, pairs, nodes
+    comm.mark("build: 3+4 routing (pairs, first-order edges)")
     # ---- layer 2: the in-edges of my order-2 rows
     ho_ei, ho_w = ops.coalesce(pairs_in.t().to(torch.int64).contiguous(), w_in, n_ho, "sum", None, False, None)
+    comm.mark("build: layer-2 coalesce")
     # ---- 5. shards.  Higher-order graph: the halo is structural — the order-2 nodes (a, b) with b in my node range that other ranks own
     pending = []
-    f_off = [0]
+    f_off, s_off = [0], [0]
     for c in f_recv:
         f_off.append(f_off[-1] + c)
-    foreign = torch.cat((nodes_in[: f_off[rank]], nodes_in[f_off[rank + 1]:]))
-    ho_halo_ids = foreign[:, 2].to(torch.int64).contiguous()                                      # ascending (senders hold ascending id ranges)
-    keep = torch.ones(int(f_order.numel()), dtype=torch.bool, device=dev)
-    s_off = [0]
     for c in f_send:
         s_off.append(s_off[-1] + c)
+    ids_in = nodes_in[:, 2]
+    ho_halo_ids = torch.cat((ids_in[: f_off[rank]], ids_in[f_off[rank + 1]:])).to(torch.int64)     # ascending (senders hold ascending id ranges)
     ho_send_idx = torch.cat((f_order[: s_off[rank]], f_order[s_off[rank + 1]:])).contiguous()     # my rows, grouped by the rank that gathers them
-    del keep
     ho_send = [0 if r == rank else f_send[r] for r in range(world)]
     ho_recv = [0 if r == rank else f_recv[r] for r in range(world)]
     src = ho_ei[0]
@@ -960,25 +1026,26 @@ def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
     src_local = torch.where(own, src - lo_h, n_ho_own + torch.searchsorted(ho_halo_ids, src.contiguous())) if ho_halo_ids.numel() else src - lo_h
     ho = _finish_graph_shard(torch.stack((src_local, ho_ei[1] - lo_h)), ho_w.to(torch.float32), lo_h, hi_h, n_ho, ho_cuts, ho_halo_ids, ho_send_idx,
                              ho_send, ho_recv, comm, ops, pending, unique_send=True)
+    comm.mark("build: higher-order shard + plan")
     # first-order graph: my in-edges (a -> b, b in my range) arrived sorted by a; its halo = the distinct foreign a (request round)
     fo_shard = build_graph_shard(nodes_in[:, 0].to(torch.int64), nodes_in[:, 1].to(torch.int64), nodes_in[:, 3].contiguous().view(torch.float32), n, fo_cuts,
                                  comm, ops, False, pending, src_sorted=True)
+    comm.mark("build: first-order shard + plan")
     bip, cap = _bipartite_shard(torch.arange(n_ho_own, **i64), fo_r[1], n_ho_own, fo_cuts, comm, ops, src_sorted=True)
     ops.check_plan_status(pending)
     fptr = fo_shard.plan.fwd_ptr
     indeg = (fptr[1:] - fptr[:-1]).to(torch.float32)                            # order-2 nodes (., b) per owned first-order node b
+    comm.mark("build: bipartite plan + status read-back")
     x_loc = _rows_of(x, fo_shard.local_rows())
     if callable(x_h) and _takes_count(x_h):
         x_h = x_h(n_ho)
     xh_loc = _rows_of(x_h, ho.local_rows())
-    sums = torch.tensor([e2_local, int(ho_ei.size(1))], dtype=torch.float64, device=dev)
-    comm.all_reduce_(sums)
-    e2, a2 = (int(t) for t in sums.tolist())
+    comm.mark("build: feature rows (owned + halo)")
     return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(),
                       y=_rows_of(y, None, lo_n, hi_n, dev), n_fo=n, n_ho=n_ho,
-                      sizes={"m": m, "N": n, "E2": e2, "E2_local": e2_local, "U2": n_ho, "A1": n_ho, "A2": a2, "A2_local": int(ho_ei.size(1)),
+                      sizes={"m": m, "N": n, "E2": e2, "E2_local": e2_local, "U2": n_ho, "A1": n_ho, "A2_local": int(ho_ei.size(1)),
                              "fo_cuts": fo_cuts, "ho_cuts": ho_cuts, "ev_cuts": plan["ev_cuts"], "fo_halo": fo_shard.n_halo, "ho_halo": ho.n_halo,
-                             "lift_events_local": end_e - lo_e, "layer1_events_local": int(mine.numel())})
+                             "lift_events_local": int(ss.ei_lift.size(1)), "layer1_events_local": m_l1})
 
 
 from .nn.sharded import ShardedDBGNN  # noqa: E402,F401  (historic import location)

@@ -372,13 +372,18 @@ class _ShardedTrunk(torch.autograd.Function):
                 st["pending"] = comm.exchange_rows_async(send, gs.send_counts, gs.recv_counts, out=buf[gs.n_own:])
             st["h"] = buf
 
+        mark = getattr(comm, "mark", lambda label: None)
+        mark("step: other")
         for l in range(n_layers):
             layer("ho", l)
+            mark("fwd: higher-order layers")
             if l == n_layers - 1:
                 bip = shard.bip
                 partial = ops.spmm(bip.fwd_ptr, bip.fwd_idx, bip.fwd_val, bip.n_dst, state["ho"]["h"], heavy=bip.fwd_heavy)      # [world * cap, H]
                 agg_pending = comm.reduce_scatter_rows_async(partial, shard.cap)
+                mark("fwd: bipartite sums")
             layer("fo", l)
+            mark("fwd: first-order layers")
         agg = agg_pending.wait()[: fo.n_own]
         y_fo, y_ho = state["fo"]["h"], state["ho"]["h"]
         ctx.shard, ctx.comm, ctx.ops, ctx.n_layers = shard, comm, ops, n_layers
@@ -429,10 +434,13 @@ class _ShardedTrunk(torch.autograd.Function):
             s["pending"] = (d_lin, x_in)
             s["handle"] = comm.exchange_rows_async(d_lin[gs.n_own:].contiguous(), gs.recv_counts, gs.send_counts)
 
+        mark = getattr(comm, "mark", lambda label: None)
+        mark("step: head + loss (fwd + bwd)")
         for l in range(n_layers - 1, -1, -1):
             if l < n_layers - 1:
                 finish_exchange("fo", l + 1)
             layer_backward("fo", l)
+            mark("bwd: first-order layers")
             if l == n_layers - 1:
                 d_full = full_pending.wait()
                 want = ctx.needs_input_grad[4 + 2 * n_layers + 2 * n_layers - 1]
@@ -441,6 +449,7 @@ class _ShardedTrunk(torch.autograd.Function):
             else:
                 finish_exchange("ho", l + 1)
             layer_backward("ho", l)
+            mark("bwd: higher-order layers (+ bipartite)")
         ctx.state = ctx.y_ho = None
         return (None, None, None, None, *grads_fo, *grads_ho)
 

@@ -214,7 +214,7 @@ def _stream_worker(rank, world, port, results):
             tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n, edge_weight=w)
             comm = pd.Comm()
             shard = pd.build_dbgnn_shard(tg, delta, x, x_h, y, comm, CpuOps())
-            sz = shard.sizes
+            sz = pd.global_sizes(shard, comm)
             assert sz["U2"] == n_ho and sz["A2"] == layers[2]["edge_index"].size(1) and \
                 sz["E2"] == om.temporal_lift_sorted(ei, t, delta, n).size(1)
             # De Bruijn property of the aligned cuts: every higher-order row is requested by at most one peer
@@ -286,7 +286,7 @@ def _world8_worker(rank, world, port, results):
                 asked["x_h"] += int(rows.numel())
                 return x_h.index_select(0, rows)
             shard = pd.build_dbgnn_shard(tg, delta, load_x, load_xh, lambda rows: y.index_select(0, rows), comm, CpuOps())
-            sz = shard.sizes
+            sz = pd.global_sizes(shard, comm)
             assert sz["U2"] == n_ho and sz["A2"] == layers[2]["edge_index"].size(1) and sz["E2"] == om.temporal_lift_sorted(ei, t, delta, n).size(1)
             assert asked["x"] == shard.fo.n_src and asked["x_h"] == shard.ho.n_src            # owned + halo rows, nothing else
             assert shard.ho.send_unique and (shard.ho.n_send == 0 or int(torch.bincount(shard.ho.send_idx).max()) == 1)

@@ -62,7 +62,8 @@ def _run_rank(rank, world, dev, comm, case):
     attrs = {} if w is None else {"edge_weight": w.to(dev)}
     tg = pp.TemporalGraph(pp.Data(edge_index=ei.to(dev), time=t.to(dev), num_nodes=case[2], **attrs))
     shard = pd.build_dbgnn_shard(tg, case[3], x.to(dev), x_h.to(dev), y.to(dev), comm)
-    assert shard.sizes["U2"] == layers[2]["num_nodes"] and shard.sizes["A2"] == layers[2]["edge_index"].size(1)
+    sz = pd.global_sizes(shard, comm)
+    assert sz["U2"] == layers[2]["num_nodes"] and sz["A2"] == layers[2]["edge_index"].size(1)
     if shard.ho.n_send:
         assert int(torch.bincount(shard.ho.send_idx).max()) == 1          # De Bruijn cuts: every row goes to at most one peer
     net = pp.nn.DBGNN(num_classes=3, num_features=(case[5], case[5]), hidden_dims=case[6]).to(dev)
@@ -183,7 +184,8 @@ def _world8_worker(rank, world, port, results):
             xd, xhd, yd = x.to(dev), x_h.to(dev), y.to(dev)
             shard = pd.build_dbgnn_shard(tg, delta, lambda rows: xd.index_select(0, rows), lambda rows: xhd.index_select(0, rows),
                                          lambda rows: yd.index_select(0, rows), comm)
-            assert shard.sizes["U2"] == layers[2]["num_nodes"] and shard.sizes["A2"] == layers[2]["edge_index"].size(1), kind
+            sz = pd.global_sizes(shard, comm)
+            assert sz["U2"] == layers[2]["num_nodes"] and sz["A2"] == layers[2]["edge_index"].size(1), kind
             assert shard.ho.send_unique and shard.x_h.size(0) == shard.ho.n_src and shard.x.size(0) == shard.fo.n_src
             net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=hidden).to(dev)
             net.load_state_dict(params)
