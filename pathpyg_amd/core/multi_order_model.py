@@ -267,9 +267,12 @@ class MultiOrderModel:
         g_ho = self.layers[max_order]
         n, n_ho = g.data.num_nodes, g_ho.data.num_nodes
         dev = g.data.edge_index.device
+        x_eye = x_h_eye = False
         if x is None:
+            x_eye = g.data.x is None
             x = g.data.x if g.data.x is not None else torch.eye(n, n, device=dev)
         if x_h is None:
+            x_h_eye = True
             x_h = torch.eye(n_ho, n_ho, device=g_ho.data.edge_index.device)
         out = Data(
             num_nodes=n,
@@ -288,6 +291,8 @@ class MultiOrderModel:
             # the hints describe exactly these tensor objects at these in-place versions; DBGNN.forward ignores them otherwise
             "stamp": tuple((t, t._version) for t in (out.edge_index, out.edge_weights, out.edge_index_higher_order,
                                                      out.edge_weights_higher_order, out.bipartite_edge_index) if t is not None),
+            # the default one-hot features: DBGNN's first layers then read W^T through the CSR instead of multiplying by an n x n identity
+            "x_eye": (out.x, out.x._version) if x_eye else None, "x_h_eye": (out.x_h, out.x_h._version) if x_h_eye else None,
             "rows_sorted": True, "bipartite_sources_sorted": mapping in ("last", "first"),
             # temporal models: the order-2 nodes ARE the first-order graph's edges, in its edge order (_LiftChain.to_second_order) -
             # DBGNN.forward then derives the "last" bipartite plan from the first-order plan's destination grouping, no extra sort

@@ -12,8 +12,10 @@ so reference checkpoints load unchanged.  What differs is the execution: each gr
 computed once and cached on the ``data`` object (PyG recomputes it on every call), every propagation is an
 atomics-free CSR segment reduction, a whole GCN layer (aggregation + the dense product on ``v_mfma_f32_16x16x4_f32`` +
 bias + ELU) is ONE hand-written kernel for layer widths 16/32/64/128/256 (``csrc/pp_gcn_fused.hip``, ``csrc/pp_gcn_wide.hip``), and
-the backward pass runs the same structure over the transposed CSR.  No library GEMM is called for those widths; other
-widths fall back to ``torch.nn.functional.linear`` + the CSR kernel.  All tensors must live on the GPU; fp32 only.
+the backward pass runs the same structure over the transposed CSR.  No library GEMM is called for ANY width: widths without a kernel of
+their own are zero-padded to the next kernel width (<= 256) or split into 256-wide blocks (:func:`dense_w`), and the reference's default
+one-hot features (``torch.eye``, multi_order_model.py:532-533) never meet a GEMM at all — ``I W^T`` is ``W^T``, the first layer is one CSR
+segment reduction over the rows of ``W^T``.  All tensors must live on the GPU; fp32 only.
 """
 from __future__ import annotations
 
@@ -78,10 +80,10 @@ class _Dense(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias, ctx.fuse_act, ctx.has_act_bias = bias is not None, fuse_act, act_bias is not None
         kind = _hip.dense_supported(weight.size(1), weight.size(0))
-        ctx.fast, ctx.one_pass = kind > 0, kind == 1
-        if ctx.fast:
-            return _hip.dense(x, weight, True, bias)[0]
-        return F.linear(x, weight, bias)
+        if kind == 0:
+            raise ValueError(f"_Dense: no kernel for a {weight.size(1)} -> {weight.size(0)} layer (use dense_w, which pads / blocks such widths)")
+        ctx.one_pass = kind == 1
+        return _hip.dense(x, weight, True, bias)[0]
 
     @staticmethod
     def backward(ctx, dy):
@@ -96,12 +98,9 @@ class _Dense(torch.autograd.Function):
             return dx, dw, db, None, dact
         if ctx.needs_input_grad[0]:
             if ctx.fuse_act:
-                if ctx.fast:
-                    dx, dact = _hip.dense(dy, weight, False, None, grad_act=x, want_colsum=want_sum)
-                else:
-                    dx, dact = _hip.act_backward(dy @ weight, x, True, want_dpre=True, want_dbias=want_sum)
+                dx, dact = _hip.dense(dy, weight, False, None, grad_act=x, want_colsum=want_sum)
             else:
-                dx = _hip.dense(dy, weight, False)[0] if ctx.fast else dy @ weight
+                dx = _hip.dense(dy, weight, False)[0]
         if need_w:
             dw, db = _hip.weight_grad(dy, x, want_bias=ctx.has_bias)
         return dx, dw, db, None, dact
@@ -267,9 +266,50 @@ def _draw_seed() -> int:
 TAG_FO, TAG_FO_OUT, TAG_HO, TAG_HO_OUT, TAG_HEAD = 0, 32, 64, 96, 128
 
 
+_KERNEL_WIDTHS = (16, 32, 64, 128, 256)
+
+
+def _kernel_shape(p: int, q: int) -> tuple[int, int]:
+    """Smallest (P', Q') >= (p, q) the dense kernels take (both <= 256)."""
+    pp_, qq = next(c for c in _KERNEL_WIDTHS if c >= p), next(c for c in _KERNEL_WIDTHS if c >= q)
+    if not _hip.dense_supported(pp_, qq):              # e.g. 32 x 256: too large for the register-resident form, too narrow for the streamed one
+        pp_, qq = max(pp_, 64), max(qq, 64)
+    return pp_, qq
+
+
+def dense_w(x: torch.Tensor, weight: torch.Tensor, bias=None, fuse_act: bool = False, act_bias=None) -> torch.Tensor:
+    """``x @ weight.T + bias`` on the hand-written MFMA kernels for EVERY width (no library GEMM):
+
+    * widths with a kernel (``_hip.dense_supported``): :class:`_Dense` directly;
+    * other widths up to 256 (e.g. 100 -> 100, 20 -> 128): input, weight and bias are zero-padded to the next kernel widths and the
+      result is sliced — the padded output columns are exactly 0 (bias 0, ELU' of a stored 0 is 1 and their gradient is sliced away);
+    * wider layers (e.g. 300 -> 16): 256-wide blocks of the input / output widths, partial products summed.
+
+    The padding and blocking are ordinary autograd ops around the kernels.  ``fuse_act`` / ``act_bias``: the contract of :class:`_Dense`."""
+    q, p = weight.shape
+    if _hip.dense_supported(p, q):
+        return _Dense.apply(x, weight, bias, fuse_act, act_bias)
+    if p <= 256 and q <= 256:
+        pp_, qq = _kernel_shape(p, q)
+        y = _Dense.apply(F.pad(x, (0, pp_ - p)), F.pad(weight, (0, pp_ - p, 0, qq - q)), None if bias is None else F.pad(bias, (0, qq - q)), fuse_act,
+                         None if act_bias is None else F.pad(act_bias, (0, pp_ - p)))
+        return y[:, :q].contiguous() if qq != q else y
+    if fuse_act:                   # the blocks below read slices of x: settle the activation contract of its producer first (one pass)
+        x = _ActBoundary.apply(x, act_bias)
+    cols = []
+    for q0 in range(0, q, 256):
+        acc = None
+        for p0 in range(0, p, 256):
+            part = dense_w(x[:, p0: p0 + 256].contiguous(), weight[q0: q0 + 256, p0: p0 + 256].contiguous(),
+                           bias[q0: q0 + 256] if (bias is not None and p0 == 0) else None)
+            acc = part if acc is None else acc + part
+        cols.append(acc)
+    return cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
+
+
 def dense(x, linear: Linear, fuse_act: bool = False, act_bias=None):
     if x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda:
-        return _Dense.apply(x, linear.weight, linear.bias, fuse_act, act_bias)
+        return dense_w(x, linear.weight, linear.bias, fuse_act, act_bias)
     return linear(x)
 
 
@@ -355,6 +395,15 @@ def _valid_hints(data) -> dict:
     if not _stamp_matches(hints.get("stamp", ()), [getattr(data, n, None) for n in names]):
         return {}
     return hints
+
+
+def _is_hinted_eye(data, name: str) -> bool:
+    """``data.x`` / ``data.x_h`` is the identity matrix ``MultiOrderModel.to_dbgnn_data`` created (its own stamp: assigning other features
+    later leaves the other hints alone)."""
+    hints = getattr(data, "_pp_hints", None) or {}
+    stamp = hints.get(name + "_eye")
+    t = getattr(data, name, None)
+    return stamp is not None and t is not None and stamp[0] is t and stamp[1] == t._version
 
 
 class GCNConv(Module):
@@ -482,7 +531,7 @@ class DBGNN(Module):
                 else:
                     agg = _Aggregate.apply(plan_bi, x_h)
                 per_edge = dense(x, bl.lin2) + bl.lin1.bias
-                x = F.elu(torch.addcmul(_Dense.apply(agg, bl.lin1.weight, None, False, None), plan_bi.self_coef.unsqueeze(1), per_edge))
+                x = F.elu(torch.addcmul(dense_w(agg, bl.lin1.weight), plan_bi.self_coef.unsqueeze(1), per_edge))
             else:
                 x_h, _ = stack_drop(self.higher_order_layers, x_h, plan_ho, TAG_HO, TAG_HO_OUT)
                 x = self.bipartite_layer((x_h, x), data.bipartite_edge_index, n_ho=n_ho, n_fo=n_fo, plan=plan_bi, activation=True)
@@ -490,10 +539,15 @@ class DBGNN(Module):
 
         # No dropout between an activation and the dense layer that consumes it: every ELU backward is fused into the
         # epilogue of that dense layer's input-gradient GEMM (see _Dense / _Propagate.grad_is_pre).
-        def stack(layers, h, plan):
+        def stack(layers, h, plan, one_hot=False):
             below = None                                            # bias of the layer whose activation `h` is
             for i, layer in enumerate(layers):
-                if _GcnLayer.supported(plan, h, layer.lin.weight):
+                if i == 0 and one_hot and h.size(0) == h.size(1) == layer.lin.weight.size(1):
+                    # h is the identity (the reference's default features, multi_order_model.py:532-533): I W^T = W^T, so the layer is
+                    # ELU(A_hat W^T + b) — one CSR segment reduction over the rows of W^T, no n x n matrix product; its backward pass
+                    # (A_hat^T dpre) is the gradient of W^T
+                    h = _Propagate.apply(plan, layer.lin.weight.t().contiguous(), None, layer.bias, True, True)
+                elif _GcnLayer.supported(plan, h, layer.lin.weight):
                     h = _GcnLayer.apply(plan, h, layer.lin.weight, layer.bias, i > 0, below)
                 else:
                     t = dense(h, layer.lin, fuse_act=i > 0, act_bias=below)
@@ -501,8 +555,8 @@ class DBGNN(Module):
                 below = layer.bias
             return h, below
 
-        x, bias_fo = stack(self.first_order_layers, x, plan_fo)
-        x_h, bias_ho = stack(self.higher_order_layers, x_h, plan_ho)
+        x, bias_fo = stack(self.first_order_layers, x, plan_fo, _is_hinted_eye(data, "x"))
+        x_h, bias_ho = stack(self.higher_order_layers, x_h, plan_ho, _is_hinted_eye(data, "x_h"))
         bl = self.bipartite_layer
         if plan_bi.fwd_val is None and x_h.size(1) % 4 == 0 and x_h.size(1) <= 256:
             # sum_j (W1 x_h[j] + b1) = W1 (sum_j x_h[j]) + deg * b1: aggregate the U higher-order rows FIRST (one gather pass over
@@ -511,7 +565,7 @@ class DBGNN(Module):
             agg = _AggregateAct.apply(plan_bi, x_h, bias_ho)
             per_edge = dense(x, bl.lin2, True, bias_fo) + bl.lin1.bias
             # (dense(): its weight gradients contract over all N rows on the MFMA kernel; the library GEMM is 4x slower there)
-            x = F.elu(torch.addcmul(_Dense.apply(agg, bl.lin1.weight, None, False, None), plan_bi.self_coef.unsqueeze(1), per_edge))
+            x = F.elu(torch.addcmul(dense_w(agg, bl.lin1.weight), plan_bi.self_coef.unsqueeze(1), per_edge))
             return dense(x, self.lin)
         x = _Propagate.apply(plan_bi, dense(x_h, bl.lin1, True, bias_ho), dense(x, bl.lin2, True, bias_fo), None, True, True)
         return dense(x, self.lin, True, None)

@@ -79,7 +79,9 @@ class HipOps:
                                    heavy=plan.fwd_heavy, out=out, drop=drop if in_kernel else None)
             saved = res[1] if want_agg else None
         else:
-            t = F.linear(x_full, weight)                               # widths without a fused kernel: library GEMM + CSR kernel
+            with torch.no_grad():                                      # widths without a fused layer kernel: padded / blocked dense kernel + CSR kernel
+                from .dbgnn import dense_w
+                t = dense_w(x_full, weight)
             out.copy_(_hip.spmm(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, plan.n_dst, t, plan.self_coef, t, bias, True, heavy=plan.fwd_heavy))
             saved = None
         if drop is not None and not in_kernel:
@@ -111,7 +113,9 @@ class HipOps:
         dw = _hip.weight_grad(g, x_full, want_bias=False)[0]
         if not need_input_grad:
             return None, None, dw
-        d_lin = g @ weight
+        with torch.no_grad():
+            from .dbgnn import dense_w
+            d_lin = dense_w(g, weight.t().contiguous())
         if fuse:
             d_lin, colsum = _hip.act_backward(d_lin, fuse_below, True, want_dpre=True, want_dbias=True)
             return d_lin, colsum, dw
@@ -154,8 +158,8 @@ class HipOps:
 
     @staticmethod
     def dense_nobias(x, weight):
-        from .dbgnn import _Dense
-        return _Dense.apply(x, weight, None, False, None)
+        from .dbgnn import dense_w
+        return dense_w(x, weight)
 
     @staticmethod
     def cross_entropy_mean(logits, target):

@@ -83,6 +83,69 @@ def test_dbgnn_forward_backward_matches_oracle(pp, seed, n, e, n_ho, e_ho, f, hi
     assert torch.equal(out2, out)
 
 
+def test_baseline_config0_one_hot_dbgnn_matches_oracle_without_a_library_gemm(pp):
+    """BASELINE configs[0]: 100 walks of 5 nodes over a 20-node alphabet, k = 2 De Bruijn model, DBGNN with the reference's
+    DEFAULT one-hot features (``to_dbgnn_data()`` without x / x_h: torch.eye, multi_order_model.py:532-533), num_features = (20, U_2),
+    hidden_dims [16, 32, 8], 2 classes — forward, loss and every gradient against the oracle (which multiplies by the identity for real);
+    and no rocBLAS / hipBLASLt kernel in the step (the first layers read W^T through the CSR)."""
+    from oracle import dbgnn as od
+    gen = torch.Generator().manual_seed(0)
+    walks = torch.randint(0, 20, (100, 5), generator=gen)
+    paths = pp.PathData(pp.IndexMap([str(i) for i in range(20)]), device=DEV)
+    paths.append_walks([tuple(str(int(v)) for v in row) for row in walks], weights=[1.0] * 100)
+    mom = pp.MultiOrderModel.from_path_data(paths, max_order=2)
+    data = mom.to_dbgnn_data(max_order=2, mapping="last")
+    n, n_ho = mom.layers[1].n, mom.layers[2].n
+    assert tuple(data.x.shape) == (n, n) and tuple(data.x_h.shape) == (n_ho, n_ho) and torch.equal(data.x_h, torch.eye(n_ho, device=DEV))
+    y = torch.randint(0, 2, (n,), generator=gen)
+    hidden = [16, 32, 8]
+    params = od.init_params(2, (n, n_ho), hidden, seed=1)
+    cpu_data = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in data.to_dict().items()}
+    want_out, want_loss, want_grads = od.loss_and_grads(params, cpu_data, y)
+    model = pp.nn.DBGNN(num_classes=2, num_features=(n, n_ho), hidden_dims=hidden).to(DEV)
+    model.load_state_dict(params)
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA, torch.profiler.ProfilerActivity.CPU]) as prof:
+        out = model(data)
+        loss = F.cross_entropy(out, y.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+    torch.testing.assert_close(out.detach().cpu(), want_out, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(loss.detach().cpu(), want_loss, rtol=RTOL, atol=ATOL)
+    for name, prm in model.named_parameters():
+        scale = float(want_grads[name].abs().max()) + 1e-12
+        torch.testing.assert_close(prm.grad.cpu(), want_grads[name], rtol=RTOL * 10, atol=max(ATOL, 2e-5 * scale), msg=lambda s_: f"{name}: {s_}")
+    names = [e.key for e in prof.key_averages()]
+    assert not [k for k in names if "Cijk" in k or "gemm" in k.lower() or "addmm" in k.lower() or "aten::mm" in k], names
+    # features assigned afterwards are no longer the identity: the hint must not survive
+    data.x_h = torch.eye(n_ho, device=DEV) * 2.0
+    out2 = model(data)
+    cpu_data["x_h"] = torch.eye(n_ho) * 2.0
+    torch.testing.assert_close(out2.detach().cpu(), od.forward(params, cpu_data), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("f,hidden", [((100, 100), [100, 72, 40]), ((300, 20), [16, 32, 8]), ((20, 128), [96, 200, 130]), ((7, 520), [300, 24, 5])])
+def test_dbgnn_widths_without_a_kernel_of_their_own_are_padded_or_blocked(pp, f, hidden):
+    """Layer widths outside {<= 64, 64, 128, 256}: zero-padded to the next kernel width or split into 256-wide blocks (nn.dbgnn.dense_w) —
+    same numbers as the oracle, still no library GEMM."""
+    from oracle import dbgnn as od
+    data, y = _bundle(21, 150, 1200, 400, 1500, f, "last")
+    params = od.init_params(3, f, hidden, seed=3)
+    want_out, want_loss, want_grads = od.loss_and_grads(params, data, y)
+    model = _to_module(pp, params, 3, f, hidden)
+    gdata = pp.Data(**{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in data.items()})
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA, torch.profiler.ProfilerActivity.CPU]) as prof:
+        out = model(gdata)
+        loss = F.cross_entropy(out, y.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+    torch.testing.assert_close(out.detach().cpu(), want_out, rtol=RTOL, atol=ATOL)
+    for name, prm in model.named_parameters():
+        scale = float(want_grads[name].abs().max()) + 1e-12
+        torch.testing.assert_close(prm.grad.cpu(), want_grads[name], rtol=RTOL * 10, atol=max(ATOL, 2e-5 * scale), msg=lambda s_: f"{name}: {s_}")
+    names = [e.key for e in prof.key_averages()]
+    assert not [k for k in names if "Cijk" in k or "gemm" in k.lower() or "addmm" in k.lower() or "aten::mm" in k], names
+
+
 def test_gcn_conv_layer_alone_with_self_loops_and_isolated_nodes(pp):
     from oracle import dbgnn as od
     ei = torch.tensor([[0, 0, 1, 3, 3], [0, 1, 0, 3, 1]])          # node 2 and 4 isolated; loops on 0 and 3
