@@ -689,6 +689,10 @@ def spmm(ptr, idx, val, n_rows: int, x: torch.Tensor, self_coef=None, s=None, bi
     if x.dtype != torch.float32:
         raise TypeError("DBGNN kernels are fp32")
     f = x.size(1)
+    if f > 256:          # the row kernels own at most 64 lanes x 4 columns per row: wider matrices go through in 256-column blocks
+        blocks = [spmm(ptr, idx, val, n_rows, x[:, c: c + 256], self_coef, None if s is None else s[:, c: c + 256],
+                       None if bias is None else bias[c: c + 256], act, heavy) for c in range(0, f, 256)]
+        return torch.cat(blocks, dim=1)
     if s is not None:
         s = s.contiguous()
     if bias is not None:

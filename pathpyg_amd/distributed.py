@@ -911,8 +911,9 @@ def distribute_stream(g, delta, comm: Comm, ops=None, weight: str = "edge_weight
     ei = _dispatch.plain(data.edge_index)
     w_all = data[weight] if weight in data else None
     stamp = (comm.world, comm.rank, repr(delta), tuple((t_, t_._version) for t_ in (data.edge_index, data.time, w_all) if t_ is not None))
-    cached = getattr(g, "_pp_stream_shard", None)
-    if cached is not None and len(cached.stamp) == len(stamp) and cached.stamp[:3] == stamp[:3] and \
+    cache = getattr(g, "_pp_stream_shards", None)           # {(world, rank): shard} — emulated ranks share the graph object
+    cached = cache.get((comm.world, comm.rank)) if isinstance(cache, dict) else None
+    if cached is not None and len(cached.stamp) == len(stamp) and cached.stamp[:3] == stamp[:3] and len(cached.stamp[3]) == len(stamp[3]) and \
             all(a is b and va == vb for (a, va), (b, vb) in zip(cached.stamp[3], stamp[3])):
         return cached
     rank, world = comm.rank, comm.world
@@ -938,7 +939,10 @@ def distribute_stream(g, delta, comm: Comm, ops=None, weight: str = "edge_weight
                         n_own_lift=hi_e - lo_e, slot=(q * cap_m + (k - ptr_t[q])).contiguous(), slot_owner=q.contiguous(), cap_n=cap_n, cap_m=cap_m,
                         stamp=stamp, delta=delta)
     try:
-        object.__setattr__(g, "_pp_stream_shard", shard)
+        if not isinstance(cache, dict):
+            cache = {}
+            object.__setattr__(g, "_pp_stream_shards", cache)
+        cache[(comm.world, comm.rank)] = shard
     except Exception:          # exotic containers: no caching, still correct
         pass
     return shard
