@@ -130,7 +130,8 @@ int pp_unique_rows_fill(const int64_t* rows, int64_t n_rows, int k, int64_t n_un
 
 /* coalesce(remap[edge_index], edge_attr, num_nodes, reduce), src/pathpyG/algorithms/lift_order.py:135-144.
  * remap may be NULL (edges already hold node ids).  _count -> {A, status}; _fill writes out_index [2,A]
- * sorted by (row, col) and the reduced weights (weight may be NULL).
+ * sorted by (row, col) and the reduced weights (weight may be NULL; weight NULL with out_weight given = UNIT weights, the reference's
+ * default `torch.ones` (lift_order.py:130-131): out_weight = run length for sum, 1 otherwise, in `dtype`, without the per-instance gather).
  * col_base [num_nodes] / col_bits (NULL / 0 = off; pass the same pair to _count and _fill): the caller knows that every column of row r
  * lies in [col_base[r], col_base[r] + 2^col_bits) - true for De Bruijn layers, where the successors of a node form one
  * contiguous id block - and the sort key shrinks from 2*bits(num_nodes) to bits(num_nodes) + col_bits bits (fewer radix passes);
@@ -173,7 +174,8 @@ int pp_gather_events(const int64_t* edge_index, const void* time, const int64_t*
  *   self_coef[i] = d[i]^2 * (weight of node i's self loop, 1 if it had none); existing self-loop edges get norm 0.
  * edge_weight may be NULL (all ones).  row_sorted != 0: the caller guarantees edge_index[0] is non-decreasing (every Graph's
  * edge index is, graph.py:103) and the source-major grouping reuses the edge order instead of sorting.
- * pp_plan_result_ptr(ws)[1] = status (bit 0: index out of range). */
+ * pp_plan_result_ptr(ws)[1] = status (bit 0: index out of range); [2] / [3] = longest row of the destination-major / source-major CSR (plans
+ * with rows above a few hundred entries want pp_spmm_heavy_f32's chunk tables) — written by every plan builder below, one read-back for all. */
 size_t pp_gcn_plan_ws_bytes(int64_t n_edges, int64_t n_nodes);
 int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int row_sorted, int32_t* in_ptr,
                 int32_t* in_idx, float* in_val, int32_t* out_ptr, int32_t* out_idx, float* out_val, float* self_coef, int32_t* dst_order,

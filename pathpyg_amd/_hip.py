@@ -303,21 +303,28 @@ def unique_rows(rows: torch.Tensor, value_range: tuple[int, int] | None = None):
     return uniq, inverse
 
 
-def coalesce(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: int, reduce: str = "sum",
+UNIT = "unit"           # `weight=UNIT`: every instance edge weighs 1.0 (the reference's default torch.ones) without materialising the vector
+
+
+def coalesce(edge_index: torch.Tensor, weight, num_nodes: int, reduce: str = "sum",
              remap: torch.Tensor | None = None, want_inverse: bool = False, col_block: tuple | None = None):
     """PyG ``coalesce`` of ``remap[edge_index]`` (or ``edge_index``): (row, col)-sorted distinct edges + reduced weights.
+    ``weight``: a vector, ``None`` (no weights) or :data:`UNIT` (float32 ones: the merged weight is the run length, no gather).
     ``want_inverse`` additionally returns, per input edge, the index of the merged edge it went into.
     ``col_block = (col_base [num_nodes] int64, col_bits)``: every column of row r lies in ``[col_base[r], col_base[r] + 2**col_bits)``
     (De Bruijn layers): shorter sort keys, same result."""
     return _drive(coalesce_steps(edge_index, weight, num_nodes, reduce, remap, want_inverse, col_block))
 
 
-def coalesce_steps(edge_index: torch.Tensor, weight: torch.Tensor | None, num_nodes: int, reduce: str = "sum",
+def coalesce_steps(edge_index: torch.Tensor, weight, num_nodes: int, reduce: str = "sum",
                    remap: torch.Tensor | None = None, want_inverse: bool = False, col_block: tuple | None = None):
     """:func:`coalesce` as a count -> fill generator for :func:`run_together`."""
     if reduce not in _REDUCE:
         raise ValueError(f"unknown reduce {reduce}")
     ei = _edge_index(edge_index)
+    unit = isinstance(weight, str) and weight == UNIT
+    if unit:
+        weight = None
     dev = require_device(ei, weight, remap)
     e = ei.size(1)
     if weight is not None:
@@ -342,7 +349,8 @@ def coalesce_steps(edge_index: torch.Tensor, weight: torch.Tensor | None, num_no
     _bad_index(status, "aggregate_edge_index (an edge refers to a node id >= number of distinct nodes)", ValueError)
     with torch.cuda.device(dev):
         out_index = torch.empty((2, n_out), dtype=torch.int64, device=dev)
-        out_weight = None if weight is None else torch.empty(n_out, dtype=weight.dtype, device=dev)
+        out_weight = (torch.empty(n_out, dtype=torch.float32, device=dev) if unit else None) if weight is None else \
+            torch.empty(n_out, dtype=weight.dtype, device=dev)
         check(L.pp_coalesce_fill(_p(weight), 2 if weight is None else _DTYPE_CODE[weight.dtype], _REDUCE[reduce], e, n_out, num_nodes,
                                  _p(col_base), col_bits, _p(out_index), _p(out_weight), _p(ws), ws.numel(), _stream()), "pp_coalesce_fill")
         if want_inverse:
@@ -475,7 +483,7 @@ class CsrPlan:
     """CSR pair of one propagation: ``fwd`` rows are the destinations, ``bwd`` rows the sources (transposed)."""
 
     __slots__ = ("n_dst", "n_src", "fwd_ptr", "fwd_idx", "fwd_val", "bwd_ptr", "bwd_idx", "bwd_val", "self_coef", "fwd_heavy", "bwd_heavy",
-                 "dst_order")
+                 "dst_order", "edge_ordered")          # edge_ordered: bwd_idx[e] is the destination of edge e (plan of a row-sorted edge list)
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -528,28 +536,27 @@ def _heavy_args(heavy: "HeavyRows | None", idx, val, x):
     return heavy.slot, heavy.aggregate(idx, val, x.contiguous())
 
 
-def _plan_row_lengths(plan: "CsrPlan") -> torch.Tensor:
-    """Device int64 [2]: longest forward / backward CSR row of a plan (two tiny launches, read with the plan status)."""
-    with torch.cuda.device(plan.fwd_ptr.device):
-        out = torch.empty(2, dtype=torch.int64, device=plan.fwd_ptr.device)
-        check(lib().pp_max_row_length_i32(_p(plan.fwd_ptr), plan.n_dst, _p(out), _stream()), "pp_max_row_length_i32")
-        check(lib().pp_max_row_length_i32(_p(plan.bwd_ptr), plan.n_src, out.data_ptr() + 8, _stream()), "pp_max_row_length_i32")
-    return out
+def _plan_report(ws: torch.Tensor) -> torch.Tensor:
+    """Device int64 [3] = {status bits, longest forward row, longest backward row} of the plan a builder just queued on workspace ``ws``
+    (pp_plan_result_ptr(ws)[1..3]: the kernels of the plan report the row lengths themselves, no extra launches)."""
+    return ws[8:32].view(torch.int64).clone()
 
 
-def _finish_plans(entries: list, what: str) -> None:
+def _finish_plans(entries: list, what: str) -> list:
     """ONE device-to-host copy for everything the host must know about freshly built plans: the bad-index status and the longest
-    rows (hub rows get their chunk tables here — the rare path, a few torch ops)."""
+    rows (hub rows get their chunk tables here — the rare path, a few torch ops).  Returns ``[(status, longest forward row, longest
+    backward row)]`` per plan."""
     if not entries:
-        return
-    host = torch.cat([torch.cat((status, lengths)) for status, _, lengths in entries]).tolist()
+        return []
+    host = (entries[0][0] if len(entries) == 1 else torch.cat([report for report, _ in entries])).tolist()
     if any(int(host[3 * k]) & 1 for k in range(len(entries))):
         raise IndexError(f"{what}: node index out of range")
-    for k, (_, plan, _) in enumerate(entries):
+    for k, (_, plan) in enumerate(entries):
         if host[3 * k + 1] > HEAVY_ROW_ENTRIES:
             plan.fwd_heavy = HeavyRows(plan.fwd_ptr, plan.n_dst)
         if host[3 * k + 2] > HEAVY_ROW_ENTRIES:
             plan.bwd_heavy = HeavyRows(plan.bwd_ptr, plan.n_src)
+    return [tuple(int(v) for v in host[3 * k: 3 * k + 3]) for k in range(len(entries))]
 
 
 def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nodes: int, row_sorted: bool | None = None,
@@ -580,7 +587,8 @@ def gcn_plan(edge_index: torch.Tensor, edge_weight: torch.Tensor | None, num_nod
             plan.dst_order = torch.empty(e, **i32)
         check(L.pp_gcn_plan(_p(ei), _p(edge_weight), e, num_nodes, 1 if row_sorted else 0, _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val), _p(plan.bwd_ptr),
                             _p(plan.bwd_idx), _p(plan.bwd_val), _p(plan.self_coef), _p(plan.dst_order), _p(ws), ws.numel(), _stream()), "pp_gcn_plan")
-        entry = (ws[8:16].view(torch.int64).clone(), plan, _plan_row_lengths(plan))
+        plan.edge_ordered = bool(row_sorted)
+        entry = (_plan_report(ws), plan)
         if status_out is None:
             _finish_plans([entry], "GCNConv")
         else:
@@ -621,7 +629,7 @@ def gcn_plan_partition(edge_index_local: torch.Tensor, edge_weight: torch.Tensor
             dinv[n_dst:] = halo_dinv(dinv[:n_dst])
         check(L.pp_gcn_plan_finish(_p(ei), _p(edge_weight), e, n_src, n_dst, rs, _p(dinv), _p(plan.fwd_idx), _p(plan.fwd_val), _p(plan.bwd_ptr),
                                    _p(plan.bwd_idx), _p(plan.bwd_val), _p(ws), ws.numel(), _stream()), "pp_gcn_plan_finish")
-        entry = (ws[8:16].view(torch.int64).clone(), plan, _plan_row_lengths(plan))
+        entry = (_plan_report(ws), plan)
         if status_out is None:
             _finish_plans([entry], "GCNConv (partition)")
         else:
@@ -635,16 +643,19 @@ def bipartite_plan_from_edge_grouping(plan_fo: CsrPlan, edge_dst: torch.Tensor, 
     first-order GCN plan already holds (``gcn_plan(..., want_dst_order=True)``).  ``edge_dst`` = ``edge_index[1]`` of that graph."""
     dev = plan_fo.fwd_ptr.device
     ptr = plan_fo.fwd_ptr
+    # (the plan of a row-sorted edge list already holds the destinations in edge order as its source-major index: no int32 copy)
+    bwd_idx = plan_fo.bwd_idx if plan_fo.edge_ordered else edge_dst.to(torch.int32).contiguous()
     plan = CsrPlan(n_dst=plan_fo.n_dst, n_src=n_ho, fwd_ptr=ptr, fwd_idx=plan_fo.dst_order, fwd_val=None,
-                   bwd_ptr=torch.arange(n_ho + 1, dtype=torch.int32, device=dev), bwd_idx=edge_dst.to(torch.int32).contiguous(), bwd_val=None,
+                   bwd_ptr=torch.arange(n_ho + 1, dtype=torch.int32, device=dev), bwd_idx=bwd_idx, bwd_val=None,
                    self_coef=(ptr[1:] - ptr[:-1]).to(torch.float32))
     plan.fwd_heavy = plan_fo.fwd_heavy              # same row pointers: the same hub rows
     return plan
 
 
-def check_plan_status(entries: list, what: str = "DBGNN") -> None:
-    """One device-to-host copy for the status words (and longest rows) collected by several plan builders."""
-    _finish_plans(entries, what)
+def check_plan_status(entries: list, what: str = "DBGNN") -> list:
+    """One device-to-host copy for the status words (and longest rows) collected by several plan builders; returns
+    ``[(status, longest forward row, longest backward row)]``."""
+    return _finish_plans(entries, what)
 
 
 def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_value: torch.Tensor | None = None,
@@ -672,7 +683,7 @@ def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_val
         check(L.pp_bipartite_plan(_p(bi), nb, n_ho, n_fo, 1 if src_sorted else 0, _p(pair_value), _p(plan.fwd_ptr), _p(plan.fwd_idx), _p(plan.fwd_val),
                                   _p(plan.self_coef), _p(plan.bwd_ptr), _p(plan.bwd_idx), _p(plan.bwd_val), _p(ws), ws.numel(), _stream()),
               "pp_bipartite_plan")
-        entry = (ws[8:16].view(torch.int64).clone(), plan, _plan_row_lengths(plan))
+        entry = (_plan_report(ws), plan)
         if status_out is None:
             _finish_plans([entry], "BipartiteGraphOperator")
         else:

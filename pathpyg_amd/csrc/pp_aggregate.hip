@@ -186,7 +186,10 @@ __global__ __launch_bounds__(kBlock) void k_coalesce_fill(const KeyT* __restrict
         out_index[a] = row;
         out_index[n_out + a] = (int64_t)(key & ((1ull << shift) - 1ull)) + (col_base ? col_base[row] : 0);
     }
-    if (!weight) return;
+    if (!weight) {          // unit weights (the reference's default, lift_order.py:130-131): sum = run length, mean / min / max = 1 - no gather
+        if (out_weight != nullptr && live) out_weight[a] = reduce == PP_REDUCE_SUM ? (T)(p1 - p0) : (T)1;
+        return;
+    }
     // A run of thousands of parallel edges (one node pair carrying a large share of a contact stream) is not walked by its lane
     // alone (~1 us per entry): it is queued for k_coalesce_long_runs, a workgroup per run.
     const uint32_t len = p1 - p0;

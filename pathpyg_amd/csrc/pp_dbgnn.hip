@@ -68,24 +68,48 @@ __global__ __launch_bounds__(kBlock) void k_plan_edges(const int64_t* __restrict
     dst_keys[e] = (uint32_t)c;
 }
 
-// destination-grouped copies: in_idx[p] = source of the p-th incoming edge, w_by_dst[p] = its weight
-__global__ __launch_bounds__(kBlock) void k_gather_by_dst(const uint2* __restrict__ packed, int64_t n_edges, const uint32_t* __restrict__ order,
-                                                         int32_t* __restrict__ in_idx, float* __restrict__ w_by_dst) {
+// destination grouping in ONE pass over the sorted keys: in_ptr (gap fill between neighbouring keys), in_idx[p] = source of the p-th incoming
+// edge, w_by_dst[p] = its weight, dst_order[p] = its edge id (three launches and a second read of the sorted keys before)
+__global__ __launch_bounds__(kBlock) void k_group_by_dst(const uint2* __restrict__ packed, int64_t n_edges, const uint32_t* __restrict__ order,
+                                                        const uint32_t* __restrict__ sorted_keys, int64_t n_dst, int32_t* __restrict__ in_ptr,
+                                                        int32_t* __restrict__ in_idx, float* __restrict__ w_by_dst, int32_t* __restrict__ dst_order) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (p >= n_edges) return;
-    const uint2 sw = packed[order[p]];
+    if (p > n_edges) return;
+    {
+        const int64_t a = p == 0 ? -1 : (int64_t)sorted_keys[p - 1];
+        int64_t b = p == n_edges ? n_dst : (int64_t)sorted_keys[p];
+        if (b > n_dst) b = n_dst;
+        for (int64_t v = a + 1; v <= b; ++v) in_ptr[v] = (int32_t)p;
+    }
+    if (p == n_edges) return;
+    const uint32_t e = order[p];
+    const uint2 sw = packed[e];
     in_idx[p] = (int32_t)sw.x;
     w_by_dst[p] = __uint_as_float(sw.y);
+    if (dst_order) dst_order[p] = (int32_t)e;
 }
 
 // weighted in-degree from the destination-grouped (contiguous) weights; existing self loops are replaced by ONE loop
 __global__ __launch_bounds__(kBlock) void k_gcn_degree_grouped(const int32_t* __restrict__ in_idx, const float* __restrict__ w_by_dst,
                                                               const uint32_t* __restrict__ dst_ptr, const int32_t* __restrict__ last_loop,
                                                               const float* __restrict__ w, int64_t n_nodes, float* __restrict__ dinv,
-                                                              float* __restrict__ self_coef) {
+                                                              float* __restrict__ self_coef, const int32_t* __restrict__ src_ptr, int64_t n_src,
+                                                              int64_t* __restrict__ longest) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < n_nodes;
     const uint32_t p0 = live ? dst_ptr[i] : 0u, p1 = live ? dst_ptr[i + 1] : 0u;
+    {   // longest[0] / longest[1]: longest destination / source row (hub rows get chunk tables, pp_spmm_heavy_f32); the grid covers
+        // max(n_nodes, n_src) rows; src_ptr == nullptr: the source grouping does not exist yet (pp_gcn_plan_finish reports it)
+        int len_fwd = (int)(p1 - p0), len_bwd = (src_ptr != nullptr && i < n_src) ? src_ptr[i + 1] - src_ptr[i] : 0;
+        len_fwd = wave_max(len_fwd);
+        len_bwd = wave_max(len_bwd);
+        // (a wave only queues an atomic when it beats the maximum it can already see: ~1.6e5 atomics on one word cost more than the kernel)
+        if (lane_id() == 0) {
+            const volatile int64_t* seen = longest;
+            if ((int64_t)len_fwd > seen[0]) atomicMax((unsigned long long*)longest, (unsigned long long)len_fwd);
+            if ((int64_t)len_bwd > seen[1]) atomicMax((unsigned long long*)(longest + 1), (unsigned long long)len_bwd);
+        }
+    }
     const bool is_long = p1 - p0 > 256u;                         // hub: summed by the whole wave below, not by this lane alone
     float deg = 0.0f;
     if (!is_long) {
@@ -441,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_act_backward(const int32_t* __r
 }
 
 struct PlanWs {
-    int64_t* status;       // [2]
+    int64_t* status;       // [4]: {unused, status bits, longest destination row, longest source row}
     uint32_t* keys;        // [E]
     uint32_t* sorted;      // [E]
     uint32_t* order;       // [E]
@@ -456,7 +480,7 @@ struct PlanWs {
 static PlanWs carve_plan(void* ws, int64_t e, int64_t n) {
     Arena a(ws, (size_t)-1);
     PlanWs w;
-    w.status = a.take<int64_t>(2);
+    w.status = a.take<int64_t>(4);
     w.keys = a.take<uint32_t>(e);
     w.sorted = a.take<uint32_t>(e);
     w.order = a.take<uint32_t>(e);
@@ -579,6 +603,19 @@ static int launch_spmm(const int32_t* ptr, const int32_t* idx, const float* val,
     return PP_OK;
 }
 
+// longest[0] / longest[1] = longest row of the destination-major / source-major CSR of a finished plan (zeroed by the caller)
+static int plan_longest_rows(const int32_t* in_ptr, int64_t n_dst, const int32_t* out_ptr, int64_t n_src, int64_t* longest, hipStream_t st) {
+    if (n_dst > 0) {
+        k_max_row_length<<<(unsigned)(ceil_div(n_dst, kBlock) < 1024 ? ceil_div(n_dst, kBlock) : 1024), kBlock, 0, st>>>(in_ptr, n_dst, longest);
+        PP_LAUNCH_CHECK();
+    }
+    if (n_src > 0) {
+        k_max_row_length<<<(unsigned)(ceil_div(n_src, kBlock) < 1024 ? ceil_div(n_src, kBlock) : 1024), kBlock, 0, st>>>(out_ptr, n_src, longest + 1);
+        PP_LAUNCH_CHECK();
+    }
+    return PP_OK;
+}
+
 }  // namespace pp
 
 using namespace pp;
@@ -597,7 +634,7 @@ int pp_gcn_plan_begin(const int64_t* edge_index, const float* edge_weight, int64
     PP_REQUIRE(n_edges < (int64_t)0x7fffffff && n_src < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_gcn_plan: E or N >= 2^31");
     PlanWs w = carve_plan(ws, n_edges, n_src);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_gcn_plan: workspace too small");
-    PP_HIP(hipMemsetAsync(w.status, 0, 2 * sizeof(int64_t), st));
+    PP_HIP(hipMemsetAsync(w.status, 0, 4 * sizeof(int64_t), st));
     if (n_src == 0) return PP_OK;
     const unsigned egrid = (unsigned)ceil_div(n_edges > 0 ? n_edges : 1, kBlock);
     if (n_dst > 0) PP_HIP(hipMemsetAsync(w.last_loop, 0xff, (size_t)n_dst * sizeof(int32_t), st));     // -1
@@ -609,20 +646,22 @@ int pp_gcn_plan_begin(const int64_t* edge_index, const float* edge_weight, int64
         k_ptr_from_sorted_i64_i32<<<1, kBlock, 0, st>>>(edge_index, 0, n_src, out_ptr);
         PP_LAUNCH_CHECK();
     }
-    // edges grouped by destination (forward aggregation): order[p] = edge id, sorted[p] = its destination
-    int rc = group_by(edge_index + n_edges, n_edges, n_dst, w, in_ptr, st, true);
-    if (rc != PP_OK) return rc;
+    // edges grouped by destination (forward aggregation): order[p] = edge id, sorted[p] = its destination; one pass over the sorted keys
+    // writes the row pointers, the (source, weight) copies and — for an order-2 De Bruijn model — the edge ids themselves, which ARE the
+    // bipartite "last" plan
     if (n_edges > 0) {
-        k_gather_by_dst<<<egrid, kBlock, 0, st>>>(w.packed, n_edges, w.order, in_idx, in_val);
-        PP_LAUNCH_CHECK();
-        if (dst_order) {       // edge ids grouped by destination: for an order-2 De Bruijn model this IS the bipartite "last" plan
-            k_u32_to_i32_ptr<<<egrid, kBlock, 0, st>>>(w.order, n_edges, dst_order);
-            PP_LAUNCH_CHECK();
-        }
+        int rc = sort_pairs<uint32_t>(w.keys, nullptr, w.sorted, w.order, n_edges, 0, bits_for((uint64_t)(n_dst > 0 ? n_dst - 1 : 0)), w.scratch,
+                                      w.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
     }
-    if (n_dst > 0) {
-        k_gcn_degree_grouped<<<(unsigned)ceil_div(n_dst, kBlock), kBlock, 0, st>>>(in_idx, in_val, (const uint32_t*)in_ptr, w.last_loop, edge_weight,
-                                                                                  n_dst, dinv, self_coef);
+    k_group_by_dst<<<(unsigned)ceil_div(n_edges + 1, kBlock), kBlock, 0, st>>>(w.packed, n_edges, w.order, w.sorted, n_dst, in_ptr, in_idx, in_val,
+                                                                              dst_order);
+    PP_LAUNCH_CHECK();
+    {   // (the grid also covers the source rows: the longest row of both groupings comes out of this launch when the source grouping exists)
+        const int64_t rows = row_sorted && n_src > n_dst ? n_src : n_dst;
+        k_gcn_degree_grouped<<<(unsigned)ceil_div(rows > 0 ? rows : 1, kBlock), kBlock, 0, st>>>(in_idx, in_val, (const uint32_t*)in_ptr, w.last_loop,
+                                                                                                edge_weight, n_dst, dinv, self_coef,
+                                                                                                row_sorted ? out_ptr : nullptr, n_src, w.status + 2);
         PP_LAUNCH_CHECK();
     }
     return PP_OK;
@@ -656,6 +695,8 @@ int pp_gcn_plan_finish(const int64_t* edge_index, const float* edge_weight, int6
         k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, dinv, 0, out_idx, out_val);
         PP_LAUNCH_CHECK();
     }
+    k_max_row_length<<<(unsigned)(ceil_div(n_src, kBlock) < 1024 ? ceil_div(n_src, kBlock) : 1024), kBlock, 0, st>>>(out_ptr, n_src, w.status + 3);
+    PP_LAUNCH_CHECK();
     return PP_OK;
 }
 
@@ -682,7 +723,7 @@ int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n
     PP_REQUIRE(n_pairs < (int64_t)0x7fffffff && nmax < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_bipartite_plan: size >= 2^31");
     PlanWs w = carve_plan(ws, n_pairs, nmax);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_bipartite_plan: workspace too small");
-    PP_HIP(hipMemsetAsync(w.status, 0, 2 * sizeof(int64_t), st));
+    PP_HIP(hipMemsetAsync(w.status, 0, 4 * sizeof(int64_t), st));
     const unsigned egrid = (unsigned)ceil_div(n_pairs > 0 ? n_pairs : 1, kBlock);
     if (n_pairs > 0) {      // validate the sources (the destinations are validated by group_by)
         k_index_key<<<egrid, kBlock, 0, st>>>(bipartite_index, n_pairs, n_ho, w.keys, w.status + 1);
@@ -710,7 +751,7 @@ int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n
             PP_LAUNCH_CHECK();
             if (pair_value && out_val) PP_HIP(hipMemcpyAsync(out_val, pair_value, (size_t)n_pairs * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
-        return PP_OK;
+        return plan_longest_rows(in_ptr, n_fo, out_ptr, n_ho, w.status + 2, st);
     }
     rc = group_by(bipartite_index, n_pairs, n_ho, w, out_ptr, st);               // by higher-order source
     if (rc != PP_OK) return rc;
@@ -722,7 +763,7 @@ int pp_bipartite_plan(const int64_t* bipartite_index, int64_t n_pairs, int64_t n
             PP_LAUNCH_CHECK();
         }
     }
-    return PP_OK;
+    return plan_longest_rows(in_ptr, n_fo, out_ptr, n_ho, w.status + 2, st);
 }
 
 const int64_t* pp_plan_result_ptr(void* ws) { return (const int64_t*)ws; }

@@ -568,6 +568,11 @@ def _even_cuts(num_nodes: int, world: int) -> list[int]:
     return [(num_nodes * r) // world for r in range(world + 1)]
 
 
+def _hip_unit():
+    from ._hip import UNIT
+    return UNIT
+
+
 def _ops_default(ops):
     if ops is not None:
         return ops
@@ -836,31 +841,31 @@ def build_dbgnn_shard(g, delta, x, x_h, y, comm: Comm, ops=None, weight: str = "
     dev = ei.device
     n, m = int(data.num_nodes), int(ei.size(1))
     unit_weights = weight not in data
-    w = torch.ones(m, device=dev) if unit_weights else data[weight]
+    w = _hip_unit() if unit_weights else data[weight]                       # (unit weights: merged weight = run length, no ones vector, no gather)
     # layer 1 and the lift of the same stream are independent: their count phases are queued together, their sizes cost ONE read-back
     (fo, fo_w, inv1), local = ops.coalesce_and_lift((ei, w, n, "sum", None, True), (ei, data.time.contiguous(), n, delta, m, 0))
     n_ho = int(fo.size(1))
-    row_ptr = ops.ptr_from_sorted(fo[0], n)                                  # int64 [n+1]: order-2 nodes (a, .) = ids row_ptr[a] .. row_ptr[a+1]
-    pending = []
     fo_cuts, ho_cuts = [0, n], [0, n_ho]
-    # the first-order graph needs nothing that follows: its plan kernels are queued NOW, in front of the size read-backs below, so the
-    # GPU has ~1 ms of work while the host waits for them
-    fo_shard = build_graph_shard(fo[0], fo[1], fo_w.to(torch.float32), n, fo_cuts, comm, ops, True, pending, want_dst_order=True, edge_index=fo)
-    widest = int((row_ptr[1:] - row_ptr[:-1]).max().item()) if n > 0 else 1
-    col_block = (row_ptr[fo[1]], max(int(widest - 1).bit_length(), 1)) if n_ho else None     # successors of (a, b): the id block of b
+    # the first-order graph needs nothing that follows: its plan kernels are queued NOW; the plan's own report (status, longest rows) is
+    # the one read-back this stage needs — its longest source row IS the widest successor block of the order-2 id space
+    pending_fo, pending_ho = [], []
+    fo_shard = build_graph_shard(fo[0], fo[1], fo_w.to(torch.float32), n, fo_cuts, comm, ops, True, pending_fo, want_dst_order=True, edge_index=fo)
+    row_ptr = fo_shard.plan.bwd_ptr.to(torch.int64)                          # [n+1]: order-2 nodes (a, .) = ids row_ptr[a] .. row_ptr[a+1]
+    report = ops.check_plan_status(pending_fo)
+    widest = report[0][2] if report else (int((row_ptr[1:] - row_ptr[:-1]).max().item()) if n > 0 else 1)
+    col_block = (row_ptr[fo[1]], max(int(max(widest, 1) - 1).bit_length(), 1)) if n_ho else None     # successors of (a, b): the id block of b
     e2 = int(local.size(1))
-    w_pairs = torch.ones(e2, device=dev) if unit_weights else w.index_select(0, local[0])   # lifted weight = weight of the source event
+    w_pairs = w if unit_weights else w.index_select(0, local[0])               # lifted weight = weight of the source event
     ho_ei, ho_w = ops.coalesce(local, w_pairs, n_ho, "sum", inv1, False, col_block)
-    ho = build_graph_shard(ho_ei[0], ho_ei[1], ho_w.to(torch.float32), n_ho, ho_cuts, comm, ops, True, pending, edge_index=ho_ei)
+    ho = build_graph_shard(ho_ei[0], ho_ei[1], ho_w.to(torch.float32), n_ho, ho_cuts, comm, ops, True, pending_ho, edge_index=ho_ei)
     bip = ops.bipartite_from_grouping(fo_shard.plan, fo[1], n_ho)
-    ops.check_plan_status(pending)
-    fptr = fo_shard.plan.fwd_ptr
-    indeg = (fptr[1:] - fptr[:-1]).to(torch.float32)                            # order-2 nodes (., b) per first-order node b
+    indeg = bip.self_coef                                                       # order-2 nodes (., b) per first-order node b
     x_loc = _rows_of(x, None, 0, n, dev)
     xh_loc = x_h(n_ho) if (callable(x_h) and _takes_count(x_h)) else _rows_of(x_h, None, 0, n_ho, dev)
     a2 = int(ho_ei.size(1))
+    # the higher-order plan's report is read by DbgnnShard.resolve(): ShardedDBGNN queues the first-order layers in front of that read-back
     return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=n, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(), y=_rows_of(y, None, 0, n, dev),
-                      n_fo=n, n_ho=n_ho,
+                      n_fo=n, n_ho=n_ho, pending=(ops, pending_ho),
                       sizes={"m": m, "N": n, "E2": e2, "E2_local": e2, "U2": n_ho, "A1": n_ho, "A2": a2, "A2_local": a2, "fo_cuts": fo_cuts,
                              "ho_cuts": ho_cuts, "fo_halo": 0, "ho_halo": 0})
 
@@ -964,7 +969,7 @@ def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
     n_fo_own = hi_n - lo_n
     m_l1 = int(ss.ei_l1.size(1))
     # ---- 1. layer 1 on the events that start in my node range  +  2. the edge-range lift (count phases queued together: one read-back)
-    w_r = torch.ones(m_l1, device=dev) if unit_weights else ss.w_l1
+    w_r = _hip_unit() if unit_weights else ss.w_l1
     (fo_r, fo_w_r, inv_r), local = ops.coalesce_and_lift((ss.ei_l1, w_r, n, "sum", None, True),
                                                          (ss.ei_lift, ss.time_lift, n, delta, ss.n_own_lift, 0))       # (ids relative to my slice)
     n_ho_own = int(fo_r.size(1))
@@ -1001,7 +1006,7 @@ def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
     pairs = torch.stack((u, v), dim=1).to(torch.int32).index_select(0, p_order)
     pairs_in = comm.exchange_rows(pairs, p_send, p_recv)
     if unit_weights:
-        w_in = torch.ones(pairs_in.size(0), device=dev)
+        w_in = _hip_unit()
     else:
         w_in = comm.exchange_rows(ss.w_lift.index_select(0, local[0]).index_select(0, p_order), p_send, p_recv)     # weight of the source event
     own_ids = torch.arange(lo_h, hi_h, **i64)

@@ -462,11 +462,21 @@ class DbgnnShard:
     """Everything one rank needs for DBGNN steps on its partition: the two graph shards, the bipartite plan, the local input features
     (owned + halo rows) and the labels of the owned first-order nodes."""
 
-    __slots__ = ("fo", "ho", "bip", "cap", "indeg", "x", "x_h", "y", "n_fo", "n_ho", "sizes")
+    __slots__ = ("fo", "ho", "bip", "cap", "indeg", "x", "x_h", "y", "n_fo", "n_ho", "sizes", "pending")
 
     def __init__(self, **kw):
         for k in self.__slots__:
             setattr(self, k, kw.get(k))
+
+    def resolve(self) -> "DbgnnShard":
+        """Read the report of the plans whose check was deferred (``pending = (ops, entries)``: bad-index status, hub rows of the
+        higher-order graph).  build_dbgnn_shard leaves it to the consumer at world size 1 so that independent kernels (the first-order
+        layers) can be queued in front of the read-back; idempotent."""
+        if self.pending is not None:
+            ops, entries = self.pending
+            self.pending = None
+            ops.check_plan_status(entries)
+        return self
 
 
 class ShardedDBGNN(torch.nn.Module):
@@ -507,6 +517,8 @@ class ShardedDBGNN(torch.nn.Module):
             return _ShardedGcnStack.apply(graph_shard, comm, ops, drop, x_full, *params), layers[-1].bias
 
         bl = m.bipartite_layer
+        if comm.world > 1:
+            shard.resolve()
         if comm.world > 1 and not dropping and len(m.first_order_layers) == len(m.higher_order_layers) and self.overlap:
             # one schedule for both stacks + the bipartite sum: every exchange runs beside kernels of the other stack (_ShardedTrunk)
             params = []
@@ -518,6 +530,7 @@ class ShardedDBGNN(torch.nn.Module):
             x = F.elu(torch.addcmul(ops.dense_nobias(agg, bl.lin1.weight), shard.indeg.unsqueeze(1), per_edge))
             return ops.dense(x, m.lin)
         x, bias_fo = stack(m.first_order_layers, shard.fo, shard.x, TAG_FO, TAG_FO_OUT)
+        shard.resolve()                       # (higher-order plan report: read while the first-order layers run)
         x_h, bias_ho = stack(m.higher_order_layers, shard.ho, shard.x_h, TAG_HO, TAG_HO_OUT)
         if dropping:            # dropout after both stacks and after the bipartite ELU (reference dbgnn.py:136,142,148), masks as above
             p = m.p_dropout

@@ -140,6 +140,8 @@ class CpuOps:
     @staticmethod
     def coalesce(edge_index, weight, num_nodes, reduce="sum", remap=None, want_inverse=False, col_block=None):
         ei = edge_index if remap is None else remap[edge_index]
+        if isinstance(weight, str):                       # pathpyg_amd._hip.UNIT: unit weights
+            weight = torch.ones(ei.size(1))
         if ei.numel() and int(ei.max()) >= num_nodes:
             raise ValueError("node id >= number of nodes")
         merged_index, merged_weight = oa.coalesce(ei, weight, num_nodes, reduce)

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.tolerance import assert_embeddings_close
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -77,8 +79,7 @@ def test_config1_2m_events_dbgnn_train_step_matches_float64_oracle(pp):
     ref = om.dbgnn_inputs(layers, 2, "last", x=x.double(), x_h=x_h.double())
     ref["edge_weights"], ref["edge_weights_higher_order"] = ref["edge_weights"].double(), ref["edge_weights_higher_order"].double()
     want_out, want_loss, want_grads = od.loss_and_grads({k: v.double() for k, v in params.items()}, ref, y)
-    scale = float(want_out.abs().max())
-    torch.testing.assert_close(out.detach().cpu().double(), want_out, rtol=1e-5, atol=1e-5 * scale)
+    assert_embeddings_close(out, want_out)                                # 1e-5 relative, element-wise (north star)
     torch.testing.assert_close(loss.detach().cpu().double(), want_loss, rtol=1e-5, atol=1e-6)
     for name, p_ in net.named_parameters():
         gs = float(want_grads[name].abs().max()) + 1e-30
@@ -336,8 +337,7 @@ def _dbgnn_step_vs_float64(pp, m, n, span, delta, f, classes=8):
     del out, loss, net, data, model, g                                   # free the fp32 path's activations before the float64 pass
     torch.cuda.empty_cache()
     want_out, want_loss, want_grads = _reference_step_float64(params, ref_in, y)
-    scale = float(want_out.abs().max())
-    torch.testing.assert_close(got_out, want_out, rtol=1e-5, atol=1e-5 * scale)
+    assert_embeddings_close(got_out, want_out)                            # 1e-5 relative, element-wise (north star)
     torch.testing.assert_close(got_loss, want_loss, rtol=1e-5, atol=1e-6)
     for name, grad in got_grads.items():
         gs = float(want_grads[name].abs().max()) + 1e-30

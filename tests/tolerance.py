@@ -1,0 +1,18 @@
+"""The floating-point bar of the parity tests (BASELINE north star: "embeddings match within 1e-5 rel fp32")."""
+import torch
+
+
+def assert_embeddings_close(got: torch.Tensor, want: torch.Tensor, rtol: float = 1e-5, what: str = "embeddings") -> None:
+    """ELEMENT-WISE ``|got - want| <= rtol * |want| + rtol * rms(want)``: 1e-5 relative for every entry, with an absolute floor tied to the
+    TYPICAL magnitude of the reference (its root mean square) — not to its largest entry — so that an entry that cancels to ~0 out of
+    O(rms) terms is still held to the rounding error of those terms and every other entry to 1e-5 of itself."""
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} != {tuple(want.shape)}"
+    rms = float(want.pow(2).mean().sqrt()) if want.numel() else 0.0
+    err = (got - want).abs()
+    bound = rtol * want.abs() + rtol * rms
+    bad = err > bound
+    if bool(bad.any()):
+        worst = int((err - bound).argmax())
+        raise AssertionError(f"{what}: {int(bad.sum())} of {want.numel()} entries beyond {rtol:g} relative (+ {rtol:g} * rms = {rtol * rms:.3e}); "
+                             f"worst: got {got.flatten()[worst]:.9g}, want {want.flatten()[worst]:.9g}, max abs err {float(err.max()):.3e}")

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run ON the GPU box: bench lines of the non-headline BASELINE shapes + the 8-rank projection, each with >= 3 warm-up steps.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/shapes; mkdir -p $O
+cd $R
+B="timeout 600 python bench.py --no-cpu-baseline --warmup 3"
+$B --emulate-ranks 8 --steps 5 --trace > $O/emulate8.json 2> $O/emulate8.err
+$B --emulate-ranks 8 --steps 5 --no-overlap > $O/emulate8_no_overlap.json 2>> $O/emulate8.err
+$B --emulate-ranks 4 --steps 5 > $O/emulate4.json 2>> $O/emulate8.err
+$B --emulate-ranks 2 --steps 5 > $O/emulate2.json 2>> $O/emulate8.err
+$B --steps 10 --events 2000000 --nodes 100000 --span 1000000 --delta 100000 > $O/config1.json 2> $O/config1.err
+$B --steps 5 --features 128 > $O/f128.json 2> $O/f128.err
+$B --steps 5 --features 256 > $O/f256.json 2> $O/f256.err
+$B --steps 5 --events 20000000 --nodes 1000000 --features 128 > $O/config3_per_gpu.json 2> $O/config3.err
+tail -c 300 $O/*.err
+for f in $O/*.json; do echo $f; python -c "
+import json,sys
+d=json.load(open('$f'))
+print({k:d.get(k) for k in ('ms_per_step','value','projected_ms_per_step','max_rank_compute_ms','amdahl_terms_ms','peak_hbm_gib') if k in d})
+"; done
