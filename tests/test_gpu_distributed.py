@@ -75,7 +75,7 @@ def _run_rank(rank, world, dev, comm, case):
     assert_embeddings_close(out, want_out[shard.fo.lo: shard.fo.hi])
     loss = sharded.loss(shard)
     loss.backward()
-    pd.all_reduce_gradients(net, average=False)
+    pd.all_reduce_gradients(net, average=False, comm=comm)
     total = loss.detach().clone().reshape(1)
     comm.all_reduce_(total)
     torch.testing.assert_close(total.cpu()[0], want_loss, rtol=RTOL, atol=ATOL)
@@ -128,7 +128,23 @@ def _gloo_worker(rank, world, port, results):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+def test_partition_path_three_ranks_as_threads_match_oracle():
+    """World size 3 (uneven cuts) with the real kernels, the ranks as threads of this process (ThreadWorld: seconds instead of the minute
+    three processes spend switching contexts on one GPU)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from pathpyg_amd import distributed as pd
+    dev = torch.device("cuda:0")
+
+    def body(comm):
+        for case in CASES:
+            _run_rank(comm.rank, 3, dev, comm, case)
+        return "ok"
+
+    assert pd.run_thread_world(3, body, dev) == ["ok"] * 3
+
+
+@pytest.mark.parametrize("world", [2])
 def test_partition_path_ranks_sharing_one_gpu_match_oracle(world):
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
@@ -299,60 +315,38 @@ def test_partition_path_dropout_matches_masked_reference(case):
         torch.testing.assert_close(prm.grad.cpu(), want_grads[name], rtol=1e-4, atol=max(ATOL, 2e-5 * scale), msg=lambda s: f"{name}: {s}")
 
 
-def _gloo_dropout_worker(rank, world, port, results):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        sys.path.insert(0, ROOT)
-        import pathpyg_amd as pp
-        from pathpyg_amd import distributed as pd
-        torch.cuda.set_device(0)
-        dev, p = torch.device("cuda:0"), 0.4
-        comm = pd.Comm()
-        for case in (CASES[0], CASES[1], CASES[2]):
-            ei, t, w, x, x_h, y, params, want, layers = _case(*case)
-            attrs = {} if w is None else {"edge_weight": w.to(dev)}
-            tg = pp.TemporalGraph(pp.Data(edge_index=ei.to(dev), time=t.to(dev), num_nodes=case[2], **attrs))
+def test_partition_path_dropout_on_ranks_sharing_one_gpu():
+    """Training-mode dropout across 3 ranks (HIP kernels; the ranks are threads of this process, ThreadWorld): the owner's layer kernel drops
+    its rows in the epilogue with the GLOBAL row id (drop_row0 = the shard's first row) before they are exchanged; loss and gradients equal
+    the single-process evaluation with the same masks."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import pathpyg_amd as pp
+    from pathpyg_amd import distributed as pd
+    dev, p = torch.device("cuda:0"), 0.4
+    torch.manual_seed(5)
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).item())
+    for case in (CASES[0], CASES[1], CASES[2]):
+        ei, t, w, x, x_h, y, params, want, layers = _case(*case)
+        want_loss, want_grads = _masked_reference(case, p, seed)
+        attrs = {} if w is None else {"edge_weight": w.to(dev)}
+        tg = pp.TemporalGraph(pp.Data(edge_index=ei.to(dev), time=t.to(dev), num_nodes=case[2], **attrs))
+
+        def body(comm):
             shard = pd.build_dbgnn_shard(tg, case[3], x.to(dev), x_h.to(dev), y.to(dev), comm)
             net = pp.nn.DBGNN(num_classes=3, num_features=(case[5], case[5]), hidden_dims=case[6], p_dropout=p).to(dev)
             net.load_state_dict(params)
             net.train()
-            torch.manual_seed(5)
-            seed = int(torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).item())
             torch.manual_seed(5)                       # every rank draws the same seed (the model agrees on the maximum)
             loss = pd.ShardedDBGNN(net, comm).loss(shard)
             loss.backward()
-            pd.all_reduce_gradients(net, average=False)
+            pd.all_reduce_gradients(net, average=False, comm=comm)
             total = loss.detach().clone().reshape(1)
             comm.all_reduce_(total)
-            want_loss, want_grads = _masked_reference(case, p, seed)
             torch.testing.assert_close(total.cpu()[0], want_loss, rtol=RTOL, atol=ATOL)
             for name, prm in net.named_parameters():
                 scale = float(want_grads[name].abs().max()) + 1e-12
                 torch.testing.assert_close(prm.grad.cpu(), want_grads[name], rtol=1e-4, atol=max(ATOL, 2e-5 * scale), msg=lambda s_: f"{case[5]} {name}: {s_}")
-        torch.cuda.synchronize()
-        results[rank] = "ok"
-    finally:
-        dist.destroy_process_group()
+            return "ok"
 
-
-@pytest.mark.parametrize("world", [3])
-def test_partition_path_dropout_on_ranks_sharing_one_gpu(world):
-    """Training-mode dropout across 2 / 3 ranks (HIP kernels, gloo collectives, one GPU): the owner's layer kernel drops its rows in the
-    epilogue with the GLOBAL row id (drop_row0 = the shard's first row) before they are exchanged; loss and gradients equal the
-    single-process evaluation with the same masks."""
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU visible")
-    ctx = mp.get_context("spawn")
-    results = ctx.Manager().dict()
-    port = _free_port()
-    procs = [ctx.Process(target=_gloo_dropout_worker, args=(r, world, port, results)) for r in range(world)]
-    for pr in procs:
-        pr.start()
-    for pr in procs:
-        pr.join(600)
-    for pr in procs:
-        if pr.is_alive():
-            pr.terminate()
-    assert dict(results) == {r: "ok" for r in range(world)}
+        assert pd.run_thread_world(3, body, dev) == ["ok"] * 3
