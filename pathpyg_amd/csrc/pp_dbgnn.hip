@@ -93,23 +93,10 @@ __global__ __launch_bounds__(kBlock) void k_group_by_dst(const uint2* __restrict
 __global__ __launch_bounds__(kBlock) void k_gcn_degree_grouped(const int32_t* __restrict__ in_idx, const float* __restrict__ w_by_dst,
                                                               const uint32_t* __restrict__ dst_ptr, const int32_t* __restrict__ last_loop,
                                                               const float* __restrict__ w, int64_t n_nodes, float* __restrict__ dinv,
-                                                              float* __restrict__ self_coef, const int32_t* __restrict__ src_ptr, int64_t n_src,
-                                                              int64_t* __restrict__ longest) {
+                                                              float* __restrict__ self_coef) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < n_nodes;
     const uint32_t p0 = live ? dst_ptr[i] : 0u, p1 = live ? dst_ptr[i + 1] : 0u;
-    {   // longest[0] / longest[1]: longest destination / source row (hub rows get chunk tables, pp_spmm_heavy_f32); the grid covers
-        // max(n_nodes, n_src) rows; src_ptr == nullptr: the source grouping does not exist yet (pp_gcn_plan_finish reports it)
-        int len_fwd = (int)(p1 - p0), len_bwd = (src_ptr != nullptr && i < n_src) ? src_ptr[i + 1] - src_ptr[i] : 0;
-        len_fwd = wave_max(len_fwd);
-        len_bwd = wave_max(len_bwd);
-        // (a wave only queues an atomic when it beats the maximum it can already see: ~1.6e5 atomics on one word cost more than the kernel)
-        if (lane_id() == 0) {
-            const volatile int64_t* seen = longest;
-            if ((int64_t)len_fwd > seen[0]) atomicMax((unsigned long long*)longest, (unsigned long long)len_fwd);
-            if ((int64_t)len_bwd > seen[1]) atomicMax((unsigned long long*)(longest + 1), (unsigned long long)len_bwd);
-        }
-    }
     const bool is_long = p1 - p0 > 256u;                         // hub: summed by the whole wave below, not by this lane alone
     float deg = 0.0f;
     if (!is_long) {
@@ -657,14 +644,15 @@ int pp_gcn_plan_begin(const int64_t* edge_index, const float* edge_weight, int64
     k_group_by_dst<<<(unsigned)ceil_div(n_edges + 1, kBlock), kBlock, 0, st>>>(w.packed, n_edges, w.order, w.sorted, n_dst, in_ptr, in_idx, in_val,
                                                                               dst_order);
     PP_LAUNCH_CHECK();
-    {   // (the grid also covers the source rows: the longest row of both groupings comes out of this launch when the source grouping exists)
-        const int64_t rows = row_sorted && n_src > n_dst ? n_src : n_dst;
-        k_gcn_degree_grouped<<<(unsigned)ceil_div(rows > 0 ? rows : 1, kBlock), kBlock, 0, st>>>(in_idx, in_val, (const uint32_t*)in_ptr, w.last_loop,
-                                                                                                edge_weight, n_dst, dinv, self_coef,
-                                                                                                row_sorted ? out_ptr : nullptr, n_src, w.status + 2);
+    if (n_dst > 0) {
+        k_gcn_degree_grouped<<<(unsigned)ceil_div(n_dst, kBlock), kBlock, 0, st>>>(in_idx, in_val, (const uint32_t*)in_ptr, w.last_loop, edge_weight,
+                                                                                  n_dst, dinv, self_coef);
         PP_LAUNCH_CHECK();
     }
-    return PP_OK;
+    // longest rows of both groupings (hub rows): bounded-grid reductions with one atomic per workgroup (folding them into the degree kernel —
+    // one guarded atomic per wave on one word — doubled that kernel's time: 133 -> 251 us at 10^7 rows); the source grouping of an unsorted
+    // edge list only exists after pp_gcn_plan_finish, which reports it then
+    return plan_longest_rows(in_ptr, n_dst, row_sorted ? out_ptr : nullptr, row_sorted ? n_src : 0, w.status + 2, st);
 }
 
 // Phase 2: dinv[0..n_src) is complete (the halo part came from the owners) -> normalised coefficients in both groupings.
@@ -695,9 +683,7 @@ int pp_gcn_plan_finish(const int64_t* edge_index, const float* edge_weight, int6
         k_gcn_coefficients<<<egrid, kBlock, 0, st>>>(edge_index, n_edges, edge_weight, w.order, dinv, 0, out_idx, out_val);
         PP_LAUNCH_CHECK();
     }
-    k_max_row_length<<<(unsigned)(ceil_div(n_src, kBlock) < 1024 ? ceil_div(n_src, kBlock) : 1024), kBlock, 0, st>>>(out_ptr, n_src, w.status + 3);
-    PP_LAUNCH_CHECK();
-    return PP_OK;
+    return plan_longest_rows(nullptr, 0, out_ptr, n_src, w.status + 2, st);
 }
 
 int pp_gcn_plan(const int64_t* edge_index, const float* edge_weight, int64_t n_edges, int64_t n_nodes, int row_sorted, int32_t* in_ptr,
