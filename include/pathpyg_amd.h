@@ -246,6 +246,14 @@ int pp_spmm_act_backward_drop_f32(const int32_t* ptr, const int32_t* idx, const 
  * dpre or dbias may be NULL. */
 int pp_act_backward_f32(const float* dY, const float* Y, int64_t n_rows, int F, int act, float* dpre, float* dbias, pp_stream_t stream);
 
+/* The element-wise tail of BipartiteGraphOperator.forward + F.elu (src/pathpyG/nn/dbgnn.py:66-69,143-144) on the first-order rows, after the
+ * re-association sum_j lin1(x_h[j]) = lin1.weight (sum_j x_h[j]) + deg * lin1.bias:  Y = ELU(A + deg[r] * (P + bias)),  A = lin1.weight applied
+ * to the summed higher-order rows, P = lin2(x), deg [n_rows] = incoming pairs per first-order node, bias [F] or NULL.
+ * _backward: dpre = dY * ELU'(Y);  dA = dpre;  dP = deg[r] * dpre;  dbias[c] = sum_r dP[r][c] (NULL: not wanted). */
+int pp_bip_combine_f32(const float* A, const float* P, const float* deg, const float* bias, int64_t n_rows, int F, float* Y, pp_stream_t stream);
+int pp_bip_combine_backward_f32(const float* dY, const float* Y, const float* deg, int64_t n_rows, int F, float* dA, float* dP, float* dbias,
+                                pp_stream_t stream);
+
 /* out[r,:] = coef[r] * X[r,:] (gradient of the bipartite self term) */
 int pp_scale_rows_f32(const float* X, const float* coef, int64_t n_rows, int F, float* out, pp_stream_t stream);
 

@@ -716,6 +716,31 @@ def spmm(ptr, idx, val, n_rows: int, x: torch.Tensor, self_coef=None, s=None, bi
     return y
 
 
+def bip_combine(a: torch.Tensor, p: torch.Tensor, deg: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """``ELU(a + deg[:, None] * (p + bias))`` in one pass (pp_bip_combine_f32)."""
+    dev = require_device(a, p, deg, bias)
+    a, p, deg = a.contiguous(), p.contiguous(), deg.to(torch.float32).contiguous()
+    if a.dtype != torch.float32 or p.shape != a.shape or deg.numel() != a.size(0):
+        raise ValueError("bip_combine: a, p [n, F] fp32 and deg [n] expected")
+    with torch.cuda.device(dev):
+        y = torch.empty_like(a)
+        check(lib().pp_bip_combine_f32(_p(a), _p(p), _p(deg), _p(None if bias is None else bias.contiguous()), a.size(0), a.size(1), _p(y), _stream()),
+              "pp_bip_combine_f32")
+    return y
+
+
+def bip_combine_backward(dy: torch.Tensor, y: torch.Tensor, deg: torch.Tensor, want_bias: bool):
+    """Backward of :func:`bip_combine`: ``(d_a, d_p, d_bias or None)`` in one pass (pp_bip_combine_backward_f32)."""
+    dev = require_device(dy, y, deg)
+    dy, deg = dy.contiguous(), deg.to(torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        da, dp = torch.empty_like(y), torch.empty_like(y)
+        db = torch.empty(y.size(1), dtype=torch.float32, device=dev) if want_bias else None
+        check(lib().pp_bip_combine_backward_f32(_p(dy), _p(y), _p(deg), y.size(0), y.size(1), _p(da), _p(dp), _p(db), _stream()),
+              "pp_bip_combine_backward_f32")
+    return da, dp, db
+
+
 def act_backward(dy: torch.Tensor, y: torch.Tensor | None, act: bool, want_dpre: bool = True, want_dbias: bool = False):
     dev = require_device(dy, y)
     dy = dy.contiguous()

@@ -343,6 +343,50 @@ __global__ __launch_bounds__(kBlock) void k_act_backward(const float* __restrict
         for (int c = threadIdx.x; c < F; c += kBlock) atomicAdd(&dbias[c], s_col[c]);
 }
 
+// ------------------------------------------------------------------ bipartite combine (reference nn/dbgnn.py:66-69,143-144)
+// y = ELU(a + deg[r] * (p + b)) on the first-order rows: a = lin1 applied to the summed higher-order rows, p = lin2(x) per first-order row,
+// b = lin1's bias (it enters once per incoming pair: deg[r] times), deg = in-degree of the bipartite graph.  One pass instead of the
+// add / addcmul / elu chain of element-wise library kernels; the backward pass below replaces elu_backward / mul / column-sum kernels.
+__global__ __launch_bounds__(kBlock) void k_bip_combine(const float* __restrict__ A, const float* __restrict__ P, const float* __restrict__ deg,
+                                                       const float* __restrict__ bias, int64_t n_rows, int F, float* __restrict__ Y) {
+    const int64_t total = n_rows * (int64_t)F;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / F;
+        const int c = (int)(i - r * F);
+        Y[i] = elu_fast(A[i] + deg[r] * (P[i] + (bias ? bias[c] : 0.f)));
+    }
+}
+
+// dpre = dY * ELU'(y); dA = dpre; dP = deg[r] * dpre; dbias[c] = sum_r dP[r][c]
+template <bool kFixedColumn>
+__global__ __launch_bounds__(kBlock) void k_bip_combine_backward(const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ deg,
+                                                                int64_t n_rows, int F, float* __restrict__ dA, float* __restrict__ dP,
+                                                                float* __restrict__ dbias) {
+    extern __shared__ float s_col[];
+    for (int c = threadIdx.x; c < F; c += kBlock) s_col[c] = 0.f;
+    __syncthreads();
+    const int64_t total = n_rows * (int64_t)F;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t first = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    float mine = 0.f;
+    for (int64_t i = first; i < total; i += stride) {
+        const int64_t r = i / F;
+        const float y = Y[i];
+        const float g = dY[i] * (y > 0.f ? 1.f : y + 1.f);
+        const float gp = deg[r] * g;
+        dA[i] = g;
+        dP[i] = gp;
+        if (dbias) {
+            if (kFixedColumn) mine += gp;
+            else atomicAdd(&s_col[(int)(i - r * F)], gp);
+        }
+    }
+    if (dbias && kFixedColumn && first < total) atomicAdd(&s_col[(int)(first % F)], mine);
+    __syncthreads();
+    if (dbias)
+        for (int c = threadIdx.x; c < F; c += kBlock) atomicAdd(&dbias[c], s_col[c]);
+}
+
 // ------------------------------------------------------------------ dropout with counter-based masks
 // out = x * keep / (1 - p)      (x may alias out)
 __global__ __launch_bounds__(kBlock) void k_dropout(const float* __restrict__ X, int64_t n_rows, int F, uint32_t key, uint32_t threshold, float scale,
@@ -822,6 +866,36 @@ int pp_act_backward_f32(const float* dY, const float* Y, int64_t n_rows, int F, 
         k_act_backward<true><<<(unsigned)g, kBlock, (size_t)F * sizeof(float), st>>>(dY, Y, n_rows, F, act, dpre, dbias);
     else
         k_act_backward<false><<<(unsigned)g, kBlock, (size_t)F * sizeof(float), st>>>(dY, Y, n_rows, F, act, dpre, dbias);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+int pp_bip_combine_f32(const float* A, const float* P, const float* deg, const float* bias, int64_t n_rows, int F, float* Y, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0 && F >= 0, PP_ERR_ARG, "pp_bip_combine_f32: negative size");
+    const int64_t total = n_rows * (int64_t)F;
+    if (total == 0) return PP_OK;
+    int64_t g = ceil_div(total, kBlock * 4);
+    if (g > kMaxGrid) g = kMaxGrid;
+    k_bip_combine<<<(unsigned)g, kBlock, 0, st>>>(A, P, deg, bias, n_rows, F, Y);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+int pp_bip_combine_backward_f32(const float* dY, const float* Y, const float* deg, int64_t n_rows, int F, float* dA, float* dP, float* dbias,
+                                pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0 && F >= 0, PP_ERR_ARG, "pp_bip_combine_backward_f32: negative size");
+    if (dbias) PP_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), st));
+    const int64_t total = n_rows * (int64_t)F;
+    if (total == 0) return PP_OK;
+    int64_t g = ceil_div(total, kBlock * 8);
+    if (g > kMaxGrid) g = kMaxGrid;
+    if (g < 1) g = 1;
+    if ((g * kBlock) % F == 0)
+        k_bip_combine_backward<true><<<(unsigned)g, kBlock, (size_t)F * sizeof(float), st>>>(dY, Y, deg, n_rows, F, dA, dP, dbias);
+    else
+        k_bip_combine_backward<false><<<(unsigned)g, kBlock, (size_t)F * sizeof(float), st>>>(dY, Y, deg, n_rows, F, dA, dP, dbias);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

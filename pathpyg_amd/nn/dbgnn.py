@@ -232,6 +232,28 @@ class _Aggregate(torch.autograd.Function):
         return None, _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, d.contiguous(), heavy=plan.bwd_heavy)
 
 
+class _BipCombine(torch.autograd.Function):
+    """``ELU(agg_lin + deg * (per_node + b1))``: the element-wise tail of the bipartite layer (reference nn/dbgnn.py:66-69,143-144 after the
+    re-association of lin1) as ONE kernel each way instead of the add / addcmul / elu chain and its three backward kernels."""
+
+    @staticmethod
+    def forward(ctx, agg_lin, per_node, deg, bias):
+        y = _hip.bip_combine(agg_lin, per_node, deg, bias)
+        ctx.save_for_backward(y, deg)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, deg = ctx.saved_tensors
+        da, dp, db = _hip.bip_combine_backward(dy, y, deg, ctx.has_bias and ctx.needs_input_grad[3])
+        return da, dp, None, db
+
+
+def bip_combine(agg_lin, per_node, deg, bias):
+    return _BipCombine.apply(agg_lin, per_node, deg, bias)
+
+
 class _DropAct(torch.autograd.Function):
     """Training-mode dropout of a matrix whose rows are the GLOBAL rows ``row0 .. row0 + n`` (or ``rows``), with the counter-based masks of
     ``pp_dropout_f32`` (no mask tensor; the same decision for the same (seed, tag, row, column) on every rank of a partitioned run).
@@ -563,9 +585,8 @@ class DBGNN(Module):
             # x_h), then everything else lives on the N first-order rows (N << U) — instead of a dense layer over all U rows
             # forward and its three-matrix backward.  Same sum, re-associated (linearity of lin1).
             agg = _AggregateAct.apply(plan_bi, x_h, bias_ho)
-            per_edge = dense(x, bl.lin2, True, bias_fo) + bl.lin1.bias
             # (dense(): its weight gradients contract over all N rows on the MFMA kernel; the library GEMM is 4x slower there)
-            x = F.elu(torch.addcmul(dense_w(agg, bl.lin1.weight), plan_bi.self_coef.unsqueeze(1), per_edge))
+            x = bip_combine(dense_w(agg, bl.lin1.weight), dense(x, bl.lin2, True, bias_fo), plan_bi.self_coef, bl.lin1.bias)
             return dense(x, self.lin)
         x = _Propagate.apply(plan_bi, dense(x_h, bl.lin1, True, bias_ho), dense(x, bl.lin2, True, bias_fo), None, True, True)
         return dense(x, self.lin, True, None)

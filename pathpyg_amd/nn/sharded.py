@@ -162,6 +162,12 @@ class HipOps:
         return dense_w(x, weight)
 
     @staticmethod
+    def bip_combine(agg_lin, per_node, deg, bias):
+        """``ELU(agg_lin + deg[:, None] * (per_node + bias))`` — one kernel each way (pp_bip_combine_f32 / _backward_f32)."""
+        from .dbgnn import bip_combine
+        return bip_combine(agg_lin, per_node, deg, bias)
+
+    @staticmethod
     def cross_entropy_mean(logits, target):
         from .dbgnn import cross_entropy
         return cross_entropy(logits, target)
@@ -526,8 +532,8 @@ class ShardedDBGNN(torch.nn.Module):
                 for layer in layers:
                     params += [layer.lin.weight, layer.bias]
             x, agg = _ShardedTrunk.apply(shard, comm, ops, len(m.first_order_layers), *params)
-            per_edge = ops.dense(x, bl.lin2, True, m.first_order_layers[-1].bias) + bl.lin1.bias
-            x = F.elu(torch.addcmul(ops.dense_nobias(agg, bl.lin1.weight), shard.indeg.unsqueeze(1), per_edge))
+            x = ops.bip_combine(ops.dense_nobias(agg, bl.lin1.weight), ops.dense(x, bl.lin2, True, m.first_order_layers[-1].bias), shard.indeg,
+                                bl.lin1.bias)
             return ops.dense(x, m.lin)
         x, bias_fo = stack(m.first_order_layers, shard.fo, shard.x, TAG_FO, TAG_FO_OUT)
         shard.resolve()                       # (higher-order plan report: read while the first-order layers run)
@@ -543,8 +549,7 @@ class ShardedDBGNN(torch.nn.Module):
             return ops.dense(ops.drop_act(x, None, p, seed, TAG_HEAD, shard.fo.lo, False), m.lin)
         # sum_j (W1 y_h[j] + b1) = W1 (sum_j y_h[j]) + deg * b1 (linearity, as in DBGNN.forward): only [N, H] partials cross xGMI
         agg = _ShardedBipartite.apply(shard.bip, comm, ops, shard.cap, shard.fo.n_own, x_h, bias_ho)
-        per_edge = ops.dense(x, bl.lin2, True, bias_fo) + bl.lin1.bias
-        x = F.elu(torch.addcmul(ops.dense_nobias(agg, bl.lin1.weight), shard.indeg.unsqueeze(1), per_edge))
+        x = ops.bip_combine(ops.dense_nobias(agg, bl.lin1.weight), ops.dense(x, bl.lin2, True, bias_fo), shard.indeg, bl.lin1.bias)
         return ops.dense(x, m.lin)
 
     def loss(self, shard: DbgnnShard) -> torch.Tensor:

@@ -257,6 +257,10 @@ class CpuOps:
         return linear(x)
 
     @staticmethod
+    def bip_combine(agg_lin, per_node, deg, bias):
+        return torch.nn.functional.elu(torch.addcmul(agg_lin, deg.unsqueeze(1), per_node + bias))
+
+    @staticmethod
     def dense_nobias(x, weight):
         return x @ weight.t()
 

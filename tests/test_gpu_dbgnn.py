@@ -664,3 +664,27 @@ def test_fused_layer_kernels_with_dropout_in_their_epilogues(pp, n, e, p_in, q_o
     want, want_sum = _hip.dropout_act_backward(lin, y1, *site, None, True, True)
     torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(colsum, want_sum, rtol=1e-4, atol=1e-4 * float(want.abs().sum(0).max() + 1))
+
+
+@pytest.mark.parametrize("n,f", [(1, 4), (1000, 8), (4097, 64), (777, 37), (300, 256)])
+def test_bip_combine_kernels_match_the_elementwise_chain(n, f):
+    """pp_bip_combine_f32 / _backward_f32 against the reference's element-wise tail (nn/dbgnn.py:66-69,143-144 after the lin1 re-association):
+    ELU(a + deg * (p + b)), its input gradients and the bias gradient."""
+    from pathpyg_amd.nn.dbgnn import bip_combine
+    g = torch.Generator().manual_seed(n * 131 + f)
+    a, p = torch.randn(n, f, generator=g), torch.randn(n, f, generator=g)
+    deg = torch.randint(0, 9, (n,), generator=g).float()
+    b = torch.randn(f, generator=g)
+    dy = torch.randn(n, f, generator=g)
+    ref_in = [t.clone().double().requires_grad_(True) for t in (a, p, b)]
+    ref = torch.nn.functional.elu(torch.addcmul(ref_in[0], deg.double().unsqueeze(1), ref_in[1] + ref_in[2]))
+    ref.backward(dy.double())
+    got_in = [t.to(DEV).requires_grad_(True) for t in (a, p, b)]
+    got = bip_combine(got_in[0], got_in[1], deg.to(DEV), got_in[2])
+    got.backward(dy.to(DEV))
+    torch.testing.assert_close(got.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=2e-6)
+    for name, x, y in zip("apb", got_in, ref_in):
+        scale = float(y.grad.abs().max()) + 1e-30
+        torch.testing.assert_close(x.grad.cpu().double(), y.grad, rtol=1e-5, atol=2e-6 * max(scale, 1.0), msg=lambda s_: f"d{name}: {s_}")
+    no_bias = bip_combine(a.to(DEV), p.to(DEV), deg.to(DEV), None)
+    torch.testing.assert_close(no_bias.cpu().double(), torch.nn.functional.elu(torch.addcmul(a.double(), deg.double().unsqueeze(1), p.double())), rtol=1e-5, atol=2e-6)
