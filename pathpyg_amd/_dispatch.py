@@ -32,7 +32,7 @@ def plain(t):
 
 
 def _stage(dev, *tensors):
-    return tuple(None if t is None else plain(t).to(dev) for t in tensors)
+    return tuple(t if (t is None or isinstance(t, str)) else plain(t).to(dev) for t in tensors)      # (str: the _hip.UNIT weight marker)
 
 
 def _back(like: torch.Tensor, *outs):
@@ -91,7 +91,7 @@ def unique_rows(rows, value_range=None):
 
 
 def coalesce(edge_index, weight, num_nodes: int, reduce: str = "sum", remap=None, want_inverse: bool = False, col_block=None):
-    dev = compute_device(edge_index, weight, remap)
+    dev = compute_device(edge_index, None if isinstance(weight, str) else weight, remap)
     ei, w, rm = _stage(dev, edge_index, weight, remap)
     if col_block is not None:
         col_block = (_stage(dev, col_block[0])[0], col_block[1])

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import torch
 
-from .. import _dispatch
+from .. import _dispatch, _hip
 from ..core.graph import Graph
 from ..data import Data
 
@@ -56,7 +56,7 @@ def aggregate_edge_index(
     ``inverse_idx`` (node id of every input row) and ``num_nodes``.
     """
     if edge_weight is None:
-        edge_weight = torch.ones(edge_index.size(1), device=edge_index.device)
+        edge_weight = _hip.UNIT          # the reference's torch.ones (:130-131) without the vector: a merged weight is its run length
     unique_nodes, inverse_idx = _dispatch.unique_rows(node_sequence)
     return _aggregate_with_known_nodes(edge_index, node_sequence.size(1), node_sequence, unique_nodes, inverse_idx, edge_weight, aggr)
 

@@ -93,7 +93,8 @@ class MultiOrderModel:
         if weight in data:
             edge_weight = data[weight]
         else:
-            edge_weight = torch.ones(edge_index.size(1), device=dev)
+            edge_weight = _hip_unit()        # the reference's torch.ones(m) (:150-151) as a marker: unit weights stay unit under the "src" lift,
+            #                                  and the weight of a merged edge is the length of its run (pp_coalesce_fill, no gather)
         first_order = torch.arange(n, device=dev).unsqueeze(1)
         chain = _LiftChain.first_order(edge_index, first_order, edge_weight, identity_nodes=True, num_first_order=n,
                                        want_pairs=max_order > 1)
@@ -102,7 +103,8 @@ class MultiOrderModel:
             m.layers[1].mapping = g.mapping
         if max_order > 1:
             ho_index = lift_order_temporal(g, delta) if event_graph is None else event_graph
-            chain = chain.to_second_order(edge_index, ho_index, aggregate_node_attributes(ho_index, edge_weight, "src"),
+            chain = chain.to_second_order(edge_index, ho_index,
+                                          edge_weight if isinstance(edge_weight, str) else aggregate_node_attributes(ho_index, edge_weight, "src"),
                                           save=cached or max_order == 2, want_edge_ids=max_order > 2)
             if cached or max_order == 2:
                 m.layers[2] = chain.graph
@@ -301,6 +303,11 @@ class MultiOrderModel:
         return out
 
 
+def _hip_unit() -> str:
+    from .._hip import UNIT
+    return UNIT
+
+
 class _LiftChain:
     """State of the order-k instance graph while climbing orders, WITHOUT per-instance node sequences.
 
@@ -367,8 +374,8 @@ class _LiftChain:
     def lift(self, aggr: str, save: bool, want_edge_ids: bool = False):
         from ..algorithms.lift_order import _aggregate_with_known_nodes
         num_instances = self.inv.numel()
-        if self.weight is None:
-            ho_index, weight = lift_order_edge_index(self.index, num_nodes=num_instances), None
+        if self.weight is None or (isinstance(self.weight, str) and aggr in ("src", "dst", "max", "mul")):      # (unit weights stay unit)
+            ho_index, weight = lift_order_edge_index(self.index, num_nodes=num_instances), self.weight
         else:
             ho_index, weight = lift_order_edge_index_weighted(self.index, self.weight, num_nodes=num_instances, aggr=aggr)
         last = aggregate_node_attributes(self.index, self.last, "dst")                 # last node of every new instance
