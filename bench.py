@@ -182,10 +182,11 @@ def gcn_backward_desc(ptr, idx, val, n_rows, n_self, d, m, self_coef, x, k, w, f
 def pmc_traffic(kernel_key: str, args) -> float | None:
     """HBM bytes per launch of a (kernel, graph) pair from the committed rocprofv3 --pmc passes (profiles/, separate FETCH_SIZE and
     WRITE_SIZE runs of this same command, gfx950 FETCH correction applied).  Only valid for the default workload at 1 GPU."""
+    pmc_traffic.source = None
     defaults = (10_000_000, 500_000, 10_000_000, 1_000_000, 64)
     if (args.events, args.nodes, args.span, args.delta, args.features) != defaults:
         return None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in PMC_TABLES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 table = json.load(fh)
@@ -193,10 +194,15 @@ def pmc_traffic(kernel_key: str, args) -> float | None:
             big = kernel_key.endswith("1.00e+07 rows")
             for key in ((short + ("@ho" if big else "@fo")), short):          # (kernels launched on one graph only have no @ split)
                 if key in table:
+                    pmc_traffic.source = "profiles/" + name
                     return float(table[key]["hbm_bytes_per_dispatch"])
         except (OSError, KeyError, ValueError):
             continue
     return None
+
+
+PMC_TABLES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+pmc_traffic.source = None
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -650,7 +656,10 @@ def main() -> int:
             gbs = b_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
             return {"kernel": key, "launches": n_, "avg_launch_ms": ms_ / max(n_, 1), "total_ms_per_step": ms_ / args.steps, "achieved": gbs,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic(key, args) if (with_traffic and world == 1) else None, "algorithmic_bytes_per_launch": b_ / max(n_, 1)}
+                    "traffic": pmc_traffic(key, args) if (with_traffic and world == 1) else None,
+                    # (`traffic` is NOT measured in this run: it is replayed from the committed rocprofv3 --pmc passes of this same command)
+                    "traffic_source": pmc_traffic.source if (with_traffic and world == 1) else None,
+                    "algorithmic_bytes_per_launch": b_ / max(n_, 1)}
         per_kernel = []
         for clock in (fwd_clock, bwd_clock, spmm_clock):
             for key, (n_, ms_, b_) in clock.groups().items():
