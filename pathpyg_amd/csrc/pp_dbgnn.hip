@@ -1232,6 +1232,113 @@ __global__ __launch_bounds__(64 * MB * KB, (MB * KB > 4 ? 4 : 3)) void k_weight_
     }
 }
 
+// The same contraction with the operands STAGED THROUGH LDS (round 3).  In k_weight_grad_blocks every wave fetches its two 256-byte column
+// slices itself: a 4-row step is 2 KB of L1 traffic per wave for 16 MFMAs, and with 4 waves per SIMD that is 64 bytes per clock and CU —
+// the whole L1 rate — for data of which only a quarter is distinct (slice bi is read by KB waves, slice bj by MB): 54 % of the fp32 matrix
+// peak at 256 x 256.  Here the workgroup copies each row stage (kWgRows rows of dH and X, distinct bytes only) into LDS once, double
+// buffered, one barrier per stage; the waves take their slices with ds_read_b128 (row stride padded by 16 bytes so that the four k-rows of
+// an MFMA step fall into different banks).
+#ifndef PP_WG_ROWS
+#define PP_WG_ROWS 8
+#endif
+constexpr int kWgRows = PP_WG_ROWS;                   // rows per LDS stage (a multiple of 4)
+
+template <int MB, int KB>
+__global__ __launch_bounds__(64 * MB * KB, (MB * KB > 4 ? 4 : 3)) void k_weight_grad_lds(const float* __restrict__ dH, const float* __restrict__ X, int64_t n_rows,
+                                                                  int64_t rows_per_group, float* __restrict__ partial,
+                                                                  float* __restrict__ partial_bias) {
+    constexpr int M = 64 * MB, K = 64 * KB, T = 64 * MB * KB, R = kWgRows;
+    constexpr int SA = M + 4, SB = K + 4;                  // padded row strides (floats)
+    constexpr int NA = R * M / 4, NB = R * K / 4;          // float4 per stage and matrix
+    constexpr int LA = (NA + T - 1) / T, LB = (NB + T - 1) / T;
+    __shared__ __attribute__((aligned(16))) float s_a[2][R * SA];
+    __shared__ __attribute__((aligned(16))) float s_b[2][R * SB];
+    const int lane = lane_id(), i = lane & 15, kq = lane >> 4;
+    const int wave = threadIdx.x >> 6, bi = wave / KB, bj = wave % KB;
+    const int64_t n_begin = (int64_t)blockIdx.x * rows_per_group;
+    int64_t n_end = n_begin + rows_per_group;
+    if (n_end > n_rows) n_end = n_rows;
+    using f32x4v = __attribute__((ext_vector_type(4))) float;
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[c][d] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float bias_acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 ra[LA], rb[LB];
+    auto gload = [&](int64_t n0) {
+#pragma unroll
+        for (int l = 0; l < LA; ++l) {
+            const int e = threadIdx.x + l * T;
+            const int row = e / (M / 4), c4 = e % (M / 4);
+            const int64_t n = n0 + row;
+            ra[l] = (e < NA && n < n_end) ? *(const float4*)(dH + n * M + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int l = 0; l < LB; ++l) {
+            const int e = threadIdx.x + l * T;
+            const int row = e / (K / 4), c4 = e % (K / 4);
+            const int64_t n = n0 + row;
+            rb[l] = (e < NB && n < n_end) ? *(const float4*)(X + n * K + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int l = 0; l < LA; ++l) {
+            const int e = threadIdx.x + l * T;
+            if (e < NA) *(float4*)(&s_a[buf][(e / (M / 4)) * SA + 4 * (e % (M / 4))]) = ra[l];
+        }
+#pragma unroll
+        for (int l = 0; l < LB; ++l) {
+            const int e = threadIdx.x + l * T;
+            if (e < NB) *(float4*)(&s_b[buf][(e / (K / 4)) * SB + 4 * (e % (K / 4))]) = rb[l];
+        }
+    };
+    gload(n_begin);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t n0 = n_begin; n0 < n_end; n0 += R) {
+        const bool more = n0 + R < n_end;
+        if (more) gload(n0 + R);                           // (in flight under the MFMAs of this stage)
+#pragma unroll
+        for (int u = 0; u < R / 4; ++u) {
+            const float4 a = *(const float4*)(&s_a[buf][(4 * u + kq) * SA + 64 * bi + 4 * i]);
+            const float4 b = *(const float4*)(&s_b[buf][(4 * u + kq) * SB + 64 * bj + 4 * i]);
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bias_acc[c] += av[c];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[d], acc[c][d], 0, 0, 0);
+            }
+        }
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* out = partial + (((int64_t)blockIdx.x * (MB * KB) + wave) << 12);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            *(float4*)(out + (4 * (4 * kq + reg) + c) * 64 + 4 * i) = make_float4(acc[c][0][reg], acc[c][1][reg], acc[c][2][reg], acc[c][3][reg]);
+    if (partial_bias && bj == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = bias_acc[c];
+            v += __shfl_xor(v, 16, kWave);
+            v += __shfl_xor(v, 32, kWave);
+            if (kq == 0) partial_bias[((int64_t)blockIdx.x * MB + bi) * 64 + 4 * i + c] = v;
+        }
+    }
+}
+
+#ifndef PP_WG_LDS_FROM
+#define PP_WG_LDS_FROM 4
+#endif
+constexpr int kWgLdsFrom = PP_WG_LDS_FROM;             // shapes with at least this many 64 x 64 blocks stage their operands through LDS
+
 // groups = workgroups resident at once (asked from the runtime once per shape), never more than the workspace formula provides
 template <int MB, int KB>
 static int launch_weight_grad_blocks(hipStream_t st, const float* dH, const float* X, int64_t n_rows, int64_t max_groups, float* partial,
@@ -1239,7 +1346,8 @@ static int launch_weight_grad_blocks(hipStream_t st, const float* dH, const floa
     static int resident = 0;
     if (resident == 0) {
         int per_cu = 0, dev = 0, cus = 0;
-        PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_weight_grad_blocks<MB, KB>, 64 * MB * KB, 0));
+        if (MB * KB >= kWgLdsFrom) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_weight_grad_lds<MB, KB>, 64 * MB * KB, 0));
+        else PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_weight_grad_blocks<MB, KB>, 64 * MB * KB, 0));
         PP_HIP(hipGetDevice(&dev));
         PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
@@ -1249,7 +1357,8 @@ static int launch_weight_grad_blocks(hipStream_t st, const float* dH, const floa
     if (groups > max_groups) groups = max_groups;
     const int64_t rows_per_group = ceil_div(ceil_div(n_rows > 0 ? n_rows : 1, groups), 4) * 4;
     groups = ceil_div(n_rows > 0 ? n_rows : 1, rows_per_group);
-    k_weight_grad_blocks<MB, KB><<<(unsigned)groups, 64 * MB * KB, 0, st>>>(dH, X, n_rows, rows_per_group, partial, partial_bias);
+    if (MB * KB >= kWgLdsFrom) k_weight_grad_lds<MB, KB><<<(unsigned)groups, 64 * MB * KB, 0, st>>>(dH, X, n_rows, rows_per_group, partial, partial_bias);
+    else k_weight_grad_blocks<MB, KB><<<(unsigned)groups, 64 * MB * KB, 0, st>>>(dH, X, n_rows, rows_per_group, partial, partial_bias);
     *groups_out = groups;
     return PP_OK;
 }
