@@ -1083,10 +1083,16 @@ constexpr int kWgSlices = 16;
 // 64 x 64 layers: the same contraction on v_mfma_f32_16x16x4_f32 with 16-byte operand loads.  Lane (i, kq) reads the four
 // consecutive columns 4i .. 4i+3 of row n + kq of dH and of X (one dwordx4 each: a load instruction covers four whole rows), and the
 // 16 MFMAs of a step pair every dH component c with every X component c': tile (c, c') accumulates dW[4*row + c][4*col + c'].
-__global__ __launch_bounds__(kBlock, 3) void k_weight_grad64(const float* __restrict__ dH, const float* __restrict__ X, int64_t n_rows,
+#ifndef PP_WG64_STEPS
+#define PP_WG64_STEPS 6
+#endif
+#ifndef PP_WG64_WAVES
+#define PP_WG64_WAVES 3
+#endif
+__global__ __launch_bounds__(kBlock, PP_WG64_WAVES) void k_weight_grad64(const float* __restrict__ dH, const float* __restrict__ X, int64_t n_rows,
                                                          int64_t rows_per_wave, float* __restrict__ partial,
                                                          float* __restrict__ partial_bias) {
-    constexpr int kSteps = 6;                              // 4-row steps per iteration, fetched in two half-batches
+    constexpr int kSteps = PP_WG64_STEPS;                  // 4-row steps per iteration, fetched in two half-batches
     const int lane = lane_id(), i = lane & 15, kq = lane >> 4;
     const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
     const int64_t n_begin = wave_global * rows_per_wave;
@@ -1408,7 +1414,11 @@ __global__ __launch_bounds__(kBlock) void k_weight_grad_reduce(const float* __re
 
 static inline int64_t weight_grad_waves(int64_t n_rows) {
     int64_t waves = ceil_div(n_rows, 2 * kWgUnroll * 8);        // at least 128 rows per wave
-    const int64_t cap = 256 * 4 * kWavesPerBlock;               // 4 workgroups per CU
+#ifndef PP_WG_CAP
+#define PP_WG_CAP 3
+#endif
+    // (k_weight_grad64 is resident at 3 workgroups per CU: a cap of 4 left a second, quarter-filled round — 1.11 -> 0.975 ms at 10^7 x 64 x 64)
+    const int64_t cap = 256 * PP_WG_CAP * kWavesPerBlock;       // workgroups per CU
     if (waves > cap) waves = cap;
     if (waves < 1) waves = 1;
     return ceil_div(waves, kWavesPerBlock) * kWavesPerBlock;
