@@ -322,8 +322,10 @@ def coalesce_steps(edge_index: torch.Tensor, weight, num_nodes: int, reduce: str
     if reduce not in _REDUCE:
         raise ValueError(f"unknown reduce {reduce}")
     ei = _edge_index(edge_index)
-    unit = isinstance(weight, str) and weight == UNIT
+    unit = isinstance(weight, str)
     if unit:
+        if weight != UNIT:
+            raise ValueError(f"edge weights must be a tensor, None or the marker {UNIT!r}, got {weight!r}")
         weight = None
     dev = require_device(ei, weight, remap)
     e = ei.size(1)
