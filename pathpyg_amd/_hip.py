@@ -17,7 +17,14 @@ _REDUCE = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3}
 DELTA_I64, DELTA_F32, DELTA_F64 = 0, 1, 2
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """hipStream_t of the current device's current stream (the raw handle: ~0.4 us instead of the ~2.7 us of building a Stream object —
+    a fifth of a shim call's host time, which is what small graphs and the per-rank step of a partitioned run are bound by)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
