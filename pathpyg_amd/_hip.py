@@ -842,7 +842,7 @@ def dense(a: torch.Tensor, weight: torch.Tensor, transposed: bool, bias: torch.T
     with torch.cuda.device(dev):
         out = torch.empty((n, q), dtype=torch.float32, device=dev)
         colsum = torch.empty(q, dtype=torch.float32, device=dev) if want_colsum else None
-        ws = _workspace(L.pp_wide_layer_ws_bytes(p, q), dev) if (not transposed and L.pp_dense_supported(p, q) == 3) else None
+        ws = _workspace(L.pp_wide_layer_ws_bytes(p, q), dev) if L.pp_dense_supported(p, q) == 3 else None       # (chunk-major / transposed W)
         check(L.pp_dense_f32(_p(a), _p(weight), 1 if transposed else 0, n, p, q, _p(bias), _p(grad_act), _p(colsum), _p(out), _p(ws),
                              0 if ws is None else ws.numel(), _stream()), "pp_dense_f32")
     return out, colsum

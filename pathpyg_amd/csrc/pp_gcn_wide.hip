@@ -411,6 +411,221 @@ static int launch_wide_pq(int P, int Q, hipStream_t st, const WideArgs& a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Dense mode of the wide layers as a plain LDS-staged GEMM (round 3):  Y[n, :Q] = epi( X[n, :P] . Wr[:Q, :P]^T ).
+// k_wide_layer keeps a wave's 16 x P tile in registers and streams W 16 output columns at a time: one workgroup barrier per 64 MFMAs of a
+// wave, an epilogue per chunk.  Here a 1024-thread workgroup owns 16 / (Q/64) row blocks x Q/64 column blocks (wave (rb, cb) = 16 or 32
+// rows x 64 columns, four accumulator tiles per row tile), the contraction runs in chunks of 32 (64 for the 128-column shapes): both operand
+// chunks are copied into LDS once per workgroup (weights from a chunk-major copy, rows permuted against bank conflicts; fetched two chunk
+// times ahead into two register sets, parked in the other LDS buffer one chunk time ahead, across row groups too), every wave takes its
+// operands with ds_read_b128 (lane (i, kq) contracts its own consecutive k of the chunk: the order inside a dot product is free), one barrier
+// per chunk, ONE epilogue per row group with 16-byte stores (column tile ct of lane i = column 4*i + ct).
+// Measured at 10^7 rows (tools/probes/dense_wide.py, ms before -> after): 256 x 256 13.84 -> 12.7 (103 TFLOP/s), 128 x 128 5.10 -> 3.31,
+// 256 -> 128 9.16 -> 6.08, 128 -> 256 8.42 -> 7.1, 64 -> 256 4.89 -> 4.15, 256 -> 64 5.61 -> 3.52.  What did NOT move it further (each built and
+// measured): conflict-free B rows, two row tiles per wave at 128 columns, the second prefetch stage, the chunk-major weights — the ISA of the
+// chunk loop is 32 back-to-back MFMAs, what is left is the workgroup barrier per chunk (64-wide chunks: +10 %).
+// chunk-major copy of the weights for k_dense_lds: Wc[c][q][kk] = (row q of Wr)[32*c + kk].  A chunk read straight from Wr touches 256 lines
+// that sit 1 KiB apart — a few L2 channels serve every CU at once; chunk-major it is one contiguous 32 KiB block.
+__global__ __launch_bounds__(kBlock) void k_chunk_major_w(const float* __restrict__ W, int P, int Q, int w_is_kq, int kc, float* __restrict__ out) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= P * Q) return;
+    const int c = e / (Q * kc), rem = e - c * (Q * kc), q = rem / kc, kk = rem - q * kc;
+    const int k = kc * c + kk;
+    out[e] = w_is_kq ? W[(size_t)k * Q + q] : W[(size_t)q * P + k];
+}
+
+constexpr int kGemmThreads = 1024;
+#ifndef PP_GEMM_KC
+#define PP_GEMM_KC 64
+#endif
+constexpr int kGemmChunk = 32;                       // contraction chunk of the 256-column shapes
+constexpr int kGemmChunkNarrow = PP_GEMM_KC;          // .. and of the 128-column shapes with P >= 128 (their LDS leaves room for 64: one barrier per
+                                                      // 64 MFMAs of a wave instead of 32 — 128 x 128 at 10^7 rows 3.70 -> 3.31 ms)
+
+#ifndef PP_GEMM_RT
+#define PP_GEMM_RT 2
+#endif
+constexpr int kGemmRowTiles = PP_GEMM_RT;             // 16-row tiles per wave: every B operand read from LDS feeds this many MFMAs
+
+template <int P, int Q, int kEpi>
+__global__ __launch_bounds__(kGemmThreads, 4) void k_dense_lds(const float* __restrict__ X, int64_t n_rows, const float* __restrict__ Wr,
+                                                             const float* __restrict__ bias, int act, float* __restrict__ Y,
+                                                             const float* __restrict__ act_in, float* __restrict__ colsum) {
+    constexpr int RT = Q == 256 ? kGemmRowTiles : 1, CB = Q / 64, RB = 16 / CB, ROWS = 16 * RT * RB, KC = (Q == 128 && P >= 128) ? kGemmChunkNarrow : kGemmChunk, NCH = P / KC,
+                  XS = KC + 4, WS = KC + 4, H = KC / 16;
+    constexpr int NX = ROWS * KC / 4, NW = Q * KC / 4;                  // float4 per chunk
+    constexpr int LX = (NX + kGemmThreads - 1) / kGemmThreads, LW = (NW + kGemmThreads - 1) / kGemmThreads;
+    __shared__ __attribute__((aligned(16))) float s_x[2][ROWS * XS];
+    __shared__ __attribute__((aligned(16))) float s_w[2][Q * WS];
+    const int lane = lane_id(), wave = threadIdx.x >> 6, i = lane & 15, kq = lane >> 4;
+    const int rb = wave / CB, cb = wave % CB;
+    const int64_t n_groups = (n_rows + ROWS - 1) / ROWS;
+    // two register sets for the chunks in flight: a chunk is fetched TWO chunk times before its MFMAs (its X rows come from HBM, ~2 us
+    // away; one chunk time is 1.7 us) and parked in LDS one chunk time before
+    float4 rx0[LX], rw0[LW], rx1[LX], rw1[LW];
+    auto gload = [&](float4 (&rx)[LX], float4 (&rw)[LW], int64_t grp, int c) {
+        const int64_t r0 = grp * ROWS;
+#pragma unroll
+        for (int l = 0; l < LX; ++l) {
+            const int e = threadIdx.x + l * kGemmThreads;
+            const int row = e / (KC / 4), k4 = e % (KC / 4);
+            const int64_t r = r0 + row;
+            rx[l] = (e < NX && r < n_rows) ? *(const float4*)(X + r * P + c * KC + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int l = 0; l < LW; ++l) {
+            const int e = threadIdx.x + l * kGemmThreads;
+            const int q = e / (KC / 4), k4 = e % (KC / 4);
+            rw[l] = e < NW ? *(const float4*)(Wr + (size_t)c * (Q * KC) + (size_t)q * KC + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);   // (Wr: chunk-major)
+        }
+    };
+    auto sstore = [&](const float4 (&rx)[LX], const float4 (&rw)[LW], int buf) {
+#pragma unroll
+        for (int l = 0; l < LX; ++l) {
+            const int e = threadIdx.x + l * kGemmThreads;
+            if (e < NX) *(float4*)(&s_x[buf][(e / (KC / 4)) * XS + 4 * (e % (KC / 4))]) = rx[l];
+        }
+#pragma unroll
+        for (int l = 0; l < LW; ++l) {
+            const int e = threadIdx.x + l * kGemmThreads;
+            // weight row q = 64*blk + 4*i' + ct goes to LDS row 64*blk + 16*ct + i': lane i of column tile ct reads rows a lane apart (no bank
+            // conflicts) and still owns 4 consecutive output columns
+            if (e < NW) {
+                const int q = e / (KC / 4);
+                const int row = (q & ~63) + 16 * (q & 3) + ((q & 63) >> 2);
+                *(float4*)(&s_w[buf][row * WS + 4 * (e % (KC / 4))]) = rw[l];
+            }
+        }
+    };
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kEpi == 0 && bias != nullptr) bias4 = *(const float4*)(bias + 64 * cb + 4 * i);
+    static_assert(NCH % 2 == 0, "chunks are walked in pairs (two register sets)");
+    if ((int64_t)blockIdx.x >= n_groups) return;
+    gload(rx0, rw0, blockIdx.x, 0);
+    sstore(rx0, rw0, 0);
+    gload(rx1, rw1, blockIdx.x, 1);
+    __syncthreads();
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        f32x4w acc[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4w{0.f, 0.f, 0.f, 0.f};
+        auto compute = [&](int buf) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                float4 a4[RT], b4[4];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a4[rt] = *(const float4*)(&s_x[buf][(16 * (RT * rb + rt) + i) * XS + (KC / 4) * kq + 4 * h]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) b4[ct] = *(const float4*)(&s_w[buf][(64 * cb + 16 * ct + i) * WS + (KC / 4) * kq + 4 * h]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float av = e == 0 ? a4[rt].x : (e == 1 ? a4[rt].y : (e == 2 ? a4[rt].z : a4[rt].w));
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) {
+                            const float bv = e == 0 ? b4[ct].x : (e == 1 ? b4[ct].y : (e == 2 ? b4[ct].z : b4[ct].w));
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[rt][ct], 0, 0, 0);
+                        }
+                    }
+            }
+        };
+        // chunk c (even) sits in LDS buffer 0, chunk c + 1 in registers set 1; (grp2, c2) = the chunk two ahead of the one being multiplied
+#pragma unroll 1
+        for (int c = 0; c < NCH; c += 2) {
+            {
+                const bool wrap = c + 2 >= NCH;
+                const int64_t g2 = wrap ? grp + gridDim.x : grp;
+                if (g2 < n_groups) gload(rx0, rw0, g2, wrap ? c + 2 - NCH : c + 2);
+                compute(0);
+                sstore(rx1, rw1, 1);                       // (chunk c + 1 always exists: NCH is even)
+                __syncthreads();
+            }
+            {
+                const bool wrap = c + 3 >= NCH;
+                const int64_t g3 = wrap ? grp + gridDim.x : grp;
+                const bool more = (wrap ? grp + gridDim.x : grp) < n_groups;
+                if (g3 < n_groups) gload(rx1, rw1, g3, wrap ? c + 3 - NCH : c + 3);
+                compute(1);
+                if (c + 2 < NCH || more) sstore(rx0, rw0, 0);
+                __syncthreads();
+            }
+        }
+        // epilogue of the row group: lane (i, kq) owns rows 16*(RT*rb + rt) + 4*kq + reg and the four consecutive columns 64*cb + 4*i ..
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t r = grp * ROWS + 16 * (RT * rb + rt) + 4 * kq + reg;
+                if (r >= n_rows) continue;
+                float v[4] = {acc[rt][0][reg], acc[rt][1][reg], acc[rt][2][reg], acc[rt][3][reg]};
+                if constexpr (kEpi == 0) {
+                    const float bb[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        pp_f32x2 p = {v[e] + bb[e], v[e + 1] + bb[e + 1]};
+                        const pp_f32x2 q = elu_fast2(p);
+                        v[e] = act ? q[0] : p[0];
+                        v[e + 1] = act ? q[1] : p[1];
+                    }
+                } else {
+                    if (act) {
+                        const float4 g4 = *(const float4*)(act_in + r * Q + 64 * cb + 4 * i);
+                        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= g[e] > 0.f ? 1.f : g[e] + 1.f;       // ELU'(pre) from the stored activation
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) csum[e] += v[e];
+                }
+                *(float4*)(Y + r * Q + 64 * cb + 4 * i) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    }
+    if constexpr (kEpi == 1) {
+        if (colsum != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = csum[e];
+                v += __shfl_xor(v, 16, kWave);
+                v += __shfl_xor(v, 32, kWave);
+                if (kq == 0) atomicAdd(&colsum[64 * cb + 4 * i + e], v);
+            }
+        }
+    }
+}
+
+template <int P, int Q, int kEpi>
+static int launch_gemm(hipStream_t st, const WideArgs& a) {
+    constexpr int ROWS = 16 * (Q == 256 ? kGemmRowTiles : 1) * (16 / (Q / 64));
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        PP_HIP(hipGetDevice(&dev));
+        PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (cus <= 0) cus = 256;
+    }
+    int64_t blocks = ceil_div(a.n_rows, ROWS);
+    if (blocks > cus) blocks = cus;                       // one 1024-thread workgroup (74 - 92 KB of LDS) per CU
+    k_dense_lds<P, Q, kEpi><<<(unsigned)blocks, kGemmThreads, 0, st>>>(a.X, a.n_rows, a.Wr, a.bias, a.act, a.Y, a.act_in, a.colsum);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+template <int kEpi>
+static int launch_gemm_pq(int P, int Q, hipStream_t st, const WideArgs& a) {
+#define PP_GEMM(PP_, QQ_) if (P == PP_ && Q == QQ_) return launch_gemm<PP_, QQ_, kEpi>(st, a)
+    PP_GEMM(64, 128); PP_GEMM(64, 256); PP_GEMM(128, 64); PP_GEMM(128, 128); PP_GEMM(128, 256); PP_GEMM(256, 64); PP_GEMM(256, 128); PP_GEMM(256, 256);
+#undef PP_GEMM
+    return PP_ERR_ARG;
+}
+
+#ifndef PP_GEMM_LDS
+#define PP_GEMM_LDS 1
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Narrow dense layers: one side small (a classifier head: 64 -> 8 or 256 -> 8 classes and its input gradient 8 -> 256; odd hidden widths):
 // the k_dense scheme (pp_dbgnn.hip) with both sides zero-padded to the next of 16/32/64/128/256 (padded P*Q <= 4096: the weight block
 // lives in P*Q/64 registers per lane) and guarded scalar I/O on the true widths.
@@ -536,6 +751,16 @@ int pp_wide_layer_f32(const int32_t* ptr, const int32_t* idx, const float* val, 
     PP_REQUIRE(heavy_slot == nullptr || heavy_sum != nullptr, PP_ERR_ARG, "pp_wide_layer_f32: heavy_slot without heavy_sum");
     if (colsum) PP_HIP(hipMemsetAsync(colsum, 0, (size_t)Q * sizeof(float), st));
     if (n_rows == 0) return PP_OK;
+    if (PP_GEMM_LDS && ptr == nullptr && agg_out == nullptr && n_self == n_rows && ws != nullptr && ws_bytes >= pp_wide_layer_ws_bytes(P, Q) &&
+        ((uintptr_t)Y | (uintptr_t)act_in | (uintptr_t)bias | (uintptr_t)ws) % 16 == 0) {
+        // dense mode: the LDS-staged GEMM on a chunk-major copy of the weights (either orientation of W)
+        pp::k_chunk_major_w<<<(unsigned)pp::ceil_div((int64_t)P * Q, pp::kBlock), pp::kBlock, 0, st>>>(W, P, Q, w_is_kq,
+                                                                                                      (Q == 128 && P >= 128) ? pp::kGemmChunkNarrow : pp::kGemmChunk, (float*)ws);
+        PP_LAUNCH_CHECK();
+        const pp::WideArgs a{nullptr, nullptr, nullptr, n_rows, n_self, X, nullptr, (const float*)ws, bias, act, pp::HeavyRows{nullptr, nullptr}, nullptr, Y,
+                             act_in, colsum};
+        return epilogue == 0 ? pp::launch_gemm_pq<0>(P, Q, st, a) : pp::launch_gemm_pq<1>(P, Q, st, a);
+    }
     const float* wr = W;
     if (w_is_kq) {              // W is [P, Q] (k-major, the input-gradient case): the kernel wants one row per output column
         PP_REQUIRE(ws != nullptr && ws_bytes >= pp_wide_layer_ws_bytes(P, Q), PP_ERR_WORKSPACE, "pp_wide_layer_f32: workspace too small");
