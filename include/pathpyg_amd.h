@@ -131,7 +131,7 @@ int pp_unique_rows_fill(const int64_t* rows, int64_t n_rows, int k, int64_t n_un
 /* coalesce(remap[edge_index], edge_attr, num_nodes, reduce), src/pathpyG/algorithms/lift_order.py:135-144.
  * remap may be NULL (edges already hold node ids).  _count -> {A, status}; _fill writes out_index [2,A]
  * sorted by (row, col) and the reduced weights (weight may be NULL; weight NULL with out_weight given = UNIT weights, the reference's
- * default `torch.ones` (lift_order.py:130-131): out_weight = run length for sum, 1 otherwise, in `dtype`, without the per-instance gather).
+ * default `torch.ones` (lift_order.py:130-131): out_weight (float32 [A], whatever `dtype` says) = run length for sum, 1 otherwise, without the per-instance gather).
  * col_base [num_nodes] / col_bits (NULL / 0 = off; pass the same pair to _count and _fill): the caller knows that every column of row r
  * lies in [col_base[r], col_base[r] + 2^col_bits) - true for De Bruijn layers, where the successors of a node form one
  * contiguous id block - and the sort key shrinks from 2*bits(num_nodes) to bits(num_nodes) + col_bits bits (fewer radix passes);
