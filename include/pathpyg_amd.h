@@ -288,7 +288,9 @@ int pp_dense_f32(const float* A, const float* W, int w_transposed, int64_t n_row
 
 /* Mean softmax cross-entropy of logits [n,C] (C <= 64) against int64 targets [n] and its gradient dlogits [n,C] (may be NULL) in
  * one pass - the loss of the train step bench.py times (the reference ships no training loop). */
-int pp_cross_entropy_f32(const float* logits, const int64_t* target, int64_t n, int C, float* loss, float* dlogits, pp_stream_t stream);
+size_t pp_cross_entropy_ws_bytes(void);       /* per-workgroup partial sums, added in a fixed order: the loss is bitwise reproducible */
+int pp_cross_entropy_f32(const float* logits, const int64_t* target, int64_t n, int C, float* loss, float* dlogits, void* ws, size_t ws_bytes,
+                         pp_stream_t stream);
 
 /* Whole backward of a dense layer y = x W^T (+ b) in one pass over dH [N,M] and x [N,K] (W is [M,K]; M, K in {16,32,64}):
  *   d_in[N,K] = (dH . W) (*) ELU'(x) when fuse_act (x is then the stored activation of the layer below), colsum_in[K] = its column

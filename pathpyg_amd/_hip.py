@@ -972,7 +972,9 @@ def cross_entropy(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = 
     with torch.cuda.device(dev):
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         grad = torch.empty_like(logits) if want_grad else None
-        check(lib().pp_cross_entropy_f32(_p(logits), _p(target), n, c, _p(loss), _p(grad), _stream()), "pp_cross_entropy_f32")
+        L = lib()
+        ws = _workspace(L.pp_cross_entropy_ws_bytes(), dev)
+        check(L.pp_cross_entropy_f32(_p(logits), _p(target), n, c, _p(loss), _p(grad), _p(ws), ws.numel(), _stream()), "pp_cross_entropy_f32")
     return loss[0], grad
 
 

@@ -1653,7 +1653,7 @@ namespace pp {
 
 template <int kMaxC>
 __global__ __launch_bounds__(kBlock) void k_cross_entropy(const float* __restrict__ logits, const int64_t* __restrict__ target, int64_t n, int C,
-                                                         float inv_n, float* __restrict__ loss, float* __restrict__ dlogits) {
+                                                         float inv_n, float* __restrict__ partial, float* __restrict__ dlogits) {
     __shared__ float s_part[kWavesPerBlock];
     float local = 0.f;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -1691,7 +1691,23 @@ __global__ __launch_bounds__(kBlock) void k_cross_entropy(const float* __restric
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < kWavesPerBlock; ++w) t += s_part[w];
-        atomicAdd(loss, t * inv_n);
+        partial[blockIdx.x] = t * inv_n;                      // (summed in a fixed order by k_sum_partials: the loss is bitwise reproducible)
+    }
+}
+
+// out[0] = sum of partial[0..n) in a fixed order (thread j takes j, j + 256, ..; fixed-shape tree over the threads)
+__global__ __launch_bounds__(kBlock) void k_sum_partials(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float s_part[kWavesPerBlock];
+    float t = 0.f;
+    for (int j = threadIdx.x; j < n; j += kBlock) t += partial[j];
+    t = wave_sum(t);
+    if (lane_id() == 0) s_part[wave_id()] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) v += s_part[w];
+        out[0] = v;
     }
 }
 
@@ -1699,18 +1715,28 @@ __global__ __launch_bounds__(kBlock) void k_cross_entropy(const float* __restric
 
 extern "C" {
 
+size_t pp_cross_entropy_ws_bytes(void) { return pp::align_up((size_t)pp::kMaxGrid * sizeof(float)); }
+
 // loss[0] = mean cross-entropy of logits [n, C] against int64 targets [n]; dlogits [n, C] (may be NULL) = its gradient.  C <= 64.
-int pp_cross_entropy_f32(const float* logits, const int64_t* target, int64_t n, int C, float* loss, float* dlogits, pp_stream_t stream) {
+// ws (pp_cross_entropy_ws_bytes()): per-workgroup partial sums, added in a fixed order — the loss is bitwise reproducible.
+int pp_cross_entropy_f32(const float* logits, const int64_t* target, int64_t n, int C, float* loss, float* dlogits, void* ws, size_t ws_bytes,
+                         pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     PP_REQUIRE(n >= 0 && C >= 1 && C <= 64, PP_ERR_ARG, "pp_cross_entropy_f32: needs 1 <= C <= 64 (got %d)", C);
-    PP_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
-    if (n == 0) return PP_OK;
+    PP_REQUIRE(ws != nullptr && ws_bytes >= pp_cross_entropy_ws_bytes(), PP_ERR_WORKSPACE, "pp_cross_entropy_f32: workspace too small");
+    if (n == 0) {
+        PP_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+        return PP_OK;
+    }
     int64_t g = pp::ceil_div(n, pp::kBlock);
     if (g > pp::kMaxGrid) g = pp::kMaxGrid;
     const float inv_n = 1.0f / (float)n;
-    if (C <= 8) pp::k_cross_entropy<8><<<(unsigned)g, pp::kBlock, 0, st>>>(logits, target, n, C, inv_n, loss, dlogits);
-    else if (C <= 16) pp::k_cross_entropy<16><<<(unsigned)g, pp::kBlock, 0, st>>>(logits, target, n, C, inv_n, loss, dlogits);
-    else pp::k_cross_entropy<64><<<(unsigned)g, pp::kBlock, 0, st>>>(logits, target, n, C, inv_n, loss, dlogits);
+    float* partial = (float*)ws;
+    if (C <= 8) pp::k_cross_entropy<8><<<(unsigned)g, pp::kBlock, 0, st>>>(logits, target, n, C, inv_n, partial, dlogits);
+    else if (C <= 16) pp::k_cross_entropy<16><<<(unsigned)g, pp::kBlock, 0, st>>>(logits, target, n, C, inv_n, partial, dlogits);
+    else pp::k_cross_entropy<64><<<(unsigned)g, pp::kBlock, 0, st>>>(logits, target, n, C, inv_n, partial, dlogits);
+    PP_LAUNCH_CHECK();
+    pp::k_sum_partials<<<1, pp::kBlock, 0, st>>>(partial, (int)g, loss);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

@@ -408,3 +408,67 @@ def test_config4_100m_events_k2_to_k5_lift_properties(pp):
             later |= equal & (ns[1:, c] > ns[:-1, c])
             equal &= ns[1:, c] == ns[:-1, c]
         assert bool(later.all())
+
+
+def test_config4_f256_property_run_above_10m_events():
+    """BASELINE configs[4] width (F = 256) ABOVE 10^7 events — 2*10^7 events, 10^6 nodes, ~2*10^7 higher-order nodes, 20 GB matrices (64-bit row
+    offsets in every gather) — where no float64 twin fits beside the step.  Size-independent properties instead: the two independent host
+    paths (MultiOrderModel + DBGNN.forward with its own plans / build_dbgnn_shard + ShardedDBGNN) agree on logits, loss and every gradient
+    within the fp32 bar; the step is bitwise reproducible; the loss is the cross-entropy of the logits; everything is finite."""
+    import pathpyg_amd as pp
+    from oracle import dbgnn as od
+    from pathpyg_amd import distributed as pd
+    n, m, delta, f, classes = 1_000_000, 20_000_000, 1_000_000, 256, 8
+    ei, t = _stream(5, m, n, 10_000_000)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=n))
+    del ei, t
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    params = od.init_params(classes, (f, f), [f, f, f], seed=9)
+    y = torch.randint(0, classes, (n,), generator=gen, device=DEV)
+
+    def api_step():
+        model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=2)
+        n_ho = model.layers[2].n
+        fg = torch.Generator(device=DEV).manual_seed(10)
+        x, x_h = torch.randn(n, f, generator=fg, device=DEV), torch.randn(n_ho, f, generator=fg, device=DEV)
+        data = model.to_dbgnn_data(max_order=2, x=x, x_h=x_h)
+        net = pp.nn.DBGNN(num_classes=classes, num_features=(f, f), hidden_dims=[f, f, f]).to(DEV)
+        net.load_state_dict(params)
+        out = net(data)
+        loss = pp.nn.dbgnn.cross_entropy(out, y)
+        loss.backward()
+        res = (out.detach().clone(), loss.detach().clone(), {k: v.grad.detach().clone() for k, v in net.named_parameters()}, n_ho)
+        del out, loss, net, data, model, x, x_h
+        torch.cuda.empty_cache()
+        return res
+
+    out_a, loss_a, grads_a, n_ho = api_step()
+    assert n_ho > 15_000_000 and n_ho * f * 4 > 2 ** 32                  # (the kWide forms of the gathers are what runs)
+    assert bool(torch.isfinite(out_a).all()) and bool(torch.isfinite(loss_a))
+    want_loss = torch.nn.functional.cross_entropy(out_a.double(), y)
+    torch.testing.assert_close(loss_a.double(), want_loss, rtol=1e-5, atol=1e-6)
+    out_b, loss_b, grads_b, _ = api_step()                                # bitwise reproducible
+    assert torch.equal(out_a, out_b) and torch.equal(loss_a, loss_b)
+    for name in grads_a:
+        if name.endswith("weight"):                                       # weight gradients: per-workgroup partials, fixed-order reduction
+            assert torch.equal(grads_a[name], grads_b[name]), name
+        else:                                                             # bias gradients: column sums folded with float atomics
+            torch.testing.assert_close(grads_a[name], grads_b[name], rtol=1e-5, atol=1e-6 * float(grads_a[name].abs().max()), msg=lambda s_: f"{name}: {s_}")
+    del out_b, grads_b
+    # the partition path at world size 1: its own orchestration (unit-weight coalesce, plans from the shard builder, deferred plan report)
+    comm = pd.Comm()
+    fg = torch.Generator(device=DEV).manual_seed(10)
+    x, x_h = torch.randn(n, f, generator=fg, device=DEV), torch.randn(n_ho, f, generator=fg, device=DEV)
+    shard = pd.build_dbgnn_shard(g, delta, x, x_h, y, comm)
+    net = pp.nn.DBGNN(num_classes=classes, num_features=(f, f), hidden_dims=[f, f, f]).to(DEV)
+    net.load_state_dict(params)
+    sharded = pd.ShardedDBGNN(net, comm)
+    out_c = sharded(shard)
+    assert_embeddings_close(out_c, out_a, what="partition path vs API path")
+    loss_c = sharded.loss(shard)
+    loss_c.backward()
+    torch.testing.assert_close(loss_c.detach(), loss_a, rtol=1e-5, atol=1e-6)
+    for name, p_ in net.named_parameters():
+        gs = float(grads_a[name].abs().max()) + 1e-30
+        torch.testing.assert_close(p_.grad, grads_a[name], rtol=1e-4, atol=1e-4 * gs, msg=lambda s_: f"{name}: {s_}")
+        assert bool(torch.isfinite(p_.grad).all()), name
