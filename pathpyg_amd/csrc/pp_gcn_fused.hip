@@ -196,8 +196,13 @@ struct TileGather {
 // takes 64 KB of LDS there: one workgroup of 8 waves per CU).  kEpi 0: Y = act(tile . W^T + bias), W [Q,P] (the layer, forward).
 // kEpi 1: Y = (tile . W) (*) ELU'(act_in), W [P,Q], + column sums: the INPUT GRADIENT of a layer over the transposed graph (X = dpre) for
 // the widths whose weight gradient does not fit beside it in registers (pp_gcn_input_grad_f32).
+#ifndef PP_FWD_WAVES
+#define PP_FWD_WAVES 4
+#endif
 template <int P, int Q, bool kHeavy, bool kWide, int kThreads = kGcnThreads, int kEpi = 0, bool kDrop = false>
-__global__ __launch_bounds__(kThreads) void k_gcn_forward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+// (64 x 64: capped at 128 registers = 4 waves per SIMD — 126 VGPRs, no accumulator AGPRs, no spills; at the 146 registers the compiler
+// takes when left alone the kernel runs 3 waves per SIMD and the layer is 6 % slower: 1.77 -> 1.66 ms at 10^7 rows)
+__global__ __launch_bounds__(kThreads, (kThreads == 256 && P == 64 && Q == 64) ? PP_FWD_WAVES : 1) void k_gcn_forward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                               const float* __restrict__ val, int64_t n_rows, const float* __restrict__ X,
                                                               const float* __restrict__ self_coef, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int act, HeavyRows heavy,
@@ -531,8 +536,11 @@ static inline bool gcn_wide_shape(int P, int Q) {
 //     d_in   = (G . W) (*) ELU'(x),  colsum_in = column sums    gradient w.r.t. the PRE-activation of the layer below + its bias gradient
 //     dW     = G^T x                                             contraction over the tile's rows on a second MFMA stream
 // Saves the write and the re-read of G (2 of the 7 N x 64 matrix passes of the two-kernel form).
+#ifndef PP_BWD_WAVES
+#define PP_BWD_WAVES 1
+#endif
 template <int M, int K, bool kHeavy, bool kWide, bool kDrop = false>
-__global__ __launch_bounds__(kGcnThreads) void k_gcn_backward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+__global__ __launch_bounds__(kGcnThreads, (M == 64 && K == 64) ? PP_BWD_WAVES : 1) void k_gcn_backward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                              const float* __restrict__ val, int64_t n_rows, const float* __restrict__ D,
                                                              const float* __restrict__ self_coef, const float* __restrict__ X,
                                                              const float* __restrict__ W, int fuse_act, HeavyRows heavy, float* __restrict__ d_in,
