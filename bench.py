@@ -171,7 +171,7 @@ def gcn_forward_desc(ptr, idx, val, n_rows, n_src, x, p, self_coef, w, q, bias, 
     return (f"k_gcn_forward<{p},{q}> (pp_gcn_forward_f32), {_rows_label(n_rows)}", total)
 
 
-def gcn_backward_desc(ptr, idx, val, n_rows, n_self, d, m, self_coef, x, k, w, fuse_act, heavy_slot, heavy_sum, d_in, colsum, dw, ws, ws_bytes,
+def gcn_backward_desc(ptr, idx, val, n_rows, n_self, nnz_hint, d, m, self_coef, x, k, w, fuse_act, heavy_slot, heavy_sum, d_in, colsum, dw, ws, ws_bytes,
                       *drop_and_stream):
     """pp_gcn_backward_f32: CSR, dpre (M wide) and the layer input (K wide) read once, the input gradient (K wide) written once."""
     nnz = CSR_SHAPE.get(idx, 0)
@@ -601,7 +601,7 @@ def main() -> int:
 
     with KernelClock(L, "pp_spmm_f32", spmm_desc) as spmm_clock, \
             KernelClock(L, "pp_gcn_forward_drop_f32", gcn_forward_desc) as fwd_clock, \
-            KernelClock(L, "pp_gcn_backward_drop_f32", gcn_backward_desc) as bwd_clock, \
+            KernelClock(L, "pp_gcn_backward_nnz_f32", gcn_backward_desc) as bwd_clock, \
             KernelClock(L, "pp_temporal_fill", lambda m, n, total, *r: ("k_expand (pp_temporal_fill)", 16 * total + 12 * m)) as fill_clock, \
             KernelClock(L, "pp_temporal_count", lift_desc, until="pp_temporal_fill") as lift_clock, \
             KernelClock(L, "pp_coalesce_count", coalesce_desc, until="pp_coalesce_fill") as agg_clock:

@@ -348,6 +348,12 @@ int pp_gcn_backward_drop_f32(const int32_t* ptr, const int32_t* idx, const float
                              const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
                              const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, double drop_p,
                              int64_t drop_seed, int64_t drop_tag, int64_t drop_row0, pp_stream_t stream);
+/* The same call with the number of CSR entries, when the caller knows it (nnz < 0: unknown): graphs with short rows (nnz <= 8 n_rows, a
+ * De Bruijn layer) run a register-capped variant of the 64 x 64 kernel (3 waves per SIMD); long-row graphs keep the 2-wave one. */
+int pp_gcn_backward_nnz_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, int64_t nnz, const float* D, int M,
+                            const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
+                            const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, double drop_p,
+                            int64_t drop_seed, int64_t drop_tag, int64_t drop_row0, pp_stream_t stream);
 int pp_gcn_input_grad_drop_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, const float* D, int M,
                                const float* self_coef, const float* W, int K, const float* X_act, int fuse_act, const int32_t* heavy_slot,
                                const float* heavy_sum, float* d_in, float* colsum_in, void* ws, size_t ws_bytes, double drop_p, int64_t drop_seed,

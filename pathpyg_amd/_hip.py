@@ -927,9 +927,9 @@ def gcn_backward(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, x: t
         dw = torch.empty((m, k), **f32)
         slot, sums = _heavy_args(heavy, idx, val, dpre)
         ws = _workspace(L.pp_gcn_backward_ws_bytes(n_rows), dev)
-        check(L.pp_gcn_backward_drop_f32(_p(ptr), _p(idx), _p(val), n_rows, n_self, _p(dpre), m, _p(self_coef), _p(x), k, _p(weight),
-                                         1 if fuse_act else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _p(dw), _p(ws), ws.numel(), dp, dseed, dtag,
-                                         drow0, _stream()), "pp_gcn_backward_drop_f32")
+        check(L.pp_gcn_backward_nnz_f32(_p(ptr), _p(idx), _p(val), n_rows, n_self, int(idx.numel()), _p(dpre), m, _p(self_coef), _p(x), k, _p(weight),
+                                        1 if fuse_act else 0, _p(slot), _p(sums), _p(d_in), _p(colsum), _p(dw), _p(ws), ws.numel(), dp, dseed, dtag,
+                                        drow0, _stream()), "pp_gcn_backward_nnz_f32")
     return d_in, colsum, dw
 
 

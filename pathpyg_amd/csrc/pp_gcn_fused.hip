@@ -31,10 +31,10 @@ constexpr int kGcnWaves = kGcnThreads / kWave;
 // full).  Per tile ONE coalesced load each brings the 17 row pointers, the 16 self coefficients (both one tile ahead) and the first 4 and
 // the next 4 (index, value) pairs of all 16 rows (lane 4*row + slot); the lane groups take them with ds_bpermute.  Rows with more than 8
 // neighbours continue chunk-wise.
-template <int P, bool kHeavy>
+template <int P, bool kHeavy, int kBatchOverride = 0>
 struct TileGather {
     static constexpr int kLanes = P / 4, kGroups = kWave / kLanes, kRows = 16 / kGroups, TS = P + 4;
-    static constexpr int kBatch = kRows < 2 ? kRows : (kRows >= 8 ? 4 : 2);      // 128-wide rows: registers to spare for a deeper gather
+    static constexpr int kBatch = kBatchOverride > 0 ? kBatchOverride : (kRows < 2 ? kRows : (kRows >= 8 ? 4 : 2));      // 128-wide rows: registers to spare for a deeper gather
     static constexpr int kShift = P == 16 ? 6 : (P == 32 ? 7 : (P == 64 ? 8 : 9));      // log2(row bytes)
     buf_t rs_x, rs_ptr, rs_self, rs_slot;
     const int32_t* idx;
@@ -536,11 +536,36 @@ static inline bool gcn_wide_shape(int P, int Q) {
 //     d_in   = (G . W) (*) ELU'(x),  colsum_in = column sums    gradient w.r.t. the PRE-activation of the layer below + its bias gradient
 //     dW     = G^T x                                             contraction over the tile's rows on a second MFMA stream
 // Saves the write and the re-read of G (2 of the 7 N x 64 matrix passes of the two-kernel form).
+// natural-layout rows of the layer input: B operand of the dW stream and source of the ELU' epilogue.  Lane (i, kq) owns rows 4*kq .. 4*kq+3 of
+// the tile and the CT consecutive columns CT*i ..: one vector load per row.
+#define PP_LOAD_XR \
+        _Pragma("unroll") \
+        for (int reg = 0; reg < 4; ++reg) { \
+            const int64_t r = t * 16 + 4 * kq + reg; \
+            const float* xp = X + r * K + CT * i; \
+            if constexpr (CT == 4) { \
+                const float4 v = r < n_rows ? *(const float4*)xp : make_float4(0.f, 0.f, 0.f, 0.f); \
+                xr[0][reg] = v.x; xr[1][reg] = v.y; xr[2][reg] = v.z; xr[3][reg] = v.w; \
+            } else { \
+                _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) xr[ct][reg] = r < n_rows ? xp[ct] : 0.f; \
+            } \
+        }
+
+// 64 x 64 (round 3): capped at 170 registers = 3 waves per SIMD, with the natural-layout X rows fetched AFTER the gather (16 registers less
+// while the gather's loads are in flight; 19 spilled registers remain): 2.75 -> 2.64 ms per 10^7-row layer.  Left alone the kernel takes
+// 158 VGPRs + 80 AGPRs (2 waves); the cap without the late fetch spills 41 registers (3.25 ms); one gather row per batch spills none and
+// gains nothing (2.75 ms).
 #ifndef PP_BWD_WAVES
-#define PP_BWD_WAVES 1
+#define PP_BWD_WAVES 3
 #endif
-template <int M, int K, bool kHeavy, bool kWide, bool kDrop = false>
-__global__ __launch_bounds__(kGcnThreads, (M == 64 && K == 64) ? PP_BWD_WAVES : 1) void k_gcn_backward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+#ifndef PP_BWD_LATE_X
+#define PP_BWD_LATE_X 1
+#endif
+#ifndef PP_BWD_BATCH
+#define PP_BWD_BATCH 0
+#endif
+template <int M, int K, bool kHeavy, bool kWide, bool kDrop = false, bool kCap = false>
+__global__ __launch_bounds__(kGcnThreads, (M == 64 && K == 64 && kCap) ? PP_BWD_WAVES : 1) void k_gcn_backward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                              const float* __restrict__ val, int64_t n_rows, const float* __restrict__ D,
                                                              const float* __restrict__ self_coef, const float* __restrict__ X,
                                                              const float* __restrict__ W, int fuse_act, HeavyRows heavy, float* __restrict__ d_in,
@@ -570,24 +595,11 @@ __global__ __launch_bounds__(kGcnThreads, (M == 64 && K == 64) ? PP_BWD_WAVES : 
     const int64_t n_tiles = (n_rows + 15) / 16;
     const int64_t step = (int64_t)gridDim.x * kGcnWaves;
     // gather stage as in k_gcn_forward: buffer loads + ds_bpermute (TileGather) unless D is 4 GiB or larger (kWide)
-    [[maybe_unused]] TileGather<M, kHeavy> gather(D, ptr, idx, val, self_coef, heavy, n_rows, n_self);
+    [[maybe_unused]] TileGather<M, kHeavy, (M == 64 && K == 64 && kCap) ? PP_BWD_BATCH : 0> gather(D, ptr, idx, val, self_coef, heavy, n_rows, n_self);
     if constexpr (!kWide) gather.prefetch((int64_t)blockIdx.x * kGcnWaves + wave);
     for (int64_t t = (int64_t)blockIdx.x * kGcnWaves + wave; t < n_tiles; t += step) {
-        // natural-layout rows of the layer input: B operand of the dW stream and source of the ELU' epilogue (in flight during the gather)
-        // lane (i, kq) owns rows 4*kq .. 4*kq+3 of the tile and the CT consecutive columns CT*i ..: one vector load per row
         float xr[CT][4];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int64_t r = t * 16 + 4 * kq + reg;
-            const float* xp = X + r * K + CT * i;
-            if constexpr (CT == 4) {
-                const float4 v = r < n_rows ? *(const float4*)xp : make_float4(0.f, 0.f, 0.f, 0.f);
-                xr[0][reg] = v.x; xr[1][reg] = v.y; xr[2][reg] = v.z; xr[3][reg] = v.w;
-            } else {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) xr[ct][reg] = r < n_rows ? xp[ct] : 0.f;
-            }
-        }
+        if constexpr (!(kCap && PP_BWD_LATE_X)) { PP_LOAD_XR }        // (in flight during the gather)
         if constexpr (kWide) {
             const int64_t r0 = t * 16 + g * kRows;
             int p[kRows + 1];
@@ -677,6 +689,7 @@ __global__ __launch_bounds__(kGcnThreads, (M == 64 && K == 64) ? PP_BWD_WAVES : 
         } else {
             gather.run(t, t + step, tile, nullptr);
         }
+        if constexpr (kCap && PP_BWD_LATE_X) { PP_LOAD_XR }         // (capped variant: fetched AFTER the gather, 16 registers less while its loads are in flight)
         __builtin_amdgcn_wave_barrier();
         // ---------------------------------------------------------------- G . W  ->  d_in tile
         float4 a[KQ / 4];
@@ -776,12 +789,17 @@ constexpr int64_t kGcnBackwardMaxBlocks = 256 * 4;
 template <int M, int K>
 static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
                                const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy, bool wide,
-                               float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out, int64_t n_self, DropSite drop) {
-    static int resident_of[2] = {0, 0};
-    const int hv = heavy.slot != nullptr ? 1 : 0;
+                               float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out, int64_t n_self, DropSite drop, bool cap) {
+    // cap: the register-capped variant (3 waves per SIMD, 64 x 64 only) — faster where rows are short (a De Bruijn layer: ~2 neighbours per
+    // row, 2.72 -> 2.60 ms at 10^7 rows), slower on long rows (the 20-neighbour first-order graph: 0.61 -> 0.70 ms); the caller decides
+    // from the average row length
+    cap = cap && M == 64 && K == 64 && !wide && heavy.slot == nullptr && drop.thr == 0u;
+    static int resident_of[3] = {0, 0, 0};
+    const int hv = cap ? 2 : (heavy.slot != nullptr ? 1 : 0);
     if (resident_of[hv] == 0) {
         int per_cu = 0, dev = 0, cus = 0;
-        if (hv) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K, true, false>, kGcnThreads, 0));
+        if (hv == 2) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K, false, false, false, true>, kGcnThreads, 0));
+        else if (hv) PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K, true, false>, kGcnThreads, 0));
         else PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_backward<M, K, false, false>, kGcnThreads, 0));
         PP_HIP(hipGetDevice(&dev));
         PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -801,7 +819,10 @@ static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* p
             k_gcn_backward<M, K, H, WIDE, false><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in, \
                                                                                            colsum_in, partial_w, n_self, drop);         \
     } while (0)
-    if (heavy.slot != nullptr) { if (wide) PP_BWD(true, true); else PP_BWD(true, false); }
+    if (cap)
+        k_gcn_backward<M, K, false, false, false, true><<<(unsigned)blocks, kGcnThreads, 0, st>>>(ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, d_in,
+                                                                                                 colsum_in, partial_w, n_self, drop);
+    else if (heavy.slot != nullptr) { if (wide) PP_BWD(true, true); else PP_BWD(true, false); }
     else { if (wide) PP_BWD(false, true); else PP_BWD(false, false); }
 #undef PP_BWD
     return PP_OK;
@@ -810,11 +831,11 @@ static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* p
 template <int M>
 static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const int32_t* ptr, const int32_t* idx, const float* val, int64_t n,
                                  const float* D, const float* self_coef, const float* X, const float* W, int fuse_act, HeavyRows heavy, bool wide,
-                                 float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out, int64_t n_self, DropSite drop) {
+                                 float* d_in, float* colsum_in, float* partial_w, int64_t* blocks_out, int64_t n_self, DropSite drop, bool cap) {
     switch (K) {
-        case 16: return launch_gcn_backward<M, 16>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self, drop);
-        case 32: return launch_gcn_backward<M, 32>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self, drop);
-        case 64: return launch_gcn_backward<M, 64>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self, drop);
+        case 16: return launch_gcn_backward<M, 16>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self, drop, cap);
+        case 32: return launch_gcn_backward<M, 32>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self, drop, cap);
+        case 64: return launch_gcn_backward<M, 64>(n_tiles, st, ptr, idx, val, n, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, partial_w, blocks_out, n_self, drop, cap);
         default: return PP_ERR_ARG;
     }
 }
@@ -919,7 +940,16 @@ int pp_gcn_backward_drop_f32(const int32_t* ptr, const int32_t* idx, const float
                              const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
                              const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, double drop_p,
                              int64_t drop_seed, int64_t drop_tag, int64_t drop_row0, pp_stream_t stream) {
+    return pp_gcn_backward_nnz_f32(ptr, idx, val, n_rows, n_self, -1, D, M, self_coef, X, K, W, fuse_act, heavy_slot, heavy_sum, d_in, colsum_in, dW, ws,
+                                   ws_bytes, drop_p, drop_seed, drop_tag, drop_row0, stream);
+}
+
+int pp_gcn_backward_nnz_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_self, int64_t nnz, const float* D, int M,
+                            const float* self_coef, const float* X, int K, const float* W, int fuse_act, const int32_t* heavy_slot,
+                            const float* heavy_sum, float* d_in, float* colsum_in, float* dW, void* ws, size_t ws_bytes, double drop_p,
+                            int64_t drop_seed, int64_t drop_tag, int64_t drop_row0, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
+    const bool cap = nnz >= 0 && nnz <= 8 * n_rows;            // short rows (every neighbour among the 8 prefetched pairs on average)
     PP_REQUIRE(drop_p >= 0.0 && drop_p < 1.0, PP_ERR_ARG, "pp_gcn_backward_drop_f32: p must lie in [0, 1)");
     PP_REQUIRE(drop_p == 0.0 || fuse_act, PP_ERR_ARG, "pp_gcn_backward_drop_f32: the fused dropout belongs to the activation below (fuse_act)");
     const pp::DropSite drop = pp::drop_site(drop_p, drop_seed, drop_tag, drop_row0);
@@ -939,9 +969,9 @@ int pp_gcn_backward_drop_f32(const int32_t* ptr, const int32_t* idx, const float
     int64_t blocks = 0;
     int rc;
     switch (M) {
-        case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop); break;
-        case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop); break;
-        case 64: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop); break;
+        case 16: rc = pp::launch_gcn_backward_k<16>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop, cap); break;
+        case 32: rc = pp::launch_gcn_backward_k<32>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop, cap); break;
+        case 64: rc = pp::launch_gcn_backward_k<64>(K, n_tiles, st, ptr, idx, val, n_rows, D, self_coef, X, W, fuse_act, heavy, wide, d_in, colsum_in, (float*)ws, &blocks, n_self, drop, cap); break;
         default: rc = PP_ERR_ARG; break;
     }
     if (rc != PP_OK) return rc;
