@@ -145,6 +145,21 @@ __device__ __forceinline__ void store_stream_u4(uint32_t* p, uint4 v) {
     __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
 }
 
+typedef float f32x4s_t __attribute__((ext_vector_type(4)));
+// 16-byte store of a matrix row piece the kernel never reads again.  `stream` (wave-uniform): the matrix is far larger than the 256 MB
+// Infinity Cache (layer outputs of the higher-order graph: consumed by a LATER kernel, gigabytes away) — the `nt` policy keeps it from
+// washing the gather sources out of the caches (round 3: 2 % on each fused layer kernel); small matrices (the first-order graph's 128 MB)
+// are kept cacheable for the kernel that gathers from them next.
+constexpr int64_t kStreamFromBytes = (int64_t)512 << 20;
+__device__ __forceinline__ void store_row_f4(float* p, float4 v, bool stream) {
+    if (stream) {
+        f32x4s_t t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4s_t*>(p));
+    } else {
+        *(float4*)p = v;
+    }
+}
+
 // Raw buffer access (buffer_load_* with a 32-bit byte offset): the address arithmetic of a gather is ONE 32-bit VALU add instead of a 64-bit
 // multiply-add, and an offset at or above kBufOob reads as zeros WITHOUT touching memory — absent neighbours, rows past the end and masked
 // lanes need neither a branch around the load nor a select behind it.  (On this chip the VALU and the matrix pipe of a SIMD do not

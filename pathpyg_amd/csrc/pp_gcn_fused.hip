@@ -177,7 +177,7 @@ struct TileGather {
                     acc[qq].x += h.x; acc[qq].y += h.y; acc[qq].z += h.z; acc[qq].w += h.w;
                 }
                 *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = acc[qq];
-                if (agg_out != nullptr && r < n_rows) *(float4*)(agg_out + r * P + 4 * l) = acc[qq];
+                if (agg_out != nullptr && r < n_rows) store_row_f4(agg_out + r * P + 4 * l, acc[qq], n_rows * (int64_t)(P * 4) >= kStreamFromBytes);
             }
         }
     }
@@ -235,6 +235,7 @@ __global__ __launch_bounds__(kThreads, (kThreads == 256 && P == 64 && Q == 64) ?
     for (int ct = 0; ct < CT; ++ct) bias_c[ct] = bias ? bias[CT * i + ct] : 0.f;
     const char* xb = (const char*)X;
     const int64_t n_tiles = (n_rows + 15) / 16;
+    const bool stream_out = n_rows * (int64_t)(Q * 4) >= kStreamFromBytes;
     const int64_t step = (int64_t)gridDim.x * kWaves;
     float col_in[CT];
 #pragma unroll
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(kThreads, (kThreads == 256 && P == 64 && Q == 64) ?
             if (reg < rows_here) {
                 if constexpr (CT >= 4) {
 #pragma unroll
-                    for (int c4 = 0; c4 < CT; c4 += 4) *(float4*)(yp + reg * Q + c4) = make_float4(y[c4], y[c4 + 1], y[c4 + 2], y[c4 + 3]);
+                    for (int c4 = 0; c4 < CT; c4 += 4) store_row_f4(yp + reg * Q + c4, make_float4(y[c4], y[c4 + 1], y[c4 + 2], y[c4 + 3]), stream_out);
                 } else if constexpr (CT == 2) *(float2*)(yp + reg * Q) = make_float2(y[0], y[1]);
                 else yp[reg * Q] = y[0];
             }
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(kGcnThreads, (M == 64 && K == 64 && kCap) ? PP_BWD_
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) col_in[ct] = 0.f;
     const int64_t n_tiles = (n_rows + 15) / 16;
+    const bool stream_out = n_rows * (int64_t)(K * 4) >= kStreamFromBytes;
     const int64_t step = (int64_t)gridDim.x * kGcnWaves;
     // gather stage as in k_gcn_forward: buffer loads + ds_bpermute (TileGather) unless D is 4 GiB or larger (kWide)
     [[maybe_unused]] TileGather<M, kHeavy, (M == 64 && K == 64 && kCap) ? PP_BWD_BATCH : 0> gather(D, ptr, idx, val, self_coef, heavy, n_rows, n_self);
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(kGcnThreads, (M == 64 && K == 64 && kCap) ? PP_BWD_
                 col_in[ct] += v[ct];                                  // rows past the end aggregate nothing: v == 0 there
             }
             if (reg < rows_here) {
-                if constexpr (CT == 4) *(float4*)(yp + reg * K) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (CT == 4) store_row_f4(yp + reg * K, make_float4(v[0], v[1], v[2], v[3]), stream_out);
                 else if constexpr (CT == 2) *(float2*)(yp + reg * K) = make_float2(v[0], v[1]);
                 else yp[reg * K] = v[0];
             }
