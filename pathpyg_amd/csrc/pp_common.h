@@ -160,6 +160,15 @@ __device__ __forceinline__ void store_row_f4(float* p, float4 v, bool stream) {
     }
 }
 
+// 16-byte load of a matrix row piece that is read exactly once (same policy and threshold as store_row_f4)
+__device__ __forceinline__ float4 load_row_f4(const float* p, bool stream) {
+    if (stream) {
+        const f32x4s_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4s_t*>(p));
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
+    return *(const float4*)p;
+}
+
 // Raw buffer access (buffer_load_* with a 32-bit byte offset): the address arithmetic of a gather is ONE 32-bit VALU add instead of a 64-bit
 // multiply-add, and an offset at or above kBufOob reads as zeros WITHOUT touching memory — absent neighbours, rows past the end and masked
 // lanes need neither a branch around the load nor a select behind it.  (On this chip the VALU and the matrix pipe of a SIMD do not

@@ -446,6 +446,12 @@ __global__ __launch_bounds__(kBlock) void k_scale_rows(const float* __restrict__
 // Persistent lane groups (kLanes = F/4 lanes per row, one float4 each) keep their column sums in registers; one LDS fold and
 // F atomics per workgroup at the end.
 // kDrop: Z is the DROPPED activation (dropout site `drop`): the mask, 1 / (1 - p) and ELU' at Z * (1 - p) go into dX.
+#ifndef PP_NT_BIP
+#define PP_NT_BIP 1
+#endif
+#ifndef PP_NT_WG
+#define PP_NT_WG 0
+#endif
 template <int kLanes, bool kDrop = false>
 __global__ __launch_bounds__(kBlock) void k_spmm_act_backward(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                              const float* __restrict__ val, int64_t n_rows, const float* __restrict__ D,
@@ -455,11 +461,12 @@ __global__ __launch_bounds__(kBlock) void k_spmm_act_backward(const int32_t* __r
     __shared__ float s_col[kGroups][kLanes * 4 + 4];
     const int g = threadIdx.x / kLanes, l = threadIdx.x % kLanes;
     const bool col_live = 4 * l < F;
+    const bool stream_rows = PP_NT_BIP && n_rows * (int64_t)F * 4 >= kStreamFromBytes;      // Z and dX: touched once, far larger than the caches
     float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t r = (int64_t)blockIdx.x * kGroups + g; r < n_rows; r += (int64_t)gridDim.x * kGroups) {
         if (!col_live) continue;
         const int p0 = ptr[r], p1 = ptr[r + 1];
-        const float4 z = *(const float4*)(Z + r * F + 4 * l);
+        const float4 z = load_row_f4(Z + r * F + 4 * l, stream_rows);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int e = p0; e < p1; e += 2) {                 // two neighbour rows in flight (the mapping plans have one or two)
             const bool two = e + 1 < p1;
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_act_backward(const int32_t* __r
         acc.x *= zz.x > 0.f ? 1.f : zz.x + 1.f; acc.y *= zz.y > 0.f ? 1.f : zz.y + 1.f;
         acc.z *= zz.z > 0.f ? 1.f : zz.z + 1.f; acc.w *= zz.w > 0.f ? 1.f : zz.w + 1.f;
         part.x += acc.x; part.y += acc.y; part.z += acc.z; part.w += acc.w;
-        *(float4*)(dX + r * F + 4 * l) = acc;
+        store_row_f4(dX + r * F + 4 * l, acc, stream_rows);
     }
     if (colsum == nullptr) return;
     *(float4*)&s_col[g][4 * l] = part;
@@ -1093,6 +1100,7 @@ __global__ __launch_bounds__(kBlock, PP_WG64_WAVES) void k_weight_grad64(const f
                                                          int64_t rows_per_wave, float* __restrict__ partial,
                                                          float* __restrict__ partial_bias) {
     constexpr int kSteps = PP_WG64_STEPS;                  // 4-row steps per iteration, fetched in two half-batches
+    const bool stream_rows = PP_NT_WG && n_rows * (int64_t)256 >= kStreamFromBytes;      // both operands are read exactly once
     const int lane = lane_id(), i = lane & 15, kq = lane >> 4;
     const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
     const int64_t n_begin = wave_global * rows_per_wave;
@@ -1113,8 +1121,8 @@ __global__ __launch_bounds__(kBlock, PP_WG64_WAVES) void k_weight_grad64(const f
         for (int u = h * kHalf; u < (h + 1) * kHalf; ++u) {
             const int64_t n = n0 + 4 * u + kq;
             const bool live = n < n_end;
-            a[u] = live ? *(const float4*)(dH + n * 64 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-            b[u] = live ? *(const float4*)(X + n * 64 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[u] = live ? load_row_f4(dH + n * 64 + 4 * i, stream_rows) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[u] = live ? load_row_f4(X + n * 64 + 4 * i, stream_rows) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto contract = [&](int h) {

@@ -539,13 +539,16 @@ static inline bool gcn_wide_shape(int P, int Q) {
 // Saves the write and the re-read of G (2 of the 7 N x 64 matrix passes of the two-kernel form).
 // natural-layout rows of the layer input: B operand of the dW stream and source of the ELU' epilogue.  Lane (i, kq) owns rows 4*kq .. 4*kq+3 of
 // the tile and the CT consecutive columns CT*i ..: one vector load per row.
+#ifndef PP_NT_XR
+#define PP_NT_XR 0
+#endif
 #define PP_LOAD_XR \
         _Pragma("unroll") \
         for (int reg = 0; reg < 4; ++reg) { \
             const int64_t r = t * 16 + 4 * kq + reg; \
             const float* xp = X + r * K + CT * i; \
             if constexpr (CT == 4) { \
-                const float4 v = r < n_rows ? *(const float4*)xp : make_float4(0.f, 0.f, 0.f, 0.f); \
+                const float4 v = r < n_rows ? load_row_f4(xp, PP_NT_XR && stream_out) : make_float4(0.f, 0.f, 0.f, 0.f); \
                 xr[0][reg] = v.x; xr[1][reg] = v.y; xr[2][reg] = v.z; xr[3][reg] = v.w; \
             } else { \
                 _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) xr[ct][reg] = r < n_rows ? xp[ct] : 0.f; \
