@@ -114,6 +114,9 @@ static int lexsort_rows(const int64_t* rows, int64_t m, int k, int64_t bias, int
 }
 
 // ------------------------------------------------------------------ coalesce
+#ifndef PP_NT_KEYS
+#define PP_NT_KEYS 1
+#endif
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void k_edge_keys(const int64_t* __restrict__ edge_index, int64_t n_edges,
                                                      const int64_t* __restrict__ remap, int64_t remap_len, int64_t num_nodes, int shift,
@@ -121,7 +124,11 @@ __global__ __launch_bounds__(kBlock) void k_edge_keys(const int64_t* __restrict_
                                                      int64_t* __restrict__ status) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= n_edges) return;
+#if PP_NT_KEYS
+    int64_t r = load_stream(edge_index + e), c = load_stream(edge_index + n_edges + e);      // (instance pairs: read once)
+#else
     int64_t r = edge_index[e], c = edge_index[n_edges + e];
+#endif
     bool bad = false;
     if (remap) {
         bad = r < 0 || r >= remap_len || c < 0 || c >= remap_len;
