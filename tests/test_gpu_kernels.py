@@ -225,6 +225,37 @@ def test_coalesce(hip, e, n, reduce):
             assert torch.equal(gw.cpu(), ww)          # left-to-right accumulation order matches the CPU scatter
 
 
+@pytest.mark.parametrize("e,n", [(1, 1), (5000, 7), (200_000, 300), (300_000, 70_000)])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+def test_coalesce_unit_weights_equal_a_ones_vector(hip, e, n, reduce):
+    """`weight=UNIT` (the reference's default torch.ones, lift_order.py:130-131, without the vector): merged weight = run length for "sum",
+    1 otherwise — bit-identical to coalescing an explicit float32 ones vector, also with a remap and with the inverse map, and through
+    aggregate_edge_index's default."""
+    import pathpyg_amd as pp
+    from oracle import aggregate as oa
+    g = torch.Generator().manual_seed(e + 17)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ones = torch.ones(e)
+    wi, ww = oa.coalesce(ei, ones, n, reduce)
+    gi, gw = hip.coalesce(cu(ei), hip.UNIT, n, reduce)
+    assert gw.dtype == torch.float32 and torch.equal(gi.cpu(), wi) and torch.equal(gw.cpu(), ww)
+    hi, hw, hinv = hip.coalesce(cu(ei), cu(ones), n, reduce, None, True)
+    ui, uw, uinv = hip.coalesce(cu(ei), hip.UNIT, n, reduce, None, True)
+    assert torch.equal(ui, hi) and torch.equal(uw, hw) and torch.equal(uinv, hinv)
+    remap = torch.randperm(n, generator=g)
+    ri, rw = hip.coalesce(cu(ei), hip.UNIT, n, reduce, cu(remap))
+    si, sw = hip.coalesce(cu(ei), cu(ones), n, reduce, cu(remap))
+    assert torch.equal(ri, si) and torch.equal(rw, sw)
+    if reduce == "sum" and e > 1:
+        seq = torch.arange(n).unsqueeze(1)
+        a = pp.algorithms.lift_order.aggregate_edge_index(cu(ei), cu(seq))                      # default weights
+        b = pp.algorithms.lift_order.aggregate_edge_index(cu(ei), cu(seq), cu(ones))
+        assert torch.equal(pp._dispatch.plain(a.data.edge_index), pp._dispatch.plain(b.data.edge_index))
+        assert torch.equal(a.data.edge_weight, b.data.edge_weight)
+    with pytest.raises(ValueError):
+        hip.coalesce(cu(ei), "ones", n, reduce)
+
+
 def test_coalesce_remap_and_bad_index(hip):
     from oracle import aggregate as oa
     g = torch.Generator().manual_seed(3)
