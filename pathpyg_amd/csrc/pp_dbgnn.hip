@@ -1477,11 +1477,20 @@ int pp_weight_grad_f32(const float* dH, const float* X, int64_t n_rows, int M, i
         PP_LAUNCH_CHECK();
         return PP_OK;
     }
-    pp::k_weight_grad<<<grid, pp::kBlock, 0, st>>>(dH, X, n_rows, M, K, rows_per_wave, partial, db ? partial_bias : nullptr);
+    // the general kernel is resident at 2 workgroups per CU (171 registers): its own, smaller cap keeps the launch to one full round
+#ifndef PP_WG_GENERIC_CAP
+#define PP_WG_GENERIC_CAP 2
+#endif
+    int64_t parts_g = parts;
+    const int64_t round_g = 256 * PP_WG_GENERIC_CAP / (i_blocks * k_blocks) > 0 ? 256 * PP_WG_GENERIC_CAP / (i_blocks * k_blocks) : 1;
+    if (parts_g > round_g) parts_g = round_g;
+    const int64_t rows_g = pp::ceil_div(pp::ceil_div(n_rows > 0 ? n_rows : 1, parts_g * pp::kWavesPerBlock), 2) * 2;
+    grid.x = (unsigned)parts_g;
+    pp::k_weight_grad<<<grid, pp::kBlock, 0, st>>>(dH, X, n_rows, M, K, rows_g, partial, db ? partial_bias : nullptr);
     PP_LAUNCH_CHECK();
     const int outs = M * K + (db ? M : 0);
     pp::k_weight_grad_reduce<<<(unsigned)pp::ceil_div(outs, pp::kBlock / pp::kWgSlices), pp::kBlock, 0, st>>>(
-        partial, db ? partial_bias : nullptr, parts, M, K, dW, db);
+        partial, db ? partial_bias : nullptr, parts_g, M, K, dW, db);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
