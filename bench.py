@@ -58,6 +58,8 @@ def parse():
                                                                  "compute time + bytes per xGMI link of every collective -> a LABELLED PROJECTION of the "
                                                                  "R-GPU step (not a measurement of R GPUs; prints its own JSON report)")
     ap.add_argument("--trace", action="store_true", help="--emulate-ranks: per-phase compute time of rank 1 in the report")
+    ap.add_argument("--host-profile", default="", help="--emulate-ranks: cProfile of rank 1's timed steps, written to this file (the host side of a "
+                                                       "rank-step; waiting for the other ranks' turns shows up as lock acquires)")
     ap.add_argument("--no-overlap", action="store_true", help="partition path without the interleaved exchange schedule (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-loop-events", type=int, default=6_000, help="smallest of the three B-loop sizes (x2, x4 follow; kept below torch's 32768-element parallel grain)")
@@ -406,16 +408,21 @@ def emulate(args) -> int:
         torch.manual_seed(0)
         net = pp.nn.DBGNN(num_classes=args.classes, num_features=(args.features, args.features), hidden_dims=[args.features] * 3,
                           p_dropout=args.dropout).to(dev)
-        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        opt = pp.nn.optim.Adam(net.parameters(), lr=1e-3)                            # (pp_adam_f32: one launch over all parameter tensors)
         sharded = ppd.ShardedDBGNN(net, comm, overlap=not args.no_overlap)
         if args.trace:
             comm.trace = {}
         build_s, sizes, loss = 0.0, {}, None
+        prof = None
         for it in range(args.warmup + args.steps):
             if it == args.warmup:
                 comm.end_turns()
                 comm.tw.plain_barrier.wait()
                 comm.reset_counters()
+                if args.host_profile and comm.rank == min(1, world - 1):
+                    import cProfile
+                    prof = cProfile.Profile()
+                    prof.enable()
             comm.barrier()                          # (step boundary: opens this rank's first turn of the step)
             opt.zero_grad(set_to_none=True)
             c0 = comm.lap()
@@ -427,6 +434,16 @@ def emulate(args) -> int:
             opt.step()
             comm.mark("step: gradient all-reduce + Adam")
             sizes = shard.sizes
+        if prof is not None:
+            prof.disable()
+            import io
+            import pstats
+            buf = io.StringIO()
+            st = pstats.Stats(prof, stream=buf)
+            st.sort_stats("tottime").print_stats(70)
+            st.sort_stats("cumtime").print_stats(r"pathpyg_amd|bench\.py|optim", 90)
+            with open(args.host_profile, "w") as fh:
+                fh.write(f"# cProfile of rank {comm.rank} of {world} emulated ranks over {args.steps} steps\n" + buf.getvalue())
         comm.end_turns()
         sizes = ppd.global_sizes(shard, comm)
         total = loss.detach().to(torch.float64).reshape(1).clone()
@@ -523,7 +540,7 @@ def main() -> int:
     torch.manual_seed(0)                                    # identical initial weights on every rank
     net = pp.nn.DBGNN(num_classes=args.classes, num_features=(args.features, args.features),
                       hidden_dims=[args.features] * 3, p_dropout=args.dropout).to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    opt = pp.nn.optim.Adam(net.parameters(), lr=1e-3)                               # (pp_adam_f32: one launch over all parameter tensors)
     sharded = ppd.ShardedDBGNN(net, comm, overlap=not args.no_overlap) if partition else None
     # world size > 1: a rank reads only its owned + halo rows of the (resident) inputs
     x_in, xh_in, y_in = (x, x_h, y) if world == 1 else ((lambda rows: x.index_select(0, rows)), (lambda rows: x_h.index_select(0, rows)),

@@ -292,6 +292,12 @@ size_t pp_cross_entropy_ws_bytes(void);       /* per-workgroup partial sums, add
 int pp_cross_entropy_f32(const float* logits, const int64_t* target, int64_t n, int C, float* loss, float* dlogits, void* ws, size_t ws_bytes,
                          pp_stream_t stream);
 
+/* One Adam step (step = 1, 2, ...) over ALL n_tensors fp32 parameter tensors in one launch per 24 tensors: HOST arrays of DEVICE pointers
+ * (params, grads, exp_avg, exp_avg_sq) and of element counts.  The update of torch.optim.Adam (amsgrad off, maximize off; weight_decay is
+ * the L2 form g + wd*p) - the optimizer step of the reference's DBGNN training loops (docs/tutorial/dbgnn.ipynb: torch.optim.Adam). */
+int pp_adam_f32(int n_tensors, void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel,
+                double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, pp_stream_t stream);
+
 /* Whole backward of a dense layer y = x W^T (+ b) in one pass over dH [N,M] and x [N,K] (W is [M,K]; M, K in {16,32,64}):
  *   d_in[N,K] = (dH . W) (*) ELU'(x) when fuse_act (x is then the stored activation of the layer below), colsum_in[K] = its column
  *   sums (that layer's bias gradient); dW[M,K] = dH^T x; db[M] = column sums of dH.  d_in/colsum_in/db may be NULL.

@@ -1761,6 +1761,78 @@ int pp_cross_entropy_f32(const float* logits, const int64_t* target, int64_t n, 
 }  // extern "C"
 
 // =====================================================================================================
+// Adam over ALL parameter tensors of a model in one launch (what torch.optim.Adam does with ~10 multi-tensor launches and, per step, a
+// few dozen host-side device queries: on a small graph or a per-rank share the optimizer's host time was 1 ms of a 3.3 ms step).
+// Same update as torch.optim.Adam (amsgrad off, maximize off):  g' = g + wd*p;  m += (1-b1)(g'-m);  v = b2 v + (1-b2) g'^2;
+// p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps).   blockIdx.y = tensor, blockIdx.x strides over its elements.
+namespace pp {
+constexpr int kAdamTensors = 24;                                  // tensors per launch (the table travels as a kernel argument)
+struct AdamTable {
+    float* p[kAdamTensors];
+    const float* g[kAdamTensors];
+    float* m[kAdamTensors];
+    float* v[kAdamTensors];
+    int64_t n[kAdamTensors];
+};
+__global__ __launch_bounds__(kBlock) void k_adam(AdamTable t, float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2, float eps, float wd) {
+    const int k = blockIdx.y;
+    const int64_t n = t.n[k];
+    float* __restrict__ p = t.p[k];
+    const float* __restrict__ g = t.g[k];
+    float* __restrict__ m = t.m[k];
+    float* __restrict__ v = t.v[k];
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+        const float pe = p[e];
+        const float ge = g[e] + wd * pe;
+        const float me = m[e] + (1.f - b1) * (ge - m[e]);
+        const float ve = b2 * v[e] + (1.f - b2) * ge * ge;
+        m[e] = me;
+        v[e] = ve;
+        p[e] = pe - lr_over_bc1 * (me / (sqrtf(ve) * inv_sqrt_bc2 + eps));
+    }
+}
+}  // namespace pp
+
+extern "C" {
+
+// One Adam step (step = 1, 2, ...) over n_tensors fp32 tensors: HOST arrays of DEVICE pointers params / grads / exp_avg / exp_avg_sq and of
+// element counts.  Replaces torch.optim.Adam.step() of the reference's training loops (docs/tutorial/dbgnn.ipynb) on the DBGNN parameters.
+int pp_adam_f32(int n_tensors, void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel,
+                double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_tensors >= 0 && step >= 1, PP_ERR_ARG, "pp_adam_f32: needs n_tensors >= 0 and step >= 1");
+    PP_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, PP_ERR_ARG, "pp_adam_f32: betas in [0, 1), eps >= 0");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    for (int k = 0; k < n_tensors;) {
+        pp::AdamTable t;
+        int cnt = 0;
+        int64_t longest = 0;
+        for (; k < n_tensors && cnt < pp::kAdamTensors; ++k) {
+            PP_REQUIRE(numel[k] >= 0, PP_ERR_ARG, "pp_adam_f32: negative element count");
+            if (numel[k] == 0) continue;
+            PP_REQUIRE(params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k], PP_ERR_ARG, "pp_adam_f32: null tensor %d", k);
+            t.p[cnt] = (float*)params[k];
+            t.g[cnt] = (const float*)grads[k];
+            t.m[cnt] = (float*)exp_avg[k];
+            t.v[cnt] = (float*)exp_avg_sq[k];
+            t.n[cnt] = numel[k];
+            if (numel[k] > longest) longest = numel[k];
+            ++cnt;
+        }
+        if (cnt == 0) continue;
+        for (int q = cnt; q < pp::kAdamTensors; ++q) { t.p[q] = nullptr; t.g[q] = nullptr; t.m[q] = nullptr; t.v[q] = nullptr; t.n[q] = 0; }
+        int64_t gx = pp::ceil_div(longest, pp::kBlock);
+        if (gx > 1024) gx = 1024;
+        pp::k_adam<<<dim3((unsigned)gx, (unsigned)cnt), pp::kBlock, 0, st>>>(t, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2,
+                                                                             (float)eps, (float)weight_decay);
+        PP_LAUNCH_CHECK();
+    }
+    return PP_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
 // Whole backward of a dense layer y = x W^T (+ b) in ONE pass over its two big operands:
 //     d_in[N,K] = (dH . W) (*) ELU'(x)      colsum_in[K] = column sums of d_in        (gradient for the layer below, as in k_dense)
 //     dW[M,K]   = dH^T x                    db[M]        = column sums of dH           (this layer's parameter gradients)

@@ -688,3 +688,55 @@ def test_bip_combine_kernels_match_the_elementwise_chain(n, f):
         torch.testing.assert_close(x.grad.cpu().double(), y.grad, rtol=1e-5, atol=2e-6 * max(scale, 1.0), msg=lambda s_: f"d{name}: {s_}")
     no_bias = bip_combine(a.to(DEV), p.to(DEV), deg.to(DEV), None)
     torch.testing.assert_close(no_bias.cpu().double(), torch.nn.functional.elu(torch.addcmul(a.double(), deg.double().unsqueeze(1), p.double())), rtol=1e-5, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# pathpyg_amd.nn.optim.Adam (pp_adam_f32: one launch over all parameter tensors) against torch.optim.Adam, the optimizer of the
+# reference's training loops (docs/tutorial/netzschleuder.ipynb:2480 — with weight decay).  fp32: 2e-6 relative + 1e-6 absolute after 6 steps.
+@pytest.mark.parametrize("weight_decay", [0.0, 5e-4])
+@pytest.mark.parametrize("n_tensors", [3, 30])            # 30 > the 24 tensors of one launch
+def test_adam_matches_torch_adam(pp, weight_decay, n_tensors):
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 64), (64,), (8, 64), (1,), (0,), (5, 7, 3)]
+    shapes = [shapes[i % len(shapes)] for i in range(n_tensors)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    mine = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    ref = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    opt = pp.nn.optim.Adam(mine, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay)
+    opt_ref = torch.optim.Adam(ref, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay)
+    for step in range(6):
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            if step == 2 and i == 1:
+                a.grad = b.grad = None                      # a parameter without a gradient is skipped (and keeps its own step count)
+                continue
+            gr = torch.randn(a.shape, generator=g).to(DEV) * (10.0 ** (i % 3 - 1))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        opt.step()
+        opt_ref.step()
+        for a, b in zip(mine, ref):
+            torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-6, atol=1e-6)      # (parameters are O(1): a few ulps)
+    sd = opt.state_dict()
+    assert len(sd["state"]) == n_tensors and sd["param_groups"][0]["lr"] == 1e-2
+
+
+def test_adam_trains_the_dbgnn_like_torch_adam(pp):
+    """Three train steps of the DBGNN with either optimizer: same losses, same parameters."""
+    data, y = _bundle(5, 40, 200, 120, 500, (16, 16))
+    losses = {}
+    params = {}
+    for name in ("hip", "torch"):
+        torch.manual_seed(3)
+        net = pp.nn.DBGNN(num_classes=3, num_features=(16, 16), hidden_dims=[16, 32, 8], p_dropout=0.0).to(DEV)
+        opt = (pp.nn.optim.Adam if name == "hip" else torch.optim.Adam)(net.parameters(), lr=5e-3, weight_decay=5e-4)
+        d = pp.Data(**{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}, y=y.to(DEV))
+        losses[name] = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = F.cross_entropy(net(d), d.y)
+            loss.backward()
+            opt.step()
+            losses[name].append(float(loss.detach()))
+        params[name] = [p.detach().clone() for p in net.parameters()]
+    assert losses["hip"] == pytest.approx(losses["torch"], rel=1e-5)
+    for a, b in zip(params["hip"], params["torch"]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)

@@ -62,6 +62,14 @@ def test_compute_entry_points_fail_loudly_without_gpu():
         _hip.temporal_lift(ei, torch.tensor([1, 2]), 3, 1)
     with pytest.raises(ValueError):                               # argument errors come first, like the reference
         pp.algorithms.aggregate_node_attributes(ei, torch.ones(3), "unknown")
+    w = torch.nn.Parameter(torch.ones(4))                         # the optimizer has no CPU path either
+    w.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        pp.nn.optim.Adam([w], lr=1e-3).step()
+    assert torch.equal(w.detach(), torch.ones(4))
+    for bad in (dict(lr=-1.0), dict(eps=-1.0), dict(betas=(1.0, 0.9)), dict(betas=(0.9, 1.0)), dict(weight_decay=-0.1)):
+        with pytest.raises(ValueError):                           # same argument checks as torch.optim.Adam
+            pp.nn.optim.Adam([w], **bad)
 
 
 def test_delta_resolution_follows_torch_promotion():
