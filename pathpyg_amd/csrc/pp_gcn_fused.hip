@@ -199,6 +199,9 @@ struct TileGather {
 #ifndef PP_FWD_WAVES
 #define PP_FWD_WAVES 4
 #endif
+#ifndef PP_XCD_TILES
+#define PP_XCD_TILES 1          // every XCD sweeps a contiguous eighth of the tiles (0: the plain round-robin order, kept for A/B measurements)
+#endif
 template <int P, int Q, bool kHeavy, bool kWide, int kThreads = kGcnThreads, int kEpi = 0, bool kDrop = false>
 // (64 x 64: capped at 128 registers = 4 waves per SIMD — 126 VGPRs, no accumulator AGPRs, no spills; at the 146 registers the compiler
 // takes when left alone the kernel runs 3 waves per SIMD and the layer is 6 % slower: 1.77 -> 1.66 ms at 10^7 rows)
@@ -236,7 +239,21 @@ __global__ __launch_bounds__(kThreads, (kThreads == 256 && P == 64 && Q == 64) ?
     const char* xb = (const char*)X;
     const int64_t n_tiles = (n_rows + 15) / 16;
     const bool stream_out = n_rows * (int64_t)(Q * 4) >= kStreamFromBytes;
-    const int64_t step = (int64_t)gridDim.x * kWaves;
+    // Tile order.  Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on die b % 8) and every die has its own L2: with the
+    // plain order (tile = b * kWaves + wave, + grid) two neighbouring 64-row groups never share an L2, although on a De Bruijn graph the rows
+    // of one destination block (a, .) gather from the SAME source set (., a).  Every die therefore sweeps a CONTIGUOUS eighth of the tiles.
+    const int64_t n_groups = (n_tiles + kWaves - 1) / kWaves;
+    const bool by_die = PP_XCD_TILES && gridDim.x % 8 == 0;
+    const int64_t per_die = (n_groups + 7) / 8, die_stride = gridDim.x / 8;
+    auto tile_at = [&](int64_t it) -> int64_t {
+        if (by_die) {
+            const int64_t q = (int64_t)(blockIdx.x >> 3) + it * die_stride;
+            const int64_t t = ((int64_t)(blockIdx.x & 7) * per_die + q) * kWaves + wave;
+            return (q < per_die && t < n_tiles) ? t : n_tiles;
+        }
+        const int64_t t = ((int64_t)blockIdx.x + it * gridDim.x) * kWaves + wave;
+        return t < n_tiles ? t : n_tiles;
+    };
     float col_in[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) col_in[ct] = 0.f;
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(kThreads, (kThreads == 256 && P == 64 && Q == 64) ?
     [[maybe_unused]] TileGather<P, kHeavy> gather(X, ptr, idx, val, self_coef, heavy, n_rows, n_self);
     if constexpr (kWide) {
         {
-            const int64_t t0 = (int64_t)blockIdx.x * kWaves + wave;
+            const int64_t t0 = tile_at(0);
 #pragma unroll
             for (int q = 0; q <= kRows; ++q) {
                 const int64_t r = t0 * 16 + g * kRows + q;
@@ -257,16 +274,18 @@ __global__ __launch_bounds__(kThreads, (kThreads == 256 && P == 64 && Q == 64) ?
         }
 
     } else {
-        gather.prefetch((int64_t)blockIdx.x * kWaves + wave);
+        gather.prefetch(tile_at(0));
     }
-    for (int64_t t = (int64_t)blockIdx.x * kWaves + wave; t < n_tiles; t += step) {
+    int64_t t_after = n_tiles;
+    for (int64_t it = 0, t = tile_at(0); t < n_tiles; ++it, t = t_after) {
+        t_after = tile_at(it + 1);
         if constexpr (kWide) {
             const int64_t r0 = t * 16 + g * kRows;
             int p[kRows + 1];
 #pragma unroll
             for (int q = 0; q <= kRows; ++q) p[q] = p_next[q];
             {
-                const int64_t tn = t + step;
+                const int64_t tn = t_after;
 #pragma unroll
                 for (int q = 0; q <= kRows; ++q) {
                     const int64_t r = tn * 16 + g * kRows + q;
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(kThreads, (kThreads == 256 && P == 64 && Q == 64) ?
             }
 
         } else {
-            gather.run(t, t + step, tile, agg_out);
+            gather.run(t, t_after, tile, agg_out);
         }
         __builtin_amdgcn_wave_barrier();
         // input gradient: the activation rows of the epilogue (lane (i, kq): rows 4*kq .., columns CT*i ..) fly during the MFMAs
@@ -492,6 +511,7 @@ static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const GcnArgs& a)
     const int resident = resident_of[hv];
     int64_t blocks = ceil_div(n_tiles, kThreads / kWave);
     if (blocks > resident) blocks = resident;
+    else blocks = (blocks + 7) / 8 * 8;                                 // (a multiple of the 8 XCDs: the kernel's tile order wants whole dies)
 #define PP_FWD(H, WIDE)                                                                                                                  \
     do {                                                                                                                                  \
         if (a.drop.thr != 0u)                                                                                                             \
