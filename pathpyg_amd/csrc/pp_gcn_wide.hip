@@ -27,6 +27,9 @@ namespace pp {
 
 using f32x4w = __attribute__((ext_vector_type(4))) float;
 
+#ifndef PP_WIDE_OCC
+#define PP_WIDE_OCC 2          // workgroups per CU of k_wide_layer (register budget 256 / 168 per lane at 2 / 3)
+#endif
 constexpr int kWideThreads = 256;
 constexpr int kWideWaves = kWideThreads / kWave;
 constexpr int kWideFirst = 4;                  // neighbours per row fetched in the first, fully overlapped, batch
@@ -68,7 +71,7 @@ __device__ __forceinline__ void wide_epilogue_row(const f32x4w (&res)[4], int re
 // kEpi 0: Y = act(tile . Wr^T + bias)            (forward; optional copy of the aggregated tile to agg_out)
 // kEpi 1: Y = (tile . Wr^T) (*) ELU'(act_in)     (input gradient; act_in NULL = no factor) + column sums
 template <int P, int Q, int kEpi>
-__global__ __launch_bounds__(kWideThreads, 2) void k_wide_layer(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+__global__ __launch_bounds__(kWideThreads, PP_WIDE_OCC) void k_wide_layer(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                                 const float* __restrict__ val, int64_t n_rows, int64_t n_self,
                                                                 const float* __restrict__ X, const float* __restrict__ self_coef,
                                                                 const float* __restrict__ Wr, const float* __restrict__ bias, int act,
