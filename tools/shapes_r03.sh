@@ -11,6 +11,8 @@ $B --steps 10 --events 2000000 --nodes 100000 --span 1000000 --delta 100000 > $O
 $B --steps 5 --features 128 > $O/f128.json 2> $O/f128.err
 $B --steps 5 --features 256 > $O/f256.json 2> $O/f256.err
 $B --steps 5 --events 20000000 --nodes 1000000 --features 128 > $O/config3_per_gpu.json 2> $O/config3.err
+# configs[4]: one GPU's eighth of the 10^8-event stream at its 256-dim width (the whole stream's DBGNN does not fit one GPU)
+$B --steps 5 --events 12500000 --nodes 625000 --span 12500000 --delta 1250000 --features 256 > $O/config4_per_gpu_share.json 2> $O/config4.err
 tail -c 300 $O/*.err
 for f in $O/*.json; do echo $f; python -c "
 import json,sys
