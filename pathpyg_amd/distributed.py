@@ -143,9 +143,12 @@ def all_reduce_gradients(module: torch.nn.Module, group=None, average: bool = Tr
     if average:
         flat /= world
     at = 0
-    for g in grads:
-        g.copy_(flat[at: at + g.numel()].view_as(g))
-        at += g.numel()
+    for p in module.parameters():          # the reduced gradients stay where they are: every .grad becomes a view of the flat buffer (no copies)
+        if p.grad is None:
+            continue
+        n_ = p.grad.numel()
+        p.grad = flat[at: at + n_].view_as(p.grad)
+        at += n_
 
 
 # =====================================================================================================

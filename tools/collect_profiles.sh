@@ -24,7 +24,9 @@ def pick(table, pat, counter):
         if pat in k and k.endswith("|" + counter):
             return v
     return None
-for key, pat in (("k_gcn_forward", "k_gcn_forward<64, 64"), ("k_gcn_backward", "k_gcn_backward<64, 64"), ("k_spmm_v4", "k_spmm_v4<16, 2"),
+# (the backward kernel runs as two instantiations: the register-capped one on the higher-order graph, the plain one on the first-order graph)
+for key, pat in (("k_gcn_forward", "k_gcn_forward<64, 64"), ("k_gcn_backward@ho", "k_gcn_backward<64, 64, false, false, false, true>"),
+                 ("k_gcn_backward@fo", "k_gcn_backward<64, 64, false, false, false, false>"), ("k_spmm_v4", "k_spmm_v4<16, 2"),
                  ("k_expand", "k_expand<true>"), ("k_temporal_count", "k_temporal_count"), ("k_spmm_act_backward", "k_spmm_act_backward<16>"),
                  ("k_weight_grad64", "k_weight_grad64")):
     fe, wr = pick(f, pat, "FETCH_SIZE"), pick(w, pat, "WRITE_SIZE")
@@ -35,7 +37,7 @@ for key, pat in (("k_gcn_forward", "k_gcn_forward<64, 64"), ("k_gcn_backward", "
     tot = [(2.0 * a + b) * 1024 for a, b in zip(fv, wv)]
     big = [i for i, t_ in enumerate(tot) if t_ >= 0.4 * max(tot)]            # launches on the 10^7-row higher-order graph
     small = [i for i, t_ in enumerate(tot) if t_ < 0.4 * max(tot)]           # launches on the 5*10^5-row first-order graph
-    for suffix, sel in ((("@ho", big), ("@fo", small)) if small else (("", big),)):
+    for suffix, sel in ((("@ho", big), ("@fo", small)) if (small and "@" not in key) else (("", big + small),)):
         out[key + suffix] = {"fetch_kib_per_dispatch": sum(fv[i] for i in sel) / len(sel), "write_kib_per_dispatch": sum(wv[i] for i in sel) / len(sel),
                              "fetch_correction": 2.0, "hbm_bytes_per_dispatch": sum(tot[i] for i in sel) / len(sel), "dispatches_in_profile": len(sel)}
 json.dump({"workload": "bench.py defaults (m=10^7, N=5*10^5, delta=10^6, F=64), partition mode at 1 GPU",
