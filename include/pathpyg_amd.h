@@ -294,7 +294,9 @@ int pp_cross_entropy_f32(const float* logits, const int64_t* target, int64_t n, 
 
 /* One Adam step (step = 1, 2, ...) over ALL n_tensors fp32 parameter tensors in one launch per 24 tensors: HOST arrays of DEVICE pointers
  * (params, grads, exp_avg, exp_avg_sq) and of element counts.  The update of torch.optim.Adam (amsgrad off, maximize off; weight_decay is
- * the L2 form g + wd*p) - the optimizer step of the reference's DBGNN training loops (docs/tutorial/dbgnn.ipynb: torch.optim.Adam). */
+ * the L2 form g + wd*p).  No reference counterpart: pathpyG ships the model (nn/dbgnn.py:72-151); its only training loop is the upstream tutorial
+ * docs/tutorial/dbgnn.ipynb, which is absent from /root/reference (.MISSING_LARGE_BLOBS:2).  This is the optimizer step such a loop takes from
+ * torch.optim.Adam (15 small launches there, one here). */
 int pp_adam_f32(int n_tensors, void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel,
                 double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, pp_stream_t stream);
 

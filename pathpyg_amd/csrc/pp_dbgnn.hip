@@ -1796,7 +1796,8 @@ __global__ __launch_bounds__(kBlock) void k_adam(AdamTable t, float lr_over_bc1,
 extern "C" {
 
 // One Adam step (step = 1, 2, ...) over n_tensors fp32 tensors: HOST arrays of DEVICE pointers params / grads / exp_avg / exp_avg_sq and of
-// element counts.  Replaces torch.optim.Adam.step() of the reference's training loops (docs/tutorial/dbgnn.ipynb) on the DBGNN parameters.
+// element counts.  Stands in for torch.optim.Adam.step() of a user's training loop around the reference's DBGNN (nn/dbgnn.py:72-151; the
+// reference itself ships no training loop).
 int pp_adam_f32(int n_tensors, void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel,
                 double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
