@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--host-profile", default="", help="--emulate-ranks: cProfile of rank 1's timed steps, written to this file (the host side of a "
                                                        "rank-step; waiting for the other ranks' turns shows up as lock acquires)")
     ap.add_argument("--no-overlap", action="store_true", help="partition path without the interleaved exchange schedule (A/B)")
+    ap.add_argument("--halo-row-backward", action="store_true", help="partition path, world > 1: the round-2 backward (fused kernel over owned + halo rows, "
+                    "its output exchanged) instead of exchanging A^T dpre and multiplying on the owned rows only (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-loop-events", type=int, default=6_000, help="smallest of the three B-loop sizes (x2, x4 follow; kept below torch's 32768-element parallel grain)")
     ap.add_argument("--cpu-sample-events", type=int, default=2_000_000, help="size of the vectorised CPU pipeline sample (B-agg, B-dbgnn)")
@@ -493,6 +495,9 @@ def main() -> int:
         print(json.dumps(cpu_baseline(args, seed=11)), flush=True)
         return 0
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ          # started by torch.distributed.run
+    if args.halo_row_backward:
+        import pathpyg_amd.nn.sharded as _sh
+        _sh.OWNED_ROW_BACKWARD = False
     if args.emulate_ranks > 1:
         return emulate(args)
     if args.gpus > 1 and not launched:

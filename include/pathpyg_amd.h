@@ -254,6 +254,12 @@ int pp_bip_combine_f32(const float* A, const float* P, const float* deg, const f
 int pp_bip_combine_backward_f32(const float* dY, const float* Y, const float* deg, int64_t n_rows, int F, float* dA, float* dP, float* dbias,
                                 pp_stream_t stream);
 
+/* Partitioned DBGNN backward (no single-process counterpart in the reference; the sum it completes is the transposed aggregation of
+ * GCNConv's backward, nn/dbgnn.py:131-140 under autograd): out[r,:] = own[r,:] + recv[slot[r],:] (slot[r] >= 0) + extra[r,:] + self_coef[r] * dpre[r,:],
+ * every addend optional (NULL); recv/slot and self_coef/dpre come in pairs; F a multiple of 4, 16-byte aligned rows; out may alias own. */
+int pp_halo_fold_f32(const float* own, const float* recv, const int32_t* slot, const float* extra, const float* self_coef, const float* dpre,
+                     int64_t n_rows, int F, float* out, pp_stream_t stream);
+
 /* out[r,:] = coef[r] * X[r,:] (gradient of the bipartite self term) */
 int pp_scale_rows_f32(const float* X, const float* coef, int64_t n_rows, int F, float* out, pp_stream_t stream);
 

@@ -793,6 +793,31 @@ def dropout_act_backward(dy: torch.Tensor, y_dropped: torch.Tensor | None, p: fl
     return dpre, dbias
 
 
+def halo_fold(own: torch.Tensor, recv: torch.Tensor | None = None, slot: torch.Tensor | None = None, extra: torch.Tensor | None = None,
+              self_coef: torch.Tensor | None = None, dpre: torch.Tensor | None = None, inplace: bool = True) -> torch.Tensor:
+    """``own + recv[slot] (where slot >= 0) + extra + self_coef[:, None] * dpre`` in one pass (pp_halo_fold_f32); written into ``own`` when
+    ``inplace``.  ``slot`` int32 [n]; fp32 matrices of one width (a multiple of 4)."""
+    dev = require_device(own, recv, slot, extra, self_coef, dpre)
+    if not own.is_contiguous():
+        raise ValueError("halo_fold: own must be contiguous")
+    if own.numel() == 0:
+        return own if inplace else own.clone()
+    if recv is not None and (slot is None or recv.size(0) == 0):
+        recv = slot = None
+    if slot is not None and recv is None:
+        slot = None
+    recv = None if recv is None else recv.contiguous()
+    extra = None if extra is None else extra.contiguous()
+    dpre = None if dpre is None else dpre.contiguous()
+    if slot is not None and slot.dtype != torch.int32:
+        raise TypeError("halo_fold: slot must be int32")
+    with torch.cuda.device(dev):
+        out = own if inplace else torch.empty_like(own)
+        check(lib().pp_halo_fold_f32(_p(own), _p(recv), _p(slot), _p(extra), _p(self_coef), _p(dpre), own.size(0), own.size(1), _p(out), _stream()),
+              "pp_halo_fold_f32")
+    return out
+
+
 def scale_rows(x: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
     dev = require_device(x, coef)
     x = x.contiguous()

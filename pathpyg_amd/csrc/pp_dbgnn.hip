@@ -440,6 +440,39 @@ __global__ __launch_bounds__(kBlock) void k_scale_rows(const float* __restrict__
     if (i < n_rows * (int64_t)F) out[i] = X[i] * coef[i / F];
 }
 
+// out[r] = own[r] + recv[slot[r]] (slot[r] >= 0) + extra[r] + self_coef[r] * dpre[r]   — every addend optional (NULL).
+// The partitioned backward pass (pathpyg_amd/nn/sharded.py): the owner of a row folds the halo contributions its consumers sent back
+// (`recv`, one row per sent row, `slot` = the inverse of the send list where every owned row has at most one consumer; `extra` = their CSR sum
+// otherwise) and the self-loop term of the transposed aggregation into its own partial sum in ONE pass (index_add_ + addcmul otherwise).
+// One float4 per thread; out may alias own.
+__global__ __launch_bounds__(kBlock) void k_halo_fold(const float* own, const float* __restrict__ recv, const int32_t* __restrict__ slot,
+                                                     const float* __restrict__ extra, const float* __restrict__ self_coef,
+                                                     const float* __restrict__ dpre, int64_t n_rows, int q, float* out) {
+    const int64_t total = n_rows * (int64_t)q;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = e / q;
+        const int c = (int)(e - r * q);
+        float4 v = *(const float4*)(own + 4 * e);
+        if (slot != nullptr) {
+            const int sl = slot[r];
+            if (sl >= 0) {
+                const float4 g = *(const float4*)(recv + ((int64_t)sl * q + c) * 4);
+                v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w;
+            }
+        }
+        if (extra != nullptr) {
+            const float4 g = *(const float4*)(extra + 4 * e);
+            v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w;
+        }
+        if (self_coef != nullptr) {
+            const float sc = self_coef[r];
+            const float4 g = *(const float4*)(dpre + 4 * e);
+            v.x += sc * g.x; v.y += sc * g.y; v.z += sc * g.z; v.w += sc * g.w;
+        }
+        *(float4*)(out + 4 * e) = v;
+    }
+}
+
 // dX[r] = (sum_e val[e] D[idx[e]]) (*) ELU'(Z[r]),  colsum[c] += dX[r][c]      (ELU' from the stored activation Z = ELU(pre))
 // The transposed aggregation of a layer whose input was an activation, fused with that activation's backward and the bias
 // gradient of the layer that produced it: one pass (gather D, read Z, write dX) instead of SpMM + a three-pass ELU backward.
@@ -948,6 +981,24 @@ int pp_scale_rows_f32(const float* X, const float* coef, int64_t n_rows, int F, 
     const int64_t total = n_rows * (int64_t)F;
     if (total <= 0) return PP_OK;
     k_scale_rows<<<(unsigned)ceil_div(total, kBlock), kBlock, 0, st>>>(X, coef, n_rows, F, out);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+int pp_halo_fold_f32(const float* own, const float* recv, const int32_t* slot, const float* extra, const float* self_coef, const float* dpre,
+                     int64_t n_rows, int F, float* out, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_rows >= 0 && F >= 4 && F % 4 == 0, PP_ERR_ARG, "pp_halo_fold_f32: F must be a positive multiple of 4");
+    PP_REQUIRE(own && out, PP_ERR_ARG, "pp_halo_fold_f32: null matrix");
+    PP_REQUIRE((slot == nullptr) == (recv == nullptr) || n_rows == 0, PP_ERR_ARG, "pp_halo_fold_f32: recv and slot come together");
+    PP_REQUIRE((self_coef == nullptr) == (dpre == nullptr), PP_ERR_ARG, "pp_halo_fold_f32: self_coef and dpre come together");
+    PP_REQUIRE(((uintptr_t)own | (uintptr_t)recv | (uintptr_t)extra | (uintptr_t)dpre | (uintptr_t)out) % 16 == 0, PP_ERR_ARG,
+               "pp_halo_fold_f32: 16-byte alignment");
+    const int64_t total = n_rows * (int64_t)(F / 4);
+    if (total == 0) return PP_OK;
+    int64_t blocks = ceil_div(total, kBlock);
+    if (blocks > kMaxGrid) blocks = kMaxGrid;
+    k_halo_fold<<<(unsigned)blocks, kBlock, 0, st>>>(own, recv, slot, extra, self_coef, dpre, n_rows, F / 4, out);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

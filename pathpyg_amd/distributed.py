@@ -661,13 +661,17 @@ def _finish_graph_shard(ei_local: torch.Tensor, weight, lo: int, hi: int, num_no
 
     plan = ops.gcn_plan_partition(ei_local, weight, n_own + n_halo, n_own, halo_dinv, row_sorted=False, status_out=status_out,
                                   want_dst_order=want_dst_order)
-    back_ptr = back_idx = None
+    back_ptr = back_idx = send_slot = None
+    if unique_send:
+        send_slot = torch.full((n_own,), -1, dtype=torch.int32, device=dev)
+        if send_idx.numel():
+            send_slot[send_idx] = torch.arange(int(send_idx.numel()), dtype=torch.int32, device=dev)
     if not unique_send:
         back_ptr, back_idx = ops.group_rows(send_idx, n_own) if send_idx.numel() else (torch.zeros(n_own + 1, dtype=torch.int32, device=dev),
                                                                                        torch.zeros(0, dtype=torch.int32, device=dev))
     return GraphShard(lo=lo, hi=hi, n_own=n_own, n_halo=n_halo, n_src=n_own + n_halo, num_nodes=num_nodes, cuts=list(cuts), plan=plan,
                       halo_ids=halo_ids, send_idx=send_idx, send_counts=send_counts, recv_counts=recv_counts, back_ptr=back_ptr,
-                      back_idx=back_idx, send_unique=unique_send)
+                      back_idx=back_idx, send_unique=unique_send, send_slot=send_slot)
 
 
 def _bipartite_shard(ho_local: torch.Tensor, fo_global: torch.Tensor, n_ho_own: int, fo_cuts: list[int], comm: Comm, ops, src_sorted: bool):

@@ -24,6 +24,8 @@ import torch.nn.functional as F
 from .. import _hip
 
 TAG_FO, TAG_FO_OUT, TAG_HO, TAG_HO_OUT, TAG_HEAD = 0, 32, 64, 96, 128          # dropout call sites (same numbering as nn.dbgnn)
+OWNED_ROW_BACKWARD = True          # _ShardedTrunk: exchange A^T dpre and run the layer's GEMMs on the owned rows only (False: the fused kernel over
+#                                    owned + halo rows, then exchange of its output — kept for A/B measurements, bench.py --halo-row-backward)
 
 
 class HipOps:
@@ -121,6 +123,37 @@ class HipOps:
             return d_lin, colsum, dw
         return d_lin, None, dw
 
+    # ---- backward of a layer with the matrix work on the OWNED rows only (world size > 1): the halo rows' partial sums A^T dpre travel back
+    # to their owners BEFORE the product with W, so both GEMMs of the layer (input gradient, weight gradient) run once per row
+    @staticmethod
+    def owned_backward_ok(weight: torch.Tensor) -> bool:
+        m, k = weight.shape
+        return m % 4 == 0 and k % 4 == 0 and _hip.gcn_fused_supported(k, m) in (1, 2)
+
+    @staticmethod
+    def transposed_sum(plan, dpre: torch.Tensor) -> torch.Tensor:
+        """``A^T dpre`` over the local source space ``[owned | halo]`` (no self term, no product): ``[n_src, M]``."""
+        return _hip.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre, heavy=plan.bwd_heavy)
+
+    @staticmethod
+    def owned_backward(gs, t_own: torch.Tensor, recv: torch.Tensor, dpre: torch.Tensor, x_own: torch.Tensor, weight: torch.Tensor, saved):
+        """``t_own`` = this rank's own partial sums for its owned rows, ``recv`` = the partial sums its consumers returned (send-list order).
+        One pass folds them + the self-loop term (pp_halo_fold_f32); then ``(d_lin * ELU'(x_own), its column sums, dW)`` on the owned rows."""
+        m, k = weight.shape
+        slot = extra = None
+        if recv.size(0):
+            if gs.send_unique:
+                slot = gs.send_slot
+            else:
+                extra = _hip.spmm(gs.back_ptr, gs.back_idx, None, gs.n_own, recv)
+        total = _hip.halo_fold(t_own, recv if slot is not None else None, slot, extra, gs.plan.self_coef, dpre)
+        if _hip.gcn_fused_supported(k, m) == 1:
+            d_in, colsum, dw, _ = _hip.dense_backward(total, x_own, weight, True, True, True, False)
+            return d_in, colsum, dw
+        dw = _hip.weight_grad(dpre, saved, want_bias=False)[0] if saved is not None else _hip.weight_grad(total, x_own, want_bias=False)[0]
+        d_in, colsum = _hip.dense(total, weight, False, None, x_own, True)
+        return d_in, colsum, dw
+
     @staticmethod
     def act_combine(d_lin_own: torch.Tensor, extra, y_below: torch.Tensor):
         """``((d_lin_own + extra) * ELU'(y_below), column sums)``: gradient w.r.t. the pre-activation of the layer below and its bias."""
@@ -180,10 +213,11 @@ class GraphShard:
     both source i and destination i); ``halo_ids``: global ids of the halo rows (ascending, hence grouped by owner);
     ``send_idx`` / ``send_counts``: owned rows each peer asked for; ``recv_counts``: halo rows coming from each peer;
     ``back_ptr`` / ``back_idx``: CSR over the owned rows into the ``[n_send]`` buffer of returned gradient rows; ``send_unique``: every
-    owned row is sent to at most one peer (De Bruijn layers cut at first-order node boundaries): returned rows are added in place."""
+    owned row is sent to at most one peer (De Bruijn layers cut at first-order node boundaries): returned rows are added in place;
+    ``send_slot`` (``send_unique`` shards): int32 ``[n_own]``, the position of an owned row in the send list or -1 — the inverse of ``send_idx``."""
 
     __slots__ = ("lo", "hi", "n_own", "n_halo", "n_src", "num_nodes", "cuts", "plan", "halo_ids", "send_idx", "send_counts", "recv_counts",
-                 "back_ptr", "back_idx", "send_unique")
+                 "back_ptr", "back_idx", "send_unique", "send_slot")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -420,6 +454,13 @@ class _ShardedTrunk(torch.autograd.Function):
             """Halo-gradient rows of layer l are back: fold them into the owned rows, ELU' of the layer below, its bias gradient."""
             s = st[name]
             gs = s["gs"]
+            if s["pending"][0] == "owned":
+                _, t_sum, x_in, dpre_l, sv, weight = s["pending"]
+                recv = s["handle"].wait()
+                s["d"], colsum, s["grads"][2 * l] = ops.owned_backward(gs, t_sum[: gs.n_own], recv, dpre_l, x_in[: gs.n_own], weight, sv)
+                s["grads"][2 * l - 1] = colsum
+                s["pending"] = None
+                return
             d_lin, x_in = s["pending"]
             recv = s["handle"].wait()
             own = d_lin[: gs.n_own]
@@ -439,6 +480,12 @@ class _ShardedTrunk(torch.autograd.Function):
             weight, x_in = s["prm"][2 * l], inputs[l]
             if l == 0:
                 s["grads"][0] = ops.layer_backward(gs.plan, s["d"], x_in, weight, saved[0], False, None)[2]
+                return
+            if OWNED_ROW_BACKWARD and getattr(ops, "owned_backward_ok", lambda w: False)(weight):
+                # gather-only pass over owned + halo rows; the halo rows' sums go home before the product with W (see HipOps.owned_backward)
+                t_sum = ops.transposed_sum(gs.plan, s["d"])
+                s["pending"] = ("owned", t_sum, x_in, s["d"], saved[l], weight)
+                s["handle"] = comm.exchange_rows_async(t_sum[gs.n_own:], gs.recv_counts, gs.send_counts)
                 return
             d_lin, _, s["grads"][2 * l] = ops.layer_backward(gs.plan, s["d"], x_in, weight, saved[l], True, None)
             s["pending"] = (d_lin, x_in)

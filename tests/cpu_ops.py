@@ -215,6 +215,28 @@ class CpuOps:
         return d_lin, None, dw
 
     @staticmethod
+    def owned_backward_ok(weight):
+        return True
+
+    @staticmethod
+    def transposed_sum(plan, dpre):
+        return CpuOps.spmm(plan.bwd_ptr, plan.bwd_idx, plan.bwd_val, plan.n_src, dpre)
+
+    @staticmethod
+    def owned_backward(gs, t_own, recv, dpre, x_own, weight, saved):
+        total = t_own + gs.plan.self_coef.unsqueeze(1) * dpre
+        if recv.size(0):
+            if gs.send_unique:
+                slot = gs.send_slot.long()
+                assert torch.equal(torch.nonzero(slot >= 0).flatten().sort().values, gs.send_idx.long().sort().values)
+                total = total + torch.where((slot >= 0).unsqueeze(1), recv[slot.clamp(min=0)], torch.zeros_like(total))
+            else:
+                total = total + CpuOps.spmm(gs.back_ptr, gs.back_idx, None, gs.n_own, recv)
+        d_in = (total @ weight) * _elu_grad(x_own)
+        dw = dpre.t() @ saved if saved is not None else total.t() @ x_own
+        return d_in, d_in.sum(0), dw
+
+    @staticmethod
     def act_combine(d_lin_own, extra, y_below):
         d = (d_lin_own if extra is None else d_lin_own + extra) * _elu_grad(y_below)
         return d, d.sum(0)

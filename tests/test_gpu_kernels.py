@@ -441,3 +441,38 @@ def test_time_stats_and_fused_event_gather(hip, dtype):
     assert torch.equal(got_t.cpu(), want.values) and torch.equal(got_ei.cpu(), ei[:, want.indices])
     assert hip.time_stats(want.values.to(DEV))[0] == 0
     assert hip.time_stats(torch.empty(0, dtype=dtype, device=DEV))[0] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,f,k", [(0, 64, 0), (1000, 64, 300), (70_000, 256, 70_000), (4097, 8, 1)])
+def test_halo_fold_matches_the_separate_passes(hip, n, f, k):
+    """pp_halo_fold_f32 (partitioned backward: own partial sums + returned halo rows + CSR sums + self-loop term in one pass) against
+    index_add_ / addcmul; every combination of the optional addends, in place and out of place."""
+    g = torch.Generator().manual_seed(n + f)
+    own = torch.randn(n, f, generator=g)
+    recv = torch.randn(k, f, generator=g)
+    send_idx = torch.randperm(n, generator=g)[:k]
+    slot = torch.full((n,), -1, dtype=torch.int32)
+    slot[send_idx] = torch.arange(k, dtype=torch.int32)
+    extra = torch.randn(n, f, generator=g)
+    coef = torch.rand(n, generator=g)
+    dpre = torch.randn(n, f, generator=g)
+    dev = "cuda"
+    for use_recv in (False, True):
+        for use_extra in (False, True):
+            for use_self in (False, True):
+                want = own.clone()
+                if use_recv and k:
+                    want.index_add_(0, send_idx, recv)
+                if use_extra:
+                    want += extra
+                if use_self:
+                    want += coef.unsqueeze(1) * dpre
+                got = hip.halo_fold(own.to(dev), recv.to(dev) if use_recv else None, slot.to(dev) if use_recv else None,
+                                    extra.to(dev) if use_extra else None, coef.to(dev) if use_self else None, dpre.to(dev) if use_self else None,
+                                    inplace=False)
+                torch.testing.assert_close(got.cpu(), want, rtol=1e-6, atol=1e-6)
+    buf = own.to(dev)
+    out = hip.halo_fold(buf, recv.to(dev), slot.to(dev), None, coef.to(dev), dpre.to(dev))
+    assert out.data_ptr() == buf.data_ptr()
+    torch.testing.assert_close(out.cpu(), own.clone().index_add_(0, send_idx, recv) + coef.unsqueeze(1) * dpre, rtol=1e-6, atol=1e-6)
