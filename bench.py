@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--host-profile", default="", help="--emulate-ranks: cProfile of rank 1's timed steps, written to this file (the host side of a "
                                                        "rank-step; waiting for the other ranks' turns shows up as lock acquires)")
     ap.add_argument("--no-overlap", action="store_true", help="partition path without the interleaved exchange schedule (A/B)")
+    ap.add_argument("--fo-halo", choices=("auto", "dense", "discovered"), default="auto", help="partition path, world > 1: halo of the first-order shard "
+                    "(dense = every foreign node, no discovery round; auto picks it when a rank's in-edges exceed 1.5 x the node count)")
     ap.add_argument("--halo-row-backward", action="store_true", help="partition path, world > 1: the round-2 backward (fused kernel over owned + halo rows, "
                     "its output exchanged) instead of exchanging A^T dpre and multiplying on the owned rows only (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -498,6 +500,9 @@ def main() -> int:
     if args.halo_row_backward:
         import pathpyg_amd.nn.sharded as _sh
         _sh.OWNED_ROW_BACKWARD = False
+    if args.fo_halo != "auto":
+        import pathpyg_amd.distributed as _pd
+        _pd.FO_DENSE_HALO = args.fo_halo == "dense"
     if args.emulate_ranks > 1:
         return emulate(args)
     if args.gpus > 1 and not launched:

@@ -607,12 +607,15 @@ def sorted_halo(src: torch.Tensor, lo: int, hi: int, cuts_t: torch.Tensor):
 
 def build_graph_shard(src: torch.Tensor, dst: torch.Tensor, weight: torch.Tensor | None, num_nodes: int, cuts: list[int], comm: Comm,
                       ops=None, row_sorted: bool = False, status_out: list | None = None, want_dst_order: bool = False,
-                      edge_index: torch.Tensor | None = None, src_sorted: bool = False):
+                      edge_index: torch.Tensor | None = None, src_sorted: bool = False, dense_halo: bool = False):
     """This rank's :class:`~pathpyg_amd.nn.sharded.GraphShard` of a graph with ``num_nodes`` nodes from the edges (GLOBAL ids) that
     point into its destination range ``[cuts[rank], cuts[rank+1])`` — GCN normalisation with PyG ``gcn_norm`` semantics
     (reference nn/dbgnn.py:104-114 through GCNConv): every in-edge of an owned node is local, so the weighted in-degree is too;
     the d^-1/2 of the halo sources comes from their owners in one 4-byte-per-row exchange.  ``edge_index``: the same edges as one
-    contiguous [2, E] tensor when the caller has it (saves a copy at world size 1); ``src_sorted``: ``src`` ascends (:func:`sorted_halo`)."""
+    contiguous [2, E] tensor when the caller has it (saves a copy at world size 1); ``src_sorted``: ``src`` ascends (:func:`sorted_halo`).
+    ``dense_halo`` (the SAME value on every rank): the halo is taken to be EVERY node of the other ranks — no discovery, no request round, no
+    read-back: local ids, counts and the return CSR are arithmetic on the cuts.  For graphs whose ranks gather from nearly all nodes anyway
+    (the first-order graph of a dense stream: 20 in-edges per node, 8 ranks -> 92 % of the nodes are sources of every rank)."""
     from .nn.sharded import GraphShard
     ops = _ops_default(ops)
     rank, world = comm.rank, comm.world
@@ -624,6 +627,20 @@ def build_graph_shard(src: torch.Tensor, dst: torch.Tensor, weight: torch.Tensor
         plan = ops.gcn_plan(whole, weight, num_nodes, row_sorted, status_out, want_dst_order=want_dst_order)
         return GraphShard(lo=0, hi=num_nodes, n_own=num_nodes, n_halo=0, n_src=num_nodes, num_nodes=num_nodes, cuts=list(cuts), plan=plan,
                           send_counts=[0], recv_counts=[0])
+    if dense_halo:
+        # local source space [owned | ids below lo | ids from hi on]: id + n_own below the range, id itself above it
+        src_local = torch.where(src < lo, src + n_own, torch.where(src >= hi, src, src - lo))
+        halo_ids = torch.cat((torch.arange(0, lo, dtype=torch.int64, device=dev), torch.arange(hi, num_nodes, dtype=torch.int64, device=dev)))
+        recv_counts = [0 if r == rank else int(cuts[r + 1] - cuts[r]) for r in range(world)]
+        send_counts = [0 if r == rank else n_own for r in range(world)]
+        peers = world - 1
+        own_rows = torch.arange(n_own, dtype=torch.int32, device=dev)
+        send_idx = own_rows.repeat(peers)                                                                   # every owned row to every peer
+        # returned gradient rows arrive peer by peer: row i of peer block p sits at p * n_own + i
+        back_ptr = torch.arange(0, n_own * peers + 1, max(peers, 1), dtype=torch.int32, device=dev)[: n_own + 1]
+        back_idx = (own_rows.unsqueeze(1) + (torch.arange(peers, dtype=torch.int32, device=dev) * n_own).unsqueeze(0)).reshape(-1)
+        return _finish_graph_shard(torch.stack((src_local, dst - lo)), weight, lo, hi, num_nodes, cuts, halo_ids, send_idx, send_counts, recv_counts,
+                                   comm, ops, status_out, unique_send=False, want_dst_order=want_dst_order, back=(back_ptr, back_idx))
     cuts_t = torch.tensor(cuts, dtype=torch.int64, device=dev)
     if src_sorted:
         src_local, halo_ids, recv_counts = sorted_halo(src, lo, hi, cuts_t)
@@ -648,7 +665,7 @@ def build_graph_shard(src: torch.Tensor, dst: torch.Tensor, weight: torch.Tensor
 
 def _finish_graph_shard(ei_local: torch.Tensor, weight, lo: int, hi: int, num_nodes: int, cuts: list[int], halo_ids: torch.Tensor,
                         send_idx: torch.Tensor, send_counts: list[int], recv_counts: list[int], comm: Comm, ops, status_out,
-                        unique_send: bool, want_dst_order: bool = False):
+                        unique_send: bool, want_dst_order: bool = False, back: tuple | None = None):
     """Rectangular GCN plan over the local source space ``[owned | halo]`` (one d^-1/2 exchange between its two phases) + the bookkeeping of
     the layer exchanges.  ``unique_send``: every owned row goes to at most one peer (De Bruijn layers): returned gradient rows are added in
     place, no CSR over the send list is needed."""
@@ -666,7 +683,9 @@ def _finish_graph_shard(ei_local: torch.Tensor, weight, lo: int, hi: int, num_no
         send_slot = torch.full((n_own,), -1, dtype=torch.int32, device=dev)
         if send_idx.numel():
             send_slot[send_idx] = torch.arange(int(send_idx.numel()), dtype=torch.int32, device=dev)
-    if not unique_send:
+    if back is not None:
+        back_ptr, back_idx = back
+    elif not unique_send:
         back_ptr, back_idx = ops.group_rows(send_idx, n_own) if send_idx.numel() else (torch.zeros(n_own + 1, dtype=torch.int32, device=dev),
                                                                                        torch.zeros(0, dtype=torch.int32, device=dev))
     return GraphShard(lo=lo, hi=hi, n_own=n_own, n_halo=n_halo, n_src=n_own + n_halo, num_nodes=num_nodes, cuts=list(cuts), plan=plan,
@@ -732,6 +751,8 @@ def shard_dbgnn_bundle(data, comm: Comm, ops=None, fo_cuts: list[int] | None = N
     return DbgnnShard(fo=fo, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x.contiguous(), x_h=x_h.contiguous(), y=y, n_fo=n_fo, n_ho=n_ho)
 
 
+FO_DENSE_HALO = None   # first-order shard of build_dbgnn_shard: None = dense halo (all foreign nodes, no discovery) when a rank's in-edges exceed
+#                        1.5 x the node count (U2 >= 1.5 * world * N), True / False force a mode (tests, A/B)
 ROW_COST = 2          # cost of a higher-order row relative to one of its in-edges when the cuts are balanced (a row is read and written once)
 
 
@@ -1044,8 +1065,9 @@ def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
                              ho_send, ho_recv, comm, ops, pending, unique_send=True)
     comm.mark("build: higher-order shard + plan")
     # first-order graph: my in-edges (a -> b, b in my range) arrived sorted by a; its halo = the distinct foreign a (request round)
+    dense_fo = FO_DENSE_HALO if FO_DENSE_HALO is not None else n_ho >= 1.5 * world * n       # (global quantities: every rank decides alike)
     fo_shard = build_graph_shard(nodes_in[:, 0].to(torch.int64), nodes_in[:, 1].to(torch.int64), nodes_in[:, 3].contiguous().view(torch.float32), n, fo_cuts,
-                                 comm, ops, False, pending, src_sorted=True)
+                                 comm, ops, False, pending, src_sorted=True, dense_halo=bool(dense_fo))
     comm.mark("build: first-order shard + plan")
     bip, cap = _bipartite_shard(torch.arange(n_ho_own, **i64), fo_r[1], n_ho_own, fo_cuts, comm, ops, src_sorted=True)
     ops.check_plan_status(pending)

@@ -312,12 +312,15 @@ def _world8_worker(rank, world, port, results):
 ROW_COST_ = 2
 
 
+@pytest.mark.parametrize("dense_fo", [True, False])
 @pytest.mark.parametrize("world", [2, 8])
-def test_thread_world_ranks_match_oracle(world):
+def test_thread_world_ranks_match_oracle(world, dense_fo, monkeypatch):
     """ThreadWorld — R ranks as threads of ONE process (what `bench.py --emulate-ranks` runs on the one GPU): collectives are copies between
-    the ranks' tensors, the ranks take turns.  Same numbers as the oracle, a compute time and a collective log per rank."""
+    the ranks' tensors, the ranks take turns.  Same numbers as the oracle, a compute time and a collective log per rank.  ``dense_fo``: the
+    first-order shard with the dense halo (every foreign node, no discovery round) and with the discovered one."""
     import pathpyg_amd as pp
     from pathpyg_amd import distributed as pd
+    monkeypatch.setattr(pd, "FO_DENSE_HALO", dense_fo)
     from oracle import dbgnn as od
     from oracle import model as om
     from tests.cpu_ops import CpuOps
@@ -360,6 +363,10 @@ def test_thread_world_ranks_match_oracle(world):
         for name, gr in r["grads"].items():
             torch.testing.assert_close(gr, want_grads[name], rtol=1e-3, atol=1e-5, msg=lambda s_: f"{name}: {s_}")
         assert r["compute_s"] > 0 and any(o for _, _, o in r["events"]) and r["sizes"]["U2"] == layers[2]["num_nodes"]
+        if dense_fo:
+            assert r["sizes"]["fo_halo"] == n - (r["hi"] - r["lo"])
+        else:
+            assert r["sizes"]["fo_halo"] <= n - (r["hi"] - r["lo"])
 
 
 def test_world8_er_and_zipf_streams_match_oracle_and_balance():

@@ -179,7 +179,8 @@ def _zipf_case(seed, m, n, delta, span, f, hidden):
     return ei, t, w, x, x_h, y, params, want, layers
 
 
-def test_partition_path_world8_er_and_zipf_on_one_gpu():
+@pytest.mark.parametrize("dense_fo", [True, False])
+def test_partition_path_world8_er_and_zipf_on_one_gpu(dense_fo, monkeypatch):
     """world size 8 with the REAL kernels — eight ranks as threads of this process sharing the one GPU
     (pathpyg_amd.distributed.ThreadWorld: device-to-device collectives; eight PROCESSES on one GPU spend minutes in context switches) —
     on an ER and a Zipf stream (weighted events) and a tiny one: the fully sharded build + the partitioned DBGNN step against the
@@ -188,6 +189,7 @@ def test_partition_path_world8_er_and_zipf_on_one_gpu():
         pytest.skip("no GPU visible")
     import pathpyg_amd as pp
     from pathpyg_amd import distributed as pd
+    monkeypatch.setattr(pd, "FO_DENSE_HALO", dense_fo)          # first-order shard: every foreign node as halo (no discovery) / the discovered halo
     dev = torch.device("cuda:0")
     cases = [("er", _case(11, 20000, 300, 30, 6000, 64, [64, 64, 64], False), 300, 30, 64, [64, 64, 64]),
              ("zipf", _zipf_case(12, 20000, 300, 30, 6000, 64, [64, 64, 64]), 300, 30, 64, [64, 64, 64]),
