@@ -422,6 +422,11 @@ def emulate(args) -> int:
             if it == args.warmup:
                 comm.end_turns()
                 comm.tw.plain_barrier.wait()
+                if comm.rank == 0:          # the ranks are threads of ONE interpreter: a cyclic-GC pass over everybody's garbage would be billed to
+                    import gc               # whichever rank's turn it interrupts (a process per rank collects only its own) -> collect once, then off
+                    gc.collect()
+                    gc.disable()
+                comm.tw.plain_barrier.wait()
                 comm.reset_counters()
                 if args.host_profile and comm.rank == min(1, world - 1):
                     import cProfile
@@ -456,6 +461,8 @@ def emulate(args) -> int:
                 "loss": float(total), "trace": comm.trace}
 
     results = ppd.run_thread_world(world, body, dev)
+    import gc
+    gc.enable()
     steps = args.steps
     compute_ms = [r["compute_s"] * 1e3 / steps for r in results]
     build_ms = [r["build_s"] * 1e3 / steps for r in results]
@@ -472,7 +479,11 @@ def emulate(args) -> int:
         "emulated_ranks": world, "steps": steps, "warmup": args.warmup, "overlap_schedule": not args.no_overlap,
         "workload": f"m={args.events}, N={args.nodes}, span={args.span}, delta={args.delta}, F={args.features}",
         "per_rank_compute_ms": compute_ms, "per_rank_graph_build_ms": build_ms,
-        "max_rank_compute_ms": slowest, "mean_rank_compute_ms": sum(compute_ms) / world,
+        "max_rank_compute_ms": slowest, "mean_rank_compute_ms": sum(compute_ms) / world, "median_rank_compute_ms": sorted(compute_ms)[world // 2],
+        # (all emulated ranks share ONE caching allocator: a retry = a failed hipMalloc answered by freeing the cache, paid by whichever rank's turn it hits)
+        "emulation_allocator": {"peak_allocated_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30,
+                                "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0)),
+                                "device_mallocs": int(torch.cuda.memory_stats().get("num_device_alloc", 0))},
         "per_rank": {k: [r["sizes"].get(k) for r in results] for k in ("E2_local", "A2_local", "lift_events_local", "layer1_events_local", "ho_halo", "fo_halo")},
         "collectives_costliest_rank": priced,
         "link_model": {"GB_per_s_per_direction_and_link": XGMI_GBS_PER_DIRECTION, "efficiency": XGMI_EFFICIENCY,
@@ -487,6 +498,8 @@ def emulate(args) -> int:
     }
     if args.trace:
         report["phase_ms_rank1"] = {k: v * 1e3 / steps for k, v in (results[min(1, world - 1)]["trace"] or {}).items()}
+        report["phase_ms_rank0"] = {k: v * 1e3 / steps for k, v in (results[0]["trace"] or {}).items()}
+        report["phase_ms_last_rank"] = {k: v * 1e3 / steps for k, v in (results[world - 1]["trace"] or {}).items()}
     print(json.dumps(report), flush=True)
     return 0
 
