@@ -219,7 +219,9 @@ class ThreadWorld:
         if rank == world - 1:
             with self.cv:
                 self.arrived.pop(seq - 1, None)
-        comm._clock_start()
+        if collect is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()          # the copies that stand in for the collective are queued asynchronously: drain them BEFORE the turn's clock
+        comm._clock_start()                   # starts, or their GPU time is billed to this rank's compute (and priced again on the link model)
         return out
 
     def release(self, comm):
