@@ -408,10 +408,16 @@ def emulate(args) -> int:
     y = torch.randint(0, args.classes, (args.nodes,), generator=feat, device=dev)
     loaders = ((lambda rows: x.index_select(0, rows)), (lambda rows: x_h.index_select(0, rows)), (lambda rows: y.index_select(0, rows)))
 
+    # identical initial weights on every rank, as in the multi-process run — drawn ONCE here: the emulated ranks are threads that share torch's
+    # global generator, seeding it in every thread would race (each rank would start from different weights)
+    torch.manual_seed(0)
+    init_state = pp.nn.DBGNN(num_classes=args.classes, num_features=(args.features, args.features), hidden_dims=[args.features] * 3,
+                             p_dropout=args.dropout).to(dev).state_dict()
+
     def body(comm):
-        torch.manual_seed(0)
         net = pp.nn.DBGNN(num_classes=args.classes, num_features=(args.features, args.features), hidden_dims=[args.features] * 3,
                           p_dropout=args.dropout).to(dev)
+        net.load_state_dict(init_state)
         opt = pp.nn.optim.Adam(net.parameters(), lr=1e-3)                            # (pp_adam_f32: one launch over all parameter tensors)
         sharded = ppd.ShardedDBGNN(net, comm, overlap=not args.no_overlap)
         if args.trace:

@@ -255,6 +255,10 @@ def test_bench_partition_default_and_rccl_world1_and_gloo_world2():
         assert abs(line["loss"] - one["loss"]) < 1e-3 * max(1.0, abs(one["loss"]))
         if nproc == 2:
             assert line["comm_bytes_per_step_rank0"]["exchange"] > 0 and line["comm_bytes_per_step_rank0"]["reduce_scatter"] > 0
+    # the emulation (R ranks as threads on the one GPU) trains the same model on the same stream: same loss after the same steps
+    emulated = _bench(["--emulate-ranks", "3"])
+    assert emulated["emulated_ranks"] == 3 and emulated["E2"] == one["config"]["E2"]
+    assert abs(emulated["loss"] - one["loss"]) < 1e-3 * max(1.0, abs(one["loss"])), (emulated["loss"], one["loss"])
     # the driver's command shape without a launcher: `python bench.py --gpus N` starts its own ranks
     self_launched = _bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"])
     assert self_launched["n_gpus"] == 2 and self_launched["config"]["E2"] == one["config"]["E2"] and self_launched["scaling"] == "strong"
