@@ -259,6 +259,11 @@ def test_bench_partition_default_and_rccl_world1_and_gloo_world2():
     emulated = _bench(["--emulate-ranks", "3"])
     assert emulated["emulated_ranks"] == 3 and emulated["E2"] == one["config"]["E2"]
     assert abs(emulated["loss"] - one["loss"]) < 1e-3 * max(1.0, abs(one["loss"])), (emulated["loss"], one["loss"])
+    # BASELINE configs[1] (2M events), forward pass at the initial weights: the 8-way sharded build + partitioned forward against the single-GPU path
+    c1 = ["--warmup", "0", "--steps", "1", "--events", "2000000", "--nodes", "100000", "--span", "1000000", "--delta", "100000"]
+    whole, split = _bench(c1), _bench(c1 + ["--emulate-ranks", "8"])
+    assert split["E2"] == whole["config"]["E2"] and split["A2"] == whole["config"]["A2"] and split["U2"] == whole["config"]["U2"]
+    assert abs(split["loss"] - whole["loss"]) < 1e-5 * abs(whole["loss"]), (split["loss"], whole["loss"])
     # the driver's command shape without a launcher: `python bench.py --gpus N` starts its own ranks
     self_launched = _bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"])
     assert self_launched["n_gpus"] == 2 and self_launched["config"]["E2"] == one["config"]["E2"] and self_launched["scaling"] == "strong"
