@@ -406,7 +406,9 @@ def emulate(args) -> int:
     x = torch.randn(args.nodes, args.features, generator=feat, device=dev)          # resident inputs, shared by the emulated ranks
     x_h = torch.randn(n_ho, args.features, generator=feat, device=dev)
     y = torch.randint(0, args.classes, (args.nodes,), generator=feat, device=dev)
-    loaders = ((lambda rows: x.index_select(0, rows)), (lambda rows: x_h.index_select(0, rows)), (lambda rows: y.index_select(0, rows)))
+    # features through row loaders (a rank touches only its owned + halo rows); the label vector (8 bytes per node) is handed over whole: a rank's
+    # labels are then a VIEW of it, and the class-range check of the loss is remembered on the base tensor instead of costing a read-back per step
+    loaders = ((lambda rows: x.index_select(0, rows)), (lambda rows: x_h.index_select(0, rows)), y)
 
     # identical initial weights on every rank, as in the multi-process run — drawn ONCE here: the emulated ranks are threads that share torch's
     # global generator, seeding it in every thread would race (each rank would start from different weights)
@@ -572,8 +574,7 @@ def main() -> int:
     opt = pp.nn.optim.Adam(net.parameters(), lr=1e-3)                               # (pp_adam_f32: one launch over all parameter tensors)
     sharded = ppd.ShardedDBGNN(net, comm, overlap=not args.no_overlap) if partition else None
     # world size > 1: a rank reads only its owned + halo rows of the (resident) inputs
-    x_in, xh_in, y_in = (x, x_h, y) if world == 1 else ((lambda rows: x.index_select(0, rows)), (lambda rows: x_h.index_select(0, rows)),
-                                                        (lambda rows: y.index_select(0, rows)))
+    x_in, xh_in, y_in = (x, x_h, y) if world == 1 else ((lambda rows: x.index_select(0, rows)), (lambda rows: x_h.index_select(0, rows)), y)
     lift_ms = []
     sizes = {}
 
