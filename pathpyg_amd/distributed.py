@@ -962,7 +962,7 @@ def distribute_stream(g, delta, comm: Comm, ops=None, weight: str = "edge_weight
     mine = order[owner_ptr[rank]: owner_ptr[rank + 1]]
     cap_n = max(max(plan["fo_cuts"][r + 1] - plan["fo_cuts"][r] for r in range(world)), 1)
     cap_m = max(max(owner_ptr[r + 1] - owner_ptr[r] for r in range(world)), 1)
-    # where the events of my lift slice sit in the [world, cap_m] buffer of all-gathered (event -> local order-2 node) maps
+    # where the events of my lift slice sit in the [world, cap_n + cap_m] buffer of all-gathered (block sizes | event -> local order-2 node) rows
     pos_of_event = torch.empty(m, dtype=torch.int64, device=dev)
     pos_of_event[order] = torch.arange(m, dtype=torch.int64, device=dev)
     k = pos_of_event[lo_e:end_e]
@@ -971,7 +971,7 @@ def distribute_stream(g, delta, comm: Comm, ops=None, weight: str = "edge_weight
     shard = StreamShard(plan=plan, world=world, rank=rank, n=n, m=m, ei_l1=ei.index_select(1, mine).contiguous(),
                         w_l1=None if w_all is None else w_all.index_select(0, mine).contiguous(), ei_lift=ei[:, lo_e:end_e].contiguous(),
                         time_lift=time[lo_e:end_e].contiguous(), w_lift=None if w_all is None else w_all[lo_e:end_e].contiguous(),
-                        n_own_lift=hi_e - lo_e, slot=(q * cap_m + (k - ptr_t[q])).contiguous(), slot_owner=q.contiguous(), cap_n=cap_n, cap_m=cap_m,
+                        n_own_lift=hi_e - lo_e, slot=(q * (cap_n + cap_m) + cap_n + (k - ptr_t[q])).contiguous(), slot_owner=q.contiguous(), cap_n=cap_n, cap_m=cap_m,
                         stamp=stamp, delta=delta)
     try:
         if not isinstance(cache, dict):
@@ -1006,12 +1006,13 @@ def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
     comm.mark("build: 1+2 layer-1 coalesce + lift")
     # global ids: per-node block sizes of all ranks (N ints over the wire) -> row_ptr; event -> order-2 node map of all ranks (m ints)
     ptr_r = ops.ptr_from_sorted(fo_r[0] - lo_n, n_fo_own)                                       # int64 [n_fo_own + 1], local
-    blocks_pad = torch.zeros(ss.cap_n, dtype=torch.int32, device=dev)
-    blocks_pad[:n_fo_own] = ptr_r[1:] - ptr_r[:-1]
-    inv_pad = torch.zeros(ss.cap_m, dtype=torch.int32, device=dev)
-    inv_pad[:m_l1] = inv_r
-    blocks_all = comm.all_gather_rows(blocks_pad).view(world, ss.cap_n)
-    inv_all = comm.all_gather_rows(inv_pad)                                                     # [world * cap_m]
+    # (one all-gather for both: [block sizes | event -> local node map] per rank)
+    both = torch.zeros(ss.cap_n + ss.cap_m, dtype=torch.int32, device=dev)
+    both[:n_fo_own] = ptr_r[1:] - ptr_r[:-1]
+    both[ss.cap_n: ss.cap_n + m_l1] = inv_r
+    gathered = comm.all_gather_rows(both).view(world, ss.cap_n + ss.cap_m)
+    blocks_all = gathered[:, : ss.cap_n]
+    inv_all = gathered.reshape(-1)                                                                # rank q's map starts at q * (cap_n + cap_m) + cap_n
     own_blocks = blocks_all.sum(dim=1, dtype=torch.int64)                                       # order-2 nodes per rank
     ho_cuts_t = torch.zeros(world + 1, **i64)
     torch.cumsum(own_blocks, 0, out=ho_cuts_t[1:])
