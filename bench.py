@@ -74,6 +74,30 @@ def parse():
     return ap.parse_args()
 
 
+class ResidentRows:
+    """Row store of a partitioned run: a rank's OWNED feature rows are resident (placed once, in a buffer with room for the halo rows behind
+    them), only the halo rows — whatever the current graph makes them — are fetched per step.  `full` stands in for the other ranks' stores (in
+    the emulation and in this bench every process can read the whole matrix; a sharded deployment fetches the halo rows over xGMI instead)."""
+
+    def __init__(self, full: torch.Tensor):
+        self.full = full
+        self.placed = {}          # (lo, hi) -> buffer [n_own + halo capacity, F]; one entry per rank (threads of the emulation share the object)
+
+    def shard_rows(self, lo: int, hi: int, halo_ids: torch.Tensor | None) -> torch.Tensor:
+        n_own, n_halo = hi - lo, 0 if halo_ids is None else int(halo_ids.numel())
+        buf = self.placed.get((lo, hi))
+        if buf is None or buf.size(0) < n_own + n_halo:
+            buf = torch.empty((n_own + n_halo + n_halo // 8 + 1, self.full.size(1)), dtype=self.full.dtype, device=self.full.device)
+            buf[:n_own] = self.full[lo:hi]                     # placement of the owned rows: once per ownership range
+            self.placed[(lo, hi)] = buf
+        if n_halo:
+            torch.index_select(self.full, 0, halo_ids, out=buf[n_own: n_own + n_halo])
+        return buf[: n_own + n_halo]
+
+    def __call__(self, rows: torch.Tensor) -> torch.Tensor:      # (plain row-loader form, world size 1 / callers without a shard)
+        return self.full.index_select(0, rows)
+
+
 def synth_stream(events: int, nodes: int, span: int, seed: int, device):
     """Temporal Erdos-Renyi stream: endpoints and timestamps i.i.d. uniform (self loops kept), unsorted."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -406,9 +430,9 @@ def emulate(args) -> int:
     x = torch.randn(args.nodes, args.features, generator=feat, device=dev)          # resident inputs, shared by the emulated ranks
     x_h = torch.randn(n_ho, args.features, generator=feat, device=dev)
     y = torch.randint(0, args.classes, (args.nodes,), generator=feat, device=dev)
-    # features through row loaders (a rank touches only its owned + halo rows); the label vector (8 bytes per node) is handed over whole: a rank's
-    # labels are then a VIEW of it, and the class-range check of the loss is remembered on the base tensor instead of costing a read-back per step
-    loaders = ((lambda rows: x.index_select(0, rows)), (lambda rows: x_h.index_select(0, rows)), y)
+    # features through resident row stores (a rank's owned rows stay placed, its halo rows are fetched per step); the label vector (8 bytes per
+    # node) is handed over whole: a rank's labels are then a VIEW of it, and the class-range check of the loss is remembered on the base tensor
+    loaders = (ResidentRows(x), ResidentRows(x_h), y)
 
     # identical initial weights on every rank, as in the multi-process run — drawn ONCE here: the emulated ranks are threads that share torch's
     # global generator, seeding it in every thread would race (each rank would start from different weights)
@@ -574,7 +598,7 @@ def main() -> int:
     opt = pp.nn.optim.Adam(net.parameters(), lr=1e-3)                               # (pp_adam_f32: one launch over all parameter tensors)
     sharded = ppd.ShardedDBGNN(net, comm, overlap=not args.no_overlap) if partition else None
     # world size > 1: a rank reads only its owned + halo rows of the (resident) inputs
-    x_in, xh_in, y_in = (x, x_h, y) if world == 1 else ((lambda rows: x.index_select(0, rows)), (lambda rows: x_h.index_select(0, rows)), y)
+    x_in, xh_in, y_in = (x, x_h, y) if world == 1 else (ResidentRows(x), ResidentRows(x_h), y)      # owned rows resident, halo rows fetched per step
     lift_ms = []
     sizes = {}
 

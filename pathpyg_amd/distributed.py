@@ -768,6 +768,17 @@ def _rows_of(source, rows: torch.Tensor | None, lo: int = 0, hi: int = 0, device
     return source.index_select(0, rows) if rows is not None else source[lo:hi]
 
 
+def _shard_rows(source, gs) -> torch.Tensor:
+    """Feature rows ``[owned | halo]`` of a graph shard.  A source with a ``shard_rows(lo, hi, halo_ids) -> [n_own + n_halo, F]`` method decides
+    itself how to provide them — a RESIDENT row store keeps a rank's owned rows where they are and only fetches the halo rows (what a deployment
+    does: the owned rows of the input features live on their rank; `bench.py` ``ResidentRows``); tensors and plain row loaders see
+    ``gs.local_rows()``."""
+    fetch = getattr(source, "shard_rows", None)
+    if fetch is not None:
+        return fetch(gs.lo, gs.hi, gs.halo_ids)
+    return _rows_of(source, gs.local_rows())
+
+
 def _window_ends(time: torch.Tensor, his: torch.Tensor, delta) -> torch.Tensor:
     """:func:`halo_end` for a vector of range ends ``his`` (device tensor), without a host read-back."""
     m = int(time.numel())
@@ -1077,10 +1088,10 @@ def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
     fptr = fo_shard.plan.fwd_ptr
     indeg = (fptr[1:] - fptr[:-1]).to(torch.float32)                            # order-2 nodes (., b) per owned first-order node b
     comm.mark("build: bipartite plan + status read-back")
-    x_loc = _rows_of(x, fo_shard.local_rows())
+    x_loc = _shard_rows(x, fo_shard)
     if callable(x_h) and _takes_count(x_h):
         x_h = x_h(n_ho)
-    xh_loc = _rows_of(x_h, ho.local_rows())
+    xh_loc = _shard_rows(x_h, ho)
     comm.mark("build: feature rows (owned + halo)")
     return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(),
                       y=_rows_of(y, None, lo_n, hi_n, dev), n_fo=n, n_ho=n_ho,
