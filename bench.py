@@ -440,6 +440,8 @@ def emulate(args) -> int:
     init_state = pp.nn.DBGNN(num_classes=args.classes, num_features=(args.features, args.features), hidden_dims=[args.features] * 3,
                              p_dropout=args.dropout).to(dev).state_dict()
 
+    alloc_mark = {}
+
     def body(comm):
         net = pp.nn.DBGNN(num_classes=args.classes, num_features=(args.features, args.features), hidden_dims=[args.features] * 3,
                           p_dropout=args.dropout).to(dev)
@@ -458,6 +460,7 @@ def emulate(args) -> int:
                     import gc               # whichever rank's turn it interrupts (a process per rank collects only its own) -> collect once, then off
                     gc.collect()
                     gc.disable()
+                    alloc_mark["device_mallocs_before_timed"] = int(torch.cuda.memory_stats().get("num_device_alloc", 0))
                 comm.tw.plain_barrier.wait()
                 comm.reset_counters()
                 if args.host_profile and comm.rank == min(1, world - 1):
@@ -515,7 +518,8 @@ def emulate(args) -> int:
         # (all emulated ranks share ONE caching allocator: a retry = a failed hipMalloc answered by freeing the cache, paid by whichever rank's turn it hits)
         "emulation_allocator": {"peak_allocated_gib": torch.cuda.max_memory_allocated() / 2 ** 30, "peak_reserved_gib": torch.cuda.max_memory_reserved() / 2 ** 30,
                                 "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0)),
-                                "device_mallocs": int(torch.cuda.memory_stats().get("num_device_alloc", 0))},
+                                "device_mallocs": int(torch.cuda.memory_stats().get("num_device_alloc", 0)),
+                                "device_mallocs_in_timed_steps": int(torch.cuda.memory_stats().get("num_device_alloc", 0)) - alloc_mark.get("device_mallocs_before_timed", 0)},
         "per_rank": {k: [r["sizes"].get(k) for r in results] for k in ("E2_local", "A2_local", "lift_events_local", "layer1_events_local", "ho_halo", "fo_halo")},
         "collectives_costliest_rank": priced,
         "link_model": {"GB_per_s_per_direction_and_link": XGMI_GBS_PER_DIRECTION, "efficiency": XGMI_EFFICIENCY,
