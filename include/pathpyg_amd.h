@@ -51,6 +51,11 @@ enum pp_delta_kind { PP_DELTA_I64 = 0, PP_DELTA_F32 = 1, PP_DELTA_F64 = 2 };
 
 int pp_version(void);
 const char* pp_last_error(void);
+/* Concurrency between two HIP streams of one process (no reference counterpart: the reference runs nn/dbgnn.py:130-145 — the first-order
+ * stack, then the higher-order stack — as one serial chain of torch ops).  The fused layer kernels launch PERSISTENT grids sized to the
+ * workgroups that are resident at once, which leaves no slot for a kernel of another stream.  pp_set_launch_share(s) lets the persistent
+ * launches of the CALLING THREAD take only s per mille of those slots (1..1000, default 1000) and returns the previous value. */
+int pp_set_launch_share(int per_mille);
 
 /* ------------------------------------------------------------------ primitives (pp_scan.hip, pp_sort.hip) */
 

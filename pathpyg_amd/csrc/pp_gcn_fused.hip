@@ -508,7 +508,7 @@ static int launch_gcn_forward(int64_t n_tiles, hipStream_t st, const GcnArgs& a)
         PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         resident_of[hv] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
     }
-    const int resident = resident_of[hv];
+    const int64_t resident = shared_grid(resident_of[hv]);
     int64_t blocks = ceil_div(n_tiles, kThreads / kWave);
     if (blocks > resident) blocks = resident;
     else blocks = (blocks + 7) / 8 * 8;                                 // (a multiple of the 8 XCDs: the kernel's tile order wants whole dies)
@@ -831,7 +831,7 @@ static int launch_gcn_backward(int64_t n_tiles, hipStream_t st, const int32_t* p
         resident_of[hv] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
         if (resident_of[hv] > kGcnBackwardMaxBlocks) resident_of[hv] = (int)kGcnBackwardMaxBlocks;
     }
-    const int resident = resident_of[hv];
+    const int64_t resident = shared_grid(resident_of[hv]);
     int64_t blocks = ceil_div(n_tiles, kGcnWaves);
     if (blocks > resident) blocks = resident;
     *blocks_out = blocks;

@@ -386,7 +386,7 @@ static int launch_wide(hipStream_t st, const WideArgs& a) {
         resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
     }
     int64_t blocks = ceil_div(ceil_div(a.n_rows, 16), kWideWaves);
-    if (blocks > resident) blocks = resident;
+    if (blocks > shared_grid(resident)) blocks = shared_grid(resident);
     k_wide_layer<P, Q, kEpi><<<(unsigned)blocks, kWideThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n_rows, a.n_self, a.X, a.self_coef, a.Wr, a.bias, a.act,
                                                                          a.heavy, a.agg_out, a.Y, a.act_in, a.colsum);
     PP_LAUNCH_CHECK();

@@ -5,6 +5,13 @@
 namespace pp {
 
 // pp_scan.hip
+// Share (per mille) of the resident workgroup slots a PERSISTENT grid of the calling thread may take (pp_set_launch_share): the kernels
+// that size their grid to "exactly what is resident at once" leave the rest of the slots to kernels of another stream.
+int launch_share_permille();
+static inline int64_t shared_grid(int64_t resident) {
+    const int64_t g = resident * launch_share_permille() / 1000;
+    return g < 8 ? 8 : g / 8 * 8;
+}
 size_t scan_ws_bytes(int64_t n);
 template <typename InT, typename OutT>
 int exclusive_scan(const InT* in, int64_t n, OutT* out, bool with_total, int64_t* total_dev, void* ws, size_t ws_bytes,

@@ -23,8 +23,7 @@
 //      row-major [2,E2] result (lexicographic (i,j) order by construction).
 // HBM algorithmic bytes: 24*m (tail, head, time) + 16*E2 (result).
 #include "pp_internal.h"
-
-#include <type_traits>
+#include "pp_window.h"
 
 namespace pp {
 
@@ -53,34 +52,6 @@ __global__ __launch_bounds__(kBlock) void k_rowptr_from_sorted(const KeyT* __res
     if (b > num_rows) b = num_rows;
     for (int64_t v = a + 1; v <= b; ++v) rowptr[v] = (uint32_t)p;
 }
-
-// ------------------------------------------------------------------ temporal window arithmetic
-// kMode 0: native dtype (int64 time + int64 delta, or float64 time + float64 delta)
-// kMode 1: int64 time, float32 delta tensor  -> everything in float32 (torch promotion)
-// kMode 2: int64 time, float64 delta tensor  -> everything in float64
-template <typename TimeT, int kMode>
-struct Window;
-template <typename TimeT>
-struct Window<TimeT, 0> {
-    using Thr = TimeT;
-    __device__ static Thr threshold(TimeT t, int64_t di, double df) {
-        if constexpr (std::is_integral<TimeT>::value) return (TimeT)(t + (TimeT)di);
-        else return (TimeT)(t + (TimeT)df);
-    }
-    __device__ static bool admits(TimeT tj, Thr thr) { return tj <= thr; }
-};
-template <>
-struct Window<int64_t, 1> {
-    using Thr = float;
-    __device__ static Thr threshold(int64_t t, int64_t, double df) { return (float)t + (float)df; }
-    __device__ static bool admits(int64_t tj, Thr thr) { return (float)tj <= thr; }
-};
-template <>
-struct Window<int64_t, 2> {
-    using Thr = double;
-    __device__ static Thr threshold(int64_t t, int64_t, double df) { return (double)t + df; }
-    __device__ static bool admits(int64_t tj, Thr thr) { return (double)tj <= thr; }
-};
 
 // marks[w] = first event id whose time the window of event 64*w (the first lane of wave w of k_temporal_count) no longer admits, over the
 // whole stream; marks[n_waves] = m.  The stream is time-sorted, so the window end of every event of wave w lies in

@@ -11,6 +11,8 @@
 namespace pp {
 
 static thread_local char g_err[512] = "";
+static thread_local int g_launch_share = 1000;
+int launch_share_permille() { return g_launch_share; }
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -252,6 +254,11 @@ extern "C" {
 
 int pp_version(void) { return PP_VERSION; }
 const char* pp_last_error(void) { return pp::g_err; }
+int pp_set_launch_share(int per_mille) {
+    const int before = pp::g_launch_share;
+    pp::g_launch_share = per_mille < 1 ? 1 : (per_mille > 1000 ? 1000 : per_mille);
+    return before;
+}
 
 size_t pp_scan_ws_bytes(int64_t n) { return pp::scan_ws_bytes(n); }
 

@@ -37,8 +37,9 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for group in self.param_groups:
-            ps, gs, ms, vs, ns = [], [], [], [], []
-            step_no = None
+            # pass 1: validate every parameter of the group; nothing is modified before all of them passed (an exception must not leave
+            # some step counters advanced with no update applied)
+            todo = []
             dev = None
             for p in group["params"]:
                 g = p.grad
@@ -53,25 +54,35 @@ class Adam(torch.optim.Optimizer):
                     raise RuntimeError(f"parameters of one group on different devices: {dev} and {p.device}")
                 if not p.is_contiguous():
                     raise RuntimeError("pathpyg_amd.nn.optim.Adam: parameters must be contiguous")
+                todo.append((p, g if g.is_contiguous() else g.contiguous()))
+            # pass 2: state + launches (parameters that joined later have their own step number, hence their own launch)
+            ps, gs, ms, vs, ns, sts = [], [], [], [], [], []
+            step_no = None
+
+            def flush():
+                self._launch(group, ps, gs, ms, vs, ns, step_no, dev)
+                for st_ in sts:                                # the counters advance once their update has been queued
+                    st_["step"] = step_no
+
+            for p, g in todo:
                 state = self.state[p]
                 if not state:
                     state["step"] = 0
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                state["step"] = int(state["step"]) + 1
-                if step_no is None:
-                    step_no = state["step"]
-                elif step_no != state["step"]:                 # (parameters that joined later: their own launch)
-                    self._launch(group, ps, gs, ms, vs, ns, step_no, dev)
-                    ps, gs, ms, vs, ns, step_no = [], [], [], [], [], state["step"]
-                g = g if g.is_contiguous() else g.contiguous()
+                mine = int(state["step"]) + 1
+                if step_no is not None and step_no != mine:
+                    flush()
+                    ps, gs, ms, vs, ns, sts = [], [], [], [], [], []
+                step_no = mine
+                sts.append(state)
                 ps.append(p)
                 gs.append(g)
                 ms.append(state["exp_avg"])
                 vs.append(state["exp_avg_sq"])
                 ns.append(p.numel())
             if ps:
-                self._launch(group, ps, gs, ms, vs, ns, step_no, dev)
+                flush()
         return loss
 
     @staticmethod
