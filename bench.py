@@ -65,6 +65,8 @@ def parse():
                     "(dense = every foreign node, no discovery round; auto picks it when a rank's in-edges exceed 1.5 x the node count)")
     ap.add_argument("--halo-row-backward", action="store_true", help="partition path, world > 1: the round-2 backward (fused kernel over owned + halo rows, "
                     "its output exchanged) instead of exchanging A^T dpre and multiplying on the owned rows only (A/B)")
+    ap.add_argument("--builder", choices=("fused", "generic"), default="fused", help="1 GPU: graph construction by the node-by-node order-2 builder "
+                    "(pp_debruijn2_*; one read-back, the event graph is never written) or by the generic kernels (lift -> coalesce -> plans)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-loop-events", type=int, default=6_000, help="smallest of the three B-loop sizes (x2, x4 follow; kept below torch's 32768-element parallel grain)")
     ap.add_argument("--cpu-sample-events", type=int, default=2_000_000, help="size of the vectorised CPU pipeline sample (B-agg, B-dbgnn)")
@@ -549,6 +551,9 @@ def main() -> int:
     if args.halo_row_backward:
         import pathpyg_amd.nn.sharded as _sh
         _sh.OWNED_ROW_BACKWARD = False
+    if args.builder == "generic":
+        import pathpyg_amd.distributed as _pd0
+        _pd0.FUSED_BUILDER = False
     if args.fo_halo != "auto":
         import pathpyg_amd.distributed as _pd
         _pd.FO_DENSE_HALO = args.fo_halo == "dense"

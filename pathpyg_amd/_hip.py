@@ -700,6 +700,74 @@ def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_val
     return plan
 
 
+class DeBruijn2:
+    """Result of :func:`debruijn2`: the GCN plans of the first-order and the order-2 graph of a temporal stream, the bipartite "last" plan
+    and the layer sizes (``m`` events, ``E2`` lifted instance pairs, ``U2`` order-2 nodes = first-order edges, ``A2`` order-2 edges)."""
+
+    __slots__ = ("fo", "ho", "bip", "sizes", "fo_weight", "fo_dst")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, weight: torch.Tensor | None = None):
+    """Order-2 De Bruijn model of a TIME-SORTED event stream, fused (pp_debruijn2_count / _fill, csrc/pp_debruijn.hip): what
+    ``coalesce`` (layer 1) + ``temporal_lift`` + ``coalesce`` (layer 2) + ``gcn_plan`` x 2 + ``bipartite_plan_from_edge_grouping`` build,
+    identical array by array, with ONE read-back and without the event graph.  ``weight``: None (unit weights) or float32 [m].
+    Returns a :class:`DeBruijn2`, or ``None`` when the builder does not apply (a node with more than 64 in- or out-events, an empty
+    stream): the caller then takes the generic path."""
+    ei = _edge_index(edge_index)
+    dev = require_device(ei, time, weight)
+    if time.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
+        time = time.to(torch.int64)
+    if time.dtype not in (torch.int64, torch.float64):
+        raise TypeError(f"timestamps must be int64 or float64, got {time.dtype}")
+    time = time.contiguous()
+    m, n = ei.size(1), int(num_nodes)
+    if time.numel() != m:
+        raise ValueError("time and edge_index disagree on the number of events")
+    if m == 0 or n == 0:
+        return None
+    if weight is not None:
+        if weight.dtype != torch.float32 or weight.numel() != m:
+            return None
+        weight = weight.contiguous()
+    kind, di, df = resolve_delta(time.dtype, delta)
+    L = lib()
+    with torch.cuda.device(dev):
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        ws = _workspace(L.pp_debruijn2_ws_bytes(m, n), dev)
+        fo_bwd_ptr, fo_fwd_ptr = torch.empty(n + 1, **i32), torch.empty(n + 1, **i32)
+        fo_bwd_idx, fo_w = torch.empty(m, **i32), torch.empty(m, **f32)
+        ho_fwd_ptr, ho_bwd_ptr = torch.empty(m + 1, **i32), torch.empty(m + 1, **i32)
+        ho_deg, fo_deg = torch.empty(m, **f32), torch.empty(n, **f32)
+        tcode = _DTYPE_CODE[time.dtype]
+        check(L.pp_debruijn2_count(_p(ei), _p(time), tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_bwd_idx), _p(fo_w), _p(fo_fwd_ptr),
+                                   _p(ho_fwd_ptr), _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), _p(ws), ws.numel(), _stream()), "pp_debruijn2_count")
+        u2, status, a2, e2, a1 = ws[:40].view(torch.int64).tolist()                      # the ONE read-back of the whole graph construction
+        _bad_index(status, "MultiOrderModel.from_temporal_graph")
+        if status & 2:
+            raise ValueError("lift_order_temporal: the events are not sorted by time (TemporalGraph sorts them on construction; "
+                             "data.time / data.edge_index were modified afterwards)")
+        if status & 4:
+            return None
+        ho = CsrPlan(n_dst=u2, n_src=u2, fwd_ptr=ho_fwd_ptr[: u2 + 1], fwd_idx=torch.empty(a2, **i32), fwd_val=torch.empty(a2, **f32),
+                     bwd_ptr=ho_bwd_ptr[: u2 + 1], bwd_idx=torch.empty(a2, **i32), bwd_val=torch.empty(a2, **f32), self_coef=torch.empty(u2, **f32),
+                     edge_ordered=True)
+        fo = CsrPlan(n_dst=n, n_src=n, fwd_ptr=fo_fwd_ptr, fwd_idx=torch.empty(a1, **i32), fwd_val=torch.empty(a1, **f32),
+                     bwd_ptr=fo_bwd_ptr, bwd_idx=fo_bwd_idx[:u2], bwd_val=torch.empty(u2, **f32), self_coef=torch.empty(n, **f32),
+                     dst_order=torch.empty(a1, **i32), edge_ordered=True)
+        check(L.pp_debruijn2_fill(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr), _p(ho_bwd_ptr),
+                                  _p(ho_deg), _p(fo_deg), _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx), _p(ho.bwd_val), _p(ho.self_coef),
+                                  _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.dst_order), _p(fo.bwd_val), _p(fo.self_coef), _p(ws), ws.numel(), _stream()),
+              "pp_debruijn2_fill")
+    bip = bipartite_plan_from_edge_grouping(fo, None, u2)
+    return DeBruijn2(fo=fo, ho=ho, bip=bip, fo_weight=fo_w[:u2], fo_dst=fo.bwd_idx,
+                     sizes={"m": m, "N": n, "E2": e2, "U2": u2, "A1": a1, "A2": a2})
+
+
 def spmm(ptr, idx, val, n_rows: int, x: torch.Tensor, self_coef=None, s=None, bias=None, act: bool = False,
          heavy: HeavyRows | None = None) -> torch.Tensor:
     """Y[r] = act(sum_p val[p] * x[idx[p]] + self_coef[r] * s[r] + bias) — fp32, rows of width F.  ``heavy``: the hub rows of this

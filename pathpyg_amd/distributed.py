@@ -753,6 +753,8 @@ def shard_dbgnn_bundle(data, comm: Comm, ops=None, fo_cuts: list[int] | None = N
     return DbgnnShard(fo=fo, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x.contiguous(), x_h=x_h.contiguous(), y=y, n_fo=n_fo, n_ho=n_ho)
 
 
+FUSED_BUILDER = True   # build_dbgnn_shard at world size 1: the node-by-node order-2 builder (pp_debruijn2_*, one read-back, no event graph) where it
+#                        applies (no node with more than 64 in- / out-events, unit or float32 weights); False: always the generic kernels (A/B, tests)
 FO_DENSE_HALO = None   # first-order shard of build_dbgnn_shard: None = dense halo (all foreign nodes, no discovery) when a rank's in-edges exceed
 #                        1.5 x the node count (U2 >= 1.5 * world * N), True / False force a mode (tests, A/B)
 ROW_COST = 2          # cost of a higher-order row relative to one of its in-edges when the cuts are balanced (a row is read and written once)
@@ -882,6 +884,22 @@ def build_dbgnn_shard(g, delta, x, x_h, y, comm: Comm, ops=None, weight: str = "
     dev = ei.device
     n, m = int(data.num_nodes), int(ei.size(1))
     unit_weights = weight not in data
+    fused = getattr(ops, "debruijn2", None) if FUSED_BUILDER else None
+    if fused is not None and m > 0 and n > 0 and (unit_weights or data[weight].dtype == torch.float32):
+        built = fused(ei, data.time, n, delta, None if unit_weights else data[weight])
+        if built is not None:              # (None: a hub node — the generic path below)
+            from .nn.sharded import GraphShard
+            n_ho = built.sizes["U2"]
+
+            def whole(plan, nodes):
+                return GraphShard(lo=0, hi=nodes, n_own=nodes, n_halo=0, n_src=nodes, num_nodes=nodes, cuts=[0, nodes], plan=plan, send_counts=[0],
+                                  recv_counts=[0])
+            xh_loc = x_h(n_ho) if (callable(x_h) and _takes_count(x_h)) else _rows_of(x_h, None, 0, n_ho, dev)
+            return DbgnnShard(fo=whole(built.fo, n), ho=whole(built.ho, n_ho), bip=built.bip, cap=n, indeg=built.bip.self_coef,
+                              x=_rows_of(x, None, 0, n, dev).contiguous(), x_h=xh_loc.contiguous(), y=_rows_of(y, None, 0, n, dev), n_fo=n, n_ho=n_ho,
+                              sizes={"m": m, "N": n, "E2": built.sizes["E2"], "E2_local": built.sizes["E2"], "U2": n_ho, "A1": built.sizes["A1"],
+                                     "A2": built.sizes["A2"], "A2_local": built.sizes["A2"], "fo_cuts": [0, n], "ho_cuts": [0, n_ho], "fo_halo": 0,
+                                     "ho_halo": 0, "builder": "fused"})
     w = _hip_unit() if unit_weights else data[weight]                       # (unit weights: merged weight = run length, no ones vector, no gather)
     # layer 1 and the lift of the same stream are independent: their count phases are queued together, their sizes cost ONE read-back
     (fo, fo_w, inv1), local = ops.coalesce_and_lift((ei, w, n, "sum", None, True), (ei, data.time.contiguous(), n, delta, m, 0))

@@ -41,6 +41,7 @@ class HipOps:
     bipartite_from_grouping = staticmethod(_hip.bipartite_plan_from_edge_grouping)
 
     # ---- lift + aggregation
+    debruijn2 = staticmethod(_hip.debruijn2)
     temporal_lift = staticmethod(_hip.temporal_lift)
     coalesce = staticmethod(_hip.coalesce)
 

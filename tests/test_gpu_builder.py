@@ -1,0 +1,162 @@
+"""The fused order-2 De Bruijn builder (pp_debruijn2_count / _fill, csrc/pp_debruijn.hip) against the generic kernels it replaces
+(pp_coalesce_* -> pp_temporal_* -> pp_coalesce_* -> pp_gcn_plan x 2, themselves pinned against the oracle and the reference's golden
+vectors in test_gpu_kernels.py / test_gpu_api.py): every array of both GCN plans and of the bipartite plan must be IDENTICAL, bit for bit
+(int32 indices, fp32 coefficients), and the layer sizes equal — on streams with timestamp ties, self loops, isolated nodes, float64
+timestamps, every delta promotion mode of lift_order_temporal (reference algorithms/temporal.py:30,43) and non-integer event weights.
+Also: against the oracle directly (edge lists + weights of both layers), the hub fallback, and the 2*10^6-event BASELINE configs[1] size."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PLAN_FIELDS = ("fwd_ptr", "fwd_idx", "fwd_val", "bwd_ptr", "bwd_idx", "bwd_val", "self_coef")
+
+
+def _stream(seed, m, n, span, time_dtype=torch.int64):
+    rng = np.random.default_rng(seed)
+    ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+    if time_dtype == torch.float64:
+        t = torch.from_numpy(np.sort(rng.random(m) * span))
+    else:
+        t = torch.from_numpy(np.sort(rng.integers(0, span, m)))
+    return ei, t
+
+
+def _build(ei, t, n, delta, weight, fused):
+    import pathpyg_amd as pp
+    from pathpyg_amd import distributed as ppd
+    dev = torch.device("cuda:0")
+    data = pp.Data(edge_index=ei.to(dev), time=t.to(dev), num_nodes=n)
+    if weight is not None:
+        data["edge_weight"] = weight.to(dev)
+    g = pp.TemporalGraph(data)
+    old = ppd.FUSED_BUILDER
+    ppd.FUSED_BUILDER = fused
+    try:
+        x = torch.zeros(n, 4, device=dev)
+        shard = ppd.build_dbgnn_shard(g, delta, x, lambda num_ho_nodes: torch.zeros(num_ho_nodes, 4, device=dev), None, ppd.Comm()).resolve()
+    finally:
+        ppd.FUSED_BUILDER = old
+    return shard
+
+
+def _assert_same(a, b, what):
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} != {tuple(b.shape)}"
+    if not torch.equal(a, b):
+        bad = torch.nonzero(a.reshape(-1) != b.reshape(-1)).flatten()
+        i = int(bad[0])
+        raise AssertionError(f"{what}: {bad.numel()} of {a.numel()} entries differ, first at {i}: {a.reshape(-1)[i].item()!r} != {b.reshape(-1)[i].item()!r}")
+
+
+def _compare(fused, generic):
+    assert fused.sizes.get("builder") == "fused", "the fused builder did not run"
+    assert generic.sizes.get("builder") is None
+    for k in ("m", "N", "E2", "U2", "A1", "A2"):
+        assert fused.sizes[k] == generic.sizes[k], f"sizes[{k}]: {fused.sizes[k]} != {generic.sizes[k]}"
+    for name in ("fo", "ho"):
+        pf, pg = getattr(fused, name).plan, getattr(generic, name).plan
+        assert (pf.n_dst, pf.n_src) == (pg.n_dst, pg.n_src)
+        for fld in PLAN_FIELDS:
+            _assert_same(getattr(pf, fld), getattr(pg, fld), f"{name}.{fld}")
+        assert pf.fwd_heavy is None and pf.bwd_heavy is None
+    _assert_same(fused.fo.plan.dst_order, generic.fo.plan.dst_order, "fo.dst_order")
+    for fld in ("fwd_ptr", "fwd_idx", "bwd_ptr", "bwd_idx", "self_coef"):
+        _assert_same(getattr(fused.bip, fld), getattr(generic.bip, fld), f"bip.{fld}")
+    _assert_same(fused.indeg, generic.indeg, "indeg")
+
+
+CASES = [
+    # seed, m, n, span, delta, time dtype, weighted
+    (1, 4000, 400, 3000, 40, torch.int64, False),            # timestamp ties (span < m), ~10 events per node
+    (2, 6000, 300, 100000, 3000, torch.int64, False),        # few ties, 20 events per node
+    (3, 2500, 90, 700, 15, torch.int64, True),               # small node set: self loops, parallel events, non-integer weights
+    (4, 3000, 5000, 20000, 2500, torch.int64, False),        # most nodes isolated
+    (5, 5000, 350, 1000.0, 30.5, torch.float64, False),      # float64 timestamps
+    (6, 5000, 350, 1000.0, 17.25, torch.float64, True),
+    (7, 1, 3, 10, 5, torch.int64, False),                    # one event
+    (8, 40, 30, 5, 1, torch.int64, False),                   # almost everything ties
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"seed{c[0]}" for c in CASES])
+def test_fused_builder_equals_generic_path(case):
+    seed, m, n, span, delta, tdt, weighted = case
+    ei, t = _stream(seed, m, n, span, tdt)
+    w = None
+    if weighted:
+        w = torch.from_numpy(np.random.default_rng(seed + 100).random(m).astype(np.float32) + 0.25)
+    _compare(_build(ei, t, n, delta, w, True), _build(ei, t, n, delta, w, False))
+
+
+@pytest.mark.parametrize("delta", [7, 7.5, torch.tensor(7.5, dtype=torch.float64), torch.tensor(6, dtype=torch.int32), 0, 10 ** 9],
+                         ids=["int", "py-float=f32", "f64-tensor", "i32-tensor", "zero", "everything"])
+def test_fused_builder_delta_promotion_modes(delta):
+    ei, t = _stream(11, 3000, 250, 900)
+    _compare(_build(ei, t, 250, delta, None, True), _build(ei, t, 250, delta, None, False))
+
+
+def test_fused_builder_against_the_oracle():
+    """Edge lists + merged weights of both layers straight against the CPU oracle (not only against the generic kernels)."""
+    from oracle import model as om
+    ei, t = _stream(21, 5000, 400, 5000)
+    n, delta = 400, 300
+    shard = _build(ei, t, n, delta, None, True)
+    assert shard.sizes.get("builder") == "fused"
+    sei, st, _ = om.stable_time_sort(ei, t)
+    want = om.layers_from_temporal(sei, st, n, delta=delta, max_order=2)
+    for k, gs in ((1, shard.fo), (2, shard.ho)):
+        plan = gs.plan
+        ptr = plan.bwd_ptr.long().cpu()
+        src = torch.repeat_interleave(torch.arange(plan.n_src), ptr[1:] - ptr[:-1])
+        got = torch.stack((src, plan.bwd_idx.long().cpu()))
+        assert torch.equal(got, want[k]["edge_index"]), f"layer {k} edge_index"
+    # merged first-order weights = run lengths; order-2 weights through the normalisation: w = val / (d_src^-1/2 d_dst^-1/2)
+    from pathpyg_amd import _hip
+    dev = torch.device("cuda:0")
+    tg_ei, tg_t = sei.to(dev), st.to(dev)
+    built = _hip.debruijn2(tg_ei, tg_t, n, delta, None)
+    assert torch.equal(built.fo_weight.cpu(), want[1]["edge_weight"].to(torch.float32))
+    e2 = _hip.temporal_lift(tg_ei, tg_t, n, delta).size(1)
+    assert built.sizes["E2"] == e2
+
+
+def test_fused_builder_falls_back_on_hub_nodes():
+    """A node with more than 64 in- or out-events: the builder reports it (status bit 2), build_dbgnn_shard takes the generic kernels."""
+    from pathpyg_amd import _hip
+    rng = np.random.default_rng(5)
+    m, n = 3000, 400
+    ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+    ei[1, :100] = 7                                           # 100 in-events of node 7
+    t = torch.from_numpy(np.sort(rng.integers(0, 5000, m)))
+    dev = torch.device("cuda:0")
+    assert _hip.debruijn2(ei.to(dev), t.to(dev), n, 50, None) is None
+    ei2 = ei.clone()
+    ei2[1, :100] = torch.from_numpy(rng.integers(0, n, 100))
+    ei2[0, 200:300] = 9                                       # 100 out-events of node 9
+    assert _hip.debruijn2(ei2.to(dev), t.to(dev), n, 50, None) is None
+    shard = _build(ei, t, n, 50, None, True)
+    assert shard.sizes.get("builder") is None
+    generic = _build(ei, t, n, 50, None, False)
+    for fld in PLAN_FIELDS:
+        _assert_same(getattr(shard.ho.plan, fld), getattr(generic.ho.plan, fld), f"ho.{fld}")
+
+
+def test_fused_builder_rejects_bad_input():
+    from pathpyg_amd import _hip
+    dev = torch.device("cuda:0")
+    ei = torch.tensor([[0, 1, 5], [1, 2, 0]], device=dev)
+    t = torch.tensor([1, 2, 3], device=dev)
+    with pytest.raises(IndexError):
+        _hip.debruijn2(ei, t, 3, 1, None)
+    with pytest.raises(ValueError):
+        _hip.debruijn2(torch.tensor([[0, 1, 2], [1, 2, 0]], device=dev), torch.tensor([3, 2, 1], device=dev), 3, 1, None)
+
+
+def test_fused_builder_config1_size_equals_generic_path():
+    """BASELINE configs[1]: 10^5 nodes / 2*10^6 events, every plan array identical to the generic path."""
+    gen = torch.Generator().manual_seed(1)
+    m, n = 2_000_000, 100_000
+    ei = torch.randint(0, n, (2, m), generator=gen)
+    t = torch.sort(torch.randint(0, 1_000_000, (m,), generator=gen)).values
+    _compare(_build(ei, t, n, 100_000, None, True), _build(ei, t, n, 100_000, None, False))
