@@ -472,11 +472,11 @@ def emulate(args) -> int:
             comm.barrier()                          # (step boundary: opens this rank's first turn of the step)
             opt.zero_grad(set_to_none=True)
             c0 = comm.lap()
-            shard = ppd.build_dbgnn_shard(g, args.delta, *loaders, comm)
+            shard = ppd.build_dbgnn_shard(g, args.delta, *loaders, comm, defer_status=True)
             build_s += comm.lap() - c0 if it >= args.warmup else 0.0
             loss = sharded.loss(shard)
             loss.backward()
-            ppd.all_reduce_gradients(net, average=False, comm=comm)
+            ppd.all_reduce_gradients(net, average=False, comm=comm, inplace_views=True)
             opt.step()
             comm.mark("step: gradient all-reduce + Adam")
             sizes = shard.sizes
@@ -615,7 +615,7 @@ def main() -> int:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         opt.zero_grad(set_to_none=True)
         e0.record()
-        shard = ppd.build_dbgnn_shard(g, args.delta, x_in, xh_in, y_in, comm)
+        shard = ppd.build_dbgnn_shard(g, args.delta, x_in, xh_in, y_in, comm, defer_status=True)
         e1.record()
         if timed:                                   # (bookkeeping of the live rooflines: pointers -> CSR sizes)
             for gs in (shard.fo, shard.ho):
@@ -625,7 +625,7 @@ def main() -> int:
             SRC_ROWS[shard.bip.bwd_idx.data_ptr()] = shard.bip.n_dst
         loss = sharded.loss(shard)
         loss.backward()
-        ppd.all_reduce_gradients(net, average=False, comm=comm)
+        ppd.all_reduce_gradients(net, average=False, comm=comm, inplace_views=True)
         opt.step()
         sizes.update(shard.sizes)
         step_partition.last_shard = shard

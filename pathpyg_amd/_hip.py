@@ -760,8 +760,9 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
                      bwd_ptr=fo_bwd_ptr, bwd_idx=fo_bwd_idx[:u2], bwd_val=torch.empty(u2, **f32), self_coef=torch.empty(n, **f32),
                      dst_order=torch.empty(a1, **i32), edge_ordered=True)
         check(L.pp_debruijn2_fill(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr), _p(ho_bwd_ptr),
-                                  _p(ho_deg), _p(fo_deg), _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx), _p(ho.bwd_val), _p(ho.self_coef),
-                                  _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.dst_order), _p(fo.bwd_val), _p(fo.self_coef), _p(ws), ws.numel(), _stream()),
+                                  _p(ho_deg), _p(fo_deg), a2, _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx), _p(ho.bwd_val), _p(ho.self_coef),
+                                  _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.dst_order), _p(fo.bwd_val), _p(fo.self_coef),
+                                  _p(torch.empty(2 * a2, **i32)), _p(ws), ws.numel(), _stream()),
               "pp_debruijn2_fill")
     bip = bipartite_plan_from_edge_grouping(fo, None, u2)
     return DeBruijn2(fo=fo, ho=ho, bip=bip, fo_weight=fo_w[:u2], fo_dst=fo.bwd_idx,

@@ -377,7 +377,10 @@ class _LiftChain:
         if self.weight is None or (isinstance(self.weight, str) and aggr in ("src", "dst", "max", "mul")):      # (unit weights stay unit)
             ho_index, weight = lift_order_edge_index(self.index, num_nodes=num_instances), self.weight
         else:
-            ho_index, weight = lift_order_edge_index_weighted(self.index, self.weight, num_nodes=num_instances, aggr=aggr)
+            w_inst = self.weight
+            if isinstance(w_inst, str):            # the UNIT marker under an aggregation that does not preserve it ("add": 1 + 1 = 2): the ones vector
+                w_inst = torch.ones(num_instances, dtype=torch.float32, device=_dispatch.plain(self.index).device)      # the reference starts from
+            ho_index, weight = lift_order_edge_index_weighted(self.index, w_inst, num_nodes=num_instances, aggr=aggr)
         last = aggregate_node_attributes(self.index, self.last, "dst")                 # last node of every new instance
         k = self.unique_nodes.size(1)
         if self.graph is not None and self.edge_ids is not None:

@@ -10,8 +10,8 @@
 // (coalesce by (source, destination), then the plan's destination grouping) and sorts the events twice more (tail lists, layer 1): five
 // global radix sorts and ~1.3e8 random accesses per step of the headline stream.  Here the structure of a De Bruijn graph does the work:
 // every order-2 edge (a,b) -> (b,c) has a MIDDLE NODE b, and everything about it is decided by b's in-events (., b, t) and out-events
-// (b, ., t).  Two sorts of the m events (by tail, by head; 32-bit keys) put both lists of every node next to each other; after that ONE WAVE
-// PER NODE works on ~20 + ~20 events in registers:
+// (b, ., t).  Two sorts of the m events (by tail; then that sequence by head, so that a node's in-events arrive ordered by (source, time);
+// 32-bit keys) put both lists of every node next to each other; after that ONE WAVE PER NODE works on ~20 + ~20 events in registers:
 //   k_db2_out   out-events of b ranked by (c, time): the distinct successors c = the order-2 nodes (b, .) = the first-order out-edges of b
 //               (block sizes -> scan -> ids), their weights (run lengths / left-to-right sums), the out-events stored in that order;
 //   k_db2_mid   in-events of b ranked by (a, time); for every run (a, b) = source node u and every instance i of it ONE ballot over the
@@ -33,8 +33,8 @@ constexpr int64_t kDb2BadIndex = 1, kDb2Unsorted = 2, kDb2Overflow = 4;
 
 struct alignas(16) Db2Rec {
     uint64_t t;       // timestamp bits (int64 or float64)
-    uint32_t u;       // order-2 node id of the event's (src, dst) pair
     uint32_t a;       // src
+    uint32_t c;       // dst
 };
 
 __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -58,11 +58,11 @@ __device__ __forceinline__ float inv_sqrt_deg(float deg) {
 template <typename TimeT>
 __device__ __forceinline__ TimeT time_of(uint64_t bits) { return __builtin_bit_cast(TimeT, bits); }
 
-// ------------------------------------------------------------------ element-wise pre-pass
+// ------------------------------------------------------------------ flat (one thread per event) kernels: every random access of the builder
+// lives here, at full memory-level parallelism; the per-node kernels below read and write contiguous ranges only
 template <typename TimeT>
 __global__ __launch_bounds__(kBlock) void k_db2_keys(const int64_t* __restrict__ ei, const TimeT* __restrict__ time, int64_t m, int64_t n,
-                                                    uint32_t* __restrict__ tkeys, uint32_t* __restrict__ hkeys, Db2Rec* __restrict__ rec,
-                                                    int64_t* __restrict__ status) {
+                                                    uint32_t* __restrict__ tkeys, Db2Rec* __restrict__ rec, int64_t* __restrict__ status) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= m) return;
     int64_t s = ei[e], d = ei[m + e];
@@ -70,11 +70,10 @@ __global__ __launch_bounds__(kBlock) void k_db2_keys(const int64_t* __restrict__
     const TimeT t = time[e];
     if (e + 1 < m && time[e + 1] < t) atomicOr((unsigned long long*)status, (unsigned long long)kDb2Unsorted);
     tkeys[e] = (uint32_t)s;
-    hkeys[e] = (uint32_t)d;
     Db2Rec r;
     r.t = __builtin_bit_cast(uint64_t, t);
-    r.u = 0xFFFFFFFFu;
     r.a = (uint32_t)s;
+    r.c = (uint32_t)d;
     rec[e] = r;
 }
 
@@ -88,84 +87,185 @@ __global__ __launch_bounds__(kBlock) void k_db2_rowptr(const uint32_t* __restric
     for (int64_t v = a + 1; v <= b; ++v) rowptr[v] = (uint32_t)p;
 }
 
-// ------------------------------------------------------------------ out side: the successors of every node
-template <typename TimeT, bool kW>
-__global__ __launch_bounds__(kBlock) void k_db2_out(const int64_t* __restrict__ dst, const TimeT* __restrict__ time, const float* __restrict__ w,
-                                                   int64_t n, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tl,
-                                                   uint32_t* __restrict__ oe_s, uint64_t* __restrict__ ot_s, uint32_t* __restrict__ oc_s,
-                                                   float* __restrict__ ow_s, uint8_t* __restrict__ ocr_s, int32_t* __restrict__ blk,
-                                                   int64_t* __restrict__ status) {
-    const int64_t node = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
-    if (node >= n) return;
-    const int l = lane_id();
-    const uint32_t p0 = tp[node];
-    const int cnt = (int)(tp[node + 1] - p0);
-    if (cnt > kWave || cnt == 0) {
-        if (l == 0) {
-            blk[node] = 0;
-            if (cnt > kWave) atomicOr((unsigned long long*)status, (unsigned long long)kDb2Overflow);
-        }
-        return;
-    }
-    const bool live = l < cnt;
-    const uint32_t e = live ? tl[p0 + l] : 0u;
-    const uint32_t c = live ? (uint32_t)dst[e] : 0xFFFFFFFFu;
-    const uint64_t tb = live ? __builtin_bit_cast(uint64_t, time[e]) : 0ull;
-    const float wv = (kW && live) ? w[e] : 0.0f;
-    int r = 0;
-    for (int kk = 0; kk < cnt; ++kk) {
-        const uint32_t ck = rl_u(c, kk);
-        r += (ck < c || (ck == c && kk < l)) ? 1 : 0;
-    }
-    const int dest = live ? r : l;                 // a permutation of the lanes: live lanes fill 0 .. cnt-1
-    const uint32_t sc = push_u(dest, c), se = push_u(dest, e);
-    const uint64_t st = push_u64(dest, tb);
-    const float sw = kW ? push_f(dest, wv) : 0.0f;
-    const uint32_t prev = (uint32_t)__shfl_up((int)sc, 1, kWave);
-    const bool head = live && (l == 0 || sc != prev);
-    const uint64_t hm = __ballot(head);
-    const int crank = (int)__popcll(hm & lanes_upto(l)) - 1;
-    const uint64_t later = hm & ~lanes_upto(l);
-    const int end = later ? __ffsll((long long)later) - 1 : cnt;
-    const int len = end - l;
-    float weight = (float)len;
-    if (kW) {
-        const int mx = wave_max(head ? len : 0);
-        float acc = 0.0f;
-        for (int p = 0; p < mx; ++p) {
-            const float v = __shfl(sw, (l + p) & (kWave - 1), kWave);
-            if (head && p < len) acc += v;         // left to right = instance (time) order, as the segment reduce of the generic coalesce
-        }
-        weight = acc;
-    }
-    if (live) {
-        oe_s[p0 + l] = se;
-        ot_s[p0 + l] = st;
-        oc_s[p0 + l] = sc;
-        ocr_s[p0 + l] = (uint8_t)crank;
-        ow_s[p0 + l] = head ? weight : 0.0f;
-    }
-    if (l == 0) blk[node] = (int32_t)__popcll(hm);
+// out-events in list order (source, time): (successor, time [, weight]) next to each other.  The successors are also the keys of the SECOND
+// sort: the list sequence, stably sorted by head node, gives every node its in-events ordered by (source node, time)
+__global__ __launch_bounds__(kBlock) void k_db2_gather_out(int64_t m, const uint32_t* __restrict__ tl, const Db2Rec* __restrict__ rec,
+                                                          const float* __restrict__ w, uint32_t* __restrict__ oc_t, uint64_t* __restrict__ ot_t,
+                                                          float* __restrict__ ow_t) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m) return;
+    const uint32_t e = tl[p];
+    const Db2Rec r = rec[e];
+    oc_t[p] = r.c;
+    ot_t[p] = r.t;
+    if (w) ow_t[p] = w[e];
 }
 
-// ids of the order-2 nodes reach the events (rec.u); the first-order edge list (destination + weight per order-2 node)
+struct alignas(16) Db2Src {
+    uint64_t t;       // timestamp bits
+    uint32_t u;       // order-2 node (source node, head node) of the event
+    uint32_t a;       // source node
+};
+
+// in-events of every node in (source, time) order: one 16-byte record per event from its position in the out-lists
+__global__ __launch_bounds__(kBlock) void k_db2_gather_in(int64_t m, const uint32_t* __restrict__ hl, const Db2Src* __restrict__ src_t,
+                                                         const float* __restrict__ ow_t, uint64_t* __restrict__ is_t, uint32_t* __restrict__ is_a,
+                                                         uint32_t* __restrict__ is_u, float* __restrict__ is_w) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= m) return;
+    const uint32_t p = hl[q];
+    const Db2Src r = src_t[p];
+    is_t[q] = r.t;
+    is_a[q] = r.a;
+    is_u[q] = r.u;
+    if (ow_t) is_w[q] = ow_t[p];
+}
+
+// per order-2 node: (weighted degree, start of its source-major row) next to each other — ONE random access per in-event in the gather below
+__global__ __launch_bounds__(kBlock) void k_db2_pack_rows(int64_t m, const float* __restrict__ ho_deg, const int32_t* __restrict__ ho_bwd_ptr,
+                                                         uint2* __restrict__ row_pack) {
+    const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (u >= m) return;
+    row_pack[u] = make_uint2(__float_as_uint(inv_sqrt_deg(ho_deg[u])), (uint32_t)ho_bwd_ptr[u]);
+}
+
+// what the fill pass needs per in-event: d^-1/2 of its order-2 node and of its source node, the start of that order-2 node's source-major row
+__global__ __launch_bounds__(kBlock) void k_db2_gather_coef(int64_t m, const uint32_t* __restrict__ is_u, const uint32_t* __restrict__ is_a,
+                                                           const uint2* __restrict__ row_pack, const float* __restrict__ fo_deg,
+                                                           float* __restrict__ du_s, int32_t* __restrict__ ob_s, float* __restrict__ da_s) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= m) return;
+    const uint32_t u = is_u[q], a = is_a[q];
+    if (u == 0xFFFFFFFFu) return;                  // (an event of an overflow node: the caller falls back)
+    const uint2 r = row_pack[u];
+    du_s[q] = __uint_as_float(r.x);
+    ob_s[q] = (int32_t)r.y;
+    da_s[q] = inv_sqrt_deg(fo_deg[a]);
+}
+
+// the source-major rows were scattered as (destination, coefficient) pairs: one 8-byte random store per entry instead of two 4-byte ones
+__global__ __launch_bounds__(kBlock) void k_db2_unzip(int64_t n, const uint2* __restrict__ pack, int32_t* __restrict__ idx, float* __restrict__ val) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const uint2 r = pack[j];
+    idx[j] = (int32_t)r.x;
+    val[j] = __uint_as_float(r.y);
+}
+
+// ------------------------------------------------------------------ out side: the successors of every node
+// kN nodes per wave, one after the other: the loads of all of them are issued before the first is worked on (the per-node work is a
+// chain of short dependent steps; 8 waves per SIMD alone do not hide the memory latency under it)
+constexpr int kDb2Nodes = 4;
+
+template <bool kW>
+struct Db2OutIn {
+    uint32_t p0;
+    int cnt;
+    uint32_t c;
+    uint64_t tb;
+    float wv;
+};
+
+template <bool kW>
+__global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ oc_t,
+                                                   const uint64_t* __restrict__ ot_t, const float* __restrict__ ow_t, uint64_t* __restrict__ ot_s,
+                                                   uint32_t* __restrict__ oc_s, float* __restrict__ ow_s, uint8_t* __restrict__ ocr_s,
+                                                   uint8_t* __restrict__ ocr_t, int32_t* __restrict__ blk, int64_t* __restrict__ status) {
+    const int64_t node0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * kDb2Nodes;
+    if (node0 >= n) return;
+    const int l = lane_id();
+    Db2OutIn<kW> in[kDb2Nodes];
+#pragma unroll
+    for (int s = 0; s < kDb2Nodes; ++s) {
+        const int64_t node = node0 + s;
+        const uint32_t b0 = node < n ? tp[node] : 0u, b1 = node < n ? tp[node + 1] : 0u;
+        in[s].p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);          // (wave-uniform by construction: scalar loop bounds, scalar addresses)
+        in[s].cnt = __builtin_amdgcn_readfirstlane((int)(b1 - b0));
+    }
+#pragma unroll
+    for (int s = 0; s < kDb2Nodes; ++s) {
+        const bool live = l < in[s].cnt && in[s].cnt <= kWave;
+        in[s].c = live ? oc_t[in[s].p0 + l] : 0xFFFFFFFFu;
+        in[s].tb = live ? ot_t[in[s].p0 + l] : 0ull;
+        in[s].wv = (kW && live) ? ow_t[in[s].p0 + l] : 0.0f;
+    }
+#pragma unroll
+    for (int s = 0; s < kDb2Nodes; ++s) {
+        const int64_t node = node0 + s;
+        if (node >= n) break;
+        const uint32_t p0 = in[s].p0;
+        const int cnt = in[s].cnt;
+        if (cnt > kWave || cnt == 0) {
+            if (l == 0) {
+                blk[node] = 0;
+                if (cnt > kWave) atomicOr((unsigned long long*)status, (unsigned long long)kDb2Overflow);
+            }
+            continue;
+        }
+        const bool live = l < cnt;
+        const uint32_t c = in[s].c;
+        int r = 0;
+        for (int kk = 0; kk < cnt; ++kk) {
+            const uint32_t ck = rl_u(c, kk);
+            r += (ck < c || (ck == c && kk < l)) ? 1 : 0;
+        }
+        const int dest = live ? r : l;                 // a permutation of the lanes: live lanes fill 0 .. cnt-1
+        const uint32_t sc = push_u(dest, c);
+        const uint64_t st = push_u64(dest, in[s].tb);
+        const float sw = kW ? push_f(dest, in[s].wv) : 0.0f;
+        const uint32_t prev = (uint32_t)__shfl_up((int)sc, 1, kWave);
+        const bool head = live && (l == 0 || sc != prev);
+        const uint64_t hm = __ballot(head);
+        const int crank = (int)__popcll(hm & lanes_upto(l)) - 1;
+        const uint64_t later = hm & ~lanes_upto(l);
+        const int end = later ? __ffsll((long long)later) - 1 : cnt;
+        const int len = end - l;
+        float weight = (float)len;
+        if (kW) {
+            const int mx = wave_max(head ? len : 0);
+            float acc = 0.0f;
+            for (int p = 0; p < mx; ++p) {
+                const float v = __shfl(sw, (l + p) & (kWave - 1), kWave);
+                if (head && p < len) acc += v;         // left to right = instance (time) order, as the segment reduce of the generic coalesce
+            }
+            weight = acc;
+        }
+        const int mine = lane_read_i(dest << 2, crank);      // successor rank of the event at LIST position l (its slot holds it after the push)
+        if (live) {
+            ot_s[p0 + l] = st;
+            oc_s[p0 + l] = sc;
+            ocr_s[p0 + l] = (uint8_t)crank;
+            ocr_t[p0 + l] = (uint8_t)mine;
+            ow_s[p0 + l] = head ? weight : 0.0f;
+        }
+        if (l == 0) blk[node] = (int32_t)__popcll(hm);
+    }
+}
+
+// per list position: the (time, order-2 node, source) record the head-side gather reads; per successor run: the first-order edge
 __global__ __launch_bounds__(kBlock) void k_db2_out_fill(int64_t m, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tkeys_s,
-                                                        const uint32_t* __restrict__ oe_s, const uint32_t* __restrict__ oc_s,
-                                                        const float* __restrict__ ow_s, const uint8_t* __restrict__ ocr_s,
-                                                        const int32_t* __restrict__ row_ptr, Db2Rec* __restrict__ rec,
-                                                        int32_t* __restrict__ fo_bwd_idx, float* __restrict__ fo_w) {
+                                                        const uint64_t* __restrict__ ot_t, const uint8_t* __restrict__ ocr_t,
+                                                        const uint32_t* __restrict__ oc_s, const float* __restrict__ ow_s,
+                                                        const uint8_t* __restrict__ ocr_s, const int32_t* __restrict__ row_ptr,
+                                                        Db2Src* __restrict__ src_t, int32_t* __restrict__ fo_bwd_idx, float* __restrict__ fo_w) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= m) return;
     const uint32_t b = tkeys_s[p];
     const uint32_t p0 = tp[b];
-    if (tp[b + 1] - p0 > (uint32_t)kWave) return;              // (overflow node: the caller falls back)
-    const uint8_t cr = ocr_s[p];
-    const uint32_t u = (uint32_t)row_ptr[b] + cr;
-    rec[oe_s[p]].u = u;
-    if (p == p0 || ocr_s[p - 1] != cr) {
-        fo_bwd_idx[u] = (int32_t)oc_s[p];
-        fo_w[u] = ow_s[p];
+    Db2Src r;
+    r.t = ot_t[p];
+    r.a = b;
+    r.u = 0xFFFFFFFFu;
+    if (tp[b + 1] - p0 <= (uint32_t)kWave) {                   // (else an overflow node: its events keep the id 0xFFFFFFFF, the caller falls back)
+        const uint32_t row0 = (uint32_t)row_ptr[b];
+        r.u = row0 + ocr_t[p];
+        const uint8_t cr = ocr_s[p];
+        if (p == p0 || ocr_s[p - 1] != cr) {
+            fo_bwd_idx[row0 + cr] = (int32_t)oc_s[p];
+            fo_w[row0 + cr] = ow_s[p];
+        }
     }
+    src_t[p] = r;
 }
 
 // source-major coefficients of the first-order graph: val(b -> c) = d_b^-1/2 w d_c^-1/2, 0 on self loops (as k_gcn_coefficients)
@@ -187,169 +287,226 @@ __global__ __launch_bounds__(kBlock) void k_db2_fo_bwd_val(int64_t m, const uint
 
 // ------------------------------------------------------------------ middle-node pass
 struct Db2Mid {
-    // inputs of both modes
-    const uint32_t *tp, *hp, *hl;
-    const Db2Rec* rec;
-    const float* w;
-    const uint64_t* ot_s;
+    const uint32_t *tp, *hp;
+    const uint64_t* ot_s;            // out-events in (successor, time) order: time, successor rank
     const uint8_t* ocr_s;
     const int32_t* row_ptr;
-    // count mode: outputs; fill mode: inputs
+    // in-events in (source, time) order
+    const uint64_t* is_t;
+    const uint32_t *is_a, *is_u;
+    const float* is_w;
+    // count pass: outputs; fill pass: inputs
     int32_t *indeg2, *outdeg2;
     float *ho_deg, *ho_lw, *fo_deg, *fo_lw;
     int32_t *nu, *pc;
     int64_t* status;
-    // fill mode
-    const int32_t *ho_fwd_ptr, *ho_bwd_ptr, *fo_fwd_ptr;
-    int32_t *in_idx2, *out_idx2, *fwd_idx1, *dst_order;
-    float *in_val2, *out_val2, *self2, *fwd_val1, *self1;
+    // fill pass
+    const float *du_s, *da_s;
+    const int32_t* ob_s;
+    const int32_t *ho_fwd_ptr, *fo_fwd_ptr;
+    int32_t *in_idx2, *fwd_idx1, *dst_order;
+    float *in_val2, *self2, *fwd_val1, *self1;
+    uint2* out_pack;
+};
+
+template <bool kFill, bool kW>
+struct Db2MidIn {
+    uint32_t p0, q0;
+    int no, ni;
+    uint64_t tj, ti;
+    int cr;
+    uint32_t ia, iu;
+    float wi, du, da;
+    int32_t ob;
+    int32_t row0;
+    float rdeg, rlw;           // fill: per successor RANK (lane r = row row0 + r): weighted degree, self-loop weight, row start
+    int32_t rip;
+    float d1, lw1;
+    int32_t fp;
 };
 
 template <typename TimeT, int kMode, bool kFill, bool kW>
 __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, double delta_f, Db2Mid a) {
     using W = Window<TimeT, kMode>;
-    const int64_t node = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
-    if (node >= n) return;
+    const int64_t node0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * kDb2Nodes;
+    if (node0 >= n) return;
     const int l = lane_id();
-    const uint32_t p0 = a.tp[node], q0 = a.hp[node];
-    const int no = (int)(a.tp[node + 1] - p0), ni = (int)(a.hp[node + 1] - q0);
-    if (no > kWave || ni > kWave) {
-        if (!kFill && l == 0) {
-            atomicOr((unsigned long long*)a.status, (unsigned long long)kDb2Overflow);
-            a.nu[node] = 0; a.pc[node] = 0; a.fo_deg[node] = 1.0f; a.fo_lw[node] = 1.0f;
+    Db2MidIn<kFill, kW> in[kDb2Nodes];
+#pragma unroll
+    for (int s = 0; s < kDb2Nodes; ++s) {
+        const int64_t node = node0 + s;
+        const bool there = node < n;
+        const uint32_t b0 = there ? a.tp[node] : 0u, b1 = there ? a.tp[node + 1] : 0u, h0 = there ? a.hp[node] : 0u, h1 = there ? a.hp[node + 1] : 0u;
+        const int32_t r0 = there ? a.row_ptr[node] : 0;
+        in[s].p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);          // (wave-uniform by construction: scalar loop bounds, scalar addresses)
+        in[s].q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0);
+        in[s].no = __builtin_amdgcn_readfirstlane((int)(b1 - b0));
+        in[s].ni = __builtin_amdgcn_readfirstlane((int)(h1 - h0));
+        in[s].row0 = __builtin_amdgcn_readfirstlane(r0);
+        if (kFill) {
+            in[s].d1 = there ? inv_sqrt_deg(a.fo_deg[node]) : 0.0f;
+            in[s].lw1 = there ? a.fo_lw[node] : 1.0f;
+            in[s].fp = __builtin_amdgcn_readfirstlane(there ? a.fo_fwd_ptr[node] : 0);
         }
-        return;
     }
-    // ---- out side: lanes in (successor, time) order
-    const bool lo_ = l < no;
-    const TimeT tj = time_of<TimeT>(lo_ ? a.ot_s[p0 + l] : 0ull);
-    const int cr = lo_ ? (int)a.ocr_s[p0 + l] : 255;
-    const int prevcr = __shfl_up(cr, 1, kWave);
-    const bool ohead = lo_ && (l == 0 || cr != prevcr);
-    const uint64_t ohm = __ballot(ohead);
-    const uint64_t olater = ohm & ~lanes_upto(l);
-    const int oend = olater ? __ffsll((long long)olater) - 1 : no;
-    const uint64_t myrun = ohead ? ((oend >= kWave ? ~0ull : lanes_below(oend)) & ~lanes_below(l)) : 0ull;
-    const uint32_t v = (uint32_t)a.row_ptr[node] + (uint32_t)(ohead ? cr : 0);
-    // ---- in side: lanes ranked by (source node, time)
-    const bool li = l < ni;
-    const uint32_t e = li ? a.hl[q0 + l] : 0u;
-    Db2Rec r;
-    r.t = 0ull; r.u = 0xFFFFFFFFu; r.a = 0xFFFFFFFFu;
-    if (li) r = a.rec[e];
-    const float wi = (kW && li) ? a.w[e] : 1.0f;
-    int rk = 0;
-    for (int kk = 0; kk < ni; ++kk) {
-        const uint32_t ak = rl_u(r.a, kk);
-        rk += (ak < r.a || (ak == r.a && kk < l)) ? 1 : 0;
-    }
-    const int dest = li ? rk : l;
-    const uint32_t sa = push_u(dest, r.a), su = push_u(dest, r.u);
-    const uint64_t sti = push_u64(dest, r.t);
-    const float swi = kW ? push_f(dest, wi) : 1.0f;
-    const uint32_t preva = (uint32_t)__shfl_up((int)sa, 1, kWave);
-    const bool ihead = li && (l == 0 || sa != preva);
-    const uint64_t ihm = __ballot(ihead);
-    // ---- fill mode: everything a run needs from memory is fetched up front, one lane per in-event / successor run
-    float du = 0.0f, da = 0.0f, dv = 0.0f, lwv = 1.0f, d1b = 0.0f, lw1b = 1.0f;
-    int32_t ob = 0, ip = 0, fp = 0;
-    if (kFill) {
-        if (ihead) {
-            du = inv_sqrt_deg(a.ho_deg[su]);
-            ob = a.ho_bwd_ptr[su];
-            da = inv_sqrt_deg(a.fo_deg[sa]);
+#pragma unroll
+    for (int s = 0; s < kDb2Nodes; ++s) {
+        const bool fits = in[s].no <= kWave && in[s].ni <= kWave;
+        const bool lo_ = fits && l < in[s].no, li = fits && l < in[s].ni;
+        in[s].tj = lo_ ? a.ot_s[in[s].p0 + l] : 0ull;
+        in[s].cr = lo_ ? (int)a.ocr_s[in[s].p0 + l] : 255;
+        in[s].ti = li ? a.is_t[in[s].q0 + l] : 0ull;
+        in[s].ia = li ? a.is_a[in[s].q0 + l] : 0xFFFFFFFFu;
+        in[s].iu = li ? a.is_u[in[s].q0 + l] : 0xFFFFFFFFu;
+        in[s].wi = (kW && li) ? a.is_w[in[s].q0 + l] : 1.0f;
+        if (kFill) {
+            in[s].du = li ? a.du_s[in[s].q0 + l] : 0.0f;
+            in[s].da = li ? a.da_s[in[s].q0 + l] : 0.0f;
+            in[s].ob = li ? a.ob_s[in[s].q0 + l] : 0;
+            // (at most `no` successor rows: lane r reads row row0 + r; a row beyond the node's block is never used)
+            in[s].rdeg = lo_ ? a.ho_deg[in[s].row0 + l] : 1.0f;
+            in[s].rlw = lo_ ? a.ho_lw[in[s].row0 + l] : 1.0f;
+            in[s].rip = lo_ ? a.ho_fwd_ptr[in[s].row0 + l] : 0;
         }
-        if (ohead) {
-            dv = inv_sqrt_deg(a.ho_deg[v]);
-            lwv = a.ho_lw[v];
-            ip = a.ho_fwd_ptr[v];
-        }
-        d1b = inv_sqrt_deg(a.fo_deg[node]);
-        lw1b = a.fo_lw[node];
-        fp = a.fo_fwd_ptr[node];
     }
-    int cnt = 0, pairs = 0, nuc = 0;
-    float deg = 0.0f, lw = -1.0f, deg1 = 0.0f, lw1 = -1.0f;
-    for (uint64_t hm = ihm; hm != 0; hm &= hm - 1) {
-        const int z0 = __ffsll((long long)hm) - 1;
-        const uint64_t nxt = hm & (hm - 1);
-        const int z1 = nxt ? __ffsll((long long)nxt) - 1 : ni;
-        const uint32_t acur = rl_u(sa, z0), ucur = rl_u(su, z0);
-        int hits = 0;
-        float facc = 0.0f, w1run = 0.0f;
-        for (int z = z0; z < z1; ++z) {
-            const TimeT ti = time_of<TimeT>(rl_u64(sti, z));
-            const typename W::Thr thr = W::threshold(ti, delta_i, delta_f);
-            const uint64_t win = __ballot(lo_ && tj > ti && W::admits(tj, thr));
-            pairs += (int)__popcll(win);
-            const int h = (int)__popcll(win & myrun);
-            hits += h;
-            if (kW) {
-                const float wz = rl_f(swi, z);
-                for (int x = 0; x < h; ++x) facc += wz;      // instance pairs in lexicographic order carry the weight of their source event
-                w1run += wz;
+#pragma unroll
+    for (int s = 0; s < kDb2Nodes; ++s) {
+        const int64_t node = node0 + s;
+        if (node >= n) break;
+        const int no = in[s].no, ni = in[s].ni;
+        if (no > kWave || ni > kWave) {
+            if (!kFill && l == 0) {
+                atomicOr((unsigned long long*)a.status, (unsigned long long)kDb2Overflow);
+                a.nu[node] = 0; a.pc[node] = 0; a.fo_deg[node] = 1.0f; a.fo_lw[node] = 1.0f;
             }
+            continue;
         }
-        if (!kW) w1run = (float)(z1 - z0);
-        const float wgt = kW ? facc : (float)hits;
-        const bool emit = ohead && hits > 0;
-        const uint64_t em = __ballot(emit);
+        // ---- out side: lanes in (successor, time) order
+        const bool lo_ = l < no;
+        const TimeT tj = time_of<TimeT>(in[s].tj);
+        const int cr = in[s].cr;
+        const int prevcr = __shfl_up(cr, 1, kWave);
+        const bool ohead = lo_ && (l == 0 || cr != prevcr);
+        const uint64_t ohm = __ballot(ohead);
+        const uint64_t olater = ohm & ~lanes_upto(l);
+        const int oend = olater ? __ffsll((long long)olater) - 1 : no;
+        const uint64_t myrun = ohead ? ((oend >= kWave ? ~0ull : lanes_below(oend)) & ~lanes_below(l)) : 0ull;
+        const uint32_t v = (uint32_t)in[s].row0 + (uint32_t)(ohead ? cr : 0);
+        // ---- in side: lanes in (source node, time) order
+        const bool li = l < ni;
+        const uint32_t sa = in[s].ia, su = in[s].iu;
+        const uint64_t sti = in[s].ti;
+        const float swi = in[s].wi;
+        const uint32_t preva = (uint32_t)__shfl_up((int)sa, 1, kWave);
+        const bool ihead = li && (l == 0 || sa != preva);
+        const uint64_t ihm = __ballot(ihead);
+        float dv = 0.0f, lwv = 1.0f;
+        int32_t ip = 0;
+        if (kFill) {                               // the successor run with rank cr takes its row's values from lane cr
+            const int from = (ohead ? cr : l) << 2;
+            dv = inv_sqrt_deg(lane_read_f(from, in[s].rdeg));
+            lwv = lane_read_f(from, in[s].rlw);
+            ip = lane_read_i(from, in[s].rip);
+        }
+        const float d1b = in[s].d1;
+        int cnt = 0, pairs = 0, nuc = 0;
+        float deg = 0.0f, lw = -1.0f, deg1 = 0.0f, lw1 = -1.0f;
+        // per in-run results are parked in lane `run index` and stored after the loop with one instruction each
+        uint32_t run_u = 0xFFFFFFFFu, run_a = 0u;
+        int32_t run_od = 0;
+        float run_val = 0.0f;
+        for (uint64_t hm = ihm; hm != 0; hm &= hm - 1) {
+            const int z0 = __ffsll((long long)hm) - 1;
+            const uint64_t nxt = hm & (hm - 1);
+            const int z1 = nxt ? __ffsll((long long)nxt) - 1 : ni;
+            const uint32_t acur = rl_u(sa, z0), ucur = rl_u(su, z0);
+            int hits = 0;
+            float facc = 0.0f, w1run = 0.0f;
+            for (int z = z0; z < z1; ++z) {
+                const TimeT ti = time_of<TimeT>(rl_u64(sti, z));
+                const typename W::Thr thr = W::threshold(ti, delta_i, delta_f);
+                const uint64_t win = __ballot(lo_ && tj > ti && W::admits(tj, thr));
+                if (!kFill) pairs += (int)__popcll(win);
+                const int h = (int)__popcll(win & myrun);
+                hits += h;
+                if (kW) {
+                    const float wz = rl_f(swi, z);
+                    for (int x = 0; x < h; ++x) facc += wz;      // instance pairs in lexicographic order carry the weight of their source event
+                    w1run += wz;
+                }
+            }
+            if (!kW) w1run = (float)(z1 - z0);
+            const float wgt = kW ? facc : (float)hits;
+            const bool emit = ohead && hits > 0;
+            const uint64_t em = __ballot(emit);
+            if (!kFill) {
+                if (emit) {
+                    ++cnt;
+                    if (ucur == v) lw = wgt; else deg += wgt;
+                }
+                if (l == nuc) { run_u = ucur; run_od = (int32_t)__popcll(em); }
+                if (acur == (uint32_t)node) lw1 = w1run; else deg1 += w1run;
+            } else {
+                const float du_ = rl_f(in[s].du, z0), da_ = rl_f(in[s].da, z0);
+                const int32_t ob_ = rl_i(in[s].ob, z0);
+                if (emit) {
+                    const float val = ucur == v ? 0.0f : du_ * wgt * dv;
+                    a.in_idx2[ip + cnt] = (int32_t)ucur;
+                    a.in_val2[ip + cnt] = val;
+                    const int rank = (int)__popcll(em & lanes_below(l));
+                    a.out_pack[ob_ + rank] = make_uint2(v, __float_as_uint(val));
+                    ++cnt;
+                }
+                if (l == nuc) {
+                    run_u = ucur;
+                    run_a = acur;
+                    run_val = acur == (uint32_t)node ? 0.0f : da_ * w1run * d1b;
+                }
+            }
+            ++nuc;
+        }
         if (!kFill) {
-            if (emit) {
-                ++cnt;
-                if (ucur == v) lw = wgt; else deg += wgt;
-            }
-            if (l == 0 && em != 0 && ucur != 0xFFFFFFFFu) a.outdeg2[ucur] = (int32_t)__popcll(em);      // (no id: the source's node overflowed)
-            if (acur == (uint32_t)node) lw1 = w1run; else deg1 += w1run;
-        } else {
-            const float du_ = rl_f(du, z0), da_ = rl_f(da, z0);
-            const int32_t ob_ = rl_i(ob, z0);
-            if (emit) {
-                const float val = ucur == v ? 0.0f : du_ * wgt * dv;
-                a.in_idx2[ip + cnt] = (int32_t)ucur;
-                a.in_val2[ip + cnt] = val;
-                const int rank = (int)__popcll(em & lanes_below(l));
-                a.out_idx2[ob_ + rank] = (int32_t)v;
-                a.out_val2[ob_ + rank] = val;
-                ++cnt;
+            if (l < nuc && run_od != 0 && run_u != 0xFFFFFFFFu) a.outdeg2[run_u] = run_od;      // (no id: the source's node overflowed)
+            if (ohead) {
+                const float l2 = lw < 0.0f ? 1.0f : lw;              // an existing self loop keeps its weight, every other node gets one of weight 1
+                a.indeg2[v] = cnt;
+                a.ho_deg[v] = deg + l2;
+                a.ho_lw[v] = l2;
             }
             if (l == 0) {
-                a.fwd_idx1[fp + nuc] = (int32_t)acur;
-                a.fwd_val1[fp + nuc] = acur == (uint32_t)node ? 0.0f : da_ * w1run * d1b;
-                a.dst_order[fp + nuc] = (int32_t)ucur;
+                const float l1 = lw1 < 0.0f ? 1.0f : lw1;
+                a.nu[node] = nuc;
+                a.pc[node] = pairs;
+                a.fo_deg[node] = deg1 + l1;
+                a.fo_lw[node] = l1;
             }
+        } else {
+            if (l < nuc) {
+                a.fwd_idx1[in[s].fp + l] = (int32_t)run_a;
+                a.fwd_val1[in[s].fp + l] = run_val;
+                a.dst_order[in[s].fp + l] = (int32_t)run_u;
+            }
+            if (ohead) a.self2[v] = dv * lwv * dv;
+            if (l == 0) a.self1[node] = d1b * in[s].lw1 * d1b;
         }
-        ++nuc;
-    }
-    if (!kFill) {
-        if (ohead) {
-            const float l2 = lw < 0.0f ? 1.0f : lw;              // an existing self loop keeps its weight, every other node gets one of weight 1
-            a.indeg2[v] = cnt;
-            a.ho_deg[v] = deg + l2;
-            a.ho_lw[v] = l2;
-        }
-        if (l == 0) {
-            const float l1 = lw1 < 0.0f ? 1.0f : lw1;
-            a.nu[node] = nuc;
-            a.pc[node] = pairs;
-            a.fo_deg[node] = deg1 + l1;
-            a.fo_lw[node] = l1;
-        }
-    } else {
-        if (ohead) a.self2[v] = dv * lwv * dv;
-        if (l == 0) a.self1[node] = d1b * lw1b * d1b;
     }
 }
 
 // ------------------------------------------------------------------ workspace
 struct Db2Ws {
     int64_t* result;         // [8]: {U2, status, A2, E2, A1 (first-order in-edges), -, -, -}
-    uint32_t *tkeys, *hkeys, *tkeys_s, *hkeys_s, *tl, *hl, *tp, *hp;
+    uint32_t *tkeys, *tkeys_s, *hkeys_s, *tl, *hl, *tp, *hp;
     Db2Rec* rec;
-    uint32_t *oe_s, *oc_s;
-    uint64_t* ot_s;
-    float* ow_s;
-    uint8_t* ocr_s;
+    Db2Src* src_t;
+    uint32_t *oc_t, *oc_s;
+    uint64_t *ot_t, *ot_s;
+    float *ow_t, *ow_s;
+    uint8_t *ocr_s, *ocr_t;
+    uint64_t* is_t;
+    uint32_t *is_a, *is_u;
+    float *is_w, *du_s, *da_s;
+    int32_t* ob_s;
+    uint2* row_pack;
     int32_t *blk, *nu, *pc, *indeg2, *outdeg2;
     float *ho_lw, *fo_lw;
     int64_t* pc_scan;
@@ -362,7 +519,6 @@ static Db2Ws carve_db2(void* ws, int64_t m, int64_t n) {
     Db2Ws w;
     w.result = a.take<int64_t>(8);
     w.tkeys = a.take<uint32_t>(m);
-    w.hkeys = a.take<uint32_t>(m);
     w.tkeys_s = a.take<uint32_t>(m);
     w.hkeys_s = a.take<uint32_t>(m);
     w.tl = a.take<uint32_t>(m);
@@ -370,11 +526,23 @@ static Db2Ws carve_db2(void* ws, int64_t m, int64_t n) {
     w.tp = a.take<uint32_t>(n + 2);
     w.hp = a.take<uint32_t>(n + 2);
     w.rec = a.take<Db2Rec>(m);
-    w.oe_s = a.take<uint32_t>(m);
+    w.src_t = a.take<Db2Src>(m);
+    w.oc_t = a.take<uint32_t>(m);
     w.oc_s = a.take<uint32_t>(m);
+    w.ot_t = a.take<uint64_t>(m);
     w.ot_s = a.take<uint64_t>(m);
+    w.ow_t = a.take<float>(m);
     w.ow_s = a.take<float>(m);
     w.ocr_s = a.take<uint8_t>(m + 16);
+    w.ocr_t = a.take<uint8_t>(m + 16);
+    w.is_t = a.take<uint64_t>(m);
+    w.is_a = a.take<uint32_t>(m);
+    w.is_u = a.take<uint32_t>(m);
+    w.is_w = a.take<float>(m);
+    w.du_s = a.take<float>(m);
+    w.da_s = a.take<float>(m);
+    w.ob_s = a.take<int32_t>(m);
+    w.row_pack = a.take<uint2>(m);
     w.blk = a.take<int32_t>(n);
     w.nu = a.take<int32_t>(n);
     w.pc = a.take<int32_t>(n);
@@ -388,6 +556,12 @@ static Db2Ws carve_db2(void* ws, int64_t m, int64_t n) {
     w.scratch = a.take<char>((int64_t)w.scratch_bytes);
     w.total_bytes = a.used;
     return w;
+}
+
+static void mid_common(Db2Mid& a, const Db2Ws& w, const int32_t* row_ptr, bool weighted) {
+    a.tp = w.tp; a.hp = w.hp; a.ot_s = w.ot_s; a.ocr_s = w.ocr_s; a.row_ptr = row_ptr;
+    a.is_t = w.is_t; a.is_a = w.is_a; a.is_u = w.is_u; a.is_w = weighted ? w.is_w : nullptr;
+    a.ho_lw = w.ho_lw; a.fo_lw = w.fo_lw;
 }
 
 template <typename TimeT, int kMode, bool kFill>
@@ -433,42 +607,38 @@ int pp_debruijn2_count(const int64_t* edge_index, const void* time, int time_dty
         PP_HIP(hipMemsetAsync(ho_bwd_ptr, 0, (size_t)(m + 1) * sizeof(int32_t), st));
         return PP_OK;
     }
-    const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n, kWavesPerBlock);
-    // 1. keys, event records; both groupings of the events (stable: time order inside a node's list)
-    if (time_dtype == PP_I64) k_db2_keys<int64_t><<<egrid, kBlock, 0, st>>>(edge_index, (const int64_t*)time, m, n, w.tkeys, w.hkeys, w.rec, w.result + 1);
-    else k_db2_keys<double><<<egrid, kBlock, 0, st>>>(edge_index, (const double*)time, m, n, w.tkeys, w.hkeys, w.rec, w.result + 1);
+    const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n, kWavesPerBlock * kDb2Nodes);
+    // 1. event records; out-lists (stable sort by tail: time order inside a list), then the list SEQUENCE sorted by head: in-lists in (source, time) order
+    if (time_dtype == PP_I64) k_db2_keys<int64_t><<<egrid, kBlock, 0, st>>>(edge_index, (const int64_t*)time, m, n, w.tkeys, w.rec, w.result + 1);
+    else k_db2_keys<double><<<egrid, kBlock, 0, st>>>(edge_index, (const double*)time, m, n, w.tkeys, w.rec, w.result + 1);
     PP_LAUNCH_CHECK();
     const int key_bits = bits_for((uint64_t)(n > 0 ? n - 1 : 0));
     int rc = sort_pairs<uint32_t>(w.tkeys, nullptr, w.tkeys_s, w.tl, m, 0, key_bits, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
-    rc = sort_pairs<uint32_t>(w.hkeys, nullptr, w.hkeys_s, w.hl, m, 0, key_bits, w.scratch, w.scratch_bytes, st);
+    k_db2_gather_out<<<egrid, kBlock, 0, st>>>(m, w.tl, w.rec, weight, w.oc_t, w.ot_t, w.ow_t);
+    PP_LAUNCH_CHECK();
+    rc = sort_pairs<uint32_t>(w.oc_t, nullptr, w.hkeys_s, w.hl, m, 0, key_bits, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
     k_db2_rowptr<<<(unsigned)ceil_div(m + 1, kBlock), kBlock, 0, st>>>(w.tkeys_s, m, n, w.tp);
     PP_LAUNCH_CHECK();
     k_db2_rowptr<<<(unsigned)ceil_div(m + 1, kBlock), kBlock, 0, st>>>(w.hkeys_s, m, n, w.hp);
     PP_LAUNCH_CHECK();
     // 2. successors of every node -> order-2 node ids
-    const int64_t* dst = edge_index + m;
-#define PP_DB2_OUT(T)                                                                                                                   \
-    do {                                                                                                                                \
-        if (weight) k_db2_out<T, true><<<ngrid, kBlock, 0, st>>>(dst, (const T*)time, weight, n, w.tp, w.tl, w.oe_s, w.ot_s, w.oc_s, w.ow_s, \
-                                                                 w.ocr_s, w.blk, w.result + 1);                                         \
-        else k_db2_out<T, false><<<ngrid, kBlock, 0, st>>>(dst, (const T*)time, nullptr, n, w.tp, w.tl, w.oe_s, w.ot_s, w.oc_s, w.ow_s,   \
-                                                           w.ocr_s, w.blk, w.result + 1);                                               \
-    } while (0)
-    if (time_dtype == PP_I64) PP_DB2_OUT(int64_t); else PP_DB2_OUT(double);
-#undef PP_DB2_OUT
+    if (weight) k_db2_out<true><<<ngrid, kBlock, 0, st>>>(n, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, w.result + 1);
+    else k_db2_out<false><<<ngrid, kBlock, 0, st>>>(n, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, w.result + 1);
     PP_LAUNCH_CHECK();
     rc = exclusive_scan<int32_t, int32_t>(w.blk, n, fo_bwd_ptr, true, w.result, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
-    k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, w.tp, w.tkeys_s, w.oe_s, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, w.rec, fo_bwd_idx, fo_w);
+    k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, w.src_t, fo_bwd_idx, fo_w);
+    PP_LAUNCH_CHECK();
+    k_db2_gather_in<<<egrid, kBlock, 0, st>>>(m, w.hl, w.src_t, weight ? w.ow_t : nullptr, w.is_t, w.is_a, w.is_u, w.is_w);
     PP_LAUNCH_CHECK();
     // 3. middle-node pass, counting
     PP_HIP(hipMemsetAsync(w.indeg2, 0, (size_t)m * sizeof(int32_t), st));
     PP_HIP(hipMemsetAsync(w.outdeg2, 0, (size_t)m * sizeof(int32_t), st));
     Db2Mid a{};
-    a.tp = w.tp; a.hp = w.hp; a.hl = w.hl; a.rec = w.rec; a.w = weight; a.ot_s = w.ot_s; a.ocr_s = w.ocr_s; a.row_ptr = fo_bwd_ptr;
-    a.indeg2 = w.indeg2; a.outdeg2 = w.outdeg2; a.ho_deg = ho_deg; a.ho_lw = w.ho_lw; a.fo_deg = fo_deg; a.fo_lw = w.fo_lw;
+    mid_common(a, w, fo_bwd_ptr, weight != nullptr);
+    a.indeg2 = w.indeg2; a.outdeg2 = w.outdeg2; a.ho_deg = ho_deg; a.fo_deg = fo_deg;
     a.nu = w.nu; a.pc = w.pc; a.status = w.result + 1;
     rc = launch_mid_any<false>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n, delta_i, delta_f, a);
     if (rc != PP_OK) return rc;
@@ -483,9 +653,9 @@ int pp_debruijn2_count(const int64_t* edge_index, const void* time, int time_dty
 
 int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
                       const int32_t* fo_bwd_ptr, const float* fo_w, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr, const int32_t* ho_bwd_ptr,
-                      const float* ho_deg, const float* fo_deg, int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx, float* ho_bwd_val,
-                      float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order, float* fo_bwd_val, float* fo_self, void* ws,
-                      size_t ws_bytes, pp_stream_t stream) {
+                      const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx,
+                      float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order, float* fo_bwd_val,
+                      float* fo_self, void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = num_nodes;
     PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "pp_debruijn2_fill: negative size");
@@ -493,15 +663,25 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_debruijn2_fill: workspace too small");
     if (n == 0) return PP_OK;
     PP_REQUIRE(m > 0, PP_ERR_ARG, "pp_debruijn2_fill: an empty stream has no order-2 model to fill (use pp_gcn_plan on the empty graph)");
-    const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n, kWavesPerBlock);
+    const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n, kWavesPerBlock * kDb2Nodes);
+    PP_REQUIRE(num_ho_edges >= 0 && (num_ho_edges == 0 || pair_scratch != nullptr), PP_ERR_ARG, "pp_debruijn2_fill: pair_scratch (8 bytes per order-2 edge) missing");
+    k_db2_pack_rows<<<egrid, kBlock, 0, st>>>(m, ho_deg, ho_bwd_ptr, w.row_pack);
+    PP_LAUNCH_CHECK();
+    k_db2_gather_coef<<<egrid, kBlock, 0, st>>>(m, w.is_u, w.is_a, w.row_pack, fo_deg, w.du_s, w.ob_s, w.da_s);
+    PP_LAUNCH_CHECK();
     Db2Mid a{};
-    a.tp = w.tp; a.hp = w.hp; a.hl = w.hl; a.rec = w.rec; a.w = weight; a.ot_s = w.ot_s; a.ocr_s = w.ocr_s; a.row_ptr = fo_bwd_ptr;
-    a.ho_deg = const_cast<float*>(ho_deg); a.ho_lw = w.ho_lw; a.fo_deg = const_cast<float*>(fo_deg); a.fo_lw = w.fo_lw;
-    a.ho_fwd_ptr = ho_fwd_ptr; a.ho_bwd_ptr = ho_bwd_ptr; a.fo_fwd_ptr = fo_fwd_ptr;
-    a.in_idx2 = ho_fwd_idx; a.in_val2 = ho_fwd_val; a.out_idx2 = ho_bwd_idx; a.out_val2 = ho_bwd_val; a.self2 = ho_self;
+    mid_common(a, w, fo_bwd_ptr, weight != nullptr);
+    a.ho_deg = const_cast<float*>(ho_deg); a.fo_deg = const_cast<float*>(fo_deg);
+    a.du_s = w.du_s; a.da_s = w.da_s; a.ob_s = w.ob_s;
+    a.ho_fwd_ptr = ho_fwd_ptr; a.fo_fwd_ptr = fo_fwd_ptr;
+    a.in_idx2 = ho_fwd_idx; a.in_val2 = ho_fwd_val; a.out_pack = (uint2*)pair_scratch; a.self2 = ho_self;
     a.fwd_idx1 = fo_fwd_idx; a.fwd_val1 = fo_fwd_val; a.dst_order = fo_dst_order; a.self1 = fo_self;
     int rc = launch_mid_any<true>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n, delta_i, delta_f, a);
     if (rc != PP_OK) return rc;
+    if (num_ho_edges > 0) {
+        k_db2_unzip<<<(unsigned)ceil_div(num_ho_edges, kBlock), kBlock, 0, st>>>(num_ho_edges, (const uint2*)pair_scratch, ho_bwd_idx, ho_bwd_val);
+        PP_LAUNCH_CHECK();
+    }
     k_db2_fo_bwd_val<<<egrid, kBlock, 0, st>>>(m, w.tp, w.tkeys_s, w.oc_s, w.ocr_s, fo_bwd_ptr, fo_w, fo_deg, fo_bwd_val);
     PP_LAUNCH_CHECK();
     return PP_OK;

@@ -127,10 +127,14 @@ def gather_lifted(local: torch.Tensor, group=None) -> torch.Tensor:
     return torch.cat([p[:, : int(s.item())] for p, s in zip(parts, sizes)], dim=1)
 
 
-def all_reduce_gradients(module: torch.nn.Module, group=None, average: bool = True, comm: "Comm | None" = None) -> None:
+def all_reduce_gradients(module: torch.nn.Module, group=None, average: bool = True, comm: "Comm | None" = None,
+                         inplace_views: bool = False) -> None:
     """Sum (``average=False``) or average the (small) DBGNN weight gradients across ranks in ONE flattened all-reduce
     (latency-bound: ~20 k floats; per-tensor calls would pay the xGMI launch latency 14 times).  ``comm``: count the bytes on (and take
-    turns through) this :class:`Comm`."""
+    turns through) this :class:`Comm`.  The reduced values are copied back into the existing ``.grad`` tensors (references taken before the
+    call — clipping lists, hooks — see them).  ``inplace_views=True`` skips that copy: every ``.grad`` is REBOUND to a view of the one flat
+    buffer (earlier references keep the unreduced values, and any surviving view keeps the whole buffer alive) — for loops that only hand the
+    gradients to the optimizer (bench.py)."""
     _, world = _world(group) if comm is None else (comm.rank, comm.world)
     grads = [p.grad for p in module.parameters() if p.grad is not None]
     if world == 1 or not grads:
@@ -143,11 +147,14 @@ def all_reduce_gradients(module: torch.nn.Module, group=None, average: bool = Tr
     if average:
         flat /= world
     at = 0
-    for p in module.parameters():          # the reduced gradients stay where they are: every .grad becomes a view of the flat buffer (no copies)
+    for p in module.parameters():
         if p.grad is None:
             continue
         n_ = p.grad.numel()
-        p.grad = flat[at: at + n_].view_as(p.grad)
+        if inplace_views:                  # the reduced gradients stay where they are: .grad becomes a view of the flat buffer (no copies)
+            p.grad = flat[at: at + n_].view_as(p.grad)
+        else:
+            p.grad.copy_(flat[at: at + n_].view_as(p.grad))
         at += n_
 
 
@@ -770,14 +777,19 @@ def _rows_of(source, rows: torch.Tensor | None, lo: int = 0, hi: int = 0, device
     return source.index_select(0, rows) if rows is not None else source[lo:hi]
 
 
-def _shard_rows(source, gs) -> torch.Tensor:
+def _shard_rows(source, gs, comm: "Comm | None" = None) -> torch.Tensor:
     """Feature rows ``[owned | halo]`` of a graph shard.  A source with a ``shard_rows(lo, hi, halo_ids) -> [n_own + n_halo, F]`` method decides
     itself how to provide them — a RESIDENT row store keeps a rank's owned rows where they are and only fetches the halo rows (what a deployment
     does: the owned rows of the input features live on their rank; `bench.py` ``ResidentRows``); tensors and plain row loaders see
     ``gs.local_rows()``."""
     fetch = getattr(source, "shard_rows", None)
     if fetch is not None:
-        return fetch(gs.lo, gs.hi, gs.halo_ids)
+        rows = fetch(gs.lo, gs.hi, gs.halo_ids)
+        if comm is not None and comm.world > 1 and gs.n_halo:
+            # a resident store serves the halo rows from the other ranks' memories: in a deployment that IS an exchange over xGMI (recv_counts
+            # rows from every peer) — logged so that byte counters and the link-model pricing of bench.py --emulate-ranks see it (ADVICE r3)
+            comm._count_exchange(gs.send_counts, rows.element_size() * rows.size(1), gs.recv_counts)
+        return rows
     return _rows_of(source, gs.local_rows())
 
 
@@ -851,7 +863,7 @@ def _route(keys_owner: torch.Tensor, world: int, ops):
     return ptr, order.long()
 
 
-def build_dbgnn_shard(g, delta, x, x_h, y, comm: Comm, ops=None, weight: str = "edge_weight"):
+def build_dbgnn_shard(g, delta, x, x_h, y, comm: Comm, ops=None, weight: str = "edge_weight", defer_status: bool = False):
     """The north-star split, straight from a time-sorted event stream replicated on every rank (what it replaces on one process:
     ``MultiOrderModel.from_temporal_graph(g, delta, max_order=2)`` + ``to_dbgnn_data`` + the plans of ``DBGNN.forward``; reference
     multi_order_model.py:124-192, 511-554, algorithms/temporal.py:17-54, lift_order.py:109-152).
@@ -874,6 +886,9 @@ def build_dbgnn_shard(g, delta, x, x_h, y, comm: Comm, ops=None, weight: str = "
 
     ``x`` [N, F] / ``x_h`` [U_2, F] / ``y`` [N]: replicated tensors, or ROW LOADERS ``f(rows int64) -> tensor`` (``x_h`` may also be a
     callable of the node count, the round-2 form, when it takes an ``int``) — a rank only ever reads its owned + halo rows.
+    ``defer_status=True`` (world size 1, generic kernels): the higher-order plan's report (bad-index status, hub-row tables) is left to
+    ``DbgnnShard.resolve()`` — which :class:`~pathpyg_amd.nn.sharded.ShardedDBGNN` calls after it has queued the first-order layers, so the
+    read-back costs no idle GPU time; a caller that uses ``shard.ho.plan`` directly must call ``resolve()`` first.  Default: resolved here.
     Returns a :class:`~pathpyg_amd.nn.sharded.DbgnnShard`; ``shard.sizes`` reports the global layer sizes."""
     ops = _ops_default(ops)
     if comm.world > 1:
@@ -922,11 +937,12 @@ def build_dbgnn_shard(g, delta, x, x_h, y, comm: Comm, ops=None, weight: str = "
     x_loc = _rows_of(x, None, 0, n, dev)
     xh_loc = x_h(n_ho) if (callable(x_h) and _takes_count(x_h)) else _rows_of(x_h, None, 0, n_ho, dev)
     a2 = int(ho_ei.size(1))
-    # the higher-order plan's report is read by DbgnnShard.resolve(): ShardedDBGNN queues the first-order layers in front of that read-back
-    return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=n, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(), y=_rows_of(y, None, 0, n, dev),
+    # defer_status: the higher-order plan's report is read by DbgnnShard.resolve() — ShardedDBGNN queues the first-order layers in front of it
+    shard = DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=n, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(), y=_rows_of(y, None, 0, n, dev),
                       n_fo=n, n_ho=n_ho, pending=(ops, pending_ho),
                       sizes={"m": m, "N": n, "E2": e2, "E2_local": e2, "U2": n_ho, "A1": n_ho, "A2": a2, "A2_local": a2, "fo_cuts": fo_cuts,
                              "ho_cuts": ho_cuts, "fo_halo": 0, "ho_halo": 0})
+    return shard if defer_status else shard.resolve()
 
 
 def global_sizes(shard, comm: Comm) -> dict:
@@ -1106,10 +1122,10 @@ def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
     fptr = fo_shard.plan.fwd_ptr
     indeg = (fptr[1:] - fptr[:-1]).to(torch.float32)                            # order-2 nodes (., b) per owned first-order node b
     comm.mark("build: bipartite plan + status read-back")
-    x_loc = _shard_rows(x, fo_shard)
+    x_loc = _shard_rows(x, fo_shard, comm)
     if callable(x_h) and _takes_count(x_h):
         x_h = x_h(n_ho)
-    xh_loc = _shard_rows(x_h, ho)
+    xh_loc = _shard_rows(x_h, ho, comm)
     comm.mark("build: feature rows (owned + halo)")
     return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x_loc.contiguous(), x_h=xh_loc.contiguous(),
                       y=_rows_of(y, None, lo_n, hi_n, dev), n_fo=n, n_ho=n_ho,

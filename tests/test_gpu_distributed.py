@@ -53,6 +53,8 @@ CASES = [
     (8, 3000, 70, 20, 1500, 256, [256, 256, 64], False),      # 256-wide layers (weights streamed through LDS) on rectangular plans
     (6, 1500, 40, 9, 500, 8, [12, 10, 6], True),             # widths without a fused kernel: library GEMM + CSR kernels
     (7, 60, 50, 2, 80, 16, [16, 16, 16], False),             # nearly empty higher-order graph, ranks without edges
+    (9, 4000, 400, 60, 6000, 64, [64, 64, 64], False),       # ~10 events per node: at world size 1 the fused order-2 builder (pp_debruijn2_*)
+    (10, 3000, 350, 45, 5000, 32, [32, 32, 16], True),       # ... with event weights
 ]
 
 
@@ -126,6 +128,51 @@ def _gloo_worker(rank, world, port, results):
         results[rank] = "ok"
     finally:
         dist.destroy_process_group()
+
+
+def _rccl_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        sys.path.insert(0, ROOT)
+        import pathpyg_amd as pp
+        from pathpyg_amd import distributed as pd
+        comm = pd.Comm()
+        assert comm.world == world and comm.native
+        for case in CASES:
+            shard, net = _run_rank(rank, world, dev, comm, case)                     # interleaved schedule, native asynchronous collectives
+            grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+            net.zero_grad(set_to_none=True)
+            serial = pd.ShardedDBGNN(net, comm, overlap=False)                       # the same step, every exchange waited for where it is issued
+            serial.loss(shard).backward()
+            pd.all_reduce_gradients(net, average=False, comm=comm)
+            for k, p in net.named_parameters():
+                torch.testing.assert_close(p.grad, grads[k], rtol=1e-5, atol=1e-6, msg=lambda s: f"{k} (overlap vs serial): {s}")
+        torch.cuda.synchronize()
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (the GPU test boxes of this "
+                                                          "project have one; the driver's multi-GPU bench is the first place this path runs)")
+def test_partition_path_two_ranks_over_rccl_overlap_matches_serial():
+    """the native asynchronous collectives (Comm._Pending: all_to_all_single / reduce_scatter_tensor / all_gather_into_tensor with
+    async_op=True) and the stream ordering the _ShardedTrunk schedule relies on — against the oracle and against the serial schedule."""
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, results)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    assert dict(results) == {0: "ok", 1: "ok"}
 
 
 def test_partition_path_three_ranks_as_threads_match_oracle():
