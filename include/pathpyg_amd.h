@@ -110,6 +110,28 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
                       float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order, float* fo_bwd_val,
                       float* fo_self, void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream);
 
+/* The same builder on ONE RANK of a node-range partition (the lift shards by edge range, the DBGNN by destination-node
+ * partition; no reference counterpart — the reference is single-process).  Rank `rank` owns the first-order nodes
+ * [node_lo, node_lo + n_own) = cuts[rank] .. cuts[rank + 1] (cuts: device int64 [world + 1]) and is handed the time-sorted events that start
+ * or end in that range (node ids stay global).  Every order-2 edge (a,b) -> (b,c) is born on the owner of its MIDDLE node b, which owns the
+ * rows (b, .): no lifted pair and no order-2 node id ever crosses a link.  Sources (a, b) with a foreign a are halo rows, numbered behind
+ * the U2 owned rows in (owner of a, b, a) order; send_idx [m] lists the owned rows other ranks gather from, grouped by that rank and ordered
+ * by (c, b) — the receiver's halo order, so one all-to-all of rows fills the halo without ids or requests; send_slot [m]: the inverse
+ * (-1 = not sent).  The first 8 int64 of ws = {U2, status, A2, E2, A1, halo rows, rows sent, -}, then recv_ptr [world + 1] and
+ * send_ptr [world + 1] (rows from / to every rank, as offsets).  Between count and fill the caller fetches ho_deg of its halo rows
+ * (ho_deg[U2 ..]) from their owners.  Fill: the order-2 plan over the local source space [owned | halo] as in pp_debruijn2_fill, and the
+ * first-order in-edges of the owned nodes as a raw list (fo_in_src, fo_in_dst: global node ids; fo_in_weight: merged weights), which go
+ * through pp_gcn_plan_begin / _finish (their normalisation needs degrees of foreign nodes). */
+int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
+                            const int64_t* cuts, int world, int rank, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
+                            int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
+                            float* ho_deg, float* fo_deg, int32_t* send_idx, int32_t* send_slot, void* ws, size_t ws_bytes, pp_stream_t stream);
+int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own, int delta_kind, int64_t delta_i, double delta_f,
+                           const float* weight, const int32_t* fo_bwd_ptr, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr,
+                           const int32_t* ho_bwd_ptr, const float* ho_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val,
+                           int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_in_src, int32_t* fo_in_dst, float* fo_in_weight,
+                           void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream);
+
 /* ------------------------------------------------------------------ order lifts (pp_lift.hip) */
 
 /* lift_order_temporal(g, delta) -> [2,E2] int64, src/pathpyG/algorithms/temporal.py:17-54.

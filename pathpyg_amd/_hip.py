@@ -769,6 +769,91 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
                      sizes={"m": m, "N": n, "E2": e2, "U2": u2, "A1": a1, "A2": a2})
 
 
+class DeBruijn2Part:
+    """Count phase of the order-2 builder on ONE RANK's node range (:func:`debruijn2_part_count`): sizes on the host, everything else on
+    the device until :func:`debruijn2_part_fill`."""
+
+    __slots__ = ("m", "n", "lo", "n_own", "world", "args", "ws", "bufs", "u2", "status", "a2", "e2", "a1", "n_halo", "n_send", "recv_counts", "send_counts",
+                 "send_idx", "send_slot", "ho_deg", "succ")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, node_lo: int, node_hi: int, cuts_dev: torch.Tensor,
+                         rank: int, delta, weight: torch.Tensor | None = None) -> "DeBruijn2Part | None":
+    """The order-2 builder for the rank that owns the nodes ``[node_lo, node_hi)`` of a partitioned stream: ``edge_index`` / ``time`` hold the
+    (time-sorted) events that start or end in that range.  Everything :func:`debruijn2` counts, restricted to the owned middle nodes, plus the
+    halo numbering (sources (a, b) with a foreign a, in (owner of a, b, a) order behind the owned rows) and the send lists (owned rows (b, c)
+    whose c another rank owns, grouped by that rank, ordered by (c, b) = the receiver's halo order).  ONE read-back.  ``None``: empty shard
+    inputs the builder does not take (the caller falls back); ``status`` bit 2 set: a node with more than 64 in- / out-events."""
+    ei = _edge_index(edge_index)
+    dev = require_device(ei, time, weight, cuts_dev)
+    if time.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
+        time = time.to(torch.int64)
+    if time.dtype not in (torch.int64, torch.float64):
+        raise TypeError(f"timestamps must be int64 or float64, got {time.dtype}")
+    time = time.contiguous()
+    m, n = ei.size(1), int(num_nodes)
+    world = int(cuts_dev.numel()) - 1
+    n_own = int(node_hi) - int(node_lo)
+    if weight is not None:
+        if weight.dtype != torch.float32 or weight.numel() != m:
+            return None
+        weight = weight.contiguous()
+    kind, di, df = resolve_delta(time.dtype, delta)
+    L = lib()
+    with torch.cuda.device(dev):
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        cap = max(m, 1)
+        ws = _workspace(L.pp_debruijn2_ws_bytes(m, n), dev)
+        bufs = {"fo_bwd_ptr": torch.empty(n_own + 1, **i32), "fo_fwd_ptr": torch.empty(n_own + 1, **i32), "fo_bwd_idx": torch.empty(cap, **i32),
+                "fo_w": torch.empty(cap, **f32), "ho_fwd_ptr": torch.empty(cap + 1, **i32), "ho_bwd_ptr": torch.empty(cap + 1, **i32),
+                "ho_deg": torch.empty(cap, **f32), "fo_deg": torch.empty(max(n, 1), **f32), "send_idx": torch.empty(cap, **i32),
+                "send_slot": torch.empty(cap, **i32)}
+        tcode = _DTYPE_CODE[time.dtype]
+        check(L.pp_debruijn2_part_count(_p(ei), _p(time), tcode, m, n, int(node_lo), n_own, _p(cuts_dev), world, int(rank), kind, di, df, _p(weight),
+                                        _p(bufs["fo_bwd_ptr"]), _p(bufs["fo_bwd_idx"]), _p(bufs["fo_w"]), _p(bufs["fo_fwd_ptr"]), _p(bufs["ho_fwd_ptr"]),
+                                        _p(bufs["ho_bwd_ptr"]), _p(bufs["ho_deg"]), _p(bufs["fo_deg"]), _p(bufs["send_idx"]), _p(bufs["send_slot"]),
+                                        _p(ws), ws.numel(), _stream()), "pp_debruijn2_part_count")
+        head = ws[: 8 * (8 + 2 * (world + 1))].view(torch.int64).tolist()                 # the ONE read-back of this rank's graph construction
+    u2, status, a2, e2, a1, n_halo, n_send = head[:7]
+    recv_ptr, send_ptr = head[8: 8 + world + 1], head[8 + world + 1: 8 + 2 * (world + 1)]
+    _bad_index(status, "MultiOrderModel.from_temporal_graph (partition)")
+    if status & 2:
+        raise ValueError("lift_order_temporal: the events are not sorted by time")
+    return DeBruijn2Part(m=m, n=n, lo=int(node_lo), n_own=n_own, world=world, args=(tcode, kind, di, df, weight), ws=ws, bufs=bufs, u2=u2, status=status,
+                         a2=a2, e2=e2, a1=a1, n_halo=n_halo, n_send=n_send, recv_counts=[recv_ptr[r + 1] - recv_ptr[r] for r in range(world)],
+                         send_counts=[send_ptr[r + 1] - send_ptr[r] for r in range(world)], send_idx=bufs["send_idx"][:n_send],
+                         send_slot=bufs["send_slot"][:u2], ho_deg=bufs["ho_deg"], succ=bufs["fo_bwd_idx"][:u2])
+
+
+def debruijn2_part_fill(c: DeBruijn2Part):
+    """Fill phase (after the d^-1/2 degrees of the halo rows arrived in ``c.ho_deg[u2: u2 + n_halo]``): ``(ho CsrPlan over [owned | halo] sources,
+    first-order in-edges (src, dst GLOBAL node ids int32, merged weight), order-2 nodes per owned first-order node)``."""
+    dev = c.ws.device
+    tcode, kind, di, df, weight = c.args
+    b = c.bufs
+    L = lib()
+    with torch.cuda.device(dev):
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        n_src = c.u2 + c.n_halo
+        ho = CsrPlan(n_dst=c.u2, n_src=n_src, fwd_ptr=b["ho_fwd_ptr"][: c.u2 + 1], fwd_idx=torch.empty(c.a2, **i32), fwd_val=torch.empty(c.a2, **f32),
+                     bwd_ptr=b["ho_bwd_ptr"][: n_src + 1], bwd_idx=torch.empty(c.a2, **i32), bwd_val=torch.empty(c.a2, **f32),
+                     self_coef=torch.empty(c.u2, **f32))
+        fo_src, fo_dst, fo_w = torch.empty(c.a1, **i32), torch.empty(c.a1, **i32), torch.empty(c.a1, **f32)
+        if c.m > 0 and c.n_own > 0:
+            check(L.pp_debruijn2_part_fill(tcode, c.m, c.n, c.lo, c.n_own, kind, di, df, _p(weight), _p(b["fo_bwd_ptr"]), _p(b["fo_fwd_ptr"]),
+                                           _p(b["ho_fwd_ptr"]), _p(b["ho_bwd_ptr"]), _p(b["ho_deg"]), c.a2, _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx),
+                                           _p(ho.bwd_val), _p(ho.self_coef), _p(fo_src), _p(fo_dst), _p(fo_w), _p(torch.empty(2 * c.a2, **i32)), _p(c.ws),
+                                           c.ws.numel(), _stream()), "pp_debruijn2_part_fill")
+        indeg = (b["fo_fwd_ptr"][1:] - b["fo_fwd_ptr"][:-1]).to(torch.float32)
+    return ho, (fo_src, fo_dst, fo_w), indeg
+
+
 def spmm(ptr, idx, val, n_rows: int, x: torch.Tensor, self_coef=None, s=None, bias=None, act: bool = False,
          heavy: HeavyRows | None = None) -> torch.Tensor:
     """Y[r] = act(sum_p val[p] * x[idx[p]] + self_coef[r] * s[r] + bias) — fp32, rows of width F.  ``heavy``: the hub rows of this

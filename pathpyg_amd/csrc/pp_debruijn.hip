@@ -30,6 +30,7 @@
 namespace pp {
 
 constexpr int64_t kDb2BadIndex = 1, kDb2Unsorted = 2, kDb2Overflow = 4;
+constexpr uint32_t kDb2Foreign = 0xFFFFFFFEu;         // order-2 node of an event whose source node another rank owns: numbered on the head side
 
 struct alignas(16) Db2Rec {
     uint64_t t;       // timestamp bits (int64 or float64)
@@ -136,11 +137,11 @@ __global__ __launch_bounds__(kBlock) void k_db2_gather_coef(int64_t m, const uin
     const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (q >= m) return;
     const uint32_t u = is_u[q], a = is_a[q];
-    if (u == 0xFFFFFFFFu) return;                  // (an event of an overflow node: the caller falls back)
+    if (u >= kDb2Foreign) return;                  // (later instance of a halo run: only the run's first event carries the id; or an overflow node)
     const uint2 r = row_pack[u];
     du_s[q] = __uint_as_float(r.x);
     ob_s[q] = (int32_t)r.y;
-    da_s[q] = inv_sqrt_deg(fo_deg[a]);
+    da_s[q] = fo_deg ? inv_sqrt_deg(fo_deg[a]) : 0.0f;
 }
 
 // the source-major rows were scattered as (destination, coefficient) pairs: one 8-byte random store per entry instead of two 4-byte ones
@@ -167,7 +168,7 @@ struct Db2OutIn {
 };
 
 template <bool kW>
-__global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ oc_t,
+__global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, int64_t lo, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ oc_t,
                                                    const uint64_t* __restrict__ ot_t, const float* __restrict__ ow_t, uint64_t* __restrict__ ot_s,
                                                    uint32_t* __restrict__ oc_s, float* __restrict__ ow_s, uint8_t* __restrict__ ocr_s,
                                                    uint8_t* __restrict__ ocr_t, int32_t* __restrict__ blk, int64_t* __restrict__ status) {
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, const uint32_t* _
 #pragma unroll
     for (int s = 0; s < kDb2Nodes; ++s) {
         const int64_t node = node0 + s;
-        const uint32_t b0 = node < n ? tp[node] : 0u, b1 = node < n ? tp[node + 1] : 0u;
+        const uint32_t b0 = node < n ? tp[lo + node] : 0u, b1 = node < n ? tp[lo + node + 1] : 0u;      // (node: index inside the owned range [lo, lo + n))
         in[s].p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);          // (wave-uniform by construction: scalar loop bounds, scalar addresses)
         in[s].cnt = __builtin_amdgcn_readfirstlane((int)(b1 - b0));
     }
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, const uint32_t* _
 }
 
 // per list position: the (time, order-2 node, source) record the head-side gather reads; per successor run: the first-order edge
-__global__ __launch_bounds__(kBlock) void k_db2_out_fill(int64_t m, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tkeys_s,
+__global__ __launch_bounds__(kBlock) void k_db2_out_fill(int64_t m, int64_t lo, int64_t n_own, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tkeys_s,
                                                         const uint64_t* __restrict__ ot_t, const uint8_t* __restrict__ ocr_t,
                                                         const uint32_t* __restrict__ oc_s, const float* __restrict__ ow_s,
                                                         const uint8_t* __restrict__ ocr_s, const int32_t* __restrict__ row_ptr,
@@ -256,8 +257,11 @@ __global__ __launch_bounds__(kBlock) void k_db2_out_fill(int64_t m, const uint32
     r.t = ot_t[p];
     r.a = b;
     r.u = 0xFFFFFFFFu;
-    if (tp[b + 1] - p0 <= (uint32_t)kWave) {                   // (else an overflow node: its events keep the id 0xFFFFFFFF, the caller falls back)
-        const uint32_t row0 = (uint32_t)row_ptr[b];
+    const int64_t bl = (int64_t)b - lo;
+    if (bl < 0 || bl >= n_own) {
+        r.u = kDb2Foreign;
+    } else if (tp[b + 1] - p0 <= (uint32_t)kWave) {            // (else an overflow node: its events keep the id 0xFFFFFFFF, the caller falls back)
+        const uint32_t row0 = (uint32_t)row_ptr[bl];
         r.u = row0 + ocr_t[p];
         const uint8_t cr = ocr_s[p];
         if (p == p0 || ocr_s[p - 1] != cr) {
@@ -287,6 +291,9 @@ __global__ __launch_bounds__(kBlock) void k_db2_fo_bwd_val(int64_t m, const uint
 
 // ------------------------------------------------------------------ middle-node pass
 struct Db2Mid {
+    int64_t lo;                      // first owned node (0 on one GPU); arrays indexed by node: tp, hp, fo_deg GLOBAL ids, everything else owned-local
+    int part;                        // partition shard: the first-order in-edges leave as a raw (source, destination, weight) list
+    int32_t* fwd_dst1;
     const uint32_t *tp, *hp;
     const uint64_t* ot_s;            // out-events in (successor, time) order: time, successor rank
     const uint8_t* ocr_s;
@@ -336,7 +343,8 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
     for (int s = 0; s < kDb2Nodes; ++s) {
         const int64_t node = node0 + s;
         const bool there = node < n;
-        const uint32_t b0 = there ? a.tp[node] : 0u, b1 = there ? a.tp[node + 1] : 0u, h0 = there ? a.hp[node] : 0u, h1 = there ? a.hp[node + 1] : 0u;
+        const int64_t gn = a.lo + node;
+        const uint32_t b0 = there ? a.tp[gn] : 0u, b1 = there ? a.tp[gn + 1] : 0u, h0 = there ? a.hp[gn] : 0u, h1 = there ? a.hp[gn + 1] : 0u;
         const int32_t r0 = there ? a.row_ptr[node] : 0;
         in[s].p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);          // (wave-uniform by construction: scalar loop bounds, scalar addresses)
         in[s].q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0);
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
         in[s].ni = __builtin_amdgcn_readfirstlane((int)(h1 - h0));
         in[s].row0 = __builtin_amdgcn_readfirstlane(r0);
         if (kFill) {
-            in[s].d1 = there ? inv_sqrt_deg(a.fo_deg[node]) : 0.0f;
+            in[s].d1 = (there && !a.part) ? inv_sqrt_deg(a.fo_deg[gn]) : 0.0f;
             in[s].lw1 = there ? a.fo_lw[node] : 1.0f;
             in[s].fp = __builtin_amdgcn_readfirstlane(there ? a.fo_fwd_ptr[node] : 0);
         }
@@ -373,11 +381,12 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
     for (int s = 0; s < kDb2Nodes; ++s) {
         const int64_t node = node0 + s;
         if (node >= n) break;
+        const uint32_t gnode = (uint32_t)(a.lo + node);
         const int no = in[s].no, ni = in[s].ni;
         if (no > kWave || ni > kWave) {
             if (!kFill && l == 0) {
                 atomicOr((unsigned long long*)a.status, (unsigned long long)kDb2Overflow);
-                a.nu[node] = 0; a.pc[node] = 0; a.fo_deg[node] = 1.0f; a.fo_lw[node] = 1.0f;
+                a.nu[node] = 0; a.pc[node] = 0; a.fo_deg[gnode] = 1.0f; a.fo_lw[node] = 1.0f;
             }
             continue;
         }
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
                     if (ucur == v) lw = wgt; else deg += wgt;
                 }
                 if (l == nuc) { run_u = ucur; run_od = (int32_t)__popcll(em); }
-                if (acur == (uint32_t)node) lw1 = w1run; else deg1 += w1run;
+                if (acur == gnode) lw1 = w1run; else deg1 += w1run;
             } else {
                 const float du_ = rl_f(in[s].du, z0), da_ = rl_f(in[s].da, z0);
                 const int32_t ob_ = rl_i(in[s].ob, z0);
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
                 if (l == nuc) {
                     run_u = ucur;
                     run_a = acur;
-                    run_val = acur == (uint32_t)node ? 0.0f : da_ * w1run * d1b;
+                    run_val = a.part ? w1run : (acur == gnode ? 0.0f : da_ * w1run * d1b);
                 }
             }
             ++nuc;
@@ -477,24 +486,98 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
                 const float l1 = lw1 < 0.0f ? 1.0f : lw1;
                 a.nu[node] = nuc;
                 a.pc[node] = pairs;
-                a.fo_deg[node] = deg1 + l1;
+                a.fo_deg[gnode] = deg1 + l1;
                 a.fo_lw[node] = l1;
             }
         } else {
             if (l < nuc) {
                 a.fwd_idx1[in[s].fp + l] = (int32_t)run_a;
                 a.fwd_val1[in[s].fp + l] = run_val;
-                a.dst_order[in[s].fp + l] = (int32_t)run_u;
+                if (a.dst_order) a.dst_order[in[s].fp + l] = (int32_t)run_u;
+                if (a.fwd_dst1) a.fwd_dst1[in[s].fp + l] = (int32_t)gnode;
             }
             if (ohead) a.self2[v] = dv * lwv * dv;
-            if (l == 0) a.self1[node] = d1b * in[s].lw1 * d1b;
+            if (l == 0 && a.self1) a.self1[node] = d1b * in[s].lw1 * d1b;
         }
     }
 }
 
+// ------------------------------------------------------------------ partition shards: halo numbering and send lists
+// One rank owns the nodes [lo, lo + n_own) and holds the events that touch them.  Its order-2 rows are the nodes (b, .) of its b; the
+// sources (a, b) with a foreign a are HALO rows, numbered behind the owned rows in the order (owner of a, b, a): the owner q of a sends its
+// rows (a, b) for this rank ordered by (b, a) (k_db2_send_keys + a stable sort by b), so the rows of one all-to-all arrive exactly in
+// halo order — no ids travel, no request round.
+__device__ __forceinline__ int owner_of(int64_t node, const int64_t* __restrict__ cuts, int world) {
+    int r = 0;
+    while (r + 1 < world && node >= cuts[r + 1]) ++r;
+    return r;
+}
+
+// key of every in-event position: the owner of its source node at the first event of a foreign (source, head) run, `world` elsewhere
+__global__ __launch_bounds__(kBlock) void k_db2_halo_keys(int64_t m, int64_t lo, int64_t n_own, const uint32_t* __restrict__ hkeys_s,
+                                                         const uint32_t* __restrict__ hp, const uint32_t* __restrict__ is_a,
+                                                         const uint32_t* __restrict__ is_u, const int64_t* __restrict__ cuts, int world,
+                                                         uint32_t* __restrict__ keys) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= m) return;
+    const uint32_t b = hkeys_s[q];
+    const int64_t bl = (int64_t)b - lo;
+    uint32_t key = (uint32_t)world;
+    if (bl >= 0 && bl < n_own && is_u[q] == kDb2Foreign && (q == (int64_t)hp[b] || is_a[q - 1] != is_a[q])) key = (uint32_t)owner_of(is_a[q], cuts, world);
+    keys[q] = key;
+}
+
+// the k-th foreign run in (owner, head, source) order is halo row k = local source id U2_own + k
+__global__ __launch_bounds__(kBlock) void k_db2_halo_assign(int64_t m, const uint32_t* __restrict__ keys_s, const uint32_t* __restrict__ order,
+                                                           int world, const int64_t* __restrict__ result, uint32_t* __restrict__ is_u) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= m || keys_s[k] >= (uint32_t)world) return;
+    is_u[order[k]] = (uint32_t)result[0] + (uint32_t)k;
+}
+
+// sort key of every owned order-2 row (b, c): c when another rank owns c (that rank gathers from the row), num_nodes otherwise
+__global__ __launch_bounds__(kBlock) void k_db2_send_keys(int64_t cap, const int64_t* __restrict__ result, const int32_t* __restrict__ fo_bwd_idx,
+                                                         int64_t lo, int64_t n_own, int64_t num_nodes, uint32_t* __restrict__ keys) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= cap) return;
+    uint32_t key = (uint32_t)num_nodes;
+    if (r < result[0]) {
+        const int64_t c = fo_bwd_idx[r];
+        if (c < lo || c >= lo + n_own) key = (uint32_t)c;
+    }
+    keys[r] = key;
+}
+
+// send_ptr[r] = first position of the sorted send keys that belongs to rank r (r = 0 .. world); recv_ptr from the sorted halo keys; both
+// published as int64 behind the sizes: result[8 ..] = recv_ptr[world + 1], then send_ptr[world + 1]; result[5] = halo rows, [6] = rows sent
+__global__ void k_db2_publish(int64_t m, const uint32_t* __restrict__ halo_keys_s, const uint32_t* __restrict__ send_keys_s,
+                              const int64_t* __restrict__ cuts, int world, int64_t num_nodes, int64_t* __restrict__ result) {
+    const int r = threadIdx.x;
+    if (r > world) return;
+    const uint32_t hk = (uint32_t)r;                                        // halo keys are owners
+    const uint32_t sk = r == world ? (uint32_t)num_nodes : (uint32_t)cuts[r];   // send keys are head nodes
+    const int64_t hpos = lower_bound_dev<uint32_t, int64_t>(halo_keys_s, 0, m, hk);
+    const int64_t spos = lower_bound_dev<uint32_t, int64_t>(send_keys_s, 0, m, sk);
+    result[8 + r] = hpos;
+    result[8 + world + 1 + r] = spos;
+    if (r == world) { result[5] = hpos; result[6] = spos; }
+}
+
+// send_slot[row] = position of an owned row in the send list (-1: no peer gathers from it)
+__global__ __launch_bounds__(kBlock) void k_db2_send_slots(int64_t m, const uint32_t* __restrict__ send_keys_s, const int32_t* __restrict__ send_idx,
+                                                          int64_t num_nodes, int32_t* __restrict__ send_slot) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= m || send_keys_s[k] >= (uint32_t)num_nodes) return;
+    send_slot[send_idx[k]] = (int32_t)k;
+}
+
 // ------------------------------------------------------------------ workspace
+constexpr int kDb2MaxWorld = 64;
+constexpr int kDb2Result = 8 + 2 * (kDb2MaxWorld + 1) + 6;
+
 struct Db2Ws {
-    int64_t* result;         // [8]: {U2, status, A2, E2, A1 (first-order in-edges), -, -, -}
+    int64_t* result;         // [kDb2Result]: {U2, status, A2, E2, A1 (first-order in-edges), halo rows, rows sent, -, recv_ptr[world+1], send_ptr[world+1]}
+    uint32_t *xkeys, *xkeys_s, *xorder;      // partition shards: halo / send-list sort keys
     uint32_t *tkeys, *tkeys_s, *hkeys_s, *tl, *hl, *tp, *hp;
     Db2Rec* rec;
     Db2Src* src_t;
@@ -517,7 +600,10 @@ struct Db2Ws {
 static Db2Ws carve_db2(void* ws, int64_t m, int64_t n) {
     Arena a(ws, (size_t)-1);
     Db2Ws w;
-    w.result = a.take<int64_t>(8);
+    w.result = a.take<int64_t>(kDb2Result);
+    w.xkeys = a.take<uint32_t>(m);
+    w.xkeys_s = a.take<uint32_t>(m);
+    w.xorder = a.take<uint32_t>(m);
     w.tkeys = a.take<uint32_t>(m);
     w.tkeys_s = a.take<uint32_t>(m);
     w.hkeys_s = a.take<uint32_t>(m);
@@ -588,26 +674,39 @@ extern "C" {
 
 size_t pp_debruijn2_ws_bytes(int64_t m, int64_t num_nodes) { return carve_db2(nullptr, m > 0 ? m : 0, num_nodes > 0 ? num_nodes : 0).total_bytes; }
 
-int pp_debruijn2_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i,
-                       double delta_f, const float* weight, int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr,
-                       int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr, float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, pp_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t n = num_nodes;
-    PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "pp_debruijn2_count: negative size");
-    PP_REQUIRE(m < (int64_t)0x7fffffff && n < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_debruijn2_count: m or num_nodes >= 2^31");
-    PP_REQUIRE(time_dtype == PP_I64 || time_dtype == PP_F64, PP_ERR_ARG, "pp_debruijn2_count: time must be int64 or float64");
-    PP_REQUIRE(delta_kind >= PP_DELTA_I64 && delta_kind <= PP_DELTA_F64, PP_ERR_ARG, "pp_debruijn2_count: bad delta kind");
+}  // extern "C"
+
+namespace pp {
+
+struct Db2Part {                   // node range of a partition shard (one GPU: lo = 0, n_own = num_nodes, world = 1, the rest unused)
+    int64_t lo, n_own;
+    const int64_t* cuts;           // device int64 [world + 1]: node ranges of all ranks
+    int world, me;
+    int32_t *send_idx, *send_slot; // [m] each
+};
+
+static int db2_count(const char* who, const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t n, const Db2Part& pt, int delta_kind,
+                     int64_t delta_i, double delta_f, const float* weight, int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr,
+                     int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr, float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, hipStream_t st) {
+    const bool part = pt.world > 1;
+    const int64_t n_own = pt.n_own;
+    PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "%s: negative size", who);
+    PP_REQUIRE(m < (int64_t)0x7ffffff0 && n < (int64_t)0x7ffffff0, PP_ERR_TOO_LARGE, "%s: m or num_nodes >= 2^31", who);
+    PP_REQUIRE(time_dtype == PP_I64 || time_dtype == PP_F64, PP_ERR_ARG, "%s: time must be int64 or float64", who);
+    PP_REQUIRE(delta_kind >= PP_DELTA_I64 && delta_kind <= PP_DELTA_F64, PP_ERR_ARG, "%s: bad delta kind", who);
+    PP_REQUIRE(pt.lo >= 0 && n_own >= 0 && pt.lo + n_own <= n && pt.world >= 1 && pt.world <= kDb2MaxWorld && pt.me >= 0 && pt.me < pt.world, PP_ERR_ARG,
+               "%s: bad node range / world", who);
     Db2Ws w = carve_db2(ws, m, n);
-    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_debruijn2_count: workspace too small");
-    PP_HIP(hipMemsetAsync(w.result, 0, 8 * sizeof(int64_t), st));
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "%s: workspace too small", who);
+    PP_HIP(hipMemsetAsync(w.result, 0, kDb2Result * sizeof(int64_t), st));
     if (m == 0 || n == 0) {
-        PP_HIP(hipMemsetAsync(fo_bwd_ptr, 0, (size_t)(n + 1) * sizeof(int32_t), st));
-        PP_HIP(hipMemsetAsync(fo_fwd_ptr, 0, (size_t)(n + 1) * sizeof(int32_t), st));
+        PP_HIP(hipMemsetAsync(fo_bwd_ptr, 0, (size_t)(n_own + 1) * sizeof(int32_t), st));
+        PP_HIP(hipMemsetAsync(fo_fwd_ptr, 0, (size_t)(n_own + 1) * sizeof(int32_t), st));
         PP_HIP(hipMemsetAsync(ho_fwd_ptr, 0, (size_t)(m + 1) * sizeof(int32_t), st));
         PP_HIP(hipMemsetAsync(ho_bwd_ptr, 0, (size_t)(m + 1) * sizeof(int32_t), st));
         return PP_OK;
     }
-    const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n, kWavesPerBlock * kDb2Nodes);
+    const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n_own > 0 ? n_own : 1, kWavesPerBlock * kDb2Nodes);
     // 1. event records; out-lists (stable sort by tail: time order inside a list), then the list SEQUENCE sorted by head: in-lists in (source, time) order
     if (time_dtype == PP_I64) k_db2_keys<int64_t><<<egrid, kBlock, 0, st>>>(edge_index, (const int64_t*)time, m, n, w.tkeys, w.rec, w.result + 1);
     else k_db2_keys<double><<<egrid, kBlock, 0, st>>>(edge_index, (const double*)time, m, n, w.tkeys, w.rec, w.result + 1);
@@ -623,32 +722,104 @@ int pp_debruijn2_count(const int64_t* edge_index, const void* time, int time_dty
     PP_LAUNCH_CHECK();
     k_db2_rowptr<<<(unsigned)ceil_div(m + 1, kBlock), kBlock, 0, st>>>(w.hkeys_s, m, n, w.hp);
     PP_LAUNCH_CHECK();
-    // 2. successors of every node -> order-2 node ids
-    if (weight) k_db2_out<true><<<ngrid, kBlock, 0, st>>>(n, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, w.result + 1);
-    else k_db2_out<false><<<ngrid, kBlock, 0, st>>>(n, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, w.result + 1);
+    // 2. successors of every owned node -> order-2 node ids
+    if (weight) k_db2_out<true><<<ngrid, kBlock, 0, st>>>(n_own, pt.lo, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, w.result + 1);
+    else k_db2_out<false><<<ngrid, kBlock, 0, st>>>(n_own, pt.lo, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, w.result + 1);
     PP_LAUNCH_CHECK();
-    rc = exclusive_scan<int32_t, int32_t>(w.blk, n, fo_bwd_ptr, true, w.result, w.scratch, w.scratch_bytes, st);
+    rc = exclusive_scan<int32_t, int32_t>(w.blk, n_own, fo_bwd_ptr, true, w.result, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
-    k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, w.src_t, fo_bwd_idx, fo_w);
+    k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, w.src_t, fo_bwd_idx, fo_w);
     PP_LAUNCH_CHECK();
     k_db2_gather_in<<<egrid, kBlock, 0, st>>>(m, w.hl, w.src_t, weight ? w.ow_t : nullptr, w.is_t, w.is_a, w.is_u, w.is_w);
     PP_LAUNCH_CHECK();
+    if (part) {
+        // 2b. send lists (who gathers from my rows) and halo numbering (whose rows I gather from), one 8-bit / one node-id sort each
+        const int nbits = bits_for((uint64_t)n);
+        k_db2_send_keys<<<egrid, kBlock, 0, st>>>(m, w.result, fo_bwd_idx, pt.lo, n_own, n, w.xkeys);
+        PP_LAUNCH_CHECK();
+        rc = sort_pairs<uint32_t>(w.xkeys, nullptr, w.xkeys_s, (uint32_t*)pt.send_idx, m, 0, nbits, w.scratch, w.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+        PP_HIP(hipMemsetAsync(pt.send_slot, 0xFF, (size_t)m * sizeof(int32_t), st));
+        k_db2_send_slots<<<egrid, kBlock, 0, st>>>(m, w.xkeys_s, pt.send_idx, n, pt.send_slot);
+        PP_LAUNCH_CHECK();
+        uint32_t* hkeys = w.xkeys;                       // (the send keys are sorted: their buffer is free)
+        uint32_t* hkeys_sorted = (uint32_t*)w.du_s;      // (fill-pass scratch, unused until then)
+        k_db2_halo_keys<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.hkeys_s, w.hp, w.is_a, w.is_u, pt.cuts, pt.world, hkeys);
+        PP_LAUNCH_CHECK();
+        rc = sort_pairs<uint32_t>(hkeys, nullptr, hkeys_sorted, w.xorder, m, 0, bits_for((uint64_t)pt.world), w.scratch, w.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+        k_db2_halo_assign<<<egrid, kBlock, 0, st>>>(m, hkeys_sorted, w.xorder, pt.world, w.result, w.is_u);
+        PP_LAUNCH_CHECK();
+        k_db2_publish<<<1, kDb2MaxWorld + 1, 0, st>>>(m, hkeys_sorted, w.xkeys_s, pt.cuts, pt.world, n, w.result);
+        PP_LAUNCH_CHECK();
+    }
     // 3. middle-node pass, counting
     PP_HIP(hipMemsetAsync(w.indeg2, 0, (size_t)m * sizeof(int32_t), st));
     PP_HIP(hipMemsetAsync(w.outdeg2, 0, (size_t)m * sizeof(int32_t), st));
     Db2Mid a{};
     mid_common(a, w, fo_bwd_ptr, weight != nullptr);
+    a.lo = pt.lo; a.part = part ? 1 : 0;
     a.indeg2 = w.indeg2; a.outdeg2 = w.outdeg2; a.ho_deg = ho_deg; a.fo_deg = fo_deg;
     a.nu = w.nu; a.pc = w.pc; a.status = w.result + 1;
-    rc = launch_mid_any<false>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n, delta_i, delta_f, a);
+    rc = launch_mid_any<false>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n_own, delta_i, delta_f, a);
     if (rc != PP_OK) return rc;
-    rc = exclusive_scan<int32_t, int32_t>(w.nu, n, fo_fwd_ptr, true, w.result + 4, w.scratch, w.scratch_bytes, st);
+    rc = exclusive_scan<int32_t, int32_t>(w.nu, n_own, fo_fwd_ptr, true, w.result + 4, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
     rc = exclusive_scan<int32_t, int32_t>(w.indeg2, m, ho_fwd_ptr, true, w.result + 2, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
     rc = exclusive_scan<int32_t, int32_t>(w.outdeg2, m, ho_bwd_ptr, true, nullptr, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
-    return exclusive_scan<int32_t, int64_t>(w.pc, n, w.pc_scan, true, w.result + 3, w.scratch, w.scratch_bytes, st);
+    return exclusive_scan<int32_t, int64_t>(w.pc, n_own, w.pc_scan, true, w.result + 3, w.scratch, w.scratch_bytes, st);
+}
+
+static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64_t lo, int64_t n_own, bool part, int delta_kind, int64_t delta_i,
+                    double delta_f, const float* weight, const int32_t* fo_bwd_ptr, const float* fo_w, const int32_t* fo_fwd_ptr,
+                    const int32_t* ho_fwd_ptr, const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t num_ho_edges,
+                    int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx,
+                    float* fo_fwd_val, int32_t* fo_dst_order, int32_t* fo_fwd_dst, float* fo_bwd_val, float* fo_self, void* pair_scratch, void* ws,
+                    size_t ws_bytes, hipStream_t st) {
+    PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "%s: negative size", who);
+    Db2Ws w = carve_db2(ws, m, n);
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "%s: workspace too small", who);
+    if (n == 0 || n_own == 0) return PP_OK;
+    PP_REQUIRE(m > 0, PP_ERR_ARG, "%s: an empty stream has no order-2 model to fill (use pp_gcn_plan on the empty graph)", who);
+    const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n_own, kWavesPerBlock * kDb2Nodes);
+    PP_REQUIRE(num_ho_edges >= 0 && (num_ho_edges == 0 || pair_scratch != nullptr), PP_ERR_ARG, "%s: pair_scratch (8 bytes per order-2 edge) missing", who);
+    k_db2_pack_rows<<<egrid, kBlock, 0, st>>>(m, ho_deg, ho_bwd_ptr, w.row_pack);
+    PP_LAUNCH_CHECK();
+    k_db2_gather_coef<<<egrid, kBlock, 0, st>>>(m, w.is_u, w.is_a, w.row_pack, part ? nullptr : fo_deg, w.du_s, w.ob_s, w.da_s);
+    PP_LAUNCH_CHECK();
+    Db2Mid a{};
+    mid_common(a, w, fo_bwd_ptr, weight != nullptr);
+    a.lo = lo; a.part = part ? 1 : 0;
+    a.ho_deg = const_cast<float*>(ho_deg); a.fo_deg = const_cast<float*>(fo_deg);
+    a.du_s = w.du_s; a.da_s = w.da_s; a.ob_s = w.ob_s;
+    a.ho_fwd_ptr = ho_fwd_ptr; a.fo_fwd_ptr = fo_fwd_ptr;
+    a.in_idx2 = ho_fwd_idx; a.in_val2 = ho_fwd_val; a.out_pack = (uint2*)pair_scratch; a.self2 = ho_self;
+    a.fwd_idx1 = fo_fwd_idx; a.fwd_val1 = fo_fwd_val; a.dst_order = fo_dst_order; a.fwd_dst1 = fo_fwd_dst; a.self1 = fo_self;
+    int rc = launch_mid_any<true>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n_own, delta_i, delta_f, a);
+    if (rc != PP_OK) return rc;
+    if (num_ho_edges > 0) {
+        k_db2_unzip<<<(unsigned)ceil_div(num_ho_edges, kBlock), kBlock, 0, st>>>(num_ho_edges, (const uint2*)pair_scratch, ho_bwd_idx, ho_bwd_val);
+        PP_LAUNCH_CHECK();
+    }
+    if (!part) {
+        k_db2_fo_bwd_val<<<egrid, kBlock, 0, st>>>(m, w.tp, w.tkeys_s, w.oc_s, w.ocr_s, fo_bwd_ptr, fo_w, fo_deg, fo_bwd_val);
+        PP_LAUNCH_CHECK();
+    }
+    return PP_OK;
+}
+
+}  // namespace pp
+
+extern "C" {
+
+int pp_debruijn2_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i,
+                       double delta_f, const float* weight, int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr,
+                       int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr, float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    const Db2Part whole{0, num_nodes, nullptr, 1, 0, nullptr, nullptr};
+    return db2_count("pp_debruijn2_count", edge_index, time, time_dtype, m, num_nodes, whole, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_bwd_idx,
+                     fo_w, fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
@@ -656,35 +827,29 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
                       const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx,
                       float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order, float* fo_bwd_val,
                       float* fo_self, void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t n = num_nodes;
-    PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "pp_debruijn2_fill: negative size");
-    Db2Ws w = carve_db2(ws, m, n);
-    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "pp_debruijn2_fill: workspace too small");
-    if (n == 0) return PP_OK;
-    PP_REQUIRE(m > 0, PP_ERR_ARG, "pp_debruijn2_fill: an empty stream has no order-2 model to fill (use pp_gcn_plan on the empty graph)");
-    const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n, kWavesPerBlock * kDb2Nodes);
-    PP_REQUIRE(num_ho_edges >= 0 && (num_ho_edges == 0 || pair_scratch != nullptr), PP_ERR_ARG, "pp_debruijn2_fill: pair_scratch (8 bytes per order-2 edge) missing");
-    k_db2_pack_rows<<<egrid, kBlock, 0, st>>>(m, ho_deg, ho_bwd_ptr, w.row_pack);
-    PP_LAUNCH_CHECK();
-    k_db2_gather_coef<<<egrid, kBlock, 0, st>>>(m, w.is_u, w.is_a, w.row_pack, fo_deg, w.du_s, w.ob_s, w.da_s);
-    PP_LAUNCH_CHECK();
-    Db2Mid a{};
-    mid_common(a, w, fo_bwd_ptr, weight != nullptr);
-    a.ho_deg = const_cast<float*>(ho_deg); a.fo_deg = const_cast<float*>(fo_deg);
-    a.du_s = w.du_s; a.da_s = w.da_s; a.ob_s = w.ob_s;
-    a.ho_fwd_ptr = ho_fwd_ptr; a.fo_fwd_ptr = fo_fwd_ptr;
-    a.in_idx2 = ho_fwd_idx; a.in_val2 = ho_fwd_val; a.out_pack = (uint2*)pair_scratch; a.self2 = ho_self;
-    a.fwd_idx1 = fo_fwd_idx; a.fwd_val1 = fo_fwd_val; a.dst_order = fo_dst_order; a.self1 = fo_self;
-    int rc = launch_mid_any<true>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n, delta_i, delta_f, a);
-    if (rc != PP_OK) return rc;
-    if (num_ho_edges > 0) {
-        k_db2_unzip<<<(unsigned)ceil_div(num_ho_edges, kBlock), kBlock, 0, st>>>(num_ho_edges, (const uint2*)pair_scratch, ho_bwd_idx, ho_bwd_val);
-        PP_LAUNCH_CHECK();
-    }
-    k_db2_fo_bwd_val<<<egrid, kBlock, 0, st>>>(m, w.tp, w.tkeys_s, w.oc_s, w.ocr_s, fo_bwd_ptr, fo_w, fo_deg, fo_bwd_val);
-    PP_LAUNCH_CHECK();
-    return PP_OK;
+    return db2_fill("pp_debruijn2_fill", time_dtype, m, num_nodes, 0, num_nodes, false, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_w, fo_fwd_ptr,
+                    ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_fwd_idx, fo_fwd_val,
+                    fo_dst_order, nullptr, fo_bwd_val, fo_self, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
+                            const int64_t* cuts, int world, int rank, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
+                            int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
+                            float* ho_deg, float* fo_deg, int32_t* send_idx, int32_t* send_slot, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    PP_REQUIRE(world >= 2 && cuts != nullptr && send_idx != nullptr && send_slot != nullptr, PP_ERR_ARG, "pp_debruijn2_part_count: world >= 2 with cuts and send buffers");
+    const Db2Part pt{node_lo, n_own, cuts, world, rank, send_idx, send_slot};
+    return db2_count("pp_debruijn2_part_count", edge_index, time, time_dtype, m, num_nodes, pt, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr,
+                     fo_bwd_idx, fo_w, fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own, int delta_kind, int64_t delta_i, double delta_f,
+                           const float* weight, const int32_t* fo_bwd_ptr, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr,
+                           const int32_t* ho_bwd_ptr, const float* ho_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val,
+                           int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_in_src, int32_t* fo_in_dst, float* fo_in_weight,
+                           void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    return db2_fill("pp_debruijn2_part_fill", time_dtype, m, num_nodes, node_lo, n_own, true, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, nullptr,
+                    fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, nullptr, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_in_src,
+                    fo_in_weight, nullptr, fo_in_dst, nullptr, nullptr, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -892,6 +892,10 @@ def build_dbgnn_shard(g, delta, x, x_h, y, comm: Comm, ops=None, weight: str = "
     Returns a :class:`~pathpyg_amd.nn.sharded.DbgnnShard`; ``shard.sizes`` reports the global layer sizes."""
     ops = _ops_default(ops)
     if comm.world > 1:
+        if FUSED_BUILDER and getattr(ops, "debruijn2_part_count", None) is not None:
+            shard = _build_partitioned_by_node(g, delta, x, x_h, y, comm, ops, weight)
+            if shard is not None:
+                return shard
         return _build_partitioned(g, delta, x, x_h, y, comm, ops, weight)
     from .nn.sharded import DbgnnShard
     data = g.data
@@ -1026,6 +1030,133 @@ def distribute_stream(g, delta, comm: Comm, ops=None, weight: str = "edge_weight
     except Exception:          # exotic containers: no caching, still correct
         pass
     return shard
+
+
+class NodeShard:
+    """One rank's share of a time-sorted stream under a NODE-RANGE partition (round 4): the events that start or end in its node range, in
+    stream order — what the node-by-node order-2 builder wants (pp_debruijn2_part_*).  Built once per stream (cached on the graph)."""
+
+    __slots__ = ("world", "rank", "n", "m", "fo_cuts", "cuts_t", "ei", "time", "w", "stamp")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+def distribute_stream_by_node(g, delta, comm: Comm, ops=None, weight: str = "edge_weight") -> NodeShard:
+    """Node ranges balanced as in :func:`partition_plan` (estimated nnz per node; exact integer arithmetic on the replicated input, identical on
+    every rank, no collective) + this rank's events: those with the tail OR the head node in its range.  Cached on ``g``."""
+    ops = _ops_default(ops)
+    data = g.data
+    ei = _dispatch.plain(data.edge_index)
+    w_all = data[weight] if weight in data else None
+    stamp = (comm.world, comm.rank, repr(delta), tuple((t_, t_._version) for t_ in (data.edge_index, data.time, w_all) if t_ is not None))
+    cache = getattr(g, "_pp_node_shards", None)
+    cached = cache.get((comm.world, comm.rank)) if isinstance(cache, dict) else None
+    if cached is not None and len(cached.stamp) == len(stamp) and cached.stamp[:3] == stamp[:3] and len(cached.stamp[3]) == len(stamp[3]) and \
+            all(a is b and va == vb for (a, va), (b, vb) in zip(cached.stamp[3], stamp[3])):
+        return cached
+    rank, world = comm.rank, comm.world
+    dev = ei.device
+    time = data.time.contiguous()
+    n, m = int(data.num_nodes), int(ei.size(1))
+    outdeg, indeg = ops.degree(ei[0], n).to(torch.int64), ops.degree(ei[1], n).to(torch.int64)
+    if m > 0:
+        span = (time[-1] - time[0]).to(torch.float64).clamp(min=1e-300)
+        delta_t = (delta.to(dev) if isinstance(delta, torch.Tensor) else torch.as_tensor(delta, device=dev)).to(torch.float64)
+        frac_q = torch.floor((delta_t / span).clamp(min=0.0, max=1.0) * 1024.0).to(torch.int64)
+    else:
+        frac_q = torch.zeros((), dtype=torch.int64, device=dev)
+    # a node b costs its events on both sides (sorted, gathered) + its rows (b, .) + its expected in-edges in(b) * out(b) * delta / span
+    node_w = (outdeg + indeg) * 1024 + outdeg * (ROW_COST * 1024 + indeg * frac_q) + 1
+    cuts_t = _balanced_cuts(node_w, world)
+    fo_cuts = cuts_t.tolist()
+    lo, hi = fo_cuts[rank], fo_cuts[rank + 1]
+    mine = torch.nonzero(((ei[0] >= lo) & (ei[0] < hi)) | ((ei[1] >= lo) & (ei[1] < hi))).flatten()
+    shard = NodeShard(world=world, rank=rank, n=n, m=m, fo_cuts=fo_cuts, cuts_t=cuts_t.contiguous(), ei=ei.index_select(1, mine).contiguous(),
+                      time=time.index_select(0, mine).contiguous(), w=None if w_all is None else w_all.index_select(0, mine).contiguous(), stamp=stamp)
+    try:
+        if not isinstance(cache, dict):
+            cache = {}
+            object.__setattr__(g, "_pp_node_shards", cache)
+        cache[(comm.world, comm.rank)] = shard
+    except Exception:
+        pass
+    return shard
+
+
+def _own_rows_buffer(source, lo: int, hi: int, n_halo: int, device) -> torch.Tensor:
+    """``[n_own + n_halo, F]`` with the owned rows ``lo .. hi`` of a feature source in front (the halo rows arrive by exchange).  A resident row
+    store (``own_buffer``) keeps that buffer placed between steps."""
+    fetch = getattr(source, "own_buffer", None)
+    if fetch is not None:
+        return fetch(lo, hi, n_halo)
+    own = _rows_of(source, None, lo, hi, device)
+    buf = torch.empty((hi - lo + n_halo, own.size(1)), dtype=own.dtype, device=own.device)
+    buf[: hi - lo] = own
+    return buf
+
+
+def _build_partitioned_by_node(g, delta, x, x_h, y, comm: Comm, ops, weight: str):
+    """World size > 1, round 4: NODE-RANGE partition on the node-by-node order-2 builder.  Rank r owns the first-order nodes of its range, is
+    handed the events that touch them (:func:`distribute_stream_by_node`, once per stream) and builds — with one read-back and without any
+    exchange of pairs, node ids or counts — the order-2 rows (b, .) of its nodes b: their in-edges come from in-events x out-events of b, all
+    local.  What crosses links per step: 2 integers per rank (sizes), the d^-1/2 degrees and the input feature rows of the halo rows, the
+    first-order degrees (inside pp_gcn_plan_begin / _finish).  Returns ``None`` when some rank holds a node with more than 64 in- / out-events
+    (every rank then takes :func:`_build_partitioned`, the generic kernels)."""
+    from .nn.sharded import DbgnnShard, GraphShard
+    rank, world = comm.rank, comm.world
+    ns = distribute_stream_by_node(g, delta, comm, ops, weight)
+    comm.mark("build: 0 stream distribution (first step only)")
+    n, fo_cuts = ns.n, ns.fo_cuts
+    lo_n, hi_n = fo_cuts[rank], fo_cuts[rank + 1]
+    dev = ns.ei.device
+    if ns.w is not None and ns.w.dtype != torch.float32:
+        return None
+    c = ops.debruijn2_part_count(ns.ei, ns.time, n, lo_n, hi_n, ns.cuts_t, rank, delta, ns.w)
+    comm.mark("build: 1 order-2 builder, count pass (sorts, successor blocks, halo numbering, send lists)")
+    # sizes of all ranks: global order-2 id ranges, E2, and whether everybody can stay on this path (one tiny collective)
+    sizes_all = comm.all_gather_ints([c.u2 if c is not None else 0, c.e2 if c is not None else 0, 1 if (c is None or c.status & 4) else 0], dev)
+    if any(row[2] for row in sizes_all):
+        return None
+    ho_cuts = [0]
+    for row in sizes_all:
+        ho_cuts.append(ho_cuts[-1] + row[0])
+    n_ho, e2 = ho_cuts[-1], sum(row[1] for row in sizes_all)
+    lo_h, hi_h = ho_cuts[rank], ho_cuts[rank + 1]
+    n_own, n_halo = c.u2, c.n_halo
+    # input features of the halo rows travel under the rest of the build; the halo rows' degrees are needed by the fill pass
+    if callable(x_h) and _takes_count(x_h):
+        x_h = x_h(n_ho)
+    xh_buf = _own_rows_buffer(x_h, lo_h, hi_h, n_halo, dev)
+    send_idx = c.send_idx
+    xh_pending = comm.exchange_rows_async(xh_buf[:n_own].index_select(0, send_idx), c.send_counts, c.recv_counts, out=xh_buf[n_own: n_own + n_halo])
+    comm.exchange_rows(c.ho_deg[:n_own].index_select(0, send_idx), c.send_counts, c.recv_counts, out=c.ho_deg[n_own: n_own + n_halo])
+    comm.mark("build: 2 halo exchanges (degrees; feature rows asynchronously)")
+    ho_plan, (fo_src, fo_dst, fo_w), indeg = ops.debruijn2_part_fill(c)
+    comm.mark("build: 3 order-2 builder, fill pass")
+
+    def fetch_halo_ids():
+        ids = comm.exchange_rows(send_idx.to(torch.int64) + lo_h, c.send_counts, c.recv_counts)
+        return ids
+
+    ho = GraphShard(lo=lo_h, hi=hi_h, n_own=n_own, n_halo=n_halo, n_src=n_own + n_halo, num_nodes=n_ho, cuts=ho_cuts, plan=ho_plan, halo_ids=None,
+                    send_idx=send_idx, send_counts=c.send_counts, recv_counts=c.recv_counts, send_unique=True, send_slot=c.send_slot,
+                    halo_fetch=fetch_halo_ids)
+    pending = []
+    # first-order graph: the in-edges of my nodes; every foreign node is a halo row (an all-gather per layer), normalised by the generic plan
+    fo_shard = build_graph_shard(fo_src.to(torch.int64), fo_dst.to(torch.int64), fo_w, n, fo_cuts, comm, ops, False, pending, dense_halo=True)
+    comm.mark("build: first-order shard + plan")
+    bip, cap = _bipartite_shard(torch.arange(n_own, dtype=torch.int64, device=dev), c.succ.to(torch.int64), n_own, fo_cuts, comm, ops, src_sorted=True)
+    ops.check_plan_status(pending)
+    comm.mark("build: bipartite plan + status read-back")
+    x_loc = _shard_rows(x, fo_shard, comm)
+    xh_pending.wait()
+    comm.mark("build: feature rows (owned + halo)")
+    return DbgnnShard(fo=fo_shard, ho=ho, bip=bip, cap=cap, indeg=indeg, x=x_loc.contiguous(), x_h=xh_buf[: n_own + n_halo],
+                      y=_rows_of(y, None, lo_n, hi_n, dev), n_fo=n, n_ho=n_ho,
+                      sizes={"m": ns.m, "N": n, "E2": e2, "E2_local": c.e2, "U2": n_ho, "A1": n_ho, "A2_local": c.a2, "fo_cuts": fo_cuts,
+                             "ho_cuts": ho_cuts, "fo_halo": fo_shard.n_halo, "ho_halo": n_halo, "events_local": int(ns.ei.size(1)), "builder": "fused"})
 
 
 def _build_partitioned(g, delta, x, x_h, y, comm: Comm, ops, weight: str):

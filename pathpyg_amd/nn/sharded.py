@@ -42,6 +42,8 @@ class HipOps:
 
     # ---- lift + aggregation
     debruijn2 = staticmethod(_hip.debruijn2)
+    debruijn2_part_count = staticmethod(_hip.debruijn2_part_count)
+    debruijn2_part_fill = staticmethod(_hip.debruijn2_part_fill)
     temporal_lift = staticmethod(_hip.temporal_lift)
     coalesce = staticmethod(_hip.coalesce)
 
@@ -218,7 +220,7 @@ class GraphShard:
     ``send_slot`` (``send_unique`` shards): int32 ``[n_own]``, the position of an owned row in the send list or -1 — the inverse of ``send_idx``."""
 
     __slots__ = ("lo", "hi", "n_own", "n_halo", "n_src", "num_nodes", "cuts", "plan", "halo_ids", "send_idx", "send_counts", "recv_counts",
-                 "back_ptr", "back_idx", "send_unique", "send_slot")
+                 "back_ptr", "back_idx", "send_unique", "send_slot", "halo_fetch")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -229,7 +231,10 @@ class GraphShard:
         return 0 if self.send_idx is None else int(self.send_idx.numel())
 
     def local_rows(self) -> torch.Tensor:
-        """Global ids of the local source space ``[owned | halo]`` (int64)."""
+        """Global ids of the local source space ``[owned | halo]`` (int64).  Shards of the node-by-node builder never exchange ids: the halo
+        ids are fetched on first use (``halo_fetch``: one exchange of 8 bytes per halo row — a COLLECTIVE, every rank calls it alike)."""
+        if self.halo_ids is None and self.halo_fetch is not None:
+            self.halo_ids = self.halo_fetch()
         own = torch.arange(self.lo, self.hi, device=self.plan.fwd_ptr.device)
         return own if self.n_halo == 0 else torch.cat((own, self.halo_ids))
 

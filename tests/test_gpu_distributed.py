@@ -58,6 +58,13 @@ CASES = [
 ]
 
 
+def _lifted_pairs(ei, t, n, delta):
+    from oracle import lift as ol
+    from oracle import model as om
+    sei, st, _ = om.stable_time_sort(ei, t)
+    return ol.temporal_lift_sorted(sei, st, delta, n).size(1)
+
+
 def _run_rank(rank, world, dev, comm, case):
     import pathpyg_amd as pp
     from pathpyg_amd import distributed as pd
@@ -68,6 +75,8 @@ def _run_rank(rank, world, dev, comm, case):
     shard = pd.build_dbgnn_shard(tg, case[3], x.to(dev), x_h.to(dev), y.to(dev), comm)
     sz = pd.global_sizes(shard, comm)
     assert sz["U2"] == layers[2]["num_nodes"] and sz["A2"] == layers[2]["edge_index"].size(1)
+    if case[0] in (9, 10):          # ~10 events per node: the node-by-node order-2 builder, at every world size (world > 1: node-range partition)
+        assert shard.sizes.get("builder") == "fused" and sz["E2"] == int(_lifted_pairs(ei, t, case[2], case[3]))
     if shard.ho.n_send:
         assert int(torch.bincount(shard.ho.send_idx).max()) == 1          # De Bruijn cuts: every row goes to at most one peer
     net = pp.nn.DBGNN(num_classes=3, num_features=(case[5], case[5]), hidden_dims=case[6]).to(dev)
@@ -240,7 +249,10 @@ def test_partition_path_world8_er_and_zipf_on_one_gpu(dense_fo, monkeypatch):
     dev = torch.device("cuda:0")
     cases = [("er", _case(11, 20000, 300, 30, 6000, 64, [64, 64, 64], False), 300, 30, 64, [64, 64, 64]),
              ("zipf", _zipf_case(12, 20000, 300, 30, 6000, 64, [64, 64, 64]), 300, 30, 64, [64, 64, 64]),
-             ("tiny", _case(13, 50, 20, 3, 60, 16, [16, 16, 16], False), 20, 3, 16, [16, 16, 16])]
+             ("tiny", _case(13, 50, 20, 3, 60, 16, [16, 16, 16], False), 20, 3, 16, [16, 16, 16]),
+             # ~12 events per node: the node-range partition on the node-by-node builder (no pair routing, no id exchange), plain and weighted
+             ("er-sparse", _case(14, 7000, 600, 70, 7000, 64, [64, 64, 64], False), 600, 70, 64, [64, 64, 64]),
+             ("er-sparse-weighted", _case(15, 5000, 450, 60, 6000, 32, [32, 32, 16], True), 450, 60, 32, [32, 32, 16])]
     for kind, (ei, t, w, x, x_h, y, params, want, layers), n, delta, f, hidden in cases:
         want_out, want_loss, want_grads = want
         attrs = {} if w is None else {"edge_weight": w.to(dev)}
@@ -253,6 +265,7 @@ def test_partition_path_world8_er_and_zipf_on_one_gpu(dense_fo, monkeypatch):
             sz = pd.global_sizes(shard, comm)
             assert sz["U2"] == layers[2]["num_nodes"] and sz["A2"] == layers[2]["edge_index"].size(1), kind
             assert shard.ho.send_unique and shard.x_h.size(0) == shard.ho.n_src and shard.x.size(0) == shard.fo.n_src
+            assert (shard.sizes.get("builder") == "fused") == (kind in ("tiny", "er-sparse", "er-sparse-weighted")), kind      # (hub nodes: generic kernels)
             net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=hidden).to(dev)
             net.load_state_dict(params)
             sharded = pd.ShardedDBGNN(net, comm)
