@@ -96,6 +96,15 @@ class ResidentRows:
             torch.index_select(self.full, 0, halo_ids, out=buf[n_own: n_own + n_halo])
         return buf[: n_own + n_halo]
 
+    def shard_rows_static(self, lo: int, hi: int, halo_ids: torch.Tensor) -> torch.Tensor:
+        """Rows of a DENSE-halo shard (halo = every foreign node, the same set at every step): fetched once, kept with the owned rows."""
+        key = ("static", lo, hi, int(halo_ids.numel()))
+        buf = self.placed.get(key)
+        if buf is None:
+            buf = torch.cat((self.full[lo:hi], self.full.index_select(0, halo_ids)))
+            self.placed[key] = buf
+        return buf
+
     def own_buffer(self, lo: int, hi: int, n_halo: int) -> torch.Tensor:
         """[n_own + n_halo, F] with the owned rows in front — placed once per ownership range; the halo rows arrive by exchange (node-range
         partition: pathpyg_amd.distributed._build_partitioned_by_node)."""

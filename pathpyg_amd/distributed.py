@@ -648,8 +648,10 @@ def build_graph_shard(src: torch.Tensor, dst: torch.Tensor, weight: torch.Tensor
         # returned gradient rows arrive peer by peer: row i of peer block p sits at p * n_own + i
         back_ptr = torch.arange(0, n_own * peers + 1, max(peers, 1), dtype=torch.int32, device=dev)[: n_own + 1]
         back_idx = (own_rows.unsqueeze(1) + (torch.arange(peers, dtype=torch.int32, device=dev) * n_own).unsqueeze(0)).reshape(-1)
-        return _finish_graph_shard(torch.stack((src_local, dst - lo)), weight, lo, hi, num_nodes, cuts, halo_ids, send_idx, send_counts, recv_counts,
-                                   comm, ops, status_out, unique_send=False, want_dst_order=want_dst_order, back=(back_ptr, back_idx))
+        gs = _finish_graph_shard(torch.stack((src_local, dst - lo)), weight, lo, hi, num_nodes, cuts, halo_ids, send_idx, send_counts, recv_counts,
+                                 comm, ops, status_out, unique_send=False, want_dst_order=want_dst_order, back=(back_ptr, back_idx))
+        gs.dense = True              # (layer exchanges of this shard: all-gather + block copies, nn.sharded.halo_fill_async)
+        return gs
     cuts_t = torch.tensor(cuts, dtype=torch.int64, device=dev)
     if src_sorted:
         src_local, halo_ids, recv_counts = sorted_halo(src, lo, hi, cuts_t)
@@ -784,6 +786,11 @@ def _shard_rows(source, gs, comm: "Comm | None" = None) -> torch.Tensor:
     ``gs.local_rows()``."""
     fetch = getattr(source, "shard_rows", None)
     if fetch is not None:
+        static = getattr(source, "shard_rows_static", None)
+        if getattr(gs, "dense", False) and static is not None:
+            # dense halo = EVERY foreign node, whatever the graph of this step looks like: the halo rows of the (static) input features do not
+            # change between steps — the store keeps them next to the owned rows (the first-order input features are replicated, 4 N F bytes)
+            return static(gs.lo, gs.hi, gs.halo_ids)
         rows = fetch(gs.lo, gs.hi, gs.halo_ids)
         if comm is not None and comm.world > 1 and gs.n_halo:
             # a resident store serves the halo rows from the other ranks' memories: in a deployment that IS an exchange over xGMI (recv_counts

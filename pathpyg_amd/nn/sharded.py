@@ -220,7 +220,7 @@ class GraphShard:
     ``send_slot`` (``send_unique`` shards): int32 ``[n_own]``, the position of an owned row in the send list or -1 — the inverse of ``send_idx``."""
 
     __slots__ = ("lo", "hi", "n_own", "n_halo", "n_src", "num_nodes", "cuts", "plan", "halo_ids", "send_idx", "send_counts", "recv_counts",
-                 "back_ptr", "back_idx", "send_unique", "send_slot", "halo_fetch")
+                 "back_ptr", "back_idx", "send_unique", "send_slot", "halo_fetch", "dense")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -239,9 +239,47 @@ class GraphShard:
         return own if self.n_halo == 0 else torch.cat((own, self.halo_ids))
 
 
+class _DenseHalo:
+    """Pending all-gather of a DENSE-halo shard (every foreign node is a halo row: the first-order graph of a dense stream): ``wait()``
+    moves the gathered blocks into the halo rows ``[ids below lo | ids from hi on]`` — no pack of the owned rows per peer, and the collective
+    is the ring / direct all-gather instead of an all-to-all of 7 copies."""
+
+    def __init__(self, shard, handle, buf):
+        self.shard, self.handle, self.buf = shard, handle, buf
+
+    def wait(self):
+        gs, out = self.shard, self.handle.wait()
+        world = len(gs.cuts) - 1
+        cap = out.size(0) // world
+        at = gs.n_own
+        for r in range(world):
+            size = gs.cuts[r + 1] - gs.cuts[r]
+            if size == 0 or gs.cuts[r] == gs.lo:
+                continue
+            self.buf[at: at + size] = out[r * cap: r * cap + size]
+            at += size
+        return self.buf[gs.n_own:]
+
+
+def halo_fill_async(shard: GraphShard, comm, buf: torch.Tensor):
+    """Start the embedding exchange of one layer (halo rows ``buf[n_own:]`` <- the owners' rows); ``.wait()`` completes it."""
+    if getattr(shard, "dense", False) and comm.world > 1:
+        world = len(shard.cuts) - 1
+        cap = max(max(shard.cuts[r + 1] - shard.cuts[r] for r in range(world)), 1)
+        own = buf[: shard.n_own]
+        if shard.n_own != cap:
+            own = F.pad(own, (0, 0, 0, cap - shard.n_own))
+        return _DenseHalo(shard, comm.all_gather_rows_async(own), buf)
+    send = buf[: shard.n_own].index_select(0, shard.send_idx)
+    return comm.exchange_rows_async(send, shard.send_counts, shard.recv_counts, out=buf[shard.n_own:])
+
+
 def halo_fill(shard: GraphShard, comm, buf: torch.Tensor) -> None:
     """Fill the halo rows ``buf[n_own:]`` with the owners' rows of ``buf[:n_own]`` — the embedding exchange of one layer."""
     if comm.world == 1:          # (a rank without halo rows still takes part: the exchange is a collective)
+        return
+    if getattr(shard, "dense", False):
+        halo_fill_async(shard, comm, buf).wait()
         return
     send = buf[: shard.n_own].index_select(0, shard.send_idx)
     comm.exchange_rows(send, shard.send_counts, shard.recv_counts, out=buf[shard.n_own:])
@@ -418,8 +456,7 @@ class _ShardedTrunk(torch.autograd.Function):
             st["inputs"].append(st["h"])
             st["saved"].append(ops.layer_forward(gs.plan, st["h"], weight, bias, l == 0, buf[: gs.n_own], None))
             if not last:
-                send = buf[: gs.n_own].index_select(0, gs.send_idx)
-                st["pending"] = comm.exchange_rows_async(send, gs.send_counts, gs.recv_counts, out=buf[gs.n_own:])
+                st["pending"] = halo_fill_async(gs, comm, buf)
             st["h"] = buf
 
         mark = getattr(comm, "mark", lambda label: None)
