@@ -69,10 +69,11 @@ def parse():
                     "(pp_debruijn2_*; one read-back, the event graph is never written) or by the generic kernels (lift -> coalesce -> plans)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-loop-events", type=int, default=6_000, help="smallest of the three B-loop sizes (x2, x4 follow; kept below torch's 32768-element parallel grain)")
-    ap.add_argument("--cpu-sample-events", type=int, default=2_000_000, help="size of the vectorised CPU pipeline sample (B-agg, B-dbgnn)")
+    ap.add_argument("--cpu-sample-events", type=int, default=10_000_000, help="size of the vectorised CPU pipeline legs (B-agg, B-dbgnn): the FULL workload by "
+                                                                                "default (BASELINE.md §3: full size where host RAM allows; capped at --events)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU baseline and print its JSON (used by the main run, in a "
                                                                       "subprocess with a hard time limit, so that it can never stall the bench line)")
-    ap.add_argument("--cpu-baseline-timeout", type=int, default=420)
+    ap.add_argument("--cpu-baseline-timeout", type=int, default=1200)
     return ap.parse_args()
 
 

@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tests.tolerance import assert_embeddings_close
+from tests.tolerance import assert_embeddings_close, assert_gradients_close
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -91,8 +91,7 @@ def _run_rank(rank, world, dev, comm, case):
     comm.all_reduce_(total)
     torch.testing.assert_close(total.cpu()[0], want_loss, rtol=RTOL, atol=ATOL)
     for name, p in net.named_parameters():
-        scale = float(want_grads[name].abs().max()) + 1e-12
-        torch.testing.assert_close(p.grad.cpu(), want_grads[name], rtol=1e-4, atol=max(ATOL, 2e-5 * scale), msg=lambda s: f"{name}: {s}")
+        assert_gradients_close(p.grad, want_grads[name], name)
     return shard, net
 
 
@@ -278,8 +277,9 @@ def test_partition_path_world8_er_and_zipf_on_one_gpu(dense_fo, monkeypatch):
             comm.all_reduce_(total)
             torch.testing.assert_close(total.cpu()[0], want_loss, rtol=RTOL, atol=ATOL)
             for name, p in net.named_parameters():
-                scale = float(want_grads[name].abs().max()) + 1e-12
-                torch.testing.assert_close(p.grad.cpu(), want_grads[name], rtol=1e-4, atol=max(ATOL, 2e-5 * scale), msg=lambda s_: f"{kind} {name}: {s_}")
+                # (zipf: hub rows sum thousands of fp32 terms in another order than the oracle — entries that cancel to ~1e-3 of the
+                #  typical magnitude carry that noise: 3e-5; every other stream: the north star's 1e-5)
+                assert_gradients_close(p.grad, want_grads[name], f"{kind} {name}", rtol=3e-5 if kind == "zipf" else 1e-5)
             return "ok"
 
         assert pd.run_thread_world(8, body, dev) == ["ok"] * 8, kind
@@ -382,8 +382,7 @@ def test_partition_path_dropout_matches_masked_reference(case):
     want_loss, want_grads = _masked_reference(case, p, seed)
     torch.testing.assert_close(loss.detach().cpu(), want_loss, rtol=RTOL, atol=ATOL)
     for name, prm in net.named_parameters():
-        scale = float(want_grads[name].abs().max()) + 1e-12
-        torch.testing.assert_close(prm.grad.cpu(), want_grads[name], rtol=1e-4, atol=max(ATOL, 2e-5 * scale), msg=lambda s: f"{name}: {s}")
+        assert_gradients_close(prm.grad, want_grads[name], name)
 
 
 def test_partition_path_dropout_on_ranks_sharing_one_gpu():
@@ -416,8 +415,7 @@ def test_partition_path_dropout_on_ranks_sharing_one_gpu():
             comm.all_reduce_(total)
             torch.testing.assert_close(total.cpu()[0], want_loss, rtol=RTOL, atol=ATOL)
             for name, prm in net.named_parameters():
-                scale = float(want_grads[name].abs().max()) + 1e-12
-                torch.testing.assert_close(prm.grad.cpu(), want_grads[name], rtol=1e-4, atol=max(ATOL, 2e-5 * scale), msg=lambda s_: f"{case[5]} {name}: {s_}")
+                assert_gradients_close(prm.grad, want_grads[name], f"{case[5]} {name}")
             return "ok"
 
         assert pd.run_thread_world(3, body, dev) == ["ok"] * 3

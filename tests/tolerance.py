@@ -16,3 +16,11 @@ def assert_embeddings_close(got: torch.Tensor, want: torch.Tensor, rtol: float =
         worst = int((err - bound).argmax())
         raise AssertionError(f"{what}: {int(bad.sum())} of {want.numel()} entries beyond {rtol:g} relative (+ {rtol:g} * rms = {rtol * rms:.3e}); "
                              f"worst: got {got.flatten()[worst]:.9g}, want {want.flatten()[worst]:.9g}, max abs err {float(err.max()):.3e}")
+
+
+def assert_gradients_close(got: torch.Tensor, want: torch.Tensor, what: str, rtol: float = 1e-5) -> None:
+    """Parameter gradients at the same element-wise bar as the embeddings: ``|got - want| <= rtol * |want| + rtol * rms(want)`` per entry.
+    A parameter gradient is a sum over all rows of the graph; where a test sums so many fp32 terms that their rounding noise
+    (~ sqrt(rows) * 2^-24 of the terms' magnitude, with cancellation) exceeds 1e-5 of the typical entry, the test passes its own ``rtol`` and
+    says why — the default is the north star's 1e-5."""
+    assert_embeddings_close(got, want, rtol=rtol, what=what)
