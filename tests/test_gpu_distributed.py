@@ -385,8 +385,9 @@ def test_partition_path_dropout_matches_masked_reference(case):
         assert_gradients_close(prm.grad, want_grads[name], name)
 
 
-def test_partition_path_dropout_on_ranks_sharing_one_gpu():
-    """Training-mode dropout across 3 ranks (HIP kernels; the ranks are threads of this process, ThreadWorld): the owner's layer kernel drops
+@pytest.mark.parametrize("world", [3, 8])
+def test_partition_path_dropout_on_ranks_sharing_one_gpu(world):
+    """Training-mode dropout across 3 and 8 ranks (HIP kernels; the ranks are threads of this process, ThreadWorld): the owner's layer kernel drops
     its rows in the epilogue with the GLOBAL row id (drop_row0 = the shard's first row) before they are exchanged; loss and gradients equal
     the single-process evaluation with the same masks."""
     if not torch.cuda.is_available():
@@ -396,7 +397,7 @@ def test_partition_path_dropout_on_ranks_sharing_one_gpu():
     dev, p = torch.device("cuda:0"), 0.4
     torch.manual_seed(5)
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).item())
-    for case in (CASES[0], CASES[1], CASES[2]):
+    for case in (CASES[0], CASES[1], CASES[2], CASES[6]):          # (the last one: node-range partition on the node-by-node builder; its halo ids are fetched lazily for the masks)
         ei, t, w, x, x_h, y, params, want, layers = _case(*case)
         want_loss, want_grads = _masked_reference(case, p, seed)
         attrs = {} if w is None else {"edge_weight": w.to(dev)}
@@ -418,4 +419,4 @@ def test_partition_path_dropout_on_ranks_sharing_one_gpu():
                 assert_gradients_close(prm.grad, want_grads[name], f"{case[5]} {name}")
             return "ok"
 
-        assert pd.run_thread_world(3, body, dev) == ["ok"] * 3
+        assert pd.run_thread_world(world, body, dev) == ["ok"] * world
