@@ -106,15 +106,17 @@ class ResidentRows:
             self.placed[key] = buf
         return buf
 
-    def own_buffer(self, lo: int, hi: int, n_halo: int) -> torch.Tensor:
-        """[n_own + n_halo, F] with the owned rows in front — placed once per ownership range; the halo rows arrive by exchange (node-range
-        partition: pathpyg_amd.distributed._build_partitioned_by_node)."""
+    def rows_buffer(self, lo: int, hi: int, row_of: torch.Tensor, n_halo: int) -> torch.Tensor:
+        """[n_own + n_halo, F] with the owned rows lo + row_of in front (the LOCAL row order of a node-range shard, which follows this step's
+        graph: one row gather per step), room for the halo rows, which arrive by exchange (pathpyg_amd.distributed._build_partitioned_by_node)."""
+        from pathpyg_amd import _hip
         n_own = hi - lo
-        buf = self.placed.get((lo, hi))
+        buf = self.placed.get(("rows", lo, hi))
         if buf is None or buf.size(0) < n_own + n_halo:
             buf = torch.empty((n_own + n_halo + n_halo // 8 + 1, self.full.size(1)), dtype=self.full.dtype, device=self.full.device)
-            buf[:n_own] = self.full[lo:hi]
-            self.placed[(lo, hi)] = buf
+            self.placed[("rows", lo, hi)] = buf
+        if n_own:
+            _hip.gather_rows(self.full[lo:hi], row_of, out=buf[:n_own])
         return buf[: n_own + n_halo]
 
     def __call__(self, rows: torch.Tensor) -> torch.Tensor:      # (plain row-loader form, world size 1 / callers without a shard)
@@ -254,7 +256,7 @@ def pmc_traffic(kernel_key: str, args) -> float | None:
     return None
 
 
-PMC_TABLES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_TABLES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 pmc_traffic.source = None
 
 

@@ -115,9 +115,11 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
  * [node_lo, node_lo + n_own) = cuts[rank] .. cuts[rank + 1] (cuts: device int64 [world + 1]) and is handed the time-sorted events that start
  * or end in that range (node ids stay global).  Every order-2 edge (a,b) -> (b,c) is born on the owner of its MIDDLE node b, which owns the
  * rows (b, .): no lifted pair and no order-2 node id ever crosses a link.  Sources (a, b) with a foreign a are halo rows, numbered behind
- * the U2 owned rows in (owner of a, b, a) order; send_idx [m] lists the owned rows other ranks gather from, grouped by that rank and ordered
- * by (c, b) — the receiver's halo order, so one all-to-all of rows fills the halo without ids or requests; send_slot [m]: the inverse
- * (-1 = not sent).  The first 8 int64 of ws = {U2, status, A2, E2, A1, halo rows, rows sent, -}, then recv_ptr [world + 1] and
+ * the U2 owned rows in (owner of a, b, a) order.  The owned rows are numbered in SEND ORDER: the rows (b, c) other ranks gather from come
+ * first, grouped by the owner of c and ordered by (c, b) — the receiver's halo order —, so the send list of every layer exchange is the
+ * contiguous prefix [0, rows sent) of a row matrix (no pack, no ids, no request round: one all-to-all of rows fills the peers' halos); rows
+ * nobody gathers from follow.  fo_bwd_idx / fo_w are in that local order (fo_bwd_ptr stays lexicographic: block sizes per node);
+ * send_slot [m]: local row -> its position in the prefix, -1 behind it; row_of [m]: local row -> lexicographic row (global id - first owned id).  The first 8 int64 of ws = {U2, status, A2, E2, A1, halo rows, rows sent, -}, then recv_ptr [world + 1] and
  * send_ptr [world + 1] (rows from / to every rank, as offsets).  Between count and fill the caller fetches ho_deg of its halo rows
  * (ho_deg[U2 ..]) from their owners.  Fill: the order-2 plan over the local source space [owned | halo] as in pp_debruijn2_fill, and the
  * first-order in-edges of the owned nodes as a raw list (fo_in_src, fo_in_dst: global node ids; fo_in_weight: merged weights), which go
@@ -125,7 +127,7 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
 int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
                             const int64_t* cuts, int world, int rank, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
                             int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
-                            float* ho_deg, float* fo_deg, int32_t* send_idx, int32_t* send_slot, void* ws, size_t ws_bytes, pp_stream_t stream);
+                            float* ho_deg, float* fo_deg, int32_t* send_slot, int32_t* row_of, void* ws, size_t ws_bytes, pp_stream_t stream);
 int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own, int delta_kind, int64_t delta_i, double delta_f,
                            const float* weight, const int32_t* fo_bwd_ptr, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr,
                            const int32_t* ho_bwd_ptr, const float* ho_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val,

@@ -774,7 +774,7 @@ class DeBruijn2Part:
     the device until :func:`debruijn2_part_fill`."""
 
     __slots__ = ("m", "n", "lo", "n_own", "world", "args", "ws", "bufs", "u2", "status", "a2", "e2", "a1", "n_halo", "n_send", "recv_counts", "send_counts",
-                 "send_idx", "send_slot", "ho_deg", "succ")
+                 "row_of", "send_slot", "ho_deg", "succ")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -785,8 +785,9 @@ def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
                          rank: int, delta, weight: torch.Tensor | None = None) -> "DeBruijn2Part | None":
     """The order-2 builder for the rank that owns the nodes ``[node_lo, node_hi)`` of a partitioned stream: ``edge_index`` / ``time`` hold the
     (time-sorted) events that start or end in that range.  Everything :func:`debruijn2` counts, restricted to the owned middle nodes, plus the
-    halo numbering (sources (a, b) with a foreign a, in (owner of a, b, a) order behind the owned rows) and the send lists (owned rows (b, c)
-    whose c another rank owns, grouped by that rank, ordered by (c, b) = the receiver's halo order).  ONE read-back.  ``None``: empty shard
+    halo numbering (sources (a, b) with a foreign a, in (owner of a, b, a) order behind the owned rows) and the LOCAL ROW ORDER: owned rows (b, c)
+    whose c another rank owns come first, grouped by that rank, ordered by (c, b) = the receiver's halo order — the send list of every exchange
+    is the prefix ``[0, n_send)`` of a row matrix; ``row_of[local row]`` = lexicographic row.  ONE read-back.  ``None``: empty shard
     inputs the builder does not take (the caller falls back); ``status`` bit 2 set: a node with more than 64 in- / out-events."""
     ei = _edge_index(edge_index)
     dev = require_device(ei, time, weight, cuts_dev)
@@ -811,12 +812,12 @@ def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
         ws = _workspace(L.pp_debruijn2_ws_bytes(m, n), dev)
         bufs = {"fo_bwd_ptr": torch.empty(n_own + 1, **i32), "fo_fwd_ptr": torch.empty(n_own + 1, **i32), "fo_bwd_idx": torch.empty(cap, **i32),
                 "fo_w": torch.empty(cap, **f32), "ho_fwd_ptr": torch.empty(cap + 1, **i32), "ho_bwd_ptr": torch.empty(cap + 1, **i32),
-                "ho_deg": torch.empty(cap, **f32), "fo_deg": torch.empty(max(n, 1), **f32), "send_idx": torch.empty(cap, **i32),
+                "ho_deg": torch.empty(cap, **f32), "fo_deg": torch.empty(max(n, 1), **f32), "row_of": torch.empty(cap, **i32),
                 "send_slot": torch.empty(cap, **i32)}
         tcode = _DTYPE_CODE[time.dtype]
         check(L.pp_debruijn2_part_count(_p(ei), _p(time), tcode, m, n, int(node_lo), n_own, _p(cuts_dev), world, int(rank), kind, di, df, _p(weight),
                                         _p(bufs["fo_bwd_ptr"]), _p(bufs["fo_bwd_idx"]), _p(bufs["fo_w"]), _p(bufs["fo_fwd_ptr"]), _p(bufs["ho_fwd_ptr"]),
-                                        _p(bufs["ho_bwd_ptr"]), _p(bufs["ho_deg"]), _p(bufs["fo_deg"]), _p(bufs["send_idx"]), _p(bufs["send_slot"]),
+                                        _p(bufs["ho_bwd_ptr"]), _p(bufs["ho_deg"]), _p(bufs["fo_deg"]), _p(bufs["send_slot"]), _p(bufs["row_of"]),
                                         _p(ws), ws.numel(), _stream()), "pp_debruijn2_part_count")
         head = ws[: 8 * (8 + 2 * (world + 1))].view(torch.int64).tolist()                 # the ONE read-back of this rank's graph construction
     u2, status, a2, e2, a1, n_halo, n_send = head[:7]
@@ -826,7 +827,7 @@ def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
         raise ValueError("lift_order_temporal: the events are not sorted by time")
     return DeBruijn2Part(m=m, n=n, lo=int(node_lo), n_own=n_own, world=world, args=(tcode, kind, di, df, weight), ws=ws, bufs=bufs, u2=u2, status=status,
                          a2=a2, e2=e2, a1=a1, n_halo=n_halo, n_send=n_send, recv_counts=[recv_ptr[r + 1] - recv_ptr[r] for r in range(world)],
-                         send_counts=[send_ptr[r + 1] - send_ptr[r] for r in range(world)], send_idx=bufs["send_idx"][:n_send],
+                         send_counts=[send_ptr[r + 1] - send_ptr[r] for r in range(world)], row_of=bufs["row_of"][:u2],
                          send_slot=bufs["send_slot"][:u2], ho_deg=bufs["ho_deg"], succ=bufs["fo_bwd_idx"][:u2])
 
 
@@ -855,7 +856,7 @@ def debruijn2_part_fill(c: DeBruijn2Part):
 
 
 def spmm(ptr, idx, val, n_rows: int, x: torch.Tensor, self_coef=None, s=None, bias=None, act: bool = False,
-         heavy: HeavyRows | None = None) -> torch.Tensor:
+         heavy: HeavyRows | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
     """Y[r] = act(sum_p val[p] * x[idx[p]] + self_coef[r] * s[r] + bias) — fp32, rows of width F.  ``heavy``: the hub rows of this
     CSR (``plan.fwd_heavy`` / ``plan.bwd_heavy``), summed by the chunked pre-pass."""
     dev = require_device(x, s, bias)
@@ -866,14 +867,17 @@ def spmm(ptr, idx, val, n_rows: int, x: torch.Tensor, self_coef=None, s=None, bi
     if f > 256:          # the row kernels own at most 64 lanes x 4 columns per row: wider matrices go through in 256-column blocks
         blocks = [spmm(ptr, idx, val, n_rows, x[:, c: c + 256], self_coef, None if s is None else s[:, c: c + 256],
                        None if bias is None else bias[c: c + 256], act, heavy) for c in range(0, f, 256)]
-        return torch.cat(blocks, dim=1)
+        y = torch.cat(blocks, dim=1)
+        return y if out is None else out.copy_(y)
     if s is not None:
         s = s.contiguous()
     if bias is not None:
         bias = bias.contiguous()
     slot, sums = _heavy_args(heavy, idx, val, x)
     with torch.cuda.device(dev):
-        y = torch.empty((n_rows, f), dtype=torch.float32, device=dev)
+        y = torch.empty((n_rows, f), dtype=torch.float32, device=dev) if out is None else out
+        if out is not None and (tuple(out.shape) != (n_rows, f) or out.dtype != torch.float32 or not out.is_contiguous()):
+            raise ValueError("spmm: out must be a contiguous fp32 [n_rows, F] tensor")
         check(lib().pp_spmm_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(x), f, _p(self_coef), _p(s), _p(bias), 1 if act else 0,
                                 _p(slot), _p(sums), _p(y), _stream()), "pp_spmm_f32")
     return y
@@ -970,6 +974,14 @@ def halo_fold(own: torch.Tensor, recv: torch.Tensor | None = None, slot: torch.T
         check(lib().pp_halo_fold_f32(_p(own), _p(recv), _p(slot), _p(extra), _p(self_coef), _p(dpre), own.size(0), own.size(1), _p(out), _stream()),
               "pp_halo_fold_f32")
     return out
+
+
+def gather_rows(x: torch.Tensor, rows: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``x[rows]`` for an fp32 matrix whose width is a multiple of 4 (pp_spmm_f32 with one unit entry per output row)."""
+    rows32 = rows.to(torch.int32).contiguous()
+    n = int(rows32.numel())
+    ptr = torch.arange(n + 1, dtype=torch.int32, device=rows32.device)
+    return spmm(ptr, rows32, None, n, x, out=out)
 
 
 def scale_rows(x: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:

@@ -243,16 +243,35 @@ __global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, int64_t lo, const
     }
 }
 
-// per list position: the (time, order-2 node, source) record the head-side gather reads; per successor run: the first-order edge
-__global__ __launch_bounds__(kBlock) void k_db2_out_fill(int64_t m, int64_t lo, int64_t n_own, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tkeys_s,
-                                                        const uint64_t* __restrict__ ot_t, const uint8_t* __restrict__ ocr_t,
-                                                        const uint32_t* __restrict__ oc_s, const float* __restrict__ ow_s,
-                                                        const uint8_t* __restrict__ ocr_s, const int32_t* __restrict__ row_ptr,
-                                                        Db2Src* __restrict__ src_t, int32_t* __restrict__ fo_bwd_idx, float* __restrict__ fo_w) {
+// per successor run: the first-order edge (destination + weight per order-2 node, in lexicographic row order)
+__global__ __launch_bounds__(kBlock) void k_db2_out_heads(int64_t m, int64_t lo, int64_t n_own, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tkeys_s,
+                                                         const uint32_t* __restrict__ oc_s, const float* __restrict__ ow_s,
+                                                         const uint8_t* __restrict__ ocr_s, const int32_t* __restrict__ row_ptr,
+                                                         int32_t* __restrict__ fo_bwd_idx, float* __restrict__ fo_w) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= m) return;
     const uint32_t b = tkeys_s[p];
+    const int64_t bl = (int64_t)b - lo;
+    if (bl < 0 || bl >= n_own) return;
     const uint32_t p0 = tp[b];
+    if (tp[b + 1] - p0 > (uint32_t)kWave) return;              // (overflow node: the caller falls back)
+    const uint8_t cr = ocr_s[p];
+    if (p == p0 || ocr_s[p - 1] != cr) {
+        const uint32_t u = (uint32_t)row_ptr[bl] + cr;
+        fo_bwd_idx[u] = (int32_t)oc_s[p];
+        fo_w[u] = ow_s[p];
+    }
+}
+
+// per list position: the (time, order-2 node, source) record the head-side gather reads.  `perm` (partition shards): local id of every
+// lexicographic row — rows other ranks gather from come first, grouped by that rank (k_db2_apply_perm)
+__global__ __launch_bounds__(kBlock) void k_db2_out_fill(int64_t m, int64_t lo, int64_t n_own, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tkeys_s,
+                                                        const uint64_t* __restrict__ ot_t, const uint8_t* __restrict__ ocr_t,
+                                                        const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ perm,
+                                                        Db2Src* __restrict__ src_t) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m) return;
+    const uint32_t b = tkeys_s[p];
     Db2Src r;
     r.t = ot_t[p];
     r.a = b;
@@ -260,14 +279,9 @@ __global__ __launch_bounds__(kBlock) void k_db2_out_fill(int64_t m, int64_t lo, 
     const int64_t bl = (int64_t)b - lo;
     if (bl < 0 || bl >= n_own) {
         r.u = kDb2Foreign;
-    } else if (tp[b + 1] - p0 <= (uint32_t)kWave) {            // (else an overflow node: its events keep the id 0xFFFFFFFF, the caller falls back)
-        const uint32_t row0 = (uint32_t)row_ptr[bl];
-        r.u = row0 + ocr_t[p];
-        const uint8_t cr = ocr_s[p];
-        if (p == p0 || ocr_s[p - 1] != cr) {
-            fo_bwd_idx[row0 + cr] = (int32_t)oc_s[p];
-            fo_w[row0 + cr] = ow_s[p];
-        }
+    } else if (tp[b + 1] - tp[b] <= (uint32_t)kWave) {         // (else an overflow node: its events keep the id 0xFFFFFFFF, the caller falls back)
+        const uint32_t row = (uint32_t)row_ptr[bl] + ocr_t[p];
+        r.u = perm ? (uint32_t)perm[row] : row;
     }
     src_t[p] = r;
 }
@@ -298,6 +312,7 @@ struct Db2Mid {
     const uint64_t* ot_s;            // out-events in (successor, time) order: time, successor rank
     const uint8_t* ocr_s;
     const int32_t* row_ptr;
+    const int32_t* perm;             // partition shards: local id of the lexicographic row (nullptr: the identity)
     // in-events in (source, time) order
     const uint64_t* is_t;
     const uint32_t *is_a, *is_u;
@@ -326,6 +341,7 @@ struct Db2MidIn {
     float wi, du, da;
     int32_t ob;
     int32_t row0;
+    int32_t rid;               // local id of the row with successor rank l (lane l)
     float rdeg, rlw;           // fill: per successor RANK (lane r = row row0 + r): weighted degree, self-loop weight, row start
     int32_t rip;
     float d1, lw1;
@@ -363,6 +379,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
         const bool lo_ = fits && l < in[s].no, li = fits && l < in[s].ni;
         in[s].tj = lo_ ? a.ot_s[in[s].p0 + l] : 0ull;
         in[s].cr = lo_ ? (int)a.ocr_s[in[s].p0 + l] : 255;
+        in[s].rid = (lo_ && a.perm) ? a.perm[in[s].row0 + l] : in[s].row0 + l;      // (at most `no` successor rows: a row beyond the node's block is never used)
         in[s].ti = li ? a.is_t[in[s].q0 + l] : 0ull;
         in[s].ia = li ? a.is_a[in[s].q0 + l] : 0xFFFFFFFFu;
         in[s].iu = li ? a.is_u[in[s].q0 + l] : 0xFFFFFFFFu;
@@ -371,10 +388,15 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
             in[s].du = li ? a.du_s[in[s].q0 + l] : 0.0f;
             in[s].da = li ? a.da_s[in[s].q0 + l] : 0.0f;
             in[s].ob = li ? a.ob_s[in[s].q0 + l] : 0;
-            // (at most `no` successor rows: lane r reads row row0 + r; a row beyond the node's block is never used)
-            in[s].rdeg = lo_ ? a.ho_deg[in[s].row0 + l] : 1.0f;
-            in[s].rlw = lo_ ? a.ho_lw[in[s].row0 + l] : 1.0f;
-            in[s].rip = lo_ ? a.ho_fwd_ptr[in[s].row0 + l] : 0;
+        }
+    }
+    if (kFill) {
+#pragma unroll
+        for (int s = 0; s < kDb2Nodes; ++s) {
+            const bool lo_ = in[s].no <= kWave && in[s].ni <= kWave && l < in[s].no;
+            in[s].rdeg = lo_ ? a.ho_deg[in[s].rid] : 1.0f;
+            in[s].rlw = lo_ ? a.ho_lw[in[s].rid] : 1.0f;
+            in[s].rip = lo_ ? a.ho_fwd_ptr[in[s].rid] : 0;
         }
     }
 #pragma unroll
@@ -400,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
         const uint64_t olater = ohm & ~lanes_upto(l);
         const int oend = olater ? __ffsll((long long)olater) - 1 : no;
         const uint64_t myrun = ohead ? ((oend >= kWave ? ~0ull : lanes_below(oend)) & ~lanes_below(l)) : 0ull;
-        const uint32_t v = (uint32_t)in[s].row0 + (uint32_t)(ohead ? cr : 0);
+        const uint32_t v = (uint32_t)lane_read_i((ohead ? cr : l) << 2, in[s].rid);       // local id of this run's row (lane cr holds the row of rank cr)
         // ---- in side: lanes in (source node, time) order
         const bool li = l < ni;
         const uint32_t sa = in[s].ia, su = in[s].iu;
@@ -563,12 +585,22 @@ __global__ void k_db2_publish(int64_t m, const uint32_t* __restrict__ halo_keys_
     if (r == world) { result[5] = hpos; result[6] = spos; }
 }
 
-// send_slot[row] = position of an owned row in the send list (-1: no peer gathers from it)
-__global__ __launch_bounds__(kBlock) void k_db2_send_slots(int64_t m, const uint32_t* __restrict__ send_keys_s, const int32_t* __restrict__ send_idx,
-                                                          int64_t num_nodes, int32_t* __restrict__ send_slot) {
+// The sorted send keys define the LOCAL ROW ORDER of a partition shard: rows other ranks gather from come first, grouped by that rank and
+// ordered by (head node, source node) — the send list of every layer exchange is the contiguous prefix [0, rows sent) of every row matrix,
+// no pack; rows nobody gathers from follow.  perm[lexicographic row] = local row; the first-order edge list moves to the local order;
+// send_slot[local row] = the row itself inside the prefix, -1 behind it.
+__global__ __launch_bounds__(kBlock) void k_db2_apply_perm(int64_t m, const int64_t* __restrict__ result, const uint32_t* __restrict__ send_keys_s,
+                                                          const uint32_t* __restrict__ order, int64_t num_nodes, const int32_t* __restrict__ succ_old,
+                                                          const float* __restrict__ w_old, int32_t* __restrict__ perm, int32_t* __restrict__ fo_bwd_idx,
+                                                          float* __restrict__ fo_w, int32_t* __restrict__ send_slot, int32_t* __restrict__ row_of) {
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= m || send_keys_s[k] >= (uint32_t)num_nodes) return;
-    send_slot[send_idx[k]] = (int32_t)k;
+    if (k >= m || k >= result[0]) return;
+    const uint32_t old = order[k];
+    perm[old] = (int32_t)k;
+    row_of[k] = (int32_t)old;
+    fo_bwd_idx[k] = succ_old[old];
+    fo_w[k] = w_old[old];
+    send_slot[k] = send_keys_s[k] < (uint32_t)num_nodes ? (int32_t)k : -1;
 }
 
 // ------------------------------------------------------------------ workspace
@@ -578,6 +610,8 @@ constexpr int kDb2Result = 8 + 2 * (kDb2MaxWorld + 1) + 6;
 struct Db2Ws {
     int64_t* result;         // [kDb2Result]: {U2, status, A2, E2, A1 (first-order in-edges), halo rows, rows sent, -, recv_ptr[world+1], send_ptr[world+1]}
     uint32_t *xkeys, *xkeys_s, *xorder;      // partition shards: halo / send-list sort keys
+    int32_t *perm, *succ_old;
+    float* w_old;
     uint32_t *tkeys, *tkeys_s, *hkeys_s, *tl, *hl, *tp, *hp;
     Db2Rec* rec;
     Db2Src* src_t;
@@ -604,6 +638,9 @@ static Db2Ws carve_db2(void* ws, int64_t m, int64_t n) {
     w.xkeys = a.take<uint32_t>(m);
     w.xkeys_s = a.take<uint32_t>(m);
     w.xorder = a.take<uint32_t>(m);
+    w.perm = a.take<int32_t>(m);
+    w.succ_old = a.take<int32_t>(m);
+    w.w_old = a.take<float>(m);
     w.tkeys = a.take<uint32_t>(m);
     w.tkeys_s = a.take<uint32_t>(m);
     w.hkeys_s = a.take<uint32_t>(m);
@@ -682,7 +719,7 @@ struct Db2Part {                   // node range of a partition shard (one GPU: 
     int64_t lo, n_own;
     const int64_t* cuts;           // device int64 [world + 1]: node ranges of all ranks
     int world, me;
-    int32_t *send_idx, *send_slot; // [m] each
+    int32_t *send_slot, *row_of;   // [m] each: local row -> its position in the send prefix (-1 behind it) / its lexicographic row
 };
 
 static int db2_count(const char* who, const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t n, const Db2Part& pt, int delta_kind,
@@ -728,22 +765,31 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
     PP_LAUNCH_CHECK();
     rc = exclusive_scan<int32_t, int32_t>(w.blk, n_own, fo_bwd_ptr, true, w.result, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
-    k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, w.src_t, fo_bwd_idx, fo_w);
+    const int32_t* perm = nullptr;
+    if (!part) {
+        k_db2_out_heads<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, fo_bwd_idx, fo_w);
+        PP_LAUNCH_CHECK();
+    } else {
+        // 2b. local row order = send order (who gathers from my rows), one node-id sort of the successors
+        k_db2_out_heads<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, w.succ_old, w.w_old);
+        PP_LAUNCH_CHECK();
+        k_db2_send_keys<<<egrid, kBlock, 0, st>>>(m, w.result, w.succ_old, pt.lo, n_own, n, w.xkeys);
+        PP_LAUNCH_CHECK();
+        rc = sort_pairs<uint32_t>(w.xkeys, nullptr, w.xkeys_s, w.xorder, m, 0, bits_for((uint64_t)n), w.scratch, w.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+        PP_HIP(hipMemsetAsync(w.perm, 0, (size_t)m * sizeof(int32_t), st));      // (lanes beyond a node's block read perm[row0 + l]: any valid row will do)
+        k_db2_apply_perm<<<egrid, kBlock, 0, st>>>(m, w.result, w.xkeys_s, w.xorder, n, w.succ_old, w.w_old, w.perm, fo_bwd_idx, fo_w, pt.send_slot, pt.row_of);
+        PP_LAUNCH_CHECK();
+        perm = w.perm;
+    }
+    k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, fo_bwd_ptr, perm, w.src_t);
     PP_LAUNCH_CHECK();
     k_db2_gather_in<<<egrid, kBlock, 0, st>>>(m, w.hl, w.src_t, weight ? w.ow_t : nullptr, w.is_t, w.is_a, w.is_u, w.is_w);
     PP_LAUNCH_CHECK();
     if (part) {
-        // 2b. send lists (who gathers from my rows) and halo numbering (whose rows I gather from), one 8-bit / one node-id sort each
-        const int nbits = bits_for((uint64_t)n);
-        k_db2_send_keys<<<egrid, kBlock, 0, st>>>(m, w.result, fo_bwd_idx, pt.lo, n_own, n, w.xkeys);
-        PP_LAUNCH_CHECK();
-        rc = sort_pairs<uint32_t>(w.xkeys, nullptr, w.xkeys_s, (uint32_t*)pt.send_idx, m, 0, nbits, w.scratch, w.scratch_bytes, st);
-        if (rc != PP_OK) return rc;
-        PP_HIP(hipMemsetAsync(pt.send_slot, 0xFF, (size_t)m * sizeof(int32_t), st));
-        k_db2_send_slots<<<egrid, kBlock, 0, st>>>(m, w.xkeys_s, pt.send_idx, n, pt.send_slot);
-        PP_LAUNCH_CHECK();
-        uint32_t* hkeys = w.xkeys;                       // (the send keys are sorted: their buffer is free)
-        uint32_t* hkeys_sorted = (uint32_t*)w.du_s;      // (fill-pass scratch, unused until then)
+        // 2c. halo numbering (whose rows I gather from): one 8-bit sort of the in-event positions by owner
+        uint32_t* hkeys = (uint32_t*)w.da_s;             // (fill-pass scratch, unused until then)
+        uint32_t* hkeys_sorted = (uint32_t*)w.du_s;
         k_db2_halo_keys<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.hkeys_s, w.hp, w.is_a, w.is_u, pt.cuts, pt.world, hkeys);
         PP_LAUNCH_CHECK();
         rc = sort_pairs<uint32_t>(hkeys, nullptr, hkeys_sorted, w.xorder, m, 0, bits_for((uint64_t)pt.world), w.scratch, w.scratch_bytes, st);
@@ -758,7 +804,7 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
     PP_HIP(hipMemsetAsync(w.outdeg2, 0, (size_t)m * sizeof(int32_t), st));
     Db2Mid a{};
     mid_common(a, w, fo_bwd_ptr, weight != nullptr);
-    a.lo = pt.lo; a.part = part ? 1 : 0;
+    a.lo = pt.lo; a.part = part ? 1 : 0; a.perm = perm;
     a.indeg2 = w.indeg2; a.outdeg2 = w.outdeg2; a.ho_deg = ho_deg; a.fo_deg = fo_deg;
     a.nu = w.nu; a.pc = w.pc; a.status = w.result + 1;
     rc = launch_mid_any<false>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n_own, delta_i, delta_f, a);
@@ -791,7 +837,7 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
     PP_LAUNCH_CHECK();
     Db2Mid a{};
     mid_common(a, w, fo_bwd_ptr, weight != nullptr);
-    a.lo = lo; a.part = part ? 1 : 0;
+    a.lo = lo; a.part = part ? 1 : 0; a.perm = part ? w.perm : nullptr;
     a.ho_deg = const_cast<float*>(ho_deg); a.fo_deg = const_cast<float*>(fo_deg);
     a.du_s = w.du_s; a.da_s = w.da_s; a.ob_s = w.ob_s;
     a.ho_fwd_ptr = ho_fwd_ptr; a.fo_fwd_ptr = fo_fwd_ptr;
@@ -835,9 +881,9 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
 int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
                             const int64_t* cuts, int world, int rank, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
                             int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
-                            float* ho_deg, float* fo_deg, int32_t* send_idx, int32_t* send_slot, void* ws, size_t ws_bytes, pp_stream_t stream) {
-    PP_REQUIRE(world >= 2 && cuts != nullptr && send_idx != nullptr && send_slot != nullptr, PP_ERR_ARG, "pp_debruijn2_part_count: world >= 2 with cuts and send buffers");
-    const Db2Part pt{node_lo, n_own, cuts, world, rank, send_idx, send_slot};
+                            float* ho_deg, float* fo_deg, int32_t* send_slot, int32_t* row_of, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    PP_REQUIRE(world >= 2 && cuts != nullptr && send_slot != nullptr && row_of != nullptr, PP_ERR_ARG, "pp_debruijn2_part_count: world >= 2 with cuts and the send_slot / row_of buffers");
+    const Db2Part pt{node_lo, n_own, cuts, world, rank, send_slot, row_of};
     return db2_count("pp_debruijn2_part_count", edge_index, time, time_dtype, m, num_nodes, pt, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr,
                      fo_bwd_idx, fo_w, fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -1092,15 +1092,27 @@ def distribute_stream_by_node(g, delta, comm: Comm, ops=None, weight: str = "edg
     return shard
 
 
-def _own_rows_buffer(source, lo: int, hi: int, n_halo: int, device) -> torch.Tensor:
-    """``[n_own + n_halo, F]`` with the owned rows ``lo .. hi`` of a feature source in front (the halo rows arrive by exchange).  A resident row
-    store (``own_buffer``) keeps that buffer placed between steps."""
-    fetch = getattr(source, "own_buffer", None)
+def _own_rows_buffer(source, lo: int, hi: int, row_of: torch.Tensor, n_halo: int, device) -> torch.Tensor:
+    """``[n_own + n_halo, F]``: the rows ``lo + row_of`` of a feature source in front (the owned rows of a partition shard in its LOCAL row
+    order), room for the halo rows (which arrive by exchange) behind them.  Row loaders are asked for exactly those rows; matrices go through
+    the row-gather kernel; a resident row store may offer ``rows_buffer(lo, hi, row_of, n_halo)`` itself."""
+    fetch = getattr(source, "rows_buffer", None)
     if fetch is not None:
-        return fetch(lo, hi, n_halo)
-    own = _rows_of(source, None, lo, hi, device)
-    buf = torch.empty((hi - lo + n_halo, own.size(1)), dtype=own.dtype, device=own.device)
-    buf[: hi - lo] = own
+        return fetch(lo, hi, row_of, n_halo)
+    n_own = hi - lo
+    if callable(source):
+        own = source(row_of.to(torch.int64) + lo)
+        buf = torch.empty((n_own + n_halo, own.size(1)), dtype=own.dtype, device=own.device)
+        buf[:n_own] = own
+        return buf
+    part = source[lo:hi]
+    buf = torch.empty((n_own + n_halo, part.size(1)), dtype=part.dtype, device=part.device)
+    if n_own:
+        if part.is_cuda and part.dtype == torch.float32 and part.size(1) % 4 == 0:
+            from . import _hip
+            _hip.gather_rows(part.contiguous(), row_of, out=buf[:n_own])
+        else:
+            torch.index_select(part, 0, row_of.to(torch.int64), out=buf[:n_own])
     return buf
 
 
@@ -1135,21 +1147,21 @@ def _build_partitioned_by_node(g, delta, x, x_h, y, comm: Comm, ops, weight: str
     # input features of the halo rows travel under the rest of the build; the halo rows' degrees are needed by the fill pass
     if callable(x_h) and _takes_count(x_h):
         x_h = x_h(n_ho)
-    xh_buf = _own_rows_buffer(x_h, lo_h, hi_h, n_halo, dev)
-    send_idx = c.send_idx
-    xh_pending = comm.exchange_rows_async(xh_buf[:n_own].index_select(0, send_idx), c.send_counts, c.recv_counts, out=xh_buf[n_own: n_own + n_halo])
-    comm.exchange_rows(c.ho_deg[:n_own].index_select(0, send_idx), c.send_counts, c.recv_counts, out=c.ho_deg[n_own: n_own + n_halo])
+    xh_buf = _own_rows_buffer(x_h, lo_h, hi_h, c.row_of, n_halo, dev)          # (owned rows in the shard's local order = send order: no pack below)
+    xh_pending = comm.exchange_rows_async(xh_buf[: c.n_send], c.send_counts, c.recv_counts, out=xh_buf[n_own: n_own + n_halo])
+    comm.exchange_rows(c.ho_deg[: c.n_send], c.send_counts, c.recv_counts, out=c.ho_deg[n_own: n_own + n_halo])
     comm.mark("build: 2 halo exchanges (degrees; feature rows asynchronously)")
     ho_plan, (fo_src, fo_dst, fo_w), indeg = ops.debruijn2_part_fill(c)
     comm.mark("build: 3 order-2 builder, fill pass")
 
+    own_ids = c.row_of.to(torch.int64) + lo_h                                   # global ids of the owned rows, local order
+
     def fetch_halo_ids():
-        ids = comm.exchange_rows(send_idx.to(torch.int64) + lo_h, c.send_counts, c.recv_counts)
-        return ids
+        return comm.exchange_rows(own_ids[: c.n_send].contiguous(), c.send_counts, c.recv_counts)
 
     ho = GraphShard(lo=lo_h, hi=hi_h, n_own=n_own, n_halo=n_halo, n_src=n_own + n_halo, num_nodes=n_ho, cuts=ho_cuts, plan=ho_plan, halo_ids=None,
-                    send_idx=send_idx, send_counts=c.send_counts, recv_counts=c.recv_counts, send_unique=True, send_slot=c.send_slot,
-                    halo_fetch=fetch_halo_ids)
+                    send_idx=None, send_counts=c.send_counts, recv_counts=c.recv_counts, send_unique=True, send_slot=c.send_slot,
+                    halo_fetch=fetch_halo_ids, send_prefix=c.n_send, own_ids=own_ids)
     pending = []
     # first-order graph: the in-edges of my nodes; every foreign node is a halo row (an all-gather per layer), normalised by the generic plan
     fo_shard = build_graph_shard(fo_src.to(torch.int64), fo_dst.to(torch.int64), fo_w, n, fo_cuts, comm, ops, False, pending, dense_halo=True)

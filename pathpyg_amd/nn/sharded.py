@@ -168,11 +168,13 @@ class HipOps:
 
     @staticmethod
     def spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum, drop=None):
-        if d.size(1) % 4 == 0 and d.size(1) <= 256:
+        """``drop = (p, seed, tag, row0[, rows])``: ``rows`` = explicit global row ids (shards whose local row order is not the global one)."""
+        rows = drop[4] if (drop is not None and len(drop) > 4) else None
+        if d.size(1) % 4 == 0 and d.size(1) <= 256 and rows is None:
             return _hip.spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum, drop)
-        g = _hip.spmm(ptr, idx, val, n_rows, d)                                                                          # odd widths: two kernels
+        g = _hip.spmm(ptr, idx, val, n_rows, d)                                                                          # odd widths / explicit rows: two kernels
         if drop is not None:
-            return _hip.dropout_act_backward(g, z, drop[0], drop[1], drop[2], drop[3], None, True, want_colsum)
+            return _hip.dropout_act_backward(g, z, drop[0], drop[1], drop[2], 0 if rows is not None else drop[3], rows, True, want_colsum)
         return _hip.act_backward(g, z, True, want_dpre=True, want_dbias=want_colsum)
 
     # ---- dense layers of the head (first-order rows only) and the loss
@@ -220,7 +222,7 @@ class GraphShard:
     ``send_slot`` (``send_unique`` shards): int32 ``[n_own]``, the position of an owned row in the send list or -1 — the inverse of ``send_idx``."""
 
     __slots__ = ("lo", "hi", "n_own", "n_halo", "n_src", "num_nodes", "cuts", "plan", "halo_ids", "send_idx", "send_counts", "recv_counts",
-                 "back_ptr", "back_idx", "send_unique", "send_slot", "halo_fetch", "dense")
+                 "back_ptr", "back_idx", "send_unique", "send_slot", "halo_fetch", "dense", "send_prefix", "own_ids")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -228,14 +230,23 @@ class GraphShard:
 
     @property
     def n_send(self) -> int:
+        if self.send_prefix is not None:
+            return int(self.send_prefix)
         return 0 if self.send_idx is None else int(self.send_idx.numel())
+
+    def send_rows(self, buf: torch.Tensor) -> torch.Tensor:
+        """The rows of ``buf[:n_own]`` the peers gather from, grouped by peer.  Shards of the node-by-node builder number their rows in send
+        order (``send_prefix`` = rows sent): the send list is a VIEW of the first rows, no pack."""
+        if self.send_prefix is not None:
+            return buf[: self.send_prefix]
+        return buf[: self.n_own].index_select(0, self.send_idx)
 
     def local_rows(self) -> torch.Tensor:
         """Global ids of the local source space ``[owned | halo]`` (int64).  Shards of the node-by-node builder never exchange ids: the halo
         ids are fetched on first use (``halo_fetch``: one exchange of 8 bytes per halo row — a COLLECTIVE, every rank calls it alike)."""
         if self.halo_ids is None and self.halo_fetch is not None:
             self.halo_ids = self.halo_fetch()
-        own = torch.arange(self.lo, self.hi, device=self.plan.fwd_ptr.device)
+        own = torch.arange(self.lo, self.hi, device=self.plan.fwd_ptr.device) if self.own_ids is None else self.own_ids
         return own if self.n_halo == 0 else torch.cat((own, self.halo_ids))
 
 
@@ -270,8 +281,7 @@ def halo_fill_async(shard: GraphShard, comm, buf: torch.Tensor):
         if shard.n_own != cap:
             own = F.pad(own, (0, 0, 0, cap - shard.n_own))
         return _DenseHalo(shard, comm.all_gather_rows_async(own), buf)
-    send = buf[: shard.n_own].index_select(0, shard.send_idx)
-    return comm.exchange_rows_async(send, shard.send_counts, shard.recv_counts, out=buf[shard.n_own:])
+    return comm.exchange_rows_async(shard.send_rows(buf), shard.send_counts, shard.recv_counts, out=buf[shard.n_own:])
 
 
 def halo_fill(shard: GraphShard, comm, buf: torch.Tensor) -> None:
@@ -281,8 +291,7 @@ def halo_fill(shard: GraphShard, comm, buf: torch.Tensor) -> None:
     if getattr(shard, "dense", False):
         halo_fill_async(shard, comm, buf).wait()
         return
-    send = buf[: shard.n_own].index_select(0, shard.send_idx)
-    comm.exchange_rows(send, shard.send_counts, shard.recv_counts, out=buf[shard.n_own:])
+    comm.exchange_rows(shard.send_rows(buf), shard.send_counts, shard.recv_counts, out=buf[shard.n_own:])
 
 
 def halo_reduce(shard: GraphShard, comm, ops, d_halo: torch.Tensor, d_own: torch.Tensor | None = None):
@@ -294,6 +303,13 @@ def halo_reduce(shard: GraphShard, comm, ops, d_halo: torch.Tensor, d_own: torch
     if recv.size(0) == 0:
         return None
     if shard.send_unique:
+        if shard.send_prefix is not None:          # rows in send order: the returned rows line up with the first rows
+            if d_own is not None:
+                d_own[: shard.send_prefix] += recv
+                return None
+            out = torch.zeros((shard.n_own, recv.size(1)), dtype=recv.dtype, device=recv.device)
+            out[: shard.send_prefix] = recv
+            return out
         if d_own is not None:
             d_own.index_add_(0, shard.send_idx, recv)
             return None
@@ -332,9 +348,10 @@ class _ShardedGcnStack(torch.autograd.Function):
         plan, n_own = shard.plan, shard.n_own
         inputs, saved = [], []
         h = x_full
+        own_rows = getattr(shard, "own_ids", None)          # shards numbered in send order: masks by explicit global row ids, one extra pass
         if drop is not None:
             p_drop, seed, tag, out_tag = drop
-            h = ops.dropout(x_full, p_drop, seed, tag, 0, shard.local_rows() if shard.n_halo or shard.lo else None)
+            h = ops.dropout(x_full, p_drop, seed, tag, 0, shard.local_rows() if (shard.n_halo or shard.lo or own_rows is not None) else None)
         for layer in range(n_layers):
             weight, bias = params[2 * layer], params[2 * layer + 1]
             last = layer == n_layers - 1
@@ -344,7 +361,9 @@ class _ShardedGcnStack(torch.autograd.Function):
             site_out = None
             if drop is not None and (not last or out_tag is not None):      # (the last layer's output: the dropout in front of the bipartite layer)
                 site_out = (p_drop, seed, out_tag if last else tag + layer + 1, shard.lo)
-            saved.append(ops.layer_forward(plan, h, weight, bias, layer == 0, buf[:n_own], site_out))
+            saved.append(ops.layer_forward(plan, h, weight, bias, layer == 0, buf[:n_own], site_out if own_rows is None else None))
+            if site_out is not None and own_rows is not None:
+                ops.dropout(buf[:n_own], site_out[0], site_out[1], site_out[2], 0, own_rows, buf[:n_own])
             if not last:
                 halo_fill(shard, comm, buf)
             h = buf
@@ -382,7 +401,9 @@ class _ShardedGcnStack(torch.autograd.Function):
                     # (where the mask is 0 the gradient is 0 whatever ELU' says) — one pass (pp_dropout_act_backward_f32)
                     d_own = d_lin[:n_own] if extra is None else d_lin[:n_own] + extra
                     p_drop, seed, tag = ctx.drop[:3]
-                    d, colsum = ops.dropout_act_backward(d_own, x_in[:n_own], p_drop, seed, tag + layer, shard.lo, None, True, True)
+                    own_rows = getattr(shard, "own_ids", None)
+                    d, colsum = ops.dropout_act_backward(d_own, x_in[:n_own], p_drop, seed, tag + layer, 0 if own_rows is not None else shard.lo, own_rows,
+                                                         True, True)
             grads[2 * layer - 1] = colsum                      # bias gradient of the layer below
         ctx.inputs = ctx.saved = None
         return (None, None, None, None, None, *grads)
@@ -508,7 +529,9 @@ class _ShardedTrunk(torch.autograd.Function):
             recv = s["handle"].wait()
             own = d_lin[: gs.n_own]
             if recv.size(0):
-                if gs.send_unique:
+                if gs.send_unique and gs.send_prefix is not None:
+                    own[: gs.send_prefix] += recv
+                elif gs.send_unique:
                     own.index_add_(0, gs.send_idx, recv)
                 else:
                     own = own + ops.spmm(gs.back_ptr, gs.back_idx, None, gs.n_own, recv)
@@ -633,7 +656,8 @@ class ShardedDBGNN(torch.nn.Module):
             # both stacks hand their outputs over DROPPED (last layer's epilogue); what is left of those two sites is their backward: one
             # element-wise pass on the first-order rows, nothing on the higher-order ones (the bipartite backward kernel takes the mask)
             x = ops.drop_act(x, bias_fo, p, seed, TAG_FO_OUT, shard.fo.lo, True, True)
-            agg = _ShardedBipartite.apply(shard.bip, comm, ops, shard.cap, shard.fo.n_own, x_h, bias_ho, True, (p, seed, TAG_HO_OUT, shard.ho.lo))
+            ho_site = (p, seed, TAG_HO_OUT, shard.ho.lo) if getattr(shard.ho, "own_ids", None) is None else (p, seed, TAG_HO_OUT, 0, shard.ho.own_ids)
+            agg = _ShardedBipartite.apply(shard.bip, comm, ops, shard.cap, shard.fo.n_own, x_h, bias_ho, True, ho_site)
             per_edge = ops.dense(x, bl.lin2) + bl.lin1.bias
             x = F.elu(torch.addcmul(ops.dense_nobias(agg, bl.lin1.weight), shard.indeg.unsqueeze(1), per_edge))
             return ops.dense(ops.drop_act(x, None, p, seed, TAG_HEAD, shard.fo.lo, False), m.lin)

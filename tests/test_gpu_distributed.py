@@ -77,7 +77,7 @@ def _run_rank(rank, world, dev, comm, case):
     assert sz["U2"] == layers[2]["num_nodes"] and sz["A2"] == layers[2]["edge_index"].size(1)
     if case[0] in (9, 10):          # ~10 events per node: the node-by-node order-2 builder, at every world size (world > 1: node-range partition)
         assert shard.sizes.get("builder") == "fused" and sz["E2"] == int(_lifted_pairs(ei, t, case[2], case[3]))
-    if shard.ho.n_send:
+    if shard.ho.n_send and shard.ho.send_idx is not None:
         assert int(torch.bincount(shard.ho.send_idx).max()) == 1          # De Bruijn cuts: every row goes to at most one peer
     net = pp.nn.DBGNN(num_classes=3, num_features=(case[5], case[5]), hidden_dims=case[6]).to(dev)
     net.load_state_dict(params)
