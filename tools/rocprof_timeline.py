@@ -11,7 +11,8 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
 rows = db.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
-marks = [i for i, r in enumerate(rows) if "k_tail_keys" in r[0] or "k_db2_keys" in r[0]]
+marks = [i for i, r in enumerate(rows) if "k_db2_keys" in r[0]] or [i for i, r in enumerate(rows) if "k_tail_keys" in r[0]]
+# (steps of the fused builder start with k_db2_keys; the generic kernels' k_tail_keys only delimits runs made with --builder generic)
 a, b = marks[-back - 1], marks[-back]
 seg = rows[a:b]
 t0 = seg[0][1]
