@@ -121,18 +121,22 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
  * nobody gathers from follow.  fo_bwd_idx / fo_w are in that local order (fo_bwd_ptr stays lexicographic: block sizes per node);
  * send_slot [m]: local row -> its position in the prefix, -1 behind it; row_of [m]: local row -> lexicographic row (global id - first owned id).  The first 8 int64 of ws = {U2, status, A2, E2, A1, halo rows, rows sent, -}, then recv_ptr [world + 1] and
  * send_ptr [world + 1] (rows from / to every rank, as offsets).  Between count and fill the caller fetches ho_deg of its halo rows
- * (ho_deg[U2 ..]) from their owners.  Fill: the order-2 plan over the local source space [owned | halo] as in pp_debruijn2_fill, and the
- * first-order in-edges of the owned nodes as a raw list (fo_in_src, fo_in_dst: global node ids; fo_in_weight: merged weights), which go
- * through pp_gcn_plan_begin / _finish (their normalisation needs degrees of foreign nodes). */
+ * (ho_deg[U2 ..]) from their owners and all-gathers fo_deg (the count pass fills the owned entries of the [num_nodes] array).  Fill: the
+ * order-2 plan over the local source space [owned | halo] as in pp_debruijn2_fill, and the rank's FIRST-ORDER SHARD with a dense halo — local
+ * source space [owned | ids below node_lo | ids from node_lo + n_own on] (num_nodes rows): destination-major rows fo_fwd_ptr / fo_fwd_idx /
+ * fo_fwd_val / fo_self of the owned nodes, source-major rows fo_shard_bwd_ptr [num_nodes + 1] (count phase) / _idx / _val [A1] — the successor
+ * runs of ALL nodes that fall into the owned range (the out-lists of foreign nodes hold exactly their events into it). */
 int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
                             const int64_t* cuts, int world, int rank, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
                             int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
-                            float* ho_deg, float* fo_deg, int32_t* send_slot, int32_t* row_of, void* ws, size_t ws_bytes, pp_stream_t stream);
+                            float* ho_deg, float* fo_deg, int32_t* send_slot, int32_t* row_of, int32_t* fo_shard_bwd_ptr, void* ws, size_t ws_bytes,
+                            pp_stream_t stream);
 int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own, int delta_kind, int64_t delta_i, double delta_f,
                            const float* weight, const int32_t* fo_bwd_ptr, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr,
-                           const int32_t* ho_bwd_ptr, const float* ho_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val,
-                           int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_in_src, int32_t* fo_in_dst, float* fo_in_weight,
-                           void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream);
+                           const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx,
+                           float* ho_fwd_val, int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val,
+                           float* fo_self, const int32_t* fo_shard_bwd_ptr, int32_t* fo_shard_bwd_idx, float* fo_shard_bwd_val, void* pair_scratch,
+                           void* ws, size_t ws_bytes, pp_stream_t stream);
 
 /* ------------------------------------------------------------------ order lifts (pp_lift.hip) */
 

@@ -813,11 +813,11 @@ def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
         bufs = {"fo_bwd_ptr": torch.empty(n_own + 1, **i32), "fo_fwd_ptr": torch.empty(n_own + 1, **i32), "fo_bwd_idx": torch.empty(cap, **i32),
                 "fo_w": torch.empty(cap, **f32), "ho_fwd_ptr": torch.empty(cap + 1, **i32), "ho_bwd_ptr": torch.empty(cap + 1, **i32),
                 "ho_deg": torch.empty(cap, **f32), "fo_deg": torch.empty(max(n, 1), **f32), "row_of": torch.empty(cap, **i32),
-                "send_slot": torch.empty(cap, **i32)}
+                "send_slot": torch.empty(cap, **i32), "fo_shard_bwd_ptr": torch.empty(n + 1, **i32)}
         tcode = _DTYPE_CODE[time.dtype]
         check(L.pp_debruijn2_part_count(_p(ei), _p(time), tcode, m, n, int(node_lo), n_own, _p(cuts_dev), world, int(rank), kind, di, df, _p(weight),
                                         _p(bufs["fo_bwd_ptr"]), _p(bufs["fo_bwd_idx"]), _p(bufs["fo_w"]), _p(bufs["fo_fwd_ptr"]), _p(bufs["ho_fwd_ptr"]),
-                                        _p(bufs["ho_bwd_ptr"]), _p(bufs["ho_deg"]), _p(bufs["fo_deg"]), _p(bufs["send_slot"]), _p(bufs["row_of"]),
+                                        _p(bufs["ho_bwd_ptr"]), _p(bufs["ho_deg"]), _p(bufs["fo_deg"]), _p(bufs["send_slot"]), _p(bufs["row_of"]), _p(bufs["fo_shard_bwd_ptr"]),
                                         _p(ws), ws.numel(), _stream()), "pp_debruijn2_part_count")
         head = ws[: 8 * (8 + 2 * (world + 1))].view(torch.int64).tolist()                 # the ONE read-back of this rank's graph construction
     u2, status, a2, e2, a1, n_halo, n_send = head[:7]
@@ -832,8 +832,9 @@ def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
 
 
 def debruijn2_part_fill(c: DeBruijn2Part):
-    """Fill phase (after the d^-1/2 degrees of the halo rows arrived in ``c.ho_deg[u2: u2 + n_halo]``): ``(ho CsrPlan over [owned | halo] sources,
-    first-order in-edges (src, dst GLOBAL node ids int32, merged weight), order-2 nodes per owned first-order node)``."""
+    """Fill phase (after the weighted degrees of the halo rows arrived in ``c.ho_deg[u2: u2 + n_halo]`` and ``c.bufs["fo_deg"]`` holds the degrees of
+    ALL first-order nodes): ``(ho CsrPlan over [owned | halo] sources, fo CsrPlan: destinations = owned nodes, sources = all nodes in the dense
+    local order [owned | ids below lo | ids from hi on], order-2 nodes per owned first-order node)``."""
     dev = c.ws.device
     tcode, kind, di, df, weight = c.args
     b = c.bufs
@@ -845,14 +846,17 @@ def debruijn2_part_fill(c: DeBruijn2Part):
         ho = CsrPlan(n_dst=c.u2, n_src=n_src, fwd_ptr=b["ho_fwd_ptr"][: c.u2 + 1], fwd_idx=torch.empty(c.a2, **i32), fwd_val=torch.empty(c.a2, **f32),
                      bwd_ptr=b["ho_bwd_ptr"][: n_src + 1], bwd_idx=torch.empty(c.a2, **i32), bwd_val=torch.empty(c.a2, **f32),
                      self_coef=torch.empty(c.u2, **f32))
-        fo_src, fo_dst, fo_w = torch.empty(c.a1, **i32), torch.empty(c.a1, **i32), torch.empty(c.a1, **f32)
+        fo = CsrPlan(n_dst=c.n_own, n_src=c.n, fwd_ptr=b["fo_fwd_ptr"], fwd_idx=torch.empty(c.a1, **i32), fwd_val=torch.empty(c.a1, **f32),
+                     bwd_ptr=b["fo_shard_bwd_ptr"], bwd_idx=torch.empty(c.a1, **i32), bwd_val=torch.empty(c.a1, **f32),
+                     self_coef=torch.empty(c.n_own, **f32))
         if c.m > 0 and c.n_own > 0:
             check(L.pp_debruijn2_part_fill(tcode, c.m, c.n, c.lo, c.n_own, kind, di, df, _p(weight), _p(b["fo_bwd_ptr"]), _p(b["fo_fwd_ptr"]),
-                                           _p(b["ho_fwd_ptr"]), _p(b["ho_bwd_ptr"]), _p(b["ho_deg"]), c.a2, _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx),
-                                           _p(ho.bwd_val), _p(ho.self_coef), _p(fo_src), _p(fo_dst), _p(fo_w), _p(torch.empty(2 * c.a2, **i32)), _p(c.ws),
+                                           _p(b["ho_fwd_ptr"]), _p(b["ho_bwd_ptr"]), _p(b["ho_deg"]), _p(b["fo_deg"]), c.a2, _p(ho.fwd_idx), _p(ho.fwd_val),
+                                           _p(ho.bwd_idx), _p(ho.bwd_val), _p(ho.self_coef), _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.self_coef),
+                                           _p(b["fo_shard_bwd_ptr"]), _p(fo.bwd_idx), _p(fo.bwd_val), _p(torch.empty(2 * c.a2, **i32)), _p(c.ws),
                                            c.ws.numel(), _stream()), "pp_debruijn2_part_fill")
         indeg = (b["fo_fwd_ptr"][1:] - b["fo_fwd_ptr"][:-1]).to(torch.float32)
-    return ho, (fo_src, fo_dst, fo_w), indeg
+    return ho, fo, indeg
 
 
 def spmm(ptr, idx, val, n_rows: int, x: torch.Tensor, self_coef=None, s=None, bias=None, act: bool = False,

@@ -168,10 +168,13 @@ struct Db2OutIn {
 };
 
 template <bool kW>
-__global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, int64_t lo, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ oc_t,
+__global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, int64_t lo, int64_t n_own, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ oc_t,
                                                    const uint64_t* __restrict__ ot_t, const float* __restrict__ ow_t, uint64_t* __restrict__ ot_s,
                                                    uint32_t* __restrict__ oc_s, float* __restrict__ ow_s, uint8_t* __restrict__ ocr_s,
-                                                   uint8_t* __restrict__ ocr_t, int32_t* __restrict__ blk, int64_t* __restrict__ status) {
+                                                   uint8_t* __restrict__ ocr_t, int32_t* __restrict__ blk, int32_t* __restrict__ fblk,
+                                                   uint8_t* __restrict__ fskip, int64_t* __restrict__ status) {
+    // n nodes from node 0 (one GPU: all of them, all owned; partition shard: all of them, [lo, lo + n_own) owned — the lists of the FOREIGN
+    // nodes hold their events into the owned range: their successor runs are the source-major rows of the rank's first-order shard)
     const int64_t node0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * kDb2Nodes;
     if (node0 >= n) return;
     const int l = lane_id();
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, int64_t lo, const
 #pragma unroll
     for (int s = 0; s < kDb2Nodes; ++s) {
         const int64_t node = node0 + s;
-        const uint32_t b0 = node < n ? tp[lo + node] : 0u, b1 = node < n ? tp[lo + node + 1] : 0u;      // (node: index inside the owned range [lo, lo + n))
+        const uint32_t b0 = node < n ? tp[node] : 0u, b1 = node < n ? tp[node + 1] : 0u;
         in[s].p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);          // (wave-uniform by construction: scalar loop bounds, scalar addresses)
         in[s].cnt = __builtin_amdgcn_readfirstlane((int)(b1 - b0));
     }
@@ -196,9 +199,13 @@ __global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, int64_t lo, const
         if (node >= n) break;
         const uint32_t p0 = in[s].p0;
         const int cnt = in[s].cnt;
+        const int64_t nl = node - lo;
+        const bool own = nl >= 0 && nl < n_own;
+        const int64_t jloc = own ? nl : (node < lo ? n_own + node : node);          // dense local source space [owned | ids below lo | ids from hi on]
         if (cnt > kWave || cnt == 0) {
             if (l == 0) {
-                blk[node] = 0;
+                if (own) blk[nl] = 0;
+                if (fblk) { fblk[jloc] = 0; fskip[node] = 0; }
                 if (cnt > kWave) atomicOr((unsigned long long*)status, (unsigned long long)kDb2Overflow);
             }
             continue;
@@ -239,7 +246,11 @@ __global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, int64_t lo, const
             ocr_t[p0 + l] = (uint8_t)mine;
             ow_s[p0 + l] = head ? weight : 0.0f;
         }
-        if (l == 0) blk[node] = (int32_t)__popcll(hm);
+        if (l == 0 && own) blk[nl] = (int32_t)__popcll(hm);
+        if (fblk) {
+            const uint64_t below = __ballot(head && (int64_t)sc < lo), inside = __ballot(head && (int64_t)sc >= lo && (int64_t)sc < lo + n_own);
+            if (l == 0) { fblk[jloc] = (int32_t)__popcll(inside); fskip[node] = (uint8_t)__popcll(below); }
+        }
     }
 }
 
@@ -286,6 +297,29 @@ __global__ __launch_bounds__(kBlock) void k_db2_out_fill(int64_t m, int64_t lo, 
     src_t[p] = r;
 }
 
+// partition shards: the source-major rows of the first-order shard (sources: ALL nodes in the dense local order, destinations: owned nodes) are the
+// successor runs that fall into the owned range; coefficients d_b^-1/2 w d_c^-1/2 from the all-gathered degrees
+__global__ __launch_bounds__(kBlock) void k_db2_fo_part_bwd(int64_t m, int64_t lo, int64_t n_own, const uint32_t* __restrict__ tp,
+                                                           const uint32_t* __restrict__ tkeys_s, const uint32_t* __restrict__ oc_s,
+                                                           const uint8_t* __restrict__ ocr_s, const float* __restrict__ ow_s,
+                                                           const uint8_t* __restrict__ fskip, const int32_t* __restrict__ fo2_ptr,
+                                                           const float* __restrict__ fo_deg, int32_t* __restrict__ idx, float* __restrict__ val) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m) return;
+    const uint32_t b = tkeys_s[p];
+    const uint32_t p0 = tp[b];
+    if (tp[b + 1] - p0 > (uint32_t)kWave) return;
+    const uint8_t cr = ocr_s[p];
+    if (!(p == p0 || ocr_s[p - 1] != cr)) return;
+    const int64_t c = oc_s[p];
+    if (c < lo || c >= lo + n_own) return;
+    const int64_t bl = (int64_t)b - lo;
+    const int64_t jloc = (bl >= 0 && bl < n_own) ? bl : ((int64_t)b < lo ? n_own + b : b);
+    const int64_t pos = (int64_t)fo2_ptr[jloc] + cr - fskip[b];
+    idx[pos] = (int32_t)(c - lo);
+    val[pos] = (int64_t)b == c ? 0.0f : inv_sqrt_deg(fo_deg[b]) * ow_s[p] * inv_sqrt_deg(fo_deg[c]);
+}
+
 // source-major coefficients of the first-order graph: val(b -> c) = d_b^-1/2 w d_c^-1/2, 0 on self loops (as k_gcn_coefficients)
 __global__ __launch_bounds__(kBlock) void k_db2_fo_bwd_val(int64_t m, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tkeys_s,
                                                           const uint32_t* __restrict__ oc_s, const uint8_t* __restrict__ ocr_s,
@@ -306,8 +340,8 @@ __global__ __launch_bounds__(kBlock) void k_db2_fo_bwd_val(int64_t m, const uint
 // ------------------------------------------------------------------ middle-node pass
 struct Db2Mid {
     int64_t lo;                      // first owned node (0 on one GPU); arrays indexed by node: tp, hp, fo_deg GLOBAL ids, everything else owned-local
-    int part;                        // partition shard: the first-order in-edges leave as a raw (source, destination, weight) list
-    int32_t* fwd_dst1;
+    int64_t n_own;                   // partition shard (> 0): first-order sources are written as dense local ids [owned | below lo | from hi on]
+    int part;
     const uint32_t *tp, *hp;
     const uint64_t* ot_s;            // out-events in (successor, time) order: time, successor rank
     const uint8_t* ocr_s;
@@ -368,7 +402,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
         in[s].ni = __builtin_amdgcn_readfirstlane((int)(h1 - h0));
         in[s].row0 = __builtin_amdgcn_readfirstlane(r0);
         if (kFill) {
-            in[s].d1 = (there && !a.part) ? inv_sqrt_deg(a.fo_deg[gn]) : 0.0f;
+            in[s].d1 = there ? inv_sqrt_deg(a.fo_deg[gn]) : 0.0f;
             in[s].lw1 = there ? a.fo_lw[node] : 1.0f;
             in[s].fp = __builtin_amdgcn_readfirstlane(there ? a.fo_fwd_ptr[node] : 0);
         }
@@ -491,7 +525,8 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
                 if (l == nuc) {
                     run_u = ucur;
                     run_a = acur;
-                    run_val = a.part ? w1run : (acur == gnode ? 0.0f : da_ * w1run * d1b);
+                    if (a.part) run_a = (int64_t)acur < a.lo ? (uint32_t)(a.n_own + acur) : ((int64_t)acur >= a.lo + a.n_own ? acur : (uint32_t)(acur - a.lo));
+                    run_val = acur == gnode ? 0.0f : da_ * w1run * d1b;
                 }
             }
             ++nuc;
@@ -516,7 +551,6 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
                 a.fwd_idx1[in[s].fp + l] = (int32_t)run_a;
                 a.fwd_val1[in[s].fp + l] = run_val;
                 if (a.dst_order) a.dst_order[in[s].fp + l] = (int32_t)run_u;
-                if (a.fwd_dst1) a.fwd_dst1[in[s].fp + l] = (int32_t)gnode;
             }
             if (ohead) a.self2[v] = dv * lwv * dv;
             if (l == 0 && a.self1) a.self1[node] = d1b * in[s].lw1 * d1b;
@@ -610,8 +644,9 @@ constexpr int kDb2Result = 8 + 2 * (kDb2MaxWorld + 1) + 6;
 struct Db2Ws {
     int64_t* result;         // [kDb2Result]: {U2, status, A2, E2, A1 (first-order in-edges), halo rows, rows sent, -, recv_ptr[world+1], send_ptr[world+1]}
     uint32_t *xkeys, *xkeys_s, *xorder;      // partition shards: halo / send-list sort keys
-    int32_t *perm, *succ_old;
+    int32_t *perm, *succ_old, *fblk;
     float* w_old;
+    uint8_t* fskip;
     uint32_t *tkeys, *tkeys_s, *hkeys_s, *tl, *hl, *tp, *hp;
     Db2Rec* rec;
     Db2Src* src_t;
@@ -641,6 +676,8 @@ static Db2Ws carve_db2(void* ws, int64_t m, int64_t n) {
     w.perm = a.take<int32_t>(m);
     w.succ_old = a.take<int32_t>(m);
     w.w_old = a.take<float>(m);
+    w.fblk = a.take<int32_t>(n);
+    w.fskip = a.take<uint8_t>(n + 16);
     w.tkeys = a.take<uint32_t>(m);
     w.tkeys_s = a.take<uint32_t>(m);
     w.hkeys_s = a.take<uint32_t>(m);
@@ -720,6 +757,7 @@ struct Db2Part {                   // node range of a partition shard (one GPU: 
     const int64_t* cuts;           // device int64 [world + 1]: node ranges of all ranks
     int world, me;
     int32_t *send_slot, *row_of;   // [m] each: local row -> its position in the send prefix (-1 behind it) / its lexicographic row
+    int32_t* fo2_bwd_ptr;          // [num_nodes + 1]: source-major row pointers of the first-order shard (dense local source order)
 };
 
 static int db2_count(const char* who, const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t n, const Db2Part& pt, int delta_kind,
@@ -744,6 +782,7 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
         return PP_OK;
     }
     const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n_own > 0 ? n_own : 1, kWavesPerBlock * kDb2Nodes);
+    const unsigned agrid = (unsigned)ceil_div(n, kWavesPerBlock * kDb2Nodes);
     // 1. event records; out-lists (stable sort by tail: time order inside a list), then the list SEQUENCE sorted by head: in-lists in (source, time) order
     if (time_dtype == PP_I64) k_db2_keys<int64_t><<<egrid, kBlock, 0, st>>>(edge_index, (const int64_t*)time, m, n, w.tkeys, w.rec, w.result + 1);
     else k_db2_keys<double><<<egrid, kBlock, 0, st>>>(edge_index, (const double*)time, m, n, w.tkeys, w.rec, w.result + 1);
@@ -760,9 +799,14 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
     k_db2_rowptr<<<(unsigned)ceil_div(m + 1, kBlock), kBlock, 0, st>>>(w.hkeys_s, m, n, w.hp);
     PP_LAUNCH_CHECK();
     // 2. successors of every owned node -> order-2 node ids
-    if (weight) k_db2_out<true><<<ngrid, kBlock, 0, st>>>(n_own, pt.lo, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, w.result + 1);
-    else k_db2_out<false><<<ngrid, kBlock, 0, st>>>(n_own, pt.lo, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, w.result + 1);
+    int32_t* fblk = part ? w.fblk : nullptr;
+    if (weight) k_db2_out<true><<<agrid, kBlock, 0, st>>>(n, pt.lo, n_own, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, fblk, w.fskip, w.result + 1);
+    else k_db2_out<false><<<agrid, kBlock, 0, st>>>(n, pt.lo, n_own, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, fblk, w.fskip, w.result + 1);
     PP_LAUNCH_CHECK();
+    if (part) {
+        rc = exclusive_scan<int32_t, int32_t>(w.fblk, n, pt.fo2_bwd_ptr, true, nullptr, w.scratch, w.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+    }
     rc = exclusive_scan<int32_t, int32_t>(w.blk, n_own, fo_bwd_ptr, true, w.result, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
     const int32_t* perm = nullptr;
@@ -804,7 +848,7 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
     PP_HIP(hipMemsetAsync(w.outdeg2, 0, (size_t)m * sizeof(int32_t), st));
     Db2Mid a{};
     mid_common(a, w, fo_bwd_ptr, weight != nullptr);
-    a.lo = pt.lo; a.part = part ? 1 : 0; a.perm = perm;
+    a.lo = pt.lo; a.n_own = n_own; a.part = part ? 1 : 0; a.perm = perm;
     a.indeg2 = w.indeg2; a.outdeg2 = w.outdeg2; a.ho_deg = ho_deg; a.fo_deg = fo_deg;
     a.nu = w.nu; a.pc = w.pc; a.status = w.result + 1;
     rc = launch_mid_any<false>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n_own, delta_i, delta_f, a);
@@ -822,8 +866,8 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
                     double delta_f, const float* weight, const int32_t* fo_bwd_ptr, const float* fo_w, const int32_t* fo_fwd_ptr,
                     const int32_t* ho_fwd_ptr, const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t num_ho_edges,
                     int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx,
-                    float* fo_fwd_val, int32_t* fo_dst_order, int32_t* fo_fwd_dst, float* fo_bwd_val, float* fo_self, void* pair_scratch, void* ws,
-                    size_t ws_bytes, hipStream_t st) {
+                    float* fo_fwd_val, int32_t* fo_dst_order, const int32_t* fo2_bwd_ptr, int32_t* fo2_bwd_idx, float* fo_bwd_val, float* fo_self,
+                    void* pair_scratch, void* ws, size_t ws_bytes, hipStream_t st) {
     PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "%s: negative size", who);
     Db2Ws w = carve_db2(ws, m, n);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "%s: workspace too small", who);
@@ -833,26 +877,25 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
     PP_REQUIRE(num_ho_edges >= 0 && (num_ho_edges == 0 || pair_scratch != nullptr), PP_ERR_ARG, "%s: pair_scratch (8 bytes per order-2 edge) missing", who);
     k_db2_pack_rows<<<egrid, kBlock, 0, st>>>(m, ho_deg, ho_bwd_ptr, w.row_pack);
     PP_LAUNCH_CHECK();
-    k_db2_gather_coef<<<egrid, kBlock, 0, st>>>(m, w.is_u, w.is_a, w.row_pack, part ? nullptr : fo_deg, w.du_s, w.ob_s, w.da_s);
+    k_db2_gather_coef<<<egrid, kBlock, 0, st>>>(m, w.is_u, w.is_a, w.row_pack, fo_deg, w.du_s, w.ob_s, w.da_s);
     PP_LAUNCH_CHECK();
     Db2Mid a{};
     mid_common(a, w, fo_bwd_ptr, weight != nullptr);
-    a.lo = lo; a.part = part ? 1 : 0; a.perm = part ? w.perm : nullptr;
+    a.lo = lo; a.n_own = n_own; a.part = part ? 1 : 0; a.perm = part ? w.perm : nullptr;
     a.ho_deg = const_cast<float*>(ho_deg); a.fo_deg = const_cast<float*>(fo_deg);
     a.du_s = w.du_s; a.da_s = w.da_s; a.ob_s = w.ob_s;
     a.ho_fwd_ptr = ho_fwd_ptr; a.fo_fwd_ptr = fo_fwd_ptr;
     a.in_idx2 = ho_fwd_idx; a.in_val2 = ho_fwd_val; a.out_pack = (uint2*)pair_scratch; a.self2 = ho_self;
-    a.fwd_idx1 = fo_fwd_idx; a.fwd_val1 = fo_fwd_val; a.dst_order = fo_dst_order; a.fwd_dst1 = fo_fwd_dst; a.self1 = fo_self;
+    a.fwd_idx1 = fo_fwd_idx; a.fwd_val1 = fo_fwd_val; a.dst_order = fo_dst_order; a.self1 = fo_self;
     int rc = launch_mid_any<true>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n_own, delta_i, delta_f, a);
     if (rc != PP_OK) return rc;
     if (num_ho_edges > 0) {
         k_db2_unzip<<<(unsigned)ceil_div(num_ho_edges, kBlock), kBlock, 0, st>>>(num_ho_edges, (const uint2*)pair_scratch, ho_bwd_idx, ho_bwd_val);
         PP_LAUNCH_CHECK();
     }
-    if (!part) {
-        k_db2_fo_bwd_val<<<egrid, kBlock, 0, st>>>(m, w.tp, w.tkeys_s, w.oc_s, w.ocr_s, fo_bwd_ptr, fo_w, fo_deg, fo_bwd_val);
-        PP_LAUNCH_CHECK();
-    }
+    if (!part) k_db2_fo_bwd_val<<<egrid, kBlock, 0, st>>>(m, w.tp, w.tkeys_s, w.oc_s, w.ocr_s, fo_bwd_ptr, fo_w, fo_deg, fo_bwd_val);
+    else k_db2_fo_part_bwd<<<egrid, kBlock, 0, st>>>(m, lo, n_own, w.tp, w.tkeys_s, w.oc_s, w.ocr_s, w.ow_s, w.fskip, fo2_bwd_ptr, fo_deg, fo2_bwd_idx, fo_bwd_val);
+    PP_LAUNCH_CHECK();
     return PP_OK;
 }
 
@@ -863,7 +906,7 @@ extern "C" {
 int pp_debruijn2_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i,
                        double delta_f, const float* weight, int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr,
                        int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr, float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, pp_stream_t stream) {
-    const Db2Part whole{0, num_nodes, nullptr, 1, 0, nullptr, nullptr};
+    const Db2Part whole{0, num_nodes, nullptr, 1, 0, nullptr, nullptr, nullptr};
     return db2_count("pp_debruijn2_count", edge_index, time, time_dtype, m, num_nodes, whole, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_bwd_idx,
                      fo_w, fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -875,27 +918,30 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
                       float* fo_self, void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream) {
     return db2_fill("pp_debruijn2_fill", time_dtype, m, num_nodes, 0, num_nodes, false, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_w, fo_fwd_ptr,
                     ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_fwd_idx, fo_fwd_val,
-                    fo_dst_order, nullptr, fo_bwd_val, fo_self, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
+                    fo_dst_order, nullptr, nullptr, fo_bwd_val, fo_self, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
                             const int64_t* cuts, int world, int rank, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
                             int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
-                            float* ho_deg, float* fo_deg, int32_t* send_slot, int32_t* row_of, void* ws, size_t ws_bytes, pp_stream_t stream) {
-    PP_REQUIRE(world >= 2 && cuts != nullptr && send_slot != nullptr && row_of != nullptr, PP_ERR_ARG, "pp_debruijn2_part_count: world >= 2 with cuts and the send_slot / row_of buffers");
-    const Db2Part pt{node_lo, n_own, cuts, world, rank, send_slot, row_of};
+                            float* ho_deg, float* fo_deg, int32_t* send_slot, int32_t* row_of, int32_t* fo_shard_bwd_ptr, void* ws, size_t ws_bytes,
+                            pp_stream_t stream) {
+    PP_REQUIRE(world >= 2 && cuts != nullptr && send_slot != nullptr && row_of != nullptr && fo_shard_bwd_ptr != nullptr, PP_ERR_ARG,
+               "pp_debruijn2_part_count: world >= 2 with cuts and the send_slot / row_of / fo_shard_bwd_ptr buffers");
+    const Db2Part pt{node_lo, n_own, cuts, world, rank, send_slot, row_of, fo_shard_bwd_ptr};
     return db2_count("pp_debruijn2_part_count", edge_index, time, time_dtype, m, num_nodes, pt, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr,
                      fo_bwd_idx, fo_w, fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own, int delta_kind, int64_t delta_i, double delta_f,
                            const float* weight, const int32_t* fo_bwd_ptr, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr,
-                           const int32_t* ho_bwd_ptr, const float* ho_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val,
-                           int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_in_src, int32_t* fo_in_dst, float* fo_in_weight,
-                           void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream) {
+                           const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx,
+                           float* ho_fwd_val, int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val,
+                           float* fo_self, const int32_t* fo_shard_bwd_ptr, int32_t* fo_shard_bwd_idx, float* fo_shard_bwd_val, void* pair_scratch,
+                           void* ws, size_t ws_bytes, pp_stream_t stream) {
     return db2_fill("pp_debruijn2_part_fill", time_dtype, m, num_nodes, node_lo, n_own, true, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, nullptr,
-                    fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, nullptr, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_in_src,
-                    fo_in_weight, nullptr, fo_in_dst, nullptr, nullptr, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
+                    fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_fwd_idx,
+                    fo_fwd_val, nullptr, fo_shard_bwd_ptr, fo_shard_bwd_idx, fo_shard_bwd_val, fo_self, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

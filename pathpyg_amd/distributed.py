@@ -596,6 +596,32 @@ def _ops_default(ops):
 # Graph shards (see pathpyg_amd.nn.sharded for the layout): halo discovery, the request exchange, the rectangular GCN plan with its
 # one d^-1/2 halo exchange, and the CSR that folds returned gradient rows into the owned rows.
 # =====================================================================================================
+_DENSE_BOOK = {}
+
+
+def _dense_halo_book(lo: int, hi: int, num_nodes: int, cuts: list[int], rank: int, dev):
+    """Bookkeeping of a DENSE-halo shard (every foreign node is a halo row): halo ids, send list, counts, return CSR — pure arithmetic on the cuts,
+    cached (the same tensors at every step of a stream)."""
+    key = (lo, hi, num_nodes, tuple(cuts), rank, str(dev))
+    book = _DENSE_BOOK.get(key)
+    if book is None:
+        world = len(cuts) - 1
+        n_own = hi - lo
+        halo_ids = torch.cat((torch.arange(0, lo, dtype=torch.int64, device=dev), torch.arange(hi, num_nodes, dtype=torch.int64, device=dev)))
+        recv_counts = [0 if r == rank else int(cuts[r + 1] - cuts[r]) for r in range(world)]
+        send_counts = [0 if r == rank else n_own for r in range(world)]
+        peers = world - 1
+        own_rows = torch.arange(n_own, dtype=torch.int32, device=dev)
+        send_idx = own_rows.repeat(peers)                                                                   # every owned row to every peer
+        # returned gradient rows arrive peer by peer: row i of peer block p sits at p * n_own + i
+        back_ptr = torch.arange(0, n_own * peers + 1, max(peers, 1), dtype=torch.int32, device=dev)[: n_own + 1]
+        back_idx = (own_rows.unsqueeze(1) + (torch.arange(peers, dtype=torch.int32, device=dev) * n_own).unsqueeze(0)).reshape(-1)
+        if len(_DENSE_BOOK) > 64:
+            _DENSE_BOOK.clear()
+        book = _DENSE_BOOK[key] = (halo_ids, send_idx, send_counts, recv_counts, back_ptr, back_idx)
+    return book
+
+
 def sorted_halo(src: torch.Tensor, lo: int, hi: int, cuts_t: torch.Tensor):
     """Halo of an edge list whose global source ids ``src`` are ASCENDING (what the exchanges of :func:`build_dbgnn_shard` deliver): the
     distinct sources outside ``[lo, hi)`` are the run heads of the list — no flag array over all nodes, no sort.  Returns ``(src_local
@@ -639,15 +665,7 @@ def build_graph_shard(src: torch.Tensor, dst: torch.Tensor, weight: torch.Tensor
     if dense_halo:
         # local source space [owned | ids below lo | ids from hi on]: id + n_own below the range, id itself above it
         src_local = torch.where(src < lo, src + n_own, torch.where(src >= hi, src, src - lo))
-        halo_ids = torch.cat((torch.arange(0, lo, dtype=torch.int64, device=dev), torch.arange(hi, num_nodes, dtype=torch.int64, device=dev)))
-        recv_counts = [0 if r == rank else int(cuts[r + 1] - cuts[r]) for r in range(world)]
-        send_counts = [0 if r == rank else n_own for r in range(world)]
-        peers = world - 1
-        own_rows = torch.arange(n_own, dtype=torch.int32, device=dev)
-        send_idx = own_rows.repeat(peers)                                                                   # every owned row to every peer
-        # returned gradient rows arrive peer by peer: row i of peer block p sits at p * n_own + i
-        back_ptr = torch.arange(0, n_own * peers + 1, max(peers, 1), dtype=torch.int32, device=dev)[: n_own + 1]
-        back_idx = (own_rows.unsqueeze(1) + (torch.arange(peers, dtype=torch.int32, device=dev) * n_own).unsqueeze(0)).reshape(-1)
+        halo_ids, send_idx, send_counts, recv_counts, back_ptr, back_idx = _dense_halo_book(lo, hi, num_nodes, cuts, rank, dev)
         gs = _finish_graph_shard(torch.stack((src_local, dst - lo)), weight, lo, hi, num_nodes, cuts, halo_ids, send_idx, send_counts, recv_counts,
                                  comm, ops, status_out, unique_send=False, want_dst_order=want_dst_order, back=(back_ptr, back_idx))
         gs.dense = True              # (layer exchanges of this shard: all-gather + block copies, nn.sharded.halo_fill_async)
@@ -1151,9 +1169,16 @@ def _build_partitioned_by_node(g, delta, x, x_h, y, comm: Comm, ops, weight: str
     xh_pending = comm.exchange_rows_async(xh_buf[: c.n_send], c.send_counts, c.recv_counts, out=xh_buf[n_own: n_own + n_halo])
     comm.exchange_rows(c.ho_deg[: c.n_send], c.send_counts, c.recv_counts, out=c.ho_deg[n_own: n_own + n_halo])
     comm.mark("build: 2 halo exchanges (degrees; feature rows asynchronously)")
-    ho_plan, (fo_src, fo_dst, fo_w), indeg = ops.debruijn2_part_fill(c)
-    comm.mark("build: 3 order-2 builder, fill pass")
-
+    # first-order degrees of ALL nodes (the count pass filled my slice): one all-gather of N floats
+    cap_n = max(max(fo_cuts[r + 1] - fo_cuts[r] for r in range(world)), 1)
+    fo_deg = c.bufs["fo_deg"]
+    mine = fo_deg[lo_n:hi_n]
+    gathered = comm.all_gather_rows(mine if hi_n - lo_n == cap_n else torch.nn.functional.pad(mine, (0, cap_n - (hi_n - lo_n))))
+    for r in range(world):
+        if r != rank and fo_cuts[r + 1] > fo_cuts[r]:
+            fo_deg[fo_cuts[r]: fo_cuts[r + 1]] = gathered[r * cap_n: r * cap_n + fo_cuts[r + 1] - fo_cuts[r]]
+    ho_plan, fo_plan, indeg = ops.debruijn2_part_fill(c)
+    comm.mark("build: 3 order-2 builder, fill pass (both plans)")
     own_ids = c.row_of.to(torch.int64) + lo_h                                   # global ids of the owned rows, local order
 
     def fetch_halo_ids():
@@ -1163,9 +1188,12 @@ def _build_partitioned_by_node(g, delta, x, x_h, y, comm: Comm, ops, weight: str
                     send_idx=None, send_counts=c.send_counts, recv_counts=c.recv_counts, send_unique=True, send_slot=c.send_slot,
                     halo_fetch=fetch_halo_ids, send_prefix=c.n_send, own_ids=own_ids)
     pending = []
-    # first-order graph: the in-edges of my nodes; every foreign node is a halo row (an all-gather per layer), normalised by the generic plan
-    fo_shard = build_graph_shard(fo_src.to(torch.int64), fo_dst.to(torch.int64), fo_w, n, fo_cuts, comm, ops, False, pending, dense_halo=True)
-    comm.mark("build: first-order shard + plan")
+    # first-order shard: straight from the builder too (dense halo: every foreign node is a source row; layer exchanges = all-gathers)
+    halo_ids, fo_send_idx, fo_send_counts, fo_recv_counts, back_ptr, back_idx = _dense_halo_book(lo_n, hi_n, n, fo_cuts, rank, dev)
+    fo_shard = GraphShard(lo=lo_n, hi=hi_n, n_own=hi_n - lo_n, n_halo=n - (hi_n - lo_n), n_src=n, num_nodes=n, cuts=list(fo_cuts), plan=fo_plan,
+                          halo_ids=halo_ids, send_idx=fo_send_idx, send_counts=fo_send_counts, recv_counts=fo_recv_counts, back_ptr=back_ptr,
+                          back_idx=back_idx, send_unique=False, send_slot=None, dense=True)
+    comm.mark("build: first-order shard")
     bip, cap = _bipartite_shard(torch.arange(n_own, dtype=torch.int64, device=dev), c.succ.to(torch.int64), n_own, fo_cuts, comm, ops, src_sorted=True)
     ops.check_plan_status(pending)
     comm.mark("build: bipartite plan + status read-back")
