@@ -177,7 +177,8 @@ class CpuOps:
     def spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum, drop=None):
         g = CpuOps.spmm(ptr, idx, val, n_rows, d)
         if drop is not None:
-            g = g * CpuOps._mask(g.size(0), g.size(1), drop[0], drop[1], drop[2], drop[3], None) * _elu_grad(z * (1.0 - drop[0]))
+            rows = drop[4] if len(drop) > 4 else None          # explicit global row ids (shards numbered in send order)
+            g = g * CpuOps._mask(g.size(0), g.size(1), drop[0], drop[1], drop[2], drop[3], rows) * _elu_grad(z * (1.0 - drop[0]))
         else:
             g = g * _elu_grad(z)
         return g, (g.sum(0) if want_colsum else None)
@@ -228,7 +229,10 @@ class CpuOps:
         if recv.size(0):
             if gs.send_unique:
                 slot = gs.send_slot.long()
-                assert torch.equal(torch.nonzero(slot >= 0).flatten().sort().values, gs.send_idx.long().sort().values)
+                if gs.send_idx is not None:
+                    assert torch.equal(torch.nonzero(slot >= 0).flatten().sort().values, gs.send_idx.long().sort().values)
+                else:          # shards numbered in send order: the send list is the prefix
+                    assert torch.equal(slot[: gs.n_send], torch.arange(gs.n_send)) and bool((slot[gs.n_send:] < 0).all())
                 total = total + torch.where((slot >= 0).unsqueeze(1), recv[slot.clamp(min=0)], torch.zeros_like(total))
             else:
                 total = total + CpuOps.spmm(gs.back_ptr, gs.back_idx, None, gs.n_own, recv)
@@ -289,3 +293,128 @@ class CpuOps:
     @staticmethod
     def cross_entropy_mean(logits, target):
         return F.cross_entropy(logits, target)
+
+
+# =====================================================================================================
+# Stand-in for the node-range partition on the node-by-node builder (pathpyg_amd._hip.debruijn2_part_count / _fill; csrc/pp_debruijn.hip):
+# an independent torch-CPU evaluation of the same CONTRACT — owned rows numbered in send order, halo rows in (owner, head, source) order, the
+# order-2 plan over [owned | halo], the first-order shard over the dense local source space — so that pathpyg_amd.distributed
+# ._build_partitioned_by_node, its collectives and the ShardedDBGNN schedule on such shards run under gloo / ThreadWorld without a GPU.
+# =====================================================================================================
+class _PartCount:
+    pass
+
+
+def _plan_from_edges(src, dst, val, n_src, n_dst, self_coef):
+    plan = _Plan()
+    plan.n_dst, plan.n_src = n_dst, n_src
+    plan.fwd_ptr, by_dst = _csr(dst, n_dst)
+    plan.bwd_ptr, by_src = _csr(src, n_src)
+    plan.fwd_idx, plan.fwd_val = src[by_dst].int(), val[by_dst]
+    plan.bwd_idx, plan.bwd_val = dst[by_src].int(), val[by_src]
+    plan.self_coef = self_coef
+    return plan
+
+
+class CpuOpsNode(CpuOps):
+    name = "cpu-test-standin (node-range partition)"
+    MAX_LIST = 64           # the builder's limit: events per node and side
+
+    @staticmethod
+    def debruijn2_part_count(edge_index, time, num_nodes, node_lo, node_hi, cuts_dev, rank, delta, weight=None):
+        src, dst = edge_index[0].long(), edge_index[1].long()
+        n, lo, hi = int(num_nodes), int(node_lo), int(node_hi)
+        cuts = [int(v) for v in cuts_dev.tolist()]
+        world = len(cuts) - 1
+        m = int(src.numel())
+        w = torch.ones(m) if weight is None else weight.float()
+        own_src, own_dst = (src >= lo) & (src < hi), (dst >= lo) & (dst < hi)
+        c = _PartCount()
+        c.m, c.n, c.lo, c.n_own, c.world = m, n, lo, hi - lo, world
+        c.status = 0
+        outdeg = torch.bincount(src[own_src] - lo, minlength=hi - lo) if hi > lo else torch.zeros(0, dtype=torch.long)
+        indeg = torch.bincount(dst[own_dst] - lo, minlength=hi - lo) if hi > lo else torch.zeros(0, dtype=torch.long)
+        if (outdeg.numel() and int(outdeg.max()) > CpuOpsNode.MAX_LIST) or (indeg.numel() and int(indeg.max()) > CpuOpsNode.MAX_LIST):
+            c.status = 4
+        # ---- owned order-2 rows = distinct (b, c) of the out-events, lexicographic; local order = send order
+        ev_out = torch.nonzero(own_src).flatten()
+        keys_out = src[ev_out] * n + dst[ev_out]
+        rows_key, inv_out = torch.unique(keys_out, return_inverse=True)
+        u2 = int(rows_key.numel())
+        w1 = torch.zeros(u2).index_add_(0, inv_out, w[ev_out])
+        succ_lex = rows_key % n
+        sent = (succ_lex < lo) | (succ_lex >= hi)
+        order = torch.sort(torch.where(sent, succ_lex, torch.full_like(succ_lex, n)), stable=True).indices          # local row -> lexicographic row
+        perm = torch.empty(u2, dtype=torch.long)
+        perm[order] = torch.arange(u2)
+        n_send = int(sent.sum())
+        succ = succ_lex[order]
+        c.u2, c.n_send, c.row_of, c.succ = u2, n_send, order.int(), succ.int()
+        c.send_counts = [0 if r == rank else int(((succ[:n_send] >= cuts[r]) & (succ[:n_send] < cuts[r + 1])).sum()) for r in range(world)]
+        c.send_slot = torch.where(torch.arange(u2) < n_send, torch.arange(u2), torch.full((u2,), -1)).int()
+        node_of_out = torch.full((m,), -1, dtype=torch.long)          # event -> local row of its (src, dst) pair (owned sources)
+        node_of_out[ev_out] = perm[inv_out]
+        # ---- halo: distinct (a, b) with a foreign a among the in-events, in (owner of a, b, a) order behind the owned rows
+        ev_in = torch.nonzero(own_dst).flatten()
+        a_in, b_in = src[ev_in], dst[ev_in]
+        foreign = ~own_src[ev_in]
+        cuts_t = torch.tensor(cuts[1:-1], dtype=torch.long)
+        owner = torch.searchsorted(cuts_t, a_in, right=True) if world > 1 else torch.zeros_like(a_in)
+        hkey = (owner * n + b_in) * n + a_in
+        halo_key, inv_halo = torch.unique(hkey[foreign], return_inverse=True)
+        n_halo = int(halo_key.numel())
+        halo_owner = halo_key // (n * n)
+        c.n_halo = n_halo
+        c.recv_counts = [int((halo_owner == r).sum()) for r in range(world)]
+        node_as_source = node_of_out.clone()                           # event -> local SOURCE row (owned row, or halo row for foreign sources)
+        node_as_source[ev_in[foreign]] = u2 + inv_halo
+        # ---- lifted pairs with an owned middle node
+        pairs = ol.temporal_lift_sorted(edge_index, time, delta, n)
+        pairs = pairs[:, own_dst[pairs[0]]]
+        c.e2 = int(pairs.size(1))
+        u, v = node_as_source[pairs[0]], node_of_out[pairs[1]]
+        n_src = u2 + n_halo
+        if pairs.size(1):
+            merged, mw = oa.coalesce(torch.stack((u, v)), w[pairs[0]], max(n_src, 1), "sum")
+        else:
+            merged, mw = torch.zeros((2, 0), dtype=torch.long), torch.zeros(0)
+        c.a2 = int(merged.size(1))
+        loop = merged[0] == merged[1]
+        lw = torch.ones(u2)
+        lw[merged[1][loop]] = mw[loop]
+        c.ho_deg = torch.zeros(max(n_src, 1))
+        c.ho_deg[:u2] = torch.zeros(u2).index_add_(0, merged[1][~loop], mw[~loop]) + lw
+        # ---- first-order in-edges of the owned nodes, their weighted degrees
+        fkey, finv = torch.unique(a_in * n + b_in, return_inverse=True)
+        fa, fb = fkey // n, fkey % n
+        fw = torch.zeros(fkey.numel()).index_add_(0, finv, w[ev_in])
+        floop = fa == fb
+        flw = torch.ones(hi - lo)
+        flw[fb[floop] - lo] = fw[floop]
+        fo_deg = torch.zeros(max(n, 1))
+        fo_deg[lo:hi] = torch.zeros(hi - lo).index_add_(0, fb[~floop] - lo, fw[~floop]) + flw
+        c.a1 = int(fkey.numel())
+        c.bufs = {"fo_deg": fo_deg}
+        c._ho = (merged, mw, lw)
+        c._fo = (fa, fb, fw, flw)
+        return c
+
+    @staticmethod
+    def debruijn2_part_fill(c):
+        def inv_sqrt(d):
+            out = d.pow(-0.5)
+            out[torch.isinf(out)] = 0
+            return out
+        merged, mw, lw = c._ho
+        n_src = c.u2 + c.n_halo
+        dinv = inv_sqrt(c.ho_deg[:max(n_src, 1)])
+        val = torch.where(merged[0] == merged[1], torch.zeros_like(mw), dinv[merged[0]] * mw * dinv[merged[1]])
+        ho = _plan_from_edges(merged[0], merged[1], val, n_src, c.u2, dinv[: c.u2] * lw * dinv[: c.u2])
+        fa, fb, fw, flw = c._fo
+        lo, hi, n_own = c.lo, c.lo + c.n_own, c.n_own
+        d1 = inv_sqrt(c.bufs["fo_deg"])
+        src_local = torch.where(fa < lo, fa + n_own, torch.where(fa >= hi, fa, fa - lo))
+        fval = torch.where(fa == fb, torch.zeros_like(fw), d1[fa] * fw * d1[fb])
+        fo = _plan_from_edges(src_local, fb - lo, fval, c.n, n_own, d1[lo:hi] * flw * d1[lo:hi])
+        indeg = (fo.fwd_ptr[1:] - fo.fwd_ptr[:-1]).float()
+        return ho, fo, indeg

@@ -373,7 +373,7 @@ def test_world8_er_and_zipf_streams_match_oracle_and_balance():
     _spawn(_world8_worker, 8, timeout=600)
 
 
-def _dropout_worker(rank, world, port, results):
+def _dropout_worker(rank, world, port, results, node_ops=False):
     """Training-mode dropout on the partitioned path: the masks are functions of (seed, tag, GLOBAL row, column), so every world size must
     reproduce the single-process evaluation of the reference forward (dbgnn.py:131-150) with those masks — logits, loss, every gradient."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -386,9 +386,12 @@ def _dropout_worker(rank, world, port, results):
         from pathpyg_amd.nn.sharded import dropout_mask
         from oracle import dbgnn as od
         from oracle import model as om
-        from tests.cpu_ops import CpuOps
+        from tests.cpu_ops import CpuOps, CpuOpsNode
         rng = np.random.default_rng(31)
         m, n, delta, span, f, p = 1800, 35, 10, 600, 8, 0.4
+        if node_ops:          # ~10 events per node: the node-range partition on the node-by-node builder (its stand-in), masks by explicit row ids
+            CpuOps = CpuOpsNode
+            m, n, delta, span = 700, 70, 25, 900
         ei = torch.from_numpy(rng.integers(0, n, (2, m)))
         t = torch.from_numpy(np.sort(rng.integers(0, span, m)))
         layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2)
@@ -426,6 +429,7 @@ def _dropout_worker(rank, world, port, results):
             tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n)
             comm = pd.Comm()
             shard = pd.build_dbgnn_shard(tg, delta, x, x_h, y, comm, CpuOps())
+            assert not (node_ops and world > 1) or shard.sizes.get("builder") == "fused"
             net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=dims, p_dropout=p)
             net.load_state_dict(params)
             net.train()
@@ -453,6 +457,115 @@ def _check_against_oracle_train(sharded, shard, net, want_out, want_loss, want_g
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_partitioned_dropout_is_reproducible_across_world_sizes(world):
     _spawn(_dropout_worker, world)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_node_range_partition_dropout_is_reproducible_across_world_sizes(world):
+    _spawn(_dropout_worker, world, True)
+
+
+def _node_partition_worker(rank, world, port, results):
+    """The NODE-RANGE partition on the node-by-node builder (round 4: pathpyg_amd.distributed._build_partitioned_by_node) under gloo, with the
+    torch-CPU stand-in of pp_debruijn2_part_* (tests/cpu_ops.py::CpuOpsNode): rows numbered in send order, halo rows without an id exchange,
+    first-order shard with a dense halo — against the single-process oracle; row loaders see exactly the owned rows."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        import pathpyg_amd as pp
+        from pathpyg_amd import distributed as pd
+        from oracle import dbgnn as od
+        from oracle import model as om
+        from tests.cpu_ops import CpuOpsNode
+        rng = np.random.default_rng(43)
+        for kind, m, n, delta, span, weighted in (("er", 900, 80, 30, 1200, False), ("er-weighted", 700, 60, 25, 900, True), ("tiny", 25, 12, 4, 40, False)):
+            ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+            t = torch.from_numpy(np.sort(rng.integers(0, span, m)))
+            w = torch.from_numpy((rng.random(m) + 0.5).astype(np.float32)) if weighted else None
+            layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2, edge_weight=w)
+            n_ho = layers[2]["num_nodes"]
+            gen = torch.Generator().manual_seed(4)
+            f = 8
+            x, x_h = torch.randn(n, f, generator=gen), torch.randn(n_ho, f, generator=gen)
+            y = torch.randint(0, 3, (n,), generator=gen)
+            params = od.init_params(3, (f, f), [12, 10, 6], seed=5)
+            want = od.loss_and_grads(params, om.dbgnn_inputs(layers, 2, "last", x=x, x_h=x_h), y)
+            tg = type("G", (), {})()
+            tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n, **({} if w is None else {"edge_weight": w}))
+            comm = pd.Comm()
+            asked = {"x_h": 0}
+
+            def load_xh(rows):
+                asked["x_h"] += int(rows.numel())
+                return x_h.index_select(0, rows)
+            shard = pd.build_dbgnn_shard(tg, delta, x, load_xh, lambda rows: y.index_select(0, rows), comm, CpuOpsNode())
+            sz = pd.global_sizes(shard, comm)
+            assert shard.sizes.get("builder") == "fused", kind
+            assert sz["U2"] == n_ho and sz["A2"] == layers[2]["edge_index"].size(1) and sz["E2"] == om.temporal_lift_sorted(ei, t, delta, n).size(1)
+            assert asked["x_h"] == shard.ho.n_own                                          # the loader is asked for the owned rows only: halo rows travel
+            assert shard.ho.send_unique and shard.ho.send_idx is None and shard.ho.send_prefix == shard.ho.n_send
+            gathered = comm.all_gather_ints([shard.ho.n_own, shard.fo.n_own, sz["E2_local"], shard.ho.n_send, shard.ho.n_halo], ei.device)
+            assert sum(r[0] for r in gathered) == n_ho and sum(r[1] for r in gathered) == n and sum(r[2] for r in gathered) == sz["E2"]
+            assert sum(r[3] for r in gathered) == sum(r[4] for r in gathered)              # every row sent is somebody's halo row
+            ids = shard.ho.local_rows()                                                    # (collective: the halo ids are fetched on first use)
+            assert torch.equal(torch.sort(ids[: shard.ho.n_own]).values, torch.arange(shard.ho.lo, shard.ho.hi))
+            torch.testing.assert_close(shard.x_h, x_h.index_select(0, ids))               # owned rows in send order + halo rows = the rows the ids name
+            net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=[12, 10, 6])
+            net.load_state_dict(params)
+            sharded = pd.ShardedDBGNN(net, comm, ops=CpuOpsNode())
+            _check_against_oracle(sharded, shard, net, *want, shard.fo.lo, shard.fo.hi)
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_node_range_partition_matches_single_process_oracle_gloo(world):
+    _spawn(_node_partition_worker, world)
+
+
+def test_node_range_partition_world8_threads_match_oracle():
+    import pathpyg_amd as pp
+    from pathpyg_amd import distributed as pd
+    from oracle import dbgnn as od
+    from oracle import model as om
+    from tests.cpu_ops import CpuOpsNode
+    rng = np.random.default_rng(47)
+    m, n, delta, span, f = 2400, 200, 40, 2400, 8
+    ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+    t = torch.from_numpy(np.sort(rng.integers(0, span, m)))
+    layers = om.layers_from_temporal(ei, t, n, delta=delta, max_order=2)
+    gen = torch.Generator().manual_seed(4)
+    x, x_h = torch.randn(n, f, generator=gen), torch.randn(layers[2]["num_nodes"], f, generator=gen)
+    y = torch.randint(0, 3, (n,), generator=gen)
+    params = od.init_params(3, (f, f), [12, 10, 6], seed=5)
+    want_out, want_loss, want_grads = od.loss_and_grads(params, om.dbgnn_inputs(layers, 2, "last", x=x, x_h=x_h), y)
+    tg = type("G", (), {})()
+    tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n)
+
+    def body(comm):
+        net = pp.nn.DBGNN(num_classes=3, num_features=(f, f), hidden_dims=[12, 10, 6])
+        net.load_state_dict(params)
+        sharded = pd.ShardedDBGNN(net, comm, ops=CpuOpsNode())
+        shard = pd.build_dbgnn_shard(tg, delta, x, x_h, y, comm, CpuOpsNode())
+        out = sharded(shard)
+        loss = sharded.loss(shard)
+        loss.backward()
+        pd.all_reduce_gradients(net, average=False, comm=comm)
+        total = loss.detach().clone().reshape(1)
+        comm.all_reduce_(total)
+        return {"out": out.detach(), "lo": shard.fo.lo, "hi": shard.fo.hi, "loss": total[0], "grads": {k: p.grad.clone() for k, p in net.named_parameters()},
+                "builder": shard.sizes.get("builder"), "events": list(comm.events)}
+
+    results = pd.run_thread_world(8, body)
+    assert sum(r["hi"] - r["lo"] for r in results) == n and all(r["builder"] == "fused" for r in results)
+    for r in results:
+        torch.testing.assert_close(r["out"], want_out[r["lo"]: r["hi"]], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(r["loss"], want_loss, rtol=1e-5, atol=1e-6)
+        for name, gr in r["grads"].items():
+            torch.testing.assert_close(gr, want_grads[name], rtol=1e-3, atol=1e-5, msg=lambda s_: f"{name}: {s_}")
+        assert any(kind == "exchange" and over for kind, _, over in r["events"])           # the halo feature rows travel as a logged (async) exchange
 
 
 # ------------------------------------------------------------------------------------------------------------------
