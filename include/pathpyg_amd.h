@@ -119,7 +119,11 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
  * first, grouped by the owner of c and ordered by (c, b) — the receiver's halo order —, so the send list of every layer exchange is the
  * contiguous prefix [0, rows sent) of a row matrix (no pack, no ids, no request round: one all-to-all of rows fills the peers' halos); rows
  * nobody gathers from follow.  fo_bwd_idx / fo_w are in that local order (fo_bwd_ptr stays lexicographic: block sizes per node);
- * send_slot [m]: local row -> its position in the prefix, -1 behind it; row_of [m]: local row -> lexicographic row (global id - first owned id).  The first 8 int64 of ws = {U2, status, A2, E2, A1, halo rows, rows sent, -}, then recv_ptr [world + 1] and
+ * send_slot [m]: local row -> its position in the prefix, -1 behind it; row_of [m]: local row -> lexicographic row (global id - first owned id).
+ * In that order ALL rows are grouped by their successor c, so the bipartite "last" plan (utils/dbgnn.py:10-46) of the shard needs no sort either:
+ * destinations = all first-order nodes in the rank-major padded layout (node c of rank r at r * pad_rows + c - cuts[r]; pad_rows >= the largest
+ * range), bip_fwd_ptr [world * pad_rows + 1] / bip_fwd_idx [m] (local rows per destination), bip_bwd_ptr [m + 1] / bip_bwd_idx [m] (one
+ * destination per row), bip_self [world * pad_rows] (in-degrees) — all written by the count phase.  The first 8 int64 of ws = {U2, status, A2, E2, A1, halo rows, rows sent, -}, then recv_ptr [world + 1] and
  * send_ptr [world + 1] (rows from / to every rank, as offsets).  Between count and fill the caller fetches ho_deg of its halo rows
  * (ho_deg[U2 ..]) from their owners and all-gathers fo_deg (the count pass fills the owned entries of the [num_nodes] array).  Fill: the
  * order-2 plan over the local source space [owned | halo] as in pp_debruijn2_fill, and the rank's FIRST-ORDER SHARD with a dense halo — local
@@ -129,8 +133,9 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
 int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
                             const int64_t* cuts, int world, int rank, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
                             int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
-                            float* ho_deg, float* fo_deg, int32_t* send_slot, int32_t* row_of, int32_t* fo_shard_bwd_ptr, void* ws, size_t ws_bytes,
-                            pp_stream_t stream);
+                            float* ho_deg, float* fo_deg, int32_t* send_slot, int32_t* row_of, int32_t* fo_shard_bwd_ptr, int64_t pad_rows,
+                            int32_t* bip_fwd_ptr, int32_t* bip_fwd_idx, int32_t* bip_bwd_ptr, int32_t* bip_bwd_idx, float* bip_self, void* ws,
+                            size_t ws_bytes, pp_stream_t stream);
 int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own, int delta_kind, int64_t delta_i, double delta_f,
                            const float* weight, const int32_t* fo_bwd_ptr, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr,
                            const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx,

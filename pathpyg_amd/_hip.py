@@ -774,7 +774,7 @@ class DeBruijn2Part:
     the device until :func:`debruijn2_part_fill`."""
 
     __slots__ = ("m", "n", "lo", "n_own", "world", "args", "ws", "bufs", "u2", "status", "a2", "e2", "a1", "n_halo", "n_send", "recv_counts", "send_counts",
-                 "row_of", "send_slot", "ho_deg", "succ")
+                 "row_of", "send_slot", "ho_deg", "succ", "bip", "pad_rows")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -782,7 +782,7 @@ class DeBruijn2Part:
 
 
 def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, node_lo: int, node_hi: int, cuts_dev: torch.Tensor,
-                         rank: int, delta, weight: torch.Tensor | None = None) -> "DeBruijn2Part | None":
+                         rank: int, delta, weight: torch.Tensor | None = None, pad_rows: int | None = None) -> "DeBruijn2Part | None":
     """The order-2 builder for the rank that owns the nodes ``[node_lo, node_hi)`` of a partitioned stream: ``edge_index`` / ``time`` hold the
     (time-sorted) events that start or end in that range.  Everything :func:`debruijn2` counts, restricted to the owned middle nodes, plus the
     halo numbering (sources (a, b) with a foreign a, in (owner of a, b, a) order behind the owned rows) and the LOCAL ROW ORDER: owned rows (b, c)
@@ -803,6 +803,7 @@ def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
         if weight.dtype != torch.float32 or weight.numel() != m:
             return None
         weight = weight.contiguous()
+    pad_rows = max(int(pad_rows) if pad_rows is not None else n, 1)          # rows per rank of the padded first-order layout (>= the largest range)
     kind, di, df = resolve_delta(time.dtype, delta)
     L = lib()
     with torch.cuda.device(dev):
@@ -813,11 +814,14 @@ def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
         bufs = {"fo_bwd_ptr": torch.empty(n_own + 1, **i32), "fo_fwd_ptr": torch.empty(n_own + 1, **i32), "fo_bwd_idx": torch.empty(cap, **i32),
                 "fo_w": torch.empty(cap, **f32), "ho_fwd_ptr": torch.empty(cap + 1, **i32), "ho_bwd_ptr": torch.empty(cap + 1, **i32),
                 "ho_deg": torch.empty(cap, **f32), "fo_deg": torch.empty(max(n, 1), **f32), "row_of": torch.empty(cap, **i32),
-                "send_slot": torch.empty(cap, **i32), "fo_shard_bwd_ptr": torch.empty(n + 1, **i32)}
+                "send_slot": torch.empty(cap, **i32), "fo_shard_bwd_ptr": torch.empty(n + 1, **i32),
+                "bip_fwd_ptr": torch.empty(world * pad_rows + 1, **i32), "bip_fwd_idx": torch.empty(cap, **i32), "bip_bwd_ptr": torch.empty(cap + 1, **i32),
+                "bip_bwd_idx": torch.empty(cap, **i32), "bip_self": torch.empty(world * pad_rows, **f32)}
         tcode = _DTYPE_CODE[time.dtype]
         check(L.pp_debruijn2_part_count(_p(ei), _p(time), tcode, m, n, int(node_lo), n_own, _p(cuts_dev), world, int(rank), kind, di, df, _p(weight),
                                         _p(bufs["fo_bwd_ptr"]), _p(bufs["fo_bwd_idx"]), _p(bufs["fo_w"]), _p(bufs["fo_fwd_ptr"]), _p(bufs["ho_fwd_ptr"]),
-                                        _p(bufs["ho_bwd_ptr"]), _p(bufs["ho_deg"]), _p(bufs["fo_deg"]), _p(bufs["send_slot"]), _p(bufs["row_of"]), _p(bufs["fo_shard_bwd_ptr"]),
+                                        _p(bufs["ho_bwd_ptr"]), _p(bufs["ho_deg"]), _p(bufs["fo_deg"]), _p(bufs["send_slot"]), _p(bufs["row_of"]), _p(bufs["fo_shard_bwd_ptr"]), pad_rows, _p(bufs["bip_fwd_ptr"]),
+                                        _p(bufs["bip_fwd_idx"]), _p(bufs["bip_bwd_ptr"]), _p(bufs["bip_bwd_idx"]), _p(bufs["bip_self"]),
                                         _p(ws), ws.numel(), _stream()), "pp_debruijn2_part_count")
         head = ws[: 8 * (8 + 2 * (world + 1))].view(torch.int64).tolist()                 # the ONE read-back of this rank's graph construction
     u2, status, a2, e2, a1, n_halo, n_send = head[:7]
@@ -828,7 +832,9 @@ def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
     return DeBruijn2Part(m=m, n=n, lo=int(node_lo), n_own=n_own, world=world, args=(tcode, kind, di, df, weight), ws=ws, bufs=bufs, u2=u2, status=status,
                          a2=a2, e2=e2, a1=a1, n_halo=n_halo, n_send=n_send, recv_counts=[recv_ptr[r + 1] - recv_ptr[r] for r in range(world)],
                          send_counts=[send_ptr[r + 1] - send_ptr[r] for r in range(world)], row_of=bufs["row_of"][:u2],
-                         send_slot=bufs["send_slot"][:u2], ho_deg=bufs["ho_deg"], succ=bufs["fo_bwd_idx"][:u2])
+                         send_slot=bufs["send_slot"][:u2], ho_deg=bufs["ho_deg"], succ=bufs["fo_bwd_idx"][:u2], pad_rows=pad_rows,
+                         bip=CsrPlan(n_dst=world * pad_rows, n_src=u2, fwd_ptr=bufs["bip_fwd_ptr"], fwd_idx=bufs["bip_fwd_idx"][:u2], fwd_val=None,
+                                     bwd_ptr=bufs["bip_bwd_ptr"][: u2 + 1], bwd_idx=bufs["bip_bwd_idx"][:u2], bwd_val=None, self_coef=bufs["bip_self"]))
 
 
 def debruijn2_part_fill(c: DeBruijn2Part):

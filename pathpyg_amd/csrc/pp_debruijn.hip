@@ -596,12 +596,44 @@ __global__ __launch_bounds__(kBlock) void k_db2_send_keys(int64_t cap, const int
                                                          int64_t lo, int64_t n_own, int64_t num_nodes, uint32_t* __restrict__ keys) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= cap) return;
-    uint32_t key = (uint32_t)num_nodes;
+    uint32_t key = (uint32_t)(num_nodes + n_own);           // (rows beyond U2: behind everything)
     if (r < result[0]) {
         const int64_t c = fo_bwd_idx[r];
-        if (c < lo || c >= lo + n_own) key = (uint32_t)c;
+        key = (c < lo || c >= lo + n_own) ? (uint32_t)c : (uint32_t)(num_nodes + (c - lo));      // kept rows: behind the sent ones, by successor as well
     }
     keys[r] = key;
+}
+
+// bipartite "last" plan of a partition shard without another sort: in the local row order ALL rows are grouped by their successor c (the send
+// prefix by foreign c, the kept rows by own c), so the rows that end in c are one contiguous range.  Destinations live in the rank-major
+// padded layout (node c of rank r at r * cap + c - cuts[r]: the partial sums reduce-scatter without a copy).
+__global__ __launch_bounds__(kBlock) void k_db2_bip_count(int64_t cap_m, const int64_t* __restrict__ result, const int32_t* __restrict__ succ,
+                                                         const int64_t* __restrict__ cuts, int world, int64_t cap_n, int32_t* __restrict__ bwd_idx,
+                                                         int32_t* __restrict__ bwd_ptr, int32_t* __restrict__ cnt) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k > cap_m || k > result[0]) return;
+    bwd_ptr[k] = (int32_t)k;                               // every order-2 row ends in exactly one first-order node
+    if (k == result[0]) return;
+    const int64_t c = succ[k];
+    const int r = owner_of(c, cuts, world);
+    const int32_t pd = (int32_t)(r * cap_n + (c - cuts[r]));
+    bwd_idx[k] = pd;
+    atomicAdd(&cnt[pd], 1);
+}
+
+// fwd_idx: the local rows in padded-destination order = [rows for ranks below me | kept rows | rows for ranks above me]; self_coef = in-degree
+__global__ __launch_bounds__(kBlock) void k_db2_bip_fill(int64_t total, const int64_t* __restrict__ result, const uint32_t* __restrict__ send_keys_s,
+                                                        int64_t cap_m, int64_t lo, int64_t num_nodes, int64_t n_pad, const int32_t* __restrict__ cnt,
+                                                        int32_t* __restrict__ fwd_idx, float* __restrict__ self_coef) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= total) return;
+    if (j < n_pad) self_coef[j] = (float)cnt[j];
+    const int64_t u2 = result[0];
+    if (j >= u2) return;
+    const int64_t n_below = lower_bound_dev<uint32_t, int64_t>(send_keys_s, 0, cap_m, (uint32_t)lo);              // rows whose successor lies below my range
+    const int64_t n_send = lower_bound_dev<uint32_t, int64_t>(send_keys_s, n_below, cap_m, (uint32_t)num_nodes);
+    const int64_t n_kept = u2 - n_send;
+    fwd_idx[j] = (int32_t)(j < n_below ? j : (j < n_below + n_kept ? n_send + (j - n_below) : j - n_kept));
 }
 
 // send_ptr[r] = first position of the sorted send keys that belongs to rank r (r = 0 .. world); recv_ptr from the sorted halo keys; both
@@ -758,6 +790,9 @@ struct Db2Part {                   // node range of a partition shard (one GPU: 
     int world, me;
     int32_t *send_slot, *row_of;   // [m] each: local row -> its position in the send prefix (-1 behind it) / its lexicographic row
     int32_t* fo2_bwd_ptr;          // [num_nodes + 1]: source-major row pointers of the first-order shard (dense local source order)
+    int64_t cap_n;                 // rows per rank of the padded first-order layout (bipartite partial sums)
+    int32_t *bip_fwd_ptr, *bip_fwd_idx, *bip_bwd_ptr, *bip_bwd_idx;      // [world * cap_n + 1], [m], [m + 1], [m]
+    float* bip_self;               // [world * cap_n]
 };
 
 static int db2_count(const char* who, const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t n, const Db2Part& pt, int delta_kind,
@@ -819,12 +854,24 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
         PP_LAUNCH_CHECK();
         k_db2_send_keys<<<egrid, kBlock, 0, st>>>(m, w.result, w.succ_old, pt.lo, n_own, n, w.xkeys);
         PP_LAUNCH_CHECK();
-        rc = sort_pairs<uint32_t>(w.xkeys, nullptr, w.xkeys_s, w.xorder, m, 0, bits_for((uint64_t)n), w.scratch, w.scratch_bytes, st);
+        rc = sort_pairs<uint32_t>(w.xkeys, nullptr, w.xkeys_s, w.xorder, m, 0, bits_for((uint64_t)(n + n_own)), w.scratch, w.scratch_bytes, st);
         if (rc != PP_OK) return rc;
         PP_HIP(hipMemsetAsync(w.perm, 0, (size_t)m * sizeof(int32_t), st));      // (lanes beyond a node's block read perm[row0 + l]: any valid row will do)
         k_db2_apply_perm<<<egrid, kBlock, 0, st>>>(m, w.result, w.xkeys_s, w.xorder, n, w.succ_old, w.w_old, w.perm, fo_bwd_idx, fo_w, pt.send_slot, pt.row_of);
         PP_LAUNCH_CHECK();
         perm = w.perm;
+        // 2b'. bipartite plan from the same order (no sort): count per padded destination (in the buffer of its self coefficients), scan, rotation
+        const int64_t n_pad = (int64_t)pt.world * pt.cap_n;
+        PP_REQUIRE(pt.cap_n >= 1 && n_pad < (int64_t)0x7ffffff0 && scan_ws_bytes(n_pad) <= w.scratch_bytes, PP_ERR_ARG, "%s: bad padded first-order layout", who);
+        int32_t* bcnt = (int32_t*)pt.bip_self;
+        PP_HIP(hipMemsetAsync(bcnt, 0, (size_t)n_pad * sizeof(int32_t), st));
+        k_db2_bip_count<<<(unsigned)ceil_div(m + 1, kBlock), kBlock, 0, st>>>(m, w.result, fo_bwd_idx, pt.cuts, pt.world, pt.cap_n, pt.bip_bwd_idx, pt.bip_bwd_ptr, bcnt);
+        PP_LAUNCH_CHECK();
+        rc = exclusive_scan<int32_t, int32_t>(bcnt, n_pad, pt.bip_fwd_ptr, true, nullptr, w.scratch, w.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+        const int64_t total = n_pad > m ? n_pad : m;
+        k_db2_bip_fill<<<(unsigned)ceil_div(total, kBlock), kBlock, 0, st>>>(total, w.result, w.xkeys_s, m, pt.lo, n, n_pad, bcnt, pt.bip_fwd_idx, pt.bip_self);
+        PP_LAUNCH_CHECK();
     }
     k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, fo_bwd_ptr, perm, w.src_t);
     PP_LAUNCH_CHECK();
@@ -906,7 +953,7 @@ extern "C" {
 int pp_debruijn2_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i,
                        double delta_f, const float* weight, int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr,
                        int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr, float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, pp_stream_t stream) {
-    const Db2Part whole{0, num_nodes, nullptr, 1, 0, nullptr, nullptr, nullptr};
+    const Db2Part whole{0, num_nodes, nullptr, 1, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     return db2_count("pp_debruijn2_count", edge_index, time, time_dtype, m, num_nodes, whole, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_bwd_idx,
                      fo_w, fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -924,11 +971,13 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
 int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
                             const int64_t* cuts, int world, int rank, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
                             int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
-                            float* ho_deg, float* fo_deg, int32_t* send_slot, int32_t* row_of, int32_t* fo_shard_bwd_ptr, void* ws, size_t ws_bytes,
-                            pp_stream_t stream) {
-    PP_REQUIRE(world >= 2 && cuts != nullptr && send_slot != nullptr && row_of != nullptr && fo_shard_bwd_ptr != nullptr, PP_ERR_ARG,
-               "pp_debruijn2_part_count: world >= 2 with cuts and the send_slot / row_of / fo_shard_bwd_ptr buffers");
-    const Db2Part pt{node_lo, n_own, cuts, world, rank, send_slot, row_of, fo_shard_bwd_ptr};
+                            float* ho_deg, float* fo_deg, int32_t* send_slot, int32_t* row_of, int32_t* fo_shard_bwd_ptr, int64_t pad_rows,
+                            int32_t* bip_fwd_ptr, int32_t* bip_fwd_idx, int32_t* bip_bwd_ptr, int32_t* bip_bwd_idx, float* bip_self, void* ws,
+                            size_t ws_bytes, pp_stream_t stream) {
+    PP_REQUIRE(world >= 2 && cuts != nullptr && send_slot != nullptr && row_of != nullptr && fo_shard_bwd_ptr != nullptr && bip_fwd_ptr != nullptr &&
+               bip_fwd_idx != nullptr && bip_bwd_ptr != nullptr && bip_bwd_idx != nullptr && bip_self != nullptr, PP_ERR_ARG,
+               "pp_debruijn2_part_count: world >= 2 with cuts and every output buffer");
+    const Db2Part pt{node_lo, n_own, cuts, world, rank, send_slot, row_of, fo_shard_bwd_ptr, pad_rows, bip_fwd_ptr, bip_fwd_idx, bip_bwd_ptr, bip_bwd_idx, bip_self};
     return db2_count("pp_debruijn2_part_count", edge_index, time, time_dtype, m, num_nodes, pt, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr,
                      fo_bwd_idx, fo_w, fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -1150,7 +1150,8 @@ def _build_partitioned_by_node(g, delta, x, x_h, y, comm: Comm, ops, weight: str
     dev = ns.ei.device
     if ns.w is not None and ns.w.dtype != torch.float32:
         return None
-    c = ops.debruijn2_part_count(ns.ei, ns.time, n, lo_n, hi_n, ns.cuts_t, rank, delta, ns.w)
+    cap_n = max(max(fo_cuts[r + 1] - fo_cuts[r] for r in range(world)), 1)          # rows per rank of the padded first-order layout
+    c = ops.debruijn2_part_count(ns.ei, ns.time, n, lo_n, hi_n, ns.cuts_t, rank, delta, ns.w, cap_n)
     comm.mark("build: 1 order-2 builder, count pass (sorts, successor blocks, halo numbering, send lists)")
     # sizes of all ranks: global order-2 id ranges, E2, and whether everybody can stay on this path (one tiny collective)
     sizes_all = comm.all_gather_ints([c.u2 if c is not None else 0, c.e2 if c is not None else 0, 1 if (c is None or c.status & 4) else 0], dev)
@@ -1170,7 +1171,6 @@ def _build_partitioned_by_node(g, delta, x, x_h, y, comm: Comm, ops, weight: str
     comm.exchange_rows(c.ho_deg[: c.n_send], c.send_counts, c.recv_counts, out=c.ho_deg[n_own: n_own + n_halo])
     comm.mark("build: 2 halo exchanges (degrees; feature rows asynchronously)")
     # first-order degrees of ALL nodes (the count pass filled my slice): one all-gather of N floats
-    cap_n = max(max(fo_cuts[r + 1] - fo_cuts[r] for r in range(world)), 1)
     fo_deg = c.bufs["fo_deg"]
     mine = fo_deg[lo_n:hi_n]
     gathered = comm.all_gather_rows(mine if hi_n - lo_n == cap_n else torch.nn.functional.pad(mine, (0, cap_n - (hi_n - lo_n))))
@@ -1194,9 +1194,11 @@ def _build_partitioned_by_node(g, delta, x, x_h, y, comm: Comm, ops, weight: str
                           halo_ids=halo_ids, send_idx=fo_send_idx, send_counts=fo_send_counts, recv_counts=fo_recv_counts, back_ptr=back_ptr,
                           back_idx=back_idx, send_unique=False, send_slot=None, dense=True)
     comm.mark("build: first-order shard")
-    bip, cap = _bipartite_shard(torch.arange(n_own, dtype=torch.int64, device=dev), c.succ.to(torch.int64), n_own, fo_cuts, comm, ops, src_sorted=True)
+    bip, cap = getattr(c, "bip", None), cap_n                  # (the builder's count pass wrote the bipartite plan: the local row order groups the rows by successor)
+    if bip is None:
+        bip, cap = _bipartite_shard(torch.arange(n_own, dtype=torch.int64, device=dev), c.succ.to(torch.int64), n_own, fo_cuts, comm, ops, src_sorted=True)
     ops.check_plan_status(pending)
-    comm.mark("build: bipartite plan + status read-back")
+    comm.mark("build: bipartite plan")
     x_loc = _shard_rows(x, fo_shard, comm)
     xh_pending.wait()
     comm.mark("build: feature rows (owned + halo)")

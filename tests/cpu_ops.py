@@ -321,7 +321,7 @@ class CpuOpsNode(CpuOps):
     MAX_LIST = 64           # the builder's limit: events per node and side
 
     @staticmethod
-    def debruijn2_part_count(edge_index, time, num_nodes, node_lo, node_hi, cuts_dev, rank, delta, weight=None):
+    def debruijn2_part_count(edge_index, time, num_nodes, node_lo, node_hi, cuts_dev, rank, delta, weight=None, pad_rows=None):
         src, dst = edge_index[0].long(), edge_index[1].long()
         n, lo, hi = int(num_nodes), int(node_lo), int(node_hi)
         cuts = [int(v) for v in cuts_dev.tolist()]
