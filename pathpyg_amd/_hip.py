@@ -492,7 +492,7 @@ class CsrPlan:
     """CSR pair of one propagation: ``fwd`` rows are the destinations, ``bwd`` rows the sources (transposed)."""
 
     __slots__ = ("n_dst", "n_src", "fwd_ptr", "fwd_idx", "fwd_val", "bwd_ptr", "bwd_idx", "bwd_val", "self_coef", "fwd_heavy", "bwd_heavy",
-                 "dst_order", "edge_ordered")          # edge_ordered: bwd_idx[e] is the destination of edge e (plan of a row-sorted edge list)
+                 "dst_order", "edge_ordered", "aug")          # edge_ordered: bwd_idx[e] is the destination of edge e (plan of a row-sorted edge list)
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -849,8 +849,11 @@ def debruijn2_part_fill(c: DeBruijn2Part):
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         n_src = c.u2 + c.n_halo
+        # source-major arrays with room for n_send entries in front: the AUGMENTED rows of the backward pass (see `aug` below) are
+        # [one unit entry per sent row | the plain entries], i.e. the same arrays read from their start
+        bwd_idx_all, bwd_val_all = torch.empty(c.n_send + c.a2, **i32), torch.empty(c.n_send + c.a2, **f32)
         ho = CsrPlan(n_dst=c.u2, n_src=n_src, fwd_ptr=b["ho_fwd_ptr"][: c.u2 + 1], fwd_idx=torch.empty(c.a2, **i32), fwd_val=torch.empty(c.a2, **f32),
-                     bwd_ptr=b["ho_bwd_ptr"][: n_src + 1], bwd_idx=torch.empty(c.a2, **i32), bwd_val=torch.empty(c.a2, **f32),
+                     bwd_ptr=b["ho_bwd_ptr"][: n_src + 1], bwd_idx=bwd_idx_all[c.n_send:], bwd_val=bwd_val_all[c.n_send:],
                      self_coef=torch.empty(c.u2, **f32))
         fo = CsrPlan(n_dst=c.n_own, n_src=c.n, fwd_ptr=b["fo_fwd_ptr"], fwd_idx=torch.empty(c.a1, **i32), fwd_val=torch.empty(c.a1, **f32),
                      bwd_ptr=b["fo_shard_bwd_ptr"], bwd_idx=torch.empty(c.a1, **i32), bwd_val=torch.empty(c.a1, **f32),
@@ -862,6 +865,14 @@ def debruijn2_part_fill(c: DeBruijn2Part):
                                            _p(b["fo_shard_bwd_ptr"]), _p(fo.bwd_idx), _p(fo.bwd_val), _p(torch.empty(2 * c.a2, **i32)), _p(c.ws),
                                            c.ws.numel(), _stream()), "pp_debruijn2_part_fill")
         indeg = (b["fo_fwd_ptr"][1:] - b["fo_fwd_ptr"][:-1]).to(torch.float32)
+        # Augmented source-major rows of the OWNED rows for the backward pass: a sent row (local id k < n_send) has no local out-edge — its
+        # out-edges live on the rank that owns its head node, whose partial sum comes back as row k of the returned halo sums.  With those
+        # stored behind dpre ([dpre | recv]) the returned sum is ONE more CSR entry (n_own + k, 1.0) of row k, and the fused backward kernels
+        # (pp_gcn_backward_f32 / pp_gcn_input_grad_f32) do the fold, the self term, both products and the weight gradient in one pass.
+        torch.arange(c.u2, c.u2 + c.n_send, out=bwd_idx_all[: c.n_send])
+        bwd_val_all[: c.n_send] = 1.0
+        aug_ptr = b["ho_bwd_ptr"][: c.u2 + 1] + torch.arange(c.u2 + 1, **i32).clamp_(max=c.n_send)
+        ho.aug = (aug_ptr, bwd_idx_all, bwd_val_all)
     return ho, fo, indeg
 
 
@@ -1049,7 +1060,8 @@ def dense(a: torch.Tensor, weight: torch.Tensor, transposed: bool, bias: torch.T
     return out, colsum
 
 
-def spmm_act_backward(ptr, idx, val, n_rows: int, d: torch.Tensor, z: torch.Tensor, want_colsum: bool, drop: tuple | None = None):
+def spmm_act_backward(ptr, idx, val, n_rows: int, d: torch.Tensor, z: torch.Tensor, want_colsum: bool, drop: tuple | None = None,
+                      out: torch.Tensor | None = None):
     """``dx = (A d) * elu'(z)`` with ``elu'`` from the stored activation ``z`` (``z > 0 ? 1 : z + 1``) and, optionally, the
     column sums of ``dx`` — one pass.  ``drop = (p, seed, tag, row0)``: ``z`` is stored dropped; mask and ``1 / (1 - p)`` go into ``dx``."""
     dev = require_device(d, z)
@@ -1057,7 +1069,9 @@ def spmm_act_backward(ptr, idx, val, n_rows: int, d: torch.Tensor, z: torch.Tens
     d, z = d.contiguous(), z.contiguous()
     f = d.size(1)
     with torch.cuda.device(dev):
-        dx = torch.empty((n_rows, f), dtype=torch.float32, device=dev)
+        dx = torch.empty((n_rows, f), dtype=torch.float32, device=dev) if out is None else out
+        if out is not None and (tuple(out.shape) != (n_rows, f) or out.dtype != torch.float32 or not out.is_contiguous()):
+            raise ValueError("spmm_act_backward: out must be a contiguous fp32 [n_rows, F] tensor")
         colsum = torch.empty(f, dtype=torch.float32, device=dev) if want_colsum else None
         check(lib().pp_spmm_act_backward_drop_f32(_p(ptr), _p(idx), _p(val), n_rows, _p(d), f, _p(z), _p(colsum), _p(dx), dp, dseed, dtag, drow0,
                                                   _stream()), "pp_spmm_act_backward_drop_f32")
@@ -1118,7 +1132,8 @@ def gcn_backward(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, x: t
     dpre, x, weight = dpre.contiguous(), x.contiguous(), weight.contiguous()
     m, k = weight.shape
     n_self = n_rows if n_self is None else int(n_self)
-    if dpre.size(1) != m or x.size(1) != k or x.size(0) != n_rows or dpre.size(0) != n_self or n_self > n_rows:
+    # (dpre may hold MORE rows than n_self: an augmented CSR of a partition shard also gathers the returned halo sums stored behind the owned rows)
+    if dpre.size(1) != m or x.size(1) != k or x.size(0) != n_rows or dpre.size(0) < n_self or n_self > n_rows:
         raise ValueError("gcn_backward: shapes do not match")
     L = lib()
     with torch.cuda.device(dev):
@@ -1148,7 +1163,7 @@ def gcn_input_grad(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, we
     dpre, weight = dpre.contiguous(), weight.contiguous()
     m, k = weight.shape
     n_self = n_rows if n_self is None else int(n_self)
-    if dpre.size(1) != m or dpre.size(0) != n_self or n_self > n_rows or (x_act is not None and tuple(x_act.shape) != (n_rows, k)):
+    if dpre.size(1) != m or dpre.size(0) < n_self or n_self > n_rows or (x_act is not None and tuple(x_act.shape) != (n_rows, k)):
         raise ValueError("gcn_input_grad: shapes do not match")
     if x_act is not None:
         x_act = x_act.contiguous()

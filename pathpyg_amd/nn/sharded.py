@@ -157,6 +157,29 @@ class HipOps:
         d_in, colsum = _hip.dense(total, weight, False, None, x_own, True)
         return d_in, colsum, dw
 
+    # ---- backward of a layer on a shard whose plan carries AUGMENTED source-major rows (node-range partition, _hip.debruijn2_part_fill): the
+    # halo sums the peers return are stored behind dpre and enter as one more CSR entry of the sent rows — the fused single-GPU kernels run unchanged
+    @staticmethod
+    def aug_backward_ok(gs, weight: torch.Tensor) -> bool:
+        return getattr(gs.plan, "aug", None) is not None and HipOps.owned_backward_ok(weight)
+
+    @staticmethod
+    def halo_transposed_sum(plan, dpre: torch.Tensor) -> torch.Tensor:
+        """``A^T dpre`` for the HALO source rows only: ``[n_src - n_dst, M]`` (what travels back to the owners)."""
+        return _hip.spmm(plan.bwd_ptr[plan.n_dst:], plan.bwd_idx, plan.bwd_val, plan.n_src - plan.n_dst, dpre, heavy=None)
+
+    @staticmethod
+    def aug_backward(gs, dbuf: torch.Tensor, x_own: torch.Tensor, weight: torch.Tensor, saved):
+        """``dbuf = [dpre (n_own rows) | returned halo sums (n_send rows)]`` -> ``(d_lin * ELU'(x_own), its column sums, dW)`` on the owned rows."""
+        m, k = weight.shape
+        aug_ptr, aug_idx, aug_val = gs.plan.aug
+        n_own = gs.n_own
+        if _hip.gcn_fused_supported(k, m) == 1:
+            return _hip.gcn_backward(aug_ptr, aug_idx, aug_val, n_own, dbuf, gs.plan.self_coef, x_own, weight, True, True, n_self=n_own)
+        dw = _hip.weight_grad(dbuf[:n_own], saved, want_bias=False)[0]
+        d_in, colsum = _hip.gcn_input_grad(aug_ptr, aug_idx, aug_val, n_own, dbuf, gs.plan.self_coef, weight, x_own, True, n_self=n_own)
+        return d_in, colsum, dw
+
     @staticmethod
     def act_combine(d_lin_own: torch.Tensor, extra, y_below: torch.Tensor):
         """``((d_lin_own + extra) * ELU'(y_below), column sums)``: gradient w.r.t. the pre-activation of the layer below and its bias."""
@@ -167,11 +190,12 @@ class HipOps:
     spmm = staticmethod(_hip.spmm)
 
     @staticmethod
-    def spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum, drop=None):
-        """``drop = (p, seed, tag, row0[, rows])``: ``rows`` = explicit global row ids (shards whose local row order is not the global one)."""
+    def spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum, drop=None, out=None):
+        """``drop = (p, seed, tag, row0[, rows])``: ``rows`` = explicit global row ids (shards whose local row order is not the global one).
+        ``out``: write the result there (the head of a ``[dpre | returned halo sums]`` buffer)."""
         rows = drop[4] if (drop is not None and len(drop) > 4) else None
         if d.size(1) % 4 == 0 and d.size(1) <= 256 and rows is None:
-            return _hip.spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum, drop)
+            return _hip.spmm_act_backward(ptr, idx, val, n_rows, d, z, want_colsum, drop, out=out)
         g = _hip.spmm(ptr, idx, val, n_rows, d)                                                                          # odd widths / explicit rows: two kernels
         if drop is not None:
             return _hip.dropout_act_backward(g, z, drop[0], drop[1], drop[2], 0 if rows is not None else drop[3], rows, True, want_colsum)
@@ -518,6 +542,13 @@ class _ShardedTrunk(torch.autograd.Function):
             """Halo-gradient rows of layer l are back: fold them into the owned rows, ELU' of the layer below, its bias gradient."""
             s = st[name]
             gs = s["gs"]
+            if s["pending"][0] == "aug":
+                _, dbuf, x_in, sv, weight = s["pending"]
+                s["handle"].wait()                                  # (the returned halo sums landed in dbuf[n_own:])
+                s["d"], colsum, s["grads"][2 * l] = ops.aug_backward(gs, dbuf, x_in[: gs.n_own], weight, sv)
+                s["grads"][2 * l - 1] = colsum
+                s["pending"] = None
+                return
             if s["pending"][0] == "owned":
                 _, t_sum, x_in, dpre_l, sv, weight = s["pending"]
                 recv = s["handle"].wait()
@@ -547,6 +578,17 @@ class _ShardedTrunk(torch.autograd.Function):
             if l == 0:
                 s["grads"][0] = ops.layer_backward(gs.plan, s["d"], x_in, weight, saved[0], False, None)[2]
                 return
+            if OWNED_ROW_BACKWARD and gs.send_prefix is not None and getattr(ops, "aug_backward_ok", lambda g_, w_: False)(gs, weight):
+                # the peers' partial sums come back into the tail of [dpre | recv]; the fused backward kernel then runs on the owned rows alone
+                d = s["d"]
+                dbuf = s.pop("dbuf", None)
+                if dbuf is None or dbuf.data_ptr() != d.data_ptr():
+                    dbuf = torch.empty((gs.n_own + gs.send_prefix, d.size(1)), dtype=d.dtype, device=d.device)
+                    dbuf[: gs.n_own] = d
+                t_halo = ops.halo_transposed_sum(gs.plan, dbuf[: gs.n_own])
+                s["pending"] = ("aug", dbuf, x_in, saved[l], weight)
+                s["handle"] = comm.exchange_rows_async(t_halo, gs.recv_counts, gs.send_counts, out=dbuf[gs.n_own:])
+                return
             if OWNED_ROW_BACKWARD and getattr(ops, "owned_backward_ok", lambda w: False)(weight):
                 # gather-only pass over owned + halo rows; the halo rows' sums go home before the product with W (see HipOps.owned_backward)
                 t_sum = ops.transposed_sum(gs.plan, s["d"])
@@ -567,7 +609,13 @@ class _ShardedTrunk(torch.autograd.Function):
             if l == n_layers - 1:
                 d_full = full_pending.wait()
                 want = ctx.needs_input_grad[4 + 2 * n_layers + 2 * n_layers - 1]
-                st["ho"]["d"], colsum_h = ops.spmm_act_backward(bip.bwd_ptr, bip.bwd_idx, bip.bwd_val, bip.n_src, d_full, ctx.y_ho, want, None)
+                out_d = None
+                if l > 0 and ho.send_prefix is not None and getattr(ops, "aug_backward_ok", lambda g_, w_: False)(ho, st["ho"]["prm"][2 * l]):
+                    st["ho"]["dbuf"] = torch.empty((ho.n_own + ho.send_prefix, ctx.y_ho.size(1)), dtype=ctx.y_ho.dtype, device=ctx.y_ho.device)
+                    out_d = st["ho"]["dbuf"][: ho.n_own]           # dpre of the last layer is born at the head of its [dpre | recv] buffer
+                    st["ho"]["d"], colsum_h = ops.spmm_act_backward(bip.bwd_ptr, bip.bwd_idx, bip.bwd_val, bip.n_src, d_full, ctx.y_ho, want, None, out_d)
+                else:
+                    st["ho"]["d"], colsum_h = ops.spmm_act_backward(bip.bwd_ptr, bip.bwd_idx, bip.bwd_val, bip.n_src, d_full, ctx.y_ho, want, None)
                 grads_ho[2 * n_layers - 1] = colsum_h
             else:
                 finish_exchange("ho", l + 1)
