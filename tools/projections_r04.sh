@@ -3,7 +3,7 @@
 # single-GPU step of the same stream measured on the same box.  -> gpurun_out/proj/*.json
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/proj; mkdir -p $O
 cd $R
-B="timeout 900 python bench.py --no-cpu-baseline --warmup 8 --steps 5"
+B="timeout 900 python bench.py --no-cpu-baseline --warmup 8 --steps ${STEPS:-10}"
 # (8 warm-up steps, for both runs so that their losses compare: 8 ranks share ONE caching allocator, which needs more than 3 steps to stop calling hipMalloc at the larger sizes —
 #  the report counts the device allocations inside the timed steps: emulation_allocator.device_mallocs_in_timed_steps must be 0)
 run() { name=$1; shift; $B "$@" > $O/${name}_1gpu.json 2> $O/${name}.err; $B --emulate-ranks 8 "$@" > $O/${name}_emulate8.json 2>> $O/${name}.err; }
