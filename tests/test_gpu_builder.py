@@ -96,6 +96,17 @@ def test_fused_builder_delta_promotion_modes(delta):
     _compare(_build(ei, t, 250, delta, None, True), _build(ei, t, 250, delta, None, False))
 
 
+@pytest.mark.parametrize("shift,scale,delta", [(0, 1, 40), (-(2 ** 62), 1, 40), (2 ** 62, 1, 2 ** 40), (0, 2 ** 33, 40 * 2 ** 33), (-(2 ** 40), 2 ** 22, 2 ** 27),
+                                               (5, 715828, 2 ** 31 + 5), (0, 1, -3)],
+                         ids=["plain", "at-int64-min", "huge-delta", "wide", "wide-negative", "span-2^31", "negative-delta"])
+def test_fused_builder_timestamps_anywhere_on_the_int64_axis(shift, scale, delta):
+    """The window test is done on the full 64-bit timestamps: streams near the ends of the int64 axis, wider than 2^31, with delta beyond
+    2^31 or negative give the plans of the generic kernels."""
+    ei, t = _stream(31, 4000, 300, 3000)
+    t = t * scale + shift
+    _compare(_build(ei, t, 300, delta, None, True), _build(ei, t, 300, delta, None, False))
+
+
 def test_fused_builder_against_the_oracle():
     """Edge lists + merged weights of both layers straight against the CPU oracle (not only against the generic kernels)."""
     from oracle import model as om
