@@ -30,6 +30,9 @@ using f32x4w = __attribute__((ext_vector_type(4))) float;
 #ifndef PP_WIDE_OCC
 #define PP_WIDE_OCC 2          // workgroups per CU of k_wide_layer (register budget 256 / 168 per lane at 2 / 3)
 #endif
+#ifndef PP_WIDE_STATIONARY
+#define PP_WIDE_STATIONARY 1   // 256 x 256 layers on k_wide_ws (weights in registers); 0 = k_wide_layer for every shape
+#endif
 constexpr int kWideThreads = 256;
 constexpr int kWideWaves = kWideThreads / kWave;
 constexpr int kWideFirst = 4;                  // neighbours per row fetched in the first, fully overlapped, batch
@@ -363,6 +366,250 @@ __global__ __launch_bounds__(kWideThreads, PP_WIDE_OCC) void k_wide_layer(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 layers, weights STATIONARY in registers (round 4).  k_wide_layer streams the 256 KB weight matrix through LDS once per 64 rows
+// (one workgroup barrier per 64 MFMAs of a wave) and runs the gathers and the matrix stage of a workgroup one after the other.  Here a
+// 512-thread workgroup (one per CU, 8 waves, 256 registers per lane) keeps the matrix in registers for the whole launch — wave w holds the
+// 32 weight rows of its output columns [32 w, 32 w + 32) as B operands, 128 VGPRs — and the aggregated 64 x 256 tile moves through a
+// double-buffered LDS tile: while the waves multiply tile n out of one buffer (every wave reads all 64 rows; 512 MFMAs per wave and tile),
+// each wave gathers 8 rows of tile n + 1 into the other: the rows themselves (self term) by LDS-DMA straight into their slots at the start
+// of the tile step, the first four neighbours of a row by register loads issued 64 MFMAs before their use.  One workgroup barrier per
+// tile, no weight traffic after the prologue.  The (index, value) pairs of a tile are fetched one tile further ahead (row pointers at the
+// start of a tile step, pairs in its middle), so no gather waits for an index load.
+// MFMA column i of column tile ct is output column 32 w + 2 i + ct: a lane ends up with two adjacent columns of a row (8-byte stores,
+// 128 contiguous bytes per row and wave).  k order inside a dot product: lane (i, kq) contracts k = 16 j + 4 kq + c at step (j, c).
+constexpr int kWsThreads = 512, kWsWaves = kWsThreads / kWave, kWsTile = 64, kWsRowsPerWave = kWsTile / kWsWaves;
+
+struct WsRowIndex {          // per-lane index state of ONE tile for this wave's 8 rows
+    int pv;                  // lanes 0..8: row pointers
+    int hv;                  // lanes 0..7: hub slot or -1
+    float scv;               // lanes 0..7: self coefficient (0 = no self term)
+    int cj4;                 // lanes 4 row + slot: the row's first four neighbours
+    float cv4;
+};
+
+template <int kEpi>
+__global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                            const float* __restrict__ val, int64_t n_rows, int64_t n_self,
+                                                            const float* __restrict__ X, const float* __restrict__ self_coef,
+                                                            const float* __restrict__ Wr, const float* __restrict__ bias, int act,
+                                                            HeavyRows heavy, float* __restrict__ agg_out, float* __restrict__ Y,
+                                                            const float* __restrict__ act_in, float* __restrict__ colsum, int dbg) {
+    constexpr int P = 256, Q = 256, TS = P + 4;
+    __shared__ __attribute__((aligned(16))) float s_tile0[kWsTile * TS];
+    __shared__ __attribute__((aligned(16))) float s_tile1[kWsTile * TS];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const bool dense = ptr == nullptr;
+    const bool self_any = dense || self_coef != nullptr;
+    const char* xb = (const char*)X;
+    const int64_t n_tiles = (n_rows + kWsTile - 1) / kWsTile;
+    const int c0 = 32 * wave + 2 * i;                                     // this lane's two output columns: c0, c0 + 1
+    float bias0 = 0.f, bias1 = 0.f;
+    if (kEpi == 0 && bias != nullptr) { bias0 = bias[c0]; bias1 = bias[c0 + 1]; }
+    float4 wreg[2][16];                                                  // B operands: [column tile][16-float block of k]
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wreg[ct][j] = *(const float4*)(Wr + (size_t)(c0 + ct) * P + 16 * j + 4 * kq);
+    float cs0 = 0.f, cs1 = 0.f;                                          // column sums of the gradient epilogue (this lane's rows)
+
+    auto load_pointers = [&](int64_t t, WsRowIndex& s) {
+        const int64_t rl = t * kWsTile + kWsRowsPerWave * wave + lane;
+        const bool live = t < n_tiles;
+        s.pv = (live && !dense && lane <= kWsRowsPerWave) ? ptr[rl < n_rows ? rl : n_rows] : 0;
+        s.hv = (live && heavy.slot != nullptr && lane < kWsRowsPerWave && rl < n_rows) ? heavy.slot[rl] : -1;
+        s.scv = (live && lane < kWsRowsPerWave && rl < n_self && rl < n_rows) ? (dense ? 1.f : (self_coef != nullptr ? self_coef[rl] : 0.f)) : 0.f;
+    };
+    auto load_pairs = [&](WsRowIndex& s) {
+        const int rr = (lane >> 2) & (kWsRowsPerWave - 1), slot = lane & 3;
+        const int pr = __shfl(s.pv, rr, kWave), pn = __shfl(s.pv, rr + 1, kWave);
+        const bool hub = __shfl(s.hv, rr, kWave) >= 0;
+        const int e = pr + slot;
+        const bool in = lane < 4 * kWsRowsPerWave && !hub && e < pn;
+        s.cj4 = in ? idx[e] : 0;
+        s.cv4 = in ? (val ? val[e] : 1.f) : 0.f;
+    };
+
+    struct RowFlight {       // one row between the issue of its neighbour loads and their use
+        float4 x[4];
+        float v[4], sc;
+        int p0, p1, hs;
+        int64_t r;
+        bool self_here;
+    };
+    // the rows THEMSELVES (self term) go straight into their slots of the tile being filled, by LDS-DMA (no registers): all 8 of a wave at the
+    // start of a tile step — 8 KB per wave in flight behind the first MFMAs
+    auto fetch_self_rows = [&](int64_t t, float* fill) {
+#pragma unroll
+        for (int q = 0; q < kWsRowsPerWave; ++q) {
+            const int64_t r = t * kWsTile + kWsRowsPerWave * wave + q;
+            if (self_any && r < n_self && r < n_rows)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + (uint64_t)r * (uint64_t)(P * 4) + (uint64_t)(16 * lane)),
+                                                 (__attribute__((address_space(3))) void*)(fill + (kWsRowsPerWave * wave + q) * TS), 16, 0, 0);
+        }
+    };
+    auto issue_row = [&](int q, int64_t t, const WsRowIndex& s, RowFlight& f) {
+        f.r = t * kWsTile + kWsRowsPerWave * wave + q;
+        f.p0 = __builtin_amdgcn_readlane(s.pv, q);
+        f.hs = __builtin_amdgcn_readlane(s.hv, q);
+        f.p1 = f.hs >= 0 ? f.p0 : __builtin_amdgcn_readlane(s.pv, q + 1);       // a hub row: its neighbour sum is already in heavy.sum
+        f.sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.scv), q));
+        f.self_here = self_any && f.r < n_self && f.r < n_rows;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f.x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            f.v[u] = 0.f;
+            if (f.p0 + u < f.p1) {                                          // (wave-uniform)
+                const int j = __builtin_amdgcn_readlane(s.cj4, 4 * q + u);
+                f.v[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.cv4), 4 * q + u));
+                f.x[u] = *(const float4*)(xb + (uint64_t)(uint32_t)j * (uint64_t)(P * 4) + (uint64_t)(16 * lane));
+            }
+        }
+    };
+    auto finish_row = [&](int q, const RowFlight& f, float* fill) {
+        float* slot = fill + (kWsRowsPerWave * wave + q) * TS + 4 * lane;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f.self_here) {
+            const float4 sr = *(const float4*)slot;
+            acc = make_float4(f.sc * sr.x, f.sc * sr.y, f.sc * sr.z, f.sc * sr.w);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc.x += f.v[u] * f.x[u].x; acc.y += f.v[u] * f.x[u].y; acc.z += f.v[u] * f.x[u].z; acc.w += f.v[u] * f.x[u].w;
+        }
+        for (int base = f.p0 + 4; base < f.p1; base += kWave) {             // rows with more than four neighbours
+            const int mine = base + lane;
+            const int my_j = mine < f.p1 ? idx[mine] : 0;
+            const float my_v = mine < f.p1 ? (val ? val[mine] : 1.f) : 0.f;
+            const int cnt = f.p1 - base < kWave ? f.p1 - base : kWave;
+            for (int e = 0; e < cnt; e += 4) {
+                float4 y[4];
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int src_lane = (e + u) < cnt ? e + u : e;
+                    const int j = __builtin_amdgcn_readlane(my_j, src_lane);
+                    v[u] = (e + u) < cnt ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), src_lane)) : 0.f;
+                    y[u] = *(const float4*)(xb + (uint64_t)(uint32_t)j * (uint64_t)(P * 4) + (uint64_t)(16 * lane));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc.x += v[u] * y[u].x; acc.y += v[u] * y[u].y; acc.z += v[u] * y[u].z; acc.w += v[u] * y[u].w;
+                }
+            }
+        }
+        if (f.hs >= 0) {
+            const float4 h = *(const float4*)(heavy.sum + (int64_t)f.hs * P + 4 * lane);
+            acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
+        }
+        if (f.r >= n_rows) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)slot = acc;
+        if (kEpi == 0 && agg_out != nullptr && f.r < n_rows) *(float4*)(agg_out + f.r * P + 4 * lane) = acc;
+    };
+
+    // prologue: the first tile, gathered without anything to hide behind; the index state of the second
+    int64_t t = blockIdx.x;
+    WsRowIndex cur{}, nxt{};
+    if (t < n_tiles) {
+        load_pointers(t, cur);
+        load_pairs(cur);
+        fetch_self_rows(t, s_tile0);
+#pragma unroll 1
+        for (int q = 0; q < kWsRowsPerWave; ++q) {
+            RowFlight f;
+            issue_row(q, t, cur, f);
+            finish_row(q, f, s_tile0);
+        }
+    }
+    load_pointers(t + gridDim.x, cur);
+    load_pairs(cur);
+    __syncthreads();
+
+    // one tile step: multiply tile t out of `tile`, gather tile t + grid into `fill` (called with the two LDS buffers in both roles: each call
+    // site sees which object its DMA writes, so that the LDS reads of the MFMA stream never wait for it)
+    auto tile_step = [&](const float* tile, float* fill) {
+        const int64_t tn = t + gridDim.x;                                 // the tile being gathered (index state: cur), tn + grid: being indexed (nxt)
+        const bool gather = tn < n_tiles && !(dbg & 1);
+        load_pointers(tn + gridDim.x, nxt);
+        if (gather) fetch_self_rows(tn, fill);
+        // 4 row tiles x 8 steps of 16 MFMAs (two 16-float k blocks x 4 x two column tiles; two accumulator chains).  The A operands of step
+        // s + 1 are read from LDS before the MFMAs of step s.  Gather rows 2 rt and 2 rt + 1 of the next tile ride on row tile rt: loads
+        // issued before steps 0 / 4, consumed behind steps 3 / 7 (64 MFMAs later).
+        float4 a[2][2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) a[0][jj] = *(const float4*)(tile + i * TS + 16 * jj + 4 * kq);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            f32x4w acc[2] = {f32x4w{0.f, 0.f, 0.f, 0.f}, f32x4w{0.f, 0.f, 0.f, 0.f}};
+            pp_f32x2 gp[4];
+            RowFlight f;
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                if (gather && (st & 3) == 0) issue_row(2 * rt + (st >> 2), tn, cur, f);
+                if (rt == 2 && st == 0) load_pairs(nxt);
+                if (kEpi == 1 && st == 6) {                               // the activations the row tile's epilogue multiplies by, 32 MFMAs ahead
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int64_t r = t * kWsTile + 16 * rt + 4 * kq + reg;
+                        gp[reg] = (act && r < n_rows) ? *(const pp_f32x2*)(act_in + r * Q + c0) : pp_f32x2{1.f, 1.f};
+                    }
+                }
+                const int cb = st & 1;
+                if (!(rt == 3 && st == 7)) {
+                    const int nrt = st == 7 ? rt + 1 : rt, nst = st == 7 ? 0 : st + 1;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) a[cb ^ 1][jj] = *(const float4*)(tile + (16 * nrt + i) * TS + 16 * (2 * nst + jj) + 4 * kq);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * st + jj;
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj].x, wreg[0][j].x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj].x, wreg[1][j].x, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj].y, wreg[0][j].y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj].y, wreg[1][j].y, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj].z, wreg[0][j].z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj].z, wreg[1][j].z, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj].w, wreg[0][j].w, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][jj].w, wreg[1][j].w, acc[1], 0, 0, 0);
+                }
+                if (gather && (st & 3) == 3) finish_row(2 * rt + (st >> 2), f, fill);
+            }
+            // the row tile's epilogue: 4 rows x 2 adjacent columns per lane
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t r = t * kWsTile + 16 * rt + 4 * kq + reg;
+                pp_f32x2 v = {acc[0][reg], acc[1][reg]};
+                if constexpr (kEpi == 0) {
+                    v += pp_f32x2{bias0, bias1};
+                    if (act) v = elu_fast2(v);
+                } else {
+                    const pp_f32x2 g = gp[reg];
+                    v[0] *= (act && !(g[0] > 0.f)) ? g[0] + 1.f : 1.f;          // ELU'(pre) from the stored activation
+                    v[1] *= (act && !(g[1] > 0.f)) ? g[1] + 1.f : 1.f;
+                    if (r < n_rows) { cs0 += v[0]; cs1 += v[1]; }
+                }
+                if (r < n_rows && !(dbg & 2)) *(pp_f32x2*)(Y + r * Q + c0) = v;
+            }
+        }
+        cur = nxt;
+        __syncthreads();
+        t += gridDim.x;
+    };
+    while (t < n_tiles) {
+        tile_step(s_tile0, s_tile1);
+        if (t >= n_tiles) break;
+        tile_step(s_tile1, s_tile0);
+    }
+    if constexpr (kEpi == 1) {
+        if (colsum != nullptr) {
+            cs0 += __shfl_xor(cs0, 16, kWave); cs0 += __shfl_xor(cs0, 32, kWave);
+            cs1 += __shfl_xor(cs1, 16, kWave); cs1 += __shfl_xor(cs1, 32, kWave);
+            if (kq == 0) { atomicAdd(&colsum[c0], cs0); atomicAdd(&colsum[c0 + 1], cs1); }
+        }
+    }
+}
+
 struct WideArgs {
     const int32_t *ptr, *idx;
     const float* val;
@@ -403,8 +650,27 @@ static int launch_wide_q(int Q, hipStream_t st, const WideArgs& a) {
     }
 }
 
+// 256 x 256: the weight-stationary kernel, one workgroup per CU
+template <int kEpi>
+static int launch_wide_ws(hipStream_t st, const WideArgs& a) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        PP_HIP(hipGetDevice(&dev));
+        PP_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        cus = n > 0 ? n : 256;
+    }
+    int64_t blocks = ceil_div(a.n_rows, kWsTile);
+    if (blocks > shared_grid(cus)) blocks = shared_grid(cus);
+    k_wide_ws<kEpi><<<(unsigned)blocks, kWsThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n_rows, a.n_self, a.X, a.self_coef, a.Wr, a.bias, a.act, a.heavy,
+                                                             a.agg_out, a.Y, a.act_in, a.colsum, getenv("PP_WS_DBG") ? atoi(getenv("PP_WS_DBG")) : 0);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
 template <int kEpi>
 static int launch_wide_pq(int P, int Q, hipStream_t st, const WideArgs& a) {
+    if (P == 256 && Q == 256 && PP_WIDE_STATIONARY && ((uintptr_t)a.Y | (uintptr_t)a.act_in) % 8 == 0) return launch_wide_ws<kEpi>(st, a);
     switch (P) {
         case 64: return launch_wide_q<64, kEpi>(Q, st, a);
         case 128: return launch_wide_q<128, kEpi>(Q, st, a);
