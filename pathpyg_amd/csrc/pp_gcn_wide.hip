@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
                                                             const float* __restrict__ X, const float* __restrict__ self_coef,
                                                             const float* __restrict__ Wr, const float* __restrict__ bias, int act,
                                                             HeavyRows heavy, float* __restrict__ agg_out, float* __restrict__ Y,
-                                                            const float* __restrict__ act_in, float* __restrict__ colsum, int dbg) {
+                                                            const float* __restrict__ act_in, float* __restrict__ colsum) {
     constexpr int P = 256, Q = 256, TS = P + 4;
     __shared__ __attribute__((aligned(16))) float s_tile0[kWsTile * TS];
     __shared__ __attribute__((aligned(16))) float s_tile1[kWsTile * TS];
@@ -471,6 +471,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
         float* slot = fill + (kWsRowsPerWave * wave + q) * TS + 4 * lane;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (f.self_here) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the row's DMA has landed (the compiler does not always order this read behind it)
             const float4 sr = *(const float4*)slot;
             acc = make_float4(f.sc * sr.x, f.sc * sr.y, f.sc * sr.z, f.sc * sr.w);
         }
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
     // site sees which object its DMA writes, so that the LDS reads of the MFMA stream never wait for it)
     auto tile_step = [&](const float* tile, float* fill) {
         const int64_t tn = t + gridDim.x;                                 // the tile being gathered (index state: cur), tn + grid: being indexed (nxt)
-        const bool gather = tn < n_tiles && !(dbg & 1);
+        const bool gather = tn < n_tiles;
         load_pointers(tn + gridDim.x, nxt);
         if (gather) fetch_self_rows(tn, fill);
         // 4 row tiles x 8 steps of 16 MFMAs (two 16-float k blocks x 4 x two column tiles; two accumulator chains).  The A operands of step
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
                     v[1] *= (act && !(g[1] > 0.f)) ? g[1] + 1.f : 1.f;
                     if (r < n_rows) { cs0 += v[0]; cs1 += v[1]; }
                 }
-                if (r < n_rows && !(dbg & 2)) *(pp_f32x2*)(Y + r * Q + c0) = v;
+                if (r < n_rows) *(pp_f32x2*)(Y + r * Q + c0) = v;
             }
         }
         cur = nxt;
@@ -663,7 +664,7 @@ static int launch_wide_ws(hipStream_t st, const WideArgs& a) {
     int64_t blocks = ceil_div(a.n_rows, kWsTile);
     if (blocks > shared_grid(cus)) blocks = shared_grid(cus);
     k_wide_ws<kEpi><<<(unsigned)blocks, kWsThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n_rows, a.n_self, a.X, a.self_coef, a.Wr, a.bias, a.act, a.heavy,
-                                                             a.agg_out, a.Y, a.act_in, a.colsum, getenv("PP_WS_DBG") ? atoi(getenv("PP_WS_DBG")) : 0);
+                                                             a.agg_out, a.Y, a.act_in, a.colsum);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

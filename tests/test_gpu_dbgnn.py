@@ -307,6 +307,8 @@ def test_dense_backward_kernel(pp, n, m, k):
     (1, 0, 256, 256, True, True), (17, 40, 256, 256, True, True), (5000, 30_000, 256, 256, True, True), (3000, 9000, 64, 256, True, False),
     (4097, 9000, 256, 64, True, True), (900, 5000, 256, 128, False, True), (2000, 9000, 128, 256, True, True),
     (300, 20_000, 256, 256, True, True),                                          # a side of 256: weights streamed through LDS in 16-column chunks
+    (63, 300, 256, 256, True, True), (64, 300, 256, 256, True, False), (65, 300, 256, 256, False, True), (129, 900, 256, 256, True, True),
+    (70_001, 200_000, 256, 256, True, True),           # 256 x 256: weights stationary in registers, 64-row tiles (edges of a tile; several tiles per workgroup)
 ])
 def test_fused_gcn_layer_kernel(pp, n, e, p, q, with_self, weighted):
     """pp_gcn_forward_f32 (aggregate, then multiply on the matrix cores) against a float64 evaluation of the reference order
@@ -336,6 +338,39 @@ def test_fused_gcn_layer_kernel(pp, n, e, p, q, with_self, weighted):
                                self_coef.to(DEV) if with_self else None, w.to(DEV), bias.to(DEV), act).cpu()
         scale = float(want.abs().max()) + 1e-12
         torch.testing.assert_close(got, want, rtol=RTOL, atol=max(ATOL, 1e-6 * scale))
+
+
+@pytest.mark.parametrize("n,n_src,n_self,e", [(1, 1, 1, 3), (64, 64, 64, 200), (1000, 1700, 1000, 4000), (5000, 9000, 3000, 30_000), (20_000, 20_000, 20_000, 0)])
+def test_wide_256_layer_on_rectangular_shards_and_the_kept_aggregate(pp, n, n_src, n_self, e):
+    """The 256 x 256 layer kernel (k_wide_ws) on what a partition shard hands it: more source rows than destination rows, the self term
+    on the first n_self rows only (input gradient), and the aggregated input A x kept for the weight gradient (forward)."""
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(n + e)
+    dst = torch.sort(torch.randint(0, n, (e,), generator=g)).values
+    ptr = torch.zeros(n + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n), 0).int()
+    idx = torch.randint(0, n_src, (max(e, 1),), generator=g, dtype=torch.int32)[:e]
+    val = torch.rand(e, generator=g) + 0.1
+    x = torch.randn(n_src, 256, generator=g)
+    w = torch.randn(256, 256, generator=g) / 16
+    bias = torch.randn(256, generator=g)
+    sc = torch.rand(n, generator=g)
+    agg = torch.zeros(n, 256, dtype=torch.float64)
+    agg.index_add_(0, dst, val.double().unsqueeze(1) * x.double()[idx.long()])
+    agg += sc.double().unsqueeze(1) * x.double()[:n]
+    want = F.elu(agg @ w.double().t() + bias.double())
+    got, got_agg = _hip.gcn_forward(ptr.to(DEV), idx.to(DEV), val.to(DEV), n, x.to(DEV), sc.to(DEV), w.to(DEV), bias.to(DEV), True, want_agg=True)
+    torch.testing.assert_close(got.cpu(), want.float(), rtol=RTOL, atol=max(ATOL, 1e-6 * float(want.abs().max())))
+    torch.testing.assert_close(got_agg.cpu(), agg.float(), rtol=RTOL, atol=max(ATOL, 1e-6 * float(agg.abs().max())))
+    d = torch.randn(n_src, 256, generator=g)
+    act = F.elu(torch.randn(n, 256, generator=g))
+    gsum = torch.zeros(n, 256, dtype=torch.float64)
+    gsum.index_add_(0, dst, val.double().unsqueeze(1) * d.double()[idx.long()])
+    gsum[:n_self] += sc[:n_self].double().unsqueeze(1) * d.double()[:n_self]
+    want_g = (gsum @ w.double()) * torch.where(act > 0, torch.ones_like(act), act + 1).double()
+    got_g, got_cs = _hip.gcn_input_grad(ptr.to(DEV), idx.to(DEV), val.to(DEV), n, d.to(DEV), sc.to(DEV), w.to(DEV), act.to(DEV), True, n_self=n_self)
+    torch.testing.assert_close(got_g.cpu(), want_g.float(), rtol=RTOL, atol=max(ATOL, 1e-6 * float(want_g.abs().max())))
+    torch.testing.assert_close(got_cs.cpu(), want_g.sum(0).float(), rtol=1e-4, atol=1e-5 * float(want_g.abs().sum(0).max() + 1))
 
 
 def test_fused_gcn_layer_rejects_unsupported_shapes(pp):
@@ -410,7 +445,8 @@ def test_fused_gcn_backward_kernel(pp, n, e, m, k, fuse):
 @pytest.mark.parametrize("n,e,m,k,fuse", [(1, 0, 128, 128, True), (17, 40, 128, 128, True), (5000, 30_000, 128, 128, True), (3000, 9000, 64, 128, False),
                                           (4097, 9000, 128, 64, True), (300, 20_000, 128, 128, True),
                                           (1, 0, 256, 256, True), (17, 40, 256, 256, True), (5000, 30_000, 256, 256, True), (3000, 9000, 64, 256, False),
-                                          (4097, 9000, 256, 64, True), (2000, 9000, 256, 128, True), (300, 20_000, 256, 256, False)])
+                                          (4097, 9000, 256, 64, True), (2000, 9000, 256, 128, True), (300, 20_000, 256, 256, False),
+                                          (63, 300, 256, 256, True), (64, 300, 256, 256, False), (65, 300, 256, 256, True), (70_001, 200_000, 256, 256, True)])
 def test_fused_gcn_input_grad_kernel(pp, n, e, m, k, fuse):
     """pp_gcn_input_grad_f32 (128-wide layers) against float64: d_in = ((A^T dpre + self*dpre) W) * elu'(x) and its column sums."""
     from pathpyg_amd import _hip
