@@ -476,9 +476,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
             acc = make_float4(f.sc * sr.x, f.sc * sr.y, f.sc * sr.z, f.sc * sr.w);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc.x += f.v[u] * f.x[u].x; acc.y += f.v[u] * f.x[u].y; acc.z += f.v[u] * f.x[u].z; acc.w += f.v[u] * f.x[u].w;
-        }
+        for (int u = 0; u < 4; ++u)
+            if (f.p0 + u < f.p1) {                                          // (wave-uniform: an absent neighbour costs no VALU slot — they are paid in matrix time)
+                acc.x += f.v[u] * f.x[u].x; acc.y += f.v[u] * f.x[u].y; acc.z += f.v[u] * f.x[u].z; acc.w += f.v[u] * f.x[u].w;
+            }
         for (int base = f.p0 + 4; base < f.p1; base += kWave) {             // rows with more than four neighbours
             const int mine = base + lane;
             const int my_j = mine < f.p1 ? idx[mine] : 0;
