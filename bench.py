@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--emulate-ranks", type=int, default=0, help="run R ranks of the partition path as R threads on ONE GPU, taking turns: per-rank "
                                                                  "compute time + bytes per xGMI link of every collective -> a LABELLED PROJECTION of the "
                                                                  "R-GPU step (not a measurement of R GPUs; prints its own JSON report)")
+    ap.add_argument("--emulate-clock", choices=("events", "drain"), default="events",
+                    help="--emulate-ranks: how a rank's turns are timed. events: two stream events per turn, nothing drained at the collectives, per rank "
+                         "max(device, host) (what a stream-ordered RCCL run pays); drain: GPU drained at the end of every turn (upper bound)")
     ap.add_argument("--trace", action="store_true", help="--emulate-ranks: per-phase compute time of rank 1 in the report")
     ap.add_argument("--host-profile", default="", help="--emulate-ranks: cProfile of rank 1's timed steps, written to this file (the host side of a "
                                                        "rank-step; waiting for the other ranks' turns shows up as lock acquires)")
@@ -418,6 +421,29 @@ def price_collectives(events, steps: int) -> dict:
     return out
 
 
+def simulate_async(events, windows, steps: int) -> float:
+    """Per-step time ONE rank would still wait for its asynchronous collectives: every such collective was logged with the positions of its
+    issue and of its wait on the rank's compute clock (`Comm.windows`).  One queue for the rank's links (each of these collectives loads all
+    seven): a transfer starts when it is issued and the previous one has finished, takes latency + bytes-on-the-busiest-link / rate, and the
+    rank stalls at the wait for whatever is not finished by then (stalls push everything behind them)."""
+    rate = XGMI_GBS_PER_DIRECTION * XGMI_EFFICIENCY * 1e9
+    items = []
+    for idx, p_issue, p_wait in windows:
+        items.append((p_issue, 0, idx))
+        items.append((max(p_wait, p_issue), 1, idx))
+    items.sort()
+    link_free, stall, finish = 0.0, 0.0, {}
+    for pos, kind, idx in items:
+        now = pos + stall
+        if kind == 0:
+            start = max(now, link_free)
+            finish[idx] = start + (COLLECTIVE_LATENCY_US * 1e-6 + events[idx][1] / rate) * 1e3
+            link_free = finish[idx]
+        elif finish.get(idx, 0.0) > now:
+            stall += finish[idx] - now
+    return stall / max(steps, 1)
+
+
 def cpu_baseline_isolated(args) -> dict:
     """The CPU baseline in its own process (no HIP runtime threads beside the host cores it measures) and under a hard time limit."""
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"]
@@ -445,6 +471,15 @@ def emulate(args) -> int:
     import pathpyg_amd as pp
     from pathpyg_amd import distributed as ppd
     world = args.emulate_ranks
+    if args.emulate_clock == "events":
+        # host waits (a read-back behind the other ranks' queued kernels) must SLEEP, not spin: the host side of a rank is priced by its thread's CPU time
+        import ctypes
+        try:
+            rc = ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(ctypes.c_uint(4))          # hipDeviceScheduleBlockingSync
+            if rc != 0:
+                print(f"bench.py: hipSetDeviceFlags(blocking sync) -> {rc}", file=sys.stderr)
+        except OSError as exc:
+            print(f"bench.py: hipSetDeviceFlags not available ({exc})", file=sys.stderr)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     ei, t = synth_stream(args.events, args.nodes, args.span, seed=1, device=dev)
@@ -475,7 +510,7 @@ def emulate(args) -> int:
         sharded = ppd.ShardedDBGNN(net, comm, overlap=not args.no_overlap)
         if args.trace:
             comm.trace = {}
-        build_s, sizes, loss = 0.0, {}, None
+        build_laps, sizes, loss = [], {}, None
         prof = None
         for it in range(args.warmup + args.steps):
             if it == args.warmup:
@@ -496,7 +531,8 @@ def emulate(args) -> int:
             opt.zero_grad(set_to_none=True)
             c0 = comm.lap()
             shard = ppd.build_dbgnn_shard(g, args.delta, *loaders, comm, defer_status=True)
-            build_s += comm.lap() - c0 if it >= args.warmup else 0.0
+            if it >= args.warmup:
+                build_laps.append((c0, comm.lap()))
             loss = sharded.loss(shard)
             loss.backward()
             ppd.all_reduce_gradients(net, average=False, comm=comm, inplace_views=True)
@@ -514,17 +550,23 @@ def emulate(args) -> int:
             with open(args.host_profile, "w") as fh:
                 fh.write(f"# cProfile of rank {comm.rank} of {world} emulated ranks over {args.steps} steps\n" + buf.getvalue())
         comm.end_turns()
+        timed = {"compute_s": comm.compute_s, "host_s": comm.host_s, "build_s": sum(comm.between(a_, b_) for a_, b_ in build_laps),
+                 "windows": [(i_, comm.position(a_) * 1e3, comm.position(b_) * 1e3) for i_, a_, b_ in comm.windows],
+                 "events": list(comm.events), "sent": dict(comm.sent_bytes), "trace": dict(comm.resolve_trace() or {}) if comm.trace is not None else None}
         sizes = ppd.global_sizes(shard, comm)
         total = loss.detach().to(torch.float64).reshape(1).clone()
         comm.all_reduce_(total)
-        return {"compute_s": comm.compute_s, "build_s": build_s, "events": list(comm.events), "sent": dict(comm.sent_bytes), "sizes": sizes,
-                "loss": float(total), "trace": comm.trace}
+        return {**timed, "sizes": sizes, "loss": float(total)}
 
-    results = ppd.run_thread_world(world, body, dev)
+    results = ppd.run_thread_world(world, body, dev, clock=args.emulate_clock)
     import gc
     gc.enable()
     steps = args.steps
-    compute_ms = [r["compute_s"] * 1e3 / steps for r in results]
+    device_ms = [r["compute_s"] * 1e3 / steps for r in results]
+    host_ms = [r["host_s"] * 1e3 / steps for r in results]
+    # "events" clock: a rank's turns cost what its queue cost (kernels + the waits for its own host inside a turn); a rank whose host needs longer
+    # than that is host-bound on a GPU of its own too -> max(host, device).  "drain" clock: the drained wall time is both.
+    compute_ms = [max(d_, h_) for d_, h_ in zip(device_ms, host_ms)] if args.emulate_clock == "events" else device_ms
     build_ms = [r["build_s"] * 1e3 / steps for r in results]
     # the rank with the costliest collectives sets the pace of every collective
     priced_all = [price_collectives(r["events"], steps) for r in results]
@@ -532,11 +574,19 @@ def emulate(args) -> int:
     slowest = max(compute_ms)
     dbgnn_ms = max(c - b for c, b in zip(compute_ms, build_ms))
     hidden = min(priced["overlapped_ms"], dbgnn_ms)
+    # the asynchronous collectives against the compute that actually ran between their issue and their wait, rank by rank
+    stall_ms = [simulate_async(r["events"], r["windows"], steps) for r in results]
+    exposed_ms = [p_["exposed_ms"] for p_ in priced_all]
+    step_ms = [c + e + s_ for c, e, s_ in zip(compute_ms, exposed_ms, stall_ms)]
     sz = results[0]["sizes"]
     report = {
         "what": f"PROJECTION of the {world}-GPU partition step from {world} ranks taking turns on ONE MI355X (threads of one process; NOT a measurement of "
                 f"{world} GPUs)",
         "emulated_ranks": world, "steps": steps, "warmup": args.warmup, "overlap_schedule": not args.no_overlap,
+        "clock": ("events: every turn of a rank bracketed by two stream events, nothing drained at the collectives (a stream-ordered RCCL run blocks its host only at the "
+                  "size read-back); per rank max(device time of its turns, CPU time of its thread in its turns)" if args.emulate_clock == "events" else
+                  "drain: the GPU is drained at the end of every turn (~45 per step) and the turn's wall time counts — an upper bound"),
+        "per_rank_device_ms": device_ms, "per_rank_host_ms": host_ms,
         "workload": f"m={args.events}, N={args.nodes}, span={args.span}, delta={args.delta}, F={args.features}",
         "per_rank_compute_ms": compute_ms, "per_rank_graph_build_ms": build_ms,
         "max_rank_compute_ms": slowest, "mean_rank_compute_ms": sum(compute_ms) / world, "median_rank_compute_ms": sorted(compute_ms)[world // 2],
@@ -552,9 +602,15 @@ def emulate(args) -> int:
                        "note": "every GPU pair of a node has its own xGMI link; a collective costs latency + bytes on its busiest link / rate"},
         "comm_bytes_per_step_rank0": {k: v / steps for k, v in results[0]["sent"].items()},
         "projected_ms_per_step_no_overlap": slowest + priced["exposed_ms"] + priced["overlapped_ms"],
-        "projected_ms_per_step": slowest + priced["exposed_ms"] + priced["overlapped_ms"] - hidden,
+        "projected_ms_per_step": max(step_ms),
+        "projected_ms_per_step_aggregate_model": slowest + priced["exposed_ms"] + priced["overlapped_ms"] - hidden,
+        "per_rank_async_stall_ms": stall_ms,
         "amdahl_terms_ms": {"slowest_rank_compute": slowest, "of_which_graph_build": max(build_ms), "collectives_exposed": priced["exposed_ms"],
-                            "collectives_async": priced["overlapped_ms"], "async_hidden_behind_dbgnn_kernels": hidden},
+                            "collectives_async": priced["overlapped_ms"], "async_still_in_flight_at_its_wait": max(stall_ms),
+                            "async_hidden_behind_dbgnn_kernels": hidden,
+                            "note": "projected = max over ranks of compute + blocking collectives + what its asynchronous collectives still have in flight at "
+                                    "their waits (simulate_async: issue / wait positions on the rank's compute clock, one queue for its links); the "
+                                    "aggregate model (round 3: sum of asynchronous link time against the DBGNN kernels' time) is kept beside it"},
         "loss": results[0]["loss"], "E2": sz.get("E2"), "U2": sz.get("U2"), "A2": sz.get("A2"),
     }
     if args.trace:

@@ -172,9 +172,12 @@ class ThreadWorld:
     Needs ``torch.autograd.set_multithreading_enabled(False)`` (backward functions then run on the calling thread; the engine's one
     device thread would otherwise block in the first rank's collective)."""
 
-    def __init__(self, world: int):
+    def __init__(self, world: int, clock: str = "drain"):
         import threading
+        if clock not in ("drain", "events"):
+            raise ValueError("ThreadWorld: clock must be 'drain' or 'events'")
         self.world = world
+        self.clock = clock                # how a rank's turns are timed, see Comm._clock_start
         self.cv = threading.Condition()
         self.baton = 0
         self.slots = [[None] * world, [None] * world]
@@ -226,10 +229,10 @@ class ThreadWorld:
         if rank == world - 1:
             with self.cv:
                 self.arrived.pop(seq - 1, None)
-        if collect is not None and torch.cuda.is_available():
+        if collect is not None and torch.cuda.is_available() and self.clock == "drain":
             torch.cuda.synchronize()          # the copies that stand in for the collective are queued asynchronously: drain them BEFORE the turn's clock
         comm._clock_start()                   # starts, or their GPU time is billed to this rank's compute (and priced again on the link model)
-        return out
+        return out                            # ("events" clock: the start event is queued behind the copies, nothing to drain)
 
     def release(self, comm):
         """End this rank's turn without a collective (before a plain barrier)."""
@@ -241,11 +244,11 @@ class ThreadWorld:
                 self.cv.notify_all()
 
 
-def run_thread_world(world: int, body, device=None):
+def run_thread_world(world: int, body, device=None, clock: str = "drain"):
     """Run ``body(comm) -> result`` on ``world`` emulated ranks (threads of this process, :class:`ThreadWorld`); returns the results in rank
-    order.  An exception in one rank stops the others and is re-raised."""
+    order.  An exception in one rank stops the others and is re-raised.  ``clock``: how the ranks' turns are timed (:meth:`Comm._clock_start`)."""
     import threading
-    tw = ThreadWorld(world)
+    tw = ThreadWorld(world, clock)
     results, errors = [None] * world, [None] * world
     previous = torch.autograd.is_multithreading_enabled() if hasattr(torch.autograd, "is_multithreading_enabled") else True
     torch.autograd.set_multithreading_enabled(False)
@@ -295,38 +298,103 @@ class Comm:
         self._holding = False
         self.sent_bytes = {"exchange": 0, "all_gather": 0, "reduce_scatter": 0, "all_reduce": 0}
         self.events = []               # (kind, bytes to / from the busiest peer, issued asynchronously)
-        self.compute_s = 0.0
+        self.windows = []              # emulation: (index into events, lap at issue, lap at wait) of every asynchronous collective
+        self._compute_s = 0.0
+        self.host_s = 0.0              # emulation: host time of this rank's turns ("events" clock: CPU time of its thread; "drain": the drained wall time)
         self._turn_start = None
         self._seq = 0
         self.trace, self._mark_at = None, 0.0
+        # "events" clock of the emulation: a turn is bracketed by two device events instead of a drained wall clock
+        self._clock = thread_world.clock if (thread_world is not None and torch.cuda.is_available()) else "drain"
+        self._intervals, self._open, self._resolved, self._marks = [], None, 0, []
+        if self._clock == "events":
+            self._mark_at = 0
 
-    # ---- emulation turns
+    # ---- emulation turns.  Two clocks:
+    #   "drain":  the GPU is drained at the end of every turn and the turn's wall time counts — every collective of a step (~45) costs the rank
+    #             an empty queue and the launch latency behind it: an UPPER bound of what a process of its own would need;
+    #   "events": a turn is bracketed by two events in the (shared, in-order) stream; nothing is drained, the ranks' data hand-offs are ordered by
+    #             the stream itself.  A turn then costs its kernels plus whatever the GPU waited for this rank's host inside the turn — what a
+    #             stream-ordered RCCL run pays: there the host blocks only where it reads a value back (one size read-back per step), not at the
+    #             collectives.  While one rank's kernels run, the next rank's thread already enqueues (as a process of its own runs ahead of its
+    #             own queue), so a rank whose host needs longer than its GPU is flattered: ``host_s`` (CPU time of the rank's thread in its turns) is reported next
+    #             to it and the projection takes max(host, device) per rank.
     def _clock_start(self):
         import time as _time
-        self._turn_start = _time.perf_counter()
+        # "events": the thread's CPU time — what the rank's host side costs; its waits (for the baton, for a read-back behind the OTHER
+        # ranks' queued kernels) are the emulation's, not the rank's
+        self._turn_start = _time.thread_time() if self._clock == "events" else _time.perf_counter()
+        if self._clock == "events":
+            self._open = torch.cuda.Event(enable_timing=True)
+            self._open.record()
 
     def _clock_stop(self):
         import time as _time
+        if self._clock == "events":
+            if self._turn_start is not None:
+                self.host_s += _time.thread_time() - self._turn_start
+                self._turn_start = None
+            if self._open is not None:
+                end = torch.cuda.Event(enable_timing=True)
+                end.record()
+                self._intervals.append((self._open, end))
+                self._open = None
+            return
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         if self._turn_start is not None:
-            self.compute_s += _time.perf_counter() - self._turn_start
+            dt = _time.perf_counter() - self._turn_start
+            self._compute_s += dt
+            self.host_s += dt
             self._turn_start = None
+
+    @property
+    def compute_s(self) -> float:
+        """Emulation: compute time of this rank's finished turns ("events" clock: drains the device to read the events)."""
+        if self._clock == "events" and self._resolved < len(self._intervals):
+            torch.cuda.synchronize()
+            for a, b in self._intervals[self._resolved:]:
+                self._compute_s += a.elapsed_time(b) * 1e-3
+            self._resolved = len(self._intervals)
+        return self._compute_s
+
+    def position(self, lap) -> float:
+        """Compute seconds from the last :meth:`reset_counters` to a :meth:`lap` result."""
+        return self.between(0, lap) if self._clock == "events" else float(lap)
+
+    def between(self, a, b) -> float:
+        """Compute seconds between two :meth:`lap` results."""
+        if self._clock == "events":
+            torch.cuda.synchronize()
+            return sum(x.elapsed_time(y) for x, y in self._intervals[a:b]) * 1e-3
+        return b - a
 
     def mark(self, label: str) -> None:
         """Emulation only (``trace`` enabled by bench.py --emulate-ranks --trace): compute time since the previous mark, under ``label``."""
         if self.trace is None or self.tw is None:
             return
         now = self.lap()
-        self.trace[label] = self.trace.get(label, 0.0) + (now - self._mark_at)
+        if self._clock == "events":
+            self._marks.append((label, self._mark_at, now))
+        else:
+            self.trace[label] = self.trace.get(label, 0.0) + (now - self._mark_at)
         self._mark_at = now
 
-    def lap(self) -> float:
-        """Emulation: fold the running turn into ``compute_s`` (GPU drained) and return it."""
-        if self._turn_start is not None:
+    def resolve_trace(self):
+        """"events" clock: turn the recorded marks into ``trace`` (seconds per label)."""
+        if self.trace is not None and self._marks:
+            for label, a, b in self._marks:
+                self.trace[label] = self.trace.get(label, 0.0) + self.between(a, b)
+            self._marks = []
+        return self.trace
+
+    def lap(self):
+        """Emulation: close the running turn's interval and open the next; returns a position for :meth:`between` ("drain" clock: the compute
+        seconds so far, GPU drained; "events" clock: an index, nothing is drained)."""
+        if self._turn_start is not None or self._open is not None:
             self._clock_stop()
             self._clock_start()
-        return self.compute_s
+        return len(self._intervals) if self._clock == "events" else self._compute_s
 
     def barrier(self):
         """A collective without payload (step boundaries of the bench; closes / opens a turn in the emulation)."""
@@ -345,8 +413,13 @@ class Comm:
     def reset_counters(self):
         self.sent_bytes = {k: 0 for k in self.sent_bytes}
         self.events = []
-        self.compute_s = 0.0
-        self._mark_at = 0.0
+        self.windows = []
+        self._compute_s, self.host_s = 0.0, 0.0
+        reopen = self._open is not None
+        self._intervals, self._open, self._resolved, self._marks = [], None, 0, []
+        self._mark_at = 0 if self._clock == "events" else 0.0
+        if reopen:
+            self._clock_start()
         if self.trace is not None:
             self.trace = {}
 
@@ -419,10 +492,19 @@ class Comm:
     # (RCCL executes on its own stream; `wait()` makes the current stream wait for it).  Host-staged backends complete eagerly — the log
     # still marks them as overlapped: the schedule, not the transport, decides what can hide behind what.
     class _Done:
-        def __init__(self, value):
-            self.value = value
+        """A collective that completed at issue (host-staged transports, the emulation).  In the emulation it remembers WHERE on the rank's
+        compute clock it was issued and where it is waited for (``Comm.windows``): bench.py prices what a link-bound transfer would still
+        have in flight at the wait."""
+
+        def __init__(self, value, comm=None):
+            self.value, self.comm = value, comm
+            if comm is not None:
+                self.idx, self.issued = len(comm.events) - 1, comm.lap()
 
         def wait(self):
+            if self.comm is not None:
+                self.comm.windows.append((self.idx, self.issued, self.comm.lap()))
+                self.comm = None
             return self.value
 
     class _Pending:
@@ -442,10 +524,10 @@ class Comm:
     def exchange_rows_async(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int], out: torch.Tensor | None = None):
         """:meth:`exchange_rows` as a handle whose ``wait()`` returns the received rows."""
         if not self.native or self.world == 1:
-            done = Comm._Done(self.exchange_rows(send, send_counts, recv_counts, out))
+            value = self.exchange_rows(send, send_counts, recv_counts, out)
             if self.world > 1:
                 self._mark_overlapped()
-            return done
+            return Comm._Done(value, self if (self.tw is not None and self.world > 1) else None)
         row_bytes = send.element_size() * math.prod(send.shape[1:])
         self._count_exchange(send_counts, row_bytes, recv_counts, overlapped=True)
         if out is None:
@@ -456,10 +538,10 @@ class Comm:
 
     def reduce_scatter_rows_async(self, x_full: torch.Tensor, rows_per_rank: int):
         if not self.native or self.world == 1:
-            done = Comm._Done(self.reduce_scatter_rows(x_full, rows_per_rank))
+            value = self.reduce_scatter_rows(x_full, rows_per_rank)
             if self.world > 1:
                 self._mark_overlapped()
-            return done
+            return Comm._Done(value, self if (self.tw is not None and self.world > 1) else None)
         block = rows_per_rank * x_full[0].numel() * x_full.element_size()
         self.sent_bytes["reduce_scatter"] += (self.world - 1) * block
         self._peer_bytes("reduce_scatter", block, overlapped=True)
@@ -470,10 +552,10 @@ class Comm:
 
     def all_gather_rows_async(self, x_local: torch.Tensor):
         if not self.native or self.world == 1:
-            done = Comm._Done(self.all_gather_rows(x_local))
+            value = self.all_gather_rows(x_local)
             if self.world > 1:
                 self._mark_overlapped()
-            return done
+            return Comm._Done(value, self if (self.tw is not None and self.world > 1) else None)
         block = x_local.numel() * x_local.element_size()
         self.sent_bytes["all_gather"] += (self.world - 1) * block
         self._peer_bytes("all_gather", block, overlapped=True)

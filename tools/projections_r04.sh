@@ -8,6 +8,7 @@ B="timeout 900 python bench.py --no-cpu-baseline --warmup 8 --steps ${STEPS:-10}
 #  the report counts the device allocations inside the timed steps: emulation_allocator.device_mallocs_in_timed_steps must be 0)
 run() { name=$1; shift; $B "$@" > $O/${name}_1gpu.json 2> $O/${name}.err; $B --emulate-ranks 8 "$@" > $O/${name}_emulate8.json 2>> $O/${name}.err; }
 run headline
+$B --emulate-ranks 8 --emulate-clock drain > $O/headline_emulate8_drain_clock.json 2>> $O/headline.err
 run config3 --events 20000000 --nodes 1000000 --features 128
 run f256 --features 256
 run events5e7 --events 50000000 --nodes 2500000 --span 50000000 --delta 5000000
@@ -15,5 +16,5 @@ tail -c 300 $O/*.err
 for f in $O/*.json; do echo $f; python -c "
 import json,sys
 d=json.loads(open('$f').read().strip().splitlines()[-1])
-print({k:d.get(k) for k in ('ms_per_step','projected_ms_per_step','projected_ms_per_step_no_overlap','max_rank_compute_ms','amdahl_terms_ms','peak_hbm_gib') if k in d})
+print({k:d.get(k) for k in ('ms_per_step','projected_ms_per_step','projected_ms_per_step_aggregate_model','projected_ms_per_step_no_overlap','max_rank_compute_ms','per_rank_host_ms','amdahl_terms_ms','peak_hbm_gib') if k in d})
 "; done
