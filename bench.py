@@ -421,7 +421,7 @@ def price_collectives(events, steps: int) -> dict:
     return out
 
 
-def simulate_async(events, windows, steps: int) -> float:
+def simulate_async(events, windows, steps: int, timeline: list | None = None) -> float:
     """Per-step time ONE rank would still wait for its asynchronous collectives: every such collective was logged with the positions of its
     issue and of its wait on the rank's compute clock (`Comm.windows`).  One queue for the rank's links (each of these collectives loads all
     seven): a transfer starts when it is issued and the previous one has finished, takes latency + bytes-on-the-busiest-link / rate, and the
@@ -432,15 +432,21 @@ def simulate_async(events, windows, steps: int) -> float:
         items.append((p_issue, 0, idx))
         items.append((max(p_wait, p_issue), 1, idx))
     items.sort()
-    link_free, stall, finish = 0.0, 0.0, {}
+    link_free, stall, finish, cost, issued = 0.0, 0.0, {}, {}, {}
     for pos, kind, idx in items:
         now = pos + stall
         if kind == 0:
             start = max(now, link_free)
-            finish[idx] = start + (COLLECTIVE_LATENCY_US * 1e-6 + events[idx][1] / rate) * 1e3
+            cost[idx] = (COLLECTIVE_LATENCY_US * 1e-6 + events[idx][1] / rate) * 1e3
+            issued[idx] = pos
+            finish[idx] = start + cost[idx]
             link_free = finish[idx]
-        elif finish.get(idx, 0.0) > now:
-            stall += finish[idx] - now
+        else:
+            late = max(finish.get(idx, 0.0) - now, 0.0)
+            stall += late
+            if timeline is not None:
+                timeline.append({"kind": events[idx][0], "MB_on_busiest_link": round(events[idx][1] / 1e6, 2), "issued_at_ms": round(issued[idx], 3),
+                                 "waited_at_ms": round(pos, 3), "link_ms": round(cost[idx], 3), "stall_ms": round(late, 3)})
     return stall / max(steps, 1)
 
 
@@ -576,6 +582,9 @@ def emulate(args) -> int:
     hidden = min(priced["overlapped_ms"], dbgnn_ms)
     # the asynchronous collectives against the compute that actually ran between their issue and their wait, rank by rank
     stall_ms = [simulate_async(r["events"], r["windows"], steps) for r in results]
+    timeline = []
+    simulate_async(results[min(1, world - 1)]["events"], results[min(1, world - 1)]["windows"], steps, timeline)
+    per_step = max(len(timeline) // max(steps, 1), 1)
     exposed_ms = [p_["exposed_ms"] for p_ in priced_all]
     step_ms = [c + e + s_ for c, e, s_ in zip(compute_ms, exposed_ms, stall_ms)]
     sz = results[0]["sizes"]
@@ -605,6 +614,8 @@ def emulate(args) -> int:
         "projected_ms_per_step": max(step_ms),
         "projected_ms_per_step_aggregate_model": slowest + priced["exposed_ms"] + priced["overlapped_ms"] - hidden,
         "per_rank_async_stall_ms": stall_ms,
+        "async_timeline_rank1_last_step": [dict(e_, issued_at_ms=round(e_["issued_at_ms"] - timeline[-per_step]["issued_at_ms"], 3),
+                                                waited_at_ms=round(e_["waited_at_ms"] - timeline[-per_step]["issued_at_ms"], 3)) for e_ in timeline[-per_step:]],
         "amdahl_terms_ms": {"slowest_rank_compute": slowest, "of_which_graph_build": max(build_ms), "collectives_exposed": priced["exposed_ms"],
                             "collectives_async": priced["overlapped_ms"], "async_still_in_flight_at_its_wait": max(stall_ms),
                             "async_hidden_behind_dbgnn_kernels": hidden,
