@@ -886,9 +886,10 @@ def main() -> int:
             "config": {"workload": f"temporal ER stream{'' if partition else ' per GPU'}: m={args.events} events, N={args.nodes} nodes, "
                                    f"t~U[0,{args.span}), delta={args.delta}, k=2, F={args.features}, hidden=[{args.features}]*3, classes={args.classes}"
                                    + (f", p_dropout={args.dropout}" if args.dropout else ""),
-                       "parallelism": (f"{world} rank(s) over {comm.backend or 'no process group'}: ONE global stream, edge-range sharded lift, "
-                                       "destination-owner aggregation (all-to-all), destination-partitioned DBGNN with one embedding exchange per "
-                                       "layer (sparse all-to-all), bipartite reduce-scatter, weight-gradient all-reduce") if partition else
+                       "parallelism": ((f"{world} rank(s) over {comm.backend or 'no process group'}: ONE global stream cut into node ranges — a rank builds the "
+                                        "order-2 edges of its MIDDLE nodes from the events that touch them (no pair routing), destination-row DBGNN with one "
+                                        "halo exchange per layer (all-to-all of contiguous row prefixes; first-order stack: all-gather), bipartite reduce-scatter, "
+                                        "weight-gradient all-reduce") if world > 1 else "1 rank: the whole stream on one GPU (no collective)") if partition else
                                       ("1 GPU" if world == 1 else f"{world} independent streams, weight-gradient all-reduce (RCCL)"),
                        "graph_construction": ("fused node-by-node order-2 builder (pp_debruijn2_*): identical layers and plans, event graph not materialised"
                                               if sizes.get("builder") == "fused" else "generic kernels: lift -> coalesce -> plans"),
