@@ -646,6 +646,19 @@ def gcn_plan_partition(edge_index_local: torch.Tensor, edge_weight: torch.Tensor
     return plan
 
 
+_IDENTITY_PTR: dict = {}
+
+
+def _identity_ptr(n: int, dev) -> torch.Tensor:
+    """``arange(n + 1)`` as int32 row pointers (one entry per row), kept for the last size asked for on a device: the order-2 node count of
+    consecutive batches of one stream rarely changes, and the array is read-only."""
+    hit = _IDENTITY_PTR.get(dev)
+    if hit is None or hit.numel() != n + 1:
+        hit = torch.arange(n + 1, dtype=torch.int32, device=dev)
+        _IDENTITY_PTR[dev] = hit
+    return hit
+
+
 def bipartite_plan_from_edge_grouping(plan_fo: CsrPlan, edge_dst: torch.Tensor, n_ho: int) -> CsrPlan:
     """Bipartite "last" plan of an order-2 De Bruijn model WITHOUT another sort: the higher-order nodes are the first-order graph's
     edges (same order), so "the higher-order nodes that end in node v" = "the edges into v" = the destination grouping the
@@ -655,7 +668,7 @@ def bipartite_plan_from_edge_grouping(plan_fo: CsrPlan, edge_dst: torch.Tensor, 
     # (the plan of a row-sorted edge list already holds the destinations in edge order as its source-major index: no int32 copy)
     bwd_idx = plan_fo.bwd_idx if plan_fo.edge_ordered else edge_dst.to(torch.int32).contiguous()
     plan = CsrPlan(n_dst=plan_fo.n_dst, n_src=n_ho, fwd_ptr=ptr, fwd_idx=plan_fo.dst_order, fwd_val=None,
-                   bwd_ptr=torch.arange(n_ho + 1, dtype=torch.int32, device=dev), bwd_idx=bwd_idx, bwd_val=None,
+                   bwd_ptr=_identity_ptr(n_ho, dev), bwd_idx=bwd_idx, bwd_val=None,
                    self_coef=(ptr[1:] - ptr[:-1]).to(torch.float32))
     plan.fwd_heavy = plan_fo.fwd_heavy              # same row pointers: the same hub rows
     return plan
