@@ -199,6 +199,34 @@ def test_partition_path_three_ranks_as_threads_match_oracle():
     assert pd.run_thread_world(3, body, dev) == ["ok"] * 3
 
 
+def test_emulation_clocks_events_and_drain_agree_on_results_and_log_every_asynchronous_collective():
+    """bench.py --emulate-clock: the "events" clock (turns bracketed by stream events, nothing drained at the collectives; the ranks' data hand-offs
+    are ordered by the shared stream alone) must give the results of the "drain" clock, positive device and host times per rank, and one
+    (issue, wait) window per asynchronous collective with issue <= wait on the rank's compute clock."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from pathpyg_amd import distributed as pd
+    dev = torch.device("cuda:0")
+    out = {}
+    for clock in ("drain", "events"):
+        def body(comm):
+            comm.reset_counters()
+            shard, net = _run_rank(comm.rank, 4, dev, comm, CASES[0])
+            comm.end_turns()
+            windows = [(i, comm.position(a), comm.position(b)) for i, a, b in comm.windows]
+            n_async = sum(1 for _, _, overlapped in comm.events if overlapped)
+            grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+            return comm.compute_s, comm.host_s, windows, n_async, grads
+        out[clock] = pd.run_thread_world(4, body, dev, clock=clock)
+    for rank in range(4):
+        for clock in ("drain", "events"):
+            compute_s, host_s, windows, n_async, _ = out[clock][rank]
+            assert compute_s > 0 and host_s > 0, (clock, rank)
+            assert n_async > 0 and len(windows) == n_async, (clock, rank, len(windows), n_async)
+            assert all(0 <= a <= b <= compute_s * 1.001 + 1e-9 for _, a, b in windows), (clock, rank, windows)
+        torch.testing.assert_close(out["events"][rank][4], out["drain"][rank][4], rtol=1e-5, atol=1e-7)      # (same kernels; float atomics may reorder)
+
+
 @pytest.mark.parametrize("world", [2])
 def test_partition_path_ranks_sharing_one_gpu_match_oracle(world):
     if not torch.cuda.is_available():
