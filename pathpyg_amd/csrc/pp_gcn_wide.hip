@@ -405,6 +405,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
     const char* xb = (const char*)X;
     const int64_t n_tiles = (n_rows + kWsTile - 1) / kWsTile;
     const int c0 = 32 * wave + 2 * i;                                     // this lane's two output columns: c0, c0 + 1
+    const uint32_t out_off = (uint32_t)(4 * kq * 256 + c0) * 4u;         // byte offset of (row 4 kq, column c0) inside a 16-row block of Y / act_in
     float bias0 = 0.f, bias1 = 0.f;
     if (kEpi == 0 && bias != nullptr) { bias0 = bias[c0]; bias1 = bias[c0 + 1]; }
     float4 wreg[2][16];                                                  // B operands: [column tile][16-float block of k]
@@ -546,15 +547,18 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
             f32x4w acc[2] = {f32x4w{0.f, 0.f, 0.f, 0.f}, f32x4w{0.f, 0.f, 0.f, 0.f}};
             pp_f32x2 gp[4];
             RowFlight f;
+            const int64_t row0 = t * kWsTile + 16 * rt;                   // first row of this row tile
+            const bool full = row0 + 16 <= n_rows;                        // (wave-uniform: the gradient epilogue tests no bound per lane on the common path)
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 if (gather && (st & 3) == 0) issue_row(2 * rt + (st >> 2), tn, cur, f);
                 if (rt == 2 && st == 0) load_pairs(nxt);
                 if (kEpi == 1 && st == 6) {                               // the activations the row tile's epilogue multiplies by, 32 MFMAs ahead
+                    const char* ab = (const char*)(act_in + row0 * Q);    // (scalar row-tile base + one constant lane offset: no per-row address VALU)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const int64_t r = t * kWsTile + 16 * rt + 4 * kq + reg;
-                        gp[reg] = (act && r < n_rows) ? *(const pp_f32x2*)(act_in + r * Q + c0) : pp_f32x2{1.f, 1.f};
+                        gp[reg] = pp_f32x2{1.f, 1.f};
+                        if (act && (full || row0 + 4 * kq + reg < n_rows)) gp[reg] = *(const pp_f32x2*)(ab + out_off + reg * Q * 4);
                     }
                 }
                 const int cb = st & 1;
@@ -589,9 +593,13 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
                     const pp_f32x2 g = gp[reg];
                     v[0] *= (act && !(g[0] > 0.f)) ? g[0] + 1.f : 1.f;          // ELU'(pre) from the stored activation
                     v[1] *= (act && !(g[1] > 0.f)) ? g[1] + 1.f : 1.f;
-                    if (r < n_rows) { cs0 += v[0]; cs1 += v[1]; }
+                    if (full || r < n_rows) {
+                        cs0 += v[0];
+                        cs1 += v[1];
+                        *(pp_f32x2*)((char*)(Y + row0 * Q) + out_off + reg * Q * 4) = v;
+                    }
                 }
-                if (r < n_rows) *(pp_f32x2*)(Y + r * Q + c0) = v;
+                if (kEpi == 0 && r < n_rows) *(pp_f32x2*)(Y + r * Q + c0) = v;
             }
         }
         cur = nxt;
