@@ -373,6 +373,39 @@ def test_wide_256_layer_on_rectangular_shards_and_the_kept_aggregate(pp, n, n_sr
     torch.testing.assert_close(got_cs.cpu(), want_g.sum(0).float(), rtol=1e-4, atol=1e-5 * float(want_g.abs().sum(0).max() + 1))
 
 
+def test_wide_256_layer_takes_hub_rows_from_the_chunked_prepass(pp):
+    """Rows longer than HEAVY_ROW_ENTRIES are summed by pp_spmm_heavy_f32; the 256 x 256 layer kernel reads the finished sums (heavy.slot /
+    heavy.sum) in both directions — with a threshold low enough that hub and ordinary rows share tiles."""
+    from pathpyg_amd import _hip
+    g = torch.Generator().manual_seed(77)
+    n, e = 3000, 40_000
+    dst = torch.sort(torch.randint(0, n, (e,), generator=g)).values
+    dst[:6000] = 17                                             # one hub row of ~6000 entries
+    dst[6000:7000] = 1500
+    dst = torch.sort(dst).values
+    ptr = torch.zeros(n + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n), 0).int()
+    idx = torch.randint(0, n, (e,), generator=g, dtype=torch.int32)
+    val = torch.rand(e, generator=g) * 0.01
+    x = torch.randn(n, 256, generator=g)
+    w = torch.randn(256, 256, generator=g) / 16
+    bias = torch.randn(256, generator=g)
+    sc = torch.rand(n, generator=g)
+    heavy = _hip.HeavyRows(ptr.to(DEV), n, threshold=300)
+    assert heavy.n_heavy >= 2
+    agg = torch.zeros(n, 256, dtype=torch.float64)
+    agg.index_add_(0, dst, val.double().unsqueeze(1) * x.double()[idx.long()])
+    agg += sc.double().unsqueeze(1) * x.double()
+    want = F.elu(agg @ w.double().t() + bias.double())
+    got = _hip.gcn_forward(ptr.to(DEV), idx.to(DEV), val.to(DEV), n, x.to(DEV), sc.to(DEV), w.to(DEV), bias.to(DEV), True, heavy=heavy)
+    torch.testing.assert_close(got.cpu(), want.float(), rtol=RTOL, atol=max(ATOL, 2e-6 * float(want.abs().max())))
+    act = F.elu(torch.randn(n, 256, generator=g))
+    want_g = (agg @ w.double()) * torch.where(act > 0, torch.ones_like(act), act + 1).double()
+    got_g, got_cs = _hip.gcn_input_grad(ptr.to(DEV), idx.to(DEV), val.to(DEV), n, x.to(DEV), sc.to(DEV), w.to(DEV), act.to(DEV), True, heavy=heavy)
+    torch.testing.assert_close(got_g.cpu(), want_g.float(), rtol=RTOL, atol=max(ATOL, 2e-6 * float(want_g.abs().max())))
+    torch.testing.assert_close(got_cs.cpu(), want_g.sum(0).float(), rtol=1e-4, atol=1e-5 * float(want_g.abs().sum(0).max() + 1))
+
+
 def test_fused_gcn_layer_rejects_unsupported_shapes(pp):
     from pathpyg_amd import _hip
     ptr = torch.zeros(5, dtype=torch.int32, device=DEV)
