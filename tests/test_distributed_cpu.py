@@ -186,7 +186,21 @@ def test_destination_partitioned_dbgnn_matches_single_process_oracle(world):
     _spawn(_dbgnn_worker, world)
 
 
-def _stream_worker(rank, world, port, results):
+class _ReducedScatter:
+    """gloo has no reduce_scatter_tensor: the same result from an all-reduce, behind the Work interface the native branch waits on."""
+
+    def __init__(self, out, src, group):
+        full = src.clone()
+        dist.all_reduce(full, group=group)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        rows = full.size(0) // world
+        out.copy_(full[rank * rows: (rank + 1) * rows])
+
+    def wait(self):
+        return True
+
+
+def _stream_worker(rank, world, port, results, native=False):
     """The whole north-star split from the event stream: sharded lift -> destination-owner aggregation -> graph shards -> DBGNN."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -213,6 +227,9 @@ def _stream_worker(rank, world, port, results):
             tg = type("G", (), {})()
             tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n, edge_weight=w)
             comm = pd.Comm()
+            if native:                    # the branches an RCCL run takes, over gloo's CPU tensors (see _node_partition_worker)
+                comm.native = True
+                dist.reduce_scatter_tensor = lambda out, src, group=None, async_op=False: _ReducedScatter(out, src, group)
             shard = pd.build_dbgnn_shard(tg, delta, x, x_h, y, comm, CpuOps())
             sz = pd.global_sizes(shard, comm)
             assert sz["U2"] == n_ho and sz["A2"] == layers[2]["edge_index"].size(1) and \
@@ -464,7 +481,7 @@ def test_node_range_partition_dropout_is_reproducible_across_world_sizes(world):
     _spawn(_dropout_worker, world, True)
 
 
-def _node_partition_worker(rank, world, port, results):
+def _node_partition_worker(rank, world, port, results, native=False):
     """The NODE-RANGE partition on the node-by-node builder (round 4: pathpyg_amd.distributed._build_partitioned_by_node) under gloo, with the
     torch-CPU stand-in of pp_debruijn2_part_* (tests/cpu_ops.py::CpuOpsNode): rows numbered in send order, halo rows without an id exchange,
     first-order shard with a dense halo — against the single-process oracle; row loaders see exactly the owned rows."""
@@ -494,6 +511,11 @@ def _node_partition_worker(rank, world, port, results):
             tg = type("G", (), {})()
             tg.data = pp.Data(edge_index=ei, time=t, num_nodes=n, **({} if w is None else {"edge_weight": w}))
             comm = pd.Comm()
+            if native:
+                # the branches an RCCL run takes — tensors handed to the collectives where they live, all_to_all_single with split
+                # lists and out= views, all_gather_into_tensor, the asynchronous forms behind Comm._Pending — on gloo's CPU tensors
+                comm.native = True
+                dist.reduce_scatter_tensor = lambda out, src, group=None, async_op=False: _ReducedScatter(out, src, group)
             asked = {"x_h": 0}
 
             def load_xh(rows):
@@ -523,6 +545,17 @@ def _node_partition_worker(rank, world, port, results):
 @pytest.mark.parametrize("world", [2, 3])
 def test_node_range_partition_matches_single_process_oracle_gloo(world):
     _spawn(_node_partition_worker, world)
+
+
+def test_edge_range_split_through_the_native_collective_branches():
+    """The round-3 split (streams with hub nodes take it at every world size) through ``Comm.native``'s branches, world 3."""
+    _spawn(_stream_worker, 3, True)
+
+
+def test_node_range_partition_through_the_native_collective_branches():
+    """The code an RCCL run executes (Comm.native: direct all_to_all_single / all_gather_into_tensor / reduce_scatter_tensor, asynchronous
+    handles waited where the _ShardedTrunk schedule needs the rows) — driven over gloo's CPU tensors, world 3, against the oracle."""
+    _spawn(_node_partition_worker, 3, True)
 
 
 def test_node_range_partition_world8_threads_match_oracle():
