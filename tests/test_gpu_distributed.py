@@ -346,6 +346,12 @@ def test_bench_partition_default_and_rccl_world1_and_gloo_world2():
     # the emulation (R ranks as threads on the one GPU) trains the same model on the same stream: same loss after the same steps
     emulated = _bench(["--emulate-ranks", "3"])
     assert emulated["emulated_ranks"] == 3 and emulated["E2"] == one["config"]["E2"]
+    # the projection: per rank max(device, host) + blocking collectives + the replayed asynchronous ones; never below the slowest rank's compute
+    assert emulated["clock"].startswith("events") and len(emulated["per_rank_device_ms"]) == 3 and min(emulated["per_rank_host_ms"]) > 0
+    assert all(s_ >= 0 for s_ in emulated["per_rank_async_stall_ms"]) and emulated["async_timeline_rank1_last_step"]
+    assert emulated["projected_ms_per_step"] >= emulated["max_rank_compute_ms"] > 0
+    drained = _bench(["--emulate-ranks", "3", "--emulate-clock", "drain"])
+    assert drained["clock"].startswith("drain") and abs(drained["loss"] - emulated["loss"]) < 1e-6 * max(1.0, abs(emulated["loss"]))
     assert abs(emulated["loss"] - one["loss"]) < 1e-3 * max(1.0, abs(one["loss"])), (emulated["loss"], one["loss"])
     # BASELINE configs[1] (2M events), forward pass at the initial weights: the 8-way sharded build + partitioned forward against the single-GPU path
     c1 = ["--warmup", "0", "--steps", "1", "--events", "2000000", "--nodes", "100000", "--span", "1000000", "--delta", "100000"]
