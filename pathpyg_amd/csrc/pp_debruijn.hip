@@ -363,6 +363,10 @@ struct Db2Mid {
     int32_t *in_idx2, *fwd_idx1, *dst_order;
     float *in_val2, *self2, *fwd_val1, *self1;
     uint2* out_pack;
+    // count -> fill: a node whose in-runs are single events that reach no successor run twice is SIMPLE: run_em[position of the in-event] = the
+    // successor runs it reaches (bit = lane of the run's first out-event); the fill pass then handles all its runs at once (no window tests)
+    uint64_t* run_em;
+    uint8_t* node_simple;
 };
 
 template <bool kFill, bool kW>
@@ -380,6 +384,8 @@ struct Db2MidIn {
     int32_t rip;
     float d1, lw1;
     int32_t fp;
+    uint64_t em;               // fill, simple nodes: run_em of the in-event at lane l
+    int simple;
 };
 
 template <typename TimeT, int kMode, bool kFill, bool kW>
@@ -405,6 +411,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
             in[s].d1 = there ? inv_sqrt_deg(a.fo_deg[gn]) : 0.0f;
             in[s].lw1 = there ? a.fo_lw[node] : 1.0f;
             in[s].fp = __builtin_amdgcn_readfirstlane(there ? a.fo_fwd_ptr[node] : 0);
+            in[s].simple = __builtin_amdgcn_readfirstlane(there ? (int)a.node_simple[node] : 0);
         }
     }
 #pragma unroll
@@ -422,6 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
             in[s].du = li ? a.du_s[in[s].q0 + l] : 0.0f;
             in[s].da = li ? a.da_s[in[s].q0 + l] : 0.0f;
             in[s].ob = li ? a.ob_s[in[s].q0 + l] : 0;
+            in[s].em = (li && in[s].simple) ? a.run_em[in[s].q0 + l] : 0ull;
         }
     }
     if (kFill) {
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
         if (no > kWave || ni > kWave) {
             if (!kFill && l == 0) {
                 atomicOr((unsigned long long*)a.status, (unsigned long long)kDb2Overflow);
-                a.nu[node] = 0; a.pc[node] = 0; a.fo_deg[gnode] = 1.0f; a.fo_lw[node] = 1.0f;
+                a.nu[node] = 0; a.pc[node] = 0; a.fo_deg[gnode] = 1.0f; a.fo_lw[node] = 1.0f; a.node_simple[node] = 0;
             }
             continue;
         }
@@ -474,7 +482,49 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
             ip = lane_read_i(from, in[s].rip);
         }
         const float d1b = in[s].d1;
+        if (kFill && in[s].simple) {
+            // ---- all in-runs of the node at once (lane r = in-event r = in-run r): no loop over the runs, no window test
+            const uint64_t em = li ? in[s].em : 0ull;
+            uint64_t col = 0ull;                                   // head lane c: the in-runs that reach successor run c (the transposed masks)
+            for (uint64_t hm2 = ohm; hm2 != 0; hm2 &= hm2 - 1) {
+                const int c = __ffsll((long long)hm2) - 1;
+                const uint64_t reach = __ballot((em >> c) & 1ull);
+                if (l == c) col = reach;
+            }
+            if (li) {
+                uint32_t run_a = sa;
+                if (a.part) run_a = (int64_t)sa < a.lo ? (uint32_t)(a.n_own + sa) : ((int64_t)sa >= a.lo + a.n_own ? sa : (uint32_t)(sa - a.lo));
+                const float w1 = kW ? swi : 1.0f;
+                a.fwd_idx1[in[s].fp + l] = (int32_t)run_a;
+                a.fwd_val1[in[s].fp + l] = sa == gnode ? 0.0f : in[s].da * w1 * d1b;
+                if (a.dst_order) a.dst_order[in[s].fp + l] = (int32_t)su;
+            }
+            const int col_lo = (int)(uint32_t)col, col_hi = (int)(uint32_t)(col >> 32);
+            for (uint64_t left = em; __ballot(left != 0ull) != 0ull;) {          // (wave-uniform trip count: the lane reads below need every lane)
+                const bool act = left != 0ull;
+                const int c = act ? __ffsll((long long)left) - 1 : 0;
+                const uint32_t vc = (uint32_t)lane_read_i(c << 2, (int)v);
+                const float dvc = lane_read_f(c << 2, dv);
+                const int32_t ipc = lane_read_i(c << 2, ip);
+                const uint64_t reach = ((uint64_t)(uint32_t)lane_read_i(c << 2, col_hi) << 32) | (uint64_t)(uint32_t)lane_read_i(c << 2, col_lo);
+                if (act) {
+                    const int pos = (int)__popcll(reach & lanes_below(l));
+                    const int rank = (int)__popcll(em & lanes_below(c));
+                    const float wgt = kW ? swi : 1.0f;
+                    const float val = su == vc ? 0.0f : in[s].du * wgt * dvc;
+                    a.in_idx2[ipc + pos] = (int32_t)su;
+                    a.in_val2[ipc + pos] = val;
+                    a.out_pack[in[s].ob + rank] = make_uint2(vc, __float_as_uint(val));
+                    left &= left - 1;
+                }
+            }
+            if (ohead) a.self2[v] = dv * lwv * dv;
+            if (l == 0 && a.self1) a.self1[node] = d1b * in[s].lw1 * d1b;
+            continue;
+        }
         int cnt = 0, pairs = 0, nuc = 0;
+        bool node_simple = true, twice = false;                    // count pass: every in-run one event / some successor run reached twice by one in-run (per lane)
+        uint64_t run_em = 0ull;
         float deg = 0.0f, lw = -1.0f, deg1 = 0.0f, lw1 = -1.0f;
         // per in-run results are parked in lane `run index` and stored after the loop with one instruction each
         uint32_t run_u = 0xFFFFFFFFu, run_a = 0u;
@@ -509,7 +559,9 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
                     ++cnt;
                     if (ucur == v) lw = wgt; else deg += wgt;
                 }
-                if (l == nuc) { run_u = ucur; run_od = (int32_t)__popcll(em); }
+                node_simple = node_simple && z1 - z0 == 1;
+                twice = twice || (ohead && hits > 1);
+                if (l == nuc) { run_u = ucur; run_od = (int32_t)__popcll(em); run_em = em; }
                 if (acur == gnode) lw1 = w1run; else deg1 += w1run;
             } else {
                 const float du_ = rl_f(in[s].du, z0), da_ = rl_f(in[s].da, z0);
@@ -539,8 +591,11 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
                 a.ho_deg[v] = deg + l2;
                 a.ho_lw[v] = l2;
             }
+            node_simple = node_simple && __ballot(twice) == 0ull;
+            if (node_simple && l < nuc) a.run_em[in[s].q0 + l] = run_em;       // (simple: run r = in-event r)
             if (l == 0) {
                 const float l1 = lw1 < 0.0f ? 1.0f : lw1;
+                a.node_simple[node] = node_simple ? 1 : 0;
                 a.nu[node] = nuc;
                 a.pc[node] = pairs;
                 a.fo_deg[gnode] = deg1 + l1;
@@ -689,6 +744,8 @@ struct Db2Ws {
     uint64_t* is_t;
     uint32_t *is_a, *is_u;
     float *is_w, *du_s, *da_s;
+    uint64_t* run_em;         // [m] count -> fill, see Db2Mid
+    uint8_t* node_simple;     // [n]
     int32_t* ob_s;
     uint2* row_pack;
     int32_t *blk, *nu, *pc, *indeg2, *outdeg2;
@@ -734,6 +791,8 @@ static Db2Ws carve_db2(void* ws, int64_t m, int64_t n) {
     w.du_s = a.take<float>(m);
     w.da_s = a.take<float>(m);
     w.ob_s = a.take<int32_t>(m);
+    w.run_em = a.take<uint64_t>(m);
+    w.node_simple = a.take<uint8_t>(n);
     w.row_pack = a.take<uint2>(m);
     w.blk = a.take<int32_t>(n);
     w.nu = a.take<int32_t>(n);
@@ -753,7 +812,7 @@ static Db2Ws carve_db2(void* ws, int64_t m, int64_t n) {
 static void mid_common(Db2Mid& a, const Db2Ws& w, const int32_t* row_ptr, bool weighted) {
     a.tp = w.tp; a.hp = w.hp; a.ot_s = w.ot_s; a.ocr_s = w.ocr_s; a.row_ptr = row_ptr;
     a.is_t = w.is_t; a.is_a = w.is_a; a.is_u = w.is_u; a.is_w = weighted ? w.is_w : nullptr;
-    a.ho_lw = w.ho_lw; a.fo_lw = w.fo_lw;
+    a.ho_lw = w.ho_lw; a.fo_lw = w.fo_lw; a.run_em = w.run_em; a.node_simple = w.node_simple;
 }
 
 template <typename TimeT, int kMode, bool kFill>
