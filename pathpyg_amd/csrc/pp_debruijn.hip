@@ -526,6 +526,68 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
         bool node_simple = true, twice = false;                    // count pass: every in-run one event / some successor run reached twice by one in-run (per lane)
         uint64_t run_em = 0ull;
         float deg = 0.0f, lw = -1.0f, deg1 = 0.0f, lw1 = -1.0f;
+        if (!kFill && (int)__popcll(ihm) == ni) {
+            // ---- count pass, every in-event from its own source node (an ER stream: all nodes): one window ballot per in-event, then all runs at once
+            uint64_t my_em = 0ull;                                 // lane r: successor runs (head lanes) in-event r reaches
+            int all_pairs = 0;
+            bool again = false;
+            for (int z = 0; z < ni; ++z) {
+                const TimeT ti = time_of<TimeT>(rl_u64(sti, z));
+                const typename W::Thr thr = W::threshold(ti, delta_i, delta_f);
+                const uint64_t win = __ballot(lo_ && tj > ti && W::admits(tj, thr));
+                all_pairs += (int)__popcll(win);
+                const int h = (int)__popcll(win & myrun);          // (myrun: the head lane's own run, 0 elsewhere)
+                again = again || h > 1;
+                const uint64_t reach = __ballot(h > 0);
+                if (l == z) my_em = reach;
+            }
+            if (__ballot(again) == 0ull) {
+                uint64_t col = 0ull;                               // head lane c: the in-events that reach successor run c
+                for (uint64_t hm2 = ohm; hm2 != 0; hm2 &= hm2 - 1) {
+                    const int c = __ffsll((long long)hm2) - 1;
+                    const uint64_t reach = __ballot((my_em >> c) & 1ull);
+                    if (l == c) col = reach;
+                }
+                if (li) {
+                    const int od = (int)__popcll(my_em);
+                    if (od != 0 && su != 0xFFFFFFFFu) a.outdeg2[su] = od;      // (no id: the source's node overflowed)
+                    a.run_em[in[s].q0 + l] = my_em;
+                }
+                // the successor rows: in-degree, weighted degree and self-loop weight, summed in the order of the in-events (as the general loop does)
+                const int su_i = (int)su;
+                for (uint64_t left = ohead ? col : 0ull; __ballot(left != 0ull) != 0ull;) {      // (wave-uniform trip count: lane reads need every lane)
+                    const bool act = left != 0ull;
+                    const int r = act ? __ffsll((long long)left) - 1 : 0;
+                    const uint32_t ur = (uint32_t)lane_read_i(r << 2, su_i);
+                    const float wr = kW ? lane_read_f(r << 2, swi) : 1.0f;
+                    if (act) {
+                        if (ur == v) lw = wr; else deg += wr;
+                        left &= left - 1;
+                    }
+                }
+                if (ohead) {
+                    const float l2 = lw < 0.0f ? 1.0f : lw;
+                    a.indeg2[v] = (int)__popcll(col);
+                    a.ho_deg[v] = deg + l2;
+                    a.ho_lw[v] = l2;
+                }
+                // the node's first-order in-edges, one per in-event, summed in their order
+                for (int z = 0; z < ni; ++z) {
+                    const float wz = kW ? rl_f(swi, z) : 1.0f;
+                    if (rl_u(sa, z) == gnode) lw1 = wz; else deg1 += wz;
+                }
+                if (l == 0) {
+                    const float l1 = lw1 < 0.0f ? 1.0f : lw1;
+                    a.node_simple[node] = 1;
+                    a.nu[node] = ni;
+                    a.pc[node] = all_pairs;
+                    a.fo_deg[gnode] = deg1 + l1;
+                    a.fo_lw[node] = l1;
+                }
+                continue;
+            }
+            // (a successor run reached twice by one in-event: the general loop below)
+        }
         // per in-run results are parked in lane `run index` and stored after the loop with one instruction each
         uint32_t run_u = 0xFFFFFFFFu, run_a = 0u;
         int32_t run_od = 0;
