@@ -130,20 +130,6 @@ __global__ __launch_bounds__(kBlock) void k_db2_pack_rows(int64_t m, const float
     row_pack[u] = make_uint2(__float_as_uint(inv_sqrt_deg(ho_deg[u])), (uint32_t)ho_bwd_ptr[u]);
 }
 
-// what the fill pass needs per in-event: d^-1/2 of its order-2 node and of its source node, the start of that order-2 node's source-major row
-__global__ __launch_bounds__(kBlock) void k_db2_gather_coef(int64_t m, const uint32_t* __restrict__ is_u, const uint32_t* __restrict__ is_a,
-                                                           const uint2* __restrict__ row_pack, const float* __restrict__ fo_deg,
-                                                           float* __restrict__ du_s, int32_t* __restrict__ ob_s, float* __restrict__ da_s) {
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (q >= m) return;
-    const uint32_t u = is_u[q], a = is_a[q];
-    if (u >= kDb2Foreign) return;                  // (later instance of a halo run: only the run's first event carries the id; or an overflow node)
-    const uint2 r = row_pack[u];
-    du_s[q] = __uint_as_float(r.x);
-    ob_s[q] = (int32_t)r.y;
-    da_s[q] = fo_deg ? inv_sqrt_deg(fo_deg[a]) : 0.0f;
-}
-
 // the source-major rows were scattered as (destination, coefficient) pairs: one 8-byte random store per entry instead of two 4-byte ones
 __global__ __launch_bounds__(kBlock) void k_db2_unzip(int64_t n, const uint2* __restrict__ pack, int32_t* __restrict__ idx, float* __restrict__ val) {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -351,14 +337,21 @@ struct Db2Mid {
     const uint64_t* is_t;
     const uint32_t *is_a, *is_u;
     const float* is_w;
+    // count pass on one GPU: the in-events are taken straight from their positions in the out-lists (hl = head-sorted order, src_t = one 16-byte
+    // record per out-list position) — the random reads of what was k_db2_gather_in, hidden behind the other waves — and written for the fill pass
+    const uint32_t* hl;
+    const Db2Src* src_t;
+    const float* ow_t;
+    uint64_t* is_t_out;
+    uint32_t *is_a_out, *is_u_out;
+    float* is_w_out;
     // count pass: outputs; fill pass: inputs
     int32_t *indeg2, *outdeg2;
     float *ho_deg, *ho_lw, *fo_deg, *fo_lw;
     int32_t *nu, *pc;
     int64_t* status;
     // fill pass
-    const float *du_s, *da_s;
-    const int32_t* ob_s;
+    const uint2* row_pack;           // per order-2 row: (d^-1/2 bits, start of its source-major row): gathered by the fill pass's lanes themselves
     const int32_t *ho_fwd_ptr, *fo_fwd_ptr;
     int32_t *in_idx2, *fwd_idx1, *dst_order;
     float *in_val2, *self2, *fwd_val1, *self1;
@@ -421,18 +414,44 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
         in[s].tj = lo_ ? a.ot_s[in[s].p0 + l] : 0ull;
         in[s].cr = lo_ ? (int)a.ocr_s[in[s].p0 + l] : 255;
         in[s].rid = (lo_ && a.perm) ? a.perm[in[s].row0 + l] : in[s].row0 + l;      // (at most `no` successor rows: a row beyond the node's block is never used)
-        in[s].ti = li ? a.is_t[in[s].q0 + l] : 0ull;
-        in[s].ia = li ? a.is_a[in[s].q0 + l] : 0xFFFFFFFFu;
-        in[s].iu = li ? a.is_u[in[s].q0 + l] : 0xFFFFFFFFu;
-        in[s].wi = (kW && li) ? a.is_w[in[s].q0 + l] : 1.0f;
+        if (!kFill && a.hl != nullptr) {
+            const uint32_t q = in[s].q0 + l;
+            const uint32_t e = li ? a.hl[q] : 0u;
+            Db2Src r;
+            r.t = 0ull; r.u = 0xFFFFFFFFu; r.a = 0xFFFFFFFFu;
+            if (li) r = a.src_t[e];
+            in[s].ti = r.t;
+            in[s].ia = r.a;
+            in[s].iu = r.u;
+            in[s].wi = (kW && li) ? a.ow_t[e] : 1.0f;
+            if (li) {
+                a.is_t_out[q] = r.t;
+                a.is_a_out[q] = r.a;
+                a.is_u_out[q] = r.u;
+                if (kW) a.is_w_out[q] = in[s].wi;
+            }
+        } else {
+            in[s].ti = li ? a.is_t[in[s].q0 + l] : 0ull;
+            in[s].ia = li ? a.is_a[in[s].q0 + l] : 0xFFFFFFFFu;
+            in[s].iu = li ? a.is_u[in[s].q0 + l] : 0xFFFFFFFFu;
+            in[s].wi = (kW && li) ? a.is_w[in[s].q0 + l] : 1.0f;
+        }
         if (kFill) {
-            in[s].du = li ? a.du_s[in[s].q0 + l] : 0.0f;
-            in[s].da = li ? a.da_s[in[s].q0 + l] : 0.0f;
-            in[s].ob = li ? a.ob_s[in[s].q0 + l] : 0;
             in[s].em = (li && in[s].simple) ? a.run_em[in[s].q0 + l] : 0ull;
         }
     }
     if (kFill) {
+#pragma unroll
+        for (int s = 0; s < kDb2Nodes; ++s) {
+            // what the fill pass needs per in-event: d^-1/2 of its order-2 row and of its source node, the start of that row's source-major entries — two
+            // random reads per lane, issued for all four nodes at once and hidden behind the other waves' instruction issue (round 4: they were a
+            // kernel of their own, 0.25 ms of pure latency)
+            const bool ok = in[s].no <= kWave && in[s].ni <= kWave && l < in[s].ni && in[s].iu < kDb2Foreign;
+            const uint2 rp = ok ? a.row_pack[in[s].iu] : make_uint2(0u, 0u);
+            in[s].du = __uint_as_float(rp.x);
+            in[s].ob = (int32_t)rp.y;
+            in[s].da = ok ? inv_sqrt_deg(a.fo_deg[in[s].ia]) : 0.0f;
+        }
 #pragma unroll
         for (int s = 0; s < kDb2Nodes; ++s) {
             const bool lo_ = in[s].no <= kWave && in[s].ni <= kWave && l < in[s].no;
@@ -996,8 +1015,10 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
     }
     k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, fo_bwd_ptr, perm, w.src_t);
     PP_LAUNCH_CHECK();
-    k_db2_gather_in<<<egrid, kBlock, 0, st>>>(m, w.hl, w.src_t, weight ? w.ow_t : nullptr, w.is_t, w.is_a, w.is_u, w.is_w);
-    PP_LAUNCH_CHECK();
+    if (part) {          // (the halo numbering below reads the in-events; on one GPU the count pass gathers them itself)
+        k_db2_gather_in<<<egrid, kBlock, 0, st>>>(m, w.hl, w.src_t, weight ? w.ow_t : nullptr, w.is_t, w.is_a, w.is_u, w.is_w);
+        PP_LAUNCH_CHECK();
+    }
     if (part) {
         // 2c. halo numbering (whose rows I gather from): one 8-bit sort of the in-event positions by owner
         uint32_t* hkeys = (uint32_t*)w.da_s;             // (fill-pass scratch, unused until then)
@@ -1019,6 +1040,10 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
     a.lo = pt.lo; a.n_own = n_own; a.part = part ? 1 : 0; a.perm = perm;
     a.indeg2 = w.indeg2; a.outdeg2 = w.outdeg2; a.ho_deg = ho_deg; a.fo_deg = fo_deg;
     a.nu = w.nu; a.pc = w.pc; a.status = w.result + 1;
+    if (!part) {
+        a.hl = w.hl; a.src_t = w.src_t; a.ow_t = weight ? w.ow_t : nullptr;
+        a.is_t_out = w.is_t; a.is_a_out = w.is_a; a.is_u_out = w.is_u; a.is_w_out = w.is_w;
+    }
     rc = launch_mid_any<false>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n_own, delta_i, delta_f, a);
     if (rc != PP_OK) return rc;
     rc = exclusive_scan<int32_t, int32_t>(w.nu, n_own, fo_fwd_ptr, true, w.result + 4, w.scratch, w.scratch_bytes, st);
@@ -1045,13 +1070,11 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
     PP_REQUIRE(num_ho_edges >= 0 && (num_ho_edges == 0 || pair_scratch != nullptr), PP_ERR_ARG, "%s: pair_scratch (8 bytes per order-2 edge) missing", who);
     k_db2_pack_rows<<<egrid, kBlock, 0, st>>>(m, ho_deg, ho_bwd_ptr, w.row_pack);
     PP_LAUNCH_CHECK();
-    k_db2_gather_coef<<<egrid, kBlock, 0, st>>>(m, w.is_u, w.is_a, w.row_pack, fo_deg, w.du_s, w.ob_s, w.da_s);
-    PP_LAUNCH_CHECK();
     Db2Mid a{};
     mid_common(a, w, fo_bwd_ptr, weight != nullptr);
     a.lo = lo; a.n_own = n_own; a.part = part ? 1 : 0; a.perm = part ? w.perm : nullptr;
     a.ho_deg = const_cast<float*>(ho_deg); a.fo_deg = const_cast<float*>(fo_deg);
-    a.du_s = w.du_s; a.da_s = w.da_s; a.ob_s = w.ob_s;
+    a.row_pack = w.row_pack;
     a.ho_fwd_ptr = ho_fwd_ptr; a.fo_fwd_ptr = fo_fwd_ptr;
     a.in_idx2 = ho_fwd_idx; a.in_val2 = ho_fwd_val; a.out_pack = (uint2*)pair_scratch; a.self2 = ho_self;
     a.fwd_idx1 = fo_fwd_idx; a.fwd_val1 = fo_fwd_val; a.dst_order = fo_dst_order; a.self1 = fo_self;
