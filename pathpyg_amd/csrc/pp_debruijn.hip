@@ -142,7 +142,14 @@ __global__ __launch_bounds__(kBlock) void k_db2_unzip(int64_t n, const uint2* __
 // ------------------------------------------------------------------ out side: the successors of every node
 // kN nodes per wave, one after the other: the loads of all of them are issued before the first is worked on (the per-node work is a
 // chain of short dependent steps; 8 waves per SIMD alone do not hide the memory latency under it)
-constexpr int kDb2Nodes = 4;
+#ifndef PP_DB2_OUT_NODES
+#define PP_DB2_OUT_NODES 2
+#endif
+#ifndef PP_DB2_MID_NODES
+#define PP_DB2_MID_NODES 1
+#endif
+constexpr int kDb2OutNodes = PP_DB2_OUT_NODES;      // nodes per wave of k_db2_out
+constexpr int kDb2Nodes = PP_DB2_MID_NODES;         // nodes per wave of k_db2_mid
 
 template <bool kW>
 struct Db2OutIn {
@@ -161,26 +168,26 @@ __global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, int64_t lo, int64
                                                    uint8_t* __restrict__ fskip, int64_t* __restrict__ status) {
     // n nodes from node 0 (one GPU: all of them, all owned; partition shard: all of them, [lo, lo + n_own) owned — the lists of the FOREIGN
     // nodes hold their events into the owned range: their successor runs are the source-major rows of the rank's first-order shard)
-    const int64_t node0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * kDb2Nodes;
+    const int64_t node0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * kDb2OutNodes;
     if (node0 >= n) return;
     const int l = lane_id();
-    Db2OutIn<kW> in[kDb2Nodes];
+    Db2OutIn<kW> in[kDb2OutNodes];
 #pragma unroll
-    for (int s = 0; s < kDb2Nodes; ++s) {
+    for (int s = 0; s < kDb2OutNodes; ++s) {
         const int64_t node = node0 + s;
         const uint32_t b0 = node < n ? tp[node] : 0u, b1 = node < n ? tp[node + 1] : 0u;
         in[s].p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);          // (wave-uniform by construction: scalar loop bounds, scalar addresses)
         in[s].cnt = __builtin_amdgcn_readfirstlane((int)(b1 - b0));
     }
 #pragma unroll
-    for (int s = 0; s < kDb2Nodes; ++s) {
+    for (int s = 0; s < kDb2OutNodes; ++s) {
         const bool live = l < in[s].cnt && in[s].cnt <= kWave;
         in[s].c = live ? oc_t[in[s].p0 + l] : 0xFFFFFFFFu;
         in[s].tb = live ? ot_t[in[s].p0 + l] : 0ull;
         in[s].wv = (kW && live) ? ow_t[in[s].p0 + l] : 0.0f;
     }
 #pragma unroll
-    for (int s = 0; s < kDb2Nodes; ++s) {
+    for (int s = 0; s < kDb2OutNodes; ++s) {
         const int64_t node = node0 + s;
         if (node >= n) break;
         const uint32_t p0 = in[s].p0;
@@ -957,7 +964,7 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
         return PP_OK;
     }
     const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n_own > 0 ? n_own : 1, kWavesPerBlock * kDb2Nodes);
-    const unsigned agrid = (unsigned)ceil_div(n, kWavesPerBlock * kDb2Nodes);
+    const unsigned agrid = (unsigned)ceil_div(n, kWavesPerBlock * kDb2OutNodes);
     // 1. event records; out-lists (stable sort by tail: time order inside a list), then the list SEQUENCE sorted by head: in-lists in (source, time) order
     if (time_dtype == PP_I64) k_db2_keys<int64_t><<<egrid, kBlock, 0, st>>>(edge_index, (const int64_t*)time, m, n, w.tkeys, w.rec, w.result + 1);
     else k_db2_keys<double><<<egrid, kBlock, 0, st>>>(edge_index, (const double*)time, m, n, w.tkeys, w.rec, w.result + 1);
