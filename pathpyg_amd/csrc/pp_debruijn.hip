@@ -313,23 +313,6 @@ __global__ __launch_bounds__(kBlock) void k_db2_fo_part_bwd(int64_t m, int64_t l
     val[pos] = (int64_t)b == c ? 0.0f : inv_sqrt_deg(fo_deg[b]) * ow_s[p] * inv_sqrt_deg(fo_deg[c]);
 }
 
-// source-major coefficients of the first-order graph: val(b -> c) = d_b^-1/2 w d_c^-1/2, 0 on self loops (as k_gcn_coefficients)
-__global__ __launch_bounds__(kBlock) void k_db2_fo_bwd_val(int64_t m, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tkeys_s,
-                                                          const uint32_t* __restrict__ oc_s, const uint8_t* __restrict__ ocr_s,
-                                                          const int32_t* __restrict__ row_ptr, const float* __restrict__ fo_w,
-                                                          const float* __restrict__ fo_deg, float* __restrict__ fo_bwd_val) {
-    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (p >= m) return;
-    const uint32_t b = tkeys_s[p];
-    const uint32_t p0 = tp[b];
-    if (tp[b + 1] - p0 > (uint32_t)kWave) return;
-    const uint8_t cr = ocr_s[p];
-    if (!(p == p0 || ocr_s[p - 1] != cr)) return;
-    const uint32_t u = (uint32_t)row_ptr[b] + cr;
-    const uint32_t c = oc_s[p];
-    fo_bwd_val[u] = b == c ? 0.0f : inv_sqrt_deg(fo_deg[b]) * fo_w[u] * inv_sqrt_deg(fo_deg[c]);
-}
-
 // ------------------------------------------------------------------ middle-node pass
 struct Db2Mid {
     int64_t lo;                      // first owned node (0 on one GPU); arrays indexed by node: tp, hp, fo_deg GLOBAL ids, everything else owned-local
@@ -358,6 +341,9 @@ struct Db2Mid {
     int32_t *nu, *pc;
     int64_t* status;
     // fill pass
+    const uint32_t* oc_s;            // fill pass on one GPU: successor node of every out-event, merged first-order weights -> the source-major
+    const float* fo_w;               // first-order coefficients are written by the owner node's wave (what was k_db2_fo_bwd_val)
+    float* fo_bwd_val;
     const uint2* row_pack;           // per order-2 row: (d^-1/2 bits, start of its source-major row): gathered by the fill pass's lanes themselves
     const int32_t *ho_fwd_ptr, *fo_fwd_ptr;
     int32_t *in_idx2, *fwd_idx1, *dst_order;
@@ -458,6 +444,16 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
             in[s].du = __uint_as_float(rp.x);
             in[s].ob = (int32_t)rp.y;
             in[s].da = ok ? inv_sqrt_deg(a.fo_deg[in[s].ia]) : 0.0f;
+            if (a.fo_bwd_val != nullptr) {
+                // source-major coefficients of the node's first-order out-edges (one per successor run): val(b -> c) = d_b^-1/2 w d_c^-1/2, 0 on a self loop
+                const bool lo_ = in[s].no <= kWave && in[s].ni <= kWave && l < in[s].no;
+                const int prev = __shfl_up(in[s].cr, 1, kWave);
+                if (lo_ && (l == 0 || in[s].cr != prev)) {
+                    const uint32_t u = (uint32_t)in[s].row0 + (uint32_t)in[s].cr;
+                    const uint32_t c = a.oc_s[in[s].p0 + l];
+                    a.fo_bwd_val[u] = (uint32_t)(a.lo + node0 + s) == c ? 0.0f : in[s].d1 * a.fo_w[u] * inv_sqrt_deg(a.fo_deg[c]);
+                }
+            }
         }
 #pragma unroll
         for (int s = 0; s < kDb2Nodes; ++s) {
@@ -1082,6 +1078,7 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
     a.lo = lo; a.n_own = n_own; a.part = part ? 1 : 0; a.perm = part ? w.perm : nullptr;
     a.ho_deg = const_cast<float*>(ho_deg); a.fo_deg = const_cast<float*>(fo_deg);
     a.row_pack = w.row_pack;
+    if (!part) { a.oc_s = w.oc_s; a.fo_w = fo_w; a.fo_bwd_val = fo_bwd_val; }
     a.ho_fwd_ptr = ho_fwd_ptr; a.fo_fwd_ptr = fo_fwd_ptr;
     a.in_idx2 = ho_fwd_idx; a.in_val2 = ho_fwd_val; a.out_pack = (uint2*)pair_scratch; a.self2 = ho_self;
     a.fwd_idx1 = fo_fwd_idx; a.fwd_val1 = fo_fwd_val; a.dst_order = fo_dst_order; a.self1 = fo_self;
@@ -1091,8 +1088,7 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
         k_db2_unzip<<<(unsigned)ceil_div(num_ho_edges, kBlock), kBlock, 0, st>>>(num_ho_edges, (const uint2*)pair_scratch, ho_bwd_idx, ho_bwd_val);
         PP_LAUNCH_CHECK();
     }
-    if (!part) k_db2_fo_bwd_val<<<egrid, kBlock, 0, st>>>(m, w.tp, w.tkeys_s, w.oc_s, w.ocr_s, fo_bwd_ptr, fo_w, fo_deg, fo_bwd_val);
-    else k_db2_fo_part_bwd<<<egrid, kBlock, 0, st>>>(m, lo, n_own, w.tp, w.tkeys_s, w.oc_s, w.ocr_s, w.ow_s, w.fskip, fo2_bwd_ptr, fo_deg, fo2_bwd_idx, fo_bwd_val);
+    if (part) k_db2_fo_part_bwd<<<egrid, kBlock, 0, st>>>(m, lo, n_own, w.tp, w.tkeys_s, w.oc_s, w.ocr_s, w.ow_s, w.fskip, fo2_bwd_ptr, fo_deg, fo2_bwd_idx, fo_bwd_val);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
