@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.0, help="p_dropout of the model (the headline number is quoted at 0; the reference's own test uses 0.4)")
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--mode", choices=("partition", "streams"), default="partition")
+    ap.add_argument("--no-api-path", action="store_true", help="skip the extra (untimed for `value`) steps through the reference API that fill api_path_ms_per_step")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: host-staged collectives (tests; several ranks may share one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (single-GPU test boxes, with --backend gloo)")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="run R ranks of the partition path as R threads on ONE GPU, taking turns: per-rank "
@@ -642,8 +643,10 @@ def main() -> int:
         import pathpyg_amd.nn.sharded as _sh
         _sh.OWNED_ROW_BACKWARD = False
     if args.builder == "generic":
+        import pathpyg_amd.core.multi_order_model as _mm0
         import pathpyg_amd.distributed as _pd0
         _pd0.FUSED_BUILDER = False
+        _mm0.FUSED_BUILDER = False
     if args.fo_halo != "auto":
         import pathpyg_amd.distributed as _pd
         _pd.FO_DENSE_HALO = args.fo_halo == "dense"
@@ -737,7 +740,7 @@ def main() -> int:
         opt.step()
         if timed:
             lift_ms.append((e0, e1))
-        if not sizes:
+        if "E2" not in sizes:
             sizes.update({"m": args.events, "N": args.nodes, "E2": int(pp.algorithms.lift_order_temporal(g, args.delta).size(1)),
                           "U2": mom.layers[2].n, "A1": mom.layers[1].m, "A2": mom.layers[2].m})
         return loss
@@ -755,6 +758,18 @@ def main() -> int:
             return wrapped
         _hip.gcn_plan, _hip.bipartite_plan = registering(_hip.gcn_plan), registering(_hip.bipartite_plan)
         _hip.bipartite_plan_from_edge_grouping = registering(_hip.bipartite_plan_from_edge_grouping)
+        fused_api = _hip.debruijn2
+
+        def debruijn2_registering(*a, **kw):          # the API path on the fused builder: its plans come out of pp_debruijn2_*
+            built = fused_api(*a, **kw)
+            if built is not None:
+                for plan in (built.fo, built.ho):
+                    register_plan(plan)
+                    SRC_ROWS[plan.fwd_idx.data_ptr()], SRC_ROWS[plan.bwd_idx.data_ptr()] = plan.n_src, plan.n_dst
+                sizes.update(built.sizes)
+                sizes["builder"] = "fused"
+            return built
+        _hip.debruijn2 = debruijn2_registering
 
     def barrier():
         if launched:
@@ -808,6 +823,29 @@ def main() -> int:
             del generic
         else:
             generic_steps = args.steps
+    # The same step through the REFERENCE API (MultiOrderModel.from_temporal_graph -> to_dbgnn_data -> DBGNN.forward -> cross_entropy ->
+    # backward -> Adam; reference multi_order_model.py:124-192, 511-554, nn/dbgnn.py:121-151), timed after the headline region on the same
+    # stream and model: what a drop-in user of the reference API gets
+    api_path = None
+    if partition and rank == 0 and world == 1 and not args.no_api_path:
+        api_sizes = dict(sizes)
+        for _ in range(max(3, min(args.warmup, 5))):
+            step_streams(False)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            step_streams(True)
+        torch.cuda.synchronize()
+        api_ms = 1e3 * (time.perf_counter() - ta) / args.steps
+        api_lift = lift_ms[-args.steps:]
+        del lift_ms[-args.steps:]
+        api_path = {"what": "MultiOrderModel.from_temporal_graph(g, delta, max_order=2) -> to_dbgnn_data(x, x_h) -> DBGNN.forward -> cross_entropy -> "
+                            "backward -> Adam, same stream / model / step count, timed after the headline region",
+                    "ms_per_step": api_ms, "graph_construction_ms": sum(a.elapsed_time(b) for a, b in api_lift) / len(api_lift),
+                    "builder": "fused (pp_debruijn2_*)" if getattr(pp.MultiOrderModel.from_temporal_graph(g, delta=args.delta, max_order=2), "_pp_fused", None)
+                    is not None else "generic kernels"}
+        sizes.clear()
+        sizes.update(api_sizes)
     # untimed extra: the k=2 -> k=3 line-graph lift of the same event graph (the lift kernel WITHOUT the continuation-list gather)
     k3 = None
     if rank == 0:
@@ -918,6 +956,9 @@ def main() -> int:
                                      "frac": (agg_bytes / (agg_total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if agg_total_ms > 0 else 0.0},
             "linegraph_fill_roofline": k3,
         }
+        if api_path is not None:
+            line["api_path_ms_per_step"] = api_path["ms_per_step"]
+            line["api_path"] = api_path
         if fused_ran:
             (fkey, (n_f, f_ms, _)), = fused_clock.groups().items()
             build_bytes = lift_bytes + agg_bytes                       # what the generic lift + both aggregations move algorithmically

@@ -99,7 +99,9 @@ int pp_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t
  *   fill phase: ho_fwd_idx/val [A2] (in-edges of every order-2 node, ascending source), ho_bwd_idx/val [A2], ho_self [U2];
  *     fo_fwd_idx/val [A1], fo_dst_order [A1] (edge id = order-2 node id of every in-edge: the bipartite "last" grouping),
  *     fo_bwd_val [U2], fo_self [N].  Values are the normalised coefficients d_src^-1/2 w d_dst^-1/2 (0 on self-loop entries).
- *     num_ho_edges = A2; pair_scratch: 8 * A2 bytes of device scratch (the source-major rows are scattered as 8-byte pairs, then split). */
+ *     num_ho_edges = A2; pair_scratch: 8 * A2 bytes of device scratch (the source-major rows are scattered as 8-byte pairs, then split).
+ *     ho_fwd_w [A2] (optional, may be NULL): the merged weights THEMSELVES (lift_order.py:139, coalesce "sum") in destination-major order —
+ *     what MultiOrderModel.layers[2].data.edge_weight is derived from when a caller reads it. */
 size_t pp_debruijn2_ws_bytes(int64_t m, int64_t num_nodes);
 int pp_debruijn2_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i,
                        double delta_f, const float* weight, int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr,
@@ -108,7 +110,7 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
                       const int32_t* fo_bwd_ptr, const float* fo_w, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr, const int32_t* ho_bwd_ptr,
                       const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx,
                       float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order, float* fo_bwd_val,
-                      float* fo_self, void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream);
+                      float* fo_self, float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream);
 
 /* The same builder on ONE RANK of a node-range partition (the lift shards by edge range, the DBGNN by destination-node
  * partition; no reference counterpart — the reference is single-process).  Rank `rank` owns the first-order nodes

@@ -713,21 +713,27 @@ def bipartite_plan(bipartite_index: torch.Tensor, n_ho: int, n_fo: int, pair_val
     return plan
 
 
+_INT32_ROWS = 0x7ffffff0           # sizes the int32 CSR arrays of the order-2 builder can hold
+
+
 class DeBruijn2:
     """Result of :func:`debruijn2`: the GCN plans of the first-order and the order-2 graph of a temporal stream, the bipartite "last" plan
     and the layer sizes (``m`` events, ``E2`` lifted instance pairs, ``U2`` order-2 nodes = first-order edges, ``A2`` order-2 edges)."""
 
-    __slots__ = ("fo", "ho", "bip", "sizes", "fo_weight", "fo_dst")
+    __slots__ = ("fo", "ho", "bip", "sizes", "fo_weight", "fo_dst", "ho_fwd_weight")
 
     def __init__(self, **kw):
         for k in self.__slots__:
             setattr(self, k, kw.get(k))
 
 
-def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, weight: torch.Tensor | None = None):
+def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, weight: torch.Tensor | None = None,
+              want_weights: bool = False, unsorted_ok: bool = False):
     """Order-2 De Bruijn model of a TIME-SORTED event stream, fused (pp_debruijn2_count / _fill, csrc/pp_debruijn.hip): what
     ``coalesce`` (layer 1) + ``temporal_lift`` + ``coalesce`` (layer 2) + ``gcn_plan`` x 2 + ``bipartite_plan_from_edge_grouping`` build,
     identical array by array, with ONE read-back and without the event graph.  ``weight``: None (unit weights) or float32 [m].
+    ``want_weights``: also keep the merged order-2 weights themselves (``ho_fwd_weight`` [A2], destination-major order, beside the normalised
+    coefficients of the plan) — what ``MultiOrderModel.layers[2].data.edge_weight`` is derived from when it is read.
     Returns a :class:`DeBruijn2`, or ``None`` when the builder does not apply (a node with more than 64 in- or out-events, an empty
     stream): the caller then takes the generic path."""
     ei = _edge_index(edge_index)
@@ -762,9 +768,13 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
         u2, status, a2, e2, a1 = ws[:40].view(torch.int64).tolist()                      # the ONE read-back of the whole graph construction
         _bad_index(status, "MultiOrderModel.from_temporal_graph")
         if status & 2:
+            if unsorted_ok:           # (the caller sorts and takes the generic path: MultiOrderModel.from_temporal_graph, multi_order_model.py:148-151)
+                return None
             raise ValueError("lift_order_temporal: the events are not sorted by time (TemporalGraph sorts them on construction; "
                              "data.time / data.edge_index were modified afterwards)")
         if status & 4:
+            return None
+        if a2 >= _INT32_ROWS:           # the builder's row pointers are int32 (the scan's TOTAL is int64, so this is the true A2): generic kernels
             return None
         ho = CsrPlan(n_dst=u2, n_src=u2, fwd_ptr=ho_fwd_ptr[: u2 + 1], fwd_idx=torch.empty(a2, **i32), fwd_val=torch.empty(a2, **f32),
                      bwd_ptr=ho_bwd_ptr[: u2 + 1], bwd_idx=torch.empty(a2, **i32), bwd_val=torch.empty(a2, **f32), self_coef=torch.empty(u2, **f32),
@@ -772,13 +782,14 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
         fo = CsrPlan(n_dst=n, n_src=n, fwd_ptr=fo_fwd_ptr, fwd_idx=torch.empty(a1, **i32), fwd_val=torch.empty(a1, **f32),
                      bwd_ptr=fo_bwd_ptr, bwd_idx=fo_bwd_idx[:u2], bwd_val=torch.empty(u2, **f32), self_coef=torch.empty(n, **f32),
                      dst_order=torch.empty(a1, **i32), edge_ordered=True)
+        ho_fwd_w = torch.empty(a2, **f32) if want_weights else None
         check(L.pp_debruijn2_fill(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr), _p(ho_bwd_ptr),
                                   _p(ho_deg), _p(fo_deg), a2, _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx), _p(ho.bwd_val), _p(ho.self_coef),
-                                  _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.dst_order), _p(fo.bwd_val), _p(fo.self_coef),
+                                  _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.dst_order), _p(fo.bwd_val), _p(fo.self_coef), _p(ho_fwd_w),
                                   _p(torch.empty(2 * a2, **i32)), _p(ws), ws.numel(), _stream()),
               "pp_debruijn2_fill")
     bip = bipartite_plan_from_edge_grouping(fo, None, u2)
-    return DeBruijn2(fo=fo, ho=ho, bip=bip, fo_weight=fo_w[:u2], fo_dst=fo.bwd_idx,
+    return DeBruijn2(fo=fo, ho=ho, bip=bip, fo_weight=fo_w[:u2], fo_dst=fo.bwd_idx, ho_fwd_weight=ho_fwd_w,
                      sizes={"m": m, "N": n, "E2": e2, "U2": u2, "A1": a1, "A2": a2})
 
 
@@ -800,8 +811,11 @@ def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
     (time-sorted) events that start or end in that range.  Everything :func:`debruijn2` counts, restricted to the owned middle nodes, plus the
     halo numbering (sources (a, b) with a foreign a, in (owner of a, b, a) order behind the owned rows) and the LOCAL ROW ORDER: owned rows (b, c)
     whose c another rank owns come first, grouped by that rank, ordered by (c, b) = the receiver's halo order — the send list of every exchange
-    is the prefix ``[0, n_send)`` of a row matrix; ``row_of[local row]`` = lexicographic row.  ONE read-back.  ``None``: empty shard
-    inputs the builder does not take (the caller falls back); ``status`` bit 2 set: a node with more than 64 in- / out-events."""
+    is the prefix ``[0, n_send)`` of a row matrix; ``row_of[local row]`` = lexicographic row.  ONE read-back.  ``None``: inputs the builder does
+    not take — a shard without events or without nodes, a weight that is not float32 (the caller reports it in its agreement collective and
+    every rank falls back).  Bad input is NOT raised here: a rank sees only its own events, so the caller gathers ``status`` (bit 0: node index
+    out of range, bit 1: events not sorted by time, bit 2: a node with more than 64 in- / out-events) from all ranks and raises everywhere
+    (a rank-local raise in front of a collective leaves the other ranks blocked in it)."""
     ei = _edge_index(edge_index)
     dev = require_device(ei, time, weight, cuts_dev)
     if time.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
@@ -812,6 +826,8 @@ def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
     m, n = ei.size(1), int(num_nodes)
     world = int(cuts_dev.numel()) - 1
     n_own = int(node_hi) - int(node_lo)
+    if m == 0 or n_own <= 0:            # (pp_debruijn2_part_count leaves the shard-level outputs of such a rank unwritten: ADVICE r4)
+        return None
     if weight is not None:
         if weight.dtype != torch.float32 or weight.numel() != m:
             return None
@@ -838,10 +854,9 @@ def debruijn2_part_count(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
                                         _p(ws), ws.numel(), _stream()), "pp_debruijn2_part_count")
         head = ws[: 8 * (8 + 2 * (world + 1))].view(torch.int64).tolist()                 # the ONE read-back of this rank's graph construction
     u2, status, a2, e2, a1, n_halo, n_send = head[:7]
+    if a2 >= _INT32_ROWS or u2 + n_halo >= _INT32_ROWS:          # int32 row pointers / local ids would wrap: reported like a hub node, every rank falls back
+        status |= 4
     recv_ptr, send_ptr = head[8: 8 + world + 1], head[8 + world + 1: 8 + 2 * (world + 1)]
-    _bad_index(status, "MultiOrderModel.from_temporal_graph (partition)")
-    if status & 2:
-        raise ValueError("lift_order_temporal: the events are not sorted by time")
     return DeBruijn2Part(m=m, n=n, lo=int(node_lo), n_own=n_own, world=world, args=(tcode, kind, di, df, weight), ws=ws, bufs=bufs, u2=u2, status=status,
                          a2=a2, e2=e2, a1=a1, n_halo=n_halo, n_send=n_send, recv_counts=[recv_ptr[r + 1] - recv_ptr[r] for r in range(world)],
                          send_counts=[send_ptr[r + 1] - send_ptr[r] for r in range(world)], row_of=bufs["row_of"][:u2],

@@ -42,11 +42,12 @@ class IndexMap:
         """Higher-order map whose ID of node ``r`` is the tuple of ``base`` IDs of ``node_sequence[r]``
         (what reference multi_order_model.py:119,177-179 builds with a Python loop)."""
         out = cls()
-        k = int(node_sequence.size(1))
+        k = int(node_sequence.shape[1])
         out.id_shape = (-1, k)
 
         def materialise() -> np.ndarray:
-            idx = node_sequence.detach().cpu().numpy()
+            ns = node_sequence.resolve() if hasattr(node_sequence, "resolve") else node_sequence       # (a data.Lazy of a builder-made layer)
+            idx = ns.detach().cpu().numpy()
             return base.node_ids[idx] if base.has_ids else idx
 
         out._pending = materialise

@@ -23,7 +23,7 @@ from ..algorithms.lift_order import (
     lift_order_edge_index_weighted,
 )
 from ..algorithms.temporal import lift_order_temporal
-from ..data import Data
+from ..data import Data, Lazy
 from ..utils.dbgnn import generate_bipartite_edge_index
 from .graph import Graph
 from .index_map import IndexMap
@@ -31,6 +31,8 @@ from .path_data import PathData
 from .temporal_graph import TemporalGraph
 
 logger = logging.getLogger("pathpyg_amd")
+
+FUSED_BUILDER = True    # from_temporal_graph(max_order=2) on device-resident streams: the node-by-node order-2 builder (pp_debruijn2_*); False = generic kernels
 
 
 class MultiOrderModel:
@@ -85,6 +87,10 @@ class MultiOrderModel:
 
         Same layers as the reference, computed without ever materialising the per-instance node sequences
         (``[E_k, k+1]`` tensors): see :class:`_LiftChain`."""
+        if max_order == 2 and event_graph is None and FUSED_BUILDER:
+            fused = _second_order_fused(g, delta, weight, cached)
+            if fused is not None:
+                return fused
         m = MultiOrderModel()
         data = g.data if g.data.is_sorted_by_time() else g.data.sort_by_time()
         edge_index = data.edge_index
@@ -268,14 +274,40 @@ class MultiOrderModel:
         g = self.layers[1]
         g_ho = self.layers[max_order]
         n, n_ho = g.data.num_nodes, g_ho.data.num_nodes
-        dev = g.data.edge_index.device
+        built = self._fused_plans(max_order, mapping)
+        dev = built.fo.fwd_ptr.device if built is not None else g.data.edge_index.device
         x_eye = x_h_eye = False
         if x is None:
             x_eye = g.data.x is None
             x = g.data.x if g.data.x is not None else torch.eye(n, n, device=dev)
         if x_h is None:
             x_h_eye = True
-            x_h = torch.eye(n_ho, n_ho, device=g_ho.data.edge_index.device)
+            x_h = torch.eye(n_ho, n_ho, device=dev if built is not None else g_ho.data.edge_index.device)
+        if built is not None:
+            # The layers came out of the order-2 builder together with the plans DBGNN.forward needs (GCN normalisation of both graphs, the
+            # bipartite "last" grouping): the bundle hands the plans over and keeps the reference's tensors as deferred views of the layers —
+            # a training step that only runs the model never materialises [2, A2] indices (reference multi_order_model.py:511-554 builds
+            # them eagerly; PyG's GCNConv re-normalises on every forward)
+            u2, a2 = int(n_ho), int(built.sizes["A2"])
+            out = Data(
+                num_nodes=n,
+                num_ho_nodes=n_ho,
+                x=x,
+                x_h=x_h,
+                edge_index=Lazy(lambda: g.data.edge_index, (2, u2)),
+                edge_index_higher_order=Lazy(lambda: g_ho.data.edge_index, (2, a2)),
+                edge_weights=g.data.edge_weight.float(),
+                edge_weights_higher_order=Lazy(lambda: g_ho.data.edge_weight.float(), (a2,)),
+                bipartite_edge_index=Lazy(lambda: generate_bipartite_edge_index(g, g_ho, mapping=mapping, device=dev), (2, u2)),
+                y=g.data.y,
+            )
+            names = ("edge_index", "edge_weights", "edge_index_higher_order", "edge_weights_higher_order", "bipartite_edge_index")
+            stamp = {name: out.peek(name) for name in names}
+            object.__setattr__(out, "_pp_plans", {"fo": built.fo, "ho": built.ho, "bi": built.bip, "stamp": stamp,
+                                                  "versions": {k: v._version for k, v in stamp.items() if isinstance(v, torch.Tensor)}})
+            object.__setattr__(out, "_pp_hints", {"stamp": (), "x_eye": (out.x, out.x._version) if x_eye else None,
+                                                  "x_h_eye": (out.x_h, out.x_h._version) if x_h_eye else None})
+            return out
         out = Data(
             num_nodes=n,
             num_ho_nodes=n_ho,
@@ -303,9 +335,99 @@ class MultiOrderModel:
         return out
 
 
+    def _fused_plans(self, max_order: int, mapping: str):
+        """The builder result behind ``layers[1]`` / ``layers[2]`` when both still are what :func:`_second_order_fused` made (same objects,
+        edge tensors neither replaced nor edited in place) and the bundle asked for is the one its plans describe; else ``None``."""
+        rec = getattr(self, "_pp_fused", None)
+        if rec is None or max_order != 2 or mapping != "last":
+            return None
+        built, layers = rec
+        for k, (graph, lazies) in layers.items():
+            if self.layers.get(k) is not graph:
+                return None
+            for name, made in lazies.items():
+                cur = graph.data.peek(name)
+                if isinstance(made, Lazy):
+                    if not (cur is made or (made.value is not None and cur is made.value and cur._version == made.version)):
+                        return None
+                elif not (cur is made[0] and cur._version == made[1]):
+                    return None
+        return built
+
+
 def _hip_unit() -> str:
     from .._hip import UNIT
     return UNIT
+
+
+def _csr_rows(ptr: torch.Tensor, total: int) -> torch.Tensor:
+    """Row id of every entry of a CSR with int32 row pointers ``ptr`` (int64 [total])."""
+    n = ptr.numel() - 1
+    return torch.repeat_interleave(torch.arange(n, device=ptr.device), (ptr[1:] - ptr[:-1]).long(), output_size=total)
+
+
+def _second_order_fused(g: TemporalGraph, delta, weight: str, cached: bool):
+    """``from_temporal_graph(g, delta, max_order=2)`` on the fused order-2 builder (``_hip.debruijn2`` -> ``pp_debruijn2_count / _fill``): ONE pass
+    over the stream yields both layers as CSR plans — no event graph, no ``[E_2, 2]`` instance tensors, one read-back.  The reference's layer
+    tensors (reference multi_order_model.py:153-181: ``edge_index``, ``edge_weight``, ``node_sequence``, ``inverse_idx`` of both layers) are
+    :class:`~pathpyg_amd.data.Lazy` views of those plans, identical to what the generic kernels produce, made when somebody reads them.
+    ``None``: the builder does not apply (host-resident stream, a weight attribute that is not float32, an unsorted stream, a hub node)."""
+    from .. import _hip
+    data = g.data
+    ei = _dispatch.plain(data.edge_index)
+    time = data.time
+    if ei is None or time is None or not ei.is_cuda or not time.is_cuda:
+        return None
+    w = None
+    if weight in data:
+        w = data[weight]
+        if not isinstance(w, torch.Tensor) or w.dtype != torch.float32 or not w.is_cuda:
+            return None
+    n, m_events = int(data.num_nodes), int(ei.size(1))
+    if n == 0 or m_events == 0:
+        return None
+    built = _hip.debruijn2(ei, time, n, delta, w, want_weights=True, unsorted_ok=True)
+    if built is None:
+        return None
+    dev = ei.device
+    fo, ho = built.fo, built.ho
+    u2, a2 = int(built.sizes["U2"]), int(built.sizes["A2"])
+
+    lazy1 = {"edge_index": Lazy(lambda: torch.stack((_csr_rows(fo.bwd_ptr, u2), fo.bwd_idx.long())), (2, u2)),
+             "node_sequence": Lazy(lambda: torch.arange(n, device=dev).unsqueeze(1), (n, 1)),
+             "inverse_idx": Lazy(lambda: torch.arange(n, device=dev), (n,))}
+    d1 = Data(edge_index=lazy1["edge_index"], num_nodes=n, node_sequence=lazy1["node_sequence"], edge_weight=built.fo_weight,
+              inverse_idx=lazy1["inverse_idx"])
+    g1 = Graph._from_parts(d1, g.mapping)
+
+    def weights2():
+        # the builder keeps the merged weights in destination-major order (contiguous stores); the layer lists its edges source-major
+        e2 = d2.edge_index
+        key_fwd = _csr_rows(ho.fwd_ptr, a2) * u2 + ho.fwd_idx.long()                       # ascending: rows ascending, sources ascending inside a row
+        return built.ho_fwd_weight[torch.searchsorted(key_fwd, e2[1] * u2 + e2[0])]
+
+    def inverse2():
+        # order-2 node of every event = its merged first-order edge (lift_order.py:133 on the [m, 2] instance rows)
+        e1 = d1.edge_index
+        return torch.searchsorted(e1[0] * n + e1[1], ei[0] * n + ei[1])
+
+    lazy2 = {"edge_index": Lazy(lambda: torch.stack((_csr_rows(ho.bwd_ptr, a2), ho.bwd_idx.long())), (2, a2)),
+             "node_sequence": Lazy(lambda: d1.edge_index.t().contiguous(), (u2, 2)),
+             "edge_weight": Lazy(weights2, (a2,)),
+             "inverse_idx": Lazy(inverse2, (m_events,))}
+    d2 = Data(edge_index=lazy2["edge_index"], num_nodes=u2, node_sequence=lazy2["node_sequence"], edge_weight=lazy2["edge_weight"],
+              inverse_idx=lazy2["inverse_idx"])
+    g2 = Graph._from_parts(d2, IndexMap.from_node_sequence(g.mapping, lazy2["node_sequence"]))
+    g2._nodes_are_fo_edges = True
+    out = MultiOrderModel()
+    if cached:
+        out.layers[1] = g1
+    out.layers[2] = g2
+    if cached:
+        out._pp_fused = (built, {1: (g1, {"edge_index": lazy1["edge_index"], "edge_weight": (built.fo_weight, built.fo_weight._version)}),
+                                 2: (g2, {"edge_index": lazy2["edge_index"], "edge_weight": lazy2["edge_weight"]})})
+    out.sizes = dict(built.sizes)
+    return out
 
 
 class _LiftChain:

@@ -348,6 +348,7 @@ struct Db2Mid {
     const int32_t *ho_fwd_ptr, *fo_fwd_ptr;
     int32_t *in_idx2, *fwd_idx1, *dst_order;
     float *in_val2, *self2, *fwd_val1, *self1;
+    float* in_w2;                    // optional: the merged weights themselves in destination-major order (MultiOrderModel.layers[2].data.edge_weight)
     uint2* out_pack;
     // count -> fill: a node whose in-runs are single events that reach no successor run twice is SIMPLE: run_em[position of the in-event] = the
     // successor runs it reaches (bit = lane of the run's first out-event); the fill pass then handles all its runs at once (no window tests)
@@ -536,6 +537,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
                     const float val = su == vc ? 0.0f : in[s].du * wgt * dvc;
                     a.in_idx2[ipc + pos] = (int32_t)su;
                     a.in_val2[ipc + pos] = val;
+                    if (a.in_w2) a.in_w2[ipc + pos] = wgt;
                     a.out_pack[in[s].ob + rank] = make_uint2(vc, __float_as_uint(val));
                     left &= left - 1;
                 }
@@ -654,6 +656,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
                     const float val = ucur == v ? 0.0f : du_ * wgt * dv;
                     a.in_idx2[ip + cnt] = (int32_t)ucur;
                     a.in_val2[ip + cnt] = val;
+                    if (a.in_w2) a.in_w2[ip + cnt] = wgt;
                     const int rank = (int)__popcll(em & lanes_below(l));
                     a.out_pack[ob_ + rank] = make_uint2(v, __float_as_uint(val));
                     ++cnt;
@@ -762,11 +765,15 @@ __global__ __launch_bounds__(kBlock) void k_db2_bip_count(int64_t cap_m, const i
 
 // fwd_idx: the local rows in padded-destination order = [rows for ranks below me | kept rows | rows for ranks above me]; self_coef = in-degree
 __global__ __launch_bounds__(kBlock) void k_db2_bip_fill(int64_t total, const int64_t* __restrict__ result, const uint32_t* __restrict__ send_keys_s,
-                                                        int64_t cap_m, int64_t lo, int64_t num_nodes, int64_t n_pad, const int32_t* __restrict__ cnt,
-                                                        int32_t* __restrict__ fwd_idx, float* __restrict__ self_coef) {
+                                                        int64_t cap_m, int64_t lo, int64_t num_nodes, int64_t n_pad, void* cnt_then_self_coef,
+                                                        int32_t* __restrict__ fwd_idx) {
+    // the per-destination counts (int32) are converted IN PLACE into the self coefficients (float): one buffer, one pointer
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= total) return;
-    if (j < n_pad) self_coef[j] = (float)cnt[j];
+    if (j < n_pad) {
+        const int32_t c = ((const int32_t*)cnt_then_self_coef)[j];
+        ((float*)cnt_then_self_coef)[j] = (float)c;
+    }
     const int64_t u2 = result[0];
     if (j >= u2) return;
     const int64_t n_below = lower_bound_dev<uint32_t, int64_t>(send_keys_s, 0, cap_m, (uint32_t)lo);              // rows whose successor lies below my range
@@ -1013,7 +1020,7 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
         rc = exclusive_scan<int32_t, int32_t>(bcnt, n_pad, pt.bip_fwd_ptr, true, nullptr, w.scratch, w.scratch_bytes, st);
         if (rc != PP_OK) return rc;
         const int64_t total = n_pad > m ? n_pad : m;
-        k_db2_bip_fill<<<(unsigned)ceil_div(total, kBlock), kBlock, 0, st>>>(total, w.result, w.xkeys_s, m, pt.lo, n, n_pad, bcnt, pt.bip_fwd_idx, pt.bip_self);
+        k_db2_bip_fill<<<(unsigned)ceil_div(total, kBlock), kBlock, 0, st>>>(total, w.result, w.xkeys_s, m, pt.lo, n, n_pad, (void*)pt.bip_self, pt.bip_fwd_idx);
         PP_LAUNCH_CHECK();
     }
     k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, fo_bwd_ptr, perm, w.src_t);
@@ -1063,7 +1070,7 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
                     const int32_t* ho_fwd_ptr, const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t num_ho_edges,
                     int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx,
                     float* fo_fwd_val, int32_t* fo_dst_order, const int32_t* fo2_bwd_ptr, int32_t* fo2_bwd_idx, float* fo_bwd_val, float* fo_self,
-                    void* pair_scratch, void* ws, size_t ws_bytes, hipStream_t st) {
+                    float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, hipStream_t st) {
     PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "%s: negative size", who);
     Db2Ws w = carve_db2(ws, m, n);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "%s: workspace too small", who);
@@ -1080,7 +1087,7 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
     a.row_pack = w.row_pack;
     if (!part) { a.oc_s = w.oc_s; a.fo_w = fo_w; a.fo_bwd_val = fo_bwd_val; }
     a.ho_fwd_ptr = ho_fwd_ptr; a.fo_fwd_ptr = fo_fwd_ptr;
-    a.in_idx2 = ho_fwd_idx; a.in_val2 = ho_fwd_val; a.out_pack = (uint2*)pair_scratch; a.self2 = ho_self;
+    a.in_idx2 = ho_fwd_idx; a.in_val2 = ho_fwd_val; a.in_w2 = ho_fwd_w; a.out_pack = (uint2*)pair_scratch; a.self2 = ho_self;
     a.fwd_idx1 = fo_fwd_idx; a.fwd_val1 = fo_fwd_val; a.dst_order = fo_dst_order; a.self1 = fo_self;
     int rc = launch_mid_any<true>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n_own, delta_i, delta_f, a);
     if (rc != PP_OK) return rc;
@@ -1109,10 +1116,10 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
                       const int32_t* fo_bwd_ptr, const float* fo_w, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr, const int32_t* ho_bwd_ptr,
                       const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx,
                       float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order, float* fo_bwd_val,
-                      float* fo_self, void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream) {
+                      float* fo_self, float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream) {
     return db2_fill("pp_debruijn2_fill", time_dtype, m, num_nodes, 0, num_nodes, false, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_w, fo_fwd_ptr,
                     ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_fwd_idx, fo_fwd_val,
-                    fo_dst_order, nullptr, nullptr, fo_bwd_val, fo_self, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
+                    fo_dst_order, nullptr, nullptr, fo_bwd_val, fo_self, ho_fwd_w, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
@@ -1137,7 +1144,7 @@ int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t
                            void* ws, size_t ws_bytes, pp_stream_t stream) {
     return db2_fill("pp_debruijn2_part_fill", time_dtype, m, num_nodes, node_lo, n_own, true, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, nullptr,
                     fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_fwd_idx,
-                    fo_fwd_val, nullptr, fo_shard_bwd_ptr, fo_shard_bwd_idx, fo_shard_bwd_val, fo_self, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
+                    fo_fwd_val, nullptr, fo_shard_bwd_ptr, fo_shard_bwd_idx, fo_shard_bwd_val, fo_self, nullptr, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

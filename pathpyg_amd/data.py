@@ -16,15 +16,46 @@ import torch
 _OPTIONAL = ("x", "y", "pos", "edge_index", "edge_attr", "edge_weight", "time")
 
 
+class Lazy:
+    """A tensor of a :class:`Data` bag that is made on first access (``make()``); ``shape`` answers the size questions without it.
+    Layers that come out of the fused order-2 builder (``pp_debruijn2_*``) hold CSR plans: their ``[2, E]`` edge indices, merged weights,
+    node sequences and inverse maps are derived from those only when somebody reads them.  After the first access the bag holds the
+    tensor itself; the ``Lazy`` remembers it (``value`` / ``version``) so that objects derived from the unresolved form can be told valid."""
+
+    __slots__ = ("make", "shape", "value", "version")
+
+    def __init__(self, make, shape):
+        self.make, self.shape = make, tuple(int(s) for s in shape)
+        self.value, self.version = None, -1
+
+    def resolve(self):
+        if self.value is None:
+            self.value = self.make()
+            self.version = self.value._version
+            self.make = None
+        return self.value
+
+
 class Data:
     def __init__(self, **attrs: Any) -> None:
         object.__setattr__(self, "_store", {})
         for key, value in attrs.items():
             self[key] = value
 
+    def _resolved(self, key: str) -> Any:
+        value = self._store[key]
+        if isinstance(value, Lazy):
+            value = value.resolve()
+            self._store[key] = value
+        return value
+
+    def peek(self, key: str) -> Any:
+        """The stored object as it is (a :class:`Lazy` stays unresolved); ``None`` when absent."""
+        return self._store.get(key)
+
     # ------------------------------------------------------------ mapping protocol
     def __getitem__(self, key: str) -> Any:
-        return self._store[key]
+        return self._resolved(key)
 
     def __setitem__(self, key: str, value: Any) -> None:
         if value is None and key in self._store:
@@ -41,7 +72,10 @@ class Data:
     def __getattr__(self, key: str) -> Any:
         store = object.__getattribute__(self, "_store")
         if key in store:
-            return store[key]
+            value = store[key]
+            if isinstance(value, Lazy):
+                value = store[key] = value.resolve()
+            return value
         if key in _OPTIONAL:
             return None
         raise AttributeError(f"'Data' object has no attribute '{key}'")
@@ -59,13 +93,13 @@ class Data:
         return list(self._store.keys())
 
     def __iter__(self) -> Iterator[tuple[str, Any]]:
-        return iter(self._store.items())
+        return iter([(key, self._resolved(key)) for key in list(self._store)])
 
     def __len__(self) -> int:
         return len(self._store)
 
     def to_dict(self) -> dict:
-        return dict(self._store)
+        return dict(iter(self))
 
     # ------------------------------------------------------------ sizes
     @property
@@ -75,7 +109,7 @@ class Data:
         x = self._store.get("x")
         if isinstance(x, torch.Tensor):
             return x.size(0)
-        ei = self._store.get("edge_index")
+        ei = self._resolved("edge_index") if "edge_index" in self._store else None
         if isinstance(ei, torch.Tensor) and ei.numel() > 0:
             return int(ei.max()) + 1
         return None
@@ -87,6 +121,8 @@ class Data:
     @property
     def num_edges(self) -> int:
         ei = self._store.get("edge_index")
+        if isinstance(ei, Lazy):
+            return ei.shape[-1]
         return int(ei.size(-1)) if isinstance(ei, torch.Tensor) else 0
 
     # ------------------------------------------------------------ attribute classification (PyG heuristics)
@@ -96,6 +132,8 @@ class Data:
 
     def _length_along_cat_dim(self, key: str):
         value = self._store[key]
+        if isinstance(value, Lazy):
+            return (value.shape[self._cat_dim(key)], False) if value.shape else (None, False)
         if isinstance(value, (list, tuple)):
             return len(value), True
         if not isinstance(value, (torch.Tensor, np.ndarray)) or value.ndim == 0:
@@ -126,19 +164,19 @@ class Data:
 
     # ------------------------------------------------------------ device / time helpers
     def to(self, device) -> "Data":
-        for key, value in list(self._store.items()):
+        for key, value in list(iter(self)):
             if isinstance(value, torch.Tensor):
                 self._store[key] = value.to(device)
         return self
 
     def clone(self) -> "Data":
         out = Data()
-        for key, value in self._store.items():
+        for key, value in iter(self):
             out[key] = value.clone() if isinstance(value, torch.Tensor) else value
         return out
 
     def is_sorted_by_time(self) -> bool:
-        t = self._store.get("time")
+        t = self._resolved("time") if "time" in self._store else None
         if t is None or t.numel() < 2:
             return True
         from . import _dispatch
@@ -146,10 +184,10 @@ class Data:
 
     def sort_by_time(self) -> "Data":
         from . import _dispatch
-        t = self._store["time"]
+        t = self._resolved("time")
         perm = _dispatch.stable_argsort(t)
         out = Data()
-        for key, value in self._store.items():
+        for key, value in iter(self):
             if key == "edge_index":
                 out[key] = value[:, perm]
             elif key == "time" or self.is_edge_attr(key):
@@ -161,7 +199,7 @@ class Data:
     def __repr__(self) -> str:
         parts = []
         for key, value in self._store.items():
-            if isinstance(value, torch.Tensor):
+            if isinstance(value, (torch.Tensor, Lazy)):
                 parts.append(f"{key}={list(value.shape)}")
             else:
                 parts.append(f"{key}={value!r}")

@@ -1236,7 +1236,13 @@ def _build_partitioned_by_node(g, delta, x, x_h, y, comm: Comm, ops, weight: str
     c = ops.debruijn2_part_count(ns.ei, ns.time, n, lo_n, hi_n, ns.cuts_t, rank, delta, ns.w, cap_n)
     comm.mark("build: 1 order-2 builder, count pass (sorts, successor blocks, halo numbering, send lists)")
     # sizes of all ranks: global order-2 id ranges, E2, and whether everybody can stay on this path (one tiny collective)
-    sizes_all = comm.all_gather_ints([c.u2 if c is not None else 0, c.e2 if c is not None else 0, 1 if (c is None or c.status & 4) else 0], dev)
+    sizes_all = comm.all_gather_ints([c.u2 if c is not None else 0, c.e2 if c is not None else 0, 1 if (c is None or c.status & 4) else 0,
+                                      (c.status & 3) if c is not None else 0], dev)
+    # bad input seen by ANY rank is raised by EVERY rank, after the collective (a rank holds only its own events)
+    if any(row[3] & 1 for row in sizes_all):
+        raise IndexError("MultiOrderModel.from_temporal_graph (partition): node index out of range")
+    if any(row[3] & 2 for row in sizes_all):
+        raise ValueError("lift_order_temporal: the events are not sorted by time")
     if any(row[2] for row in sizes_all):
         return None
     ho_cuts = [0]

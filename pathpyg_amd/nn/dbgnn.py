@@ -419,6 +419,27 @@ def _valid_hints(data) -> dict:
     return hints
 
 
+def _valid_plans(data):
+    """``(first-order plan, higher-order plan, bipartite plan)`` handed over by ``MultiOrderModel.to_dbgnn_data`` when the layers came out of
+    the order-2 builder (``pp_debruijn2_*`` builds the GCN normalisation of both graphs and the bipartite grouping with the layers) — honoured
+    only while the bundle's five graph tensors are what the plans were made for: still deferred, or resolved to the deferred value and not
+    edited in place since; a replaced or edited tensor sends ``forward`` to the plans built from the tensors."""
+    rec = getattr(data, "_pp_plans", None)
+    peek = getattr(data, "peek", None)
+    if not rec or peek is None:
+        return None
+    for name, made in rec["stamp"].items():
+        cur = peek(name)
+        if isinstance(made, torch.Tensor):
+            if not (cur is made and cur._version == rec["versions"][name]):
+                return None
+        elif not (cur is made or (made.value is not None and cur is made.value and cur._version == made.version)):
+            return None
+    if int(data.num_nodes) != rec["fo"].n_dst or int(data.num_ho_nodes) != rec["ho"].n_dst:
+        return None
+    return rec["fo"], rec["ho"], rec["bi"]
+
+
 def _is_hinted_eye(data, name: str) -> bool:
     """``data.x`` / ``data.x_h`` is the identity matrix ``MultiOrderModel.to_dbgnn_data`` created (its own stamp: assigning other features
     later leaves the other hints alone)."""
@@ -496,22 +517,27 @@ class DBGNN(Module):
         n_fo, n_ho = int(data.num_nodes), int(data.num_ho_nodes)
         # bundles made by MultiOrderModel.to_dbgnn_data carry hints (every Graph's edge index is row-sorted, the bipartite
         # sources are arange) that save three device round trips; foreign bundles are checked on the device instead
-        hints = _valid_hints(data)
-        rows_sorted = True if hints.get("rows_sorted") else None
-        bip_sorted = True if hints.get("bipartite_sources_sorted") else None
-        from_edges = bool(hints.get("bipartite_is_fo_edge_heads"))     # order-2 temporal model, "last" mapping: no bipartite sort
-        pending = []
-        plan_fo = _cached(data, "fo", (data.edge_index, data.edge_weights),
-                          lambda: _hip.gcn_plan(data.edge_index, data.edge_weights, n_fo, rows_sorted, pending, want_dst_order=from_edges))
-        plan_ho = _cached(data, "ho", (data.edge_index_higher_order, data.edge_weights_higher_order),
-                          lambda: _hip.gcn_plan(data.edge_index_higher_order, data.edge_weights_higher_order, n_ho, rows_sorted, pending))
-        if not from_edges:
-            plan_bi = _cached(data, "bi", (data.bipartite_edge_index,),
-                              lambda: _hip.bipartite_plan(data.bipartite_edge_index, n_ho, n_fo, None, bip_sorted, pending))
-        _hip.check_plan_status(pending)
-        if from_edges:
-            plan_bi = _cached(data, "bi", (data.edge_index, data.edge_weights),
-                              lambda: _hip.bipartite_plan_from_edge_grouping(plan_fo, _dispatch_plain(data.edge_index)[1], n_ho))
+        handed = _valid_plans(data)
+        if handed is not None:
+            # the layers came out of the fused order-2 builder with their plans: nothing to normalise, sort or check here
+            plan_fo, plan_ho, plan_bi = handed
+        else:
+            hints = _valid_hints(data)
+            rows_sorted = True if hints.get("rows_sorted") else None
+            bip_sorted = True if hints.get("bipartite_sources_sorted") else None
+            from_edges = bool(hints.get("bipartite_is_fo_edge_heads"))     # order-2 temporal model, "last" mapping: no bipartite sort
+            pending = []
+            plan_fo = _cached(data, "fo", (data.edge_index, data.edge_weights),
+                              lambda: _hip.gcn_plan(data.edge_index, data.edge_weights, n_fo, rows_sorted, pending, want_dst_order=from_edges))
+            plan_ho = _cached(data, "ho", (data.edge_index_higher_order, data.edge_weights_higher_order),
+                              lambda: _hip.gcn_plan(data.edge_index_higher_order, data.edge_weights_higher_order, n_ho, rows_sorted, pending))
+            if not from_edges:
+                plan_bi = _cached(data, "bi", (data.bipartite_edge_index,),
+                                  lambda: _hip.bipartite_plan(data.bipartite_edge_index, n_ho, n_fo, None, bip_sorted, pending))
+            _hip.check_plan_status(pending)
+            if from_edges:
+                plan_bi = _cached(data, "bi", (data.edge_index, data.edge_weights),
+                                  lambda: _hip.bipartite_plan_from_edge_grouping(plan_fo, _dispatch_plain(data.edge_index)[1], n_ho))
 
         if self.p_dropout > 0 and self.training:
             # dropout -> GCNConv -> ELU (reference dbgnn.py:131-146).  The layers stay on the fused kernels (aggregation + MFMA product + bias +
