@@ -790,7 +790,7 @@ def main() -> int:
             KernelClock(L, "pp_temporal_fill", lambda m, n, total, *r: ("k_expand (pp_temporal_fill)", 16 * total + 12 * m)) as fill_clock, \
             KernelClock(L, "pp_temporal_count", lift_desc, until="pp_temporal_fill") as lift_clock, \
             KernelClock(L, "pp_coalesce_count", coalesce_desc, until="pp_coalesce_fill") as agg_clock, \
-            KernelClock(L, "pp_debruijn2_count", lambda ei_p, t_p, tdt, m, *r: ("fused order-2 builder (pp_debruijn2_count .. pp_debruijn2_fill)", 24 * m),
+            KernelClock(L, "pp_debruijn2_lists", lambda ei_p, t_p, tdt, m, *r: ("fused order-2 builder (pp_debruijn2_lists .. pp_debruijn2_fill)", 24 * m),
                         until="pp_debruijn2_fill") as fused_clock:
         clocks = (spmm_clock, fwd_clock, bwd_clock, fill_clock, lift_clock, agg_clock, fused_clock)
         for _ in range(args.warmup):

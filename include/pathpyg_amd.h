@@ -84,18 +84,30 @@ int pp_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t
 /* MultiOrderModel.from_temporal_graph(g, delta, max_order=2) (src/pathpyG/core/multi_order_model.py:124-192: lift_order_temporal,
  * algorithms/temporal.py:17-54, + aggregate_edge_index for layers 1 and 2, algorithms/lift_order.py:109-152) together with what
  * DBGNN.forward derives from the two layers on every call (gcn_norm through GCNConv, src/pathpyG/nn/dbgnn.py:104-114,130-140) and the
- * bipartite "last" index (utils/dbgnn.py:10-46) — in ONE count -> read-back -> fill pair, node by node, without materialising the
- * event graph.  Same inputs as pp_temporal_count (time-sorted events, delta as torch.tensor(delta) sees it); weight: NULL (every event
- * weighs 1: the reference's default torch.ones) or float32 [m].  Results are identical, array by array, to
- * pp_coalesce_* (layer 1) -> pp_temporal_* -> pp_coalesce_* (layer 2) -> pp_gcn_plan x 2 on the same stream.
+ * bipartite "last" index (utils/dbgnn.py:10-46) — node by node, without materialising the event graph, in three calls:
+ *   pp_debruijn2_lists  the two sorts of the events (out-lists, in-lists), hub classification -> 16 int64 statistics copied to `host_stats`
+ *                       (pinned host memory; the copy is asynchronous and followed by the out-side kernel of the ordinary nodes, so that
+ *                       pp_debruijn2_lists_wait — the ONE call of this library that blocks — returns while the GPU is still busy);
+ *   pp_debruijn2_count  everything up to the sizes (the first five int64 of ws), which the caller reads back;
+ *   pp_debruijn2_fill   both plans.
+ * Same inputs as pp_temporal_count (time-sorted events, delta as torch.tensor(delta) sees it); weight: NULL (every event weighs 1: the
+ * reference's default torch.ones) or float32 [m].  Results are identical, array by array, to pp_coalesce_* (layer 1) -> pp_temporal_* ->
+ * pp_coalesce_* (layer 2) -> pp_gcn_plan x 2 on the same stream (bit for bit where the partial sums are exact: see "hub nodes" in
+ * pp_debruijn.hip for streams with non-integer weights on nodes of more than 64 events).
+ * HUB NODES: a node with more than 64 in- or more than 64 out-events is worked on by several waves (chunks of 256 in-events) instead of
+ * one; host_stats = {hub nodes, (out-hubs << 32) | their out-events, tasks, part columns, -, longest rows (4), longest in-list, longest
+ * out-list, ...} sizes the extra workspace: pp_debruijn2_hub_ws_bytes(out-hub events, out-hubs, part columns); the same five numbers go to
+ * count and fill (all 0 and hub_ws NULL when there is no hub).  After count the hub block (ws int64 [138 .. 154)) also holds [4] the lifted
+ * pairs through hub nodes (E2 = ws[3] + that) and [5..8] the longest order-2 destination- / source-major and first-order destination- /
+ * source-major row among the hubs' rows (the caller's chunked pre-pass for rows beyond 512 entries, pp_spmm_heavy_f32).
  * Order-2 node u = first-order edge u (lexicographic (src, dst) order).  Outputs, all int32 / float32:
  *   count phase (capacities in brackets; U2 = order-2 nodes, A2 = order-2 edges, A1 = U2 = first-order edges):
  *     fo_bwd_ptr [N+1], fo_bwd_idx [m], fo_w [m]     source-major first-order graph: successors of every node + merged weights (first U2 entries)
  *     fo_fwd_ptr [N+1]                                destination-major row pointers of the first-order graph
  *     ho_fwd_ptr [m+1], ho_bwd_ptr [m+1]              row pointers of the order-2 graph, destination- / source-major (first U2+1 entries; constant after)
  *     ho_deg [m], fo_deg [N]                          weighted in-degree incl. the self loop of gcn_norm (add_remaining_self_loops, fill 1)
- *   the first five int64 of ws = {U2, status, A2, E2, A1}; status bit 0: node index outside [0, N); bit 1: time not ascending;
- *     bit 2: a node has more than 64 in- or out-events — this builder does not apply, use the generic entry points.
+ *   the first five int64 of ws = {U2, status, A2, E2 (without the hubs' pairs), A1}; status bit 0: node index outside [0, N); bit 1: time
+ *     not ascending; bit 2: (partition shards only) a node has more than 64 in- or out-events.
  *   fill phase: ho_fwd_idx/val [A2] (in-edges of every order-2 node, ascending source), ho_bwd_idx/val [A2], ho_self [U2];
  *     fo_fwd_idx/val [A1], fo_dst_order [A1] (edge id = order-2 node id of every in-edge: the bipartite "last" grouping),
  *     fo_bwd_val [U2], fo_self [N].  Values are the normalised coefficients d_src^-1/2 w d_dst^-1/2 (0 on self-loop entries).
@@ -103,14 +115,21 @@ int pp_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t
  *     ho_fwd_w [A2] (optional, may be NULL): the merged weights THEMSELVES (lift_order.py:139, coalesce "sum") in destination-major order —
  *     what MultiOrderModel.layers[2].data.edge_weight is derived from when a caller reads it. */
 size_t pp_debruijn2_ws_bytes(int64_t m, int64_t num_nodes);
-int pp_debruijn2_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i,
-                       double delta_f, const float* weight, int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr,
-                       int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr, float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, pp_stream_t stream);
+size_t pp_debruijn2_hub_ws_bytes(int64_t hub_out_events, int64_t out_hubs, int64_t hub_parts);
+int pp_debruijn2_lists(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, const float* weight, void* ws,
+                       size_t ws_bytes, int64_t* host_stats, pp_stream_t stream);
+int pp_debruijn2_lists_wait(void);
+int pp_debruijn2_count(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
+                       int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
+                       float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, int64_t hub_nodes, int64_t out_hubs, int64_t hub_out_events,
+                       int64_t hub_tasks, int64_t hub_parts, void* hub_ws, size_t hub_ws_bytes, pp_stream_t stream);
 int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
-                      const int32_t* fo_bwd_ptr, const float* fo_w, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr, const int32_t* ho_bwd_ptr,
-                      const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx,
-                      float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order, float* fo_bwd_val,
-                      float* fo_self, float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream);
+                      const int32_t* fo_bwd_ptr, const int32_t* fo_bwd_idx, const float* fo_w, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr,
+                      const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val,
+                      int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order,
+                      float* fo_bwd_val, float* fo_self, float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, int64_t hub_nodes,
+                      int64_t out_hubs, int64_t hub_out_events, int64_t hub_tasks, int64_t hub_parts, void* hub_ws, size_t hub_ws_bytes,
+                      pp_stream_t stream);
 
 /* The same builder on ONE RANK of a node-range partition (the lift shards by edge range, the DBGNN by destination-node
  * partition; no reference counterpart — the reference is single-process).  Rank `rank` owns the first-order nodes

@@ -7,6 +7,8 @@ happens in the HIP kernels.  There is no CPU implementation behind these calls.
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 
 from ._lib import check, lib
@@ -727,15 +729,30 @@ class DeBruijn2:
             setattr(self, k, kw.get(k))
 
 
+_HUB_STATS = 8 + 2 * (64 + 1)          # index of the hub block inside the builder's int64 result header (csrc/pp_debruijn.hip: kDb2HubStats)
+_HUB_PART_BYTES_MAX = 24 << 30         # per-task partial results of the hub nodes (768 bytes per part column): beyond this the generic kernels
+_tls = threading.local()
+
+
+def _pinned_stats() -> torch.Tensor:
+    """Pinned int64 [16] of the calling thread: where pp_debruijn2_lists copies the hub statistics (asynchronously)."""
+    buf = getattr(_tls, "stats", None)
+    if buf is None:
+        buf = _tls.stats = torch.empty(16, dtype=torch.int64).pin_memory()
+    return buf
+
+
 def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, weight: torch.Tensor | None = None,
               want_weights: bool = False, unsorted_ok: bool = False):
-    """Order-2 De Bruijn model of a TIME-SORTED event stream, fused (pp_debruijn2_count / _fill, csrc/pp_debruijn.hip): what
+    """Order-2 De Bruijn model of a TIME-SORTED event stream, fused (pp_debruijn2_lists / _count / _fill, csrc/pp_debruijn.hip): what
     ``coalesce`` (layer 1) + ``temporal_lift`` + ``coalesce`` (layer 2) + ``gcn_plan`` x 2 + ``bipartite_plan_from_edge_grouping`` build,
-    identical array by array, with ONE read-back and without the event graph.  ``weight``: None (unit weights) or float32 [m].
+    identical array by array, without the event graph.  Two read-backs: the hub statistics (behind the sorts; the wait runs under the
+    out-side kernel) and the layer sizes.  Nodes with more than 64 in- / out-events (hubs) are worked on chunk-wise by the same builder;
+    rows of more than 512 entries get the chunk tables of the DBGNN kernels (``HeavyRows``).  ``weight``: None (unit weights) or float32 [m].
     ``want_weights``: also keep the merged order-2 weights themselves (``ho_fwd_weight`` [A2], destination-major order, beside the normalised
     coefficients of the plan) — what ``MultiOrderModel.layers[2].data.edge_weight`` is derived from when it is read.
-    Returns a :class:`DeBruijn2`, or ``None`` when the builder does not apply (a node with more than 64 in- or out-events, an empty
-    stream): the caller then takes the generic path."""
+    Returns a :class:`DeBruijn2`, or ``None`` when the builder does not apply (an empty stream, a weight vector that is not float32, more than
+    2^31 order-2 edges, hub partials beyond 24 GiB; with ``unsorted_ok`` an unsorted stream): the caller then takes the generic path."""
     ei = _edge_index(edge_index)
     dev = require_device(ei, time, weight)
     if time.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
@@ -758,14 +775,32 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         ws = _workspace(L.pp_debruijn2_ws_bytes(m, n), dev)
-        fo_bwd_ptr, fo_fwd_ptr = torch.empty(n + 1, **i32), torch.empty(n + 1, **i32)
+        tcode = _DTYPE_CODE[time.dtype]
+        stats = _pinned_stats()
+        check(L.pp_debruijn2_lists(_p(ei), _p(time), tcode, m, n, _p(weight), _p(ws), ws.numel(), stats.data_ptr(), _stream()), "pp_debruijn2_lists")
+        fo_bwd_ptr, fo_fwd_ptr = torch.empty(n + 1, **i32), torch.empty(n + 1, **i32)       # (allocated while the GPU sorts)
         fo_bwd_idx, fo_w = torch.empty(m, **i32), torch.empty(m, **f32)
         ho_fwd_ptr, ho_bwd_ptr = torch.empty(m + 1, **i32), torch.empty(m + 1, **i32)
         ho_deg, fo_deg = torch.empty(m, **f32), torch.empty(n, **f32)
-        tcode = _DTYPE_CODE[time.dtype]
-        check(L.pp_debruijn2_count(_p(ei), _p(time), tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_bwd_idx), _p(fo_w), _p(fo_fwd_ptr),
-                                   _p(ho_fwd_ptr), _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), _p(ws), ws.numel(), _stream()), "pp_debruijn2_count")
-        u2, status, a2, e2, a1 = ws[:40].view(torch.int64).tolist()                      # the ONE read-back of the whole graph construction
+        check(L.pp_debruijn2_lists_wait(), "pp_debruijn2_lists_wait")                         # read-back 1 of 2: is there a hub node, how large
+        hubs, packed, tasks, parts = (int(v) for v in stats[:4].tolist())
+        out_hubs, out_events = packed >> 32, packed & 0xFFFFFFFF
+        hub_ws = None
+        if hubs:
+            if parts * 768 > _HUB_PART_BYTES_MAX:
+                return None
+            hub_ws = _workspace(L.pp_debruijn2_hub_ws_bytes(out_events, out_hubs, parts), dev)
+        hub_args = (hubs, out_hubs, out_events, tasks, parts, _p(hub_ws), hub_ws.numel() if hub_ws is not None else 0)
+        check(L.pp_debruijn2_count(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_bwd_idx), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr),
+                                   _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), _p(ws), ws.numel(), *hub_args, _stream()), "pp_debruijn2_count")
+        if hubs:
+            head = ws[: 8 * (_HUB_STATS + 16)].view(torch.int64).tolist()                    # read-back 2 of 2: the layer sizes (+ the hubs' share)
+            u2, status, a2, e2, a1 = head[:5]
+            e2 += head[_HUB_STATS + 4]
+            longest = head[_HUB_STATS + 5: _HUB_STATS + 9]
+        else:
+            u2, status, a2, e2, a1 = ws[:40].view(torch.int64).tolist()
+            longest = (0, 0, 0, 0)
         _bad_index(status, "MultiOrderModel.from_temporal_graph")
         if status & 2:
             if unsorted_ok:           # (the caller sorts and takes the generic path: MultiOrderModel.from_temporal_graph, multi_order_model.py:148-151)
@@ -783,14 +818,23 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
                      bwd_ptr=fo_bwd_ptr, bwd_idx=fo_bwd_idx[:u2], bwd_val=torch.empty(u2, **f32), self_coef=torch.empty(n, **f32),
                      dst_order=torch.empty(a1, **i32), edge_ordered=True)
         ho_fwd_w = torch.empty(a2, **f32) if want_weights else None
-        check(L.pp_debruijn2_fill(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr), _p(ho_bwd_ptr),
-                                  _p(ho_deg), _p(fo_deg), a2, _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx), _p(ho.bwd_val), _p(ho.self_coef),
-                                  _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.dst_order), _p(fo.bwd_val), _p(fo.self_coef), _p(ho_fwd_w),
-                                  _p(torch.empty(2 * a2, **i32)), _p(ws), ws.numel(), _stream()),
+        check(L.pp_debruijn2_fill(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_bwd_idx), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr),
+                                  _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), a2, _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx), _p(ho.bwd_val),
+                                  _p(ho.self_coef), _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.dst_order), _p(fo.bwd_val), _p(fo.self_coef), _p(ho_fwd_w),
+                                  _p(torch.empty(2 * a2, **i32)), _p(ws), ws.numel(), *hub_args, _stream()),
               "pp_debruijn2_fill")
+        # hub rows of the plans (more than 512 entries): the chunk tables of the row kernels' pre-pass, as pp_gcn_plan's report triggers them
+        if longest[0] > HEAVY_ROW_ENTRIES:
+            ho.fwd_heavy = HeavyRows(ho.fwd_ptr, u2)
+        if longest[1] > HEAVY_ROW_ENTRIES:
+            ho.bwd_heavy = HeavyRows(ho.bwd_ptr, u2)
+        if longest[2] > HEAVY_ROW_ENTRIES:
+            fo.fwd_heavy = HeavyRows(fo.fwd_ptr, n)
+        if longest[3] > HEAVY_ROW_ENTRIES:
+            fo.bwd_heavy = HeavyRows(fo.bwd_ptr, n)
     bip = bipartite_plan_from_edge_grouping(fo, None, u2)
     return DeBruijn2(fo=fo, ho=ho, bip=bip, fo_weight=fo_w[:u2], fo_dst=fo.bwd_idx, ho_fwd_weight=ho_fwd_w,
-                     sizes={"m": m, "N": n, "E2": e2, "U2": u2, "A1": a1, "A2": a2})
+                     sizes={"m": m, "N": n, "E2": e2, "U2": u2, "A1": a1, "A2": a2, "hub_nodes": hubs, "hub_tasks": tasks})
 
 
 class DeBruijn2Part:

@@ -22,14 +22,19 @@
 //               coefficients d^-1/2 w d^-1/2 of both CSRs, the first-order graph's destination-major CSR and the bipartite index.
 // The event graph never exists in HBM; E2 (the number of lifted instance pairs) is the sum of the popcounts.  Results are IDENTICAL to the
 // generic path (same ids, same order inside every row, same fp32 sums) — tests/test_gpu_builder.py compares them array by array.
-// Limits: a node with more than 64 in- or out-events sets status bit 2 (kDb2Overflow) and the caller falls back to the generic path (hub
-// nodes of scale-free streams); event weights float32 or absent (unit weights: the reference's default torch.ones).
+// HUB NODES (round 5): a node with more than 64 in- or out-events does not fit one wave.  pp_debruijn2_lists classifies the nodes after the two
+// sorts and reports {hub nodes, their out-events, tasks, part columns} (the caller reads them back while the out-side kernel of the other
+// nodes runs); such nodes are then worked on by k_db2_hub — see "hub nodes" below — and every other node stays on the one-wave kernels: no
+// whole-stream fallback.  Node-range partitions (pp_debruijn2_part_*) still report hubs through status bit 2 (kDb2Overflow) and their
+// caller falls back.  Event weights float32 or absent (unit weights: the reference's default torch.ones).
 #include "pp_internal.h"
 #include "pp_window.h"
 
 namespace pp {
 
 constexpr int64_t kDb2BadIndex = 1, kDb2Unsorted = 2, kDb2Overflow = 4;
+constexpr int kHubChunk = 256;                        // in-events per hub task (one wave)
+constexpr uint8_t kHubOut = 1, kHubIn = 2;            // hub_flag bits: more than 64 out-events / in-events
 constexpr uint32_t kDb2Foreign = 0xFFFFFFFEu;         // order-2 node of an event whose source node another rank owns: numbered on the head side
 
 struct alignas(16) Db2Rec {
@@ -58,6 +63,7 @@ __device__ __forceinline__ float inv_sqrt_deg(float deg) {
 }
 template <typename TimeT>
 __device__ __forceinline__ TimeT time_of(uint64_t bits) { return __builtin_bit_cast(TimeT, bits); }
+__device__ __forceinline__ int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------ flat (one thread per event) kernels: every random access of the builder
 // lives here, at full memory-level parallelism; the per-node kernels below read and write contiguous ranges only
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, int64_t lo, int64
                                                    const uint64_t* __restrict__ ot_t, const float* __restrict__ ow_t, uint64_t* __restrict__ ot_s,
                                                    uint32_t* __restrict__ oc_s, float* __restrict__ ow_s, uint8_t* __restrict__ ocr_s,
                                                    uint8_t* __restrict__ ocr_t, int32_t* __restrict__ blk, int32_t* __restrict__ fblk,
-                                                   uint8_t* __restrict__ fskip, int64_t* __restrict__ status) {
+                                                   uint8_t* __restrict__ fskip, int64_t* __restrict__ status, int hubs_handled) {
     // n nodes from node 0 (one GPU: all of them, all owned; partition shard: all of them, [lo, lo + n_own) owned — the lists of the FOREIGN
     // nodes hold their events into the owned range: their successor runs are the source-major rows of the rank's first-order shard)
     const int64_t node0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * kDb2OutNodes;
@@ -195,6 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, int64_t lo, int64
         const int64_t nl = node - lo;
         const bool own = nl >= 0 && nl < n_own;
         const int64_t jloc = own ? nl : (node < lo ? n_own + node : node);          // dense local source space [owned | ids below lo | ids from hi on]
+        if (cnt > kWave && hubs_handled) continue;             // (an out-hub: k_db2_hub_out_* rank its out-events and write its block size)
         if (cnt > kWave || cnt == 0) {
             if (l == 0) {
                 if (own) blk[nl] = 0;
@@ -251,14 +258,25 @@ __global__ __launch_bounds__(kBlock) void k_db2_out(int64_t n, int64_t lo, int64
 __global__ __launch_bounds__(kBlock) void k_db2_out_heads(int64_t m, int64_t lo, int64_t n_own, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tkeys_s,
                                                          const uint32_t* __restrict__ oc_s, const float* __restrict__ ow_s,
                                                          const uint8_t* __restrict__ ocr_s, const int32_t* __restrict__ row_ptr,
-                                                         int32_t* __restrict__ fo_bwd_idx, float* __restrict__ fo_w) {
+                                                         int32_t* __restrict__ fo_bwd_idx, float* __restrict__ fo_w,
+                                                         const uint32_t* __restrict__ hoff, const uint32_t* __restrict__ rank_s) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= m) return;
     const uint32_t b = tkeys_s[p];
     const int64_t bl = (int64_t)b - lo;
     if (bl < 0 || bl >= n_own) return;
     const uint32_t p0 = tp[b];
-    if (tp[b + 1] - p0 > (uint32_t)kWave) return;              // (overflow node: the caller falls back)
+    if (tp[b + 1] - p0 > (uint32_t)kWave) {
+        if (rank_s == nullptr) return;                         // (partition shard: overflow node, the caller falls back)
+        const uint32_t j = hoff[b] + ((uint32_t)p - p0);       // out-hub: 32-bit successor ranks in the hub scratch
+        const uint32_t cr = rank_s[j];
+        if (p == p0 || rank_s[j - 1] != cr) {
+            const uint32_t u = (uint32_t)row_ptr[bl] + cr;
+            fo_bwd_idx[u] = (int32_t)oc_s[p];
+            fo_w[u] = ow_s[p];
+        }
+        return;
+    }
     const uint8_t cr = ocr_s[p];
     if (p == p0 || ocr_s[p - 1] != cr) {
         const uint32_t u = (uint32_t)row_ptr[bl] + cr;
@@ -272,7 +290,8 @@ __global__ __launch_bounds__(kBlock) void k_db2_out_heads(int64_t m, int64_t lo,
 __global__ __launch_bounds__(kBlock) void k_db2_out_fill(int64_t m, int64_t lo, int64_t n_own, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tkeys_s,
                                                         const uint64_t* __restrict__ ot_t, const uint8_t* __restrict__ ocr_t,
                                                         const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ perm,
-                                                        Db2Src* __restrict__ src_t) {
+                                                        Db2Src* __restrict__ src_t, const uint32_t* __restrict__ hoff,
+                                                        const uint32_t* __restrict__ rank_t) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= m) return;
     const uint32_t b = tkeys_s[p];
@@ -286,6 +305,8 @@ __global__ __launch_bounds__(kBlock) void k_db2_out_fill(int64_t m, int64_t lo, 
     } else if (tp[b + 1] - tp[b] <= (uint32_t)kWave) {         // (else an overflow node: its events keep the id 0xFFFFFFFF, the caller falls back)
         const uint32_t row = (uint32_t)row_ptr[bl] + ocr_t[p];
         r.u = perm ? (uint32_t)perm[row] : row;
+    } else if (rank_t != nullptr) {                            // out-hub (one GPU): rank of the event's successor from the hub scratch
+        r.u = (uint32_t)row_ptr[bl] + rank_t[hoff[b] + ((uint32_t)p - tp[b])];
     }
     src_t[p] = r;
 }
@@ -354,6 +375,7 @@ struct Db2Mid {
     // successor runs it reaches (bit = lane of the run's first out-event); the fill pass then handles all its runs at once (no window tests)
     uint64_t* run_em;
     uint8_t* node_simple;
+    int hubs_handled;                // one GPU: nodes with more than 64 in- / out-events are left to k_db2_hub (no overflow status)
 };
 
 template <bool kFill, bool kW>
@@ -471,6 +493,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
         const uint32_t gnode = (uint32_t)(a.lo + node);
         const int no = in[s].no, ni = in[s].ni;
         if (no > kWave || ni > kWave) {
+            if (a.hubs_handled) continue;
             if (!kFill && l == 0) {
                 atomicOr((unsigned long long*)a.status, (unsigned long long)kDb2Overflow);
                 a.nu[node] = 0; a.pc[node] = 0; a.fo_deg[gnode] = 1.0f; a.fo_lw[node] = 1.0f; a.node_simple[node] = 0;
@@ -700,6 +723,458 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
     }
 }
 
+// ------------------------------------------------------------------ hub nodes (round 5)
+// A node with more than 64 in-events or more than 64 out-events.  Every order-2 edge through it is still decided by its in-events x
+// out-events; what changes is who works on them:
+//   k_db2_hub_classify   one thread per node, after both row pointers: hub flags, and for every hub its tasks (chunks of kHubChunk in-events,
+//                        one wave each), its slice of the per-task partial results and — for more than 64 out-events — its slice of the
+//                        out-hub scratch.  The totals {hubs, out-hub events, tasks, part columns} are what pp_debruijn2_lists reports.
+//   k_db2_hub_out_*      out-events of the out-hubs in (successor, time) order by ONE radix sort of (slice, successor) keys over exactly
+//                        those events (the list sequence is in time order and the sort is stable), then run heads -> scan -> 32-bit
+//                        successor ranks, run starts, block sizes, merged first-order weights — what k_db2_out does in registers.
+//   k_db2_hub            the middle-node pass of one task.  LANES ARE SUCCESSOR RUNS (64 per round; a node with more runs takes several rounds
+//                        over its in-chunk), in-events are walked one by one.  Continuations of in-event i inside run r: with at most 64
+//                        out-events the window ballot over the out-events in registers, popcount against the run's lane mask (as k_db2_mid);
+//                        with more, two bisections over the run's times (it is sorted by time) for the window t_i < t <= t_i + delta.
+//                        At the end of an in-run (a, b): ballot of the runs it reached = its out-degree / its source-major row, every
+//                        reached run takes one more entry of its destination-major row.  A run that starts in the chunk is finished by this
+//                        task however far it reaches; a chunk that starts inside a run skips to its end (bisection: sources ascend).
+//                        Count pass: per task and run the number of entries, the weighted-degree share and the self-loop weight (a part
+//                        column of 64 lanes); k_db2_hub_combine turns them into in-degrees, degrees and EXCLUSIVE prefixes per task, in task
+//                        order (fixed summation order, bit-reproducible); the fill pass starts every row at its task's prefix.
+// Sums: in-run weights and degrees are summed in (in-event, task) order — identical to the one-wave kernels and the generic path whenever
+// the partial sums are exactly representable (unit and integer-valued weights below 2^24), a different association of the same fp32 terms
+// otherwise (as the chunked reduction of long runs in pp_coalesce_*); with more than 64 out-events an in-event's weight enters as
+// w * (number of continuations) instead of by repeated addition.
+struct Db2Hub {
+    const uint8_t* flag;             // [n] kHubOut | kHubIn
+    const uint32_t *hoff, *oslot;    // [n] out-hubs: first slot of the out-hub scratch, index among the out-hubs
+    const uint32_t *tbase;           // [n] first task of a hub
+    const int64_t* pbase;            // [n] first part column of a hub
+    const uint32_t *task_node, *hub_list;
+    const uint32_t* run_start;       // out-hub scratch: [hoff + oslot + r] = first out-event (list-relative) of successor run r, one sentinel behind
+    int32_t* part_cnt;               // [P * 64] per (task, round, run): entries (count pass), then their exclusive prefix over the tasks
+    float *part_deg, *part_lw;
+    int32_t *task_runs, *task_runbase;
+    float *task_deg1, *task_lw1;
+    int64_t* stats;                  // result + kDb2HubStats
+    int64_t num_nodes;
+    const int32_t* succ;             // fill: successor node of every order-2 row (fo_bwd_idx)
+};
+constexpr int kDb2HubStats = 8 + 2 * (64 + 1);        // index of the hub block inside the result header (behind recv_ptr / send_ptr of 64 ranks)
+// stats[0] hubs, [1] (out-hubs << 32) | their out-events, [2] tasks, [3] part columns, [4] lifted pairs through hubs,
+// [5..8] longest row: order-2 destination-major / source-major, first-order destination-major / source-major, [9] longest in-list, [10] out-list
+
+__global__ __launch_bounds__(kBlock) void k_db2_hub_classify(int64_t n, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ hp,
+                                                            uint8_t* __restrict__ flag, uint32_t* __restrict__ hoff, uint32_t* __restrict__ oslot,
+                                                            uint32_t* __restrict__ tbase, int64_t* __restrict__ pbase, uint32_t* __restrict__ task_node,
+                                                            uint32_t* __restrict__ hub_list, int64_t* __restrict__ stats) {
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (b >= n) return;
+    const int64_t no = (int64_t)tp[b + 1] - tp[b], ni = (int64_t)hp[b + 1] - hp[b];
+    const uint8_t f = (uint8_t)((no > kWave ? kHubOut : 0) | (ni > kWave ? kHubIn : 0));
+    flag[b] = f;
+    if (!f) return;
+    const int64_t ntask = ni > 0 ? ceil_div_dev(ni, kHubChunk) : 1;
+    const int64_t nrc = no > 0 ? ceil_div_dev(no < n ? no : n, kWave) : 1;          // rounds of 64 successor runs, upper bound (runs <= min(no, n))
+    hub_list[atomicAdd((unsigned long long*)&stats[0], 1ull)] = (uint32_t)b;
+    const uint32_t t0 = (uint32_t)atomicAdd((unsigned long long*)&stats[2], (unsigned long long)ntask);
+    tbase[b] = t0;
+    pbase[b] = (int64_t)atomicAdd((unsigned long long*)&stats[3], (unsigned long long)(ntask * nrc));
+    for (int64_t k = 0; k < ntask; ++k) task_node[t0 + k] = (uint32_t)b;
+    if (no > kWave) {           // ONE atomic for (index among the out-hubs, first event slot): both follow the same arrival order
+        const unsigned long long old = atomicAdd((unsigned long long*)&stats[1], (1ull << 32) | (unsigned long long)no);
+        oslot[b] = (uint32_t)(old >> 32);
+        hoff[b] = (uint32_t)old;
+    }
+    atomicMax((unsigned long long*)&stats[9], (unsigned long long)ni);
+    atomicMax((unsigned long long*)&stats[10], (unsigned long long)no);
+}
+
+// in-events of the hub nodes in (source, time) order: what k_db2_mid's count prologue gathers for the other nodes
+__global__ __launch_bounds__(kBlock) void k_db2_hub_gather_in(int64_t m, const uint32_t* __restrict__ hkeys_s, const uint8_t* __restrict__ flag,
+                                                             const uint32_t* __restrict__ hl, const Db2Src* __restrict__ src_t,
+                                                             const float* __restrict__ ow_t, uint64_t* __restrict__ is_t, uint32_t* __restrict__ is_a,
+                                                             uint32_t* __restrict__ is_u, float* __restrict__ is_w) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= m || !flag[hkeys_s[q]]) return;
+    const uint32_t p = hl[q];
+    const Db2Src r = src_t[p];
+    is_t[q] = r.t;
+    is_a[q] = r.a;
+    is_u[q] = r.u;
+    if (ow_t) is_w[q] = ow_t[p];
+}
+
+// out-hubs, step 1: (slice, successor) key + list position of every out-event, compacted into the node's slice
+__global__ __launch_bounds__(kBlock) void k_db2_hub_out_keys(int64_t m, const uint32_t* __restrict__ tkeys_s, const uint32_t* __restrict__ tp,
+                                                            const uint8_t* __restrict__ flag, const uint32_t* __restrict__ hoff,
+                                                            const uint32_t* __restrict__ oc_t, int key_bits, uint64_t* __restrict__ keys,
+                                                            uint32_t* __restrict__ pos) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m) return;
+    const uint32_t b = tkeys_s[p];
+    if (!(flag[b] & kHubOut)) return;
+    const uint32_t j = hoff[b] + ((uint32_t)p - tp[b]);
+    keys[j] = ((uint64_t)hoff[b] << key_bits) | (uint64_t)oc_t[p];
+    pos[j] = (uint32_t)p;
+}
+
+// step 2 (after the sort): run heads.  The slices are sorted by their first slot, so element j of the sorted sequence lies in the slice of the
+// node its event belongs to, at `j - hoff`
+__global__ __launch_bounds__(kBlock) void k_db2_hub_out_heads(int64_t h_out, const uint64_t* __restrict__ keys_s, const uint32_t* __restrict__ pos_s,
+                                                             const uint32_t* __restrict__ tkeys_s, const uint32_t* __restrict__ hoff,
+                                                             uint32_t* __restrict__ head) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= h_out) return;
+    const uint32_t b = tkeys_s[pos_s[j]];
+    head[j] = ((uint32_t)j == hoff[b] || keys_s[j] != keys_s[j - 1]) ? 1u : 0u;
+}
+
+// step 3 (after the scan of the heads): successor ranks, the (successor, time)-ordered out-list, run starts, block sizes
+template <bool kW>
+__global__ __launch_bounds__(kBlock) void k_db2_hub_out_write(int64_t h_out, const uint64_t* __restrict__ keys_s, const uint32_t* __restrict__ pos_s,
+                                                             const uint32_t* __restrict__ head, const uint32_t* __restrict__ head_scan,
+                                                             const uint32_t* __restrict__ tkeys_s, const uint32_t* __restrict__ tp,
+                                                             const uint32_t* __restrict__ hoff, const uint32_t* __restrict__ oslot, int key_bits,
+                                                             const uint64_t* __restrict__ ot_t, const float* __restrict__ ow_t,
+                                                             uint64_t* __restrict__ ot_s, uint32_t* __restrict__ oc_s, float* __restrict__ ow_s,
+                                                             uint32_t* __restrict__ rank_s, uint32_t* __restrict__ rank_t,
+                                                             uint32_t* __restrict__ run_start, int32_t* __restrict__ blk, int64_t* __restrict__ stats) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= h_out) return;
+    const uint32_t p = pos_s[j];
+    const uint32_t b = tkeys_s[p];
+    const uint32_t h0 = hoff[b], p0 = tp[b], no = tp[b + 1] - p0;
+    const uint32_t within = (uint32_t)j - h0;
+    const uint32_t r = head_scan[j] + head[j] - 1u - head_scan[h0];      // rank of this event's successor among the node's distinct successors
+    const uint32_t c = (uint32_t)(keys_s[j] & ((1ull << key_bits) - 1ull));
+    ot_s[p0 + within] = ot_t[p];
+    oc_s[p0 + within] = c;
+    ow_s[p0 + within] = kW ? ow_t[p] : 0.0f;                             // (weighted: the instance weight for now, k_db2_hub_out_runs sums the runs)
+    rank_s[j] = r;
+    rank_t[h0 + (p - p0)] = r;
+    uint32_t* rs = run_start + (h0 + oslot[b]);
+    if (head[j]) rs[r] = within;
+    if (within == no - 1u) {
+        rs[r + 1u] = no;
+        blk[b] = (int32_t)(r + 1u);
+        atomicMax((unsigned long long*)&stats[8], (unsigned long long)(r + 1u));
+    }
+}
+
+// step 4: merged first-order weight of every successor run at its head (0 elsewhere, as k_db2_out leaves them): run length, or the
+// left-to-right sum of the instance weights
+template <bool kW>
+__global__ __launch_bounds__(kBlock) void k_db2_hub_out_runs(int64_t h_out, const uint32_t* __restrict__ pos_s, const uint32_t* __restrict__ head,
+                                                            const uint32_t* __restrict__ rank_s, const uint32_t* __restrict__ tkeys_s,
+                                                            const uint32_t* __restrict__ tp, const uint32_t* __restrict__ hoff,
+                                                            const uint32_t* __restrict__ oslot, const uint32_t* __restrict__ run_start,
+                                                            float* __restrict__ ow_s) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= h_out) return;
+    const uint32_t b = tkeys_s[pos_s[j]];
+    const uint32_t h0 = hoff[b], p0 = tp[b];
+    const uint32_t within = (uint32_t)j - h0;
+    if (!head[j]) {
+        if (!kW) ow_s[p0 + within] = 0.0f;
+        return;
+    }
+    const uint32_t* rs = run_start + (h0 + oslot[b]);
+    const uint32_t end = rs[rank_s[j] + 1u];
+    if (!kW) { ow_s[p0 + within] = (float)(end - within); return; }
+    float acc = 0.0f;
+    for (uint32_t x = within; x < end; ++x) acc += ow_s[p0 + x];          // (the run's own entries: nobody else touches them)
+    ow_s[p0 + within] = acc;
+    for (uint32_t x = within + 1u; x < end; ++x) ow_s[p0 + x] = 0.0f;
+}
+
+template <typename TimeT, int kMode, bool kFill, bool kW>
+__global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t delta_i, double delta_f, Db2Mid a, Db2Hub h) {
+    using W = Window<TimeT, kMode>;
+    const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
+    if (task >= n_tasks) return;
+    const int l = lane_id();
+    const uint32_t b = h.task_node[task];
+    const int64_t k = task - (int64_t)h.tbase[b];
+    const uint32_t p0 = a.tp[b], q0 = a.hp[b];
+    const int64_t no = (int64_t)a.tp[b + 1] - p0, ni = (int64_t)a.hp[b + 1] - q0;
+    const int32_t row0 = a.row_ptr[b];
+    const int64_t R = (int64_t)a.row_ptr[b + 1] - row0;                                  // successor runs = order-2 rows (b, .)
+    const bool oh = no > kWave;
+    const int64_t rounds = R > 0 ? (R + kWave - 1) / kWave : 1;
+    const int64_t nrc = no > 0 ? ((no < h.num_nodes ? no : h.num_nodes) + kWave - 1) / kWave : 1;      // part columns per task (k_db2_hub_classify)
+    const int64_t part0 = h.pbase[b] + k * nrc;
+    const int64_t qend = (int64_t)q0 + ni;
+    int64_t qa = (int64_t)q0 + k * kHubChunk;
+    const int64_t qb = qa + kHubChunk < qend ? qa + kHubChunk : qend;
+    if (k > 0 && qa < qend) {                                     // the chunk starts inside a run of an earlier chunk: skip to the run's end
+        const uint32_t prev = a.is_a[qa - 1];
+        if (a.is_a[qa] == prev) qa = upper_bound_dev<uint32_t, int64_t>(a.is_a, qa, qend, prev);
+    }
+    // out-events in registers when they fit: lanes = out-events in (successor, time) order for the window ballot, lane r also = run r
+    bool lo_ = false;
+    uint64_t runmask = 0ull;
+    TimeT tj = TimeT(0);
+    if (!oh) {
+        lo_ = l < no;
+        tj = time_of<TimeT>(lo_ ? a.ot_s[p0 + l] : 0ull);
+        const int cr = lo_ ? (int)a.ocr_s[p0 + l] : 255;
+        const int prevcr = __shfl_up(cr, 1, kWave);
+        const uint64_t ohm = __ballot(lo_ && (l == 0 || cr != prevcr));
+        uint64_t from = ohm;
+        for (int i = 0; i < l && from; ++i) from &= from - 1;      // heads from the l-th on
+        if (from) {
+            const int rs = __ffsll((long long)from) - 1;
+            const uint64_t nxt = from & (from - 1);
+            const int re = nxt ? __ffsll((long long)nxt) - 1 : (int)no;
+            runmask = (re >= kWave ? ~0ull : lanes_below(re)) & ~lanes_below(rs);
+        }
+    }
+    const uint32_t* rsb = oh ? h.run_start + (h.hoff[b] + h.oslot[b]) : nullptr;
+    const float d1b = kFill ? inv_sqrt_deg(a.fo_deg[b]) : 0.0f;
+    const int32_t fp = kFill ? a.fo_fwd_ptr[b] + h.task_runbase[task] : 0;
+    if (kFill && k == 0 && l == 0 && a.self1) a.self1[b] = d1b * a.fo_lw[b] * d1b;
+    long long pairs = 0;
+    int runs = 0, longest_src = 0;
+    float deg1 = 0.0f, lw1 = -1.0f;
+    int od0 = 0, od1 = 0, od2 = 0, od3 = 0;                        // entries of the source-major row of in-run `ord` so far: lane ord % 64, register ord / 64
+    for (int64_t c = 0; c < rounds; ++c) {
+        const int64_t rr = c * kWave + l;
+        const bool valid = rr < R;
+        const uint32_t v = (uint32_t)(row0 + rr);
+        int64_t rs = 0, re = 0;
+        if (oh && valid) { rs = (int64_t)p0 + rsb[rr]; re = (int64_t)p0 + rsb[rr + 1]; }
+        int cnt = 0;
+        float deg = 0.0f, lw = -1.0f, dv = 0.0f;
+        int32_t ip = 0;
+        if (kFill && valid) {
+            dv = inv_sqrt_deg(a.ho_deg[v]);
+            ip = a.ho_fwd_ptr[v] + h.part_cnt[(part0 + c) * kWave + l];
+            if (k == 0) {
+                const float lwv = a.ho_lw[v];
+                a.self2[v] = dv * lwv * dv;
+                if (a.fo_bwd_val != nullptr) {
+                    const uint32_t cn = (uint32_t)h.succ[v];
+                    a.fo_bwd_val[v] = cn == b ? 0.0f : d1b * a.fo_w[v] * inv_sqrt_deg(a.fo_deg[cn]);
+                }
+            }
+        }
+        // ---- the in-runs that start in [qa, qb)
+        uint32_t cur_a = 0u, cur_u = 0xFFFFFFFFu;
+        int ord = -1, hits = 0;
+        float facc = 0.0f, w1run = 0.0f, du_r = 0.0f, da_r = 0.0f;
+        int32_t ob_r = 0;
+        bool open = false;
+        auto finish = [&]() {
+            const float wgt = kW ? facc : (float)hits;
+            const bool emit = valid && hits > 0;
+            const uint64_t em = __ballot(emit);
+            const int reached = (int)__popcll(em);
+            const int slot = ord >> 6, olane = ord & (kWave - 1);
+            const int odsel = slot == 0 ? od0 : (slot == 1 ? od1 : (slot == 2 ? od2 : od3));
+            const int before = rl_i(odsel, olane);                    // entries of this in-run's row from earlier rounds
+            if (l == olane) {
+                if (slot == 0) od0 += reached; else if (slot == 1) od1 += reached; else if (slot == 2) od2 += reached; else od3 += reached;
+            }
+            if (!kFill) {
+                if (emit) {
+                    ++cnt;
+                    if (cur_u == v) lw = wgt; else deg += wgt;
+                }
+                if (c == rounds - 1) {
+                    const int total = before + reached;
+                    if (l == 0 && total != 0 && cur_u < kDb2Foreign) a.outdeg2[cur_u] = total;
+                    longest_src = total > longest_src ? total : longest_src;
+                }
+                if (c == 0) {
+                    ++runs;
+                    if (cur_a == b) lw1 = w1run; else deg1 += w1run;
+                }
+            } else {
+                if (emit) {
+                    const float val = cur_u == v ? 0.0f : du_r * wgt * dv;
+                    a.in_idx2[ip + cnt] = (int32_t)cur_u;
+                    a.in_val2[ip + cnt] = val;
+                    if (a.in_w2) a.in_w2[ip + cnt] = wgt;
+                    const int rank = before + (int)__popcll(em & lanes_below(l));
+                    a.out_pack[ob_r + rank] = make_uint2(v, __float_as_uint(val));
+                    ++cnt;
+                }
+                if (c == 0 && l == 0) {
+                    a.fwd_idx1[fp + ord] = (int32_t)cur_a;
+                    a.fwd_val1[fp + ord] = cur_a == b ? 0.0f : da_r * w1run * d1b;
+                    if (a.dst_order) a.dst_order[fp + ord] = (int32_t)cur_u;
+                }
+            }
+        };
+        bool stop = false;
+        for (int64_t qq = qa; qq < qend && !stop; qq += kWave) {
+            const int64_t q = qq + l;
+            const bool li = q < qend;
+            const uint64_t sti = li ? a.is_t[q] : 0ull;
+            const uint32_t sa = li ? a.is_a[q] : 0xFFFFFFFFu, su = li ? a.is_u[q] : 0xFFFFFFFFu;
+            const float swi = (kW && li) ? a.is_w[q] : 1.0f;
+            float du_l = 0.0f, da_l = 0.0f;
+            int32_t ob_l = 0;
+            if (kFill) {                                             // d^-1/2 of the in-event's order-2 row and source node, start of its source-major row
+                const bool ok = li && su < kDb2Foreign;
+                const uint2 rp = ok ? a.row_pack[su] : make_uint2(0u, 0u);
+                du_l = __uint_as_float(rp.x);
+                ob_l = (int32_t)rp.y;
+                da_l = ok ? inv_sqrt_deg(a.fo_deg[sa]) : 0.0f;
+            }
+            const int nz = qend - qq < kWave ? (int)(qend - qq) : kWave;
+            for (int z = 0; z < nz; ++z) {
+                const uint32_t az = rl_u(sa, z);
+                if (!open || az != cur_a) {                          // position qq + z begins a run
+                    if (open) finish();
+                    open = false;
+                    if (qq + z >= qb) { stop = true; break; }         // it belongs to the next chunk's task
+                    open = true;
+                    cur_a = az;
+                    cur_u = rl_u(su, z);
+                    ++ord;
+                    hits = 0; facc = 0.0f; w1run = 0.0f;
+                    if (kFill) { du_r = rl_f(du_l, z); da_r = rl_f(da_l, z); ob_r = rl_i(ob_l, z); }
+                }
+                const TimeT ti = time_of<TimeT>(rl_u64(sti, z));
+                const typename W::Thr thr = W::threshold(ti, delta_i, delta_f);
+                int ci = 0;
+                if (!oh) {
+                    const uint64_t win = __ballot(lo_ && tj > ti && W::admits(tj, thr));
+                    ci = (int)__popcll(win & runmask);
+                    if (kW) {
+                        const float wz = rl_f(swi, z);
+                        for (int x = 0; x < ci; ++x) facc += wz;      // as k_db2_mid: instance pairs in lexicographic order carry the weight of their source event
+                        w1run += wz;
+                    }
+                } else {
+                    if (valid) {
+                        int64_t lo = rs, hi = re;
+                        while (lo < hi) {                             // first out-event of the run later than t_i
+                            const int64_t mid = lo + ((hi - lo) >> 1);
+                            if (time_of<TimeT>(a.ot_s[mid]) > ti) hi = mid; else lo = mid + 1;
+                        }
+                        int64_t lo2 = lo, hi2 = re;
+                        while (lo2 < hi2) {                           // first one beyond the window
+                            const int64_t mid = lo2 + ((hi2 - lo2) >> 1);
+                            if (!W::admits(time_of<TimeT>(a.ot_s[mid]), thr)) hi2 = mid; else lo2 = mid + 1;
+                        }
+                        ci = (int)(lo2 - lo);
+                    }
+                    if (kW) {
+                        const float wz = rl_f(swi, z);
+                        facc = __fadd_rn(facc, __fmul_rn(wz, (float)ci));
+                        w1run += wz;
+                    }
+                }
+                if (!kW) w1run += 1.0f;
+                hits += ci;
+                pairs += ci;
+            }
+        }
+        if (open) finish();
+        if (!kFill) {
+            const int64_t pi = (part0 + c) * kWave + l;
+            h.part_cnt[pi] = cnt;
+            h.part_deg[pi] = deg;
+            h.part_lw[pi] = lw;
+        }
+        // the next round walks the same runs again: `ord` restarts, the row prefixes od0..3 stay
+    }
+    if (!kFill) {
+        const long long total = wave_sum(pairs);
+        const int longest = wave_max(longest_src);
+        if (l == 0) {
+            h.task_runs[task] = runs;
+            h.task_deg1[task] = deg1;
+            h.task_lw1[task] = lw1;
+            if (total) atomicAdd((unsigned long long*)&h.stats[4], (unsigned long long)total);
+            atomicMax((unsigned long long*)&h.stats[6], (unsigned long long)longest);
+        }
+    }
+}
+
+// per hub node: the tasks' partial results in task order -> in-degrees, weighted degrees, self-loop weights of its order-2 rows and the
+// exclusive prefix of every task (where its entries start inside a destination-major row); first-order in-degree / degree of the node
+__global__ __launch_bounds__(kBlock) void k_db2_hub_combine(int64_t n_hubs, Db2Mid a, Db2Hub h) {
+    const int64_t slot = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
+    if (slot >= n_hubs) return;
+    const int l = lane_id();
+    const uint32_t b = h.hub_list[slot];
+    const int64_t no = (int64_t)a.tp[b + 1] - a.tp[b], ni = (int64_t)a.hp[b + 1] - a.hp[b];
+    const int32_t row0 = a.row_ptr[b];
+    const int64_t R = (int64_t)a.row_ptr[b + 1] - row0;
+    const int64_t rounds = R > 0 ? (R + kWave - 1) / kWave : 1;
+    const int64_t nrc = no > 0 ? ((no < h.num_nodes ? no : h.num_nodes) + kWave - 1) / kWave : 1;
+    const int64_t ntask = ni > 0 ? (ni + kHubChunk - 1) / kHubChunk : 1;
+    const int64_t t0 = h.tbase[b], pb = h.pbase[b];
+    int longest = 0;
+    constexpr int kBatch = 8;
+    for (int64_t c = 0; c < rounds; ++c) {
+        int running = 0;
+        float deg = 0.0f, lw = -1.0f;
+        for (int64_t k0 = 0; k0 < ntask; k0 += kBatch) {
+            int x[kBatch];
+            float d[kBatch], t[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const bool in = k0 + j < ntask;
+                const int64_t pi = (pb + (k0 + j) * nrc + c) * kWave + l;
+                x[j] = in ? h.part_cnt[pi] : 0;
+                d[j] = in ? h.part_deg[pi] : 0.0f;
+                t[j] = in ? h.part_lw[pi] : -1.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                if (k0 + j < ntask) {
+                    h.part_cnt[(pb + (k0 + j) * nrc + c) * kWave + l] = running;
+                    running += x[j];
+                    deg += d[j];
+                    if (t[j] >= 0.0f) lw = t[j];
+                }
+            }
+        }
+        const int64_t rr = c * kWave + l;
+        if (rr < R) {
+            const uint32_t v = (uint32_t)(row0 + rr);
+            const float l2 = lw < 0.0f ? 1.0f : lw;              // an existing self loop keeps its weight, every other node gets one of weight 1
+            a.indeg2[v] = running;
+            a.ho_deg[v] = deg + l2;
+            a.ho_lw[v] = l2;
+            longest = running > longest ? running : longest;
+        }
+    }
+    // the node itself: in-runs per task -> first-order in-degree + where every task's first-order entries start; weighted degree
+    int base = 0;
+    float deg1 = 0.0f, lw1 = -1.0f;
+    for (int64_t k0 = 0; k0 < ntask; k0 += kWave) {
+        const bool in = k0 + l < ntask;
+        const int r = in ? h.task_runs[t0 + k0 + l] : 0;
+        const int inc = wave_inclusive_sum(r);
+        if (in) h.task_runbase[t0 + k0 + l] = base + inc - r;
+        base += rl_i(inc, kWave - 1);
+        const float dl = in ? h.task_deg1[t0 + k0 + l] : 0.0f, tl_ = in ? h.task_lw1[t0 + k0 + l] : -1.0f;
+        for (int z = 0; z < kWave; ++z) {                          // task order (fixed)
+            deg1 += rl_f(dl, z);
+            const float tz = rl_f(tl_, z);
+            if (tz >= 0.0f) lw1 = tz;
+        }
+    }
+    longest = wave_max(longest);
+    if (l == 0) {
+        const float l1 = lw1 < 0.0f ? 1.0f : lw1;
+        a.nu[b] = base;
+        a.pc[b] = 0;                                               // (the hubs' lifted pairs are counted in stats[4])
+        a.fo_deg[b] = deg1 + l1;
+        a.fo_lw[b] = l1;
+        a.node_simple[b] = 0;
+        atomicMax((unsigned long long*)&h.stats[5], (unsigned long long)longest);
+        atomicMax((unsigned long long*)&h.stats[7], (unsigned long long)base);
+    }
+}
+
 // ------------------------------------------------------------------ partition shards: halo numbering and send lists
 // One rank owns the nodes [lo, lo + n_own) and holds the events that touch them.  Its order-2 rows are the nodes (b, .) of its b; the
 // sources (a, b) with a foreign a are HALO rows, numbered behind the owned rows in the order (owner of a, b, a): the owner q of a sends its
@@ -817,7 +1292,9 @@ __global__ __launch_bounds__(kBlock) void k_db2_apply_perm(int64_t m, const int6
 
 // ------------------------------------------------------------------ workspace
 constexpr int kDb2MaxWorld = 64;
-constexpr int kDb2Result = 8 + 2 * (kDb2MaxWorld + 1) + 6;
+constexpr int kDb2HubStatCount = 16;
+constexpr int kDb2Result = 8 + 2 * (kDb2MaxWorld + 1) + kDb2HubStatCount;
+static_assert(kDb2HubStats == 8 + 2 * (kDb2MaxWorld + 1), "hub block of the result header");
 
 struct Db2Ws {
     int64_t* result;         // [kDb2Result]: {U2, status, A2, E2, A1 (first-order in-edges), halo rows, rows sent, -, recv_ptr[world+1], send_ptr[world+1]}
@@ -842,9 +1319,17 @@ struct Db2Ws {
     int32_t *blk, *nu, *pc, *indeg2, *outdeg2;
     float *ho_lw, *fo_lw;
     int64_t* pc_scan;
+    // hub nodes: tables sized by (m, n); everything sized by the hubs themselves lives in the caller's hub workspace (Db2HubWs)
+    uint8_t* hub_flag;
+    uint32_t *hoff, *oslot, *tbase, *task_node, *hub_list;
+    int64_t* pbase;
+    int32_t *task_runs, *task_runbase;
+    float *task_deg1, *task_lw1;
     void* scratch;
     size_t scratch_bytes, total_bytes;
 };
+
+static inline int64_t db2_task_cap(int64_t m, int64_t n) { return m / kHubChunk + n + 1; }      // sum over hubs of max(1, ceil(in-events / chunk))
 
 static Db2Ws carve_db2(void* ws, int64_t m, int64_t n) {
     Arena a(ws, (size_t)-1);
@@ -893,11 +1378,84 @@ static Db2Ws carve_db2(void* ws, int64_t m, int64_t n) {
     w.ho_lw = a.take<float>(m);
     w.fo_lw = a.take<float>(n);
     w.pc_scan = a.take<int64_t>(n + 1);
+    w.hub_flag = a.take<uint8_t>(n + 16);
+    w.hoff = a.take<uint32_t>(n);
+    w.oslot = a.take<uint32_t>(n);
+    w.tbase = a.take<uint32_t>(n);
+    w.hub_list = a.take<uint32_t>(n);
+    w.pbase = a.take<int64_t>(n);
+    const int64_t tcap = db2_task_cap(m, n);
+    w.task_node = a.take<uint32_t>(tcap);
+    w.task_runs = a.take<int32_t>(tcap);
+    w.task_runbase = a.take<int32_t>(tcap);
+    w.task_deg1 = a.take<float>(tcap);
+    w.task_lw1 = a.take<float>(tcap);
     size_t sb = scan_ws_bytes(m > n ? m : n), s2 = sort_ws_bytes(m, 4);
     w.scratch_bytes = s2 > sb ? s2 : sb;
     w.scratch = a.take<char>((int64_t)w.scratch_bytes);
     w.total_bytes = a.used;
     return w;
+}
+
+struct Db2HubWs {
+    uint64_t *keys, *keys_s;         // [H]
+    uint32_t *pos, *pos_s, *head, *head_scan, *rank_s, *rank_t;      // [H] ([H + 1] for the scan)
+    uint32_t* run_start;             // [H + out-hubs + 1]
+    int32_t* part_cnt;               // [P * 64]
+    float *part_deg, *part_lw;
+    void* scratch;
+    size_t scratch_bytes, total_bytes;
+};
+
+static Db2HubWs carve_db2_hub(void* ws, int64_t h_out, int64_t out_hubs, int64_t parts) {
+    Arena a(ws, (size_t)-1);
+    Db2HubWs w;
+    w.keys = a.take<uint64_t>(h_out);
+    w.keys_s = a.take<uint64_t>(h_out);
+    w.pos = a.take<uint32_t>(h_out);
+    w.pos_s = a.take<uint32_t>(h_out);
+    w.head = a.take<uint32_t>(h_out);
+    w.head_scan = a.take<uint32_t>(h_out + 1);
+    w.rank_s = a.take<uint32_t>(h_out);
+    w.rank_t = a.take<uint32_t>(h_out);
+    w.run_start = a.take<uint32_t>(h_out + out_hubs + 1);
+    w.part_cnt = a.take<int32_t>(parts * kWave);
+    w.part_deg = a.take<float>(parts * kWave);
+    w.part_lw = a.take<float>(parts * kWave);
+    const size_t sb = scan_ws_bytes(h_out), s2 = sort_ws_bytes(h_out, 8);
+    w.scratch_bytes = s2 > sb ? s2 : sb;
+    w.scratch = a.take<char>((int64_t)w.scratch_bytes);
+    w.total_bytes = a.used;
+    return w;
+}
+
+struct Db2HubSizes {                 // what pp_debruijn2_lists reported (0 everywhere: no hub node)
+    int64_t hubs, out_hubs, out_events, tasks, parts;
+};
+
+static void hub_common(Db2Hub& h, const Db2Ws& w, const Db2HubWs& hw, int64_t n) {
+    h.flag = w.hub_flag; h.hoff = w.hoff; h.oslot = w.oslot; h.tbase = w.tbase; h.pbase = w.pbase; h.task_node = w.task_node; h.hub_list = w.hub_list;
+    h.run_start = hw.run_start; h.part_cnt = hw.part_cnt; h.part_deg = hw.part_deg; h.part_lw = hw.part_lw;
+    h.task_runs = w.task_runs; h.task_runbase = w.task_runbase; h.task_deg1 = w.task_deg1; h.task_lw1 = w.task_lw1;
+    h.stats = w.result + kDb2HubStats; h.num_nodes = n; h.succ = nullptr;
+}
+
+template <typename TimeT, int kMode, bool kFill>
+static void launch_hub(bool weighted, unsigned grid, hipStream_t st, int64_t tasks, int64_t di, double df, const Db2Mid& a, const Db2Hub& h) {
+    if (weighted) k_db2_hub<TimeT, kMode, kFill, true><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h);
+    else k_db2_hub<TimeT, kMode, kFill, false><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h);
+}
+
+template <bool kFill>
+static int launch_hub_any(int time_dtype, int delta_kind, bool weighted, hipStream_t st, int64_t tasks, int64_t di, double df, const Db2Mid& a,
+                          const Db2Hub& h) {
+    const unsigned grid = (unsigned)ceil_div(tasks, kWavesPerBlock);
+    if (time_dtype == PP_F64) launch_hub<double, 0, kFill>(weighted, grid, st, tasks, di, df, a, h);
+    else if (delta_kind == PP_DELTA_I64) launch_hub<int64_t, 0, kFill>(weighted, grid, st, tasks, di, df, a, h);
+    else if (delta_kind == PP_DELTA_F32) launch_hub<int64_t, 1, kFill>(weighted, grid, st, tasks, di, df, a, h);
+    else launch_hub<int64_t, 2, kFill>(weighted, grid, st, tasks, di, df, a, h);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
 }
 
 static void mid_common(Db2Mid& a, const Db2Ws& w, const int32_t* row_ptr, bool weighted) {
@@ -930,6 +1488,10 @@ extern "C" {
 
 size_t pp_debruijn2_ws_bytes(int64_t m, int64_t num_nodes) { return carve_db2(nullptr, m > 0 ? m : 0, num_nodes > 0 ? num_nodes : 0).total_bytes; }
 
+size_t pp_debruijn2_hub_ws_bytes(int64_t hub_out_events, int64_t out_hubs, int64_t hub_parts) {
+    return carve_db2_hub(nullptr, hub_out_events > 0 ? hub_out_events : 0, out_hubs > 0 ? out_hubs : 0, hub_parts > 0 ? hub_parts : 0).total_bytes;
+}
+
 }  // extern "C"
 
 namespace pp {
@@ -945,30 +1507,33 @@ struct Db2Part {                   // node range of a partition shard (one GPU: 
     float* bip_self;               // [world * cap_n]
 };
 
-static int db2_count(const char* who, const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t n, const Db2Part& pt, int delta_kind,
-                     int64_t delta_i, double delta_f, const float* weight, int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr,
-                     int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr, float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, hipStream_t st) {
+static thread_local hipEvent_t tls_stats_event = nullptr;      // recorded behind the copy of the hub statistics (pp_debruijn2_lists)
+
+// 1. event records; out-lists (stable sort by tail: time order inside a list), then the list SEQUENCE sorted by head: in-lists in (source, time)
+//    order; row pointers of both; one GPU: hub classification, its totals copied to `host_stats` (asynchronously), then the out-side kernel of
+//    the other nodes — the caller's wait for the totals runs under it
+static int db2_lists(const char* who, const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t n, const Db2Part& pt,
+                     const float* weight, void* ws, size_t ws_bytes, int64_t* host_stats, hipStream_t st) {
     const bool part = pt.world > 1;
     const int64_t n_own = pt.n_own;
     PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "%s: negative size", who);
     PP_REQUIRE(m < (int64_t)0x7ffffff0 && n < (int64_t)0x7ffffff0, PP_ERR_TOO_LARGE, "%s: m or num_nodes >= 2^31", who);
     PP_REQUIRE(time_dtype == PP_I64 || time_dtype == PP_F64, PP_ERR_ARG, "%s: time must be int64 or float64", who);
-    PP_REQUIRE(delta_kind >= PP_DELTA_I64 && delta_kind <= PP_DELTA_F64, PP_ERR_ARG, "%s: bad delta kind", who);
     PP_REQUIRE(pt.lo >= 0 && n_own >= 0 && pt.lo + n_own <= n && pt.world >= 1 && pt.world <= kDb2MaxWorld && pt.me >= 0 && pt.me < pt.world, PP_ERR_ARG,
                "%s: bad node range / world", who);
     Db2Ws w = carve_db2(ws, m, n);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "%s: workspace too small", who);
     PP_HIP(hipMemsetAsync(w.result, 0, kDb2Result * sizeof(int64_t), st));
     if (m == 0 || n == 0) {
-        PP_HIP(hipMemsetAsync(fo_bwd_ptr, 0, (size_t)(n_own + 1) * sizeof(int32_t), st));
-        PP_HIP(hipMemsetAsync(fo_fwd_ptr, 0, (size_t)(n_own + 1) * sizeof(int32_t), st));
-        PP_HIP(hipMemsetAsync(ho_fwd_ptr, 0, (size_t)(m + 1) * sizeof(int32_t), st));
-        PP_HIP(hipMemsetAsync(ho_bwd_ptr, 0, (size_t)(m + 1) * sizeof(int32_t), st));
+        if (host_stats) {
+            PP_HIP(hipMemcpyAsync(host_stats, w.result + kDb2HubStats, kDb2HubStatCount * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            if (!tls_stats_event) PP_HIP(hipEventCreateWithFlags(&tls_stats_event, hipEventDisableTiming));
+            PP_HIP(hipEventRecord(tls_stats_event, st));
+        }
         return PP_OK;
     }
-    const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n_own > 0 ? n_own : 1, kWavesPerBlock * kDb2Nodes);
+    const unsigned egrid = (unsigned)ceil_div(m, kBlock);
     const unsigned agrid = (unsigned)ceil_div(n, kWavesPerBlock * kDb2OutNodes);
-    // 1. event records; out-lists (stable sort by tail: time order inside a list), then the list SEQUENCE sorted by head: in-lists in (source, time) order
     if (time_dtype == PP_I64) k_db2_keys<int64_t><<<egrid, kBlock, 0, st>>>(edge_index, (const int64_t*)time, m, n, w.tkeys, w.rec, w.result + 1);
     else k_db2_keys<double><<<egrid, kBlock, 0, st>>>(edge_index, (const double*)time, m, n, w.tkeys, w.rec, w.result + 1);
     PP_LAUNCH_CHECK();
@@ -983,11 +1548,78 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
     PP_LAUNCH_CHECK();
     k_db2_rowptr<<<(unsigned)ceil_div(m + 1, kBlock), kBlock, 0, st>>>(w.hkeys_s, m, n, w.hp);
     PP_LAUNCH_CHECK();
-    // 2. successors of every owned node -> order-2 node ids
+    if (!part) {
+        k_db2_hub_classify<<<(unsigned)ceil_div(n, kBlock), kBlock, 0, st>>>(n, w.tp, w.hp, w.hub_flag, w.hoff, w.oslot, w.tbase, w.pbase, w.task_node,
+                                                                           w.hub_list, w.result + kDb2HubStats);
+        PP_LAUNCH_CHECK();
+        if (host_stats) {
+            PP_HIP(hipMemcpyAsync(host_stats, w.result + kDb2HubStats, kDb2HubStatCount * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            if (!tls_stats_event) PP_HIP(hipEventCreateWithFlags(&tls_stats_event, hipEventDisableTiming));
+            PP_HIP(hipEventRecord(tls_stats_event, st));
+        }
+    }
+    // 2. successors of every node with at most 64 out-events -> block sizes of the order-2 node ids
     int32_t* fblk = part ? w.fblk : nullptr;
-    if (weight) k_db2_out<true><<<agrid, kBlock, 0, st>>>(n, pt.lo, n_own, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, fblk, w.fskip, w.result + 1);
-    else k_db2_out<false><<<agrid, kBlock, 0, st>>>(n, pt.lo, n_own, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, fblk, w.fskip, w.result + 1);
+    const int hubs_handled = part ? 0 : 1;
+    if (weight) k_db2_out<true><<<agrid, kBlock, 0, st>>>(n, pt.lo, n_own, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, fblk, w.fskip, w.result + 1, hubs_handled);
+    else k_db2_out<false><<<agrid, kBlock, 0, st>>>(n, pt.lo, n_own, w.tp, w.oc_t, w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, w.ocr_s, w.ocr_t, w.blk, fblk, w.fskip, w.result + 1, hubs_handled);
     PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+static int db2_count(const char* who, int time_dtype, int64_t m, int64_t n, const Db2Part& pt, int delta_kind, int64_t delta_i, double delta_f,
+                     const float* weight, int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr,
+                     int32_t* ho_bwd_ptr, float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, const Db2HubSizes& hs, void* hub_ws,
+                     size_t hub_ws_bytes, hipStream_t st) {
+    const bool part = pt.world > 1;
+    const int64_t n_own = pt.n_own;
+    PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "%s: negative size", who);
+    PP_REQUIRE(delta_kind >= PP_DELTA_I64 && delta_kind <= PP_DELTA_F64, PP_ERR_ARG, "%s: bad delta kind", who);
+    Db2Ws w = carve_db2(ws, m, n);
+    PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "%s: workspace too small", who);
+    if (m == 0 || n == 0) {
+        PP_HIP(hipMemsetAsync(fo_bwd_ptr, 0, (size_t)(n_own + 1) * sizeof(int32_t), st));
+        PP_HIP(hipMemsetAsync(fo_fwd_ptr, 0, (size_t)(n_own + 1) * sizeof(int32_t), st));
+        PP_HIP(hipMemsetAsync(ho_fwd_ptr, 0, (size_t)(m + 1) * sizeof(int32_t), st));
+        PP_HIP(hipMemsetAsync(ho_bwd_ptr, 0, (size_t)(m + 1) * sizeof(int32_t), st));
+        return PP_OK;
+    }
+    PP_REQUIRE(hs.hubs >= 0 && hs.hubs <= n && hs.out_hubs >= 0 && hs.out_hubs <= hs.hubs && hs.out_events >= 0 && hs.out_events <= m && hs.tasks >= hs.hubs &&
+               hs.tasks <= db2_task_cap(m, n) && hs.parts >= hs.tasks && (hs.hubs == 0 || !part), PP_ERR_ARG, "%s: bad hub sizes", who);
+    Db2HubWs hw = carve_db2_hub(hs.hubs > 0 ? hub_ws : nullptr, hs.out_events, hs.out_hubs, hs.parts);
+    PP_REQUIRE(hs.hubs == 0 || (hub_ws != nullptr && hub_ws_bytes >= hw.total_bytes), PP_ERR_WORKSPACE, "%s: hub workspace too small", who);
+    const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n_own > 0 ? n_own : 1, kWavesPerBlock * kDb2Nodes);
+    const int key_bits = bits_for((uint64_t)(n > 0 ? n - 1 : 0));
+    int rc;
+    // 2'. out-hubs: their out-events in (successor, time) order by one sort over exactly those events
+    if (hs.out_events > 0) {
+        const unsigned hgrid = (unsigned)ceil_div(hs.out_events, kBlock);
+        k_db2_hub_out_keys<<<egrid, kBlock, 0, st>>>(m, w.tkeys_s, w.tp, w.hub_flag, w.hoff, w.oc_t, key_bits, hw.keys, hw.pos);
+        PP_LAUNCH_CHECK();
+        rc = sort_pairs<uint64_t>(hw.keys, hw.pos, hw.keys_s, hw.pos_s, hs.out_events, 0, key_bits + bits_for((uint64_t)hs.out_events), hw.scratch,
+                                  hw.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+        k_db2_hub_out_heads<<<hgrid, kBlock, 0, st>>>(hs.out_events, hw.keys_s, hw.pos_s, w.tkeys_s, w.hoff, hw.head);
+        PP_LAUNCH_CHECK();
+        rc = exclusive_scan<uint32_t, uint32_t>(hw.head, hs.out_events, hw.head_scan, true, nullptr, hw.scratch, hw.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+        if (weight) {
+            k_db2_hub_out_write<true><<<hgrid, kBlock, 0, st>>>(hs.out_events, hw.keys_s, hw.pos_s, hw.head, hw.head_scan, w.tkeys_s, w.tp, w.hoff, w.oslot, key_bits,
+                                                               w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, hw.rank_s, hw.rank_t, hw.run_start, w.blk,
+                                                               w.result + kDb2HubStats);
+            PP_LAUNCH_CHECK();
+            k_db2_hub_out_runs<true><<<hgrid, kBlock, 0, st>>>(hs.out_events, hw.pos_s, hw.head, hw.rank_s, w.tkeys_s, w.tp, w.hoff, w.oslot, hw.run_start, w.ow_s);
+        } else {
+            k_db2_hub_out_write<false><<<hgrid, kBlock, 0, st>>>(hs.out_events, hw.keys_s, hw.pos_s, hw.head, hw.head_scan, w.tkeys_s, w.tp, w.hoff, w.oslot, key_bits,
+                                                                w.ot_t, w.ow_t, w.ot_s, w.oc_s, w.ow_s, hw.rank_s, hw.rank_t, hw.run_start, w.blk,
+                                                                w.result + kDb2HubStats);
+            PP_LAUNCH_CHECK();
+            k_db2_hub_out_runs<false><<<hgrid, kBlock, 0, st>>>(hs.out_events, hw.pos_s, hw.head, hw.rank_s, w.tkeys_s, w.tp, w.hoff, w.oslot, hw.run_start, w.ow_s);
+        }
+        PP_LAUNCH_CHECK();
+    }
+    const uint32_t* hoff = hs.out_events > 0 ? w.hoff : nullptr;
+    const uint32_t *rank_s = hs.out_events > 0 ? hw.rank_s : nullptr, *rank_t = hs.out_events > 0 ? hw.rank_t : nullptr;
     if (part) {
         rc = exclusive_scan<int32_t, int32_t>(w.fblk, n, pt.fo2_bwd_ptr, true, nullptr, w.scratch, w.scratch_bytes, st);
         if (rc != PP_OK) return rc;
@@ -996,11 +1628,11 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
     if (rc != PP_OK) return rc;
     const int32_t* perm = nullptr;
     if (!part) {
-        k_db2_out_heads<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, fo_bwd_idx, fo_w);
+        k_db2_out_heads<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, fo_bwd_idx, fo_w, hoff, rank_s);
         PP_LAUNCH_CHECK();
     } else {
         // 2b. local row order = send order (who gathers from my rows), one node-id sort of the successors
-        k_db2_out_heads<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, w.succ_old, w.w_old);
+        k_db2_out_heads<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, w.succ_old, w.w_old, nullptr, nullptr);
         PP_LAUNCH_CHECK();
         k_db2_send_keys<<<egrid, kBlock, 0, st>>>(m, w.result, w.succ_old, pt.lo, n_own, n, w.xkeys);
         PP_LAUNCH_CHECK();
@@ -1023,7 +1655,7 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
         k_db2_bip_fill<<<(unsigned)ceil_div(total, kBlock), kBlock, 0, st>>>(total, w.result, w.xkeys_s, m, pt.lo, n, n_pad, (void*)pt.bip_self, pt.bip_fwd_idx);
         PP_LAUNCH_CHECK();
     }
-    k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, fo_bwd_ptr, perm, w.src_t);
+    k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, fo_bwd_ptr, perm, w.src_t, hoff, rank_t);
     PP_LAUNCH_CHECK();
     if (part) {          // (the halo numbering below reads the in-events; on one GPU the count pass gathers them itself)
         k_db2_gather_in<<<egrid, kBlock, 0, st>>>(m, w.hl, w.src_t, weight ? w.ow_t : nullptr, w.is_t, w.is_a, w.is_u, w.is_w);
@@ -1047,7 +1679,7 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
     PP_HIP(hipMemsetAsync(w.outdeg2, 0, (size_t)m * sizeof(int32_t), st));
     Db2Mid a{};
     mid_common(a, w, fo_bwd_ptr, weight != nullptr);
-    a.lo = pt.lo; a.n_own = n_own; a.part = part ? 1 : 0; a.perm = perm;
+    a.lo = pt.lo; a.n_own = n_own; a.part = part ? 1 : 0; a.perm = perm; a.hubs_handled = part ? 0 : 1;
     a.indeg2 = w.indeg2; a.outdeg2 = w.outdeg2; a.ho_deg = ho_deg; a.fo_deg = fo_deg;
     a.nu = w.nu; a.pc = w.pc; a.status = w.result + 1;
     if (!part) {
@@ -1056,6 +1688,18 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
     }
     rc = launch_mid_any<false>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n_own, delta_i, delta_f, a);
     if (rc != PP_OK) return rc;
+    if (hs.hubs > 0) {
+        // 3'. hub nodes: their in-events, one wave per chunk of them, the chunks' shares combined in task order
+        k_db2_hub_gather_in<<<egrid, kBlock, 0, st>>>(m, w.hkeys_s, w.hub_flag, w.hl, w.src_t, weight ? w.ow_t : nullptr, w.is_t, w.is_a, w.is_u, w.is_w);
+        PP_LAUNCH_CHECK();
+        Db2Hub h{};
+        hub_common(h, w, hw, n);
+        a.hl = nullptr;
+        rc = launch_hub_any<false>(time_dtype, delta_kind, weight != nullptr, st, hs.tasks, delta_i, delta_f, a, h);
+        if (rc != PP_OK) return rc;
+        k_db2_hub_combine<<<(unsigned)ceil_div(hs.hubs, kWavesPerBlock), kBlock, 0, st>>>(hs.hubs, a, h);
+        PP_LAUNCH_CHECK();
+    }
     rc = exclusive_scan<int32_t, int32_t>(w.nu, n_own, fo_fwd_ptr, true, w.result + 4, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
     rc = exclusive_scan<int32_t, int32_t>(w.indeg2, m, ho_fwd_ptr, true, w.result + 2, w.scratch, w.scratch_bytes, st);
@@ -1066,23 +1710,26 @@ static int db2_count(const char* who, const int64_t* edge_index, const void* tim
 }
 
 static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64_t lo, int64_t n_own, bool part, int delta_kind, int64_t delta_i,
-                    double delta_f, const float* weight, const int32_t* fo_bwd_ptr, const float* fo_w, const int32_t* fo_fwd_ptr,
+                    double delta_f, const float* weight, const int32_t* fo_bwd_ptr, const int32_t* fo_bwd_idx, const float* fo_w, const int32_t* fo_fwd_ptr,
                     const int32_t* ho_fwd_ptr, const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t num_ho_edges,
                     int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx,
                     float* fo_fwd_val, int32_t* fo_dst_order, const int32_t* fo2_bwd_ptr, int32_t* fo2_bwd_idx, float* fo_bwd_val, float* fo_self,
-                    float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, hipStream_t st) {
+                    float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, const Db2HubSizes& hs, void* hub_ws, size_t hub_ws_bytes,
+                    hipStream_t st) {
     PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "%s: negative size", who);
     Db2Ws w = carve_db2(ws, m, n);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "%s: workspace too small", who);
     if (n == 0 || n_own == 0) return PP_OK;
     PP_REQUIRE(m > 0, PP_ERR_ARG, "%s: an empty stream has no order-2 model to fill (use pp_gcn_plan on the empty graph)", who);
+    Db2HubWs hw = carve_db2_hub(hs.hubs > 0 ? hub_ws : nullptr, hs.out_events, hs.out_hubs, hs.parts);
+    PP_REQUIRE(hs.hubs == 0 || (!part && hub_ws != nullptr && hub_ws_bytes >= hw.total_bytes), PP_ERR_WORKSPACE, "%s: hub workspace too small", who);
     const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n_own, kWavesPerBlock * kDb2Nodes);
     PP_REQUIRE(num_ho_edges >= 0 && (num_ho_edges == 0 || pair_scratch != nullptr), PP_ERR_ARG, "%s: pair_scratch (8 bytes per order-2 edge) missing", who);
     k_db2_pack_rows<<<egrid, kBlock, 0, st>>>(m, ho_deg, ho_bwd_ptr, w.row_pack);
     PP_LAUNCH_CHECK();
     Db2Mid a{};
     mid_common(a, w, fo_bwd_ptr, weight != nullptr);
-    a.lo = lo; a.n_own = n_own; a.part = part ? 1 : 0; a.perm = part ? w.perm : nullptr;
+    a.lo = lo; a.n_own = n_own; a.part = part ? 1 : 0; a.perm = part ? w.perm : nullptr; a.hubs_handled = part ? 0 : 1;
     a.ho_deg = const_cast<float*>(ho_deg); a.fo_deg = const_cast<float*>(fo_deg);
     a.row_pack = w.row_pack;
     if (!part) { a.oc_s = w.oc_s; a.fo_w = fo_w; a.fo_bwd_val = fo_bwd_val; }
@@ -1091,6 +1738,13 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
     a.fwd_idx1 = fo_fwd_idx; a.fwd_val1 = fo_fwd_val; a.dst_order = fo_dst_order; a.self1 = fo_self;
     int rc = launch_mid_any<true>(time_dtype, delta_kind, weight != nullptr, ngrid, st, n_own, delta_i, delta_f, a);
     if (rc != PP_OK) return rc;
+    if (hs.hubs > 0) {
+        Db2Hub h{};
+        hub_common(h, w, hw, n);
+        h.succ = fo_bwd_idx;
+        rc = launch_hub_any<true>(time_dtype, delta_kind, weight != nullptr, st, hs.tasks, delta_i, delta_f, a, h);
+        if (rc != PP_OK) return rc;
+    }
     if (num_ho_edges > 0) {
         k_db2_unzip<<<(unsigned)ceil_div(num_ho_edges, kBlock), kBlock, 0, st>>>(num_ho_edges, (const uint2*)pair_scratch, ho_bwd_idx, ho_bwd_val);
         PP_LAUNCH_CHECK();
@@ -1104,22 +1758,39 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
 
 extern "C" {
 
-int pp_debruijn2_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i,
-                       double delta_f, const float* weight, int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr,
-                       int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr, float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, pp_stream_t stream) {
+int pp_debruijn2_lists(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, const float* weight, void* ws,
+                       size_t ws_bytes, int64_t* host_stats, pp_stream_t stream) {
     const Db2Part whole{0, num_nodes, nullptr, 1, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
-    return db2_count("pp_debruijn2_count", edge_index, time, time_dtype, m, num_nodes, whole, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_bwd_idx,
-                     fo_w, fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, (hipStream_t)stream);
+    return db2_lists("pp_debruijn2_lists", edge_index, time, time_dtype, m, num_nodes, whole, weight, ws, ws_bytes, host_stats, (hipStream_t)stream);
+}
+
+int pp_debruijn2_lists_wait(void) {
+    if (tls_stats_event) PP_HIP(hipEventSynchronize(tls_stats_event));
+    return PP_OK;
+}
+
+int pp_debruijn2_count(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
+                       int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
+                       float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, int64_t hub_nodes, int64_t out_hubs, int64_t hub_out_events,
+                       int64_t hub_tasks, int64_t hub_parts, void* hub_ws, size_t hub_ws_bytes, pp_stream_t stream) {
+    const Db2Part whole{0, num_nodes, nullptr, 1, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const Db2HubSizes hs{hub_nodes, out_hubs, hub_out_events, hub_tasks, hub_parts};
+    return db2_count("pp_debruijn2_count", time_dtype, m, num_nodes, whole, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_bwd_idx, fo_w, fo_fwd_ptr,
+                     ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, hs, hub_ws, hub_ws_bytes, (hipStream_t)stream);
 }
 
 int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
-                      const int32_t* fo_bwd_ptr, const float* fo_w, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr, const int32_t* ho_bwd_ptr,
-                      const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx,
-                      float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order, float* fo_bwd_val,
-                      float* fo_self, float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, pp_stream_t stream) {
-    return db2_fill("pp_debruijn2_fill", time_dtype, m, num_nodes, 0, num_nodes, false, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_w, fo_fwd_ptr,
-                    ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_fwd_idx, fo_fwd_val,
-                    fo_dst_order, nullptr, nullptr, fo_bwd_val, fo_self, ho_fwd_w, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
+                      const int32_t* fo_bwd_ptr, const int32_t* fo_bwd_idx, const float* fo_w, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr,
+                      const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val,
+                      int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order,
+                      float* fo_bwd_val, float* fo_self, float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, int64_t hub_nodes,
+                      int64_t out_hubs, int64_t hub_out_events, int64_t hub_tasks, int64_t hub_parts, void* hub_ws, size_t hub_ws_bytes,
+                      pp_stream_t stream) {
+    const Db2HubSizes hs{hub_nodes, out_hubs, hub_out_events, hub_tasks, hub_parts};
+    return db2_fill("pp_debruijn2_fill", time_dtype, m, num_nodes, 0, num_nodes, false, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_bwd_idx, fo_w,
+                    fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_fwd_idx,
+                    fo_fwd_val, fo_dst_order, nullptr, nullptr, fo_bwd_val, fo_self, ho_fwd_w, pair_scratch, ws, ws_bytes, hs, hub_ws, hub_ws_bytes,
+                    (hipStream_t)stream);
 }
 
 int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
@@ -1132,8 +1803,11 @@ int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int tim
                bip_fwd_idx != nullptr && bip_bwd_ptr != nullptr && bip_bwd_idx != nullptr && bip_self != nullptr, PP_ERR_ARG,
                "pp_debruijn2_part_count: world >= 2 with cuts and every output buffer");
     const Db2Part pt{node_lo, n_own, cuts, world, rank, send_slot, row_of, fo_shard_bwd_ptr, pad_rows, bip_fwd_ptr, bip_fwd_idx, bip_bwd_ptr, bip_bwd_idx, bip_self};
-    return db2_count("pp_debruijn2_part_count", edge_index, time, time_dtype, m, num_nodes, pt, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr,
-                     fo_bwd_idx, fo_w, fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, (hipStream_t)stream);
+    const int rc = db2_lists("pp_debruijn2_part_count", edge_index, time, time_dtype, m, num_nodes, pt, weight, ws, ws_bytes, nullptr, (hipStream_t)stream);
+    if (rc != PP_OK) return rc;
+    const Db2HubSizes none{0, 0, 0, 0, 0};
+    return db2_count("pp_debruijn2_part_count", time_dtype, m, num_nodes, pt, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_bwd_idx, fo_w,
+                     fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, none, nullptr, 0, (hipStream_t)stream);
 }
 
 int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own, int delta_kind, int64_t delta_i, double delta_f,
@@ -1142,9 +1816,11 @@ int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t
                            float* ho_fwd_val, int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val,
                            float* fo_self, const int32_t* fo_shard_bwd_ptr, int32_t* fo_shard_bwd_idx, float* fo_shard_bwd_val, void* pair_scratch,
                            void* ws, size_t ws_bytes, pp_stream_t stream) {
-    return db2_fill("pp_debruijn2_part_fill", time_dtype, m, num_nodes, node_lo, n_own, true, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, nullptr,
+    const Db2HubSizes none{0, 0, 0, 0, 0};
+    return db2_fill("pp_debruijn2_part_fill", time_dtype, m, num_nodes, node_lo, n_own, true, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, nullptr, nullptr,
                     fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_fwd_idx,
-                    fo_fwd_val, nullptr, fo_shard_bwd_ptr, fo_shard_bwd_idx, fo_shard_bwd_val, fo_self, nullptr, pair_scratch, ws, ws_bytes, (hipStream_t)stream);
+                    fo_fwd_val, nullptr, fo_shard_bwd_ptr, fo_shard_bwd_idx, fo_shard_bwd_val, fo_self, nullptr, pair_scratch, ws, ws_bytes, none, nullptr, 0,
+                    (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -3,7 +3,8 @@
 vectors in test_gpu_kernels.py / test_gpu_api.py): every array of both GCN plans and of the bipartite plan must be IDENTICAL, bit for bit
 (int32 indices, fp32 coefficients), and the layer sizes equal — on streams with timestamp ties, self loops, isolated nodes, float64
 timestamps, every delta promotion mode of lift_order_temporal (reference algorithms/temporal.py:30,43) and non-integer event weights.
-Also: against the oracle directly (edge lists + weights of both layers), the hub fallback, and the 2*10^6-event BASELINE configs[1] size."""
+Also: hub nodes (more than 64 in- / out-events: chunk-wise inside the same builder, round 5), the oracle directly (see also
+test_gpu_builder_oracle.py), and the 2*10^6-event BASELINE configs[1] size."""
 import numpy as np
 import pytest
 import torch
@@ -49,7 +50,14 @@ def _assert_same(a, b, what):
         raise AssertionError(f"{what}: {bad.numel()} of {a.numel()} entries differ, first at {i}: {a.reshape(-1)[i].item()!r} != {b.reshape(-1)[i].item()!r}")
 
 
-def _compare(fused, generic):
+def _assert_close(a, b, what, rtol):
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} != {tuple(b.shape)}"
+    torch.testing.assert_close(a, b, rtol=rtol, atol=0, msg=lambda m: f"{what}: {m}")
+
+
+def _compare(fused, generic, hubs=False, float_rtol=None):
+    """``float_rtol``: non-integer event weights on hub nodes — the hub tasks' partial sums are combined in task order, a different
+    association of the same fp32 terms than the generic path's left-to-right sums (integer arrays stay bit-identical)."""
     assert fused.sizes.get("builder") == "fused", "the fused builder did not run"
     assert generic.sizes.get("builder") is None
     for k in ("m", "N", "E2", "U2", "A1", "A2"):
@@ -58,8 +66,18 @@ def _compare(fused, generic):
         pf, pg = getattr(fused, name).plan, getattr(generic, name).plan
         assert (pf.n_dst, pf.n_src) == (pg.n_dst, pg.n_src)
         for fld in PLAN_FIELDS:
-            _assert_same(getattr(pf, fld), getattr(pg, fld), f"{name}.{fld}")
-        assert pf.fwd_heavy is None and pf.bwd_heavy is None
+            if float_rtol is not None and getattr(pf, fld).dtype == torch.float32:
+                _assert_close(getattr(pf, fld), getattr(pg, fld), f"{name}.{fld}", float_rtol)
+            else:
+                _assert_same(getattr(pf, fld), getattr(pg, fld), f"{name}.{fld}")
+        if hubs:            # rows beyond 512 entries: both paths must have found the same ones
+            for side in ("fwd_heavy", "bwd_heavy"):
+                hf, hg = getattr(pf, side), getattr(pg, side)
+                assert (hf is None) == (hg is None), f"{name}.{side}"
+                if hf is not None:
+                    _assert_same(hf.slot, hg.slot, f"{name}.{side}.slot")
+        else:
+            assert pf.fwd_heavy is None and pf.bwd_heavy is None
     _assert_same(fused.fo.plan.dst_order, generic.fo.plan.dst_order, "fo.dst_order")
     for fld in ("fwd_ptr", "fwd_idx", "bwd_ptr", "bwd_idx", "self_coef"):
         _assert_same(getattr(fused.bip, fld), getattr(generic.bip, fld), f"bip.{fld}")
@@ -132,25 +150,93 @@ def test_fused_builder_against_the_oracle():
     assert built.sizes["E2"] == e2
 
 
-def test_fused_builder_falls_back_on_hub_nodes():
-    """A node with more than 64 in- or out-events: the builder reports it (status bit 2), build_dbgnn_shard takes the generic kernels."""
+def _hub_stream(kind, seed=5):
+    """Streams with nodes of more than 64 in- / out-events (the builder's hub path, csrc/pp_debruijn.hip "hub nodes")."""
+    rng = np.random.default_rng(seed)
+    if kind == "in-hub":                 # one node with 100 in-events
+        m, n, span = 3000, 400, 5000
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        ei[1, :100] = 7
+    elif kind == "out-hub":              # one node with 100 out-events
+        m, n, span = 3000, 400, 5000
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        ei[0, 200:300] = 9
+    elif kind == "both":                 # a node that is both, several hubs, hub -> hub events, self loops on a hub
+        m, n, span = 6000, 300, 4000
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        ei[1, :400] = 3
+        ei[0, 300:900] = 3
+        ei[0, 1000:1200] = 11
+        ei[1, 1100:1400] = 12
+        ei[1, 2000:2100] = 11
+    elif kind == "dense":                # few nodes, many events: every node a hub on both sides, long (source, node) and (node, successor) runs
+        m, n, span = 8000, 12, 3000
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+    elif kind == "many-successors":      # a hub with more than 64 distinct successors AND sources: several rounds of 64 runs, chunks of 256 in-events
+        m, n, span = 9000, 700, 6000
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        ei[0, :1500] = 5
+        ei[1, 1500:3500] = 5
+    elif kind == "zipf":                 # scale-free destinations (BASELINE configs[2] generator): many in-hubs of every size
+        m, n, span = 40000, 3000, 30000
+        ranks = np.arange(1, n + 1, dtype=np.float64) ** -1.2
+        dst = rng.choice(n, size=m, p=ranks / ranks.sum())
+        ei = torch.from_numpy(np.stack((rng.integers(0, n, m), dst)))
+    elif kind == "long-run":             # one node pair carrying a sixth of the stream: an in-run far longer than a chunk
+        m, n, span = 6000, 50, 4000
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        ei[0, ::6] = 4
+        ei[1, ::6] = 8
+    else:
+        raise ValueError(kind)
+    t = torch.from_numpy(np.sort(rng.integers(0, span, ei.size(1))))
+    return ei, t, n
+
+
+HUB_KINDS = ["in-hub", "out-hub", "both", "dense", "many-successors", "zipf", "long-run"]
+
+
+@pytest.mark.parametrize("kind", HUB_KINDS)
+@pytest.mark.parametrize("delta", [60, 900], ids=["narrow", "wide"])
+def test_fused_builder_hub_nodes_equal_generic_path(kind, delta):
+    """Nodes with more than 64 in- or out-events stay inside the fused builder (no whole-stream fallback) and every plan array equals the
+    generic kernels' — reference algorithms/temporal.py:33-53 and lift_order.py:133-144 know no such limit."""
     from pathpyg_amd import _hip
-    rng = np.random.default_rng(5)
-    m, n = 3000, 400
-    ei = torch.from_numpy(rng.integers(0, n, (2, m)))
-    ei[1, :100] = 7                                           # 100 in-events of node 7
-    t = torch.from_numpy(np.sort(rng.integers(0, 5000, m)))
+    ei, t, n = _hub_stream(kind)
     dev = torch.device("cuda:0")
-    assert _hip.debruijn2(ei.to(dev), t.to(dev), n, 50, None) is None
-    ei2 = ei.clone()
-    ei2[1, :100] = torch.from_numpy(rng.integers(0, n, 100))
-    ei2[0, 200:300] = 9                                       # 100 out-events of node 9
-    assert _hip.debruijn2(ei2.to(dev), t.to(dev), n, 50, None) is None
-    shard = _build(ei, t, n, 50, None, True)
-    assert shard.sizes.get("builder") is None
-    generic = _build(ei, t, n, 50, None, False)
-    for fld in PLAN_FIELDS:
-        _assert_same(getattr(shard.ho.plan, fld), getattr(generic.ho.plan, fld), f"ho.{fld}")
+    built = _hip.debruijn2(ei.to(dev), t.to(dev), n, delta, None)
+    assert built is not None and built.sizes["hub_nodes"] > 0, "the stream has no hub node / the builder gave up"
+    _compare(_build(ei, t, n, delta, None, True), _build(ei, t, n, delta, None, False), hubs=True)
+
+
+@pytest.mark.parametrize("kind", ["both", "dense", "many-successors", "zipf"])
+@pytest.mark.parametrize("integer", [True, False], ids=["integer-weights", "fractional-weights"])
+def test_fused_builder_hub_nodes_weighted(kind, integer):
+    ei, t, n = _hub_stream(kind, seed=9)
+    rng = np.random.default_rng(19)
+    m = ei.size(1)
+    w = torch.from_numpy(rng.integers(1, 4, m).astype(np.float32) if integer else (rng.random(m).astype(np.float32) + 0.25))
+    _compare(_build(ei, t, n, 200, w, True), _build(ei, t, n, 200, w, False), hubs=True, float_rtol=None if integer else 1e-5)
+
+
+@pytest.mark.parametrize("delta", [7, 7.5, torch.tensor(7.5, dtype=torch.float64), torch.tensor(6, dtype=torch.int32), 0, 10 ** 9],
+                         ids=["int", "py-float=f32", "f64-tensor", "i32-tensor", "zero", "everything"])
+def test_fused_builder_hub_nodes_delta_promotion_modes(delta):
+    ei, t, n = _hub_stream("both")
+    t = torch.sort(t % 900).values
+    _compare(_build(ei, t, n, delta, None, True), _build(ei, t, n, delta, None, False), hubs=True)
+
+
+def test_fused_builder_hub_nodes_float64_time_and_rows_beyond_512():
+    """float64 timestamps through the bisection window test of the out-hubs; a delta that connects everything makes rows of several
+    thousand entries (the chunk tables of the DBGNN row kernels must appear on both paths)."""
+    ei, t, n = _hub_stream("dense")
+    tf = torch.sort(torch.from_numpy(np.random.default_rng(3).random(ei.size(1)) * 3000.0)).values
+    _compare(_build(ei, tf, n, 45.5, None, True), _build(ei, tf, n, 45.5, None, False), hubs=True)
+    ei2, t2, n2 = _hub_stream("many-successors")
+    fused = _build(ei2, t2, n2, 10 ** 9, None, True)
+    assert fused.ho.plan.fwd_heavy is not None or fused.ho.plan.bwd_heavy is not None
+    _compare(fused, _build(ei2, t2, n2, 10 ** 9, None, False), hubs=True)
 
 
 def test_fused_builder_rejects_bad_input():
