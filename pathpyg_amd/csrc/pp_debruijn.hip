@@ -960,56 +960,14 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
                 }
             }
         }
-        // ---- the in-runs that start in [qa, qb)
+        // ---- the in-runs that start in [qa, qb).  One virtual event behind the node's last in-event closes the last run: the run epilogue
+        // exists once, inside the loop (a lambda over the kernel's argument structs would force them into scratch memory)
         uint32_t cur_a = 0u, cur_u = 0xFFFFFFFFu;
         int ord = -1, hits = 0;
         float facc = 0.0f, w1run = 0.0f, du_r = 0.0f, da_r = 0.0f;
         int32_t ob_r = 0;
-        bool open = false;
-        auto finish = [&]() {
-            const float wgt = kW ? facc : (float)hits;
-            const bool emit = valid && hits > 0;
-            const uint64_t em = __ballot(emit);
-            const int reached = (int)__popcll(em);
-            const int slot = ord >> 6, olane = ord & (kWave - 1);
-            const int odsel = slot == 0 ? od0 : (slot == 1 ? od1 : (slot == 2 ? od2 : od3));
-            const int before = rl_i(odsel, olane);                    // entries of this in-run's row from earlier rounds
-            if (l == olane) {
-                if (slot == 0) od0 += reached; else if (slot == 1) od1 += reached; else if (slot == 2) od2 += reached; else od3 += reached;
-            }
-            if (!kFill) {
-                if (emit) {
-                    ++cnt;
-                    if (cur_u == v) lw = wgt; else deg += wgt;
-                }
-                if (c == rounds - 1) {
-                    const int total = before + reached;
-                    if (l == 0 && total != 0 && cur_u < kDb2Foreign) a.outdeg2[cur_u] = total;
-                    longest_src = total > longest_src ? total : longest_src;
-                }
-                if (c == 0) {
-                    ++runs;
-                    if (cur_a == b) lw1 = w1run; else deg1 += w1run;
-                }
-            } else {
-                if (emit) {
-                    const float val = cur_u == v ? 0.0f : du_r * wgt * dv;
-                    a.in_idx2[ip + cnt] = (int32_t)cur_u;
-                    a.in_val2[ip + cnt] = val;
-                    if (a.in_w2) a.in_w2[ip + cnt] = wgt;
-                    const int rank = before + (int)__popcll(em & lanes_below(l));
-                    a.out_pack[ob_r + rank] = make_uint2(v, __float_as_uint(val));
-                    ++cnt;
-                }
-                if (c == 0 && l == 0) {
-                    a.fwd_idx1[fp + ord] = (int32_t)cur_a;
-                    a.fwd_val1[fp + ord] = cur_a == b ? 0.0f : da_r * w1run * d1b;
-                    if (a.dst_order) a.dst_order[fp + ord] = (int32_t)cur_u;
-                }
-            }
-        };
-        bool stop = false;
-        for (int64_t qq = qa; qq < qend && !stop; qq += kWave) {
+        bool open = false, stop = qa >= qend;
+        for (int64_t qq = qa; !stop; qq += kWave) {
             const int64_t q = qq + l;
             const bool li = q < qend;
             const uint64_t sti = li ? a.is_t[q] : 0ull;
@@ -1025,12 +983,56 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
                 da_l = ok ? inv_sqrt_deg(a.fo_deg[sa]) : 0.0f;
             }
             const int nz = qend - qq < kWave ? (int)(qend - qq) : kWave;
-            for (int z = 0; z < nz; ++z) {
-                const uint32_t az = rl_u(sa, z);
-                if (!open || az != cur_a) {                          // position qq + z begins a run
-                    if (open) finish();
-                    open = false;
-                    if (qq + z >= qb) { stop = true; break; }         // it belongs to the next chunk's task
+            const int nsteps = qq + nz >= qend ? nz + 1 : nz;          // + the virtual event behind the last one
+            for (int z = 0; z < nsteps; ++z) {
+                const bool real = z < nz;
+                const uint32_t az = real ? rl_u(sa, z & (kWave - 1)) : 0xFFFFFFFEu;
+                if (!open || az != cur_a) {                          // position qq + z begins a run (or is the end)
+                    if (open) {
+                        // ---- epilogue of in-run (cur_a, b) = order-2 node cur_u
+                        const float wgt = kW ? facc : (float)hits;
+                        const bool emit = valid && hits > 0;
+                        const uint64_t em = __ballot(emit);
+                        const int reached = (int)__popcll(em);
+                        const int slot = ord >> 6, olane = ord & (kWave - 1);
+                        const int odsel = slot == 0 ? od0 : (slot == 1 ? od1 : (slot == 2 ? od2 : od3));
+                        const int before = rl_i(odsel, olane);        // entries of this in-run's row from earlier rounds
+                        if (l == olane) {
+                            if (slot == 0) od0 += reached; else if (slot == 1) od1 += reached; else if (slot == 2) od2 += reached; else od3 += reached;
+                        }
+                        if (!kFill) {
+                            if (emit) {
+                                ++cnt;
+                                if (cur_u == v) lw = wgt; else deg += wgt;
+                            }
+                            if (c == rounds - 1) {
+                                const int total = before + reached;
+                                if (l == 0 && total != 0 && cur_u < kDb2Foreign) a.outdeg2[cur_u] = total;
+                                longest_src = total > longest_src ? total : longest_src;
+                            }
+                            if (c == 0) {
+                                ++runs;
+                                if (cur_a == b) lw1 = w1run; else deg1 += w1run;
+                            }
+                        } else {
+                            if (emit) {
+                                const float val = cur_u == v ? 0.0f : du_r * wgt * dv;
+                                a.in_idx2[ip + cnt] = (int32_t)cur_u;
+                                a.in_val2[ip + cnt] = val;
+                                if (a.in_w2) a.in_w2[ip + cnt] = wgt;
+                                const int rank = before + (int)__popcll(em & lanes_below(l));
+                                a.out_pack[ob_r + rank] = make_uint2(v, __float_as_uint(val));
+                                ++cnt;
+                            }
+                            if (c == 0 && l == 0) {
+                                a.fwd_idx1[fp + ord] = (int32_t)cur_a;
+                                a.fwd_val1[fp + ord] = cur_a == b ? 0.0f : da_r * w1run * d1b;
+                                if (a.dst_order) a.dst_order[fp + ord] = (int32_t)cur_u;
+                            }
+                        }
+                        open = false;
+                    }
+                    if (!real || qq + z >= qb) { stop = true; break; }     // the end, or a run of the next chunk's task
                     open = true;
                     cur_a = az;
                     cur_u = rl_u(su, z);
@@ -1074,7 +1076,6 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
                 pairs += ci;
             }
         }
-        if (open) finish();
         if (!kFill) {
             const int64_t pi = (part0 + c) * kWave + l;
             h.part_cnt[pi] = cnt;
