@@ -966,7 +966,9 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
         int ord = -1, hits = 0;
         float facc = 0.0f, w1run = 0.0f, du_r = 0.0f, da_r = 0.0f;
         int32_t ob_r = 0;
-        bool open = false, stop = qa >= qend;
+        bool open = false, stop = qa >= qend, fresh = true;
+        int64_t wlo = 0, whi = 0;                                    // more than 64 out-events: this lane's window into its run, see below
+        uint64_t tlo = 0ull, thi = 0ull;
         for (int64_t qq = qa; !stop; qq += kWave) {
             const int64_t q = qq + l;
             const bool li = q < qend;
@@ -1038,6 +1040,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
                     cur_u = rl_u(su, z);
                     ++ord;
                     hits = 0; facc = 0.0f; w1run = 0.0f;
+                    fresh = true;
                     if (kFill) { du_r = rl_f(du_l, z); da_r = rl_f(da_l, z); ob_r = rl_i(ob_l, z); }
                 }
                 const TimeT ti = time_of<TimeT>(rl_u64(sti, z));
@@ -1053,18 +1056,58 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
                     }
                 } else {
                     if (valid) {
-                        int64_t lo = rs, hi = re;
-                        while (lo < hi) {                             // first out-event of the run later than t_i
-                            const int64_t mid = lo + ((hi - lo) >> 1);
-                            if (time_of<TimeT>(a.ot_s[mid]) > ti) hi = mid; else lo = mid + 1;
+                        // window [wlo, whi) of the run's out-events continuing in-event i.  Inside an in-run the timestamps ascend, so both ends
+                        // only move forward: a few single steps from where the previous instance left them (their timestamps sit in
+                        // registers: no load at all when nothing moves), a bisection over the rest when that is not enough or the in-run
+                        // has just begun
+                        if (fresh) {
+                            int64_t lo = rs, hi = re;
+                            while (lo < hi) {                         // first out-event of the run later than t_i
+                                const int64_t mid = lo + ((hi - lo) >> 1);
+                                if (time_of<TimeT>(a.ot_s[mid]) > ti) hi = mid; else lo = mid + 1;
+                            }
+                            wlo = lo;
+                            hi = re;
+                            while (lo < hi) {                         // first one beyond the window
+                                const int64_t mid = lo + ((hi - lo) >> 1);
+                                if (!W::admits(time_of<TimeT>(a.ot_s[mid]), thr)) hi = mid; else lo = mid + 1;
+                            }
+                            whi = lo;
+                            tlo = wlo < re ? a.ot_s[wlo] : 0ull;
+                            thi = whi < re ? a.ot_s[whi] : 0ull;
+                        } else {
+                            for (int step = 0; wlo < re && !(time_of<TimeT>(tlo) > ti); ++step) {
+                                if (step == 4) {
+                                    int64_t lo = wlo, hi = re;
+                                    while (lo < hi) {
+                                        const int64_t mid = lo + ((hi - lo) >> 1);
+                                        if (time_of<TimeT>(a.ot_s[mid]) > ti) hi = mid; else lo = mid + 1;
+                                    }
+                                    wlo = lo;
+                                    tlo = wlo < re ? a.ot_s[wlo] : 0ull;
+                                    break;
+                                }
+                                ++wlo;
+                                tlo = wlo < re ? a.ot_s[wlo] : 0ull;
+                            }
+                            for (int step = 0; whi < re && W::admits(time_of<TimeT>(thi), thr); ++step) {
+                                if (step == 4) {
+                                    int64_t lo = whi, hi = re;
+                                    while (lo < hi) {
+                                        const int64_t mid = lo + ((hi - lo) >> 1);
+                                        if (!W::admits(time_of<TimeT>(a.ot_s[mid]), thr)) hi = mid; else lo = mid + 1;
+                                    }
+                                    whi = lo;
+                                    thi = whi < re ? a.ot_s[whi] : 0ull;
+                                    break;
+                                }
+                                ++whi;
+                                thi = whi < re ? a.ot_s[whi] : 0ull;
+                            }
                         }
-                        int64_t lo2 = lo, hi2 = re;
-                        while (lo2 < hi2) {                           // first one beyond the window
-                            const int64_t mid = lo2 + ((hi2 - lo2) >> 1);
-                            if (!W::admits(time_of<TimeT>(a.ot_s[mid]), thr)) hi2 = mid; else lo2 = mid + 1;
-                        }
-                        ci = (int)(lo2 - lo);
+                        ci = whi > wlo ? (int)(whi - wlo) : 0;
                     }
+                    fresh = false;
                     if (kW) {
                         const float wz = rl_f(swi, z);
                         facc = __fadd_rn(facc, __fmul_rn(wz, (float)ci));
@@ -1112,7 +1155,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub_combine(int64_t n_hubs, Db2M
     const int64_t ntask = ni > 0 ? (ni + kHubChunk - 1) / kHubChunk : 1;
     const int64_t t0 = h.tbase[b], pb = h.pbase[b];
     int longest = 0;
-    constexpr int kBatch = 8;
+    constexpr int kBatch = 16;
     for (int64_t c = 0; c < rounds; ++c) {
         int running = 0;
         float deg = 0.0f, lw = -1.0f;

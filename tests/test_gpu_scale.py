@@ -507,6 +507,7 @@ def _partition_step_vs_single_gpu(pp, m, n, span, delta, f, world=8):
                 "sizes": {k: sizes[k] for k in ("E2", "U2", "A2")}, "builder": shard.sizes.get("builder")}
 
     one = step(pd.Comm())
+    torch.cuda.empty_cache()                  # (the emulated ranks hold their shards all at once: ~1.9x the single-GPU footprint)
     parts = pd.run_thread_world(world, step, DEV)
     assert one["builder"] == "fused" and all(p_["builder"] == "fused" for p_ in parts)          # (ER stream: the node-by-node builder on both sides)
     assert all(p_["sizes"] == one["sizes"] for p_ in parts), (one["sizes"], parts[0]["sizes"])
@@ -535,3 +536,85 @@ def test_headline_10m_events_fused_builder_equals_generic_kernels(pp):
     fused = _build(ei, t, 500_000, 1_000_000, None, True)
     generic = _build(ei, t, 500_000, 1_000_000, None, False)
     _compare(fused, generic)
+
+
+def _layers_of(built, n):
+    """(edge_index, merged weights) of both layers from a DeBruijn2's plans, on the host: layer 1 source-major, layer 2 source-major with the
+    weights permuted from the builder's destination-major order."""
+    out = {}
+    fo, ho = built.fo, built.ho
+    u2, a2 = built.sizes["U2"], built.sizes["A2"]
+    ptr = fo.bwd_ptr.long()
+    out[1] = (torch.stack((torch.repeat_interleave(torch.arange(n, device=DEV), ptr[1:] - ptr[:-1]), fo.bwd_idx.long())).cpu(), built.fo_weight.cpu())
+    ptr = ho.bwd_ptr.long()
+    src = torch.repeat_interleave(torch.arange(u2, device=DEV), ptr[1:] - ptr[:-1])
+    dst = ho.bwd_idx.long()
+    fptr = ho.fwd_ptr.long()
+    fdst = torch.repeat_interleave(torch.arange(u2, device=DEV), fptr[1:] - fptr[:-1])
+    pos = torch.searchsorted(fdst * u2 + ho.fwd_idx.long(), dst * u2 + src)
+    out[2] = (torch.stack((src, dst)).cpu(), built.ho_fwd_weight[pos].cpu())
+    assert a2 == dst.numel()
+    return out
+
+
+def test_config2_20m_scale_free_stream_stays_on_the_fused_builder(pp):
+    """BASELINE configs[2]'s generator (10^6 nodes / 2*10^7 events, scale-free destinations: one node with ~2*10^6 in-events, ~3*10^4 nodes
+    beyond 64) through the fused order-2 builder — no fallback: edge lists and merged weights of both layers equal the
+    ORACLE's at delta = 1.5*10^5, every plan array equals the generic kernels' at delta = 1.5*10^6 (E2 = 5.5*10^7)."""
+    from oracle import model as om
+    from pathpyg_amd import _hip
+    from tests.test_gpu_builder import _build, _compare
+    n, m = 1_000_000, 20_000_000
+    ei, t = _stream(3, m, n, 10_000_000, zipf=True)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=n))
+    sei, st = g.data.edge_index, g.data.time
+    built = _hip.debruijn2(sei, st, n, 150_000, None, want_weights=True)
+    assert built is not None and built.sizes["hub_nodes"] > 10_000
+    got = _layers_of(built, n)
+    want = om.layers_from_temporal(sei.cpu(), st.cpu(), n, delta=150_000, max_order=2)
+    for k in (1, 2):
+        assert torch.equal(got[k][0], want[k]["edge_index"]), f"layer {k} edge_index"
+        assert torch.equal(got[k][1], want[k]["edge_weight"].float()), f"layer {k} merged weights"
+    assert built.sizes["E2"] == int(want[2]["edge_weight"].double().sum())          # unit weights: the merged weights count the lifted pairs
+    del built, got, want
+    fused = _build(sei.cpu(), st.cpu(), n, 1_500_000, None, True)
+    generic = _build(sei.cpu(), st.cpu(), n, 1_500_000, None, False)
+    assert fused.sizes["E2"] > 50_000_000
+    _compare(fused, generic, hubs=True)
+
+
+def test_contact_network_96_nodes_2m_events_stays_on_the_fused_builder(pp):
+    """The shape of the reference's documented datasets (96 nodes / 2.17*10^6 events): every node has ~2*10^4 in- and
+    out-events.  Fused builder against the oracle (delta = 30) and against the generic kernels (delta = 300, E2 = 6*10^6)."""
+    from oracle import model as om
+    from pathpyg_amd import _hip
+    from tests.test_gpu_builder import _build, _compare
+    n, m = 96, 2_000_000
+    ei, t = _stream(5, m, n, 2_000_000)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=n))
+    sei, st = g.data.edge_index, g.data.time
+    built = _hip.debruijn2(sei, st, n, 30, None, want_weights=True)
+    assert built is not None and built.sizes["hub_nodes"] == n
+    got = _layers_of(built, n)
+    want = om.layers_from_temporal(sei.cpu(), st.cpu(), n, delta=30, max_order=2)
+    for k in (1, 2):
+        assert torch.equal(got[k][0], want[k]["edge_index"]), f"layer {k} edge_index"
+        assert torch.equal(got[k][1], want[k]["edge_weight"].float()), f"layer {k} merged weights"
+    del built, got, want
+    _compare(_build(sei.cpu(), st.cpu(), n, 300, None, True), _build(sei.cpu(), st.cpu(), n, 300, None, False), hubs=True)
+    # through the reference API: layers, bundle, one DBGNN step
+    mom = pp.MultiOrderModel.from_temporal_graph(g, delta=300, max_order=2)
+    assert getattr(mom, "_pp_fused", None) is not None
+    data = mom.to_dbgnn_data(max_order=2, x=torch.randn(n, 16, device=DEV), x_h=torch.randn(mom.layers[2].n, 16, device=DEV))
+    net = pp.nn.DBGNN(num_classes=3, num_features=(16, 16), hidden_dims=[16, 16, 16]).to(DEV)
+    out = net(data)
+    out.sum().backward()
+    assert bool(torch.isfinite(out).all())
+
+
+def test_config4_f256_8_rank_partition_equals_single_gpu_step(pp):
+    """BASELINE configs[4]'s width through the split: F = 256, 8 ranks against the single-GPU step at 1.6*10^7 events /
+    8*10^5 nodes — the 8 emulated ranks live on ONE GPU and hold their shards (with halos: ~1.9x the single-GPU footprint) all at once;
+    at 2*10^7 events that is 285 of the 288 GB (measured: out of memory), the single-GPU twin at 2*10^7 is
+    test_config4_f256_property_run_above_10m_events."""
+    _partition_step_vs_single_gpu(pp, 16_000_000, 800_000, 8_000_000, 800_000, 256)
