@@ -961,13 +961,27 @@ def main() -> int:
             line["api_path"] = api_path
         if fused_ran:
             (fkey, (n_f, f_ms, _)), = fused_clock.groups().items()
-            build_bytes = lift_bytes + agg_bytes                       # what the generic lift + both aggregations move algorithmically
             f_avg = f_ms / max(n_f, 1)
-            line["graph_build_roofline"] = {"what": "fused order-2 De Bruijn builder (event records, 2 radix sorts of the events, per-node passes, CSR of both "
-                                                    "layers incl. gcn_norm): SURVEY §8d bytes of lift (24 m + 16 E2) + both aggregations over its kernels' time",
-                                            "kernel": fkey, "avg_ms": f_avg, "algorithmic_bytes": build_bytes,
-                                            "achieved": build_bytes / (f_avg * 1e-3) / 1e9 if f_avg > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                            "frac": (build_bytes / (f_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if f_avg > 0 else 0.0}
+            # what the fused builder really moves per call (ADVICE r4 / VERDICT r4 #5): the events in (src, dst, t = 24 B each) and both
+            # CSR plans out — first-order: 2 row-pointer arrays, (index, coefficient) both ways, self coefficients, the bipartite grouping;
+            # order-2: the same over U2 rows / A2 edges (+ the merged weights when the API path keeps them).  The event graph [2, E2] is
+            # never written, so the SURVEY §8d bytes of the generic pipeline are NOT bytes this builder moves: they are kept beside,
+            # labelled, as an equivalent-work speed, and no fraction-of-peak claim rests on them.
+            n_nodes = float(args.nodes)
+            moved = (24.0 * m_rank + (8.0 * (n_nodes + 1) + 16.0 * a1 + 4.0 * n_nodes + 4.0 * a1)
+                     + (8.0 * (u2 + 1) + 16.0 * a2 + 4.0 * u2))
+            generic_bytes = lift_bytes + agg_bytes
+            line["graph_build_roofline"] = {
+                "what": "fused order-2 De Bruijn builder (event records, 2 radix sorts of the events, per-node passes, CSR of both layers incl. gcn_norm "
+                        "and the bipartite grouping): bytes it really moves = events in + plans out, over its kernels' time (pp_debruijn2_lists .. _fill)",
+                "kernel": fkey, "avg_ms": f_avg, "bytes_moved": moved,
+                "achieved": moved / (f_avg * 1e-3) / 1e9 if f_avg > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (moved / (f_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if f_avg > 0 else 0.0,
+                "bound": "latency / instruction issue of the per-node waves and ~1.2e8 random accesses, not bytes (DESIGN §5)",
+                "generic_pipeline_equivalent": {
+                    "what": "SURVEY §8d bytes of what the builder REPLACES (lift 24 m + 16 E2, both aggregations) over the builder's time: an "
+                            "equivalent-work speed for comparison with lift_roofline / aggregation_roofline, not bandwidth the builder reaches",
+                    "algorithmic_bytes": generic_bytes, "GB_per_s": generic_bytes / (f_avg * 1e-3) / 1e9 if f_avg > 0 else 0.0}}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline_isolated(args)
         print(json.dumps(line), flush=True)

@@ -613,8 +613,8 @@ def test_contact_network_96_nodes_2m_events_stays_on_the_fused_builder(pp):
 
 
 def test_config4_f256_8_rank_partition_equals_single_gpu_step(pp):
-    """BASELINE configs[4]'s width through the split: F = 256, 8 ranks against the single-GPU step at 1.6*10^7 events /
-    8*10^5 nodes — the 8 emulated ranks live on ONE GPU and hold their shards (with halos: ~1.9x the single-GPU footprint) all at once;
-    at 2*10^7 events that is 285 of the 288 GB (measured: out of memory), the single-GPU twin at 2*10^7 is
-    test_config4_f256_property_run_above_10m_events."""
-    _partition_step_vs_single_gpu(pp, 16_000_000, 800_000, 8_000_000, 800_000, 256)
+    """BASELINE configs[4]'s width through the split: F = 256, 8 ranks against the single-GPU step on the headline stream
+    (10^7 events, 5*10^5 nodes — the F = 256 projection's workload).  The 8 emulated ranks live on ONE GPU and hold their shards, halos,
+    saved activations and exchange buffers all at once: at 1.6*10^7 and 2*10^7 events that exceeds the 288 GB (measured: 285 GB allocated,
+    out of memory); the single-GPU twin at 2*10^7 events is test_config4_f256_property_run_above_10m_events."""
+    _partition_step_vs_single_gpu(pp, 10_000_000, 500_000, 10_000_000, 1_000_000, 256)
