@@ -896,6 +896,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
     if (task >= n_tasks) return;
     const int l = lane_id();
     const uint32_t b = h.task_node[task];
+    if (!kW && (h.flag[b] & kHubOut)) return;                      // (unit weights: k_db2_hubx takes the out-hubs run by run)
     const int64_t k = task - (int64_t)h.tbase[b];
     const uint32_t p0 = a.tp[b], q0 = a.hp[b];
     const int64_t no = (int64_t)a.tp[b + 1] - p0, ni = (int64_t)a.hp[b + 1] - q0;
@@ -1128,6 +1129,268 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
         // the next round walks the same runs again: `ord` restarts, the row prefixes od0..3 stay
     }
     if (!kFill) {
+        const long long total = wave_sum(pairs);
+        const int longest = wave_max(longest_src);
+        if (l == 0) {
+            h.task_runs[task] = runs;
+            h.task_deg1[task] = deg1;
+            h.task_lw1[task] = lw1;
+            if (total) atomicAdd((unsigned long long*)&h.stats[4], (unsigned long long)total);
+            atomicMax((unsigned long long*)&h.stats[6], (unsigned long long)longest);
+        }
+    }
+}
+
+// OUT-HUBS WITH UNIT WEIGHTS, run at a time (round 5): the middle-node pass of k_db2_hub for nodes with more than 64 out-events when every
+// event weighs 1 — the shape of the reference's documented contact streams (tens of nodes, 10^4 events per node and side).  k_db2_hub walks
+// the in-events one by one and each lane chases its own run of out-events through memory: one dependent load per step.  Here an in-run
+// (a, b) is taken as a whole: its instance times go to LDS (pieces of 512), the out-events of b between the first instance's window start and
+// the last instance's window end are streamed ONCE in time order (coalesced: timestamp + 32-bit successor rank), and every out-event counts
+// the instances it continues by two bisections over the LDS times (t_i < t_j and t_j <= t_i + delta are monotone in t_i) and adds that count
+// to its successor's slot of an LDS histogram (integer atomics: exact, order-free).  The histogram of 512 runs is the `hits` vector of eight
+// 64-lane columns at once; nodes with more runs take several rounds.  Same tasks, same part columns, same epilogue as k_db2_hub.
+constexpr int kHubxRuns = 512, kHubxInst = 512, kHubxCols = kHubxRuns / kWave;
+
+template <typename TimeT, int kMode, bool kFill>
+__global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t delta_i, double delta_f, Db2Mid a, Db2Hub h, const uint64_t* __restrict__ ot_t,
+                                                    const uint32_t* __restrict__ rank_t) {
+    using W = Window<TimeT, kMode>;
+    __shared__ uint32_t s_hist[kWavesPerBlock][kHubxRuns];
+    __shared__ uint64_t s_time[kWavesPerBlock][kHubxInst];
+    const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
+    if (task >= n_tasks) return;
+    const uint32_t b = h.task_node[task];
+    if (!(h.flag[b] & kHubOut)) return;                          // (k_db2_hub's node)
+    const int l = lane_id();
+    uint32_t* hist = s_hist[wave_id()];
+    uint64_t* tms = s_time[wave_id()];
+    const int64_t k = task - (int64_t)h.tbase[b];
+    const uint32_t p0 = a.tp[b], q0 = a.hp[b];
+    const int64_t no = (int64_t)a.tp[b + 1] - p0, ni = (int64_t)a.hp[b + 1] - q0;
+    const int32_t row0 = a.row_ptr[b];
+    const int64_t R = (int64_t)a.row_ptr[b + 1] - row0;
+    const int64_t nrc = no > 0 ? ((no < h.num_nodes ? no : h.num_nodes) + kWave - 1) / kWave : 1;
+    const int64_t part0 = h.pbase[b] + k * nrc;
+    const int64_t qend = (int64_t)q0 + ni;
+    int64_t qa = (int64_t)q0 + k * kHubChunk;
+    const int64_t qb = qa + kHubChunk < qend ? qa + kHubChunk : qend;
+    if (k > 0 && qa < qend) {
+        const uint32_t prev = a.is_a[qa - 1];
+        if (a.is_a[qa] == prev) qa = upper_bound_dev<uint32_t, int64_t>(a.is_a, qa, qend, prev);
+    }
+    const uint64_t* otb = ot_t + p0;                              // out-events of b in time order
+    const uint32_t* rkb = rank_t + h.hoff[b];                     // their successor ranks
+    for (int i = l; i < kHubxRuns; i += kWave) hist[i] = 0u;
+    const float d1b = kFill ? inv_sqrt_deg(a.fo_deg[b]) : 0.0f;
+    const int32_t fp = kFill ? a.fo_fwd_ptr[b] + h.task_runbase[task] : 0;
+    if (kFill && k == 0 && l == 0 && a.self1) a.self1[b] = d1b * a.fo_lw[b] * d1b;
+    long long pairs = 0;
+    int runs = 0, longest_src = 0;
+    float deg1 = 0.0f, lw1 = -1.0f;
+    int od0 = 0, od1 = 0, od2 = 0, od3 = 0;
+    const int64_t rounds = R > 0 ? (R + kHubxRuns - 1) / kHubxRuns : 1;
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t rbase = rd * kHubxRuns;
+        const int ncol = (int)((R - rbase + kWave - 1) / kWave < kHubxCols ? (R - rbase + kWave - 1) / kWave : kHubxCols);       // (0 when the node has no successor)
+        int cnt[kHubxCols];
+        float deg[kHubxCols], lw[kHubxCols], dv[kHubxCols];
+        int32_t ip[kHubxCols];
+#pragma unroll
+        for (int cc = 0; cc < kHubxCols; ++cc) {
+            cnt[cc] = 0; deg[cc] = 0.0f; lw[cc] = -1.0f; dv[cc] = 0.0f; ip[cc] = 0;
+            const int64_t rr = rbase + cc * kWave + l;
+            if (kFill && cc < ncol && rr < R) {
+                const uint32_t v = (uint32_t)(row0 + rr);
+                dv[cc] = inv_sqrt_deg(a.ho_deg[v]);
+                ip[cc] = a.ho_fwd_ptr[v] + h.part_cnt[(part0 + rbase / kWave + cc) * kWave + l];
+                if (k == 0) {
+                    const float lwv = a.ho_lw[v];
+                    a.self2[v] = dv[cc] * lwv * dv[cc];
+                    if (a.fo_bwd_val != nullptr) {
+                        const uint32_t cn = (uint32_t)h.succ[v];
+                        a.fo_bwd_val[v] = cn == b ? 0.0f : d1b * a.fo_w[v] * inv_sqrt_deg(a.fo_deg[cn]);
+                    }
+                }
+            }
+        }
+        int ord = -1;
+        for (int64_t q = qa; q < qb;) {                          // q: first in-event of a run that begins in this chunk
+            const uint32_t cur_a = a.is_a[q], cur_u = a.is_u[q];
+            ++ord;
+            float du_r = 0.0f, da_r = 0.0f;
+            int32_t ob_r = 0;
+            if (kFill && cur_u < kDb2Foreign) {
+                const uint2 rp = a.row_pack[cur_u];
+                du_r = __uint_as_float(rp.x);
+                ob_r = (int32_t)rp.y;
+                da_r = inv_sqrt_deg(a.fo_deg[cur_a]);
+            }
+            int64_t qp = q;
+            bool run_done = false;
+            while (!run_done) {
+                // ---- one piece: up to kHubxInst instance times of the run -> LDS
+                int got = 0;
+                while (got < kHubxInst) {
+                    const int64_t qx = qp + got + l;
+                    const bool li = qx < qend;
+                    const uint32_t sa = li ? a.is_a[qx] : 0xFFFFFFFFu;
+                    const uint64_t st_ = li ? a.is_t[qx] : 0ull;
+                    const uint64_t mism = __ballot(!li || sa != cur_a);
+                    const int upto = mism ? __ffsll((long long)mism) - 1 : kWave;
+                    const int room = kHubxInst - got;
+                    const int take = upto < room ? upto : room;
+                    if (l < take) tms[got + l] = st_;
+                    got += take;
+                    if (upto < kWave && upto <= room) { run_done = true; break; }
+                    if (take < kWave) break;                          // the piece is full
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int ninst = got;
+                if (ninst == 0) break;
+                qp += ninst;
+                if (ncol > 0) {
+                    const TimeT t_first = time_of<TimeT>(tms[0]), t_last = time_of<TimeT>(tms[ninst - 1]);
+                    const typename W::Thr thr_last = W::threshold(t_last, delta_i, delta_f);
+                    int64_t g0 = 0, hi = no;
+                    while (g0 < hi) {                                 // first out-event later than the first instance
+                        const int64_t mid = g0 + ((hi - g0) >> 1);
+                        if (time_of<TimeT>(otb[mid]) > t_first) hi = mid; else g0 = mid + 1;
+                    }
+                    int64_t g1 = g0;
+                    hi = no;
+                    while (g1 < hi) {                                 // first one beyond the last instance's window
+                        const int64_t mid = g1 + ((hi - g1) >> 1);
+                        if (!W::admits(time_of<TimeT>(otb[mid]), thr_last)) hi = mid; else g1 = mid + 1;
+                    }
+                    // the out-events ascend in time and so do the instances: two cursors into the LDS times follow the scan (ilo: instances
+                    // earlier than the batch's first out-event, plo: instances whose window ends before it) and bracket every lane's
+                    // own counts, so the per-lane bisections run over the few instances that fall inside ONE batch's time span — and a
+                    // batch that no instance's window reaches (most of them when delta is small) is dropped after four LDS reads.
+                    int ilo = 0, plo = 0;
+                    constexpr int kAhead = 4;                             // batches whose loads are in flight together (the scan is latency-bound per wave)
+                    for (int64_t j00 = g0; j00 < g1; j00 += kAhead * kWave) {
+                        uint64_t tbq[kAhead];
+                        uint32_t rkq[kAhead];
+#pragma unroll
+                        for (int x = 0; x < kAhead; ++x) {
+                            const int64_t jx = j00 + x * kWave + l;
+                            tbq[x] = jx < g1 ? otb[jx] : 0ull;
+                            rkq[x] = jx < g1 ? rkb[jx] : 0xFFFFFFFFu;
+                        }
+#pragma unroll
+                        for (int x = 0; x < kAhead; ++x) {
+                            const int64_t j0 = j00 + x * kWave;
+                            if (j0 >= g1) break;
+                            const uint64_t tb = tbq[x];
+                            const uint32_t rk = rkq[x] - (uint32_t)rbase;
+                            const int64_t j = j0 + l;
+                            const int nv = g1 - j0 < kWave ? (int)(g1 - j0) : kWave;
+                            const TimeT t0 = time_of<TimeT>(rl_u64(tb, 0)), tl = time_of<TimeT>(rl_u64(tb, nv - 1));
+                            while (ilo < ninst && time_of<TimeT>(tms[ilo]) < t0) ++ilo;
+                            while (plo < ninst && !W::admits(t0, W::threshold(time_of<TimeT>(tms[plo]), delta_i, delta_f))) ++plo;
+                            int ihi = ilo, phi = plo;
+                            while (ihi < ninst && time_of<TimeT>(tms[ihi]) < tl) ++ihi;
+                            if (ihi <= plo) continue;                     // no instance both earlier than an out-event of the batch and still open
+                            while (phi < ninst && !W::admits(tl, W::threshold(time_of<TimeT>(tms[phi]), delta_i, delta_f))) ++phi;
+                            if (j < g1 && rk < (uint32_t)kHubxRuns) {
+                                const TimeT tj = time_of<TimeT>(tb);
+                                int lo = ilo, hi2 = ihi;
+                                while (lo < hi2) {                        // instances earlier than t_j
+                                    const int mid = (lo + hi2) >> 1;
+                                    if (time_of<TimeT>(tms[mid]) < tj) lo = mid + 1; else hi2 = mid;
+                                }
+                                const int lb = lo;
+                                lo = plo; hi2 = phi < lb ? phi : lb;
+                                while (lo < hi2) {                        // ... of which the first whose window still reaches t_j
+                                    const int mid = (lo + hi2) >> 1;
+                                    if (!W::admits(tj, W::threshold(time_of<TimeT>(tms[mid]), delta_i, delta_f))) lo = mid + 1; else hi2 = mid;
+                                }
+                                const int c = lb - lo;
+                                if (c > 0) {
+                                    atomicAdd(&hist[rk], (uint32_t)c);
+                                    pairs += c;
+                                }
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const int64_t ninst_run = qp - q;
+            const float w1run = (float)ninst_run;
+            // ---- epilogue of in-run (cur_a, b) = order-2 node cur_u, one 64-run column after the other (ascending successor)
+            const int slot = ord >> 6, olane = ord & (kWave - 1);
+#pragma unroll
+            for (int cc = 0; cc < kHubxCols; ++cc) {
+                if (cc < ncol) {
+                    const int64_t rr = rbase + cc * kWave + l;
+                    const bool valid = rr < R;
+                    const uint32_t v = (uint32_t)(row0 + rr);
+                    const int hits = (int)hist[cc * kWave + l];
+                    hist[cc * kWave + l] = 0u;
+                    const float wgt = (float)hits;
+                    const bool emit = valid && hits > 0;
+                    const uint64_t em = __ballot(emit);
+                    const int reached = (int)__popcll(em);
+                    const int odsel = slot == 0 ? od0 : (slot == 1 ? od1 : (slot == 2 ? od2 : od3));
+                    const int before = rl_i(odsel, olane);
+                    if (l == olane) {
+                        if (slot == 0) od0 += reached; else if (slot == 1) od1 += reached; else if (slot == 2) od2 += reached; else od3 += reached;
+                    }
+                    if (!kFill) {
+                        if (emit) {
+                            ++cnt[cc];
+                            if (cur_u == v) lw[cc] = wgt; else deg[cc] += wgt;
+                        }
+                    } else if (emit) {
+                        const float val = cur_u == v ? 0.0f : du_r * wgt * dv[cc];
+                        a.in_idx2[ip[cc] + cnt[cc]] = (int32_t)cur_u;
+                        a.in_val2[ip[cc] + cnt[cc]] = val;
+                        if (a.in_w2) a.in_w2[ip[cc] + cnt[cc]] = wgt;
+                        const int rank = before + (int)__popcll(em & lanes_below(l));
+                        a.out_pack[ob_r + rank] = make_uint2(v, __float_as_uint(val));
+                        ++cnt[cc];
+                    }
+                }
+            }
+            if (!kFill && rd == rounds - 1) {
+                const int odsel = slot == 0 ? od0 : (slot == 1 ? od1 : (slot == 2 ? od2 : od3));
+                const int total = rl_i(odsel, olane);
+                if (l == 0 && total != 0 && cur_u < kDb2Foreign) a.outdeg2[cur_u] = total;
+                longest_src = total > longest_src ? total : longest_src;
+            }
+            if (rd == 0) {
+                if (!kFill) {
+                    ++runs;
+                    if (cur_a == b) lw1 = w1run; else deg1 += w1run;
+                } else if (l == 0) {
+                    a.fwd_idx1[fp + ord] = (int32_t)cur_a;
+                    a.fwd_val1[fp + ord] = cur_a == b ? 0.0f : da_r * w1run * d1b;
+                    if (a.dst_order) a.dst_order[fp + ord] = (int32_t)cur_u;
+                }
+            }
+            q = qp;
+        }
+        if (!kFill) {
+#pragma unroll
+            for (int cc = 0; cc < kHubxCols; ++cc) {
+                if (cc < ncol) {
+                    const int64_t pi = (part0 + rbase / kWave + cc) * kWave + l;
+                    h.part_cnt[pi] = cnt[cc];
+                    h.part_deg[pi] = deg[cc];
+                    h.part_lw[pi] = lw[cc];
+                }
+            }
+        }
+    }
+    if (!kFill) {
+        if (R == 0 && l < kWave) {                                // (no successor: the one part column k_db2_hub_combine reads)
+            h.part_cnt[part0 * kWave + l] = 0;
+            h.part_deg[part0 * kWave + l] = 0.0f;
+            h.part_lw[part0 * kWave + l] = -1.0f;
+        }
         const long long total = wave_sum(pairs);
         const int longest = wave_max(longest_src);
         if (l == 0) {
@@ -1491,6 +1754,18 @@ static void launch_hub(bool weighted, unsigned grid, hipStream_t st, int64_t tas
 }
 
 template <bool kFill>
+static int launch_hubx_any(int time_dtype, int delta_kind, hipStream_t st, int64_t tasks, int64_t di, double df, const Db2Mid& a, const Db2Hub& h,
+                           const uint64_t* ot_t, const uint32_t* rank_t) {
+    const unsigned grid = (unsigned)ceil_div(tasks, kWavesPerBlock);
+    if (time_dtype == PP_F64) k_db2_hubx<double, 0, kFill><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h, ot_t, rank_t);
+    else if (delta_kind == PP_DELTA_I64) k_db2_hubx<int64_t, 0, kFill><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h, ot_t, rank_t);
+    else if (delta_kind == PP_DELTA_F32) k_db2_hubx<int64_t, 1, kFill><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h, ot_t, rank_t);
+    else k_db2_hubx<int64_t, 2, kFill><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h, ot_t, rank_t);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+template <bool kFill>
 static int launch_hub_any(int time_dtype, int delta_kind, bool weighted, hipStream_t st, int64_t tasks, int64_t di, double df, const Db2Mid& a,
                           const Db2Hub& h) {
     const unsigned grid = (unsigned)ceil_div(tasks, kWavesPerBlock);
@@ -1741,6 +2016,10 @@ static int db2_count(const char* who, int time_dtype, int64_t m, int64_t n, cons
         a.hl = nullptr;
         rc = launch_hub_any<false>(time_dtype, delta_kind, weight != nullptr, st, hs.tasks, delta_i, delta_f, a, h);
         if (rc != PP_OK) return rc;
+        if (hs.out_events > 0 && weight == nullptr) {
+            rc = launch_hubx_any<false>(time_dtype, delta_kind, st, hs.tasks, delta_i, delta_f, a, h, w.ot_t, hw.rank_t);
+            if (rc != PP_OK) return rc;
+        }
         k_db2_hub_combine<<<(unsigned)ceil_div(hs.hubs, kWavesPerBlock), kBlock, 0, st>>>(hs.hubs, a, h);
         PP_LAUNCH_CHECK();
     }
@@ -1788,6 +2067,10 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
         h.succ = fo_bwd_idx;
         rc = launch_hub_any<true>(time_dtype, delta_kind, weight != nullptr, st, hs.tasks, delta_i, delta_f, a, h);
         if (rc != PP_OK) return rc;
+        if (hs.out_events > 0 && weight == nullptr) {
+            rc = launch_hubx_any<true>(time_dtype, delta_kind, st, hs.tasks, delta_i, delta_f, a, h, w.ot_t, hw.rank_t);
+            if (rc != PP_OK) return rc;
+        }
     }
     if (num_ho_edges > 0) {
         k_db2_unzip<<<(unsigned)ceil_div(num_ho_edges, kBlock), kBlock, 0, st>>>(num_ho_edges, (const uint2*)pair_scratch, ho_bwd_idx, ho_bwd_val);
