@@ -51,7 +51,11 @@ def parse():
     ap.add_argument("--features", type=int, default=64)
     ap.add_argument("--dropout", type=float, default=0.0, help="p_dropout of the model (the headline number is quoted at 0; the reference's own test uses 0.4)")
     ap.add_argument("--classes", type=int, default=8)
-    ap.add_argument("--mode", choices=("partition", "streams"), default="partition")
+    ap.add_argument("--mode", choices=("auto", "partition", "streams"), default="auto",
+                    help="auto: the north-star partition at 1 GPU and from 8 GPUs on; at 2..7 GPUs `streams` (independent streams, weak scaling) — "
+                         "xGMI is point-to-point, so a rank's halo (7/8 of its order-2 source rows on an ER stream, whatever the cut) crosses W-1 links: "
+                         "640 MB per layer exchange on ONE link at 2 ranks, 160 MB at 4, 40 MB at 8; the projections (profiles/r04_shapes/emulate{2,4}.json) "
+                         "put the 2- and 4-rank partition step at 42.7 / 14.8 ms against 14.0 ms on one GPU: reported as what it is, not as scaling")
     ap.add_argument("--no-api-path", action="store_true", help="skip the extra (untimed for `value`) steps through the reference API that fill api_path_ms_per_step")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: host-staged collectives (tests; several ranks may share one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (single-GPU test boxes, with --backend gloo)")
@@ -678,6 +682,13 @@ def main() -> int:
     from pathpyg_amd import distributed as ppd
     from pathpyg_amd._lib import lib
 
+    mode_note = None
+    if args.mode == "auto":
+        args.mode = "partition" if (world == 1 or world >= 8) else "streams"
+        if world > 1 and args.mode == "streams":
+            mode_note = (f"{world} GPUs: the node-range partition of ONE stream is link-bound below 8 ranks on point-to-point xGMI (projected "
+                         "42.7 ms at 2 ranks, 14.8 ms at 4 against 14.0 ms on one GPU) — this line runs independent streams (weak scaling, "
+                         "weight-gradient all-reduce); `--mode partition` forces the split")
     partition = args.mode == "partition"
     comm = ppd.Comm()
     # ---- inputs, resident in HBM before the timed region.  partition: ONE stream replicated on every rank; streams: one per rank
@@ -918,6 +929,7 @@ def main() -> int:
             "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "strong" if partition else "weak",
+            **({"mode_note": mode_note} if mode_note else {}),
             "vs_baseline": None,
             "dtype": "int64 lift / f32 DBGNN",
             "data": "synthetic",

@@ -333,7 +333,7 @@ def test_bench_partition_default_and_rccl_world1_and_gloo_world2():
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     small = ["--events", "200000", "--nodes", "10000", "--span", "200000", "--delta", "20000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
-    for nproc, extra in ((1, []), (2, ["--backend", "gloo", "--share-gpu"])):
+    for nproc, extra in ((1, []), (2, ["--backend", "gloo", "--share-gpu", "--mode", "partition"])):
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
                             "--master-port", str(port + nproc), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + small + extra,
                            capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -359,8 +359,11 @@ def test_bench_partition_default_and_rccl_world1_and_gloo_world2():
     assert split["E2"] == whole["config"]["E2"] and split["A2"] == whole["config"]["A2"] and split["U2"] == whole["config"]["U2"]
     assert abs(split["loss"] - whole["loss"]) < 1e-5 * abs(whole["loss"]), (split["loss"], whole["loss"])
     # the driver's command shape without a launcher: `python bench.py --gpus N` starts its own ranks
-    self_launched = _bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"])
+    self_launched = _bench(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--mode", "partition"])
     assert self_launched["n_gpus"] == 2 and self_launched["config"]["E2"] == one["config"]["E2"] and self_launched["scaling"] == "strong"
+    # default mode at 2 ranks: independent streams (the 2- / 4-rank split of ONE stream is link-bound on point-to-point xGMI), said so in the line
+    auto = _bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"])
+    assert auto["n_gpus"] == 2 and auto["scaling"] == "weak" and "link-bound" in auto["mode_note"] and auto["value"] > 0
 
 
 def _masked_reference(case, p, seed):
