@@ -142,15 +142,16 @@ def synth_stream(events: int, nodes: int, span: int, seed: int, device):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # live kernel timing: HIP events around C-ABI entry points on the stream they launch on
 class KernelClock:
-    """HIP events around every call of one C-ABI entry point; with `until`: around the call of `name` (the count phase) AND around the
-    following call of `until` (the fill phase) — two intervals, because count phases of independent operations are queued together and
-    other kernels run between an operation's count and its fill."""
+    """HIP events around every call of one C-ABI entry point; with `until` (one name or several): around the call of `name` (the count
+    phase) AND around the following call of each `until` entry point in turn (count / fill phases) — separate intervals, because count phases
+    of independent operations are queued together and other kernels run between an operation's phases."""
 
-    def __init__(self, lib, name: str, describe, until: str | None = None):
-        self.lib, self.name, self.describe, self.until = lib, name, describe, until
+    def __init__(self, lib, name: str, describe, until=None):
+        self.lib, self.name, self.describe = lib, name, describe
+        self.until = [until] if isinstance(until, str) else list(until or [])
         self.orig = getattr(lib, name)
-        self.orig_until = getattr(lib, until) if until else None
-        self.records = []          # (start_event, end_event, start2 | None, end2 | None, key, bytes)
+        self.orig_until = [getattr(lib, u) for u in self.until]
+        self.records = []          # ([(start_event, end_event), ...], key, bytes)
         self.enabled = False
         self._open = None
 
@@ -167,34 +168,36 @@ class KernelClock:
             if not self.enabled:
                 return self.orig(*args)
             rc, e0, e1 = self._timed(self.orig, args)
-            if self.until is None:
-                self.records.append((e0, e1, None, None) + tuple(self.describe(*args)))
+            if not self.until:
+                self.records.append(([(e0, e1)],) + tuple(self.describe(*args)))
             else:
-                self._open = (e0, e1) + tuple(self.describe(*args))
+                self._open = ([(e0, e1)],) + tuple(self.describe(*args))
             return rc
         setattr(self.lib, self.name, wrapped)
-        if self.until:
-            def wrapped_until(*args):
-                if not (self.enabled and self._open is not None):
-                    return self.orig_until(*args)
-                rc, f0, f1 = self._timed(self.orig_until, args)
-                self.records.append((self._open[0], self._open[1], f0, f1) + self._open[2:])
-                self._open = None
+        for k, (name, orig) in enumerate(zip(self.until, self.orig_until)):
+            def wrapped_until(*args, _k=k, _orig=orig):
+                if not (self.enabled and self._open is not None and len(self._open[0]) == _k + 1):
+                    return _orig(*args)
+                rc, f0, f1 = self._timed(_orig, args)
+                self._open[0].append((f0, f1))
+                if _k + 1 == len(self.until):
+                    self.records.append(self._open)
+                    self._open = None
                 return rc
-            setattr(self.lib, self.until, wrapped_until)
+            setattr(self.lib, name, wrapped_until)
         return self
 
     def __exit__(self, *exc):
         setattr(self.lib, self.name, self.orig)
-        if self.until:
-            setattr(self.lib, self.until, self.orig_until)
+        for name, orig in zip(self.until, self.orig_until):
+            setattr(self.lib, name, orig)
 
     def groups(self) -> dict:
         """{key: (launches, total ms, total algorithmic bytes)}"""
         out = {}
-        for e0, e1, f0, f1, key, nbytes in self.records:
+        for intervals, key, nbytes in self.records:
             n, ms, b = out.get(key, (0, 0.0, 0))
-            out[key] = (n + 1, ms + e0.elapsed_time(e1) + (f0.elapsed_time(f1) if f0 is not None else 0.0), b + nbytes)
+            out[key] = (n + 1, ms + sum(e0.elapsed_time(e1) for e0, e1 in intervals), b + nbytes)
         return out
 
 
@@ -802,7 +805,7 @@ def main() -> int:
             KernelClock(L, "pp_temporal_count", lift_desc, until="pp_temporal_fill") as lift_clock, \
             KernelClock(L, "pp_coalesce_count", coalesce_desc, until="pp_coalesce_fill") as agg_clock, \
             KernelClock(L, "pp_debruijn2_lists", lambda ei_p, t_p, tdt, m, *r: ("fused order-2 builder (pp_debruijn2_lists .. pp_debruijn2_fill)", 24 * m),
-                        until="pp_debruijn2_fill") as fused_clock:
+                        until=("pp_debruijn2_count", "pp_debruijn2_fill")) as fused_clock:
         clocks = (spmm_clock, fwd_clock, bwd_clock, fill_clock, lift_clock, agg_clock, fused_clock)
         for _ in range(args.warmup):
             step(False)

@@ -1404,11 +1404,17 @@ __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t de
 }
 
 // per hub node: the tasks' partial results in task order -> in-degrees, weighted degrees, self-loop weights of its order-2 rows and the
-// exclusive prefix of every task (where its entries start inside a destination-major row); first-order in-degree / degree of the node
-__global__ __launch_bounds__(kBlock) void k_db2_hub_combine(int64_t n_hubs, Db2Mid a, Db2Hub h) {
-    const int64_t slot = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
+// exclusive prefix of every task (where its entries start inside a destination-major row); first-order in-degree / degree of the node.
+// One workgroup of 8 waves per hub: the task list is cut into 8 contiguous pieces, every wave sums its piece, the pieces' totals meet in LDS,
+// every wave rewrites its piece's counts as prefixes (a node with 2*10^6 in-events has 7 800 tasks: 1.7 -> 0.3 ms on BASELINE configs[2]'s
+// stream).  Sums in (piece, task) order: fixed, bit-reproducible.
+constexpr int kCombineWaves = 8;
+__global__ __launch_bounds__(kCombineWaves* kWave) void k_db2_hub_combine(int64_t n_hubs, Db2Mid a, Db2Hub h) {
+    __shared__ int s_cnt[kCombineWaves][kWave];
+    __shared__ float s_deg[kCombineWaves][kWave], s_lw[kCombineWaves][kWave];
+    const int64_t slot = blockIdx.x;
     if (slot >= n_hubs) return;
-    const int l = lane_id();
+    const int l = lane_id(), w = wave_id();
     const uint32_t b = h.hub_list[slot];
     const int64_t no = (int64_t)a.tp[b + 1] - a.tp[b], ni = (int64_t)a.hp[b + 1] - a.hp[b];
     const int32_t row0 = a.row_ptr[b];
@@ -1417,17 +1423,19 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub_combine(int64_t n_hubs, Db2M
     const int64_t nrc = no > 0 ? ((no < h.num_nodes ? no : h.num_nodes) + kWave - 1) / kWave : 1;
     const int64_t ntask = ni > 0 ? (ni + kHubChunk - 1) / kHubChunk : 1;
     const int64_t t0 = h.tbase[b], pb = h.pbase[b];
+    const int64_t per = (ntask + kCombineWaves - 1) / kCombineWaves;
+    const int64_t k_lo = w * per < ntask ? w * per : ntask, k_hi = k_lo + per < ntask ? k_lo + per : ntask;
     int longest = 0;
     constexpr int kBatch = 16;
     for (int64_t c = 0; c < rounds; ++c) {
-        int running = 0;
+        int total = 0;
         float deg = 0.0f, lw = -1.0f;
-        for (int64_t k0 = 0; k0 < ntask; k0 += kBatch) {
+        for (int64_t k0 = k_lo; k0 < k_hi; k0 += kBatch) {
             int x[kBatch];
             float d[kBatch], t[kBatch];
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
-                const bool in = k0 + j < ntask;
+                const bool in = k0 + j < k_hi;
                 const int64_t pi = (pb + (k0 + j) * nrc + c) * kWave + l;
                 x[j] = in ? h.part_cnt[pi] : 0;
                 d[j] = in ? h.part_deg[pi] : 0.0f;
@@ -1435,24 +1443,52 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub_combine(int64_t n_hubs, Db2M
             }
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
-                if (k0 + j < ntask) {
+                total += x[j];
+                deg += d[j];
+                if (t[j] >= 0.0f) lw = t[j];
+            }
+        }
+        s_cnt[w][l] = total;
+        s_deg[w][l] = deg;
+        s_lw[w][l] = lw;
+        __syncthreads();
+        int running = 0;
+        for (int ww = 0; ww < w; ++ww) running += s_cnt[ww][l];
+        for (int64_t k0 = k_lo; k0 < k_hi; k0 += kBatch) {
+            int x[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) x[j] = k0 + j < k_hi ? h.part_cnt[(pb + (k0 + j) * nrc + c) * kWave + l] : 0;
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                if (k0 + j < k_hi) {
                     h.part_cnt[(pb + (k0 + j) * nrc + c) * kWave + l] = running;
                     running += x[j];
-                    deg += d[j];
-                    if (t[j] >= 0.0f) lw = t[j];
                 }
             }
         }
-        const int64_t rr = c * kWave + l;
-        if (rr < R) {
-            const uint32_t v = (uint32_t)(row0 + rr);
-            const float l2 = lw < 0.0f ? 1.0f : lw;              // an existing self loop keeps its weight, every other node gets one of weight 1
-            a.indeg2[v] = running;
-            a.ho_deg[v] = deg + l2;
-            a.ho_lw[v] = l2;
-            longest = running > longest ? running : longest;
+        if (w == kCombineWaves - 1) {
+            const int64_t rr = c * kWave + l;
+            if (rr < R) {
+                float dsum = 0.0f, lwf = -1.0f;
+                for (int ww = 0; ww < kCombineWaves; ++ww) {
+                    dsum += s_deg[ww][l];
+                    if (s_lw[ww][l] >= 0.0f) lwf = s_lw[ww][l];
+                }
+                const uint32_t v = (uint32_t)(row0 + rr);
+                const float l2 = lwf < 0.0f ? 1.0f : lwf;          // an existing self loop keeps its weight, every other node gets one of weight 1
+                a.indeg2[v] = running;
+                a.ho_deg[v] = dsum + l2;
+                a.ho_lw[v] = l2;
+                longest = running > longest ? running : longest;
+            }
         }
+        __syncthreads();
     }
+    if (w == kCombineWaves - 1) {
+        longest = wave_max(longest);
+        if (l == 0) atomicMax((unsigned long long*)&h.stats[5], (unsigned long long)longest);
+    }
+    if (w != 0) return;
     // the node itself: in-runs per task -> first-order in-degree + where every task's first-order entries start; weighted degree
     int base = 0;
     float deg1 = 0.0f, lw1 = -1.0f;
@@ -1463,13 +1499,10 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub_combine(int64_t n_hubs, Db2M
         if (in) h.task_runbase[t0 + k0 + l] = base + inc - r;
         base += rl_i(inc, kWave - 1);
         const float dl = in ? h.task_deg1[t0 + k0 + l] : 0.0f, tl_ = in ? h.task_lw1[t0 + k0 + l] : -1.0f;
-        for (int z = 0; z < kWave; ++z) {                          // task order (fixed)
-            deg1 += rl_f(dl, z);
-            const float tz = rl_f(tl_, z);
-            if (tz >= 0.0f) lw1 = tz;
-        }
+        const float tmax = wave_max(tl_);                          // (at most one task met the node's own self loop)
+        if (tmax >= 0.0f) lw1 = tmax;
+        deg1 += wave_sum(dl);                                      // a fixed-order tree over the 64 tasks, the blocks of 64 in order
     }
-    longest = wave_max(longest);
     if (l == 0) {
         const float l1 = lw1 < 0.0f ? 1.0f : lw1;
         a.nu[b] = base;
@@ -1477,7 +1510,6 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub_combine(int64_t n_hubs, Db2M
         a.fo_deg[b] = deg1 + l1;
         a.fo_lw[b] = l1;
         a.node_simple[b] = 0;
-        atomicMax((unsigned long long*)&h.stats[5], (unsigned long long)longest);
         atomicMax((unsigned long long*)&h.stats[7], (unsigned long long)base);
     }
 }
@@ -2020,7 +2052,7 @@ static int db2_count(const char* who, int time_dtype, int64_t m, int64_t n, cons
             rc = launch_hubx_any<false>(time_dtype, delta_kind, st, hs.tasks, delta_i, delta_f, a, h, w.ot_t, hw.rank_t);
             if (rc != PP_OK) return rc;
         }
-        k_db2_hub_combine<<<(unsigned)ceil_div(hs.hubs, kWavesPerBlock), kBlock, 0, st>>>(hs.hubs, a, h);
+        k_db2_hub_combine<<<(unsigned)hs.hubs, kCombineWaves * kWave, 0, st>>>(hs.hubs, a, h);
         PP_LAUNCH_CHECK();
     }
     rc = exclusive_scan<int32_t, int32_t>(w.nu, n_own, fo_fwd_ptr, true, w.result + 4, w.scratch, w.scratch_bytes, st);
