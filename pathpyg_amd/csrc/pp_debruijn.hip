@@ -1149,7 +1149,13 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
 // the instances it continues by two bisections over the LDS times (t_i < t_j and t_j <= t_i + delta are monotone in t_i) and adds that count
 // to its successor's slot of an LDS histogram (integer atomics: exact, order-free).  The histogram of 512 runs is the `hits` vector of eight
 // 64-lane columns at once; nodes with more runs take several rounds.  Same tasks, same part columns, same epilogue as k_db2_hub.
-constexpr int kHubxRuns = 512, kHubxInst = 512, kHubxCols = kHubxRuns / kWave;
+#ifndef PP_HUBX_RUNS
+#define PP_HUBX_RUNS 512
+#endif
+#ifndef PP_HUBX_AHEAD
+#define PP_HUBX_AHEAD 4
+#endif
+constexpr int kHubxRuns = PP_HUBX_RUNS, kHubxInst = 512, kHubxCols = kHubxRuns / kWave;
 
 template <typename TimeT, int kMode, bool kFill>
 __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t delta_i, double delta_f, Db2Mid a, Db2Hub h, const uint64_t* __restrict__ ot_t,
@@ -1263,13 +1269,17 @@ __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t de
                         const int64_t mid = g1 + ((hi - g1) >> 1);
                         if (!W::admits(time_of<TimeT>(otb[mid]), thr_last)) hi = mid; else g1 = mid + 1;
                     }
-                    // the out-events ascend in time and so do the instances: two cursors into the LDS times follow the scan (ilo: instances
-                    // earlier than the batch's first out-event, plo: instances whose window ends before it) and bracket every lane's
-                    // own counts, so the per-lane bisections run over the few instances that fall inside ONE batch's time span — and a
-                    // batch that no instance's window reaches (most of them when delta is small) is dropped after four LDS reads.
-                    int ilo = 0, plo = 0;
-                    constexpr int kAhead = 4;                             // batches whose loads are in flight together (the scan is latency-bound per wave)
-                    for (int64_t j00 = g0; j00 < g1; j00 += kAhead * kWave) {
+                    // the out-events ascend in time and so do the instances: ONE cursor into the LDS times follows the scan — `plo`, the first
+                    // instance whose window has not ended before the batch's first out-event (its time and threshold sit in registers).  A
+                    // batch whose last out-event is not later than that instance is dropped after two compares (most batches when delta is
+                    // small against the spacing of the instances); otherwise the few instances that begin before the batch ends are
+                    // tested against every lane's out-event directly: c_j = #{i : t_i < t_j <= t_i + delta}.  The scan ends with the last window.
+                    int plo = 0;
+                    TimeT t_plo = time_of<TimeT>(tms[0]);
+                    typename W::Thr thr_plo = W::threshold(t_plo, delta_i, delta_f);
+                    constexpr int kAhead = PP_HUBX_AHEAD;                 // batches whose loads are in flight together
+                    bool done = false;
+                    for (int64_t j00 = g0; j00 < g1 && !done; j00 += kAhead * kWave) {
                         uint64_t tbq[kAhead];
                         uint32_t rkq[kAhead];
 #pragma unroll
@@ -1281,36 +1291,28 @@ __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t de
 #pragma unroll
                         for (int x = 0; x < kAhead; ++x) {
                             const int64_t j0 = j00 + x * kWave;
-                            if (j0 >= g1) break;
+                            if (j0 >= g1 || done) break;
                             const uint64_t tb = tbq[x];
-                            const uint32_t rk = rkq[x] - (uint32_t)rbase;
-                            const int64_t j = j0 + l;
                             const int nv = g1 - j0 < kWave ? (int)(g1 - j0) : kWave;
                             const TimeT t0 = time_of<TimeT>(rl_u64(tb, 0)), tl = time_of<TimeT>(rl_u64(tb, nv - 1));
-                            while (ilo < ninst && time_of<TimeT>(tms[ilo]) < t0) ++ilo;
-                            while (plo < ninst && !W::admits(t0, W::threshold(time_of<TimeT>(tms[plo]), delta_i, delta_f))) ++plo;
-                            int ihi = ilo, phi = plo;
-                            while (ihi < ninst && time_of<TimeT>(tms[ihi]) < tl) ++ihi;
-                            if (ihi <= plo) continue;                     // no instance both earlier than an out-event of the batch and still open
-                            while (phi < ninst && !W::admits(tl, W::threshold(time_of<TimeT>(tms[phi]), delta_i, delta_f))) ++phi;
-                            if (j < g1 && rk < (uint32_t)kHubxRuns) {
-                                const TimeT tj = time_of<TimeT>(tb);
-                                int lo = ilo, hi2 = ihi;
-                                while (lo < hi2) {                        // instances earlier than t_j
-                                    const int mid = (lo + hi2) >> 1;
-                                    if (time_of<TimeT>(tms[mid]) < tj) lo = mid + 1; else hi2 = mid;
-                                }
-                                const int lb = lo;
-                                lo = plo; hi2 = phi < lb ? phi : lb;
-                                while (lo < hi2) {                        // ... of which the first whose window still reaches t_j
-                                    const int mid = (lo + hi2) >> 1;
-                                    if (!W::admits(tj, W::threshold(time_of<TimeT>(tms[mid]), delta_i, delta_f))) lo = mid + 1; else hi2 = mid;
-                                }
-                                const int c = lb - lo;
-                                if (c > 0) {
-                                    atomicAdd(&hist[rk], (uint32_t)c);
-                                    pairs += c;
-                                }
+                            while (!W::admits(t0, thr_plo)) {             // windows that ended before this batch
+                                if (++plo >= ninst) break;
+                                t_plo = time_of<TimeT>(tms[plo]);
+                                thr_plo = W::threshold(t_plo, delta_i, delta_f);
+                            }
+                            if (plo >= ninst) { done = true; break; }
+                            if (!(t_plo < tl)) continue;                  // the next open instance begins after the batch
+                            const TimeT tj = time_of<TimeT>(tb);
+                            int c = 0;
+                            for (int ii = plo; ii < ninst; ++ii) {
+                                const TimeT ti = time_of<TimeT>(tms[ii]);
+                                if (!(ti < tl)) break;
+                                c += (ti < tj && W::admits(tj, W::threshold(ti, delta_i, delta_f))) ? 1 : 0;
+                            }
+                            const uint32_t rk = rkq[x] - (uint32_t)rbase;
+                            if (c > 0 && j0 + l < g1 && rk < (uint32_t)kHubxRuns) {
+                                atomicAdd(&hist[rk], (uint32_t)c);
+                                pairs += c;
                             }
                         }
                     }
