@@ -50,8 +50,26 @@ def train_step(d):
     return loss
 
 
-timed("train step, plans rebuilt (fresh bundle each step)", lambda: train_step(mom.to_dbgnn_data(max_order=2, mapping="last", x=x, x_h=x_h)))
-timed("train step, cached plans (same bundle)", lambda: train_step(data))
+timed("train step, fresh bundle each step (plans handed over)", lambda: train_step(mom.to_dbgnn_data(max_order=2, mapping="last", x=x, x_h=x_h)))
+timed("train step, same bundle", lambda: train_step(data))
+
+
+def api_step():
+    model = pp.MultiOrderModel.from_temporal_graph(tg, delta=delta, max_order=2)
+    return train_step(model.to_dbgnn_data(max_order=2, mapping="last", x=x, x_h=x_h))
+
+
+timed("WHOLE API STEP: from_temporal_graph(2) + to_dbgnn_data + train step", api_step)
+import pathpyg_amd.core.multi_order_model as mm  # noqa: E402
+mm.FUSED_BUILDER = False
+timed("  the same with the generic kernels (FUSED_BUILDER = False)", api_step, 3)
+mm.FUSED_BUILDER = True
+# the reference's layer tensors are deferred views of the builder's plans: what reading each of them costs (fresh model per read)
+for layer, key in ((1, "edge_index"), (2, "edge_index"), (2, "edge_weight"), (2, "node_sequence"), (2, "inverse_idx")):
+    def read(layer=layer, key=key):
+        model = pp.MultiOrderModel.from_temporal_graph(tg, delta=delta, max_order=2)
+        return model.layers[layer].data[key]
+    timed(f"from_temporal_graph(2) + read layers[{layer}].data.{key}", read, 3)
 net.eval()
 with torch.no_grad():
     timed("inference forward, cached plans", lambda: net(data))
