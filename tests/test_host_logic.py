@@ -220,3 +220,81 @@ def test_halo_end_is_a_tight_conservative_bound_for_every_delta_dtype():
         tf = torch.sort(torch.rand(500, generator=g, dtype=torch.float64)).values
         assert halo_end(tf, 100, 0.1) == 100 + int((tf[100:] <= tf[99] + 0.1).sum())
     assert halo_end(t, 0, 5) == 0 and halo_end(t, t.numel(), 5) == t.numel()
+
+
+# ------------------------------------------------------------------ deferred layer tensors (round 5: layers that come out of the order-2 builder)
+def test_data_lazy_tensors_resolve_on_first_read_and_answer_sizes_before():
+    from pathpyg_amd.data import Data, Lazy
+    made = []
+
+    def make():
+        made.append(1)
+        return torch.arange(6).reshape(2, 3)
+
+    lazy = Lazy(make, (2, 3))
+    d = Data(edge_index=lazy, num_nodes=4, edge_weight=torch.ones(3))
+    assert d.num_edges == 3 and d.num_nodes == 4 and not made                       # sizes come from the declared shape
+    assert d.is_edge_attr("edge_weight") and "edge_index" in d and d.peek("edge_index") is lazy and not made
+    assert "edge_index=[2, 3]" in repr(d) and not made
+    ei = d.edge_index
+    assert made == [1] and torch.equal(ei, torch.arange(6).reshape(2, 3))
+    assert d.edge_index is ei and d["edge_index"] is ei and made == [1]               # made once; the bag now holds the tensor itself
+    assert d.peek("edge_index") is ei and lazy.value is ei and lazy.version == ei._version
+    # clone / to / iteration resolve whatever is still deferred
+    d2 = Data(edge_index=Lazy(lambda: torch.zeros(2, 5, dtype=torch.long), (2, 5)), num_nodes=3)
+    c = d2.clone()
+    assert isinstance(c.peek("edge_index"), torch.Tensor) and c.num_edges == 5
+    assert dict(iter(Data(a=Lazy(lambda: torch.ones(2), (2,)))))["a"].shape == (2,)
+
+
+def test_graph_from_parts_reads_nothing_and_index_map_defers_too():
+    import numpy as np
+    from pathpyg_amd.core.graph import Graph
+    from pathpyg_amd.core.index_map import IndexMap
+    from pathpyg_amd.data import Data, Lazy
+    made = []
+
+    def deferred(value, name):
+        def make():
+            made.append(name)
+            return value
+        return Lazy(make, value.shape)
+
+    ei = torch.tensor([[0, 0, 1], [1, 2, 2]])
+    ns = torch.tensor([[0, 1], [0, 2], [1, 2]])
+    data = Data(edge_index=deferred(ei, "edge_index"), num_nodes=3, node_sequence=deferred(ns, "node_sequence"), edge_weight=torch.ones(3))
+    base = IndexMap(["a", "b", "c"])
+    g = Graph._from_parts(data, IndexMap.from_node_sequence(base, data.peek("node_sequence")))
+    assert (g.n, g.m, g.order) == (3, 3, 2) and not made                               # sizes and order without touching a tensor
+    assert [tuple(r) for r in np.asarray(g.mapping.node_ids).tolist()] == [("a", "b"), ("a", "c"), ("b", "c")] and made == ["node_sequence"]
+    assert torch.equal(g.data.edge_index, ei) and made == ["node_sequence", "edge_index"]
+    assert torch.equal(g.data.node_sequence, ns) and made == ["node_sequence", "edge_index"]     # (the map's read and the bag's read share one tensor)
+
+
+def test_dbgnn_forward_honours_handed_plans_only_while_the_bundle_is_untouched():
+    from types import SimpleNamespace
+
+    from pathpyg_amd.data import Data, Lazy
+    from pathpyg_amd.nn.dbgnn import _valid_plans
+    names = ("edge_index", "edge_weights", "edge_index_higher_order", "edge_weights_higher_order", "bipartite_edge_index")
+    lazies = {n: Lazy(lambda: torch.zeros(2, 4, dtype=torch.long), (2, 4)) for n in names if n != "edge_weights"}
+    w = torch.ones(4)
+    d = Data(num_nodes=3, num_ho_nodes=4, edge_weights=w, **lazies)
+    stamp = {n: d.peek(n) for n in names}
+    plans = {"fo": SimpleNamespace(n_dst=3), "ho": SimpleNamespace(n_dst=4), "bi": object(), "stamp": stamp, "versions": {"edge_weights": w._version}}
+    object.__setattr__(d, "_pp_plans", plans)
+    assert _valid_plans(d) == (plans["fo"], plans["ho"], plans["bi"])
+    _ = d.edge_index_higher_order                                                       # reading a deferred tensor keeps the plans
+    assert _valid_plans(d) is not None
+    d.edge_index_higher_order.add_(1)                                                   # editing it in place does not
+    assert _valid_plans(d) is None
+    d2 = Data(num_nodes=3, num_ho_nodes=4, edge_weights=w, **{n: Lazy(lambda: torch.zeros(2, 4, dtype=torch.long), (2, 4)) for n in lazies})
+    object.__setattr__(d2, "_pp_plans", dict(plans, stamp={n: d2.peek(n) for n in names}))
+    assert _valid_plans(d2) is not None
+    d2.edge_index = torch.zeros(2, 4, dtype=torch.long)                                 # replacing a tensor does not either
+    assert _valid_plans(d2) is None
+    d3 = Data(num_nodes=5, num_ho_nodes=4, edge_weights=w, **{n: Lazy(lambda: torch.zeros(2, 4, dtype=torch.long), (2, 4)) for n in lazies})
+    object.__setattr__(d3, "_pp_plans", dict(plans, stamp={n: d3.peek(n) for n in names}))
+    assert _valid_plans(d3) is None                                                     # the bundle's node count no longer matches the plan
+    w.mul_(2)
+    assert _valid_plans(d) is None
