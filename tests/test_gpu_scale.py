@@ -9,7 +9,10 @@ import numpy as np
 import pytest
 import torch
 
-from tests.tolerance import assert_embeddings_close
+from tests.tolerance import assert_embeddings_close, assert_gradients_within
+
+GRAD_BOUNDS = {}          # parameter-name substring -> rtol where 1e-5 cannot hold: EMPTY — measured at every full-size shape (round 5, `pytest -s`):
+#                           every parameter gradient needs 5e-8 .. 1.9e-6 against float64 / the single-GPU step, so all are held to the north star's 1e-5
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -56,7 +59,7 @@ def test_config1_2m_events_matches_oracle_exactly(pp):
 def test_config1_2m_events_dbgnn_train_step_matches_float64_oracle(pp):
     """configs[1] end to end at full size: k=2 layers -> DBGNN (64-dim features, hidden 64) forward / cross-entropy / backward on
     the GPU against the oracle evaluated in float64 (its own rounding is then negligible): logits and loss within 1e-5 relative,
-    every parameter gradient within 1e-4 of its largest entry (fp32 sums over 2*10^6 rows in a different order)."""
+    every parameter gradient at the same element-wise 1e-5 bar (tests/tolerance.py; measured need: <= 1.5e-6)."""
     from oracle import dbgnn as od
     from oracle import model as om
     n, m, delta, f, classes = 100_000, 2_000_000, 100_000, 64, 8
@@ -82,8 +85,7 @@ def test_config1_2m_events_dbgnn_train_step_matches_float64_oracle(pp):
     assert_embeddings_close(out, want_out)                                # 1e-5 relative, element-wise (north star)
     torch.testing.assert_close(loss.detach().cpu().double(), want_loss, rtol=1e-5, atol=1e-6)
     for name, p_ in net.named_parameters():
-        gs = float(want_grads[name].abs().max()) + 1e-30
-        torch.testing.assert_close(p_.grad.cpu().double(), want_grads[name], rtol=1e-4, atol=1e-4 * gs), name
+        assert_gradients_within(p_.grad, want_grads[name], f"configs[1] {name}", GRAD_BOUNDS)
 
 
 def _is_lexsorted(index):
@@ -340,8 +342,7 @@ def _dbgnn_step_vs_float64(pp, m, n, span, delta, f, classes=8):
     assert_embeddings_close(got_out, want_out)                            # 1e-5 relative, element-wise (north star)
     torch.testing.assert_close(got_loss, want_loss, rtol=1e-5, atol=1e-6)
     for name, grad in got_grads.items():
-        gs = float(want_grads[name].abs().max()) + 1e-30
-        torch.testing.assert_close(grad, want_grads[name], rtol=1e-4, atol=1e-4 * gs, msg=lambda s_: f"{name}: {s_}")
+        assert_gradients_within(grad, want_grads[name], f"float64 reference, {name}", GRAD_BOUNDS)
     return sizes
 
 
@@ -469,15 +470,14 @@ def test_config4_f256_property_run_above_10m_events():
     loss_c.backward()
     torch.testing.assert_close(loss_c.detach(), loss_a, rtol=1e-5, atol=1e-6)
     for name, p_ in net.named_parameters():
-        gs = float(grads_a[name].abs().max()) + 1e-30
-        torch.testing.assert_close(p_.grad, grads_a[name], rtol=1e-4, atol=1e-4 * gs, msg=lambda s_: f"{name}: {s_}")
+        assert_gradients_within(p_.grad, grads_a[name], f"partition path vs API path, {name}", GRAD_BOUNDS)
         assert bool(torch.isfinite(p_.grad).all()), name
 
 
 def _partition_step_vs_single_gpu(pp, m, n, span, delta, f, world=8):
     """One train step (graph construction + forward + loss + backward) of the SAME stream on the whole GPU and split `world` ways (ranks as
     threads of this process on the one GPU, real kernels, device-to-device collectives): identical layer sizes, logits at 1e-5 element-wise,
-    loss at 1e-6 relative, every parameter gradient (fp32 sums over 10^7 rows in two different orders: 1e-4)."""
+    loss at 1e-6 relative, every parameter gradient at the element-wise 1e-5 bar (measured need: <= 1.9e-6)."""
     from pathpyg_amd import distributed as pd
     from tests.tolerance import assert_gradients_close
     classes = 8
@@ -515,7 +515,7 @@ def _partition_step_vs_single_gpu(pp, m, n, span, delta, f, world=8):
     assert_embeddings_close(logits, one["out"], what=f"{world}-rank logits vs one GPU")
     assert abs(parts[0]["loss"] - one["loss"]) <= 1e-6 * abs(one["loss"]), (parts[0]["loss"], one["loss"])
     for name, grad in one["grads"].items():
-        assert_gradients_close(parts[0]["grads"][name], grad, f"{world}-rank gradient of {name}", rtol=1e-4)
+        assert_gradients_within(parts[0]["grads"][name], grad, f"{world}-rank gradient of {name}", GRAD_BOUNDS)
 
 
 def test_headline_10m_events_8_rank_partition_equals_single_gpu_step(pp):
