@@ -56,6 +56,7 @@ def parse():
                          "xGMI is point-to-point, so a rank's halo (7/8 of its order-2 source rows on an ER stream, whatever the cut) crosses W-1 links: "
                          "640 MB per layer exchange on ONE link at 2 ranks, 160 MB at 4, 40 MB at 8; the projections (profiles/r04_shapes/emulate{2,4}.json) "
                          "put the 2- and 4-rank partition step at 42.7 / 14.8 ms against 14.0 ms on one GPU: reported as what it is, not as scaling")
+    ap.add_argument("--no-hub-streams", action="store_true", help="skip the builder timings on the two hub streams (hub_streams in the line)")
     ap.add_argument("--no-api-path", action="store_true", help="skip the extra (untimed for `value`) steps through the reference API that fill api_path_ms_per_step")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: host-staged collectives (tests; several ranks may share one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (single-GPU test boxes, with --backend gloo)")
@@ -396,6 +397,48 @@ def cpu_baseline(args, seed: int) -> dict:
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
+def hub_streams(dev) -> dict:
+    """Graph construction (both layers + both GCN plans + the bipartite grouping) on two streams WITH hub nodes, fused order-2 builder against the
+    generic kernels (lift -> coalesce -> coalesce -> plans), same stream, same box; `plans_identical`: every CSR array of both plans compared."""
+    import pathpyg_amd as pp
+    from pathpyg_amd import _hip
+    from pathpyg_amd import distributed as ppd
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, out
+
+    gen = torch.Generator(device=dev).manual_seed(3)
+    report = {}
+    for name, n, m, span, delta, scale_free in (("configs[2] generator: scale-free destinations, 1e6 nodes / 2e7 events", 1_000_000, 20_000_000, 10_000_000, 1_500_000, True),
+                                                 ("contact stream: 96 nodes / 2e6 events", 96, 2_000_000, 2_000_000, 300, False)):
+        src = torch.randint(0, n, (m,), generator=gen, device=dev)
+        if scale_free:
+            dst = (n * torch.rand(m, generator=gen, device=dev, dtype=torch.float64).pow(6.0)).long().clamp_(max=n - 1)
+        else:
+            dst = torch.randint(0, n, (m,), generator=gen, device=dev)
+        t = torch.randint(0, span, (m,), generator=gen, device=dev)
+        tg = pp.TemporalGraph(pp.Data(edge_index=torch.stack((src, dst)), time=t, num_nodes=n))
+        del src, dst, t
+        ms_f, built = timed(lambda: _hip.debruijn2(tg.data.edge_index, tg.data.time, n, delta, None), 3)
+        ppd.FUSED_BUILDER = False
+        x0 = torch.zeros(n, 4, device=dev)
+        ms_g, shard = timed(lambda: ppd.build_dbgnn_shard(tg, delta, x0, lambda num_ho_nodes: torch.zeros(num_ho_nodes, 4, device=dev), None, ppd.Comm()).resolve(), 2)
+        ppd.FUSED_BUILDER = True
+        same = built is not None and all(torch.equal(getattr(built.ho, f), getattr(shard.ho.plan, f)) and torch.equal(getattr(built.fo, f), getattr(shard.fo.plan, f))
+                                         for f in ("fwd_ptr", "fwd_idx", "fwd_val", "bwd_ptr", "bwd_idx", "bwd_val", "self_coef"))
+        report[name] = {"delta": delta, "fused_builder_ms": ms_f, "generic_kernels_ms": ms_g, "builder": "fused" if built is not None else "generic (fallback)",
+                        "plans_identical": bool(same), **({k: built.sizes[k] for k in ("E2", "U2", "A2", "hub_nodes", "hub_tasks")} if built is not None else {})}
+        del built, shard, tg, x0
+        torch.cuda.empty_cache()
+    return report
+
+
 def relaunch(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run on this node."""
     with socket.socket() as s:
@@ -867,6 +910,11 @@ def main() -> int:
         torch.cuda.reset_peak_memory_stats(dev)
         sizes.clear()
         sizes.update(api_sizes)
+    # Streams with HUB NODES through the same builder (round 5; outside the timed region, rank 0 at one GPU): BASELINE configs[2]'s scale-free
+    # generator and a contact stream of the shape of the reference's documented datasets — fused builder against the generic kernels, plans compared
+    hub_report = None
+    if partition and rank == 0 and world == 1 and not args.no_hub_streams:
+        hub_report = hub_streams(dev)
     # untimed extra: the k=2 -> k=3 line-graph lift of the same event graph (the lift kernel WITHOUT the continuation-list gather)
     k3 = None
     if rank == 0:
@@ -979,6 +1027,8 @@ def main() -> int:
         if api_path is not None:
             line["api_path_ms_per_step"] = api_path["ms_per_step"]
             line["api_path"] = api_path
+        if hub_report is not None:
+            line["hub_streams"] = hub_report
         if fused_ran:
             (fkey, (n_f, f_ms, _)), = fused_clock.groups().items()
             f_avg = f_ms / max(n_f, 1)
