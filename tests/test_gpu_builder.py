@@ -182,6 +182,11 @@ def _hub_stream(kind, seed=5):
         ranks = np.arange(1, n + 1, dtype=np.float64) ** -1.2
         dst = rng.choice(n, size=m, p=ranks / ranks.sum())
         ei = torch.from_numpy(np.stack((rng.integers(0, n, m), dst)))
+    elif kind == "source-sink":          # a hub with out-events only (no in-event at all) and one with in-events only
+        m, n, span = 3000, 400, 5000
+        ei = torch.from_numpy(rng.integers(2, n, (2, m)))
+        ei[0, :150] = 0                      # node 0: 150 out-events, never a destination
+        ei[1, 200:350] = 1                   # node 1: 150 in-events, never a source
     elif kind == "long-run":             # one node pair carrying a sixth of the stream: an in-run far longer than a chunk
         m, n, span = 6000, 50, 4000
         ei = torch.from_numpy(rng.integers(0, n, (2, m)))
@@ -193,7 +198,7 @@ def _hub_stream(kind, seed=5):
     return ei, t, n
 
 
-HUB_KINDS = ["in-hub", "out-hub", "both", "dense", "many-successors", "zipf", "long-run"]
+HUB_KINDS = ["in-hub", "out-hub", "both", "dense", "many-successors", "zipf", "long-run", "source-sink"]
 
 
 @pytest.mark.parametrize("kind", HUB_KINDS)
