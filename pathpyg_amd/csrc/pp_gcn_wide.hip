@@ -379,6 +379,22 @@ __global__ __launch_bounds__(kWideThreads, PP_WIDE_OCC) void k_wide_layer(const 
 // MFMA column i of column tile ct is output column 32 w + 2 i + ct: a lane ends up with two adjacent columns of a row (8-byte stores,
 // 128 contiguous bytes per row and wave).  k order inside a dot product: lane (i, kq) contracts k = 16 j + 4 kq + c at step (j, c).
 constexpr int kWsThreads = 512, kWsWaves = kWsThreads / kWave, kWsTile = 64, kWsRowsPerWave = kWsTile / kWsWaves;
+// MEASUREMENT SWITCHES (never set in the product build; tools/probes/wide_ws_counters.sh builds the variants and collects the SQ counters of
+// DESIGN §5 from THIS source): bit 0 = no gather at all (no index loads, no neighbour / self rows: the matrix stream runs on whatever the LDS
+// tiles hold), bit 1 = no stores of Y / agg_out.  Results are meaningless with either bit set.
+#ifndef PP_WS_DBG
+#define PP_WS_DBG 0
+#endif
+#ifndef PP_WS_REAL_BRANCHES
+#define PP_WS_REAL_BRANCHES 0   // 1: real branches around the per-neighbour FMAs instead of the compiler's if-conversion (6 VALU per neighbour SLOT whether the
+//                                 neighbour exists or not).  Measured (round 5, same box, 10^7 rows): 272 VALU instructions fewer per tile step and SLOWER — forward
+//                                 13.9 -> 15.6 ms: the branches cut the MFMA stream's schedule; kept as a switch for A/B runs only
+#endif
+#ifndef PP_WS_INIT_ROWS
+#define PP_WS_INIT_ROWS (-1)    // every neighbour slot of a row in flight zeroed at issue (20 v_mov per row that nothing reads): 1 always, 0 never, -1 (default) in the
+//                                 forward form only — measured (round 5, same box): without them the input gradient runs 15.28 -> 14.57 ms, the forward layer
+//                                 13.9 -> 15.1 ms (what the zeroing buys the forward form is its schedule, not its values)
+#endif
 
 struct WsRowIndex {          // per-lane index state of ONE tile for this wave's 8 rows
     int pv;                  // lanes 0..8: row pointers
@@ -459,9 +475,11 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
         f.self_here = self_any && f.r < n_self && f.r < n_rows;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            f.x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            f.v[u] = 0.f;
-            if (f.p0 + u < f.p1) {                                          // (wave-uniform)
+            if constexpr (PP_WS_INIT_ROWS > 0 || (PP_WS_INIT_ROWS < 0 && kEpi == 0)) {
+                f.x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                f.v[u] = 0.f;
+            }
+            if (f.p0 + u < f.p1) {                                          // (wave-uniform; finish_row reads x[u] / v[u] under the same test only)
                 const int j = __builtin_amdgcn_readlane(s.cj4, 4 * q + u);
                 f.v[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.cv4), 4 * q + u));
                 f.x[u] = *(const float4*)(xb + (uint64_t)(uint32_t)j * (uint64_t)(P * 4) + (uint64_t)(16 * lane));
@@ -479,6 +497,9 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (f.p0 + u < f.p1) {                                          // (wave-uniform: an absent neighbour costs no VALU slot — they are paid in matrix time)
+#if PP_WS_REAL_BRANCHES
+                asm volatile("" ::: "memory");                              // (keeps the compiler from turning the branch into 2 FMAs + 4 selects that always run)
+#endif
                 acc.x += f.v[u] * f.x[u].x; acc.y += f.v[u] * f.x[u].y; acc.z += f.v[u] * f.x[u].z; acc.w += f.v[u] * f.x[u].w;
             }
         for (int base = f.p0 + 4; base < f.p1; base += kWave) {             // rows with more than four neighbours
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
     // prologue: the first tile, gathered without anything to hide behind; the index state of the second
     int64_t t = blockIdx.x;
     WsRowIndex cur{}, nxt{};
-    if (t < n_tiles) {
+    if (!(PP_WS_DBG & 1) && t < n_tiles) {
         load_pointers(t, cur);
         load_pairs(cur);
         fetch_self_rows(t, s_tile0);
@@ -525,16 +546,18 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
             finish_row(q, f, s_tile0);
         }
     }
-    load_pointers(t + gridDim.x, cur);
-    load_pairs(cur);
+    if (!(PP_WS_DBG & 1)) {
+        load_pointers(t + gridDim.x, cur);
+        load_pairs(cur);
+    }
     __syncthreads();
 
     // one tile step: multiply tile t out of `tile`, gather tile t + grid into `fill` (called with the two LDS buffers in both roles: each call
     // site sees which object its DMA writes, so that the LDS reads of the MFMA stream never wait for it)
     auto tile_step = [&](const float* tile, float* fill) {
         const int64_t tn = t + gridDim.x;                                 // the tile being gathered (index state: cur), tn + grid: being indexed (nxt)
-        const bool gather = tn < n_tiles;
-        load_pointers(tn + gridDim.x, nxt);
+        const bool gather = !(PP_WS_DBG & 1) && tn < n_tiles;
+        if (!(PP_WS_DBG & 1)) load_pointers(tn + gridDim.x, nxt);
         if (gather) fetch_self_rows(tn, fill);
         // 4 row tiles x 8 steps of 16 MFMAs (two 16-float k blocks x 4 x two column tiles; two accumulator chains).  The A operands of step
         // s + 1 are read from LDS before the MFMAs of step s.  Gather rows 2 rt and 2 rt + 1 of the next tile ride on row tile rt: loads
@@ -552,7 +575,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 if (gather && (st & 3) == 0) issue_row(2 * rt + (st >> 2), tn, cur, f);
-                if (rt == 2 && st == 0) load_pairs(nxt);
+                if (!(PP_WS_DBG & 1) && rt == 2 && st == 0) load_pairs(nxt);
                 if (kEpi == 1 && st == 6) {                               // the activations the row tile's epilogue multiplies by, 32 MFMAs ahead
                     const char* ab = (const char*)(act_in + row0 * Q);    // (scalar row-tile base + one constant lane offset: no per-row address VALU)
 #pragma unroll
@@ -596,10 +619,13 @@ __global__ __launch_bounds__(kWsThreads, 1) void k_wide_ws(const int32_t* __rest
                     if (full || r < n_rows) {
                         cs0 += v[0];
                         cs1 += v[1];
-                        *(pp_f32x2*)((char*)(Y + row0 * Q) + out_off + reg * Q * 4) = v;
+                        if (!(PP_WS_DBG & 2)) *(pp_f32x2*)((char*)(Y + row0 * Q) + out_off + reg * Q * 4) = v;
                     }
                 }
-                if (kEpi == 0 && r < n_rows) *(pp_f32x2*)(Y + r * Q + c0) = v;
+                if (kEpi == 0 && r < n_rows) {
+                    if (!(PP_WS_DBG & 2)) *(pp_f32x2*)(Y + r * Q + c0) = v;
+                    else if (v[0] == 1.2345e-30f) Y[r * Q + c0] = v[1];      // (keeps the value alive without a store that ever happens)
+                }
             }
         }
         cur = nxt;
