@@ -767,7 +767,7 @@ constexpr int kDb2HubStats = 8 + 2 * (64 + 1);        // index of the hub block 
 
 __global__ __launch_bounds__(kBlock) void k_db2_hub_classify(int64_t n, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ hp,
                                                             uint8_t* __restrict__ flag, uint32_t* __restrict__ hoff, uint32_t* __restrict__ oslot,
-                                                            uint32_t* __restrict__ tbase, int64_t* __restrict__ pbase, uint32_t* __restrict__ task_node,
+                                                            uint32_t* __restrict__ tbase, int64_t* __restrict__ pbase,
                                                             uint32_t* __restrict__ hub_list, int64_t* __restrict__ stats) {
     const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (b >= n) return;
@@ -781,7 +781,6 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub_classify(int64_t n, const ui
     const uint32_t t0 = (uint32_t)atomicAdd((unsigned long long*)&stats[2], (unsigned long long)ntask);
     tbase[b] = t0;
     pbase[b] = (int64_t)atomicAdd((unsigned long long*)&stats[3], (unsigned long long)(ntask * nrc));
-    for (int64_t k = 0; k < ntask; ++k) task_node[t0 + k] = (uint32_t)b;
     if (no > kWave) {           // ONE atomic for (index among the out-hubs, first event slot): both follow the same arrival order
         const unsigned long long old = atomicAdd((unsigned long long*)&stats[1], (1ull << 32) | (unsigned long long)no);
         oslot[b] = (uint32_t)(old >> 32);
@@ -789,6 +788,17 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub_classify(int64_t n, const ui
     }
     atomicMax((unsigned long long*)&stats[9], (unsigned long long)ni);
     atomicMax((unsigned long long*)&stats[10], (unsigned long long)no);
+}
+
+// task -> node, one workgroup per hub (a node with 2*10^6 in-events has 7 800 tasks: written by ONE thread of the classification they took 0.13 ms)
+__global__ __launch_bounds__(kBlock) void k_db2_hub_tasks(int64_t n_hubs, const uint32_t* __restrict__ hub_list, const uint32_t* __restrict__ hp,
+                                                         const uint32_t* __restrict__ tbase, uint32_t* __restrict__ task_node) {
+    if ((int64_t)blockIdx.x >= n_hubs) return;
+    const uint32_t b = hub_list[blockIdx.x];
+    const int64_t ni = (int64_t)hp[b + 1] - hp[b];
+    const int64_t ntask = ni > 0 ? ceil_div_dev(ni, kHubChunk) : 1;
+    const uint32_t t0 = tbase[b];
+    for (int64_t k = threadIdx.x; k < ntask; k += kBlock) task_node[t0 + k] = b;
 }
 
 // in-events of the hub nodes in (source, time) order: what k_db2_mid's count prologue gathers for the other nodes
@@ -1902,8 +1912,8 @@ static int db2_lists(const char* who, const int64_t* edge_index, const void* tim
     k_db2_rowptr<<<(unsigned)ceil_div(m + 1, kBlock), kBlock, 0, st>>>(w.hkeys_s, m, n, w.hp);
     PP_LAUNCH_CHECK();
     if (!part) {
-        k_db2_hub_classify<<<(unsigned)ceil_div(n, kBlock), kBlock, 0, st>>>(n, w.tp, w.hp, w.hub_flag, w.hoff, w.oslot, w.tbase, w.pbase, w.task_node,
-                                                                           w.hub_list, w.result + kDb2HubStats);
+        k_db2_hub_classify<<<(unsigned)ceil_div(n, kBlock), kBlock, 0, st>>>(n, w.tp, w.hp, w.hub_flag, w.hoff, w.oslot, w.tbase, w.pbase, w.hub_list,
+                                                                           w.result + kDb2HubStats);
         PP_LAUNCH_CHECK();
         if (host_stats) {
             PP_HIP(hipMemcpyAsync(host_stats, w.result + kDb2HubStats, kDb2HubStatCount * sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -1944,6 +1954,10 @@ static int db2_count(const char* who, int time_dtype, int64_t m, int64_t n, cons
     const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n_own > 0 ? n_own : 1, kWavesPerBlock * kDb2Nodes);
     const int key_bits = bits_for((uint64_t)(n > 0 ? n - 1 : 0));
     int rc;
+    if (hs.hubs > 0) {
+        k_db2_hub_tasks<<<(unsigned)hs.hubs, kBlock, 0, st>>>(hs.hubs, w.hub_list, w.hp, w.tbase, w.task_node);
+        PP_LAUNCH_CHECK();
+    }
     // 2'. out-hubs: their out-events in (successor, time) order by one sort over exactly those events
     if (hs.out_events > 0) {
         const unsigned hgrid = (unsigned)ceil_div(hs.out_events, kBlock);
