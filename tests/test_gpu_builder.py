@@ -232,6 +232,18 @@ def test_fused_builder_hub_nodes_delta_promotion_modes(delta):
     _compare(_build(ei, t, n, delta, None, True), _build(ei, t, n, delta, None, False), hubs=True)
 
 
+@pytest.mark.parametrize("kind", ["both", "dense"])
+@pytest.mark.parametrize("shift,scale,delta", [(-(2 ** 62), 1, 40), (2 ** 62, 1, 2 ** 40), (0, 2 ** 33, 40 * 2 ** 33), (0, 1, -3), (0, 1, 0)],
+                         ids=["at-int64-min", "huge-delta", "wide", "negative-delta", "zero-delta"])
+def test_fused_builder_hub_nodes_timestamps_anywhere_on_the_int64_axis(kind, shift, scale, delta):
+    """The hub kernels' window tests (ballot in registers, forward-only windows, the run-at-a-time scan) on the full 64-bit timestamps."""
+    ei, t, n = _hub_stream(kind)
+    t = t * scale + shift
+    _compare(_build(ei, t, n, delta, None, True), _build(ei, t, n, delta, None, False), hubs=True)
+    w = torch.from_numpy(np.random.default_rng(29).integers(1, 4, ei.size(1)).astype(np.float32))
+    _compare(_build(ei, t, n, delta, w, True), _build(ei, t, n, delta, w, False), hubs=True)
+
+
 def test_fused_builder_hub_nodes_float64_time_and_rows_beyond_512():
     """float64 timestamps through the bisection window test of the out-hubs; a delta that connects everything makes rows of several
     thousand entries (the chunk tables of the DBGNN row kernels must appear on both paths)."""
