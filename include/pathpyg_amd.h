@@ -87,9 +87,11 @@ int pp_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t
  * bipartite "last" index (utils/dbgnn.py:10-46) — node by node, without materialising the event graph, in three calls:
  *   pp_debruijn2_lists  the two sorts of the events (out-lists, in-lists), hub classification -> 16 int64 statistics copied to `host_stats`
  *                       (pinned host memory; the copy is asynchronous and followed by the out-side kernel of the ordinary nodes, so that
- *                       pp_debruijn2_lists_wait — the ONE call of this library that blocks — returns while the GPU is still busy);
- *   pp_debruijn2_count  everything up to the sizes (the first five int64 of ws), which the caller reads back;
- *   pp_debruijn2_fill   both plans.
+ *                       pp_debruijn2_wait — the ONE call of this library that blocks — returns while the GPU is still busy);
+ *   pp_debruijn2_count  everything up to the sizes (the first five int64 of ws).  `host_result` (pinned int64 [154], may be NULL): the whole result
+ *                       header is copied there asynchronously, the first size-independent kernel of the fill pass is queued behind the copy,
+ *                       pp_debruijn2_wait returns when the copy has landed (NULL: the caller reads the header from ws itself);
+ *   pp_debruijn2_fill   both plans (`rows_packed` = 1 when the count call was given a host_result).
  * Same inputs as pp_temporal_count (time-sorted events, delta as torch.tensor(delta) sees it); weight: NULL (every event weighs 1: the
  * reference's default torch.ones) or float32 [m].  Results are identical, array by array, to pp_coalesce_* (layer 1) -> pp_temporal_* ->
  * pp_coalesce_* (layer 2) -> pp_gcn_plan x 2 on the same stream (bit for bit where the partial sums are exact: see "hub nodes" in
@@ -118,18 +120,18 @@ size_t pp_debruijn2_ws_bytes(int64_t m, int64_t num_nodes);
 size_t pp_debruijn2_hub_ws_bytes(int64_t hub_out_events, int64_t out_hubs, int64_t hub_parts);
 int pp_debruijn2_lists(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, const float* weight, void* ws,
                        size_t ws_bytes, int64_t* host_stats, pp_stream_t stream);
-int pp_debruijn2_lists_wait(void);
+int pp_debruijn2_wait(void);
 int pp_debruijn2_count(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
                        int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
                        float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, int64_t hub_nodes, int64_t out_hubs, int64_t hub_out_events,
-                       int64_t hub_tasks, int64_t hub_parts, void* hub_ws, size_t hub_ws_bytes, pp_stream_t stream);
+                       int64_t hub_tasks, int64_t hub_parts, void* hub_ws, size_t hub_ws_bytes, int64_t* host_result, pp_stream_t stream);
 int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
                       const int32_t* fo_bwd_ptr, const int32_t* fo_bwd_idx, const float* fo_w, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr,
                       const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t num_ho_edges, int32_t* ho_fwd_idx, float* ho_fwd_val,
                       int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order,
                       float* fo_bwd_val, float* fo_self, float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, int64_t hub_nodes,
                       int64_t out_hubs, int64_t hub_out_events, int64_t hub_tasks, int64_t hub_parts, void* hub_ws, size_t hub_ws_bytes,
-                      pp_stream_t stream);
+                      int rows_packed, pp_stream_t stream);
 
 /* The same builder on ONE RANK of a node-range partition (the lift shards by edge range, the DBGNN by destination-node
  * partition; no reference counterpart — the reference is single-process).  Rank `rank` owns the first-order nodes

@@ -735,10 +735,11 @@ _tls = threading.local()
 
 
 def _pinned_stats() -> torch.Tensor:
-    """Pinned int64 [16] of the calling thread: where pp_debruijn2_lists copies the hub statistics (asynchronously)."""
+    """Pinned int64 [16 + 154] of the calling thread: where pp_debruijn2_lists copies the hub statistics ([:16]) and pp_debruijn2_count the
+    result header ([16:]), both asynchronously."""
     buf = getattr(_tls, "stats", None)
     if buf is None:
-        buf = _tls.stats = torch.empty(16, dtype=torch.int64).pin_memory()
+        buf = _tls.stats = torch.empty(16 + _HUB_STATS + 16, dtype=torch.int64).pin_memory()
     return buf
 
 
@@ -782,7 +783,7 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
         fo_bwd_idx, fo_w = torch.empty(m, **i32), torch.empty(m, **f32)
         ho_fwd_ptr, ho_bwd_ptr = torch.empty(m + 1, **i32), torch.empty(m + 1, **i32)
         ho_deg, fo_deg = torch.empty(m, **f32), torch.empty(n, **f32)
-        check(L.pp_debruijn2_lists_wait(), "pp_debruijn2_lists_wait")                         # read-back 1 of 2: is there a hub node, how large
+        check(L.pp_debruijn2_wait(), "pp_debruijn2_wait")                                     # read-back 1 of 2: is there a hub node, how large
         hubs, packed, tasks, parts = (int(v) for v in stats[:4].tolist())
         out_hubs, out_events = packed >> 32, packed & 0xFFFFFFFF
         hub_ws = None
@@ -792,15 +793,13 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
             hub_ws = _workspace(L.pp_debruijn2_hub_ws_bytes(out_events, out_hubs, parts), dev)
         hub_args = (hubs, out_hubs, out_events, tasks, parts, _p(hub_ws), hub_ws.numel() if hub_ws is not None else 0)
         check(L.pp_debruijn2_count(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_bwd_idx), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr),
-                                   _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), _p(ws), ws.numel(), *hub_args, _stream()), "pp_debruijn2_count")
-        if hubs:
-            head = ws[: 8 * (_HUB_STATS + 16)].view(torch.int64).tolist()                    # read-back 2 of 2: the layer sizes (+ the hubs' share)
-            u2, status, a2, e2, a1 = head[:5]
-            e2 += head[_HUB_STATS + 4]
-            longest = head[_HUB_STATS + 5: _HUB_STATS + 9]
-        else:
-            u2, status, a2, e2, a1 = ws[:40].view(torch.int64).tolist()
-            longest = (0, 0, 0, 0)
+                                   _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), _p(ws), ws.numel(), *hub_args, stats.data_ptr() + 128, _stream()),
+              "pp_debruijn2_count")
+        check(L.pp_debruijn2_wait(), "pp_debruijn2_wait")                                     # read-back 2 of 2: the layer sizes (+ the hubs' share)
+        head = stats[16:].tolist()
+        u2, status, a2, e2, a1 = head[:5]
+        e2 += head[_HUB_STATS + 4]
+        longest = head[_HUB_STATS + 5: _HUB_STATS + 9] if hubs else (0, 0, 0, 0)
         _bad_index(status, "MultiOrderModel.from_temporal_graph")
         if status & 2:
             if unsorted_ok:           # (the caller sorts and takes the generic path: MultiOrderModel.from_temporal_graph, multi_order_model.py:148-151)
@@ -821,7 +820,7 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
         check(L.pp_debruijn2_fill(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_bwd_idx), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr),
                                   _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), a2, _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx), _p(ho.bwd_val),
                                   _p(ho.self_coef), _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.dst_order), _p(fo.bwd_val), _p(fo.self_coef), _p(ho_fwd_w),
-                                  _p(torch.empty(2 * a2, **i32)), _p(ws), ws.numel(), *hub_args, _stream()),
+                                  _p(torch.empty(2 * a2, **i32)), _p(ws), ws.numel(), *hub_args, 1, _stream()),
               "pp_debruijn2_fill")
         # hub rows of the plans (more than 512 entries): the chunk tables of the row kernels' pre-pass, as pp_gcn_plan's report triggers them
         if longest[0] > HEAVY_ROW_ENTRIES:

@@ -311,6 +311,42 @@ __global__ __launch_bounds__(kBlock) void k_db2_out_fill(int64_t m, int64_t lo, 
     src_t[p] = r;
 }
 
+// one GPU: k_db2_out_heads + k_db2_out_fill in ONE pass over the list positions (same tail node, same row pointers, same ranks; round 5)
+__global__ __launch_bounds__(kBlock) void k_db2_out_ids(int64_t m, const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tkeys_s,
+                                                       const uint32_t* __restrict__ oc_s, const float* __restrict__ ow_s,
+                                                       const uint8_t* __restrict__ ocr_s, const uint64_t* __restrict__ ot_t,
+                                                       const uint8_t* __restrict__ ocr_t, const int32_t* __restrict__ row_ptr,
+                                                       int32_t* __restrict__ fo_bwd_idx, float* __restrict__ fo_w, Db2Src* __restrict__ src_t,
+                                                       const uint32_t* __restrict__ hoff, const uint32_t* __restrict__ rank_s,
+                                                       const uint32_t* __restrict__ rank_t) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m) return;
+    const uint32_t b = tkeys_s[p];
+    const uint32_t p0 = tp[b], cnt = tp[b + 1] - p0;
+    const uint32_t row0 = (uint32_t)row_ptr[b];
+    Db2Src r;
+    r.t = ot_t[p];
+    r.a = b;
+    r.u = 0xFFFFFFFFu;
+    if (cnt <= (uint32_t)kWave) {
+        const uint8_t cr = ocr_s[p];
+        if (p == p0 || ocr_s[p - 1] != cr) {               // head of a successor run: the first-order edge b -> c = order-2 node row0 + rank
+            fo_bwd_idx[row0 + cr] = (int32_t)oc_s[p];
+            fo_w[row0 + cr] = ow_s[p];
+        }
+        r.u = row0 + ocr_t[p];
+    } else if (rank_s != nullptr) {                        // out-hub: 32-bit ranks in the hub scratch
+        const uint32_t j = hoff[b] + ((uint32_t)p - p0);
+        const uint32_t cr = rank_s[j];
+        if (p == p0 || rank_s[j - 1] != cr) {
+            fo_bwd_idx[row0 + cr] = (int32_t)oc_s[p];
+            fo_w[row0 + cr] = ow_s[p];
+        }
+        r.u = row0 + rank_t[j];
+    }
+    src_t[p] = r;
+}
+
 // partition shards: the source-major rows of the first-order shard (sources: ALL nodes in the dense local order, destinations: owned nodes) are the
 // successor runs that fall into the owned range; coefficients d_b^-1/2 w d_c^-1/2 from the all-gathered degrees
 __global__ __launch_bounds__(kBlock) void k_db2_fo_part_bwd(int64_t m, int64_t lo, int64_t n_own, const uint32_t* __restrict__ tp,
@@ -1933,7 +1969,7 @@ static int db2_lists(const char* who, const int64_t* edge_index, const void* tim
 static int db2_count(const char* who, int time_dtype, int64_t m, int64_t n, const Db2Part& pt, int delta_kind, int64_t delta_i, double delta_f,
                      const float* weight, int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr,
                      int32_t* ho_bwd_ptr, float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, const Db2HubSizes& hs, void* hub_ws,
-                     size_t hub_ws_bytes, hipStream_t st) {
+                     size_t hub_ws_bytes, int64_t* host_result, hipStream_t st) {
     const bool part = pt.world > 1;
     const int64_t n_own = pt.n_own;
     PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "%s: negative size", who);
@@ -1995,7 +2031,8 @@ static int db2_count(const char* who, int time_dtype, int64_t m, int64_t n, cons
     if (rc != PP_OK) return rc;
     const int32_t* perm = nullptr;
     if (!part) {
-        k_db2_out_heads<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.oc_s, w.ow_s, w.ocr_s, fo_bwd_ptr, fo_bwd_idx, fo_w, hoff, rank_s);
+        k_db2_out_ids<<<egrid, kBlock, 0, st>>>(m, w.tp, w.tkeys_s, w.oc_s, w.ow_s, w.ocr_s, w.ot_t, w.ocr_t, fo_bwd_ptr, fo_bwd_idx, fo_w, w.src_t, hoff,
+                                               rank_s, rank_t);
         PP_LAUNCH_CHECK();
     } else {
         // 2b. local row order = send order (who gathers from my rows), one node-id sort of the successors
@@ -2022,8 +2059,10 @@ static int db2_count(const char* who, int time_dtype, int64_t m, int64_t n, cons
         k_db2_bip_fill<<<(unsigned)ceil_div(total, kBlock), kBlock, 0, st>>>(total, w.result, w.xkeys_s, m, pt.lo, n, n_pad, (void*)pt.bip_self, pt.bip_fwd_idx);
         PP_LAUNCH_CHECK();
     }
-    k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, fo_bwd_ptr, perm, w.src_t, hoff, rank_t);
-    PP_LAUNCH_CHECK();
+    if (part) {
+        k_db2_out_fill<<<egrid, kBlock, 0, st>>>(m, pt.lo, n_own, w.tp, w.tkeys_s, w.ot_t, w.ocr_t, fo_bwd_ptr, perm, w.src_t, hoff, rank_t);
+        PP_LAUNCH_CHECK();
+    }
     if (part) {          // (the halo numbering below reads the in-events; on one GPU the count pass gathers them itself)
         k_db2_gather_in<<<egrid, kBlock, 0, st>>>(m, w.hl, w.src_t, weight ? w.ow_t : nullptr, w.is_t, w.is_a, w.is_u, w.is_w);
         PP_LAUNCH_CHECK();
@@ -2071,13 +2110,26 @@ static int db2_count(const char* who, int time_dtype, int64_t m, int64_t n, cons
         k_db2_hub_combine<<<(unsigned)hs.hubs, kCombineWaves * kWave, 0, st>>>(hs.hubs, a, h);
         PP_LAUNCH_CHECK();
     }
-    rc = exclusive_scan<int32_t, int32_t>(w.nu, n_own, fo_fwd_ptr, true, w.result + 4, w.scratch, w.scratch_bytes, st);
+    // first-order in-row pointers, both order-2 row pointers and E2 = sum of the per-node pair counts: four scans, one launch triple
+    const int32_t* s_in[4] = {w.nu, w.indeg2, w.outdeg2, w.pc};
+    const int64_t s_n[4] = {n_own, m, m, n_own};
+    int32_t* s_out[4] = {fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, nullptr};
+    int64_t* s_tot[4] = {w.result + 4, w.result + 2, nullptr, w.result + 3};
+    PP_REQUIRE(scan_multi_ws_bytes(s_n, 4) <= w.scratch_bytes, PP_ERR_WORKSPACE, "%s: scan scratch too small", who);
+    rc = exclusive_scan_multi(s_in, s_n, s_out, s_tot, 4, w.scratch, w.scratch_bytes, st);
     if (rc != PP_OK) return rc;
-    rc = exclusive_scan<int32_t, int32_t>(w.indeg2, m, ho_fwd_ptr, true, w.result + 2, w.scratch, w.scratch_bytes, st);
-    if (rc != PP_OK) return rc;
-    rc = exclusive_scan<int32_t, int32_t>(w.outdeg2, m, ho_bwd_ptr, true, nullptr, w.scratch, w.scratch_bytes, st);
-    if (rc != PP_OK) return rc;
-    return exclusive_scan<int32_t, int64_t>(w.pc, n_own, w.pc_scan, true, w.result + 3, w.scratch, w.scratch_bytes, st);
+    if (host_result != nullptr) {
+        // the sizes travel to the caller's pinned buffer NOW; the first kernel of the fill pass that needs no size (degree^-1/2 + row start of every
+        // order-2 row, packed) is queued behind the copy and runs while the host wakes up and sizes the plans
+        PP_HIP(hipMemcpyAsync(host_result, w.result, kDb2Result * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        if (!tls_stats_event) PP_HIP(hipEventCreateWithFlags(&tls_stats_event, hipEventDisableTiming));
+        PP_HIP(hipEventRecord(tls_stats_event, st));
+        if (!part) {
+            k_db2_pack_rows<<<egrid, kBlock, 0, st>>>(m, ho_deg, ho_bwd_ptr, w.row_pack);
+            PP_LAUNCH_CHECK();
+        }
+    }
+    return PP_OK;
 }
 
 static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64_t lo, int64_t n_own, bool part, int delta_kind, int64_t delta_i,
@@ -2086,7 +2138,7 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
                     int32_t* ho_fwd_idx, float* ho_fwd_val, int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx,
                     float* fo_fwd_val, int32_t* fo_dst_order, const int32_t* fo2_bwd_ptr, int32_t* fo2_bwd_idx, float* fo_bwd_val, float* fo_self,
                     float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, const Db2HubSizes& hs, void* hub_ws, size_t hub_ws_bytes,
-                    hipStream_t st) {
+                    bool rows_packed, hipStream_t st) {
     PP_REQUIRE(m >= 0 && n >= 0, PP_ERR_ARG, "%s: negative size", who);
     Db2Ws w = carve_db2(ws, m, n);
     PP_REQUIRE(ws_bytes >= w.total_bytes, PP_ERR_WORKSPACE, "%s: workspace too small", who);
@@ -2096,8 +2148,10 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
     PP_REQUIRE(hs.hubs == 0 || (!part && hub_ws != nullptr && hub_ws_bytes >= hw.total_bytes), PP_ERR_WORKSPACE, "%s: hub workspace too small", who);
     const unsigned egrid = (unsigned)ceil_div(m, kBlock), ngrid = (unsigned)ceil_div(n_own, kWavesPerBlock * kDb2Nodes);
     PP_REQUIRE(num_ho_edges >= 0 && (num_ho_edges == 0 || pair_scratch != nullptr), PP_ERR_ARG, "%s: pair_scratch (8 bytes per order-2 edge) missing", who);
-    k_db2_pack_rows<<<egrid, kBlock, 0, st>>>(m, ho_deg, ho_bwd_ptr, w.row_pack);
-    PP_LAUNCH_CHECK();
+    if (!rows_packed) {                          // (one GPU: the count call queued it behind its size copy)
+        k_db2_pack_rows<<<egrid, kBlock, 0, st>>>(m, ho_deg, ho_bwd_ptr, w.row_pack);
+        PP_LAUNCH_CHECK();
+    }
     Db2Mid a{};
     mid_common(a, w, fo_bwd_ptr, weight != nullptr);
     a.lo = lo; a.n_own = n_own; a.part = part ? 1 : 0; a.perm = part ? w.perm : nullptr; a.hubs_handled = part ? 0 : 1;
@@ -2139,7 +2193,7 @@ int pp_debruijn2_lists(const int64_t* edge_index, const void* time, int time_dty
     return db2_lists("pp_debruijn2_lists", edge_index, time, time_dtype, m, num_nodes, whole, weight, ws, ws_bytes, host_stats, (hipStream_t)stream);
 }
 
-int pp_debruijn2_lists_wait(void) {
+int pp_debruijn2_wait(void) {
     if (tls_stats_event) PP_HIP(hipEventSynchronize(tls_stats_event));
     return PP_OK;
 }
@@ -2147,11 +2201,11 @@ int pp_debruijn2_lists_wait(void) {
 int pp_debruijn2_count(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
                        int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
                        float* ho_deg, float* fo_deg, void* ws, size_t ws_bytes, int64_t hub_nodes, int64_t out_hubs, int64_t hub_out_events,
-                       int64_t hub_tasks, int64_t hub_parts, void* hub_ws, size_t hub_ws_bytes, pp_stream_t stream) {
+                       int64_t hub_tasks, int64_t hub_parts, void* hub_ws, size_t hub_ws_bytes, int64_t* host_result, pp_stream_t stream) {
     const Db2Part whole{0, num_nodes, nullptr, 1, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     const Db2HubSizes hs{hub_nodes, out_hubs, hub_out_events, hub_tasks, hub_parts};
     return db2_count("pp_debruijn2_count", time_dtype, m, num_nodes, whole, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_bwd_idx, fo_w, fo_fwd_ptr,
-                     ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, hs, hub_ws, hub_ws_bytes, (hipStream_t)stream);
+                     ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, hs, hub_ws, hub_ws_bytes, host_result, (hipStream_t)stream);
 }
 
 int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
@@ -2160,12 +2214,12 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
                       int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val, int32_t* fo_dst_order,
                       float* fo_bwd_val, float* fo_self, float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, int64_t hub_nodes,
                       int64_t out_hubs, int64_t hub_out_events, int64_t hub_tasks, int64_t hub_parts, void* hub_ws, size_t hub_ws_bytes,
-                      pp_stream_t stream) {
+                      int rows_packed, pp_stream_t stream) {
     const Db2HubSizes hs{hub_nodes, out_hubs, hub_out_events, hub_tasks, hub_parts};
     return db2_fill("pp_debruijn2_fill", time_dtype, m, num_nodes, 0, num_nodes, false, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_bwd_idx, fo_w,
                     fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_fwd_idx,
                     fo_fwd_val, fo_dst_order, nullptr, nullptr, fo_bwd_val, fo_self, ho_fwd_w, pair_scratch, ws, ws_bytes, hs, hub_ws, hub_ws_bytes,
-                    (hipStream_t)stream);
+                    rows_packed != 0, (hipStream_t)stream);
 }
 
 int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
@@ -2182,7 +2236,7 @@ int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int tim
     if (rc != PP_OK) return rc;
     const Db2HubSizes none{0, 0, 0, 0, 0};
     return db2_count("pp_debruijn2_part_count", time_dtype, m, num_nodes, pt, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_bwd_idx, fo_w,
-                     fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, none, nullptr, 0, (hipStream_t)stream);
+                     fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, ws, ws_bytes, none, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
 int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own, int delta_kind, int64_t delta_i, double delta_f,
@@ -2195,7 +2249,7 @@ int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t
     return db2_fill("pp_debruijn2_part_fill", time_dtype, m, num_nodes, node_lo, n_own, true, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, nullptr, nullptr,
                     fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr, ho_deg, fo_deg, num_ho_edges, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_fwd_idx,
                     fo_fwd_val, nullptr, fo_shard_bwd_ptr, fo_shard_bwd_idx, fo_shard_bwd_val, fo_self, nullptr, pair_scratch, ws, ws_bytes, none, nullptr, 0,
-                    (hipStream_t)stream);
+                    false, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -16,6 +16,21 @@ size_t scan_ws_bytes(int64_t n);
 template <typename InT, typename OutT>
 int exclusive_scan(const InT* in, int64_t n, OutT* out, bool with_total, int64_t* total_dev, void* ws, size_t ws_bytes,
                    hipStream_t st, int64_t* slot_owner = nullptr, int64_t slot_stride = 1, int64_t slot_cap = 0);
+// several int32 -> int32 exclusive scans (out[j] has n[j] + 1 entries; nullptr: reduction only) in one launch triple
+constexpr int kScanMaxJobs = 4;
+struct ScanJob {
+    const int32_t* in;
+    int32_t* out;
+    int64_t n, tile0;
+    int64_t *total, *tile_sum;
+};
+struct ScanJobs {
+    ScanJob job[kScanMaxJobs];
+    int count;
+};
+size_t scan_multi_ws_bytes(const int64_t* n, int count);
+int exclusive_scan_multi(const int32_t* const* in, const int64_t* n, int32_t* const* out, int64_t* const* total_dev, int count, void* ws,
+                         size_t ws_bytes, hipStream_t st);
 template <typename IdxT>
 int histogram(const IdxT* idx, int64_t n, int64_t nbins, int32_t* bins, hipStream_t st);
 int minmax_i64(const int64_t* a, int64_t n, int64_t* out2, hipStream_t st);

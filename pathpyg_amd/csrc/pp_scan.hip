@@ -4,7 +4,7 @@
 //   torch_geometric.utils.cumsum / degree   (reference src/pathpyG/algorithms/lift_order.py:65,74,77)
 // All of them are pure HBM streams: 16-byte loads per lane, wave shuffles for the
 // intra-wave step, LDS only for the 4 per-wave partials of a 256-thread workgroup.
-#include "pp_common.h"
+#include "pp_internal.h"
 
 #include <stdarg.h>
 
@@ -20,6 +20,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+size_t scan_ws_bytes(int64_t n);
 constexpr int kScanItems = 8;                       // consecutive items per thread
 constexpr int kScanTile = kBlock * kScanItems;      // 2048 items per workgroup
 
@@ -139,6 +140,128 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(const InT* __restrict__ i
         run += v[k];
         if (write_total && i == n - 1) out[n] = (OutT)run;   // out has n+1 entries
     }
+}
+
+// ---- several int32 -> int32 scans in ONE launch triple (round 5: the order-2 builder ends its count pass with four scans back to back; at the
+// sizes of a partition rank every launch costs its floor).  A job with `out == nullptr` is a reduction only (its total).
+__global__ __launch_bounds__(kBlock) void k_tile_sums_multi(ScanJobs js) {
+    __shared__ int64_t part[kWavesPerBlock];
+    int j = 0;
+    while (j + 1 < js.count && (int64_t)blockIdx.x >= js.job[j + 1].tile0) ++j;
+    const ScanJob& job = js.job[j];
+    const int64_t tile = (int64_t)blockIdx.x - job.tile0;
+    const int64_t base = tile * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int64_t v[kScanItems];
+    load_items<int32_t>(job.in, base, job.n, ((uintptr_t)job.in & 15) == 0, v);
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) s += v[k];
+    s = wave_sum(s);
+    if (lane_id() == 0) part[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) t += part[w];
+        job.tile_sum[tile] = t;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_tile_sums_multi(ScanJobs js) {
+    __shared__ int64_t scratch[kWavesPerBlock + 1];
+    const ScanJob& job = js.job[blockIdx.x];
+    const int64_t ntiles = (job.n + kScanTile - 1) / kScanTile;
+    const int64_t per_thread = (ntiles + kBlock - 1) / kBlock;
+    const int64_t begin = (int64_t)threadIdx.x * per_thread;
+    const int64_t end = begin + per_thread < ntiles ? begin + per_thread : ntiles;
+    int64_t sum = 0;
+    for (int64_t i = begin; i < end; ++i) sum += job.tile_sum[i];
+    int64_t tot;
+    int64_t run = block_exclusive_sum(sum, scratch, &tot);
+    for (int64_t i = begin; i < end; ++i) {
+        const int64_t c = job.tile_sum[i];
+        job.tile_sum[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 0 && job.total) *job.total = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_tiles_multi(ScanJobs js) {
+    __shared__ int64_t scratch[kWavesPerBlock + 1];
+    int j = 0;
+    while (j + 1 < js.count && (int64_t)blockIdx.x >= js.job[j + 1].tile0) ++j;
+    const ScanJob& job = js.job[j];
+    if (job.out == nullptr) return;                        // (reduction only; uniform per workgroup)
+    const int64_t tile = (int64_t)blockIdx.x - job.tile0;
+    const int64_t n = job.n;
+    const int64_t base = tile * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int64_t v[kScanItems];
+    load_items<int32_t>(job.in, base, n, ((uintptr_t)job.in & 15) == 0, v);
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) s += v[k];
+    int64_t tot;
+    int64_t run = job.tile_sum[tile] + block_exclusive_sum(s, scratch, &tot);
+    int32_t* out = job.out;
+    if (base + kScanItems < n && ((uintptr_t)out & 15) == 0) {
+        struct alignas(16) Chunk { int32_t x[4]; };
+#pragma unroll
+        for (int c = 0; c < kScanItems / 4; ++c) {
+            Chunk ch;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ch.x[e] = (int32_t)run;
+                run += v[c * 4 + e];
+            }
+            *reinterpret_cast<Chunk*>(out + base + c * 4) = ch;
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = base + k;
+        if (i < n) out[i] = (int32_t)run;
+        run += v[k];
+        if (i == n - 1) out[n] = (int32_t)run;             // out has n + 1 entries
+    }
+}
+
+size_t scan_multi_ws_bytes(const int64_t* n, int count) {
+    size_t total = 0;
+    for (int j = 0; j < count; ++j) total += scan_ws_bytes(n[j]);
+    return total;
+}
+
+// out[j][i] = sum(in[j][0..i)), i in [0, n_j]; total_dev[j] optional (int64); out[j] == nullptr: only the total.  Empty jobs are written here.
+int exclusive_scan_multi(const int32_t* const* in, const int64_t* n, int32_t* const* out, int64_t* const* total_dev, int count, void* ws,
+                         size_t ws_bytes, hipStream_t st) {
+    PP_REQUIRE(count >= 1 && count <= kScanMaxJobs, PP_ERR_ARG, "exclusive_scan_multi: 1..%d jobs", kScanMaxJobs);
+    ScanJobs js{};
+    Arena a(ws, ws_bytes);
+    int64_t tiles = 0;
+    for (int j = 0; j < count; ++j) {
+        PP_REQUIRE(n[j] >= 0, PP_ERR_ARG, "exclusive_scan_multi: negative length");
+        if (n[j] == 0) {
+            if (out[j]) PP_HIP(hipMemsetAsync(out[j], 0, sizeof(int32_t), st));
+            if (total_dev[j]) PP_HIP(hipMemsetAsync(total_dev[j], 0, sizeof(int64_t), st));
+            continue;
+        }
+        ScanJob& job = js.job[js.count++];
+        job.in = in[j]; job.out = out[j]; job.n = n[j]; job.total = total_dev[j];
+        job.tile0 = tiles;
+        const int64_t nt = ceil_div(n[j], kScanTile);
+        job.tile_sum = a.take<int64_t>(nt + 1);
+        tiles += nt;
+    }
+    PP_REQUIRE(a.ok(), PP_ERR_WORKSPACE, "exclusive_scan_multi: workspace too small");
+    if (js.count == 0) return PP_OK;
+    k_tile_sums_multi<<<(unsigned)tiles, kBlock, 0, st>>>(js);
+    PP_LAUNCH_CHECK();
+    k_scan_tile_sums_multi<<<(unsigned)js.count, kBlock, 0, st>>>(js);
+    PP_LAUNCH_CHECK();
+    k_scan_tiles_multi<<<(unsigned)tiles, kBlock, 0, st>>>(js);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
 }
 
 size_t scan_ws_bytes(int64_t n) { return align_up((size_t)(ceil_div(n > 0 ? n : 1, kScanTile) + 1) * sizeof(int64_t)); }
