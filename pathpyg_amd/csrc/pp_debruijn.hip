@@ -768,20 +768,19 @@ __global__ __launch_bounds__(kBlock) void k_db2_mid(int64_t n, int64_t delta_i, 
 //   k_db2_hub_out_*      out-events of the out-hubs in (successor, time) order by ONE radix sort of (slice, successor) keys over exactly
 //                        those events (the list sequence is in time order and the sort is stable), then run heads -> scan -> 32-bit
 //                        successor ranks, run starts, block sizes, merged first-order weights — what k_db2_out does in registers.
-//   k_db2_hub            the middle-node pass of one task.  LANES ARE SUCCESSOR RUNS (64 per round; a node with more runs takes several rounds
-//                        over its in-chunk), in-events are walked one by one.  Continuations of in-event i inside run r: with at most 64
-//                        out-events the window ballot over the out-events in registers, popcount against the run's lane mask (as k_db2_mid);
-//                        with more, two bisections over the run's times (it is sorted by time) for the window t_i < t <= t_i + delta.
+//   k_db2_hub            the middle-node pass of one task of a node with at most 64 out-events.  LANES ARE SUCCESSOR RUNS, in-events are walked
+//                        one by one: the window ballot over the out-events in registers, popcount against the run's lane mask (as k_db2_mid).
 //                        At the end of an in-run (a, b): ballot of the runs it reached = its out-degree / its source-major row, every
 //                        reached run takes one more entry of its destination-major row.  A run that starts in the chunk is finished by this
 //                        task however far it reaches; a chunk that starts inside a run skips to its end (bisection: sources ascend).
+//   k_db2_hubx           the same for a node with MORE than 64 out-events, an in-run at a time (see there).
 //                        Count pass: per task and run the number of entries, the weighted-degree share and the self-loop weight (a part
 //                        column of 64 lanes); k_db2_hub_combine turns them into in-degrees, degrees and EXCLUSIVE prefixes per task, in task
 //                        order (fixed summation order, bit-reproducible); the fill pass starts every row at its task's prefix.
 // Sums: in-run weights and degrees are summed in (in-event, task) order — identical to the one-wave kernels and the generic path whenever
 // the partial sums are exactly representable (unit and integer-valued weights below 2^24), a different association of the same fp32 terms
-// otherwise (as the chunked reduction of long runs in pp_coalesce_*); with more than 64 out-events an in-event's weight enters as
-// w * (number of continuations) instead of by repeated addition.
+// otherwise (as the chunked reduction of long runs in pp_coalesce_*); with more than 64 out-events a merged weight is the sum, over the
+// successor's out-events in time order, of the weights of the instances each continues.
 struct Db2Hub {
     const uint8_t* flag;             // [n] kHubOut | kHubIn
     const uint32_t *hoff, *oslot;    // [n] out-hubs: first slot of the out-hub scratch, index among the out-hubs
@@ -942,13 +941,12 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
     if (task >= n_tasks) return;
     const int l = lane_id();
     const uint32_t b = h.task_node[task];
-    if (!kW && (h.flag[b] & kHubOut)) return;                      // (unit weights: k_db2_hubx takes the out-hubs run by run)
+    if (h.flag[b] & kHubOut) return;                               // (more than 64 out-events: k_db2_hubx takes the node run by run)
     const int64_t k = task - (int64_t)h.tbase[b];
     const uint32_t p0 = a.tp[b], q0 = a.hp[b];
     const int64_t no = (int64_t)a.tp[b + 1] - p0, ni = (int64_t)a.hp[b + 1] - q0;
     const int32_t row0 = a.row_ptr[b];
     const int64_t R = (int64_t)a.row_ptr[b + 1] - row0;                                  // successor runs = order-2 rows (b, .)
-    const bool oh = no > kWave;
     const int64_t rounds = R > 0 ? (R + kWave - 1) / kWave : 1;
     const int64_t nrc = no > 0 ? ((no < h.num_nodes ? no : h.num_nodes) + kWave - 1) / kWave : 1;      // part columns per task (k_db2_hub_classify)
     const int64_t part0 = h.pbase[b] + k * nrc;
@@ -959,13 +957,11 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
         const uint32_t prev = a.is_a[qa - 1];
         if (a.is_a[qa] == prev) qa = upper_bound_dev<uint32_t, int64_t>(a.is_a, qa, qend, prev);
     }
-    // out-events in registers when they fit: lanes = out-events in (successor, time) order for the window ballot, lane r also = run r
-    bool lo_ = false;
+    // the (at most 64) out-events in registers: lanes = out-events in (successor, time) order for the window ballot, lane r also = run r
     uint64_t runmask = 0ull;
-    TimeT tj = TimeT(0);
-    if (!oh) {
-        lo_ = l < no;
-        tj = time_of<TimeT>(lo_ ? a.ot_s[p0 + l] : 0ull);
+    const bool lo_ = l < no;
+    const TimeT tj = time_of<TimeT>(lo_ ? a.ot_s[p0 + l] : 0ull);
+    {
         const int cr = lo_ ? (int)a.ocr_s[p0 + l] : 255;
         const int prevcr = __shfl_up(cr, 1, kWave);
         const uint64_t ohm = __ballot(lo_ && (l == 0 || cr != prevcr));
@@ -978,7 +974,6 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
             runmask = (re >= kWave ? ~0ull : lanes_below(re)) & ~lanes_below(rs);
         }
     }
-    const uint32_t* rsb = oh ? h.run_start + (h.hoff[b] + h.oslot[b]) : nullptr;
     const float d1b = kFill ? inv_sqrt_deg(a.fo_deg[b]) : 0.0f;
     const int32_t fp = kFill ? a.fo_fwd_ptr[b] + h.task_runbase[task] : 0;
     if (kFill && k == 0 && l == 0 && a.self1) a.self1[b] = d1b * a.fo_lw[b] * d1b;
@@ -990,8 +985,6 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
         const int64_t rr = c * kWave + l;
         const bool valid = rr < R;
         const uint32_t v = (uint32_t)(row0 + rr);
-        int64_t rs = 0, re = 0;
-        if (oh && valid) { rs = (int64_t)p0 + rsb[rr]; re = (int64_t)p0 + rsb[rr + 1]; }
         int cnt = 0;
         float deg = 0.0f, lw = -1.0f, dv = 0.0f;
         int32_t ip = 0;
@@ -1013,9 +1006,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
         int ord = -1, hits = 0;
         float facc = 0.0f, w1run = 0.0f, du_r = 0.0f, da_r = 0.0f;
         int32_t ob_r = 0;
-        bool open = false, stop = qa >= qend, fresh = true;
-        int64_t wlo = 0, whi = 0;                                    // more than 64 out-events: this lane's window into its run, see below
-        uint64_t tlo = 0ull, thi = 0ull;
+        bool open = false, stop = qa >= qend;
         for (int64_t qq = qa; !stop; qq += kWave) {
             const int64_t q = qq + l;
             const bool li = q < qend;
@@ -1087,79 +1078,16 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
                     cur_u = rl_u(su, z);
                     ++ord;
                     hits = 0; facc = 0.0f; w1run = 0.0f;
-                    fresh = true;
                     if (kFill) { du_r = rl_f(du_l, z); da_r = rl_f(da_l, z); ob_r = rl_i(ob_l, z); }
                 }
                 const TimeT ti = time_of<TimeT>(rl_u64(sti, z));
                 const typename W::Thr thr = W::threshold(ti, delta_i, delta_f);
-                int ci = 0;
-                if (!oh) {
-                    const uint64_t win = __ballot(lo_ && tj > ti && W::admits(tj, thr));
-                    ci = (int)__popcll(win & runmask);
-                    if (kW) {
-                        const float wz = rl_f(swi, z);
-                        for (int x = 0; x < ci; ++x) facc += wz;      // as k_db2_mid: instance pairs in lexicographic order carry the weight of their source event
-                        w1run += wz;
-                    }
-                } else {
-                    if (valid) {
-                        // window [wlo, whi) of the run's out-events continuing in-event i.  Inside an in-run the timestamps ascend, so both ends
-                        // only move forward: a few single steps from where the previous instance left them (their timestamps sit in
-                        // registers: no load at all when nothing moves), a bisection over the rest when that is not enough or the in-run
-                        // has just begun
-                        if (fresh) {
-                            int64_t lo = rs, hi = re;
-                            while (lo < hi) {                         // first out-event of the run later than t_i
-                                const int64_t mid = lo + ((hi - lo) >> 1);
-                                if (time_of<TimeT>(a.ot_s[mid]) > ti) hi = mid; else lo = mid + 1;
-                            }
-                            wlo = lo;
-                            hi = re;
-                            while (lo < hi) {                         // first one beyond the window
-                                const int64_t mid = lo + ((hi - lo) >> 1);
-                                if (!W::admits(time_of<TimeT>(a.ot_s[mid]), thr)) hi = mid; else lo = mid + 1;
-                            }
-                            whi = lo;
-                            tlo = wlo < re ? a.ot_s[wlo] : 0ull;
-                            thi = whi < re ? a.ot_s[whi] : 0ull;
-                        } else {
-                            for (int step = 0; wlo < re && !(time_of<TimeT>(tlo) > ti); ++step) {
-                                if (step == 4) {
-                                    int64_t lo = wlo, hi = re;
-                                    while (lo < hi) {
-                                        const int64_t mid = lo + ((hi - lo) >> 1);
-                                        if (time_of<TimeT>(a.ot_s[mid]) > ti) hi = mid; else lo = mid + 1;
-                                    }
-                                    wlo = lo;
-                                    tlo = wlo < re ? a.ot_s[wlo] : 0ull;
-                                    break;
-                                }
-                                ++wlo;
-                                tlo = wlo < re ? a.ot_s[wlo] : 0ull;
-                            }
-                            for (int step = 0; whi < re && W::admits(time_of<TimeT>(thi), thr); ++step) {
-                                if (step == 4) {
-                                    int64_t lo = whi, hi = re;
-                                    while (lo < hi) {
-                                        const int64_t mid = lo + ((hi - lo) >> 1);
-                                        if (!W::admits(time_of<TimeT>(a.ot_s[mid]), thr)) hi = mid; else lo = mid + 1;
-                                    }
-                                    whi = lo;
-                                    thi = whi < re ? a.ot_s[whi] : 0ull;
-                                    break;
-                                }
-                                ++whi;
-                                thi = whi < re ? a.ot_s[whi] : 0ull;
-                            }
-                        }
-                        ci = whi > wlo ? (int)(whi - wlo) : 0;
-                    }
-                    fresh = false;
-                    if (kW) {
-                        const float wz = rl_f(swi, z);
-                        facc = __fadd_rn(facc, __fmul_rn(wz, (float)ci));
-                        w1run += wz;
-                    }
+                const uint64_t win = __ballot(lo_ && tj > ti && W::admits(tj, thr));
+                const int ci = (int)__popcll(win & runmask);
+                if (kW) {
+                    const float wz = rl_f(swi, z);
+                    for (int x = 0; x < ci; ++x) facc += wz;          // as k_db2_mid: instance pairs in lexicographic order carry the weight of their source event
+                    w1run += wz;
                 }
                 if (!kW) w1run += 1.0f;
                 hits += ci;
@@ -1187,9 +1115,9 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
     }
 }
 
-// OUT-HUBS WITH UNIT WEIGHTS, run at a time (round 5): the middle-node pass of k_db2_hub for nodes with more than 64 out-events when every
-// event weighs 1 — the shape of the reference's documented contact streams (tens of nodes, 10^4 events per node and side).  k_db2_hub walks
-// the in-events one by one and each lane chases its own run of out-events through memory: one dependent load per step.  Here an in-run
+// OUT-HUBS, run at a time (round 5): the middle-node pass for nodes with more than 64 out-events — the shape of the reference's documented
+// contact streams (tens of nodes, 10^4 events per node and side).  Walking the in-events one by one with each lane chasing its own run of
+// out-events through memory costs one dependent load per step (the first form of this round: 26 ms on such a stream).  Here an in-run
 // (a, b) is taken as a whole: its instance times go to LDS (pieces of 512), the out-events of b between the first instance's window start and
 // the last instance's window end are streamed ONCE in time order (coalesced: timestamp + 32-bit successor rank), and every out-event counts
 // the instances it continues by two bisections over the LDS times (t_i < t_j and t_j <= t_i + delta are monotone in t_i) and adds that count
@@ -1203,12 +1131,18 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
 #endif
 constexpr int kHubxRuns = PP_HUBX_RUNS, kHubxInst = 512, kHubxCols = kHubxRuns / kWave;
 
-template <typename TimeT, int kMode, bool kFill>
+template <typename TimeT, int kMode, bool kFill, bool kW>
 __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t delta_i, double delta_f, Db2Mid a, Db2Hub h, const uint64_t* __restrict__ ot_t,
                                                     const uint32_t* __restrict__ rank_t) {
     using W = Window<TimeT, kMode>;
     __shared__ uint32_t s_hist[kWavesPerBlock][kHubxRuns];
     __shared__ uint64_t s_time[kWavesPerBlock][kHubxInst];
+    // weighted streams: the instance weights beside their times, and a second histogram of the weight sums (fp32 LDS atomics of ONE wave:
+    // the order is the scan's — out-events in time order, lanes ascending — the same on every run)
+    __shared__ float s_wt[kWavesPerBlock][kW ? kHubxInst : 1];
+    __shared__ float s_histw[kWavesPerBlock][kW ? kHubxRuns : 1];
+    float* wts = s_wt[wave_id()];
+    float* histw = s_histw[wave_id()];
     const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
     if (task >= n_tasks) return;
     const uint32_t b = h.task_node[task];
@@ -1232,7 +1166,10 @@ __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t de
     }
     const uint64_t* otb = ot_t + p0;                              // out-events of b in time order
     const uint32_t* rkb = rank_t + h.hoff[b];                     // their successor ranks
-    for (int i = l; i < kHubxRuns; i += kWave) hist[i] = 0u;
+    for (int i = l; i < kHubxRuns; i += kWave) {
+        hist[i] = 0u;
+        if (kW) histw[i] = 0.0f;
+    }
     const float d1b = kFill ? inv_sqrt_deg(a.fo_deg[b]) : 0.0f;
     const int32_t fp = kFill ? a.fo_fwd_ptr[b] + h.task_runbase[task] : 0;
     if (kFill && k == 0 && l == 0 && a.self1) a.self1[b] = d1b * a.fo_lw[b] * d1b;
@@ -1279,6 +1216,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t de
             }
             int64_t qp = q;
             bool run_done = false;
+            float w1sum = 0.0f;                                       // weighted: the run's first-order weight (sum of its instances)
             while (!run_done) {
                 // ---- one piece: up to kHubxInst instance times of the run -> LDS
                 int got = 0;
@@ -1287,11 +1225,16 @@ __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t de
                     const bool li = qx < qend;
                     const uint32_t sa = li ? a.is_a[qx] : 0xFFFFFFFFu;
                     const uint64_t st_ = li ? a.is_t[qx] : 0ull;
+                    const float sw_ = (kW && li) ? a.is_w[qx] : 0.0f;
                     const uint64_t mism = __ballot(!li || sa != cur_a);
                     const int upto = mism ? __ffsll((long long)mism) - 1 : kWave;
                     const int room = kHubxInst - got;
                     const int take = upto < room ? upto : room;
-                    if (l < take) tms[got + l] = st_;
+                    if (l < take) {
+                        tms[got + l] = st_;
+                        if (kW) wts[got + l] = sw_;
+                    }
+                    if (kW) w1sum += wave_sum(l < take ? sw_ : 0.0f);
                     got += take;
                     if (upto < kWave && upto <= room) { run_done = true; break; }
                     if (take < kWave) break;                          // the piece is full
@@ -1350,14 +1293,18 @@ __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t de
                             if (!(t_plo < tl)) continue;                  // the next open instance begins after the batch
                             const TimeT tj = time_of<TimeT>(tb);
                             int c = 0;
+                            float wsum = 0.0f;
                             for (int ii = plo; ii < ninst; ++ii) {
                                 const TimeT ti = time_of<TimeT>(tms[ii]);
                                 if (!(ti < tl)) break;
-                                c += (ti < tj && W::admits(tj, W::threshold(ti, delta_i, delta_f))) ? 1 : 0;
+                                const bool hit = ti < tj && W::admits(tj, W::threshold(ti, delta_i, delta_f));
+                                c += hit ? 1 : 0;
+                                if (kW) wsum += hit ? wts[ii] : 0.0f;
                             }
                             const uint32_t rk = rkq[x] - (uint32_t)rbase;
                             if (c > 0 && j0 + l < g1 && rk < (uint32_t)kHubxRuns) {
                                 atomicAdd(&hist[rk], (uint32_t)c);
+                                if (kW) atomicAdd(&histw[rk], wsum);
                                 pairs += c;
                             }
                         }
@@ -1367,7 +1314,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t de
                 __builtin_amdgcn_wave_barrier();
             }
             const int64_t ninst_run = qp - q;
-            const float w1run = (float)ninst_run;
+            const float w1run = kW ? w1sum : (float)ninst_run;
             // ---- epilogue of in-run (cur_a, b) = order-2 node cur_u, one 64-run column after the other (ascending successor)
             const int slot = ord >> 6, olane = ord & (kWave - 1);
 #pragma unroll
@@ -1378,7 +1325,11 @@ __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t de
                     const uint32_t v = (uint32_t)(row0 + rr);
                     const int hits = (int)hist[cc * kWave + l];
                     hist[cc * kWave + l] = 0u;
-                    const float wgt = (float)hits;
+                    float wgt = (float)hits;
+                    if (kW) {
+                        wgt = histw[cc * kWave + l];
+                        histw[cc * kWave + l] = 0.0f;
+                    }
                     const bool emit = valid && hits > 0;
                     const uint64_t em = __ballot(emit);
                     const int reached = (int)__popcll(em);
@@ -1833,14 +1784,21 @@ static void launch_hub(bool weighted, unsigned grid, hipStream_t st, int64_t tas
     else k_db2_hub<TimeT, kMode, kFill, false><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h);
 }
 
+template <typename TimeT, int kMode, bool kFill>
+static void launch_hubx(bool weighted, unsigned grid, hipStream_t st, int64_t tasks, int64_t di, double df, const Db2Mid& a, const Db2Hub& h,
+                        const uint64_t* ot_t, const uint32_t* rank_t) {
+    if (weighted) k_db2_hubx<TimeT, kMode, kFill, true><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h, ot_t, rank_t);
+    else k_db2_hubx<TimeT, kMode, kFill, false><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h, ot_t, rank_t);
+}
+
 template <bool kFill>
-static int launch_hubx_any(int time_dtype, int delta_kind, hipStream_t st, int64_t tasks, int64_t di, double df, const Db2Mid& a, const Db2Hub& h,
-                           const uint64_t* ot_t, const uint32_t* rank_t) {
+static int launch_hubx_any(int time_dtype, int delta_kind, bool weighted, hipStream_t st, int64_t tasks, int64_t di, double df, const Db2Mid& a,
+                           const Db2Hub& h, const uint64_t* ot_t, const uint32_t* rank_t) {
     const unsigned grid = (unsigned)ceil_div(tasks, kWavesPerBlock);
-    if (time_dtype == PP_F64) k_db2_hubx<double, 0, kFill><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h, ot_t, rank_t);
-    else if (delta_kind == PP_DELTA_I64) k_db2_hubx<int64_t, 0, kFill><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h, ot_t, rank_t);
-    else if (delta_kind == PP_DELTA_F32) k_db2_hubx<int64_t, 1, kFill><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h, ot_t, rank_t);
-    else k_db2_hubx<int64_t, 2, kFill><<<grid, kBlock, 0, st>>>(tasks, di, df, a, h, ot_t, rank_t);
+    if (time_dtype == PP_F64) launch_hubx<double, 0, kFill>(weighted, grid, st, tasks, di, df, a, h, ot_t, rank_t);
+    else if (delta_kind == PP_DELTA_I64) launch_hubx<int64_t, 0, kFill>(weighted, grid, st, tasks, di, df, a, h, ot_t, rank_t);
+    else if (delta_kind == PP_DELTA_F32) launch_hubx<int64_t, 1, kFill>(weighted, grid, st, tasks, di, df, a, h, ot_t, rank_t);
+    else launch_hubx<int64_t, 2, kFill>(weighted, grid, st, tasks, di, df, a, h, ot_t, rank_t);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
@@ -2103,8 +2061,8 @@ static int db2_count(const char* who, int time_dtype, int64_t m, int64_t n, cons
         a.hl = nullptr;
         rc = launch_hub_any<false>(time_dtype, delta_kind, weight != nullptr, st, hs.tasks, delta_i, delta_f, a, h);
         if (rc != PP_OK) return rc;
-        if (hs.out_events > 0 && weight == nullptr) {
-            rc = launch_hubx_any<false>(time_dtype, delta_kind, st, hs.tasks, delta_i, delta_f, a, h, w.ot_t, hw.rank_t);
+        if (hs.out_events > 0) {
+            rc = launch_hubx_any<false>(time_dtype, delta_kind, weight != nullptr, st, hs.tasks, delta_i, delta_f, a, h, w.ot_t, hw.rank_t);
             if (rc != PP_OK) return rc;
         }
         k_db2_hub_combine<<<(unsigned)hs.hubs, kCombineWaves * kWave, 0, st>>>(hs.hubs, a, h);
@@ -2169,8 +2127,8 @@ static int db2_fill(const char* who, int time_dtype, int64_t m, int64_t n, int64
         h.succ = fo_bwd_idx;
         rc = launch_hub_any<true>(time_dtype, delta_kind, weight != nullptr, st, hs.tasks, delta_i, delta_f, a, h);
         if (rc != PP_OK) return rc;
-        if (hs.out_events > 0 && weight == nullptr) {
-            rc = launch_hubx_any<true>(time_dtype, delta_kind, st, hs.tasks, delta_i, delta_f, a, h, w.ot_t, hw.rank_t);
+        if (hs.out_events > 0) {
+            rc = launch_hubx_any<true>(time_dtype, delta_kind, weight != nullptr, st, hs.tasks, delta_i, delta_f, a, h, w.ot_t, hw.rank_t);
             if (rc != PP_OK) return rc;
         }
     }

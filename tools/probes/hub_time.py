@@ -15,12 +15,14 @@ n, m, span = 96, 2_000_000, 2_000_000
 ei = torch.randint(0, n, (2, m), generator=g, device=dev)
 t = torch.randint(0, span, (m,), generator=g, device=dev)
 tg = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=n))
-for delta in (30, 300):
-    for _ in range(2):
-        _hip.debruijn2(tg.data.edge_index, tg.data.time, n, delta, None)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        b = _hip.debruijn2(tg.data.edge_index, tg.data.time, n, delta, None)
-    torch.cuda.synchronize()
-    print(f"delta={delta}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms  E2={b.sizes['E2']}")
+w = torch.rand(m, generator=g, device=dev) + 0.25
+for weight in (None, w):
+    for delta in (30, 300):
+        for _ in range(2):
+            _hip.debruijn2(tg.data.edge_index, tg.data.time, n, delta, weight)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            b = _hip.debruijn2(tg.data.edge_index, tg.data.time, n, delta, weight)
+        torch.cuda.synchronize()
+        print(f"{'unit weights' if weight is None else 'float32 weights'}, delta={delta}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms  E2={b.sizes['E2']}")
