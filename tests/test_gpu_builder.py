@@ -274,3 +274,19 @@ def test_fused_builder_config1_size_equals_generic_path():
     ei = torch.randint(0, n, (2, m), generator=gen)
     t = torch.sort(torch.randint(0, 1_000_000, (m,), generator=gen)).values
     _compare(_build(ei, t, n, 100_000, None, True), _build(ei, t, n, 100_000, None, False))
+
+
+@pytest.mark.parametrize("kind", ["dense", "many-successors", "zipf"])
+def test_fused_builder_hub_nodes_fractional_weights_are_bit_reproducible(kind):
+    """Fractional event weights on hub nodes: the task partials are combined in task order and the run-at-a-time kernel's fp32 histogram is fed by
+    ONE wave in scan order — two builds of the same stream give the same bits."""
+    from pathpyg_amd import _hip
+    ei, t, n = _hub_stream(kind, seed=13)
+    w = torch.from_numpy(np.random.default_rng(31).random(ei.size(1)).astype(np.float32) + 0.25)
+    dev = torch.device("cuda:0")
+    builds = [_hip.debruijn2(ei.to(dev), t.to(dev), n, 250, w.to(dev), want_weights=True) for _ in range(3)]
+    for other in builds[1:]:
+        for name in ("fo", "ho"):
+            for fld in PLAN_FIELDS:
+                _assert_same(getattr(getattr(builds[0], name), fld), getattr(getattr(other, name), fld), f"{name}.{fld}")
+        _assert_same(builds[0].ho_fwd_weight, other.ho_fwd_weight, "ho_fwd_weight")
