@@ -1023,6 +1023,57 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub(int64_t n_tasks, int64_t del
                 da_l = ok ? inv_sqrt_deg(a.fo_deg[sa]) : 0.0f;
             }
             const int nz = qend - qq < kWave ? (int)(qend - qq) : kWave;
+            if (open && nz == kWave && rl_u(sa, 0) == cur_a && rl_u(sa, kWave - 1) == cur_a) {
+                // A LONG IN-RUN: all 64 events of this sub-chunk (and maybe many more) continue the open run.  Walking them one by one is serial
+                // in the run's length (a node pair carrying a third of a 2*10^6-event stream: 260 ms); the rest of the run [qq, qe2) is counted
+                // FROM THE OUT-EVENTS' SIDE instead: lane j = out-event j counts the instances it continues by two bisections over the run's
+                // (ascending) instance times — t_i < t_j and t_j <= t_i + delta are monotone in t_i — and every run sums its lanes' counts.
+                const int64_t qe2 = upper_bound_dev<uint32_t, int64_t>(a.is_a, qq + kWave, qend, cur_a);
+                int64_t lb = qq, pp = qq;
+                if (lo_) {
+                    int64_t lo = qq, hi = qe2;
+                    while (lo < hi) {                                  // instances earlier than t_j
+                        const int64_t mid = lo + ((hi - lo) >> 1);
+                        if (time_of<TimeT>(a.is_t[mid]) < tj) lo = mid + 1; else hi = mid;
+                    }
+                    lb = lo;
+                    lo = qq; hi = lb;
+                    while (lo < hi) {                                  // ... of which the first whose window still reaches t_j
+                        const int64_t mid = lo + ((hi - lo) >> 1);
+                        if (!W::admits(tj, W::threshold(time_of<TimeT>(a.is_t[mid]), delta_i, delta_f))) lo = mid + 1; else hi = mid;
+                    }
+                    pp = lo;
+                }
+                const int cj = (int)(lb - pp);                         // (0 on lanes beyond the out-events)
+                float wj = 0.0f;
+                if (kW) {
+                    // the weights of those instances, summed by the whole wave per out-event (ascending instance order inside every lane's share)
+                    for (int x = 0; x < (int)no; ++x) {
+                        const int64_t w0 = rl_i((int)(pp - qq), x) + qq, w1 = rl_i((int)(lb - qq), x) + qq;
+                        float part = 0.0f;
+                        for (int64_t y = w0 + l; y < w1; y += kWave) part += a.is_w[y];
+                        part = wave_sum(part);
+                        if (l == x) wj = part;
+                    }
+                    float wall = 0.0f;
+                    for (int64_t y = qq + l; y < qe2; y += kWave) wall += a.is_w[y];
+                    w1run += wave_sum(wall);
+                } else {
+                    w1run += (float)(qe2 - qq);
+                }
+                int hsum = 0;
+                float fsum = 0.0f;
+                for (int x = 0; x < (int)no; ++x) {                    // every run takes its lanes' counts (uniform loop: lane reads need every lane)
+                    const int cx = rl_i(cj, x);
+                    const float wx = kW ? rl_f(wj, x) : 0.0f;
+                    if ((runmask >> x) & 1ull) { hsum += cx; fsum += wx; }
+                }
+                hits += hsum;
+                pairs += hsum;
+                if (kW) facc += fsum;
+                qq = qe2 - kWave;                                      // (the loop's step brings it to the run's end: the next event closes the run)
+                continue;
+            }
             const int nsteps = qq + nz >= qend ? nz + 1 : nz;          // + the virtual event behind the last one
             for (int z = 0; z < nsteps; ++z) {
                 const bool real = z < nz;

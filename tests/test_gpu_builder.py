@@ -187,6 +187,11 @@ def _hub_stream(kind, seed=5):
         ei = torch.from_numpy(rng.integers(2, n, (2, m)))
         ei[0, :150] = 0                      # node 0: 150 out-events, never a destination
         ei[1, 200:350] = 1                   # node 1: 150 in-events, never a source
+    elif kind == "long-run-few-successors":   # an in-run of 1500 instances at a node with ~15 out-events: counted from the out-events' side
+        m, n, span = 6000, 400, 4000
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        ei[0, ::4] = 7
+        ei[1, ::4] = 9
     elif kind == "long-run":             # one node pair carrying a sixth of the stream: an in-run far longer than a chunk
         m, n, span = 6000, 50, 4000
         ei = torch.from_numpy(rng.integers(0, n, (2, m)))
@@ -198,7 +203,7 @@ def _hub_stream(kind, seed=5):
     return ei, t, n
 
 
-HUB_KINDS = ["in-hub", "out-hub", "both", "dense", "many-successors", "zipf", "long-run", "source-sink"]
+HUB_KINDS = ["in-hub", "out-hub", "both", "dense", "many-successors", "zipf", "long-run", "long-run-few-successors", "source-sink"]
 
 
 @pytest.mark.parametrize("kind", HUB_KINDS)
@@ -214,7 +219,7 @@ def test_fused_builder_hub_nodes_equal_generic_path(kind, delta):
     _compare(_build(ei, t, n, delta, None, True), _build(ei, t, n, delta, None, False), hubs=True)
 
 
-@pytest.mark.parametrize("kind", ["both", "dense", "many-successors", "zipf"])
+@pytest.mark.parametrize("kind", ["both", "dense", "many-successors", "zipf", "long-run", "long-run-few-successors"])
 @pytest.mark.parametrize("integer", [True, False], ids=["integer-weights", "fractional-weights"])
 def test_fused_builder_hub_nodes_weighted(kind, integer):
     ei, t, n = _hub_stream(kind, seed=9)
