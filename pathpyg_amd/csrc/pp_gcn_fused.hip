@@ -1476,7 +1476,7 @@ int pp_gcn_forward_staged_f32(const int32_t* ptr, const int32_t* idx, const floa
     PP_REQUIRE(((uintptr_t)X | (uintptr_t)Y) % 16 == 0, PP_ERR_ARG, "pp_gcn_forward_staged_f32: X and Y must be 16-byte aligned");
     PP_REQUIRE((uint64_t)n_src * 256u < (uint64_t)pp::kBufOob && n_rows < ((int64_t)1 << 30) - 64, PP_ERR_TOO_LARGE,
                "pp_gcn_forward_staged_f32: X of 4 GiB or more (use pp_gcn_forward_f32)");
-    PP_REQUIRE(grp_cnt != nullptr && grp_list != nullptr && slot != nullptr && fallback != nullptr, PP_ERR_ARG, "pp_gcn_forward_staged_f32: no stage plan");
+    PP_REQUIRE(grp_cnt != nullptr && grp_list != nullptr && fallback != nullptr, PP_ERR_ARG, "pp_gcn_forward_staged_f32: no stage plan");      // (slot: NULL for a graph without entries)
     if (n_rows == 0) return PP_OK;
     const pp::GcnArgs a{ptr, idx, val, n_rows, X, self_coef, W, bias, act, pp::HeavyRows{nullptr, nullptr}, false, nullptr, Y, nullptr, nullptr, n_rows,
                         pp::drop_site(0.0, 0, 0, 0)};
