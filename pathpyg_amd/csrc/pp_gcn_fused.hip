@@ -871,27 +871,40 @@ static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const i
 // the rows (b, .) of one block gather from the same few sources (., b).  On the headline graph the plain kernel issues 1.9 * 10^7 row gathers
 // per launch (4.86 GB) for 9.2 * 10^6 distinct (group, source) pairs (2.36 GB, tools/probes/tile_reuse.py), and the L2 (4 MB per die against
 // ~7 MB of traffic per die and tile time) catches under half of the repeats (counter traffic of the gather 4.0 GB).  Here every distinct source
-// row of a group is fetched ONCE into an LDS stage and the four waves sum their rows' neighbours out of the stage.
+// row of a group is fetched ONCE into an LDS stage and the four waves sum their rows' neighbours out of the stage: 7.7 GB of traffic per launch
+// instead of 9.3.  An OPT-IN entry point (pp_gcn_forward_staged_f32): 1.59 ms per launch against 1.65 ms for k_gcn_forward on the headline
+// layer (same box) — the plan costs 0.066 ms, so a step that builds its graph anew gains nothing, an epoch loop over one graph 3-4 %.
 //   k_stage_plan  (once per plan) one wave per 64-row group: its <= 256 column indices go into a wave-private LDS hash table (atomicCAS, open
 //                 addressing), distinct sources are numbered in order of their first entry (ballot + popcount: the same numbering on every
-//                 run) -> grp_list [group][128] source rows, grp_cnt [group], slot [entry] = stage slot of the entry's source.  A group
-//                 with more than 256 entries or more than 128 distinct sources is marked (grp_cnt 255) and appended to a list: the layer
+//                 run) -> grp_list [group][96] source rows, grp_cnt [group], slot [entry] = stage slot of the entry's source.  A group
+//                 with more than 256 entries or more than 96 distinct sources is marked (grp_cnt 255) and appended to a list: the layer
 //                 kernel gathers those the TileGather way in a second loop.
 //   k_gcn_forward_staged  persistent workgroups of four waves, a workgroup walks groups (tile = 4 * group + wave).  Everything a group needs
-//                 is in flight one group ahead: at the top of group A's turn its stage rows (eight float4 per thread: 16 lanes per row),
+//                 is in flight one group ahead: at the top of group A's turn its stage rows (six float4 per thread: 16 lanes per row),
 //                 its self rows, row pointers and (slot, value) entries sit in registers — they were requested while the group before was
-//                 multiplied — and go to LDS between two barriers; then the loads of group B are issued (its list and pointers came one
-//                 turn earlier still) and A is summed (first four entries of a lane group's four rows as sixteen independent LDS chains),
-//                 multiplied on the matrix cores and stored.  Two workgroups per CU (69 KB of LDS each).
-//                 EVERY memory instruction of the main loop is a buffer access whose absence is an out-of-range offset, never a branch, and
-//                 the prologue ends with four out-of-range stores: the compiler counts outstanding memory operations per path and takes the
-//                 SAFE count where paths meet — with a store-free entry path (or a store-free `continue` for the waves past the last tile)
-//                 every wait for the next group's list became a wait for the previous group's STORES (thread-0 cycle counters, first
-//                 form: 39 % of the kernel inside that wait; 1.88 ms per launch against 1.70 ms for the plain kernel).
-// (Measured on the way, same box, 10^7-row headline layer, plain kernel 1.68 ms: the dedup INSIDE the layer kernel — hash + numbering with
-// four workgroup barriers per group, loads issued and awaited in the same turn, three workgroups per CU — 2.95 ms; thread-0 cycle counters
-// per phase: wait for the previous turn's memory 16 %, dedup 17 %, load wait 21 %, summing 24 %, MFMA + store 20 %.)
-constexpr int kStageSlots = 128, kStageNnz = 256, kStageKeep = kStageSlots / 16;
+//                 multiplied — and go to LDS between two barriers; then the requests of group B go out in portions between the pieces of
+//                 A's arithmetic (its list and pointers came one turn earlier still): A is summed (first four entries of a lane group's
+//                 four rows as sixteen independent LDS chains), multiplied on the matrix cores and stored.
+// What the kernel's time was made of, each step measured on the GPU (thread-0 cycle counters per phase: -DPP_STAGE_PROF, tools/probes/fwd_stage.py):
+//   * the dedup INSIDE the layer kernel (hash + numbering, four workgroup barriers per group, loads issued and awaited in the same turn): 2.95 ms;
+//   * plan + one-turn-ahead requests, 2 workgroups per CU: 1.88 ms, 39 % of it inside the wait for the next group's LIST — a wait for the previous
+//     group's STORES: the compiler counts outstanding memory operations per path and takes the SAFE count where paths meet, so a store-free
+//     entry path, a `continue` for the waves past the last tile, a branch around a store or a register COPY of a value in flight (rotating
+//     b <- c at the end of a turn) each turn some wait into "everything issued so far".  Hence: every memory instruction of the main loop is a
+//     buffer access whose absence is an out-of-range offset made from a mask the compiler cannot see through, never a branch; the values of a
+//     turn are "used" by empty asm statements at the top, so all waits sit there and none behind the turn's requests; group-wide values are
+//     loaded through a lane-dependent zero so that they do not look uniform (a uniform value is moved to a scalar register at once = waited
+//     for at once); the (value, value) pairs of the entries are pairs in LDS (a packed multiply-add that broadcasts one register names the
+//     register PAIR, whose other half may be the destination of a request in flight); the self-term products are pinned in front of the requests;
+//   * all of that, requests as one burst behind the second barrier: 1.82 ms, 52 % of it issuing 34 requests — every wave of the CU stands at the
+//     request queue at once and the queue is empty while they all compute; requests in four portions between sum / MFMA halves: 1.68 ms;
+//   * a TWO-turn-ahead form (two register sets for the stage rows): 1.76 ms at 256 registers — the allocator splits live ranges and copies
+//     values in flight at the loop's latch; kept under /tmp only;
+//   * THREE workgroups per CU: the waves' tiles live inside the stage (one barrier more), 96 slots, one register set for the first requests,
+//     the bias in LDS, the stores at the end of their own turn: 167 registers, 43.8 KB of LDS: 1.59 ms.  What is left (35 % top wait, 38 %
+//     MFMA + requests) is the per-CU request concurrency: 12 waves that move in lockstep per workgroup keep ~45 KB in flight per CU where the
+//     16 free-running waves of k_gcn_forward keep ~56 KB (5.65 TB/s of traffic against 4.8 TB/s here).
+constexpr int kStageSlots = 96, kStageNnz = 256, kStageKeep = kStageSlots / 16;
 constexpr uint8_t kStageFallback = 255;
 
 __global__ __launch_bounds__(kGcnThreads) void k_stage_plan(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t n_rows, int64_t n_groups,
@@ -1032,31 +1045,36 @@ __device__ __forceinline__ void stage_mfma(const float* __restrict__ tile, const
     stage_mfma_finish(out, bias_c, act, y);
 }
 
+#ifndef PP_STAGE_WGS
+#define PP_STAGE_WGS 3
+#endif
 template <bool kStream>
-__global__ __launch_bounds__(kGcnThreads, 2) void k_gcn_forward_staged(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+__global__ __launch_bounds__(kGcnThreads, PP_STAGE_WGS) void k_gcn_forward_staged(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
                                                                        int64_t n_rows, const float* __restrict__ X, const float* __restrict__ self_coef,
                                                                        const float* __restrict__ W, const float* __restrict__ bias, int act, StageArgs sp,
                                                                        float* __restrict__ Y, int64_t n_self) {
     constexpr int P = 64, Q = 64, kRows = 4, CT = 4, TS = P + 4, kWaves = kGcnWaves;
     __shared__ __attribute__((aligned(16))) float s_b[P * Q];
-    __shared__ __attribute__((aligned(16))) float s_tile[kWaves][16 * TS];
+    // (the waves' 16-row tiles live INSIDE the stage: once every wave has summed its rows the stage is dead until the next group's rows are
+    // written, and 17 KB of LDS less is what lets a third workgroup onto the CU)
     __shared__ __attribute__((aligned(16))) float s_stage[kStageSlots * P];
+    static_assert(kStageSlots * P >= kWaves * 16 * TS, "the tiles fit into the stage");
     __shared__ int s_gptr[65];
     // (entry values as PAIRS (v, v): a packed multiply-add that broadcasts ONE register still names the register pair, and the pair's other half
     // may be the destination of a request in flight — the compiler then waits for that request in the middle of the sums)
     __shared__ __attribute__((aligned(8))) pp_f32x2 s_gval[kStageNnz];
     __shared__ uint8_t s_slot[kStageNnz];
+    __shared__ __attribute__((aligned(16))) float s_bias[Q];
     for (int e = threadIdx.x; e < P * Q; e += kGcnThreads) {
         const int j = e / P, k = e - j * P;
         s_b[k * Q + j] = W[e];
     }
+    if (threadIdx.x < Q) s_bias[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
     __syncthreads();
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const int g = lane >> 4, l = lane & 15, i = lane & 15, kq = lane >> 4, lg = tid >> 4;
-    float* tile = s_tile[wave];
-    float bias_c[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) bias_c[ct] = bias ? bias[CT * i + ct] : 0.f;
+    float* tile = s_stage + wave * 16 * TS;
+    const float* bias_c = s_bias + CT * i;                          // (read where it is added: four registers less across the turn)
     const int64_t n_tiles = (n_rows + 15) / 16, n_groups = (n_tiles + kWaves - 1) / kWaves;
     // every die sweeps a contiguous eighth of the groups (as k_gcn_forward)
     const bool by_die = gridDim.x % 8 == 0;
@@ -1125,21 +1143,18 @@ __global__ __launch_bounds__(kGcnThreads, 2) void k_gcn_forward_staged(const int
         PP_STAGE_ENTRY(G, P0, P1, CNT);                                                             \
     } while (0)
     int64_t grp = group_at(0), grp_b = group_at(1);
-    // two register sets (x, y) take the first loads in turn: no value with its load still in flight is ever COPIED (a copy is a use: rotating
-    // b <- c at the end of a turn made the compiler wait there for the loads it had just issued, the next group's rows included)
-    int x_mine = 0, x_p0 = 0, x_p1 = 0, x_cnt = 0, x_lst[kStageKeep], y_mine = 0, y_p0 = 0, y_p1 = 0, y_cnt = 0, y_lst[kStageKeep];
+    // the first requests of the next group (no value with its load still in flight is ever COPIED: a copy is a use — rotating b <- c at the end
+    // of a turn made the compiler wait there for the loads it had just issued, the next group's rows included)
+    int x_mine = 0, x_p0 = 0, x_p1 = 0, x_cnt = 0, x_lst[kStageKeep];
     {
         int lst0[kStageKeep];
         PP_STAGE_FIRST(grp, a_mine, a_p0, a_p1, a_cnt, lst0);
         PP_STAGE_SECOND(grp, a_p0, a_p1, a_cnt, lst0);
         PP_STAGE_FIRST(grp_b, x_mine, x_p0, x_p1, x_cnt, x_lst);
-#pragma unroll
-        for (int k = 0; k < kStageKeep; ++k) y_lst[k] = 0;
     }
     // the stores of a group wait in registers until the NEXT turn's requests go out: a store in flight makes every wait behind it stricter
     // than its loads need (thread-0 counters with the stores at the end of their own turn: 41 % of the kernel in the waits for the next
     // group's list, which had long arrived — the wait was for the stores just issued)
-    float yp[4][4] = {};
     int64_t p_row0 = 0;
     uint32_t p_dead = 0xFFFFFFFFu;
 #define PP_STAGE_STORES()                                                                                                         \
@@ -1221,18 +1236,19 @@ __global__ __launch_bounds__(kGcnThreads, 2) void k_gcn_forward_staged(const int
                     acc[q][0] = __builtin_elementwise_fma(c, xv[0], acc[q][0]);                                                  \
                     acc[q][1] = __builtin_elementwise_fma(c, xv[1], acc[q][1]);                                                  \
                 }                                                                                                                \
-                *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = make_float4(acc[q][0][0], acc[q][0][1], acc[q][1][0], acc[q][1][1]); \
             }                                                                                                                    \
         }                                                                                                                        \
+        __syncthreads();                                             /* every wave has read what it needs of the stage */        \
+        _Pragma("unroll") for (int q = 0; q < kRows; ++q)                                                                        \
+            *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = make_float4(acc[q][0][0], acc[q][0][1], acc[q][1][0], acc[q][1][1]); \
         PP_PROF_MARK(5);                                                                                                         \
         __builtin_amdgcn_wave_barrier();                                                                                         \
         PP_STAGE_ROWS(grp_b, B_CNT, B_LST, kStageKeep / 2, kStageKeep);                                                          \
         f32x4 out[4];                                                                                                            \
         _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) out[ct] = f32x4{0.f, 0.f, 0.f, 0.f};                                    \
         stage_mfma_part<0, 2>(tile, s_b, i, kq, out);                /* (a wave past the last tile multiplies stale numbers) */   \
-        PP_STAGE_SELF(grp_b, B_CNT);                                                                                             \
+        PP_STAGE_SELF(grp_b, B_CNT);                                 /* (not earlier: sixteen registers that the sums need) */    \
         a_mine = B_MINE; a_p0 = B_P0; a_p1 = B_P1; a_cnt = B_CNT;                                                                \
-        PP_STAGE_STORES()                                            /* (the group before) */                                    \
         stage_mfma_part<2, 4>(tile, s_b, i, kq, out);                                                                            \
         PP_STAGE_FIRST(grp_c, C_MINE, C_P0, C_P1, C_CNT, C_LST);                                                                 \
         float y[4][4];                                                                                                           \
@@ -1242,27 +1258,31 @@ __global__ __launch_bounds__(kGcnThreads, 2) void k_gcn_forward_staged(const int
         p_row0 = t * 16 + 4 * kq;                                                                                                \
         p_dead = live ? 0u : 0xFFFFFFFFu;                                                                                        \
         asm volatile("" : "+v"(p_dead));                                                                                         \
-        _Pragma("unroll") for (int reg = 0; reg < 4; ++reg)                                                                      \
-            _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) yp[reg][ct] = y[reg][ct];                                           \
+        _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                                    \
+            const uint32_t past = p_row0 + reg < n_rows ? p_dead : 0xFFFFFFFFu;                                                  \
+            const uint32_t off = ((((uint32_t)(p_row0 + reg) << 8) + 16u * i) & ~past) | (kBufOob & past);                       \
+            if constexpr (kStream) buf_store_f4_nt(rs_y, off, make_float4(y[reg][0], y[reg][1], y[reg][2], y[reg][3]));          \
+            else buf_store_f4(rs_y, off, make_float4(y[reg][0], y[reg][1], y[reg][2], y[reg][3]));                               \
+        }                                                                                                                        \
         grp = grp_b;                                                                                                             \
         grp_b = grp_c;                                                                                                           \
         ++it;                                                                                                                    \
         PP_PROF_MARK(6);                                                                                                         \
     }
     for (int64_t it = 0; grp < n_groups;) {
-        PP_STAGE_TURN(x_mine, x_p0, x_p1, x_cnt, x_lst, y_mine, y_p0, y_p1, y_cnt, y_lst)
-        if (grp >= n_groups) break;
-        PP_STAGE_TURN(y_mine, y_p0, y_p1, y_cnt, y_lst, x_mine, x_p0, x_p1, x_cnt, x_lst)
+        // (ONE set of registers for the first requests: a group's list is dead once its second requests are out, its pointers are copied —
+        // arrived — before the next group's first requests are written over them, as the last requests of the turn)
+        PP_STAGE_TURN(x_mine, x_p0, x_p1, x_cnt, x_lst, x_mine, x_p0, x_p1, x_cnt, x_lst)
     }
 #undef PP_STAGE_TURN
-    PP_STAGE_STORES()
 #undef PP_STAGE_STORES
 #undef PP_STAGE_FIRST
 #undef PP_STAGE_SECOND
 #undef PP_STAGE_ROWS
 #undef PP_STAGE_SELF
 #undef PP_STAGE_ENTRY
-    // ---- the groups the plan could not stage (more than 256 entries or 128 distinct sources): gathered the ordinary way
+    __syncthreads();
+    // ---- the groups the plan could not stage (more than 256 entries or 96 distinct sources): gathered the ordinary way
     const int n_fb = sp.fallback[0];
     for (int k = blockIdx.x; k < n_fb; k += gridDim.x) {
         const int64_t t = (int64_t)sp.fallback[1 + k] * kWaves + wave;

@@ -1,7 +1,7 @@
 """GPU tests of the staged 64 x 64 layer kernel (pp_gcn_stage_plan_i32 / pp_gcn_forward_staged_f32): the stage plan against a torch
 restatement of its definition (distinct sources of every 64-row group in order of first appearance), the layer against the plain kernel and
 against a float64 evaluation of ``ELU((A x + diag(self) x) W^T + b)`` (reference: GCNConv inside nn/dbgnn.py:131-140) at the 1e-5 bar of
-tests/tolerance.py.  The cases cover groups the plan cannot stage (more than 256 entries, more than 128 distinct sources), empty rows,
+tests/tolerance.py.  The cases cover groups the plan cannot stage (more than 256 entries, more than pp_gcn_stage_slots() = 96 distinct sources), empty rows,
 a ragged last group, rectangular graphs, missing values / self terms."""
 import pytest
 import torch
@@ -57,7 +57,7 @@ CASES = {
     "ragged-last-group": (1000 + 37, 1500, 1.9, (), 30),
     "no-repeats": (4096, 200000, 2.5, (), None),
     "dense-rows-fall-back": (3000, 3000, 1.5, (5, 700, 701, 2999), 25),
-    "many-distinct-fall-back": (2048, 100000, 3.4, (), None),          # groups of ~218 entries, nearly all distinct: more than 128 sources
+    "many-distinct-fall-back": (2048, 100000, 3.4, (), None),          # groups of ~218 entries, nearly all distinct: more sources than the stage has slots
     "tiny": (5, 9, 1.0, (), None),
     "empty-rows": (700, 700, 0.0, (), None),
 }
