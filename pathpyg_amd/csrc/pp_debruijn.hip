@@ -33,7 +33,20 @@
 namespace pp {
 
 constexpr int64_t kDb2BadIndex = 1, kDb2Unsorted = 2, kDb2Overflow = 4;
-constexpr int kHubChunk = 256;                        // in-events per hub task (one wave)
+constexpr int kHubChunk = 256;                        // in-events per hub task (one wave) ..
+// .. except for a node with FEW in-events and a LONG out-list: a task of k_db2_hubx streams the out-list's window once per in-run, so the work of
+// one task grows with the out-list while the node has one or two tasks (a node pair that carries a third of a 2*10^6-event stream: 20 in-runs
+// over a 6.7*10^5-event out-list in ONE wave, 6.5 ms per pass).  Such a node gets smaller chunks — more tasks for the same in-events; the per-task
+// partial results add up as before (an order-2 edge belongs to exactly one in-run).  At most 256 tasks per such node, and there are at most
+// m / kHubLongOut of them: db2_task_cap.
+constexpr int64_t kHubLongOut = 4096, kHubFewIn = 4096;
+__host__ __device__ __forceinline__ int hub_chunk(int64_t ni, int64_t no) {
+    if (no <= kHubLongOut || ni > kHubFewIn) return kHubChunk;
+    int c = kHubChunk;
+    for (int64_t x = kHubLongOut; x < no && c > 1; x <<= 1) c >>= 1;
+    const int least = ni <= 256 ? 1 : 16;
+    return c < least ? least : c;
+}
 constexpr uint8_t kHubOut = 1, kHubIn = 2;            // hub_flag bits: more than 64 out-events / in-events
 constexpr uint32_t kDb2Foreign = 0xFFFFFFFEu;         // order-2 node of an event whose source node another rank owns: numbered on the head side
 
@@ -810,7 +823,7 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub_classify(int64_t n, const ui
     const uint8_t f = (uint8_t)((no > kWave ? kHubOut : 0) | (ni > kWave ? kHubIn : 0));
     flag[b] = f;
     if (!f) return;
-    const int64_t ntask = ni > 0 ? ceil_div_dev(ni, kHubChunk) : 1;
+    const int64_t ntask = ni > 0 ? ceil_div_dev(ni, (int64_t)hub_chunk(ni, no)) : 1;
     const int64_t nrc = no > 0 ? ceil_div_dev(no < n ? no : n, kWave) : 1;          // rounds of 64 successor runs, upper bound (runs <= min(no, n))
     hub_list[atomicAdd((unsigned long long*)&stats[0], 1ull)] = (uint32_t)b;
     const uint32_t t0 = (uint32_t)atomicAdd((unsigned long long*)&stats[2], (unsigned long long)ntask);
@@ -827,11 +840,11 @@ __global__ __launch_bounds__(kBlock) void k_db2_hub_classify(int64_t n, const ui
 
 // task -> node, one workgroup per hub (a node with 2*10^6 in-events has 7 800 tasks: written by ONE thread of the classification they took 0.13 ms)
 __global__ __launch_bounds__(kBlock) void k_db2_hub_tasks(int64_t n_hubs, const uint32_t* __restrict__ hub_list, const uint32_t* __restrict__ hp,
-                                                         const uint32_t* __restrict__ tbase, uint32_t* __restrict__ task_node) {
+                                                         const uint32_t* __restrict__ tp, const uint32_t* __restrict__ tbase, uint32_t* __restrict__ task_node) {
     if ((int64_t)blockIdx.x >= n_hubs) return;
     const uint32_t b = hub_list[blockIdx.x];
-    const int64_t ni = (int64_t)hp[b + 1] - hp[b];
-    const int64_t ntask = ni > 0 ? ceil_div_dev(ni, kHubChunk) : 1;
+    const int64_t ni = (int64_t)hp[b + 1] - hp[b], no = (int64_t)tp[b + 1] - tp[b];
+    const int64_t ntask = ni > 0 ? ceil_div_dev(ni, (int64_t)hub_chunk(ni, no)) : 1;
     const uint32_t t0 = tbase[b];
     for (int64_t k = threadIdx.x; k < ntask; k += kBlock) task_node[t0 + k] = b;
 }
@@ -1209,8 +1222,9 @@ __global__ __launch_bounds__(kBlock) void k_db2_hubx(int64_t n_tasks, int64_t de
     const int64_t nrc = no > 0 ? ((no < h.num_nodes ? no : h.num_nodes) + kWave - 1) / kWave : 1;
     const int64_t part0 = h.pbase[b] + k * nrc;
     const int64_t qend = (int64_t)q0 + ni;
-    int64_t qa = (int64_t)q0 + k * kHubChunk;
-    const int64_t qb = qa + kHubChunk < qend ? qa + kHubChunk : qend;
+    const int64_t chunk = hub_chunk(ni, no);
+    int64_t qa = (int64_t)q0 + k * chunk;
+    const int64_t qb = qa + chunk < qend ? qa + chunk : qend;
     if (k > 0 && qa < qend) {
         const uint32_t prev = a.is_a[qa - 1];
         if (a.is_a[qa] == prev) qa = upper_bound_dev<uint32_t, int64_t>(a.is_a, qa, qend, prev);
@@ -1471,7 +1485,8 @@ __global__ __launch_bounds__(kCombineWaves* kWave) void k_db2_hub_combine(int64_
     const int64_t R = (int64_t)a.row_ptr[b + 1] - row0;
     const int64_t rounds = R > 0 ? (R + kWave - 1) / kWave : 1;
     const int64_t nrc = no > 0 ? ((no < h.num_nodes ? no : h.num_nodes) + kWave - 1) / kWave : 1;
-    const int64_t ntask = ni > 0 ? (ni + kHubChunk - 1) / kHubChunk : 1;
+    const int64_t chunk = hub_chunk(ni, no);
+    const int64_t ntask = ni > 0 ? (ni + chunk - 1) / chunk : 1;
     const int64_t t0 = h.tbase[b], pb = h.pbase[b];
     const int64_t per = (ntask + kCombineWaves - 1) / kCombineWaves;
     const int64_t k_lo = w * per < ntask ? w * per : ntask, k_hi = k_lo + per < ntask ? k_lo + per : ntask;
@@ -1718,7 +1733,7 @@ struct Db2Ws {
     size_t scratch_bytes, total_bytes;
 };
 
-static inline int64_t db2_task_cap(int64_t m, int64_t n) { return m / kHubChunk + n + 1; }      // sum over hubs of max(1, ceil(in-events / chunk))
+static inline int64_t db2_task_cap(int64_t m, int64_t n) { return m / kHubChunk + n + 1 + 256 * (m / kHubLongOut); }      // sum over hubs of max(1, ceil(in-events / chunk)); hub_chunk
 
 static Db2Ws carve_db2(void* ws, int64_t m, int64_t n) {
     Arena a(ws, (size_t)-1);
@@ -2000,7 +2015,7 @@ static int db2_count(const char* who, int time_dtype, int64_t m, int64_t n, cons
     const int key_bits = bits_for((uint64_t)(n > 0 ? n - 1 : 0));
     int rc;
     if (hs.hubs > 0) {
-        k_db2_hub_tasks<<<(unsigned)hs.hubs, kBlock, 0, st>>>(hs.hubs, w.hub_list, w.hp, w.tbase, w.task_node);
+        k_db2_hub_tasks<<<(unsigned)hs.hubs, kBlock, 0, st>>>(hs.hubs, w.hub_list, w.hp, w.tp, w.tbase, w.task_node);
         PP_LAUNCH_CHECK();
     }
     // 2'. out-hubs: their out-events in (successor, time) order by one sort over exactly those events

@@ -192,6 +192,14 @@ def _hub_stream(kind, seed=5):
         ei = torch.from_numpy(rng.integers(0, n, (2, m)))
         ei[0, ::4] = 7
         ei[1, ::4] = 9
+    elif kind == "few-in-long-out":      # ~70 in-events, 67 000 out-events: the node's tasks get chunks of 8 in-events (hub_chunk)
+        m, n, span = 200_000, 3000, 150_000
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        ei[0, ::3] = 7
+    elif kind == "some-in-long-out":     # ~700 in-events, 67 000 out-events: chunks of 16 in-events
+        m, n, span = 200_000, 300, 150_000
+        ei = torch.from_numpy(rng.integers(0, n, (2, m)))
+        ei[0, ::3] = 7
     elif kind == "long-run":             # one node pair carrying a sixth of the stream: an in-run far longer than a chunk
         m, n, span = 6000, 50, 4000
         ei = torch.from_numpy(rng.integers(0, n, (2, m)))
@@ -203,7 +211,8 @@ def _hub_stream(kind, seed=5):
     return ei, t, n
 
 
-HUB_KINDS = ["in-hub", "out-hub", "both", "dense", "many-successors", "zipf", "long-run", "long-run-few-successors", "source-sink"]
+HUB_KINDS = ["in-hub", "out-hub", "both", "dense", "many-successors", "zipf", "long-run", "long-run-few-successors", "few-in-long-out", "some-in-long-out",
+             "source-sink"]
 
 
 @pytest.mark.parametrize("kind", HUB_KINDS)
@@ -219,7 +228,7 @@ def test_fused_builder_hub_nodes_equal_generic_path(kind, delta):
     _compare(_build(ei, t, n, delta, None, True), _build(ei, t, n, delta, None, False), hubs=True)
 
 
-@pytest.mark.parametrize("kind", ["both", "dense", "many-successors", "zipf", "long-run", "long-run-few-successors"])
+@pytest.mark.parametrize("kind", ["both", "dense", "many-successors", "zipf", "long-run", "long-run-few-successors", "few-in-long-out"])
 @pytest.mark.parametrize("integer", [True, False], ids=["integer-weights", "fractional-weights"])
 def test_fused_builder_hub_nodes_weighted(kind, integer):
     ei, t, n = _hub_stream(kind, seed=9)
