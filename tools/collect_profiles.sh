@@ -30,7 +30,8 @@ for key, pat in (("k_gcn_forward", "k_gcn_forward<64, 64"), ("k_gcn_backward@ho"
                  ("k_expand", "k_expand<true>"), ("k_temporal_count", "k_temporal_count"), ("k_spmm_act_backward", "k_spmm_act_backward<16>"),
                  ("k_weight_grad64", "k_weight_grad64"), ("k_db2_mid@count", "k_db2_mid<long, 0, false"), ("k_db2_mid@fill", "k_db2_mid<long, 0, true"),
                  ("k_db2_out", "k_db2_out<false>"), ("k_db2_gather_out", "k_db2_gather_out"), ("k_db2_out_ids", "k_db2_out_ids"),
-                 ("k_db2_keys", "k_db2_keys"), ("k_db2_unzip", "k_db2_unzip")):
+                 ("k_db2_keys", "k_db2_keys"), ("k_db2_unzip", "k_db2_unzip"), ("k_gcn_forward_staged", "k_gcn_forward_staged"),
+                 ("k_stage_plan", "k_stage_plan")):
     fe, wr = pick(f, pat, "FETCH_SIZE"), pick(w, pat, "WRITE_SIZE")
     if not fe or not wr or fe["dispatches"] != wr["dispatches"]:
         continue
