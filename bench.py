@@ -269,7 +269,7 @@ def pmc_traffic(kernel_key: str, args) -> float | None:
     return None
 
 
-PMC_TABLES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_TABLES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 pmc_traffic.source = None
 
 

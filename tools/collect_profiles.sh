@@ -7,17 +7,27 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+# (--no-staged-forward: the section launches k_gcn_forward 23 more times on the order-2 graph WITHOUT the kept aggregate — the per-dispatch mean of the
+# timed step's two launches would drift; the staged kernel gets its own passes below)
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-staged-forward"
 rm -rf /tmp/p_stats; rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o x -- $CMD > /tmp/log_stats.txt 2>&1
 python $R/tools/rocprof_summary.py $(find /tmp/p_stats -name "*.db" | head -1) --top 70 > $OUT/${TAG}_bench_kernel_stats.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$C; rocprofv3 --pmc $C --kernel-trace -d /tmp/p_$C -o x -- $CMD > /tmp/log_$C.txt 2>&1
   python $R/tools/rocprof_pmc.py $(find /tmp/p_$C -name "*.db" | head -1) --top 40 --json /tmp/pmc_$C.json > $OUT/${TAG}_pmc_$C.txt 2>&1
 done
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/ps_$C; rocprofv3 --pmc $C --kernel-trace -d /tmp/ps_$C -o x -- python $R/tools/probes/fwd_stage.py > /tmp/log_s$C.txt 2>&1
+  python $R/tools/rocprof_pmc.py $(find /tmp/ps_$C -name "*.db" | head -1) --top 12 --json /tmp/pmc_s$C.json > $OUT/${TAG}_pmc_staged_forward_$C.txt 2>&1
+done
 timeout 600 python $R/bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_stderr.txt
 python - <<PY
 import json
 f, w = json.load(open("/tmp/pmc_FETCH_SIZE.json")), json.load(open("/tmp/pmc_WRITE_SIZE.json"))
+for tab, path in ((f, "/tmp/pmc_sFETCH_SIZE.json"), (w, "/tmp/pmc_sWRITE_SIZE.json")):      # the staged layer kernel and its plan: tools/probes/fwd_stage.py
+    for k, v in json.load(open(path)).items():
+        if "k_gcn_forward_staged" in k or "k_stage_plan" in k:
+            tab[k] = v
 out = {}
 def pick(table, pat, counter):
     for k, v in table.items():
