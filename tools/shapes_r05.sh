@@ -18,6 +18,9 @@ $B --steps 5 --events 12500000 --nodes 625000 --span 12500000 --delta 1250000 --
 timeout 900 python bench.py --no-cpu-baseline --warmup 2 --steps 3 --events 100000000 --nodes 5000000 --span 100000000 --delta 10000000 > $O/events_1e8.json 2> $O/events_1e8.err
 timeout 600 python tools/probes/api_flow.py > $O/api_flow.txt 2> $O/api_flow.err
 timeout 600 python tools/probes/hub_streams.py > $O/hub_streams.txt 2> $O/hub_streams.err
+timeout 300 python tools/probes/long_run.py > $O/long_run.txt 2> $O/long_run.err
+timeout 300 python tools/probes/tile_reuse.py > $O/tile_reuse.txt 2> $O/tile_reuse.err
+timeout 300 python tools/probes/fwd_stage.py > $O/fwd_stage.txt 2> $O/fwd_stage.err
 timeout 900 python tools/probes/config2_scale_free.py > $O/config2_scale_free.txt 2> $O/config2.err
 timeout 900 python tools/probes/multi_order.py > $O/multi_order.txt 2> $O/multi_order.err
 tail -c 200 $O/*.err
