@@ -899,7 +899,7 @@ static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const i
 //   * all of that, requests as one burst behind the second barrier: 1.82 ms, 52 % of it issuing 34 requests — every wave of the CU stands at the
 //     request queue at once and the queue is empty while they all compute; requests in four portions between sum / MFMA halves: 1.68 ms;
 //   * a TWO-turn-ahead form (two register sets for the stage rows): 1.76 ms at 256 registers — the allocator splits live ranges and copies
-//     values in flight at the loop's latch; kept under /tmp only;
+//     values in flight at the loop's latch; not kept;
 //   * THREE workgroups per CU: the waves' tiles live inside the stage (one barrier more), 96 slots, one register set for the first requests,
 //     the bias in LDS, the stores at the end of their own turn: 167 registers, 43.8 KB of LDS: 1.59 ms.  What is left (35 % top wait, 38 %
 //     MFMA + requests) is the per-CU request concurrency: 12 waves that move in lockstep per workgroup keep ~45 KB in flight per CU where the
