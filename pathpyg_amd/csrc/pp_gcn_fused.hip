@@ -903,7 +903,11 @@ static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const i
 //   * THREE workgroups per CU: the waves' tiles live inside the stage (one barrier more), 96 slots, one register set for the first requests,
 //     the bias in LDS, the stores at the end of their own turn: 167 registers, 43.8 KB of LDS: 1.59 ms.  What is left (35 % top wait, 38 %
 //     MFMA + requests) is the per-CU request concurrency: 12 waves that move in lockstep per workgroup keep ~45 KB in flight per CU where the
-//     16 free-running waves of k_gcn_forward keep ~56 KB (5.65 TB/s of traffic against 4.8 TB/s here).
+//     16 free-running waves of k_gcn_forward keep ~56 KB (5.65 TB/s of traffic against 4.8 TB/s here);
+//   * the same per WAVE (a wave-private stage of the <= 32 distinct rows of its 16-row tile inside k_gcn_forward, no workgroup barrier, a
+//     plan per tile: 3.03 GB of gathers instead of 2.36): 1.74 ms — two dependent round trips per tile (list -> rows) at 12 waves per CU;
+//     with the list fetched a tile ahead 4 registers spill and the kernel takes 1.89 ms; with TileGather inlined for the tiles the plan
+//     cannot stage 17-20 registers spill (2.12 ms).  Not kept.
 constexpr int kStageSlots = 96, kStageNnz = 256, kStageKeep = kStageSlots / 16;
 constexpr uint8_t kStageFallback = 255;
 
