@@ -734,6 +734,15 @@ _HUB_PART_BYTES_MAX = 24 << 30         # per-task partial results of the hub nod
 _tls = threading.local()
 
 
+_A2_GUESS: dict = {}                    # (m, n, want_weights) -> A2 of the last build of a stream of that shape (debruijn2 allocates ahead of its read-back)
+
+
+def _a2_buffers(a2: int, want_weights: bool, i32: dict, f32: dict) -> tuple:
+    """The A2-sized outputs of :func:`debruijn2`: forward / backward index + value arrays, the 2 * A2 pack scratch, the raw weights."""
+    return (torch.empty(a2, **i32), torch.empty(a2, **f32), torch.empty(a2, **i32), torch.empty(a2, **f32), torch.empty(2 * a2, **i32),
+            torch.empty(a2, **f32) if want_weights else None)
+
+
 def _pinned_stats() -> torch.Tensor:
     """Pinned int64 [16 + 154] of the calling thread: where pp_debruijn2_lists copies the hub statistics ([:16]) and pp_debruijn2_count the
     result header ([16:]), both asynchronously."""
@@ -795,6 +804,13 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
         check(L.pp_debruijn2_count(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_bwd_idx), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr),
                                    _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), _p(ws), ws.numel(), *hub_args, stats.data_ptr() + 128, _stream()),
               "pp_debruijn2_count")
+        # The outputs are allocated WHILE the count pass runs, not behind the read-back of its sizes (the GPU idles through everything the host
+        # does between that read-back and the fill call): U2 = A1 <= m is a bound, A2 is guessed from the last build of a stream of this shape
+        # (an epoch loop, a rolling window) and re-allocated when the guess is short or more than a quarter too long.
+        ho_self, fo_fwd_idx, fo_fwd_val = torch.empty(m, **f32), torch.empty(m, **i32), torch.empty(m, **f32)
+        fo_dst_order, fo_bwd_val, fo_self = torch.empty(m, **i32), torch.empty(m, **f32), torch.empty(n, **f32)
+        guess = _A2_GUESS.get((m, n, want_weights), 0)
+        a2_bufs = _a2_buffers(guess, want_weights, i32, f32) if guess else None
         check(L.pp_debruijn2_wait(), "pp_debruijn2_wait")                                     # read-back 2 of 2: the layer sizes (+ the hubs' share)
         head = stats[16:].tolist()
         u2, status, a2, e2, a1 = head[:5]
@@ -810,17 +826,19 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
             return None
         if a2 >= _INT32_ROWS:           # the builder's row pointers are int32 (the scan's TOTAL is int64, so this is the true A2): generic kernels
             return None
-        ho = CsrPlan(n_dst=u2, n_src=u2, fwd_ptr=ho_fwd_ptr[: u2 + 1], fwd_idx=torch.empty(a2, **i32), fwd_val=torch.empty(a2, **f32),
-                     bwd_ptr=ho_bwd_ptr[: u2 + 1], bwd_idx=torch.empty(a2, **i32), bwd_val=torch.empty(a2, **f32), self_coef=torch.empty(u2, **f32),
-                     edge_ordered=True)
-        fo = CsrPlan(n_dst=n, n_src=n, fwd_ptr=fo_fwd_ptr, fwd_idx=torch.empty(a1, **i32), fwd_val=torch.empty(a1, **f32),
-                     bwd_ptr=fo_bwd_ptr, bwd_idx=fo_bwd_idx[:u2], bwd_val=torch.empty(u2, **f32), self_coef=torch.empty(n, **f32),
-                     dst_order=torch.empty(a1, **i32), edge_ordered=True)
-        ho_fwd_w = torch.empty(a2, **f32) if want_weights else None
+        if a2_bufs is None or not (a2 <= guess <= a2 + a2 // 4 + 1024):
+            a2_bufs = _a2_buffers(a2, want_weights, i32, f32)
+        _A2_GUESS[(m, n, want_weights)] = a2
+        ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, pack, ho_fwd_w = (None if b is None else b[:k * a2] for b, k in zip(a2_bufs, (1, 1, 1, 1, 2, 1)))
+        ho = CsrPlan(n_dst=u2, n_src=u2, fwd_ptr=ho_fwd_ptr[: u2 + 1], fwd_idx=ho_fwd_idx, fwd_val=ho_fwd_val,
+                     bwd_ptr=ho_bwd_ptr[: u2 + 1], bwd_idx=ho_bwd_idx, bwd_val=ho_bwd_val, self_coef=ho_self[:u2], edge_ordered=True)
+        fo = CsrPlan(n_dst=n, n_src=n, fwd_ptr=fo_fwd_ptr, fwd_idx=fo_fwd_idx[:a1], fwd_val=fo_fwd_val[:a1],
+                     bwd_ptr=fo_bwd_ptr, bwd_idx=fo_bwd_idx[:u2], bwd_val=fo_bwd_val[:u2], self_coef=fo_self,
+                     dst_order=fo_dst_order[:a1], edge_ordered=True)
         check(L.pp_debruijn2_fill(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_bwd_idx), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr),
                                   _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), a2, _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx), _p(ho.bwd_val),
                                   _p(ho.self_coef), _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.dst_order), _p(fo.bwd_val), _p(fo.self_coef), _p(ho_fwd_w),
-                                  _p(torch.empty(2 * a2, **i32)), _p(ws), ws.numel(), *hub_args, 1, _stream()),
+                                  _p(pack), _p(ws), ws.numel(), *hub_args, 1, _stream()),
               "pp_debruijn2_fill")
         # hub rows of the plans (more than 512 entries): the chunk tables of the row kernels' pre-pass, as pp_gcn_plan's report triggers them
         if longest[0] > HEAVY_ROW_ENTRIES:

@@ -2218,7 +2218,14 @@ int pp_debruijn2_lists(const int64_t* edge_index, const void* time, int time_dty
 }
 
 int pp_debruijn2_wait(void) {
-    if (tls_stats_event) PP_HIP(hipEventSynchronize(tls_stats_event));
+    if (!tls_stats_event) return PP_OK;
+    // (the copy is a few hundred microseconds away at most: poll first — a blocking wait adds the wake-up of the thread to the time the GPU idles)
+    for (int spin = 0; spin < 20000; ++spin) {
+        const hipError_t e = hipEventQuery(tls_stats_event);
+        if (e == hipSuccess) return PP_OK;
+        if (e != hipErrorNotReady) PP_HIP(e);
+    }
+    PP_HIP(hipEventSynchronize(tls_stats_event));
     return PP_OK;
 }
 
