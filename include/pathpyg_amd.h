@@ -132,6 +132,18 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
                       float* fo_bwd_val, float* fo_self, float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes, int64_t hub_nodes,
                       int64_t out_hubs, int64_t hub_out_events, int64_t hub_tasks, int64_t hub_parts, void* hub_ws, size_t hub_ws_bytes,
                       int rows_packed, pp_stream_t stream);
+/* pp_debruijn2_wait + pp_debruijn2_fill in ONE call, for a caller that allocated the A2-sized outputs ahead of the size read-back with a guessed
+ * capacity (ho_edge_capacity entries; pair_scratch 8 * capacity bytes): waits for the header pp_debruijn2_count copied to host_result, and launches
+ * the fill at once when the stream is good (status 0) and A2 fits — *launched = 1 — so that nothing of the caller's host code sits between the
+ * read-back and the fill; otherwise *launched = 0 and nothing was queued (the caller reads the header, allocates exactly and calls
+ * pp_debruijn2_fill, or reports the status). */
+int pp_debruijn2_fill_ready(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
+                            const int32_t* fo_bwd_ptr, const int32_t* fo_bwd_idx, const float* fo_w, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr,
+                            const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t ho_edge_capacity, int32_t* ho_fwd_idx,
+                            float* ho_fwd_val, int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val,
+                            int32_t* fo_dst_order, float* fo_bwd_val, float* fo_self, float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes,
+                            int64_t hub_nodes, int64_t out_hubs, int64_t hub_out_events, int64_t hub_tasks, int64_t hub_parts, void* hub_ws,
+                            size_t hub_ws_bytes, int rows_packed, const int64_t* host_result, int64_t* launched, pp_stream_t stream);
 
 /* The same builder on ONE RANK of a node-range partition (the lift shards by edge range, the DBGNN by destination-node
  * partition; no reference counterpart — the reference is single-process).  Rank `rank` owns the first-order nodes

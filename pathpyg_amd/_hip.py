@@ -811,7 +811,19 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
         fo_dst_order, fo_bwd_val, fo_self = torch.empty(m, **i32), torch.empty(m, **f32), torch.empty(n, **f32)
         guess = _A2_GUESS.get((m, n, want_weights), 0)
         a2_bufs = _a2_buffers(guess, want_weights, i32, f32) if guess else None
-        check(L.pp_debruijn2_wait(), "pp_debruijn2_wait")                                     # read-back 2 of 2: the layer sizes (+ the hubs' share)
+        launched = False
+        if a2_bufs is not None:
+            # .. and with a guess the fill is launched by the SAME C call that waits for the sizes (when the stream is good and A2 fits): no host
+            # code between read-back and fill
+            flag = stats[15:16]
+            check(L.pp_debruijn2_fill_ready(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_bwd_idx), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr),
+                                            _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), guess, _p(a2_bufs[0]), _p(a2_bufs[1]), _p(a2_bufs[2]), _p(a2_bufs[3]),
+                                            _p(ho_self), _p(fo_fwd_idx), _p(fo_fwd_val), _p(fo_dst_order), _p(fo_bwd_val), _p(fo_self), _p(a2_bufs[5]),
+                                            _p(a2_bufs[4]), _p(ws), ws.numel(), *hub_args, 1, stats.data_ptr() + 128, flag.data_ptr(), _stream()),
+                  "pp_debruijn2_fill_ready")
+            launched = bool(int(flag[0]))
+        else:
+            check(L.pp_debruijn2_wait(), "pp_debruijn2_wait")                                 # read-back 2 of 2: the layer sizes (+ the hubs' share)
         head = stats[16:].tolist()
         u2, status, a2, e2, a1 = head[:5]
         e2 += head[_HUB_STATS + 4]
@@ -826,7 +838,7 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
             return None
         if a2 >= _INT32_ROWS:           # the builder's row pointers are int32 (the scan's TOTAL is int64, so this is the true A2): generic kernels
             return None
-        if a2_bufs is None or not (a2 <= guess <= a2 + a2 // 4 + 1024):
+        if not launched and (a2_bufs is None or not (a2 <= guess <= a2 + a2 // 4 + 1024)):
             a2_bufs = _a2_buffers(a2, want_weights, i32, f32)
         _A2_GUESS[(m, n, want_weights)] = a2
         ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, pack, ho_fwd_w = (None if b is None else b[:k * a2] for b, k in zip(a2_bufs, (1, 1, 1, 1, 2, 1)))
@@ -835,11 +847,12 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
         fo = CsrPlan(n_dst=n, n_src=n, fwd_ptr=fo_fwd_ptr, fwd_idx=fo_fwd_idx[:a1], fwd_val=fo_fwd_val[:a1],
                      bwd_ptr=fo_bwd_ptr, bwd_idx=fo_bwd_idx[:u2], bwd_val=fo_bwd_val[:u2], self_coef=fo_self,
                      dst_order=fo_dst_order[:a1], edge_ordered=True)
-        check(L.pp_debruijn2_fill(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_bwd_idx), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr),
-                                  _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), a2, _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx), _p(ho.bwd_val),
-                                  _p(ho.self_coef), _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.dst_order), _p(fo.bwd_val), _p(fo.self_coef), _p(ho_fwd_w),
-                                  _p(pack), _p(ws), ws.numel(), *hub_args, 1, _stream()),
-              "pp_debruijn2_fill")
+        if not launched:
+            check(L.pp_debruijn2_fill(tcode, m, n, kind, di, df, _p(weight), _p(fo_bwd_ptr), _p(fo_bwd_idx), _p(fo_w), _p(fo_fwd_ptr), _p(ho_fwd_ptr),
+                                      _p(ho_bwd_ptr), _p(ho_deg), _p(fo_deg), a2, _p(ho.fwd_idx), _p(ho.fwd_val), _p(ho.bwd_idx), _p(ho.bwd_val),
+                                      _p(ho.self_coef), _p(fo.fwd_idx), _p(fo.fwd_val), _p(fo.dst_order), _p(fo.bwd_val), _p(fo.self_coef), _p(ho_fwd_w),
+                                      _p(pack), _p(ws), ws.numel(), *hub_args, 1, _stream()),
+                  "pp_debruijn2_fill")
         # hub rows of the plans (more than 512 entries): the chunk tables of the row kernels' pre-pass, as pp_gcn_plan's report triggers them
         if longest[0] > HEAVY_ROW_ENTRIES:
             ho.fwd_heavy = HeavyRows(ho.fwd_ptr, u2)

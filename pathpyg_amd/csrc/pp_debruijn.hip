@@ -2253,6 +2253,26 @@ int pp_debruijn2_fill(int time_dtype, int64_t m, int64_t num_nodes, int delta_ki
                     rows_packed != 0, (hipStream_t)stream);
 }
 
+int pp_debruijn2_fill_ready(int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
+                            const int32_t* fo_bwd_ptr, const int32_t* fo_bwd_idx, const float* fo_w, const int32_t* fo_fwd_ptr, const int32_t* ho_fwd_ptr,
+                            const int32_t* ho_bwd_ptr, const float* ho_deg, const float* fo_deg, int64_t ho_edge_capacity, int32_t* ho_fwd_idx,
+                            float* ho_fwd_val, int32_t* ho_bwd_idx, float* ho_bwd_val, float* ho_self, int32_t* fo_fwd_idx, float* fo_fwd_val,
+                            int32_t* fo_dst_order, float* fo_bwd_val, float* fo_self, float* ho_fwd_w, void* pair_scratch, void* ws, size_t ws_bytes,
+                            int64_t hub_nodes, int64_t out_hubs, int64_t hub_out_events, int64_t hub_tasks, int64_t hub_parts, void* hub_ws,
+                            size_t hub_ws_bytes, int rows_packed, const int64_t* host_result, int64_t* launched, pp_stream_t stream) {
+    PP_REQUIRE(host_result != nullptr && launched != nullptr && ho_edge_capacity >= 0, PP_ERR_ARG, "pp_debruijn2_fill_ready: host_result, launched");
+    *launched = 0;
+    const int rc = pp_debruijn2_wait();
+    if (rc != PP_OK) return rc;
+    const int64_t status = host_result[1], a2 = host_result[2];
+    if (status != 0 || a2 > ho_edge_capacity || a2 >= ((int64_t)1 << 31) - 64) return PP_OK;      // (the caller reads the header and decides)
+    *launched = 1;
+    return pp_debruijn2_fill(time_dtype, m, num_nodes, delta_kind, delta_i, delta_f, weight, fo_bwd_ptr, fo_bwd_idx, fo_w, fo_fwd_ptr, ho_fwd_ptr, ho_bwd_ptr,
+                             ho_deg, fo_deg, a2, ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, ho_self, fo_fwd_idx, fo_fwd_val, fo_dst_order, fo_bwd_val,
+                             fo_self, ho_fwd_w, pair_scratch, ws, ws_bytes, hub_nodes, out_hubs, hub_out_events, hub_tasks, hub_parts, hub_ws, hub_ws_bytes,
+                             rows_packed, stream);
+}
+
 int pp_debruijn2_part_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int64_t node_lo, int64_t n_own,
                             const int64_t* cuts, int world, int rank, int delta_kind, int64_t delta_i, double delta_f, const float* weight,
                             int32_t* fo_bwd_ptr, int32_t* fo_bwd_idx, float* fo_w, int32_t* fo_fwd_ptr, int32_t* ho_fwd_ptr, int32_t* ho_bwd_ptr,
