@@ -150,9 +150,12 @@ class KernelClock:
 
     def __init__(self, lib, name: str, describe, until=None):
         self.lib, self.name, self.describe = lib, name, describe
-        self.until = [until] if isinstance(until, str) else list(until or [])
+        # (a phase may be entered through either of several entry points: a tuple of names — pp_debruijn2_fill / pp_debruijn2_fill_ready)
+        phases = [until] if isinstance(until, str) else list(until or [])
+        self.until = [(k, u) for k, names in enumerate(phases) for u in ((names,) if isinstance(names, str) else names)]
+        self.n_phases = len(phases)
         self.orig = getattr(lib, name)
-        self.orig_until = [getattr(lib, u) for u in self.until]
+        self.orig_until = [getattr(lib, u) for _, u in self.until]
         self.records = []          # ([(start_event, end_event), ...], key, bytes)
         self.enabled = False
         self._open = None
@@ -176,13 +179,13 @@ class KernelClock:
                 self._open = ([(e0, e1)],) + tuple(self.describe(*args))
             return rc
         setattr(self.lib, self.name, wrapped)
-        for k, (name, orig) in enumerate(zip(self.until, self.orig_until)):
+        for (k, name), orig in zip(self.until, self.orig_until):
             def wrapped_until(*args, _k=k, _orig=orig):
                 if not (self.enabled and self._open is not None and len(self._open[0]) == _k + 1):
                     return _orig(*args)
                 rc, f0, f1 = self._timed(_orig, args)
                 self._open[0].append((f0, f1))
-                if _k + 1 == len(self.until):
+                if _k + 1 == self.n_phases:
                     self.records.append(self._open)
                     self._open = None
                 return rc
@@ -191,7 +194,7 @@ class KernelClock:
 
     def __exit__(self, *exc):
         setattr(self.lib, self.name, self.orig)
-        for name, orig in zip(self.until, self.orig_until):
+        for (_, name), orig in zip(self.until, self.orig_until):
             setattr(self.lib, name, orig)
 
     def groups(self) -> dict:
@@ -889,7 +892,7 @@ def main() -> int:
             KernelClock(L, "pp_temporal_count", lift_desc, until="pp_temporal_fill") as lift_clock, \
             KernelClock(L, "pp_coalesce_count", coalesce_desc, until="pp_coalesce_fill") as agg_clock, \
             KernelClock(L, "pp_debruijn2_lists", lambda ei_p, t_p, tdt, m, *r: ("fused order-2 builder (pp_debruijn2_lists .. pp_debruijn2_fill)", 24 * m),
-                        until=("pp_debruijn2_count", "pp_debruijn2_fill")) as fused_clock:
+                        until=("pp_debruijn2_count", ("pp_debruijn2_fill_ready", "pp_debruijn2_fill"))) as fused_clock:
         clocks = (spmm_clock, fwd_clock, bwd_clock, fill_clock, lift_clock, agg_clock, fused_clock)
         for _ in range(args.warmup):
             step(False)
