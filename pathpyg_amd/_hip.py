@@ -840,6 +840,8 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
             return None
         if not launched and (a2_bufs is None or not (a2 <= guess <= a2 + a2 // 4 + 1024)):
             a2_bufs = _a2_buffers(a2, want_weights, i32, f32)
+        if len(_A2_GUESS) >= 64 and (m, n, want_weights) not in _A2_GUESS:      # (a handful of stream shapes at a time: drop the oldest)
+            _A2_GUESS.pop(next(iter(_A2_GUESS)))
         _A2_GUESS[(m, n, want_weights)] = a2
         ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, pack, ho_fwd_w = (None if b is None else b[:k * a2] for b, k in zip(a2_bufs, (1, 1, 1, 1, 2, 1)))
         ho = CsrPlan(n_dst=u2, n_src=u2, fwd_ptr=ho_fwd_ptr[: u2 + 1], fwd_idx=ho_fwd_idx, fwd_val=ho_fwd_val,
