@@ -559,6 +559,17 @@ static inline bool gcn_wide_shape(int P, int Q) {
 // Saves the write and the re-read of G (2 of the 7 N x 64 matrix passes of the two-kernel form).
 // natural-layout rows of the layer input: B operand of the dW stream and source of the ELU' epilogue.  Lane (i, kq) owns rows 4*kq .. 4*kq+3 of
 // the tile and the CT consecutive columns CT*i ..: one vector load per row.
+__device__ __forceinline__ void buf_store_f4_nt(buf_t r, uint32_t off, float4 v) {
+    decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) t;
+    __builtin_memcpy(&t, &v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)off, 0, 2);                          // aux bit 1 = nt on gfx94x / gfx950
+}
+__device__ __forceinline__ void buf_store_f4(buf_t r, uint32_t off, float4 v) {
+    decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) t;
+    __builtin_memcpy(&t, &v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)off, 0, 0);
+}
+
 #ifndef PP_NT_XR
 #define PP_NT_XR 0
 #endif
@@ -567,7 +578,10 @@ static inline bool gcn_wide_shape(int P, int Q) {
         for (int reg = 0; reg < 4; ++reg) { \
             const int64_t r = t * 16 + 4 * kq + reg; \
             const float* xp = X + r * K + CT * i; \
-            if constexpr (CT == 4) { \
+            if constexpr (CT == 4 && !kWide) {   /* (32-bit offsets: no 64-bit lane addresses to keep across the loop) */ \
+                const float4 v = buf_load_f4(rs_xin, r < n_rows ? (uint32_t)r * (uint32_t)(K * 4) + 16u * i : kBufOob); \
+                xr[0][reg] = v.x; xr[1][reg] = v.y; xr[2][reg] = v.z; xr[3][reg] = v.w; \
+            } else if constexpr (CT == 4) { \
                 const float4 v = r < n_rows ? load_row_f4(xp, PP_NT_XR && stream_out) : make_float4(0.f, 0.f, 0.f, 0.f); \
                 xr[0][reg] = v.x; xr[1][reg] = v.y; xr[2][reg] = v.z; xr[3][reg] = v.w; \
             } else { \
@@ -608,6 +622,7 @@ __global__ __launch_bounds__(kGcnThreads, (M == 64 && K == 64 && kCap) ? PP_BWD_
     const int i = lane & 15, kq = lane >> 4;
     float* tile = s_tile[wave];
     const char* db = (const char*)D;
+    [[maybe_unused]] const buf_t rs_xin = buf_of(X), rs_din = buf_of(d_in);
     f32x4 acc_w[MT][CT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -758,7 +773,7 @@ __global__ __launch_bounds__(kGcnThreads, (M == 64 && K == 64 && kCap) ? PP_BWD_
                 for (int ct = 0; ct < CT; ++ct)
                     acc_w[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[mt][reg], xr[ct][reg], acc_w[mt][ct], 0, 0, 0);
         __builtin_amdgcn_wave_barrier();
-        float* yp = d_in + (t * 16 + 4 * kq) * K + CT * i;
+        [[maybe_unused]] float* yp = d_in + (t * 16 + 4 * kq) * K + CT * i;
         const int rows_here = n_rows - (t * 16 + 4 * kq) < 4 ? (int)(n_rows - (t * 16 + 4 * kq)) : 4;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -777,7 +792,11 @@ __global__ __launch_bounds__(kGcnThreads, (M == 64 && K == 64 && kCap) ? PP_BWD_
                 }
                 col_in[ct] += v[ct];                                  // rows past the end aggregate nothing: v == 0 there
             }
-            if (reg < rows_here) {
+            if constexpr (CT == 4 && !kWide) {
+                const uint32_t off = reg < rows_here ? (uint32_t)(t * 16 + 4 * kq + reg) * (uint32_t)(K * 4) + 16u * i : kBufOob;
+                if (stream_out) buf_store_f4_nt(rs_din, off, make_float4(v[0], v[1], v[2], v[3]));
+                else buf_store_f4(rs_din, off, make_float4(v[0], v[1], v[2], v[3]));
+            } else if (reg < rows_here) {
                 if constexpr (CT == 4) store_row_f4(yp + reg * K, make_float4(v[0], v[1], v[2], v[3]), stream_out);
                 else if constexpr (CT == 2) *(float2*)(yp + reg * K) = make_float2(v[0], v[1]);
                 else yp[reg * K] = v[0];
@@ -995,17 +1014,6 @@ struct StageArgs {
 #else
 #define PP_PROF_MARK(i) do { } while (0)
 #endif
-
-__device__ __forceinline__ void buf_store_f4_nt(buf_t r, uint32_t off, float4 v) {
-    decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) t;
-    __builtin_memcpy(&t, &v, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)off, 0, 2);                          // aux bit 1 = nt on gfx94x / gfx950
-}
-__device__ __forceinline__ void buf_store_f4(buf_t r, uint32_t off, float4 v) {
-    decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) t;
-    __builtin_memcpy(&t, &v, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)off, 0, 0);
-}
 
 // tile (16 rows, LDS, row stride 68) . W^T + bias, ELU (the second half of k_gcn_forward<64,64>) in pieces, so that requests can go out between them:
 // stage_mfma_part<C0, C1> adds the k-quarters C0 .. C1-1 to out[ct][reg] = row 4*kq + reg, column 4*i + ct; stage_mfma_finish = bias + ELU
