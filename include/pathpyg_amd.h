@@ -178,6 +178,41 @@ int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t
                            float* fo_self, const int32_t* fo_shard_bwd_ptr, int32_t* fo_shard_bwd_idx, float* fo_shard_bwd_val, void* pair_scratch,
                            void* ws, size_t ws_bytes, pp_stream_t stream);
 
+/* ------------------------------------------------------------------ all orders of a temporal stream, level by level (pp_multiorder.hip)
+ *
+ * MultiOrderModel.from_temporal_graph(g, delta, max_order >= 3), src/pathpyG/core/multi_order_model.py:124-192: lift_order_temporal
+ * (algorithms/temporal.py:17-54) followed, per order, by iterate_lift_order (multi_order_model.py:83-122) = lift_order_edge_index(_weighted,
+ * aggr="src") (algorithms/lift_order.py:48-106) + the node-sequence extension (:114) + aggregate_edge_index (lift_order.py:109-152).
+ * The layers come out as source-major CSR (int32 row pointers / columns, float32 merged weights) — the reference's edge_index is
+ * (row of every entry, column), its edge_weight the weights; neither the instance graphs [2, E_k] nor the [E_k, k] node sequences exist.
+ *
+ * A LEVEL k holds the order-(k+1) instances (time-respecting paths of k events) grouped by type (= edge of layer k = node of layer k+1),
+ * types in lexicographic order:  tptr [types + 1] instance range of every type;  ibase [types + 1] first child of every type's instances
+ * (ibase[types] = instances of level k+1);  col [types] column of the type in layer k;  tlast [types] its last node;
+ * inst [instances] 16-byte records {window first, window count | head bit, last node, float32 weight of the first event}.
+ *
+ * pp_multiorder_prepare: level 1 from a finished pp_temporal_count (same stream, same delta; `lift_ws` is its workspace).  All outputs
+ *   have capacity m (tptr / ibase: m + 1, rowptr: num_nodes + 1); `tab` [m] 16-byte records is the continuation table every step reads.
+ *   Layer 1 = (rowptr, tlast as columns, w).  pp_multiorder_result_ptr(ws) = {types, status, instances of level 2 (= E2), long runs};
+ *   status: bit 0 node index out of range, bit 1 time not ascending (both from pp_temporal_count).
+ * pp_multiorder_step: level k+1 from level k.  cand_ptr / cand_last: row pointers of layer k (over ITS nodes) and the last nodes of
+ *   level k's types (the candidates a column is looked up in; for k = 1: rowptr and tlast of pp_multiorder_prepare).  Outputs with capacity
+ *   n_children (tptr_out / ibase_out: n_children + 1): child = inst of level k+1, row_ptr [n_types + 1] = row pointers of layer k+1,
+ *   col_out / w_out = its columns and merged weights, tlast_out, tptr_out, ibase_out as above.  last != 0: the top layer — tptr_out,
+ *   ibase_out, tlast_out are not written (may be NULL).  weighted == 0: every event weighs 1 (merged weight = run length).
+ *   pp_multiorder_result_ptr(ws) = {types of level k+1, status, instances of level k+2, types handled by workgroups};
+ *   status bit 2: a type with more than 4096 children — the outputs are incomplete, use the generic kernels (pp_linegraph_*, pp_coalesce_*). */
+size_t pp_multiorder_prepare_ws_bytes(int64_t m);
+int pp_multiorder_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, const float* weight, void* lift_ws, size_t lift_ws_bytes,
+                          void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes,
+                          pp_stream_t stream);
+const int64_t* pp_multiorder_result_ptr(void* ws);
+size_t pp_multiorder_step_ws_bytes(int64_t n_types, int64_t n_children);
+int pp_multiorder_step(int64_t n_types, int64_t n_children, const int32_t* tptr, const int32_t* ibase, const int32_t* col, const void* inst,
+                       const int32_t* cand_ptr, const int32_t* cand_last, const void* tab, int weighted, int last, void* child, int32_t* row_ptr,
+                       int32_t* tptr_out, int32_t* ibase_out, int32_t* tlast_out, int32_t* col_out, float* w_out, void* ws, size_t ws_bytes,
+                       pp_stream_t stream);
+
 /* ------------------------------------------------------------------ order lifts (pp_lift.hip) */
 
 /* lift_order_temporal(g, delta) -> [2,E2] int64, src/pathpyG/algorithms/temporal.py:17-54.

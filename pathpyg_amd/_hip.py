@@ -869,6 +869,93 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
                      sizes={"m": m, "N": n, "E2": e2, "U2": u2, "A1": a1, "A2": a2, "hub_nodes": hubs, "hub_tasks": tasks})
 
 
+class MultiOrderLayer:
+    """One De Bruijn layer as source-major CSR (:func:`multi_order_temporal`): ``row_ptr`` int32 [n_nodes + 1], ``col`` int32 [n_edges], ``weight``
+    float32 [n_edges] (merged weights), ``last`` int32 [n_edges] (last first-order node of every edge = of every node of the next layer; ``None``
+    for the top layer of a build)."""
+
+    __slots__ = ("n_nodes", "n_edges", "n_instances", "row_ptr", "col", "weight", "last")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, weight: torch.Tensor | None, max_order: int):
+    """All De Bruijn layers 1..max_order of a TIME-SORTED event stream, level by level (pp_multiorder_prepare / _step, csrc/pp_multiorder.hip):
+    no instance graph ``[2, E_k]``, no per-instance node sequences, no global sort beyond the two of the first order; one read-back per order.
+    Returns ``[MultiOrderLayer]`` (index k - 1 = layer k; ``n_instances`` = E_k, the instance edges the reference would have lifted) or ``None``
+    when the generic kernels have to take over: a layer without edges, a node sequence with more than 4096 continuations (dense contact
+    streams), 2^31 or more instances at some order, an unsorted stream."""
+    ei = _edge_index(edge_index)
+    dev = require_device(ei, time, weight)
+    if time.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
+        time = time.to(torch.int64)
+    if time.dtype not in (torch.int64, torch.float64):
+        raise TypeError(f"timestamps must be int64 or float64, got {time.dtype}")
+    time = time.contiguous()
+    m, n = ei.size(1), int(num_nodes)
+    if time.numel() != m:
+        raise ValueError("time and edge_index disagree on the number of events")
+    if m == 0 or n == 0 or m >= _INT32_ROWS:
+        return None
+    if weight is not None:
+        if weight.dtype != torch.float32 or weight.numel() != m:
+            return None
+        weight = weight.contiguous()
+    kind, di, df = resolve_delta(time.dtype, delta)
+    L = lib()
+    with torch.cuda.device(dev):
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        lift_ws = _workspace(L.pp_temporal_ws_bytes(m, n), dev)
+        check(L.pp_temporal_count(_p(ei), _p(time), _DTYPE_CODE[time.dtype], m, m, n, kind, di, df, _p(lift_ws), lift_ws.numel(), _stream()),
+              "pp_temporal_count")
+        tab = torch.empty((m, 4), **i32)
+        inst = torch.empty((m, 4), **i32)
+        tptr, ibase = torch.empty(m + 1, **i32), torch.empty(m + 1, **i32)
+        tlast, w = torch.empty(m, **i32), torch.empty(m, **f32)
+        row_ptr = torch.empty(n + 1, **i32)
+        ws = _workspace(L.pp_multiorder_prepare_ws_bytes(m), dev)
+        check(L.pp_multiorder_prepare(_p(ei), m, n, _p(weight), _p(lift_ws), lift_ws.numel(), _p(tab), _p(inst), _p(tptr), _p(ibase), _p(tlast), _p(w),
+                                      _p(row_ptr), _p(ws), ws.numel(), _stream()), "pp_multiorder_prepare")
+        types, status, children, _ = ws[:32].view(torch.int64).tolist()
+        del lift_ws, ws
+        _bad_index(status, "MultiOrderModel.from_temporal_graph")
+        if status & 2:
+            return None                  # (unsorted: the caller sorts and takes the generic path)
+        layers = [MultiOrderLayer(n_nodes=n, n_edges=types, n_instances=m, row_ptr=row_ptr, col=tlast[:types], weight=w[:types], last=tlast[:types])]
+        col, cand_ptr, cand_last = tlast, row_ptr, tlast
+        for k in range(2, max_order + 1):
+            if types == 0 or children == 0 or children >= _INT32_ROWS:
+                return None
+            last = k == max_order
+            child = torch.empty((children, 4), **i32)
+            row_next = torch.empty(types + 1, **i32)
+            col_next, w_next = torch.empty(children, **i32), torch.empty(children, **f32)
+            tptr_next = ibase_next = tlast_next = None
+            if not last:
+                tptr_next, ibase_next, tlast_next = torch.empty(children + 1, **i32), torch.empty(children + 1, **i32), torch.empty(children, **i32)
+            ws = _workspace(L.pp_multiorder_step_ws_bytes(types, children), dev)
+            check(L.pp_multiorder_step(types, children, _p(tptr), _p(ibase), _p(col), _p(inst), _p(cand_ptr), _p(cand_last), _p(tab),
+                                       0 if weight is None else 1, 1 if last else 0, _p(child), _p(row_next), _p(tptr_next), _p(ibase_next),
+                                       _p(tlast_next), _p(col_next), _p(w_next), _p(ws), ws.numel(), _stream()), "pp_multiorder_step")
+            new_types, status, new_children, _ = ws[:32].view(torch.int64).tolist()
+            del ws
+            if status & 4:
+                return None
+            if 2 * new_types < children:                    # far fewer types than instances: do not keep the instance-sized buffers alive
+                col_next, w_next = col_next[:new_types].clone(), w_next[:new_types].clone()
+                if not last:
+                    tlast_next = tlast_next[:new_types].clone()
+            layers.append(MultiOrderLayer(n_nodes=types, n_edges=new_types, n_instances=children, row_ptr=row_next, col=col_next[:new_types],
+                                          weight=w_next[:new_types], last=None if last else tlast_next[:new_types]))
+            tptr, ibase, col, inst = tptr_next, ibase_next, col_next, child
+            cand_ptr, cand_last = row_next, tlast_next
+            types, children = new_types, new_children
+    return layers
+
+
 class DeBruijn2Part:
     """Count phase of the order-2 builder on ONE RANK's node range (:func:`debruijn2_part_count`): sizes on the host, everything else on
     the device until :func:`debruijn2_part_fill`."""

@@ -91,6 +91,17 @@ class MultiOrderModel:
             fused = _second_order_fused(g, delta, weight, cached)
             if fused is not None:
                 return fused
+        if max_order >= 3 and event_graph is None and FUSED_BUILDER:
+            fused = _multi_order_fused(g, delta, max_order, weight, cached)
+            if fused is not None:
+                return fused
+        return MultiOrderModel._from_temporal_graph_generic(g, delta, max_order, weight, cached, event_graph)
+
+    @staticmethod
+    def _from_temporal_graph_generic(g: TemporalGraph, delta, max_order: int, weight: str, cached: bool, event_graph) -> "MultiOrderModel":
+        """:meth:`from_temporal_graph` on the generic kernels, order by order as the reference goes: event graph (``pp_temporal_*``), line-graph
+        lifts (``pp_linegraph_*``), coalesce per layer (``pp_coalesce_*``) — any ``max_order``, ``event_graph=``, host-resident streams, weights of
+        any dtype, streams the level-by-level builders hand back."""
         m = MultiOrderModel()
         data = g.data if g.data.is_sorted_by_time() else g.data.sort_by_time()
         edge_index = data.edge_index
@@ -371,7 +382,7 @@ def _second_order_fused(g: TemporalGraph, delta, weight: str, cached: bool):
     over the stream yields both layers as CSR plans — no event graph, no ``[E_2, 2]`` instance tensors, one read-back.  The reference's layer
     tensors (reference multi_order_model.py:153-181: ``edge_index``, ``edge_weight``, ``node_sequence``, ``inverse_idx`` of both layers) are
     :class:`~pathpyg_amd.data.Lazy` views of those plans, identical to what the generic kernels produce, made when somebody reads them.
-    ``None``: the builder does not apply (host-resident stream, a weight attribute that is not float32, an unsorted stream, a hub node)."""
+    ``None``: the builder does not apply (host-resident stream, a weight attribute that is not float32, an unsorted stream)."""
     from .. import _hip
     data = g.data
     ei = _dispatch.plain(data.edge_index)
@@ -384,7 +395,7 @@ def _second_order_fused(g: TemporalGraph, delta, weight: str, cached: bool):
         if not isinstance(w, torch.Tensor) or w.dtype != torch.float32 or not w.is_cuda:
             return None
     n, m_events = int(data.num_nodes), int(ei.size(1))
-    if n == 0 or m_events == 0:
+    if n == 0 or m_events == 0 or not data.is_sorted_by_time():          # (unsorted: one cheap kernel instead of the builder's whole count pass)
         return None
     built = _hip.debruijn2(ei, time, n, delta, w, want_weights=True, unsorted_ok=True)
     if built is None:
@@ -431,6 +442,73 @@ def _second_order_fused(g: TemporalGraph, delta, weight: str, cached: bool):
         out._pp_fused = (built, {1: (g1, {"edge_index": lazy1["edge_index"], "edge_weight": (built.fo_weight, built.fo_weight._version)}),
                                  2: (g2, {"edge_index": lazy2["edge_index"], "edge_weight": lazy2["edge_weight"]})})
     out.sizes = dict(built.sizes)
+    return out
+
+
+def _multi_order_fused(g: TemporalGraph, delta, max_order: int, weight: str, cached: bool):
+    """``from_temporal_graph(g, delta, max_order >= 3)`` level by level (``_hip.multi_order_temporal`` -> ``pp_multiorder_prepare`` / ``_step``): every
+    layer comes out as source-major CSR with merged weights; the reference's layer tensors (reference multi_order_model.py:153-191) are
+    :class:`~pathpyg_amd.data.Lazy` views — ``edge_index`` = (row of every CSR entry, column), ``node_sequence`` of layer k = the sequence of the
+    entry's row in layer k-1 followed by the entry's last node (De Bruijn property: the nodes of layer k ARE the edges of layer k-1),
+    ``inverse_idx`` of the layers from 3 on through the generic kernels (it numbers the reference's instance graph, which this builder never makes).
+    ``None``: the builder does not apply (host-resident or unsorted stream, a weight attribute that is not float32, a layer without edges, a node
+    sequence with more than 4096 continuations, 2^31 instances)."""
+    from .. import _hip
+    data = g.data
+    ei = _dispatch.plain(data.edge_index)
+    time = data.time
+    if ei is None or time is None or not ei.is_cuda or not time.is_cuda:
+        return None
+    w = None
+    if weight in data:
+        w = data[weight]
+        if not isinstance(w, torch.Tensor) or w.dtype != torch.float32 or not w.is_cuda:
+            return None
+    n, m_events = int(data.num_nodes), int(ei.size(1))
+    if n == 0 or m_events == 0 or not data.is_sorted_by_time():
+        return None
+    built = _hip.multi_order_temporal(ei, time, n, delta, w, max_order)
+    if built is None:
+        return None
+    dev = ei.device
+    out = MultiOrderModel()
+    out.sizes = {"m": m_events, "N": n, "layers": [(b.n_nodes, b.n_edges, b.n_instances) for b in built]}
+    prev_index = prev_seq = None
+    for k, b in enumerate(built, start=1):
+        keep = cached or k == max_order
+
+        def index_of(b=b):
+            return torch.stack((_csr_rows(b.row_ptr, b.n_edges), b.col.long()))
+
+        index = Lazy(index_of, (2, b.n_edges))
+        if k == 1:
+            seq = Lazy(lambda: torch.arange(n, device=dev).unsqueeze(1), (n, 1))
+            inverse = Lazy(lambda: torch.arange(n, device=dev), (n,))
+        else:
+            def seq_of(prev_index=prev_index, prev_seq=prev_seq, last=built[k - 2].last):
+                # node u of layer k = edge u of layer k-1: the sequence of that edge's source node, then the edge's last node
+                return _dispatch.gather_concat(prev_seq.resolve(), prev_index.resolve()[0].contiguous(), last.long())
+
+            seq = Lazy(seq_of, (b.n_nodes, k))
+            if k == 2:
+                def inverse_of(first=prev_index):
+                    # order-2 node of every event = its merged first-order edge (lift_order.py:133 on the [m, 2] instance rows)
+                    e1 = first.resolve()
+                    return torch.searchsorted(e1[0] * n + e1[1], ei[0] * n + ei[1])
+            else:
+                def inverse_of(k=k):
+                    # the reference numbers the order-k INSTANCES (edges of the order-(k-1) instance graph, lexicographic): only the generic
+                    # kernels make that graph
+                    return MultiOrderModel._from_temporal_graph_generic(g, delta, k, weight, False, None).layers[k].data.inverse_idx
+
+            inverse = Lazy(inverse_of, (built[k - 2].n_instances,))
+        if keep:
+            d = Data(edge_index=index, num_nodes=b.n_nodes, node_sequence=seq, edge_weight=b.weight, inverse_idx=inverse)
+            mapping = g.mapping if k == 1 else IndexMap.from_node_sequence(g.mapping, seq)
+            out.layers[k] = Graph._from_parts(d, mapping)
+            if k == 2:
+                out.layers[k]._nodes_are_fo_edges = True
+        prev_index, prev_seq = index, seq
     return out
 
 

@@ -1930,7 +1930,21 @@ struct Db2Part {                   // node range of a partition shard (one GPU: 
     float* bip_self;               // [world * cap_n]
 };
 
-static thread_local hipEvent_t tls_stats_event = nullptr;      // recorded behind the copy of the hub statistics (pp_debruijn2_lists)
+// Recorded behind the asynchronous copies of the builder's statistics / sizes.  An event belongs to the device that was current when it was made and can
+// only be recorded on a stream of that device: one event per (thread, device), made on first use (one thread may build on several devices);
+// `tls_stats_event` is the one recorded last — what pp_debruijn2_wait waits for.
+static constexpr int kDb2MaxDevices = 64;
+static thread_local hipEvent_t tls_stats_events[kDb2MaxDevices] = {};
+static thread_local hipEvent_t tls_stats_event = nullptr;
+static int record_stats_event(hipStream_t st) {
+    int dev = 0;
+    PP_HIP(hipGetDevice(&dev));
+    PP_REQUIRE(dev >= 0 && dev < kDb2MaxDevices, PP_ERR_ARG, "pp_debruijn2: device ordinal %d out of range", dev);
+    if (!tls_stats_events[dev]) PP_HIP(hipEventCreateWithFlags(&tls_stats_events[dev], hipEventDisableTiming));
+    tls_stats_event = tls_stats_events[dev];
+    PP_HIP(hipEventRecord(tls_stats_event, st));
+    return PP_OK;
+}
 
 // 1. event records; out-lists (stable sort by tail: time order inside a list), then the list SEQUENCE sorted by head: in-lists in (source, time)
 //    order; row pointers of both; one GPU: hub classification, its totals copied to `host_stats` (asynchronously), then the out-side kernel of
@@ -1950,8 +1964,7 @@ static int db2_lists(const char* who, const int64_t* edge_index, const void* tim
     if (m == 0 || n == 0) {
         if (host_stats) {
             PP_HIP(hipMemcpyAsync(host_stats, w.result + kDb2HubStats, kDb2HubStatCount * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-            if (!tls_stats_event) PP_HIP(hipEventCreateWithFlags(&tls_stats_event, hipEventDisableTiming));
-            PP_HIP(hipEventRecord(tls_stats_event, st));
+            { const int erc = record_stats_event(st); if (erc != PP_OK) return erc; }
         }
         return PP_OK;
     }
@@ -1977,8 +1990,7 @@ static int db2_lists(const char* who, const int64_t* edge_index, const void* tim
         PP_LAUNCH_CHECK();
         if (host_stats) {
             PP_HIP(hipMemcpyAsync(host_stats, w.result + kDb2HubStats, kDb2HubStatCount * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-            if (!tls_stats_event) PP_HIP(hipEventCreateWithFlags(&tls_stats_event, hipEventDisableTiming));
-            PP_HIP(hipEventRecord(tls_stats_event, st));
+            { const int erc = record_stats_event(st); if (erc != PP_OK) return erc; }
         }
     }
     // 2. successors of every node with at most 64 out-events -> block sizes of the order-2 node ids
@@ -2146,8 +2158,7 @@ static int db2_count(const char* who, int time_dtype, int64_t m, int64_t n, cons
         // the sizes travel to the caller's pinned buffer NOW; the first kernel of the fill pass that needs no size (degree^-1/2 + row start of every
         // order-2 row, packed) is queued behind the copy and runs while the host wakes up and sizes the plans
         PP_HIP(hipMemcpyAsync(host_result, w.result, kDb2Result * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        if (!tls_stats_event) PP_HIP(hipEventCreateWithFlags(&tls_stats_event, hipEventDisableTiming));
-        PP_HIP(hipEventRecord(tls_stats_event, st));
+        { const int erc = record_stats_event(st); if (erc != PP_OK) return erc; }
         if (!part) {
             k_db2_pack_rows<<<egrid, kBlock, 0, st>>>(m, ho_deg, ho_bwd_ptr, w.row_pack);
             PP_LAUNCH_CHECK();

@@ -1460,7 +1460,9 @@ int pp_gcn_backward_nnz_f32(const int32_t* ptr, const int32_t* idx, const float*
     PP_REQUIRE(pp_dense_supported(M, K) == 1, PP_ERR_ARG, "pp_gcn_backward_f32: unsupported layer shape %dx%d (supported: 16/32/64)", M, K);
     PP_REQUIRE((n_rows == 0 || d_in != nullptr) && dW != nullptr, PP_ERR_ARG, "pp_gcn_backward_f32: d_in and dW are required");
     PP_REQUIRE(((uintptr_t)D) % 16 == 0, PP_ERR_ARG, "pp_gcn_backward_f32: D must be 16-byte aligned");
-    const bool wide = (uint64_t)n_rows * (uint64_t)M * 4 >= (uint64_t)pp::kBufOob || n_rows >= ((int64_t)1 << 30) - 64;      // 64-bit row addresses
+    // 64-bit row addresses as soon as ANY of the addressed matrices reaches 4 GiB: D is [n_rows, M], X and d_in are [n_rows, K] (with
+    // M < K the gradient fitted 32-bit offsets while X / d_in did not, and their offsets wrapped)
+    const bool wide = (uint64_t)n_rows * (uint64_t)(M > K ? M : K) * 4 >= (uint64_t)pp::kBufOob || n_rows >= ((int64_t)1 << 30) - 64;
     PP_REQUIRE(ws_bytes >= pp_gcn_backward_ws_bytes(n_rows), PP_ERR_WORKSPACE, "pp_gcn_backward_f32: workspace too small");
     if (colsum_in) PP_HIP(hipMemsetAsync(colsum_in, 0, (size_t)K * sizeof(float), st));
     if (n_rows == 0) {

@@ -43,6 +43,17 @@ template <typename KeyT>
 int sort_pairs(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out, int64_t n, int begin_bit,
                int end_bit, void* ws, size_t ws_bytes, hipStream_t st);
 
+// pp_lift.hip: views into the workspace of a finished pp_temporal_count (m events, num_nodes nodes)
+struct TemporalLists {
+    const uint32_t* ids;         // [m] event ids grouped by tail node, ascending (= time order) inside a node's list
+    const uint32_t* rowptr;      // [num_nodes + 1] list bounds
+    const uint32_t* first_pos;   // [m] per event: position in `ids` of its first continuation
+    const int32_t* count;        // [m] per event: number of continuations (consecutive entries of `ids`)
+    const int64_t* result;       // {E2, status}
+    size_t total_bytes;
+};
+TemporalLists temporal_lists(void* ws, int64_t m, int64_t num_nodes);
+
 // pp_dbgnn.hip
 int weight_grad_reduce(const float* partial_w, const float* partial_b, int64_t n_parts, int M, int K, float* dW, float* db, hipStream_t st);
 

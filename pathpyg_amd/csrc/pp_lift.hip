@@ -616,6 +616,12 @@ static LiftWs carve_lift(void* ws, int64_t n_src, int64_t num_nodes, bool tempor
     return w;
 }
 
+// the per-node event lists and per-event continuation windows pp_temporal_count left in its workspace (pp_multiorder.hip builds on them)
+TemporalLists temporal_lists(void* ws, int64_t m, int64_t num_nodes) {
+    const LiftWs w = carve_lift(ws, m, num_nodes, true);
+    return TemporalLists{w.ids, w.rowptr, w.first_pos, w.count, w.result, w.total_bytes};
+}
+
 // the per-tile start sources come from the count phase's scan when the result is at most 32x the source count; beyond that every
 // wave searches for its own start (amortised by the amount of output per source)
 template <bool kList>

@@ -1,0 +1,566 @@
+// pathpyg_amd — the De Bruijn layers of ALL orders of a temporal stream, level by level, without instance graphs (round 6).
+//
+// Reference path replaced (paths relative to the pathpyG repository root):
+//   MultiOrderModel.from_temporal_graph, max_order >= 3     src/pathpyG/core/multi_order_model.py:124-192
+//     = lift_order_temporal                                 src/pathpyG/algorithms/temporal.py:17-54
+//     + per order: iterate_lift_order                       src/pathpyG/core/multi_order_model.py:83-122
+//         lift_order_edge_index(_weighted, aggr="src")      src/pathpyG/algorithms/lift_order.py:48-106
+//         node-sequence extension                           src/pathpyG/core/multi_order_model.py:114
+//         aggregate_edge_index (unique rows + coalesce)     src/pathpyG/algorithms/lift_order.py:109-152
+//
+// The reference (and the generic kernels of this library) materialise the order-k INSTANCE graph [2, E_k], its [E_k, k] node
+// sequences, sort them (torch.unique(dim=0)) and sort the remapped edges again (coalesce) — per order.  None of that is needed:
+//
+//   * An order-(k+1) instance is a time-respecting path of k events.  All that the NEXT order ever asks of it is (i) its TYPE — the
+//     node sequence it realises, i.e. a node of layer k+1 = an edge of layer k (De Bruijn property) —, (ii) the continuations of its
+//     LAST event, and (iii) the weight of its first event (lift_order_edge_index_weighted with aggr="src" hands it down unchanged).
+//   * The continuations of an event are a contiguous window of the time-ordered out-list of its head node (pp_temporal_count).  `tab`
+//     holds, per list position, {head node of that event, ITS window (first, count), event id}: reading the window of an instance's
+//     last event yields, per child instance, the new last node AND the child's own window — one random 16..128-byte access per parent.
+//   * Instances are kept GROUPED BY TYPE, types in lexicographic order of their node sequences, instances of one type in lexicographic
+//     order of their event sequences (= the reference's instance numbering restricted to the type).  The children of all instances of
+//     type s, stably sorted by their new last node d, are then exactly the instances of the types s ++ d, in the right order: the
+//     global sorts of the reference shrink to one tiny sort per type (a lane's registers; LDS for hubs), the weight of a merged edge is
+//     the count (or the left-to-right sum, PyG's coalesce order) of a run, and everything is written sequentially.
+//   * Layer k+1's edge (s -> c): c is the type suffix(s) ++ d.  suffix(s) is the column u of s in layer k, the candidates are u's
+//     out-edges in layer k (one contiguous id block, last nodes ascending): a bisection in a handful of entries.
+//
+// Per level: k_mo_children (+ k_mo_children_big) -> scan of the row lengths -> k_mo_types (+ k_mo_types_big) -> scan of the children
+// counts.  No read-back between them; the caller reads {types, status, children of the next level} once per level.
+// Algorithmic bytes per level (what the generic kernels move — 16 E_k + 16 E_{k+1} for the lift, 8 k E_{k+1} for the
+// sequences, 16 E_{k+1} + 20 A_{k+1} for the aggregation) are reported by bench.py beside the time; the bytes this path moves are
+// 16 I_k + 32 I_{k+1} + 20 A_{k+1} + the window reads.
+#include "pp_internal.h"
+
+namespace pp {
+
+constexpr int64_t kMoBadIndex = 1, kMoUnsorted = 2, kMoOverflow = 4;
+constexpr int kMoSmall = 8;              // children of one type a single lane sorts in registers
+constexpr int kMoSmallParents = 8;       // ... and instances of that type it walks
+#ifndef PP_MO_BIG
+#define PP_MO_BIG 4096
+#endif
+constexpr int kMoBigMax = PP_MO_BIG;     // children of one type a workgroup sorts in LDS; beyond: status bit kMoOverflow (caller falls back)
+constexpr int kMoLongRun = 128;          // level 1: events of one node pair summed by a wave instead of a lane
+constexpr uint32_t kHeadBit = 0x80000000u;
+
+// an instance: {first, count | head bit} of its last event's window in `tab`, last node, weight of its first event
+__device__ __forceinline__ uint4 mo_inst(uint32_t cf, uint32_t cc, bool head, uint32_t d, float w) {
+    return make_uint4(cf, cc | (head ? kHeadBit : 0u), d, __float_as_uint(w));
+}
+__device__ __forceinline__ bool mo_small(int parents, int children) { return parents <= kMoSmallParents && children <= kMoSmall; }
+
+// ------------------------------------------------------------------ level 1: the events grouped by (source, target), time order inside
+__global__ __launch_bounds__(kBlock) void k_mo_key_dst(const int64_t* __restrict__ dst, int64_t m, uint32_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < m) keys[i] = (uint32_t)dst[i];
+}
+__global__ __launch_bounds__(kBlock) void k_mo_key_src(const int64_t* __restrict__ src, const uint32_t* __restrict__ perm, int64_t m,
+                                                      uint32_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < m) keys[i] = (uint32_t)src[perm[i]];
+}
+__global__ __launch_bounds__(kBlock) void k_mo_key_pair(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t m, int bits,
+                                                       uint32_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < m) keys[i] = ((uint32_t)src[i] << bits) | (uint32_t)dst[i];
+}
+
+// position j of the (source, target, time) order: the node pair of its event
+__global__ __launch_bounds__(kBlock) void k_mo_pairs(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const uint32_t* __restrict__ perm,
+                                                    int64_t m, uint2* __restrict__ ab) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t e = perm[j];
+    ab[j] = make_uint2((uint32_t)src[e], (uint32_t)dst[e]);
+}
+
+// the level-1 instance of position j + the flag "first event of its node pair"
+__global__ __launch_bounds__(kBlock) void k_mo_inst1(const uint2* __restrict__ ab, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ first_pos,
+                                                    const int32_t* __restrict__ count, const float* __restrict__ weight, int64_t m,
+                                                    uint4* __restrict__ inst, int32_t* __restrict__ head) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= m) return;
+    const uint2 me = ab[j];
+    bool h = j == 0;
+    if (!h) { const uint2 pv = ab[j - 1]; h = pv.x != me.x || pv.y != me.y; }
+    const uint32_t e = perm[j];
+    inst[j] = mo_inst(first_pos[e], (uint32_t)count[e], h, me.y, weight ? weight[e] : 1.0f);
+    head[j] = h ? 1 : 0;
+}
+
+// the types of level 1 = layer 1's edges: instance range, last node (= column), row pointers over the first-order nodes
+__global__ __launch_bounds__(kBlock) void k_mo_types1(const uint2* __restrict__ ab, const int32_t* __restrict__ head_before, int64_t m, int64_t n,
+                                                     int32_t* __restrict__ tptr, int32_t* __restrict__ tlast, int32_t* __restrict__ rowptr) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= m) return;
+    const int32_t t = head_before[j];
+    const bool h = head_before[j + 1] != t;
+    const uint2 me = ab[j];
+    if (h) {
+        tptr[t] = (int32_t)j;
+        tlast[t] = (int32_t)me.y;
+        const int64_t a_prev = j == 0 ? -1 : (int64_t)ab[j - 1].x;
+        for (int64_t v = a_prev + 1; v <= (int64_t)me.x; ++v) rowptr[v] = t;
+    }
+    if (j == m - 1) {
+        const int32_t total = head_before[m];
+        tptr[total] = (int32_t)m;
+        for (int64_t v = (int64_t)me.x + 1; v <= n; ++v) rowptr[v] = total;
+    }
+}
+
+// merged weight (run length, or the left-to-right sum: PyG's coalesce order) and number of children of every level-1 type
+template <bool kWeighted>
+__global__ __launch_bounds__(kBlock) void k_mo_sums1(const int32_t* __restrict__ tptr, const int32_t* __restrict__ n_types, const uint4* __restrict__ inst,
+                                                    float* __restrict__ w, int32_t* __restrict__ csum, int32_t* __restrict__ long_list,
+                                                    int32_t* __restrict__ long_count) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= *n_types) return;
+    const int32_t x0 = tptr[t], x1 = tptr[t + 1];
+    if (x1 - x0 > kMoLongRun) { long_list[atomicAdd(long_count, 1)] = (int32_t)t; return; }
+    float acc = 0.f;
+    int32_t c = 0;
+    for (int32_t x = x0; x < x1; ++x) {
+        const uint4 it = inst[x];
+        acc += __uint_as_float(it.w);
+        c += (int32_t)(it.y & ~kHeadBit);
+    }
+    w[t] = kWeighted ? acc : (float)(x1 - x0);
+    csum[t] = c;
+}
+
+// node pairs with very many events: one wave per pair, every lane a contiguous chunk left to right, chunks combined in lane order
+template <bool kWeighted>
+__global__ __launch_bounds__(kBlock) void k_mo_sums1_long(const int32_t* __restrict__ tptr, const uint4* __restrict__ inst, const int32_t* __restrict__ long_list,
+                                                         const int32_t* __restrict__ long_count, float* __restrict__ w, int32_t* __restrict__ csum) {
+    const int n_long = *long_count;
+    for (int g = blockIdx.x * kWavesPerBlock + wave_id(); g < n_long; g += gridDim.x * kWavesPerBlock) {
+        const int32_t t = long_list[g];
+        const int32_t x0 = tptr[t], x1 = tptr[t + 1];
+        const int32_t chunk = (x1 - x0 + kWave - 1) / kWave;
+        const int32_t b = x0 + lane_id() * chunk, e = b + chunk < x1 ? b + chunk : x1;
+        float acc = 0.f;
+        int32_t c = 0;
+        for (int32_t x = b; x < e; ++x) {
+            const uint4 it = inst[x];
+            acc += __uint_as_float(it.w);
+            c += (int32_t)(it.y & ~kHeadBit);
+        }
+        float total = 0.f;
+        for (int l = 0; l < kWave; ++l) total += __shfl(acc, l, kWave);        // fixed order
+        c = wave_sum<int32_t>(c);
+        if (lane_id() == 0) { w[t] = kWeighted ? total : (float)(x1 - x0); csum[t] = c; }
+    }
+}
+
+// tab[p]: the event at position p of the per-node out-lists — its head node, its own continuation window, its id
+__global__ __launch_bounds__(kBlock) void k_mo_tab(const uint32_t* __restrict__ ids, const int64_t* __restrict__ dst, const uint32_t* __restrict__ first_pos,
+                                                  const int32_t* __restrict__ count, int64_t m, uint4* __restrict__ tab) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m) return;
+    const uint32_t l = ids[p];
+    tab[p] = make_uint4((uint32_t)dst[l], first_pos[l], (uint32_t)count[l], l);
+}
+
+// ------------------------------------------------------------------ one level: children of every type, sorted by their new last node
+// stable odd-even transposition sort of 8 register slots by d (strict compare: equal last nodes keep their order)
+#define PP_MO_CE(i, j)                                                                                  \
+    do {                                                                                                \
+        const bool sw = d[i] > d[j];                                                                    \
+        const uint32_t td = sw ? d[j] : d[i], tf = sw ? cf[j] : cf[i], tc = sw ? cc[j] : cc[i], tw = sw ? w[j] : w[i]; \
+        d[j] = sw ? d[i] : d[j]; cf[j] = sw ? cf[i] : cf[j]; cc[j] = sw ? cc[i] : cc[j]; w[j] = sw ? w[i] : w[j];      \
+        d[i] = td; cf[i] = tf; cc[i] = tc; w[i] = tw;                                                   \
+    } while (0)
+
+__global__ __launch_bounds__(kBlock) void k_mo_children(int64_t n_types, const int32_t* __restrict__ tptr, const int32_t* __restrict__ ibase,
+                                                       const uint4* __restrict__ inst, const uint4* __restrict__ tab, uint4* __restrict__ out,
+                                                       int32_t* __restrict__ deg, int32_t* __restrict__ big_list, int32_t* __restrict__ big_count) {
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n_types) return;
+    const int32_t x0 = tptr[s], x1 = tptr[s + 1];
+    const int32_t c0 = ibase[s], n = ibase[s + 1] - c0;
+    if (n == 0) { deg[s] = 0; return; }
+    if (!mo_small(x1 - x0, n)) { big_list[atomicAdd(big_count, 1)] = (int32_t)s; return; }
+    uint32_t d[kMoSmall], cf[kMoSmall], cc[kMoSmall], w[kMoSmall];
+#pragma unroll
+    for (int q = 0; q < kMoSmall; ++q) { d[q] = 0xFFFFFFFFu; cf[q] = 0; cc[q] = 0; w[q] = 0; }
+    if (x1 - x0 == 1) {
+        // one instance (the rule on sparse streams): its window's entries requested back to back
+        const uint4 pi = inst[x0];
+        const uint4* src = tab + pi.x;
+#pragma unroll
+        for (int q = 0; q < kMoSmall; ++q)
+            if (q < n) { const uint4 e = src[q]; d[q] = e.x; cf[q] = e.y; cc[q] = e.z; w[q] = pi.w; }
+    } else {
+        int filled = 0;
+        for (int32_t x = x0; x < x1; ++x) {
+            const uint4 pi = inst[x];
+            const int c = (int)(pi.y & ~kHeadBit);
+            for (int j = 0; j < c; ++j) {
+                const uint4 e = tab[pi.x + j];
+#pragma unroll
+                for (int q = 0; q < kMoSmall; ++q)
+                    if (q == filled) { d[q] = e.x; cf[q] = e.y; cc[q] = e.z; w[q] = pi.w; }
+                ++filled;
+            }
+        }
+    }
+    if (n > 1) {
+#pragma unroll
+        for (int round = 0; round < kMoSmall; ++round) {
+            if ((round & 1) == 0) { PP_MO_CE(0, 1); PP_MO_CE(2, 3); PP_MO_CE(4, 5); PP_MO_CE(6, 7); }
+            else { PP_MO_CE(1, 2); PP_MO_CE(3, 4); PP_MO_CE(5, 6); }
+        }
+    }
+    int heads = 0;
+#pragma unroll
+    for (int q = 0; q < kMoSmall; ++q) {
+        if (q < n) {
+            const bool h = q == 0 || d[q] != d[q > 0 ? q - 1 : 0];
+            heads += h ? 1 : 0;
+            out[c0 + q] = make_uint4(cf[q], cc[q] | (h ? kHeadBit : 0u), d[q], w[q]);
+        }
+    }
+    deg[s] = heads;
+}
+
+// types with more children (or instances) than a lane takes: one workgroup each, (last node, slot) keys sorted in LDS
+__global__ __launch_bounds__(kBlock) void k_mo_children_big(const int32_t* __restrict__ tptr, const int32_t* __restrict__ ibase, const uint4* __restrict__ inst,
+                                                           const uint4* __restrict__ tab, uint4* __restrict__ out, int32_t* __restrict__ deg,
+                                                           const int32_t* __restrict__ big_list, const int32_t* __restrict__ big_count,
+                                                           int64_t* __restrict__ status) {
+    __shared__ uint32_t s_src[kMoBigMax];
+    __shared__ uint32_t s_w[kMoBigMax];
+    __shared__ uint64_t s_key[kMoBigMax];
+    __shared__ uint32_t s_scratch[kWavesPerBlock + 1];
+    const int n_big = *big_count;
+    const int tid = threadIdx.x;
+    for (int g = blockIdx.x; g < n_big; g += gridDim.x) {
+        const int32_t s = big_list[g];
+        const int32_t x0 = tptr[s], x1 = tptr[s + 1];
+        const int32_t c0 = ibase[s], n = ibase[s + 1] - c0;
+        if (n > kMoBigMax) {                 // (uniform)
+            if (tid == 0) { atomicOr((unsigned long long*)status, (unsigned long long)kMoOverflow); deg[s] = 0; }
+            continue;
+        }
+        uint32_t running = 0;
+        for (int32_t xb = x0; xb < x1; xb += kBlock) {
+            const int32_t x = xb + tid;
+            uint4 pi = make_uint4(0u, 0u, 0u, 0u);
+            if (x < x1) pi = inst[x];
+            const uint32_t c = pi.y & ~kHeadBit;
+            uint32_t total;
+            const uint32_t at = running + block_exclusive_sum<uint32_t>(c, s_scratch, &total);
+            for (uint32_t j = 0; j < c; ++j) { s_src[at + j] = pi.x + j; s_w[at + j] = pi.w; }
+            running += total;
+        }
+        __syncthreads();
+        int np2 = 2;
+        while (np2 < n) np2 <<= 1;
+        for (int c = tid; c < np2; c += kBlock) s_key[c] = c < n ? (((uint64_t)tab[s_src[c]].x << 32) | (uint64_t)c) : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= np2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < np2; i += kBlock) {
+                    const int o = i ^ j;
+                    if (o > i) {
+                        const uint64_t a = s_key[i], b = s_key[o];
+                        if ((a > b) == ((i & k) == 0)) { s_key[i] = b; s_key[o] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        uint32_t heads = 0;
+        for (int r = tid; r < n; r += kBlock) {
+            const uint64_t key = s_key[r];
+            const uint32_t c = (uint32_t)key, dd = (uint32_t)(key >> 32);
+            const bool h = r == 0 || (uint32_t)(s_key[r - 1] >> 32) != dd;
+            const uint4 e = tab[s_src[c]];
+            out[c0 + r] = make_uint4(e.y, e.z | (h ? kHeadBit : 0u), dd, s_w[c]);
+            heads += h ? 1u : 0u;
+        }
+        uint32_t total;
+        block_exclusive_sum<uint32_t>(heads, s_scratch, &total);
+        if (tid == 0) deg[s] = (int32_t)total;
+        __syncthreads();
+    }
+}
+
+// position of `key` among the ascending last nodes cand[0 .. bc) of the candidate block (it is there: the suffix of a path is a path)
+__device__ __forceinline__ int32_t mo_find(const int32_t* __restrict__ cand, int32_t lo, int32_t bc, int32_t key) {
+    int32_t hi = bc;
+    while (lo < hi) {
+        const int32_t mid = lo + ((hi - lo) >> 1);
+        if (cand[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// the new types of every parent type: instance range, last node, column (= id of the suffix type), merged weight, number of children.
+// kLast: the top layer — only columns and weights are wanted
+template <bool kWeighted, bool kLast>
+__global__ __launch_bounds__(kBlock) void k_mo_types(int64_t n_types, const int32_t* __restrict__ tptr, const int32_t* __restrict__ ibase,
+                                                    const int32_t* __restrict__ col, const int32_t* __restrict__ cand_ptr,
+                                                    const int32_t* __restrict__ cand_last, const uint4* __restrict__ child,
+                                                    const int32_t* __restrict__ row_ptr, int32_t* __restrict__ tptr_out, int32_t* __restrict__ tlast_out,
+                                                    int32_t* __restrict__ col_out, float* __restrict__ w_out, int32_t* __restrict__ csum_out) {
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n_types) return;
+    const int32_t c0 = ibase[s], n = ibase[s + 1] - c0;
+    if (!kLast && s == n_types - 1) tptr_out[row_ptr[n_types]] = ibase[n_types];
+    if (n == 0 || !mo_small(tptr[s + 1] - tptr[s], n)) return;
+    const int32_t u = col[s];
+    const int32_t bf = cand_ptr[u], bc = cand_ptr[u + 1] - bf;
+    const int32_t* cand = cand_last + bf;
+    uint4 it[kMoSmall];
+#pragma unroll
+    for (int q = 0; q < kMoSmall; ++q) it[q] = q < n ? child[c0 + q] : make_uint4(0u, 0u, 0u, 0u);
+    int32_t pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pre[q] = q < bc ? cand[q] : 0x7fffffff;
+    int32_t t = row_ptr[s] - 1;
+    int32_t at = 0;                      // candidates below `at` are smaller than the current last node
+    float acc = 0.f;
+    int32_t cnt = 0, cs = 0;
+#pragma unroll
+    for (int q = 0; q < kMoSmall; ++q) {
+        if (q < n) {
+            if (it[q].y & kHeadBit) {
+                if (cnt) { w_out[t] = kWeighted ? acc : (float)cnt; if (!kLast) csum_out[t] = cs; }
+                ++t;
+                acc = 0.f; cnt = 0; cs = 0;
+                const int32_t dd = (int32_t)it[q].z;
+                int32_t pos;
+                if (dd <= pre[3]) pos = dd <= pre[0] ? 0 : (dd <= pre[1] ? 1 : (dd <= pre[2] ? 2 : 3));
+                else pos = mo_find(cand, at > 4 ? at : 4, bc, dd);
+                at = pos + 1;
+                col_out[t] = bf + pos;
+                if (!kLast) { tptr_out[t] = c0 + q; tlast_out[t] = dd; }
+            }
+            acc += __uint_as_float(it[q].w);
+            ++cnt;
+            cs += (int32_t)(it[q].y & ~kHeadBit);
+        }
+    }
+    if (cnt) { w_out[t] = kWeighted ? acc : (float)cnt; if (!kLast) csum_out[t] = cs; }
+}
+
+template <bool kWeighted, bool kLast>
+__global__ __launch_bounds__(kBlock) void k_mo_types_big(const int32_t* __restrict__ ibase, const int32_t* __restrict__ col, const int32_t* __restrict__ cand_ptr,
+                                                        const int32_t* __restrict__ cand_last, const uint4* __restrict__ child,
+                                                        const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ big_list,
+                                                        const int32_t* __restrict__ big_count, int32_t* __restrict__ tptr_out,
+                                                        int32_t* __restrict__ tlast_out, int32_t* __restrict__ col_out, float* __restrict__ w_out,
+                                                        int32_t* __restrict__ csum_out) {
+    __shared__ uint32_t s_scratch[kWavesPerBlock + 1];
+    const int n_big = *big_count;
+    const int tid = threadIdx.x;
+    for (int g = blockIdx.x; g < n_big; g += gridDim.x) {
+        const int32_t s = big_list[g];
+        const int32_t c0 = ibase[s], n = ibase[s + 1] - c0;
+        if (n > kMoBigMax) continue;
+        const int32_t u = col[s];
+        const int32_t bf = cand_ptr[u], bc = cand_ptr[u + 1] - bf;
+        const int32_t t0 = row_ptr[s];
+        uint32_t ranks = 0;
+        for (int32_t rb = 0; rb < n; rb += kBlock) {
+            const int32_t r = rb + tid;
+            uint4 it = make_uint4(0u, 0u, 0u, 0u);
+            if (r < n) it = child[c0 + r];
+            const bool h = r < n && (it.y & kHeadBit);
+            uint32_t total;
+            const uint32_t ex = block_exclusive_sum<uint32_t>(h ? 1u : 0u, s_scratch, &total);
+            if (h) {
+                const int32_t t = t0 + (int32_t)(ranks + ex);
+                const int32_t dd = (int32_t)it.z;
+                col_out[t] = bf + mo_find(cand_last + bf, 0, bc, dd);
+                if (!kLast) { tptr_out[t] = c0 + r; tlast_out[t] = dd; }
+                float acc = __uint_as_float(it.w);
+                int32_t cnt = 1, cs = (int32_t)(it.y & ~kHeadBit);
+                for (int32_t q = r + 1; q < n; ++q) {
+                    const uint4 nx = child[c0 + q];
+                    if (nx.y & kHeadBit) break;
+                    acc += __uint_as_float(nx.w);
+                    ++cnt;
+                    cs += (int32_t)(nx.y & ~kHeadBit);
+                }
+                w_out[t] = kWeighted ? acc : (float)cnt;
+                if (!kLast) csum_out[t] = cs;
+            }
+            ranks += total;
+        }
+    }
+}
+
+struct MoPrepWs {
+    int64_t* result;          // {types of level 1, status, children of level 1 (= E2), node pairs with long runs}
+    uint32_t *keys_a, *keys_b, *vals_a, *vals_b;
+    uint2* ab;
+    int32_t *head, *head_before, *csum, *long_list, *counters;
+    void* scratch;
+    size_t scratch_bytes, total_bytes;
+};
+
+static MoPrepWs carve_mo_prep(void* ws, int64_t m) {
+    Arena a(ws, (size_t)-1);
+    MoPrepWs w;
+    w.result = a.take<int64_t>(4);
+    w.keys_a = a.take<uint32_t>(m);
+    w.keys_b = a.take<uint32_t>(m);
+    w.vals_a = a.take<uint32_t>(m);
+    w.vals_b = a.take<uint32_t>(m);
+    w.ab = a.take<uint2>(m);
+    w.head = a.take<int32_t>(m);
+    w.head_before = a.take<int32_t>(m + 1);
+    w.csum = a.take<int32_t>(m);
+    w.long_list = a.take<int32_t>(m);
+    w.counters = a.take<int32_t>(4);
+    const size_t s1 = sort_ws_bytes(m, 4), s2 = scan_ws_bytes(m + 1);
+    w.scratch_bytes = s1 > s2 ? s1 : s2;
+    w.scratch = a.take<char>((int64_t)w.scratch_bytes);
+    w.total_bytes = a.used;
+    return w;
+}
+
+struct MoStepWs {
+    int64_t* result;          // {new types, status, children of the new level, types handled by workgroups}
+    int32_t *deg, *csum, *big_list, *counters;
+    void* scratch;
+    size_t scratch_bytes, total_bytes;
+};
+
+static MoStepWs carve_mo_step(void* ws, int64_t n_types, int64_t n_children) {
+    Arena a(ws, (size_t)-1);
+    MoStepWs w;
+    w.result = a.take<int64_t>(4);
+    w.deg = a.take<int32_t>(n_types);
+    w.csum = a.take<int32_t>(n_children);
+    w.big_list = a.take<int32_t>(n_types);
+    w.counters = a.take<int32_t>(4);
+    const int64_t longest = n_types > n_children ? n_types : n_children;
+    w.scratch_bytes = scan_ws_bytes(longest + 1);
+    w.scratch = a.take<char>((int64_t)w.scratch_bytes);
+    w.total_bytes = a.used;
+    return w;
+}
+
+__global__ void k_mo_finish(const int32_t* __restrict__ counters, const int64_t* __restrict__ lift_result, int64_t* __restrict__ result) {
+    result[3] = counters[0];
+    if (lift_result) atomicOr((unsigned long long*)(result + 1), (unsigned long long)lift_result[1]);
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" {
+
+size_t pp_multiorder_prepare_ws_bytes(int64_t m) { return carve_mo_prep(nullptr, m).total_bytes; }
+
+int pp_multiorder_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, const float* weight, void* lift_ws, size_t lift_ws_bytes,
+                          void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes,
+                          pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(m > 0 && num_nodes > 0, PP_ERR_ARG, "pp_multiorder_prepare: empty stream");
+    PP_REQUIRE(m < (int64_t)0x7ffffff0 && num_nodes < ((int64_t)1 << 31), PP_ERR_TOO_LARGE, "pp_multiorder_prepare: m or num_nodes >= 2^31");
+    const TemporalLists tl = temporal_lists(lift_ws, m, num_nodes);
+    PP_REQUIRE(lift_ws_bytes >= tl.total_bytes, PP_ERR_WORKSPACE, "pp_multiorder_prepare: not a pp_temporal_count workspace of this stream");
+    MoPrepWs p = carve_mo_prep(ws, m);
+    PP_REQUIRE(ws_bytes >= p.total_bytes, PP_ERR_WORKSPACE, "pp_multiorder_prepare: workspace too small");
+    PP_HIP(hipMemsetAsync(p.result, 0, 4 * sizeof(int64_t), st));
+    PP_HIP(hipMemsetAsync(p.counters, 0, 4 * sizeof(int32_t), st));
+    PP_HIP(hipMemsetAsync(p.csum, 0, (size_t)m * sizeof(int32_t), st));
+    const int64_t* src = edge_index;
+    const int64_t* dst = edge_index + m;
+    const unsigned grid = (unsigned)ceil_div(m, kBlock);
+    const int bits = bits_for((uint64_t)(num_nodes - 1));
+    const uint32_t* perm;
+    int rc;
+    // the events in (source, target, time) order: stable sorts of the time-ordered stream
+    if (2 * bits <= 32) {
+        k_mo_key_pair<<<grid, kBlock, 0, st>>>(src, dst, m, bits, p.keys_a);
+        PP_LAUNCH_CHECK();
+        rc = sort_pairs<uint32_t>(p.keys_a, nullptr, p.keys_b, p.vals_b, m, 0, 2 * bits, p.scratch, p.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+        perm = p.vals_b;
+    } else {
+        k_mo_key_dst<<<grid, kBlock, 0, st>>>(dst, m, p.keys_a);
+        PP_LAUNCH_CHECK();
+        rc = sort_pairs<uint32_t>(p.keys_a, nullptr, p.keys_b, p.vals_a, m, 0, bits, p.scratch, p.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+        k_mo_key_src<<<grid, kBlock, 0, st>>>(src, p.vals_a, m, p.keys_a);
+        PP_LAUNCH_CHECK();
+        rc = sort_pairs<uint32_t>(p.keys_a, p.vals_a, p.keys_b, p.vals_b, m, 0, bits, p.scratch, p.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+        perm = p.vals_b;
+    }
+    k_mo_pairs<<<grid, kBlock, 0, st>>>(src, dst, perm, m, p.ab);
+    PP_LAUNCH_CHECK();
+    k_mo_inst1<<<grid, kBlock, 0, st>>>(p.ab, perm, tl.first_pos, tl.count, weight, m, (uint4*)inst, p.head);
+    PP_LAUNCH_CHECK();
+    rc = exclusive_scan<int32_t, int32_t>(p.head, m, p.head_before, true, p.result, p.scratch, p.scratch_bytes, st);
+    if (rc != PP_OK) return rc;
+    k_mo_types1<<<grid, kBlock, 0, st>>>(p.ab, p.head_before, m, num_nodes, tptr, tlast, rowptr);
+    PP_LAUNCH_CHECK();
+    if (weight) k_mo_sums1<true><<<grid, kBlock, 0, st>>>(tptr, p.head_before + m, (const uint4*)inst, w, p.csum, p.long_list, p.counters);
+    else k_mo_sums1<false><<<grid, kBlock, 0, st>>>(tptr, p.head_before + m, (const uint4*)inst, w, p.csum, p.long_list, p.counters);
+    PP_LAUNCH_CHECK();
+    if (weight) k_mo_sums1_long<true><<<256, kBlock, 0, st>>>(tptr, (const uint4*)inst, p.long_list, p.counters, w, p.csum);
+    else k_mo_sums1_long<false><<<256, kBlock, 0, st>>>(tptr, (const uint4*)inst, p.long_list, p.counters, w, p.csum);
+    PP_LAUNCH_CHECK();
+    rc = exclusive_scan<int32_t, int32_t>(p.csum, m, ibase, true, p.result + 2, p.scratch, p.scratch_bytes, st);
+    if (rc != PP_OK) return rc;
+    k_mo_tab<<<grid, kBlock, 0, st>>>(tl.ids, dst, tl.first_pos, tl.count, m, (uint4*)tab);
+    PP_LAUNCH_CHECK();
+    k_mo_finish<<<1, 1, 0, st>>>(p.counters, tl.result, p.result);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+const int64_t* pp_multiorder_result_ptr(void* ws) { return (const int64_t*)ws; }
+
+size_t pp_multiorder_step_ws_bytes(int64_t n_types, int64_t n_children) { return carve_mo_step(nullptr, n_types, n_children).total_bytes; }
+
+int pp_multiorder_step(int64_t n_types, int64_t n_children, const int32_t* tptr, const int32_t* ibase, const int32_t* col, const void* inst,
+                       const int32_t* cand_ptr, const int32_t* cand_last, const void* tab, int weighted, int last, void* child, int32_t* row_ptr,
+                       int32_t* tptr_out, int32_t* ibase_out, int32_t* tlast_out, int32_t* col_out, float* w_out, void* ws, size_t ws_bytes,
+                       pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(n_types > 0 && n_children > 0, PP_ERR_ARG, "pp_multiorder_step: empty level");
+    PP_REQUIRE(n_types < (int64_t)0x7ffffff0 && n_children < (int64_t)0x7ffffff0, PP_ERR_TOO_LARGE, "pp_multiorder_step: level with 2^31 or more instances");
+    MoStepWs p = carve_mo_step(ws, n_types, n_children);
+    PP_REQUIRE(ws_bytes >= p.total_bytes, PP_ERR_WORKSPACE, "pp_multiorder_step: workspace too small");
+    PP_HIP(hipMemsetAsync(p.result, 0, 4 * sizeof(int64_t), st));
+    PP_HIP(hipMemsetAsync(p.counters, 0, 4 * sizeof(int32_t), st));
+    const unsigned grid = (unsigned)ceil_div(n_types, kBlock);
+    k_mo_children<<<grid, kBlock, 0, st>>>(n_types, tptr, ibase, (const uint4*)inst, (const uint4*)tab, (uint4*)child, p.deg, p.big_list, p.counters);
+    PP_LAUNCH_CHECK();
+    k_mo_children_big<<<1024, kBlock, 0, st>>>(tptr, ibase, (const uint4*)inst, (const uint4*)tab, (uint4*)child, p.deg, p.big_list, p.counters,
+                                               p.result + 1);
+    PP_LAUNCH_CHECK();
+    int rc = exclusive_scan<int32_t, int32_t>(p.deg, n_types, row_ptr, true, p.result, p.scratch, p.scratch_bytes, st);
+    if (rc != PP_OK) return rc;
+    if (!last) PP_HIP(hipMemsetAsync(p.csum, 0, (size_t)n_children * sizeof(int32_t), st));
+#define PP_MO_TYPES(W, L)                                                                                                                          \
+    do {                                                                                                                                           \
+        k_mo_types<W, L><<<grid, kBlock, 0, st>>>(n_types, tptr, ibase, col, cand_ptr, cand_last, (const uint4*)child, row_ptr, tptr_out,          \
+                                                  tlast_out, col_out, w_out, p.csum);                                                              \
+        k_mo_types_big<W, L><<<1024, kBlock, 0, st>>>(ibase, col, cand_ptr, cand_last, (const uint4*)child, row_ptr, p.big_list, p.counters,       \
+                                                      tptr_out, tlast_out, col_out, w_out, p.csum);                                                \
+    } while (0)
+    if (weighted) { if (last) PP_MO_TYPES(true, true); else PP_MO_TYPES(true, false); }
+    else { if (last) PP_MO_TYPES(false, true); else PP_MO_TYPES(false, false); }
+#undef PP_MO_TYPES
+    PP_LAUNCH_CHECK();
+    if (!last) {
+        rc = exclusive_scan<int32_t, int32_t>(p.csum, n_children, ibase_out, true, p.result + 2, p.scratch, p.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+    }
+    k_mo_finish<<<1, 1, 0, st>>>(p.counters, nullptr, p.result);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // extern "C"
