@@ -20,12 +20,12 @@
 //   * Instances are kept GROUPED BY TYPE, types in lexicographic order of their node sequences, instances of one type in lexicographic
 //     order of their event sequences (= the reference's instance numbering restricted to the type).  The children of all instances of
 //     type s, stably sorted by their new last node d, are then exactly the instances of the types s ++ d, in the right order: the
-//     global sorts of the reference shrink to one tiny sort per type (a lane's registers; LDS for hubs), the weight of a merged edge is
+//     global sorts of the reference shrink to one tiny sort per type (a lane's registers; a wave's or a workgroup's LDS for the larger ones), the weight of a merged edge is
 //     the count (or the left-to-right sum, PyG's coalesce order) of a run, and everything is written sequentially.
 //   * Layer k+1's edge (s -> c): c is the type suffix(s) ++ d.  suffix(s) is the column u of s in layer k, the candidates are u's
 //     out-edges in layer k (one contiguous id block, last nodes ascending): a bisection in a handful of entries.
 //
-// Per level: k_mo_children (+ k_mo_children_big) -> scan of the row lengths -> k_mo_types (+ k_mo_types_big) -> scan of the children
+// Per level: k_mo_children (+ k_mo_children_wave, k_mo_children_big) -> scan of the row lengths -> k_mo_types (+ k_mo_types_big) -> scan of the children
 // counts.  No read-back between them; the caller reads {types, status, children of the next level} once per level.
 // Algorithmic bytes per level (what the generic kernels move — 16 E_k + 16 E_{k+1} for the lift, 8 k E_{k+1} for the
 // sequences, 16 E_{k+1} + 20 A_{k+1} for the aggregation) are reported by bench.py beside the time; the bytes this path moves are
@@ -35,8 +35,7 @@
 namespace pp {
 
 constexpr int64_t kMoBadIndex = 1, kMoUnsorted = 2, kMoOverflow = 4;
-constexpr int kMoSmall = 8;              // children of one type a single lane sorts in registers
-constexpr int kMoSmallParents = 8;       // ... and instances of that type it walks
+constexpr int kMoSmall = 8;              // children of a one-instance type a single lane sorts in registers
 #ifndef PP_MO_BIG
 #define PP_MO_BIG 4096
 #endif
@@ -48,7 +47,6 @@ constexpr uint32_t kHeadBit = 0x80000000u;
 __device__ __forceinline__ uint4 mo_inst(uint32_t cf, uint32_t cc, bool head, uint32_t d, float w) {
     return make_uint4(cf, cc | (head ? kHeadBit : 0u), d, __float_as_uint(w));
 }
-__device__ __forceinline__ bool mo_small(int parents, int children) { return parents <= kMoSmallParents && children <= kMoSmall; }
 
 // ------------------------------------------------------------------ level 1: the events grouped by (source, target), time order inside
 __global__ __launch_bounds__(kBlock) void k_mo_key_dst(const int64_t* __restrict__ dst, int64_t m, uint32_t* __restrict__ keys) {
@@ -173,38 +171,46 @@ __global__ __launch_bounds__(kBlock) void k_mo_tab(const uint32_t* __restrict__ 
         d[i] = td; cf[i] = tf; cc[i] = tc; w[i] = tw;                                                   \
     } while (0)
 
+// Which kernel takes a type: a LANE (k_mo_children) when it has one instance and at most kMoSmall children — the rule on sparse streams;
+// a WAVE together with 63 other such types (k_mo_children_wave) up to kMoWaveCap children and kMoWaveParents instances; a WORKGROUP beyond.
+constexpr int kMoWaveCap = 256;
+constexpr int kMoWaveParents = 2048;
+__device__ __forceinline__ bool mo_lane_type(int parents, int children) { return parents == 1 && children <= kMoSmall; }
+__device__ __forceinline__ bool mo_big_type(int parents, int children) { return children > kMoWaveCap || parents > kMoWaveParents; }
+
+// appends the flagged lanes' types to a list, one atomic per wave, lane order kept inside the wave's piece
+__device__ __forceinline__ void mo_append(bool flag, int32_t value, int32_t* __restrict__ list, int32_t* __restrict__ count) {
+    const uint64_t mask = __ballot(flag);
+    if (mask == 0ull) return;
+    const int leader = __ffsll((long long)mask) - 1;
+    int32_t base = 0;
+    if (lane_id() == leader) base = atomicAdd(count, (int32_t)__popcll(mask));
+    base = __shfl(base, leader, kWave);
+    if (flag) list[base + (int32_t)__popcll(mask & lanemask_lt())] = value;
+}
+
 __global__ __launch_bounds__(kBlock) void k_mo_children(int64_t n_types, const int32_t* __restrict__ tptr, const int32_t* __restrict__ ibase,
                                                        const uint4* __restrict__ inst, const uint4* __restrict__ tab, uint4* __restrict__ out,
-                                                       int32_t* __restrict__ deg, int32_t* __restrict__ big_list, int32_t* __restrict__ big_count) {
+                                                       int32_t* __restrict__ deg, uint8_t* __restrict__ cls, int32_t* __restrict__ big_list,
+                                                       int32_t* __restrict__ counters) {
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (s >= n_types) return;
-    const int32_t x0 = tptr[s], x1 = tptr[s + 1];
-    const int32_t c0 = ibase[s], n = ibase[s + 1] - c0;
-    if (n == 0) { deg[s] = 0; return; }
-    if (!mo_small(x1 - x0, n)) { big_list[atomicAdd(big_count, 1)] = (int32_t)s; return; }
+    const bool valid = s < n_types;
+    int32_t x0 = 0, parents = 0, c0 = 0, n = 0;
+    if (valid) { x0 = tptr[s]; parents = tptr[s + 1] - x0; c0 = ibase[s]; n = ibase[s + 1] - c0; }
+    const bool mine = valid && n > 0 && mo_lane_type(parents, n);
+    const bool big = valid && n > 0 && mo_big_type(parents, n);
+    if (valid) cls[s] = (n > 0 && !mine && !big) ? 1 : 0;          // 1: left to the wave kernel
+    mo_append(big, (int32_t)s, big_list, counters);                 // (rare: one atomic per wave that has one)
+    if (valid && n == 0) deg[s] = 0;
+    if (!mine) return;
     uint32_t d[kMoSmall], cf[kMoSmall], cc[kMoSmall], w[kMoSmall];
+    // one instance: its window's entries requested back to back
+    const uint4 pi = inst[x0];
+    const uint4* src = tab + pi.x;
 #pragma unroll
-    for (int q = 0; q < kMoSmall; ++q) { d[q] = 0xFFFFFFFFu; cf[q] = 0; cc[q] = 0; w[q] = 0; }
-    if (x1 - x0 == 1) {
-        // one instance (the rule on sparse streams): its window's entries requested back to back
-        const uint4 pi = inst[x0];
-        const uint4* src = tab + pi.x;
-#pragma unroll
-        for (int q = 0; q < kMoSmall; ++q)
-            if (q < n) { const uint4 e = src[q]; d[q] = e.x; cf[q] = e.y; cc[q] = e.z; w[q] = pi.w; }
-    } else {
-        int filled = 0;
-        for (int32_t x = x0; x < x1; ++x) {
-            const uint4 pi = inst[x];
-            const int c = (int)(pi.y & ~kHeadBit);
-            for (int j = 0; j < c; ++j) {
-                const uint4 e = tab[pi.x + j];
-#pragma unroll
-                for (int q = 0; q < kMoSmall; ++q)
-                    if (q == filled) { d[q] = e.x; cf[q] = e.y; cc[q] = e.z; w[q] = pi.w; }
-                ++filled;
-            }
-        }
+    for (int q = 0; q < kMoSmall; ++q) {
+        d[q] = 0xFFFFFFFFu; cf[q] = 0; cc[q] = 0; w[q] = pi.w;
+        if (q < n) { const uint4 e = src[q]; d[q] = e.x; cf[q] = e.y; cc[q] = e.z; }
     }
     if (n > 1) {
 #pragma unroll
@@ -223,6 +229,144 @@ __global__ __launch_bounds__(kBlock) void k_mo_children(int64_t n_types, const i
         }
     }
     deg[s] = heads;
+}
+
+// The types in between (class 1), ONE WAVE PER 64 CONSECUTIVE TYPES: lanes are CHILD SLOTS, not types — a type with two instances and five children and a
+// type with 30 instances and 200 children cost the wave the same per child.  The wave takes its types in batches of at most kMoWaveCap
+// children: (1) the instances of the batch's types, type after type, in rounds of 64: wave prefix sum of their children counts; those that
+// have children are compacted into LDS (window first, weight, type, first child slot) and mark that slot; a running maximum over the slots
+// maps every slot to its instance; (2) every lane fetches the tab
+// entries of its slots (the entries of one window are consecutive: coalesced) and leaves the key (type, new last node, slot) in LDS;
+// (3) bitonic sort of the keys (unique, so it is the stable sort by last node inside every type); (4) the sorted children are written as
+// consecutive 16-byte records, heads counted per type.
+constexpr int kMoWaveTypes = 64;
+struct MoWaveLds {
+    uint64_t keys[kMoWaveCap];
+    uint32_t nz_cf[kMoWaveCap], nz_w[kMoWaveCap], ccf[kMoWaveCap], ccc[kMoWaveCap];
+    uint16_t marks[kMoWaveCap], nz_off[kMoWaveCap];
+    uint8_t nz_type[kMoWaveCap];
+    int32_t adj[kMoWaveTypes], deg[kMoWaveTypes], x0s[kMoWaveTypes], pin[kMoWaveTypes];
+};
+
+__global__ __launch_bounds__(kBlock) void k_mo_children_wave(const int32_t* __restrict__ tptr, const int32_t* __restrict__ ibase,
+                                                            const uint4* __restrict__ inst, const uint4* __restrict__ tab, uint4* __restrict__ out,
+                                                            int32_t* __restrict__ deg, const uint8_t* __restrict__ cls, int64_t n_types) {
+    __shared__ MoWaveLds lds[kWavesPerBlock];
+    MoWaveLds& L = lds[wave_id()];
+    const int lane = lane_id();
+    {
+        const int64_t s = ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * kMoWaveTypes + lane;
+        const bool valid = s < n_types && cls[s] == 1;
+        if (__ballot(valid) == 0ull) return;            // (all of the wave's types were a lane's or a workgroup's: the rule on sparse streams)
+        int32_t x0 = 0, x1 = 0, c0 = 0, n = 0;
+        if (valid) { x0 = tptr[s]; x1 = tptr[s + 1]; c0 = ibase[s]; n = ibase[s + 1] - c0; }
+        L.deg[lane] = 0;
+        const int32_t incl = wave_inclusive_sum<int32_t>(n);
+        const int32_t pin_incl = wave_inclusive_sum<int32_t>(x1 - x0);
+        L.x0s[lane] = x0;
+        L.pin[lane] = pin_incl - (x1 - x0);
+        int l0 = 0;
+        while (l0 < kWave) {
+            const int32_t base = l0 ? __shfl(incl, l0 - 1, kWave) : 0;
+            const uint64_t from = l0 ? ~((1ull << l0) - 1ull) : ~0ull;
+            const uint64_t over = __ballot(incl - base > kMoWaveCap) & from;        // first type that no longer fits (every type alone fits)
+            const int l1 = over ? __ffsll((long long)over) - 1 : kWave;
+            const int32_t nb = __shfl(incl, l1 - 1, kWave) - base;
+            if (nb > 0) {
+                const bool in_batch = lane >= l0 && lane < l1;
+                if (in_batch) L.adj[lane] = c0 - (incl - n - base);
+                for (int i = lane; i < kMoWaveCap; i += kWave) L.marks[i] = 0;
+                __builtin_amdgcn_wave_barrier();
+                // the instances of the batch's types as ONE sequence (type after type), 64 per round
+                const int32_t fa = __shfl(pin_incl - (x1 - x0), l0, kWave), fb = __shfl(pin_incl, l1 - 1, kWave);
+                int32_t run_off = 0, run_k = 0;
+                for (int32_t f0 = fa; f0 < fb; f0 += kWave) {
+                    const int32_t f = f0 + lane;
+                    const bool live = f < fb;
+                    int lo = l0, hi = l1;                      // last type of the batch whose instances start at or before f
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (L.pin[mid] <= f) lo = mid; else hi = mid;
+                    }
+                    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+                    if (live) rec = inst[L.x0s[lo] + (f - L.pin[lo])];
+                    const int32_t c = (int32_t)(rec.y & ~kHeadBit);
+                    const int32_t ci = wave_inclusive_sum<int32_t>(c);
+                    const uint64_t some = __ballot(c > 0);
+                    if (c > 0) {
+                        const int k = run_k + (int)__popcll(some & lanemask_lt());
+                        const int32_t off = run_off + ci - c;
+                        L.nz_cf[k] = rec.x; L.nz_off[k] = (uint16_t)off; L.nz_w[k] = rec.w; L.nz_type[k] = (uint8_t)lo;
+                        L.marks[off] = (uint16_t)(k + 1);
+                    }
+                    run_off += __shfl(ci, kWave - 1, kWave);
+                    run_k += (int)__popcll(some);
+                }
+                __builtin_amdgcn_wave_barrier();
+                {   // slot -> instance: inclusive running maximum of the marks... of marks ordered by slot: an instance's mark is the largest at
+                    // or before its slots only if marks grow with the slot — they need not (k is handed out in arrival order), so the value
+                    // spread is the mark's SLOT, and the instance is read through it
+                    uint32_t v[4], m = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q] = L.marks[4 * lane + q] ? (uint32_t)(4 * lane + q + 1) : 0u; m = v[q] > m ? v[q] : m; v[q] = m; }
+                    uint32_t sc_m = m;
+#pragma unroll
+                    for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+                        const uint32_t o = __shfl_up(sc_m, dlt, kWave);
+                        if (lane >= dlt) sc_m = o > sc_m ? o : sc_m;
+                    }
+                    uint32_t before = __shfl_up(sc_m, 1, kWave);
+                    if (lane == 0) before = 0;
+                    uint32_t owner[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) owner[q] = v[q] > before ? v[q] : before;     // 1 + first slot of the instance that owns this slot
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t kk[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) kk[q] = owner[q] ? L.marks[owner[q] - 1] : 0u;
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) L.marks[4 * lane + q] = (uint16_t)kk[q];
+                }
+                __builtin_amdgcn_wave_barrier();
+                int np2 = 2;
+                while (np2 < nb) np2 <<= 1;
+                for (int slot = lane; slot < np2; slot += kWave) {
+                    uint64_t key = ~0ull;
+                    if (slot < nb) {
+                        const int k = (int)L.marks[slot] - 1;
+                        const uint4 e = tab[L.nz_cf[k] + (uint32_t)(slot - (int)L.nz_off[k])];
+                        L.ccf[slot] = e.y; L.ccc[slot] = e.z;
+                        key = ((uint64_t)L.nz_type[k] << 40) | ((uint64_t)e.x << 8) | (uint64_t)slot;
+                    }
+                    L.keys[slot] = key;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int k = 2; k <= np2; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int p = lane; p < (np2 >> 1); p += kWave) {
+                            const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), o = i | j;
+                            const uint64_t a = L.keys[i], b = L.keys[o];
+                            if ((a > b) == ((i & k) == 0)) { L.keys[i] = b; L.keys[o] = a; }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                for (int pos = lane; pos < nb; pos += kWave) {
+                    const uint64_t key = L.keys[pos];
+                    const uint64_t prev = pos ? L.keys[pos - 1] : ~0ull;
+                    const bool h = (key >> 8) != (prev >> 8);
+                    const int t_l = (int)(key >> 40), slot = (int)(key & 0xffu);
+                    const int k = (int)L.marks[slot] - 1;
+                    out[L.adj[t_l] + pos] = make_uint4(L.ccf[slot], L.ccc[slot] | (h ? kHeadBit : 0u), (uint32_t)(key >> 8), L.nz_w[k]);
+                    if (h) atomicAdd(&L.deg[t_l], 1);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            l0 = l1;
+        }
+        if (valid) deg[s] = L.deg[lane];
+    }
 }
 
 // types with more children (or instances) than a lane takes: one workgroup each, (last node, slot) keys sorted in LDS
@@ -299,24 +443,24 @@ __device__ __forceinline__ int32_t mo_find(const int32_t* __restrict__ cand, int
 }
 
 // the new types of every parent type: instance range, last node, column (= id of the suffix type), merged weight, number of children.
-// kLast: the top layer — only columns and weights are wanted
+// One lane per parent type, its children 8 at a time (requested back to back); the types the children pass handed to the workgroup
+// kernel (mo_big_type) are skipped here.  kLast: the top layer — only columns and weights are wanted
 template <bool kWeighted, bool kLast>
 __global__ __launch_bounds__(kBlock) void k_mo_types(int64_t n_types, const int32_t* __restrict__ tptr, const int32_t* __restrict__ ibase,
                                                     const int32_t* __restrict__ col, const int32_t* __restrict__ cand_ptr,
                                                     const int32_t* __restrict__ cand_last, const uint4* __restrict__ child,
-                                                    const int32_t* __restrict__ row_ptr, int32_t* __restrict__ tptr_out, int32_t* __restrict__ tlast_out,
-                                                    int32_t* __restrict__ col_out, float* __restrict__ w_out, int32_t* __restrict__ csum_out) {
+                                                    const int32_t* __restrict__ row_ptr, int32_t* __restrict__ tptr_out,
+                                                    int32_t* __restrict__ tlast_out, int32_t* __restrict__ col_out, float* __restrict__ w_out,
+                                                    int32_t* __restrict__ csum_out) {
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (s >= n_types) return;
     const int32_t c0 = ibase[s], n = ibase[s + 1] - c0;
     if (!kLast && s == n_types - 1) tptr_out[row_ptr[n_types]] = ibase[n_types];
-    if (n == 0 || !mo_small(tptr[s + 1] - tptr[s], n)) return;
+    if (n == 0) return;
+    if (mo_big_type(tptr[s + 1] - tptr[s], n)) return;
     const int32_t u = col[s];
     const int32_t bf = cand_ptr[u], bc = cand_ptr[u + 1] - bf;
     const int32_t* cand = cand_last + bf;
-    uint4 it[kMoSmall];
-#pragma unroll
-    for (int q = 0; q < kMoSmall; ++q) it[q] = q < n ? child[c0 + q] : make_uint4(0u, 0u, 0u, 0u);
     int32_t pre[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) pre[q] = q < bc ? cand[q] : 0x7fffffff;
@@ -324,24 +468,29 @@ __global__ __launch_bounds__(kBlock) void k_mo_types(int64_t n_types, const int3
     int32_t at = 0;                      // candidates below `at` are smaller than the current last node
     float acc = 0.f;
     int32_t cnt = 0, cs = 0;
+    for (int32_t b0 = 0; b0 < n; b0 += kMoSmall) {
+        uint4 it[kMoSmall];
 #pragma unroll
-    for (int q = 0; q < kMoSmall; ++q) {
-        if (q < n) {
-            if (it[q].y & kHeadBit) {
-                if (cnt) { w_out[t] = kWeighted ? acc : (float)cnt; if (!kLast) csum_out[t] = cs; }
-                ++t;
-                acc = 0.f; cnt = 0; cs = 0;
-                const int32_t dd = (int32_t)it[q].z;
-                int32_t pos;
-                if (dd <= pre[3]) pos = dd <= pre[0] ? 0 : (dd <= pre[1] ? 1 : (dd <= pre[2] ? 2 : 3));
-                else pos = mo_find(cand, at > 4 ? at : 4, bc, dd);
-                at = pos + 1;
-                col_out[t] = bf + pos;
-                if (!kLast) { tptr_out[t] = c0 + q; tlast_out[t] = dd; }
+        for (int q = 0; q < kMoSmall; ++q) it[q] = b0 + q < n ? child[c0 + b0 + q] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int q = 0; q < kMoSmall; ++q) {
+            if (b0 + q < n) {
+                if (it[q].y & kHeadBit) {
+                    if (cnt) { w_out[t] = kWeighted ? acc : (float)cnt; if (!kLast) csum_out[t] = cs; }
+                    ++t;
+                    acc = 0.f; cnt = 0; cs = 0;
+                    const int32_t dd = (int32_t)it[q].z;
+                    int32_t pos;
+                    if (dd <= pre[3]) pos = dd <= pre[0] ? 0 : (dd <= pre[1] ? 1 : (dd <= pre[2] ? 2 : 3));
+                    else pos = mo_find(cand, at > 4 ? at : 4, bc, dd);
+                    at = pos + 1;
+                    col_out[t] = bf + pos;
+                    if (!kLast) { tptr_out[t] = c0 + b0 + q; tlast_out[t] = dd; }
+                }
+                acc += __uint_as_float(it[q].w);
+                ++cnt;
+                cs += (int32_t)(it[q].y & ~kHeadBit);
             }
-            acc += __uint_as_float(it[q].w);
-            ++cnt;
-            cs += (int32_t)(it[q].y & ~kHeadBit);
         }
     }
     if (cnt) { w_out[t] = kWeighted ? acc : (float)cnt; if (!kLast) csum_out[t] = cs; }
@@ -427,6 +576,7 @@ static MoPrepWs carve_mo_prep(void* ws, int64_t m) {
 struct MoStepWs {
     int64_t* result;          // {new types, status, children of the new level, types handled by workgroups}
     int32_t *deg, *csum, *big_list, *counters;
+    uint8_t* cls;
     void* scratch;
     size_t scratch_bytes, total_bytes;
 };
@@ -437,6 +587,7 @@ static MoStepWs carve_mo_step(void* ws, int64_t n_types, int64_t n_children) {
     w.result = a.take<int64_t>(4);
     w.deg = a.take<int32_t>(n_types);
     w.csum = a.take<int32_t>(n_children);
+    w.cls = a.take<uint8_t>(n_types);
     w.big_list = a.take<int32_t>(n_types);
     w.counters = a.take<int32_t>(4);
     const int64_t longest = n_types > n_children ? n_types : n_children;
@@ -535,7 +686,11 @@ int pp_multiorder_step(int64_t n_types, int64_t n_children, const int32_t* tptr,
     PP_HIP(hipMemsetAsync(p.result, 0, 4 * sizeof(int64_t), st));
     PP_HIP(hipMemsetAsync(p.counters, 0, 4 * sizeof(int32_t), st));
     const unsigned grid = (unsigned)ceil_div(n_types, kBlock);
-    k_mo_children<<<grid, kBlock, 0, st>>>(n_types, tptr, ibase, (const uint4*)inst, (const uint4*)tab, (uint4*)child, p.deg, p.big_list, p.counters);
+    k_mo_children<<<grid, kBlock, 0, st>>>(n_types, tptr, ibase, (const uint4*)inst, (const uint4*)tab, (uint4*)child, p.deg, p.cls, p.big_list,
+                                           p.counters);
+    PP_LAUNCH_CHECK();
+    k_mo_children_wave<<<(unsigned)ceil_div(n_types, kWavesPerBlock * kMoWaveTypes), kBlock, 0, st>>>(tptr, ibase, (const uint4*)inst, (const uint4*)tab,
+                                                                                                    (uint4*)child, p.deg, p.cls, n_types);
     PP_LAUNCH_CHECK();
     k_mo_children_big<<<1024, kBlock, 0, st>>>(tptr, ibase, (const uint4*)inst, (const uint4*)tab, (uint4*)child, p.deg, p.big_list, p.counters,
                                                p.result + 1);

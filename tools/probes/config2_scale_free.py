@@ -27,5 +27,5 @@ for delta in (150_000, 1_500_000):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 3 * 1e3
         sizes = {o: (l.n, l.m) for o, l in mom.layers.items()}
-        print(f"delta={delta} max_order={k}: {ms:8.2f} ms  layers (nodes, edges): {sizes}  peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+        print(f"delta={delta} max_order={k}: {ms:8.2f} ms  layers (nodes, edges): {sizes}  level-by-level={'layers' in getattr(mom, 'sizes', {})}  peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
         del mom
