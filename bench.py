@@ -58,6 +58,7 @@ def parse():
                          "put the 2- and 4-rank partition step at 42.7 / 14.8 ms against 14.0 ms on one GPU: reported as what it is, not as scaling")
     ap.add_argument("--no-hub-streams", action="store_true", help="skip the builder timings on the two hub streams (hub_streams in the line)")
     ap.add_argument("--no-staged-forward", action="store_true", help="skip the plain-against-staged timing of the order-2 layer kernel (staged_forward in the line)")
+    ap.add_argument("--no-multi-order", action="store_true", help="skip the K = 2..5 / K = 1..3 multi-order builds (multi_order in the line)")
     ap.add_argument("--no-api-path", action="store_true", help="skip the extra (untimed for `value`) steps through the reference API that fill api_path_ms_per_step")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: host-staged collectives (tests; several ranks may share one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (single-GPU test boxes, with --backend gloo)")
@@ -440,6 +441,82 @@ def hub_streams(dev) -> dict:
                         "plans_identical": bool(same), **({k: built.sizes[k] for k in ("E2", "U2", "A2", "hub_nodes", "hub_tasks")} if built is not None else {})}
         del built, shard, tg, x0
         torch.cuda.empty_cache()
+    return report
+
+
+def multi_order(g, nodes: int, delta, dev) -> dict:
+    """The multi-order half of the metric (BASELINE configs[2] "k = 1..3 lift only", configs[4] "k = 2..5 lift"): untimed for `value`.
+    ``MultiOrderModel.from_temporal_graph(g, delta, K)`` for K = 2..5 on the headline stream and K = 1..3 on the configs[2] generator — wall time
+    per call, and per LAYER (HIP events around the C calls of the level-by-level builder, pp_multiorder_prepare / pp_multiorder_step): instance
+    edges E_k the reference lifts, nodes U_k, edges A_k, the SURVEY §8(d) bytes of the generic pipeline for that layer (line-graph lift
+    16 E_{k-1} + 16 E_k, coalesce 20 E_k + 20 A_k; layer 2: the temporal lift's 24 m + 16 E_2) and the bytes this builder moves
+    (16 I_{k-1} + 48 I_k + 20 A_k: parent records in, child records out and in again, the window table read per child, the layer out),
+    both over the layer's time against 8 TB/s."""
+    import pathpyg_amd as pp
+    from pathpyg_amd import _hip
+
+    def wall(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, out
+
+    def per_layer(tg, n, d, k_max):
+        data = tg.data
+        best = None
+        for _ in range(3):
+            clock = []
+            built = _hip.multi_order_temporal(data.edge_index, data.time, n, d, None, k_max, clock=clock)
+            torch.cuda.synchronize()
+            if built is None:
+                return None
+            ms = [a.elapsed_time(b) for _, a, b in clock]
+            if best is None or sum(ms) < sum(best):
+                best = ms
+        m_events = built[0].n_instances
+        rows = [{"phase": "continuation windows + layer 1 (pp_temporal_count + pp_multiorder_prepare)", "ms": best[0], "U": built[0].n_nodes,
+                 "A": built[0].n_edges, "E": m_events}]
+        for k in range(2, k_max + 1):
+            b, prev = built[k - 1], built[k - 2]
+            table = (24 * m_events + 16 * b.n_instances if k == 2 else 16 * prev.n_instances + 16 * b.n_instances) + 20 * b.n_instances + 20 * b.n_edges
+            moved = 16 * prev.n_instances + 48 * b.n_instances + 20 * b.n_edges
+            ms_k = best[k - 1]
+            rows.append({"phase": f"layer {k} (pp_multiorder_step)", "ms": ms_k, "U": b.n_nodes, "A": b.n_edges, "E": b.n_instances,
+                         "table_bytes": table, "moved_bytes": moved,
+                         "frac_table": table / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_moved": moved / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        del built
+        return rows
+
+    report = {"what": "MultiOrderModel.from_temporal_graph(g, delta, max_order = K): wall ms per call, then the layers one by one (HIP events); outside the timed "
+                      "region; E = instance edges of the reference's lift, U / A = nodes / edges of the layer; fractions of 8 TB/s",
+              "builder": "level by level (pp_multiorder_prepare / pp_multiorder_step) from K = 3 on, fused order-2 builder (pp_debruijn2_*) at K = 2"}
+    head = {}
+    for k in (2, 3, 4, 5):
+        ms, mom = wall(lambda: pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=k))
+        head[f"K={k}"] = {"ms": ms, "level_by_level": "layers" in getattr(mom, "sizes", {})}
+        del mom
+    head["layers"] = per_layer(g, nodes, delta, 5)
+    report["headline stream"] = head
+    torch.cuda.empty_cache()
+    gen = torch.Generator(device=dev).manual_seed(3)
+    n, m, span, d2 = 1_000_000, 20_000_000, 10_000_000, 1_500_000
+    src = torch.randint(0, n, (m,), generator=gen, device=dev)
+    dst = (n * torch.rand(m, generator=gen, device=dev, dtype=torch.float64).pow(6.0)).long().clamp_(max=n - 1)
+    t = torch.randint(0, span, (m,), generator=gen, device=dev)
+    tg = pp.TemporalGraph(pp.Data(edge_index=torch.stack((src, dst)), time=t, num_nodes=n))
+    del src, dst, t
+    c2 = {"delta": d2}
+    for k in (1, 2, 3):
+        ms, mom = wall(lambda: pp.MultiOrderModel.from_temporal_graph(tg, delta=d2, max_order=k))
+        c2[f"K={k}"] = {"ms": ms, "level_by_level": "layers" in getattr(mom, "sizes", {})}
+        del mom
+    c2["layers"] = per_layer(tg, n, d2, 3)
+    report["configs[2] generator: scale-free destinations, 1e6 nodes / 2e7 events"] = c2
+    del tg
+    torch.cuda.empty_cache()
     return report
 
 
@@ -959,6 +1036,9 @@ def main() -> int:
     hub_report = None
     if partition and rank == 0 and world == 1 and not args.no_hub_streams:
         hub_report = hub_streams(dev)
+    multi_order_report = None
+    if partition and rank == 0 and world == 1 and not args.no_multi_order:
+        multi_order_report = multi_order(g, args.nodes, args.delta, dev)
     staged_report = None
     if partition and rank == 0 and world == 1 and args.features == 64 and not args.no_staged_forward:
         staged_report = staged_forward(g, args.nodes, args.delta, dev)
@@ -1077,6 +1157,8 @@ def main() -> int:
             line["api_path"] = api_path
         if hub_report is not None:
             line["hub_streams"] = hub_report
+        if multi_order_report is not None:
+            line["multi_order"] = multi_order_report
         if staged_report is not None:
             line["staged_forward"] = staged_report
         if fused_ran:

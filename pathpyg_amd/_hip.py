@@ -881,14 +881,23 @@ class MultiOrderLayer:
             setattr(self, k, kw.get(k))
 
 
-def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, weight: torch.Tensor | None, max_order: int):
+def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, weight: torch.Tensor | None, max_order: int,
+                         clock: list | None = None):
     """All De Bruijn layers 1..max_order of a TIME-SORTED event stream, level by level (pp_multiorder_prepare / _step, csrc/pp_multiorder.hip):
     no instance graph ``[2, E_k]``, no per-instance node sequences, no global sort beyond the two of the first order; one read-back per order.
     Returns ``[MultiOrderLayer]`` (index k - 1 = layer k; ``n_instances`` = E_k, the instance edges the reference would have lifted) or ``None``
     when the generic kernels have to take over: a layer without edges, a node sequence with more than 4096 continuations (dense contact
-    streams), 2^31 or more instances at some order, an unsorted stream."""
+    streams), 2^31 or more instances at some order, an unsorted stream.  ``clock``: a list that receives one ``(name, start event, end event)``
+    per phase — the windows and level 1 ("prepare"), then every step ("layer k") — for measurements (bench.py)."""
     ei = _edge_index(edge_index)
     dev = require_device(ei, time, weight)
+
+    def tick():
+        if clock is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
     if time.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
         time = time.to(torch.int64)
     if time.dtype not in (torch.int64, torch.float64):
@@ -909,6 +918,7 @@ def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         lift_ws = _workspace(L.pp_temporal_ws_bytes(m, n), dev)
+        t0 = tick()
         check(L.pp_temporal_count(_p(ei), _p(time), _DTYPE_CODE[time.dtype], m, m, n, kind, di, df, _p(lift_ws), lift_ws.numel(), _stream()),
               "pp_temporal_count")
         tab = torch.empty((m, 4), **i32)
@@ -919,6 +929,8 @@ def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
         ws = _workspace(L.pp_multiorder_prepare_ws_bytes(m), dev)
         check(L.pp_multiorder_prepare(_p(ei), m, n, _p(weight), _p(lift_ws), lift_ws.numel(), _p(tab), _p(inst), _p(tptr), _p(ibase), _p(tlast), _p(w),
                                       _p(row_ptr), _p(ws), ws.numel(), _stream()), "pp_multiorder_prepare")
+        if clock is not None:
+            clock.append(("prepare", t0, tick()))
         types, status, children, _ = ws[:32].view(torch.int64).tolist()
         del lift_ws, ws
         _bad_index(status, "MultiOrderModel.from_temporal_graph")
@@ -937,9 +949,12 @@ def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
             if not last:
                 tptr_next, ibase_next, tlast_next = torch.empty(children + 1, **i32), torch.empty(children + 1, **i32), torch.empty(children, **i32)
             ws = _workspace(L.pp_multiorder_step_ws_bytes(types, children), dev)
+            t0 = tick()
             check(L.pp_multiorder_step(types, children, _p(tptr), _p(ibase), _p(col), _p(inst), _p(cand_ptr), _p(cand_last), _p(tab),
                                        0 if weight is None else 1, 1 if last else 0, _p(child), _p(row_next), _p(tptr_next), _p(ibase_next),
                                        _p(tlast_next), _p(col_next), _p(w_next), _p(ws), ws.numel(), _stream()), "pp_multiorder_step")
+            if clock is not None:
+                clock.append((f"layer {k}", t0, tick()))
             new_types, status, new_children, _ = ws[:32].view(torch.int64).tolist()
             del ws
             if status & 4:

@@ -25,11 +25,13 @@
 //   * Layer k+1's edge (s -> c): c is the type suffix(s) ++ d.  suffix(s) is the column u of s in layer k, the candidates are u's
 //     out-edges in layer k (one contiguous id block, last nodes ascending): a bisection in a handful of entries.
 //
-// Per level: k_mo_children (+ k_mo_children_wave, k_mo_children_big) -> scan of the row lengths -> k_mo_types (+ k_mo_types_big) -> scan of the children
+// Per level: k_mo_children (+ k_mo_children_wave, k_mo_children_big) -> scan of the row lengths -> k_mo_types (+ k_mo_types_wave, k_mo_types_big) -> scan of the children
 // counts.  No read-back between them; the caller reads {types, status, children of the next level} once per level.
 // Algorithmic bytes per level (what the generic kernels move — 16 E_k + 16 E_{k+1} for the lift, 8 k E_{k+1} for the
 // sequences, 16 E_{k+1} + 20 A_{k+1} for the aggregation) are reported by bench.py beside the time; the bytes this path moves are
 // 16 I_k + 32 I_{k+1} + 20 A_{k+1} + the window reads.
+#include <stdlib.h>
+
 #include "pp_internal.h"
 
 namespace pp {
@@ -49,62 +51,60 @@ __device__ __forceinline__ uint4 mo_inst(uint32_t cf, uint32_t cc, bool head, ui
 }
 
 // ------------------------------------------------------------------ level 1: the events grouped by (source, target), time order inside
-__global__ __launch_bounds__(kBlock) void k_mo_key_dst(const int64_t* __restrict__ dst, int64_t m, uint32_t* __restrict__ keys) {
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_mo_key_pair(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t m, int64_t n, int bits,
+                                                       KeyT* __restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < m) keys[i] = (uint32_t)dst[i];
-}
-__global__ __launch_bounds__(kBlock) void k_mo_key_src(const int64_t* __restrict__ src, const uint32_t* __restrict__ perm, int64_t m,
-                                                      uint32_t* __restrict__ keys) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < m) keys[i] = (uint32_t)src[perm[i]];
-}
-__global__ __launch_bounds__(kBlock) void k_mo_key_pair(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t m, int bits,
-                                                       uint32_t* __restrict__ keys) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < m) keys[i] = ((uint32_t)src[i] << bits) | (uint32_t)dst[i];
+    if (i >= m) return;
+    int64_t a = src[i], b = dst[i];
+    if (a < 0 || a >= n) a = 0;            // (pp_temporal_count has set the status bit: the caller raises; nothing here may run off an array)
+    if (b < 0 || b >= n) b = 0;
+    keys[i] = ((KeyT)a << bits) | (KeyT)b;
 }
 
-// position j of the (source, target, time) order: the node pair of its event
-__global__ __launch_bounds__(kBlock) void k_mo_pairs(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const uint32_t* __restrict__ perm,
-                                                    int64_t m, uint2* __restrict__ ab) {
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= m) return;
-    const uint32_t e = perm[j];
-    ab[j] = make_uint2((uint32_t)src[e], (uint32_t)dst[e]);
+// everything the later gathers want to know about an event, in one 16-byte record: head node, continuation window, weight
+__global__ __launch_bounds__(kBlock) void k_mo_events(const int64_t* __restrict__ dst, const uint32_t* __restrict__ first_pos,
+                                                     const int32_t* __restrict__ count, const float* __restrict__ weight, int64_t m, int64_t n,
+                                                     uint4* __restrict__ ev) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= m) return;
+    int64_t b = dst[e];
+    if (b < 0 || b >= n) b = 0;
+    ev[e] = make_uint4((uint32_t)b, first_pos[e], (uint32_t)count[e], __float_as_uint(weight ? weight[e] : 1.0f));
 }
 
-// the level-1 instance of position j + the flag "first event of its node pair"
-__global__ __launch_bounds__(kBlock) void k_mo_inst1(const uint2* __restrict__ ab, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ first_pos,
-                                                    const int32_t* __restrict__ count, const float* __restrict__ weight, int64_t m,
-                                                    uint4* __restrict__ inst, int32_t* __restrict__ head) {
+// the level-1 instance of position j of the (source, target, time) order + the flag "first event of its node pair"
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_mo_inst1(const KeyT* __restrict__ sorted, const uint32_t* __restrict__ perm, const uint4* __restrict__ ev,
+                                                    int64_t m, uint4* __restrict__ inst, int32_t* __restrict__ head) {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= m) return;
-    const uint2 me = ab[j];
-    bool h = j == 0;
-    if (!h) { const uint2 pv = ab[j - 1]; h = pv.x != me.x || pv.y != me.y; }
-    const uint32_t e = perm[j];
-    inst[j] = mo_inst(first_pos[e], (uint32_t)count[e], h, me.y, weight ? weight[e] : 1.0f);
+    const bool h = j == 0 || sorted[j - 1] != sorted[j];
+    const uint4 r = ev[perm[j]];
+    inst[j] = make_uint4(r.y, r.z | (h ? kHeadBit : 0u), r.x, r.w);
     head[j] = h ? 1 : 0;
 }
 
 // the types of level 1 = layer 1's edges: instance range, last node (= column), row pointers over the first-order nodes
-__global__ __launch_bounds__(kBlock) void k_mo_types1(const uint2* __restrict__ ab, const int32_t* __restrict__ head_before, int64_t m, int64_t n,
-                                                     int32_t* __restrict__ tptr, int32_t* __restrict__ tlast, int32_t* __restrict__ rowptr) {
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_mo_types1(const KeyT* __restrict__ sorted, int bits, const int32_t* __restrict__ head_before, int64_t m,
+                                                     int64_t n, int32_t* __restrict__ tptr, int32_t* __restrict__ tlast, int32_t* __restrict__ rowptr) {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= m) return;
     const int32_t t = head_before[j];
     const bool h = head_before[j + 1] != t;
-    const uint2 me = ab[j];
+    const KeyT me = sorted[j];
+    const int64_t a = (int64_t)(me >> bits);
     if (h) {
         tptr[t] = (int32_t)j;
-        tlast[t] = (int32_t)me.y;
-        const int64_t a_prev = j == 0 ? -1 : (int64_t)ab[j - 1].x;
-        for (int64_t v = a_prev + 1; v <= (int64_t)me.x; ++v) rowptr[v] = t;
+        tlast[t] = (int32_t)(me & (((KeyT)1 << bits) - 1));
+        const int64_t a_prev = j == 0 ? -1 : (int64_t)(sorted[j - 1] >> bits);
+        for (int64_t v = a_prev + 1; v <= a; ++v) rowptr[v] = t;
     }
     if (j == m - 1) {
         const int32_t total = head_before[m];
         tptr[total] = (int32_t)m;
-        for (int64_t v = (int64_t)me.x + 1; v <= n; ++v) rowptr[v] = total;
+        for (int64_t v = a + 1; v <= n; ++v) rowptr[v] = total;
     }
 }
 
@@ -153,12 +153,12 @@ __global__ __launch_bounds__(kBlock) void k_mo_sums1_long(const int32_t* __restr
 }
 
 // tab[p]: the event at position p of the per-node out-lists — its head node, its own continuation window, its id
-__global__ __launch_bounds__(kBlock) void k_mo_tab(const uint32_t* __restrict__ ids, const int64_t* __restrict__ dst, const uint32_t* __restrict__ first_pos,
-                                                  const int32_t* __restrict__ count, int64_t m, uint4* __restrict__ tab) {
+__global__ __launch_bounds__(kBlock) void k_mo_tab(const uint32_t* __restrict__ ids, const uint4* __restrict__ ev, int64_t m, uint4* __restrict__ tab) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= m) return;
     const uint32_t l = ids[p];
-    tab[p] = make_uint4((uint32_t)dst[l], first_pos[l], (uint32_t)count[l], l);
+    const uint4 r = ev[l];
+    tab[p] = make_uint4(r.x, r.y, r.z, l);
 }
 
 // ------------------------------------------------------------------ one level: children of every type, sorted by their new last node
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void k_mo_children(int64_t n_types, const i
     if (valid) { x0 = tptr[s]; parents = tptr[s + 1] - x0; c0 = ibase[s]; n = ibase[s + 1] - c0; }
     const bool mine = valid && n > 0 && mo_lane_type(parents, n);
     const bool big = valid && n > 0 && mo_big_type(parents, n);
-    if (valid) cls[s] = (n > 0 && !mine && !big) ? 1 : 0;          // 1: left to the wave kernel
+    if (valid) cls[s] = big ? 2 : ((n > 0 && !mine) ? 1 : 0);      // 1: left to the wave kernel, 2: to the workgroup kernel
     mo_append(big, (int32_t)s, big_list, counters);                 // (rare: one atomic per wave that has one)
     if (valid && n == 0) deg[s] = 0;
     if (!mine) return;
@@ -254,10 +254,13 @@ __global__ __launch_bounds__(kBlock) void k_mo_children_wave(const int32_t* __re
     __shared__ MoWaveLds lds[kWavesPerBlock];
     MoWaveLds& L = lds[wave_id()];
     const int lane = lane_id();
-    {
-        const int64_t s = ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * kMoWaveTypes + lane;
+    // (a bounded grid, every wave strides over the 64-type pieces: on sparse streams almost every piece has nothing for this kernel, and
+    //  a quarter of a million workgroups that read 256 bytes and leave cost 0.24 ms at 6.8 * 10^7 types)
+    for (int64_t first = ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * kMoWaveTypes; first < n_types;
+         first += (int64_t)gridDim.x * kWavesPerBlock * kMoWaveTypes) {
+        const int64_t s = first + lane;
         const bool valid = s < n_types && cls[s] == 1;
-        if (__ballot(valid) == 0ull) return;            // (all of the wave's types were a lane's or a workgroup's: the rule on sparse streams)
+        if (__ballot(valid) == 0ull) continue;          // (all of the piece's types were a lane's or a workgroup's: the rule on sparse streams)
         int32_t x0 = 0, x1 = 0, c0 = 0, n = 0;
         if (valid) { x0 = tptr[s]; x1 = tptr[s + 1]; c0 = ibase[s]; n = ibase[s + 1] - c0; }
         L.deg[lane] = 0;
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(kBlock) void k_mo_children_wave(const int32_t* __re
             l0 = l1;
         }
         if (valid) deg[s] = L.deg[lane];
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -432,6 +436,7 @@ __global__ __launch_bounds__(kBlock) void k_mo_children_big(const int32_t* __res
     }
 }
 
+constexpr int kMoPre = 16;
 // position of `key` among the ascending last nodes cand[0 .. bc) of the candidate block (it is there: the suffix of a path is a path)
 __device__ __forceinline__ int32_t mo_find(const int32_t* __restrict__ cand, int32_t lo, int32_t bc, int32_t key) {
     int32_t hi = bc;
@@ -443,57 +448,169 @@ __device__ __forceinline__ int32_t mo_find(const int32_t* __restrict__ cand, int
 }
 
 // the new types of every parent type: instance range, last node, column (= id of the suffix type), merged weight, number of children.
-// One lane per parent type, its children 8 at a time (requested back to back); the types the children pass handed to the workgroup
-// kernel (mo_big_type) are skipped here.  kLast: the top layer — only columns and weights are wanted
+// One lane per parent type of class 0 (one instance, at most kMoSmall children: the types k_mo_children took); the others belong to
+// k_mo_types_wave / k_mo_types_big.  kLast: the top layer — only columns and weights are wanted
 template <bool kWeighted, bool kLast>
 __global__ __launch_bounds__(kBlock) void k_mo_types(int64_t n_types, const int32_t* __restrict__ tptr, const int32_t* __restrict__ ibase,
                                                     const int32_t* __restrict__ col, const int32_t* __restrict__ cand_ptr,
                                                     const int32_t* __restrict__ cand_last, const uint4* __restrict__ child,
                                                     const int32_t* __restrict__ row_ptr, int32_t* __restrict__ tptr_out,
                                                     int32_t* __restrict__ tlast_out, int32_t* __restrict__ col_out, float* __restrict__ w_out,
-                                                    int32_t* __restrict__ csum_out) {
+                                                    int32_t* __restrict__ csum_out, int all_wave) {
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (s >= n_types) return;
     const int32_t c0 = ibase[s], n = ibase[s + 1] - c0;
     if (!kLast && s == n_types - 1) tptr_out[row_ptr[n_types]] = ibase[n_types];
-    if (n == 0) return;
-    if (mo_big_type(tptr[s + 1] - tptr[s], n)) return;
+    if (all_wave || n == 0 || !mo_lane_type(tptr[s + 1] - tptr[s], n)) return;
     const int32_t u = col[s];
     const int32_t bf = cand_ptr[u], bc = cand_ptr[u + 1] - bf;
     const int32_t* cand = cand_last + bf;
-    int32_t pre[4];
+    uint4 it[kMoSmall];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pre[q] = q < bc ? cand[q] : 0x7fffffff;
+    for (int q = 0; q < kMoSmall; ++q) it[q] = q < n ? child[c0 + q] : make_uint4(0u, 0u, 0u, 0u);
+    // the first kMoPre candidates in registers (one or two cache lines, requested back to back): the position of a last node among them is
+    // the number of smaller ones — no dependent loads; longer blocks (first-order hubs) finish by bisection behind them
+    int32_t pre[kMoPre];
+#pragma unroll
+    for (int q = 0; q < kMoPre; ++q) pre[q] = q < bc ? cand[q] : 0x7fffffff;
     int32_t t = row_ptr[s] - 1;
     int32_t at = 0;                      // candidates below `at` are smaller than the current last node
     float acc = 0.f;
     int32_t cnt = 0, cs = 0;
-    for (int32_t b0 = 0; b0 < n; b0 += kMoSmall) {
-        uint4 it[kMoSmall];
 #pragma unroll
-        for (int q = 0; q < kMoSmall; ++q) it[q] = b0 + q < n ? child[c0 + b0 + q] : make_uint4(0u, 0u, 0u, 0u);
+    for (int q = 0; q < kMoSmall; ++q) {
+        if (q < n) {
+            if (it[q].y & kHeadBit) {
+                if (cnt) { w_out[t] = kWeighted ? acc : (float)cnt; if (!kLast) csum_out[t] = cs; }
+                ++t;
+                acc = 0.f; cnt = 0; cs = 0;
+                const int32_t dd = (int32_t)it[q].z;
+                int32_t pos = 0;
 #pragma unroll
-        for (int q = 0; q < kMoSmall; ++q) {
-            if (b0 + q < n) {
-                if (it[q].y & kHeadBit) {
-                    if (cnt) { w_out[t] = kWeighted ? acc : (float)cnt; if (!kLast) csum_out[t] = cs; }
-                    ++t;
-                    acc = 0.f; cnt = 0; cs = 0;
-                    const int32_t dd = (int32_t)it[q].z;
-                    int32_t pos;
-                    if (dd <= pre[3]) pos = dd <= pre[0] ? 0 : (dd <= pre[1] ? 1 : (dd <= pre[2] ? 2 : 3));
-                    else pos = mo_find(cand, at > 4 ? at : 4, bc, dd);
-                    at = pos + 1;
-                    col_out[t] = bf + pos;
-                    if (!kLast) { tptr_out[t] = c0 + b0 + q; tlast_out[t] = dd; }
-                }
-                acc += __uint_as_float(it[q].w);
-                ++cnt;
-                cs += (int32_t)(it[q].y & ~kHeadBit);
+                for (int c = 0; c < kMoPre; ++c) pos += pre[c] < dd ? 1 : 0;
+                if (pos == kMoPre) pos = mo_find(cand, at > kMoPre ? at : kMoPre, bc, dd);
+                at = pos + 1;
+                col_out[t] = bf + pos;
+                if (!kLast) { tptr_out[t] = c0 + q; tlast_out[t] = dd; }
             }
+            acc += __uint_as_float(it[q].w);
+            ++cnt;
+            cs += (int32_t)(it[q].y & ~kHeadBit);
         }
     }
     if (cnt) { w_out[t] = kWeighted ? acc : (float)cnt; if (!kLast) csum_out[t] = cs; }
+}
+
+// The same for the types of class 1 (k_mo_children_wave's), ONE WAVE PER 64 CONSECUTIVE TYPES, lanes = CHILD SLOTS in rounds of 64: the
+// records arrive by one coalesced load per round, a slot's type by bisection over the 64 types' first children (LDS), the id of a new type
+// = first id of its parent's row + the heads of that parent before it (ballots; `h_span` carries the count for a parent that spans rounds).
+// A new type's run of children (up to the next head) is summed by its head lane LEFT TO RIGHT from LDS (PyG's coalesce order); a run that
+// reaches the end of a round stays open (`o_*`) and is extended by lane 0 of the next round.
+struct MoTypesLds {
+    int32_t cb[kMoWaveTypes + 1], bf[kMoWaveTypes], bc[kMoWaveTypes], rp[kMoWaveTypes];
+    uint32_t w[kWave], cc[kWave];
+    uint8_t mid[kMoWaveTypes];
+};
+
+template <bool kWeighted, bool kLast>
+__global__ __launch_bounds__(kBlock) void k_mo_types_wave(int64_t n_types, const int32_t* __restrict__ ibase, const int32_t* __restrict__ col,
+                                                         const int32_t* __restrict__ cand_ptr, const int32_t* __restrict__ cand_last,
+                                                         const uint4* __restrict__ child, const int32_t* __restrict__ row_ptr,
+                                                         const uint8_t* __restrict__ cls, int32_t* __restrict__ tptr_out,
+                                                         int32_t* __restrict__ tlast_out, int32_t* __restrict__ col_out, float* __restrict__ w_out,
+                                                         int32_t* __restrict__ csum_out, int all_wave) {
+    __shared__ MoTypesLds lds[kWavesPerBlock];
+    MoTypesLds& L = lds[wave_id()];
+    const int lane = lane_id();
+    for (int64_t first = ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * kMoWaveTypes; first < n_types;
+         first += (int64_t)gridDim.x * kWavesPerBlock * kMoWaveTypes) {
+    const int64_t s = first + lane;
+    const bool valid = s < n_types;
+    const bool is_mid = valid && (cls[s] == 1 || (all_wave && cls[s] == 0 && ibase[s + 1] > ibase[s]));
+    const uint64_t mids = __ballot(is_mid);
+    if (mids == 0ull) continue;
+    const int32_t c0 = ibase[valid ? s : n_types];
+    const int32_t c1 = valid ? ibase[s + 1] : c0;
+    L.cb[lane] = c0;
+    if (lane == kWave - 1) L.cb[kWave] = c1;
+    L.mid[lane] = is_mid ? 1 : 0;
+    if (is_mid) {
+        const int32_t u = col[s];
+        const int32_t b0 = cand_ptr[u];
+        L.bf[lane] = b0; L.bc[lane] = cand_ptr[u + 1] - b0; L.rp[lane] = row_ptr[s];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int first_mid = __ffsll((long long)mids) - 1, last_mid = 63 - __clzll((long long)mids);
+    const int32_t c_begin = L.cb[first_mid], c_end = L.cb[last_mid + 1];
+    int32_t h_span = 0;                  // heads of the type that owns lane 0's slot, in earlier rounds
+    int32_t o_t = -1, o_cnt = 0, o_cs = 0;    // the open run: its type id, children so far, their children
+    float o_acc = 0.f;
+    for (int32_t cr = c_begin; cr < c_end; cr += kWave) {
+        const int32_t c = cr + lane;
+        int lo = 0, hi = kWave;          // last type whose children start at or before c
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (L.cb[mid] <= c) lo = mid; else hi = mid;
+        }
+        const bool act = c < c_end && L.mid[lo];
+        const uint64_t acts = __ballot(act);
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        if (act) rec = child[c];
+        const bool head = act && (rec.y & kHeadBit);
+        const uint64_t hb = __ballot(head);
+        // close or extend the open run (lane 0 speaks for it)
+        if (o_t >= 0 && !((acts & 1ull) && !(hb & 1ull))) {
+            if (lane == 0) { w_out[o_t] = kWeighted ? o_acc : (float)o_cnt; if (!kLast) csum_out[o_t] = o_cs; }
+            o_t = -1;
+        }
+        if (acts == 0ull) { h_span = 0; continue; }
+        L.w[lane] = rec.w; L.cc[lane] = rec.y & ~kHeadBit;
+        __builtin_amdgcn_wave_barrier();
+        // my run ends before the next head, the first inactive slot, or the end of the round
+        const uint64_t stops = (hb | ~acts) & ~((2ull << lane) - 1ull);
+        const int run_end = stops ? __ffsll((long long)stops) - 1 : kWave;
+        const int st = L.cb[lo] - cr;                                         // lane of my type's first slot (negative: an earlier round)
+        const uint64_t before_type = st > 0 ? ((1ull << st) - 1ull) : 0ull;
+        const int32_t t = act ? L.rp[lo] + (st < 0 ? h_span : 0) + (int32_t)__popcll(hb & lanemask_lt() & ~before_type) : 0;
+        const bool owner = head || (lane == 0 && act);                        // (lane 0 without a head: the open run goes on)
+        float acc = 0.f;
+        int32_t cs = 0;
+        if (owner) {
+            if (!head) { acc = o_acc; cs = o_cs; }
+            for (int q = lane; q < run_end; ++q) { acc += __uint_as_float(L.w[q]); cs += (int32_t)L.cc[q]; }
+        }
+        const int32_t cnt = (owner && !head ? o_cnt : 0) + (run_end - lane);
+        const int32_t my_t = head ? t : o_t;
+        if (head) {
+            const int32_t dd = (int32_t)rec.z, b0 = L.bf[lo], bcount = L.bc[lo];
+            const int32_t* cand = cand_last + b0;
+            int32_t pos = 0;
+            const int32_t lim = bcount < kMoPre ? bcount : kMoPre;
+            for (int32_t q = 0; q < lim; ++q) pos += cand[q] < dd ? 1 : 0;
+            if (pos == kMoPre) pos = mo_find(cand, kMoPre, bcount, dd);
+            col_out[t] = b0 + pos;
+            if (!kLast) { tptr_out[t] = c; tlast_out[t] = dd; }
+        }
+        // the run that reaches the end of the round stays open; the others are final
+        const uint64_t owners = __ballot(owner);
+        const int last_owner = 63 - __clzll((long long)owners);               // (owners != 0: the first active slot of a round is a head or lane 0)
+        const bool reaches = __shfl(run_end, last_owner, kWave) == kWave;
+        if (owner && !(lane == last_owner && reaches)) { w_out[my_t] = kWeighted ? acc : (float)cnt; if (!kLast) csum_out[my_t] = cs; }
+        if (reaches) {
+            o_t = __shfl(my_t, last_owner, kWave); o_acc = __shfl(acc, last_owner, kWave);
+            o_cs = __shfl(cs, last_owner, kWave); o_cnt = __shfl(cnt, last_owner, kWave);
+        } else {
+            o_t = -1;
+        }
+        // heads of the type that continues into the next round
+        const int st_last = __shfl(st, kWave - 1, kWave);
+        const uint64_t before_last = st_last > 0 ? ((1ull << st_last) - 1ull) : 0ull;
+        h_span = (st_last < 0 ? h_span : 0) + (int32_t)__popcll(hb & ~before_last);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (o_t >= 0 && lane == 0) { w_out[o_t] = kWeighted ? o_acc : (float)o_cnt; if (!kLast) csum_out[o_t] = o_cs; }
+    __builtin_amdgcn_wave_barrier();
+    }
 }
 
 template <bool kWeighted, bool kLast>
@@ -545,8 +662,9 @@ __global__ __launch_bounds__(kBlock) void k_mo_types_big(const int32_t* __restri
 
 struct MoPrepWs {
     int64_t* result;          // {types of level 1, status, children of level 1 (= E2), node pairs with long runs}
-    uint32_t *keys_a, *keys_b, *vals_a, *vals_b;
-    uint2* ab;
+    void *keys_a, *keys_b;    // (source, target) keys before / after the sort: uint32 or uint64 [m]
+    uint32_t* perm;           // [m] the events in (source, target, time) order
+    uint4* ev;                // [m] per event {head node, window first, window count, weight}
     int32_t *head, *head_before, *csum, *long_list, *counters;
     void* scratch;
     size_t scratch_bytes, total_bytes;
@@ -556,21 +674,42 @@ static MoPrepWs carve_mo_prep(void* ws, int64_t m) {
     Arena a(ws, (size_t)-1);
     MoPrepWs w;
     w.result = a.take<int64_t>(4);
-    w.keys_a = a.take<uint32_t>(m);
-    w.keys_b = a.take<uint32_t>(m);
-    w.vals_a = a.take<uint32_t>(m);
-    w.vals_b = a.take<uint32_t>(m);
-    w.ab = a.take<uint2>(m);
+    w.keys_a = a.take<uint64_t>(m);
+    w.keys_b = a.take<uint64_t>(m);
+    w.perm = a.take<uint32_t>(m);
+    w.ev = a.take<uint4>(m);
     w.head = a.take<int32_t>(m);
     w.head_before = a.take<int32_t>(m + 1);
     w.csum = a.take<int32_t>(m);
     w.long_list = a.take<int32_t>(m);
     w.counters = a.take<int32_t>(4);
-    const size_t s1 = sort_ws_bytes(m, 4), s2 = scan_ws_bytes(m + 1);
+    const size_t s1 = sort_ws_bytes(m, 8), s2 = scan_ws_bytes(m + 1);
     w.scratch_bytes = s1 > s2 ? s1 : s2;
     w.scratch = a.take<char>((int64_t)w.scratch_bytes);
     w.total_bytes = a.used;
     return w;
+}
+
+template <typename KeyT>
+static int mo_level1(const MoPrepWs& p, const TemporalLists& tl, const int64_t* src, const int64_t* dst, const float* weight, int64_t m,
+                     int64_t num_nodes, int bits, uint4* inst, int32_t* tptr, int32_t* tlast, int32_t* rowptr, hipStream_t st) {
+    const unsigned grid = (unsigned)ceil_div(m, kBlock);
+    KeyT* keys = (KeyT*)p.keys_a;
+    KeyT* sorted = (KeyT*)p.keys_b;
+    // the events in (source, target, time) order: ONE stable sort of the time-ordered stream by the (source, target) key
+    k_mo_key_pair<KeyT><<<grid, kBlock, 0, st>>>(src, dst, m, num_nodes, bits, keys);
+    PP_LAUNCH_CHECK();
+    int rc = sort_pairs<KeyT>(keys, nullptr, sorted, p.perm, m, 0, 2 * bits, p.scratch, p.scratch_bytes, st);
+    if (rc != PP_OK) return rc;
+    k_mo_events<<<grid, kBlock, 0, st>>>(dst, tl.first_pos, tl.count, weight, m, num_nodes, p.ev);
+    PP_LAUNCH_CHECK();
+    k_mo_inst1<KeyT><<<grid, kBlock, 0, st>>>(sorted, p.perm, p.ev, m, inst, p.head);
+    PP_LAUNCH_CHECK();
+    rc = exclusive_scan<int32_t, int32_t>(p.head, m, p.head_before, true, p.result, p.scratch, p.scratch_bytes, st);
+    if (rc != PP_OK) return rc;
+    k_mo_types1<KeyT><<<grid, kBlock, 0, st>>>(sorted, bits, p.head_before, m, num_nodes, tptr, tlast, rowptr);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
 }
 
 struct MoStepWs {
@@ -627,34 +766,9 @@ int pp_multiorder_prepare(const int64_t* edge_index, int64_t m, int64_t num_node
     const int64_t* dst = edge_index + m;
     const unsigned grid = (unsigned)ceil_div(m, kBlock);
     const int bits = bits_for((uint64_t)(num_nodes - 1));
-    const uint32_t* perm;
-    int rc;
-    // the events in (source, target, time) order: stable sorts of the time-ordered stream
-    if (2 * bits <= 32) {
-        k_mo_key_pair<<<grid, kBlock, 0, st>>>(src, dst, m, bits, p.keys_a);
-        PP_LAUNCH_CHECK();
-        rc = sort_pairs<uint32_t>(p.keys_a, nullptr, p.keys_b, p.vals_b, m, 0, 2 * bits, p.scratch, p.scratch_bytes, st);
-        if (rc != PP_OK) return rc;
-        perm = p.vals_b;
-    } else {
-        k_mo_key_dst<<<grid, kBlock, 0, st>>>(dst, m, p.keys_a);
-        PP_LAUNCH_CHECK();
-        rc = sort_pairs<uint32_t>(p.keys_a, nullptr, p.keys_b, p.vals_a, m, 0, bits, p.scratch, p.scratch_bytes, st);
-        if (rc != PP_OK) return rc;
-        k_mo_key_src<<<grid, kBlock, 0, st>>>(src, p.vals_a, m, p.keys_a);
-        PP_LAUNCH_CHECK();
-        rc = sort_pairs<uint32_t>(p.keys_a, p.vals_a, p.keys_b, p.vals_b, m, 0, bits, p.scratch, p.scratch_bytes, st);
-        if (rc != PP_OK) return rc;
-        perm = p.vals_b;
-    }
-    k_mo_pairs<<<grid, kBlock, 0, st>>>(src, dst, perm, m, p.ab);
-    PP_LAUNCH_CHECK();
-    k_mo_inst1<<<grid, kBlock, 0, st>>>(p.ab, perm, tl.first_pos, tl.count, weight, m, (uint4*)inst, p.head);
-    PP_LAUNCH_CHECK();
-    rc = exclusive_scan<int32_t, int32_t>(p.head, m, p.head_before, true, p.result, p.scratch, p.scratch_bytes, st);
+    int rc = 2 * bits <= 32 ? mo_level1<uint32_t>(p, tl, src, dst, weight, m, num_nodes, bits, (uint4*)inst, tptr, tlast, rowptr, st)
+                            : mo_level1<uint64_t>(p, tl, src, dst, weight, m, num_nodes, bits, (uint4*)inst, tptr, tlast, rowptr, st);
     if (rc != PP_OK) return rc;
-    k_mo_types1<<<grid, kBlock, 0, st>>>(p.ab, p.head_before, m, num_nodes, tptr, tlast, rowptr);
-    PP_LAUNCH_CHECK();
     if (weight) k_mo_sums1<true><<<grid, kBlock, 0, st>>>(tptr, p.head_before + m, (const uint4*)inst, w, p.csum, p.long_list, p.counters);
     else k_mo_sums1<false><<<grid, kBlock, 0, st>>>(tptr, p.head_before + m, (const uint4*)inst, w, p.csum, p.long_list, p.counters);
     PP_LAUNCH_CHECK();
@@ -663,7 +777,7 @@ int pp_multiorder_prepare(const int64_t* edge_index, int64_t m, int64_t num_node
     PP_LAUNCH_CHECK();
     rc = exclusive_scan<int32_t, int32_t>(p.csum, m, ibase, true, p.result + 2, p.scratch, p.scratch_bytes, st);
     if (rc != PP_OK) return rc;
-    k_mo_tab<<<grid, kBlock, 0, st>>>(tl.ids, dst, tl.first_pos, tl.count, m, (uint4*)tab);
+    k_mo_tab<<<grid, kBlock, 0, st>>>(tl.ids, p.ev, m, (uint4*)tab);
     PP_LAUNCH_CHECK();
     k_mo_finish<<<1, 1, 0, st>>>(p.counters, tl.result, p.result);
     PP_LAUNCH_CHECK();
@@ -689,8 +803,9 @@ int pp_multiorder_step(int64_t n_types, int64_t n_children, const int32_t* tptr,
     k_mo_children<<<grid, kBlock, 0, st>>>(n_types, tptr, ibase, (const uint4*)inst, (const uint4*)tab, (uint4*)child, p.deg, p.cls, p.big_list,
                                            p.counters);
     PP_LAUNCH_CHECK();
-    k_mo_children_wave<<<(unsigned)ceil_div(n_types, kWavesPerBlock * kMoWaveTypes), kBlock, 0, st>>>(tptr, ibase, (const uint4*)inst, (const uint4*)tab,
-                                                                                                    (uint4*)child, p.deg, p.cls, n_types);
+    const int64_t pieces = ceil_div(n_types, kWavesPerBlock * kMoWaveTypes);
+    const unsigned wave_grid = (unsigned)(pieces < 4096 ? pieces : 4096);
+    k_mo_children_wave<<<wave_grid, kBlock, 0, st>>>(tptr, ibase, (const uint4*)inst, (const uint4*)tab, (uint4*)child, p.deg, p.cls, n_types);
     PP_LAUNCH_CHECK();
     k_mo_children_big<<<1024, kBlock, 0, st>>>(tptr, ibase, (const uint4*)inst, (const uint4*)tab, (uint4*)child, p.deg, p.big_list, p.counters,
                                                p.result + 1);
@@ -698,10 +813,17 @@ int pp_multiorder_step(int64_t n_types, int64_t n_children, const int32_t* tptr,
     int rc = exclusive_scan<int32_t, int32_t>(p.deg, n_types, row_ptr, true, p.result, p.scratch, p.scratch_bytes, st);
     if (rc != PP_OK) return rc;
     if (!last) PP_HIP(hipMemsetAsync(p.csum, 0, (size_t)n_children * sizeof(int32_t), st));
+    // the lane types' share of the types pass: below the top layer (five outputs per new type) the wave kernel's coalesced stores win
+    // (headline stream, 10^7 .. 3.6 * 10^7 parent types: 0.65 / 0.65 / 1.06 ms against 0.73 / 0.92 / 1.25 ms), at the top layer (two outputs)
+    // one lane per type does (1.44 against 1.69 ms at 6.8 * 10^7 types).  PP_MO_TYPES_WAVE=0/1: measurement switch
+    static const char* const force = getenv("PP_MO_TYPES_WAVE");
+    const int all_wave = force ? (force[0] == '1' ? 1 : 0) : (last ? 0 : 1);
 #define PP_MO_TYPES(W, L)                                                                                                                          \
     do {                                                                                                                                           \
         k_mo_types<W, L><<<grid, kBlock, 0, st>>>(n_types, tptr, ibase, col, cand_ptr, cand_last, (const uint4*)child, row_ptr, tptr_out,          \
-                                                  tlast_out, col_out, w_out, p.csum);                                                              \
+                                                  tlast_out, col_out, w_out, p.csum, all_wave);                                                              \
+        k_mo_types_wave<W, L><<<all_wave ? (unsigned)pieces : wave_grid, kBlock, 0, st>>>(                                                         \
+            n_types, ibase, col, cand_ptr, cand_last, (const uint4*)child, row_ptr, p.cls, tptr_out, tlast_out, col_out, w_out, p.csum, all_wave); \
         k_mo_types_big<W, L><<<1024, kBlock, 0, st>>>(ibase, col, cand_ptr, cand_last, (const uint4*)child, row_ptr, p.big_list, p.counters,       \
                                                       tptr_out, tlast_out, col_out, w_out, p.csum);                                                \
     } while (0)
