@@ -57,7 +57,6 @@ def parse():
                          "640 MB per layer exchange on ONE link at 2 ranks, 160 MB at 4, 40 MB at 8; the projections (profiles/r04_shapes/emulate{2,4}.json) "
                          "put the 2- and 4-rank partition step at 42.7 / 14.8 ms against 14.0 ms on one GPU: reported as what it is, not as scaling")
     ap.add_argument("--no-hub-streams", action="store_true", help="skip the builder timings on the two hub streams (hub_streams in the line)")
-    ap.add_argument("--no-staged-forward", action="store_true", help="skip the plain-against-staged timing of the order-2 layer kernel (staged_forward in the line)")
     ap.add_argument("--no-multi-order", action="store_true", help="skip the K = 2..5 / K = 1..3 multi-order builds (multi_order in the line)")
     ap.add_argument("--no-api-path", action="store_true", help="skip the extra (untimed for `value`) steps through the reference API that fill api_path_ms_per_step")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: host-staged collectives (tests; several ranks may share one GPU)")
@@ -273,7 +272,7 @@ def pmc_traffic(kernel_key: str, args) -> float | None:
     return None
 
 
-PMC_TABLES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_TABLES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 pmc_traffic.source = None
 
 
@@ -518,46 +517,6 @@ def multi_order(g, nodes: int, delta, dev) -> dict:
     del tg
     torch.cuda.empty_cache()
     return report
-
-
-def staged_forward(g, nodes: int, delta, dev) -> dict:
-    """The second order-2 layer (64 x 64) of the headline stream through k_gcn_forward and through the staged form (pp_gcn_forward_staged_f32:
-    every distinct source row of a 64-row group fetched once; opt-in, csrc/pp_gcn_fused.hip), same box, same plan, 20 launches each; the
-    algorithmic bytes are those of the `roofline` entry (fused-form compulsory bytes), the gather's share is given both ways."""
-    from pathpyg_amd import _hip
-
-    plan = _hip.debruijn2(g.data.edge_index, g.data.time, nodes, delta, None).ho
-    rows, nnz = plan.fwd_ptr.numel() - 1, plan.fwd_idx.numel()
-    if not _hip.gcn_stage_wanted(rows, rows, nnz, 64, 64):
-        return {"skipped": "the staged form does not apply to this layer (long rows or X of 4 GiB and more)"}
-    gen = torch.Generator(device=dev).manual_seed(5)
-    x = torch.randn(rows, 64, generator=gen, device=dev)
-    w = torch.randn(64, 64, generator=gen, device=dev) / 8
-    b = torch.randn(64, generator=gen, device=dev)
-    y = torch.empty(rows, 64, device=dev)
-
-    def timed(fn, reps=20):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e3
-
-    plan_ms = timed(lambda: _hip.gcn_stage_plan(plan.fwd_ptr, plan.fwd_idx, rows))
-    sp = _hip.gcn_stage_plan(plan.fwd_ptr, plan.fwd_idx, rows)
-    cnt = sp.grp_cnt.long()
-    distinct = int(cnt[cnt < 255].sum())
-    plain_ms = timed(lambda: _hip.gcn_forward(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, rows, x, plan.self_coef, w, b, True, out=y))
-    y_plain = y.clone()
-    staged_ms = timed(lambda: _hip.gcn_forward_staged(plan.fwd_ptr, plan.fwd_idx, plan.fwd_val, rows, x, plan.self_coef, w, b, True, sp, out=y))
-    return {"what": "order-2 layer 64 x 64 of the headline stream, k_gcn_forward against k_gcn_forward_staged (opt-in entry point), same plan",
-            "rows": rows, "row_gathers": nnz, "distinct_sources_over_64_row_groups": distinct, "groups_on_the_ordinary_path": int((cnt == 255).sum()),
-            "plain_ms": plain_ms, "staged_ms": staged_ms, "stage_plan_ms": plan_ms,
-            "max_abs_difference": float((y - y_plain).abs().max()),
-            "gather_bytes": {"plain": 256 * nnz, "staged": 256 * distinct}}
 
 
 def relaunch(args) -> int:
@@ -1039,10 +998,6 @@ def main() -> int:
     multi_order_report = None
     if partition and rank == 0 and world == 1 and not args.no_multi_order:
         multi_order_report = multi_order(g, args.nodes, args.delta, dev)
-    staged_report = None
-    if partition and rank == 0 and world == 1 and args.features == 64 and not args.no_staged_forward:
-        staged_report = staged_forward(g, args.nodes, args.delta, dev)
-        torch.cuda.empty_cache()
     # untimed extra: the k=2 -> k=3 line-graph lift of the same event graph (the lift kernel WITHOUT the continuation-list gather)
     k3 = None
     if rank == 0:
@@ -1159,8 +1114,6 @@ def main() -> int:
             line["hub_streams"] = hub_report
         if multi_order_report is not None:
             line["multi_order"] = multi_order_report
-        if staged_report is not None:
-            line["staged_forward"] = staged_report
         if fused_ran:
             (fkey, (n_f, f_ms, _)), = fused_clock.groups().items()
             f_avg = f_ms / max(n_f, 1)

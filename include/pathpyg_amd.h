@@ -199,7 +199,7 @@ int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t
  *   level k's types (the candidates a column is looked up in; for k = 1: rowptr and tlast of pp_multiorder_prepare).  Outputs with capacity
  *   n_children (tptr_out / ibase_out: n_children + 1): child = inst of level k+1, row_ptr [n_types + 1] = row pointers of layer k+1,
  *   col_out / w_out = its columns and merged weights, tlast_out, tptr_out, ibase_out as above.  last != 0: the top layer — tptr_out,
- *   ibase_out, tlast_out are not written (may be NULL).  weighted == 0: every event weighs 1 (merged weight = run length).
+ *   ibase_out, tlast_out are not written (may be NULL) and `child` is scratch of 4 (weighted: 8) bytes per child instead of 16.  weighted == 0: every event weighs 1 (merged weight = run length).
  *   pp_multiorder_result_ptr(ws) = {types of level k+1, status, instances of level k+2, types handled by workgroups};
  *   status bit 2: a type with more than 4096 children — the outputs are incomplete, use the generic kernels (pp_linegraph_*, pp_coalesce_*). */
 size_t pp_multiorder_prepare_ws_bytes(int64_t m);
@@ -467,21 +467,6 @@ int pp_gcn_fused_supported(int P, int Q);
 int pp_gcn_forward_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X, int P,
                        const float* self_coef, const float* W, int Q, const float* bias, int act, const int32_t* heavy_slot, const float* heavy_sum,
                        float* agg_out, float* Y, pp_stream_t stream);
-
-/* The 64 x 64 layer (same result as pp_gcn_forward_f32 with P = Q = 64, no agg_out, no hub rows) for graphs whose 64-row groups gather the
- * same source rows repeatedly — the order-2 De Bruijn layer of nn/dbgnn.py:131-140, where the rows (b, .) of a block all gather from the
- * sources (., b): every DISTINCT source row of a group is fetched once into LDS and summed from there (csrc/pp_gcn_fused.hip).
- * pp_gcn_stage_plan_i32, once per CSR: grp_cnt [ceil(n_rows / 64)] (distinct sources of the group; 255 = the group has more than 256
- * entries or more than pp_gcn_stage_slots() distinct sources and is gathered the ordinary way inside the kernel), grp_list
- * [groups * pp_gcn_stage_slots()] int32 (the distinct sources in order of first appearance), slot [entries] (stage slot of every entry),
- * fallback [1 + groups] int32 ([0] = number of marked groups, then their indices in no particular order).
- * X must stay below 4 GiB (n_src * 256 bytes), else PP_ERR_TOO_LARGE: use pp_gcn_forward_f32. */
-int pp_gcn_stage_slots(void);
-int pp_gcn_stage_plan_i32(const int32_t* ptr, const int32_t* idx, int64_t n_rows, uint8_t* grp_cnt, int32_t* grp_list, uint8_t* slot, int32_t* fallback,
-                          pp_stream_t stream);
-int pp_gcn_forward_staged_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X,
-                              const float* self_coef, const float* W, const float* bias, int act, const uint8_t* grp_cnt, const int32_t* grp_list,
-                              const uint8_t* slot, const int32_t* fallback, float* Y, pp_stream_t stream);
 
 /* Backward of that layer in one kernel (pp_spmm_f32 over the source-major CSR + pp_dense_backward_f32 without the round trip of the
  * aggregated gradient through HBM):  G = A^T D + diag(self_coef) D with D = dpre [n_rows,M];

@@ -942,7 +942,7 @@ def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
             if types == 0 or children == 0 or children >= _INT32_ROWS:
                 return None
             last = k == max_order
-            child = torch.empty((children, 4), **i32)
+            child = torch.empty((children, (1 if weight is None else 2) if last else 4), **i32)      # (the top layer's children are nobody's parents)
             row_next = torch.empty(types + 1, **i32)
             col_next, w_next = torch.empty(children, **i32), torch.empty(children, **f32)
             tptr_next = ibase_next = tlast_next = None
@@ -1324,60 +1324,6 @@ def gcn_forward(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, 
                                             1 if act else 0, _p(slot), _p(sums), _p(agg), _p(y), dp, dseed, dtag, drow0, _stream()),
               "pp_gcn_forward_drop_f32")
     return (y, agg) if want_agg else y
-
-
-class StagePlan:
-    """Per 64-row group of a CSR: its distinct source rows (``grp_list`` [groups, slots] int32, ``grp_cnt`` [groups] uint8; 255 = the group is
-    gathered the ordinary way) and the stage slot of every entry (``slot`` [entries] uint8) — :func:`gcn_stage_plan`."""
-
-    __slots__ = ("grp_cnt", "grp_list", "slot", "fallback")
-
-    def __init__(self, grp_cnt, grp_list, slot, fallback):
-        self.grp_cnt, self.grp_list, self.slot, self.fallback = grp_cnt, grp_list, slot, fallback
-
-
-STAGE_MAX_ENTRIES_PER_ROW = 3.5     # 64 rows then carry <= 224 of the 256 entries a staged group may have on average
-STAGE_MAX_SOURCE_BYTES = 0xFFFFF000  # the staged kernel addresses X with 32-bit offsets
-
-
-def gcn_stage_plan(ptr: torch.Tensor, idx: torch.Tensor, n_rows: int) -> StagePlan:
-    """Stage plan of a destination-major CSR (pp_gcn_stage_plan_i32): one kernel, no read-back."""
-    dev = require_device(ptr, idx)
-    groups = (n_rows + 63) // 64
-    with torch.cuda.device(dev):
-        slots = int(lib().pp_gcn_stage_slots())
-        sp = StagePlan(torch.empty(groups, dtype=torch.uint8, device=dev), torch.empty((groups, slots), dtype=torch.int32, device=dev),
-                       torch.empty(idx.numel(), dtype=torch.uint8, device=dev), torch.empty(1 + groups, dtype=torch.int32, device=dev))
-        check(lib().pp_gcn_stage_plan_i32(_p(ptr), _p(idx), n_rows, _p(sp.grp_cnt), _p(sp.grp_list), _p(sp.slot), _p(sp.fallback), _stream()),
-              "pp_gcn_stage_plan_i32")
-    return sp
-
-
-def gcn_stage_wanted(n_rows: int, n_src: int, entries: int, p: int, q: int) -> bool:
-    """Whether the staged form of the layer kernel is the one to use: a 64 x 64 layer over short rows (a De Bruijn layer), X below 4 GiB."""
-    return p == 64 and q == 64 and n_rows >= 64 and 0 < entries <= STAGE_MAX_ENTRIES_PER_ROW * n_rows and n_src * 256 < STAGE_MAX_SOURCE_BYTES
-
-
-def gcn_forward_staged(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor | None, n_rows: int, x: torch.Tensor, self_coef: torch.Tensor | None,
-                       weight: torch.Tensor, bias: torch.Tensor | None, act: bool, stage: StagePlan, out: torch.Tensor | None = None) -> torch.Tensor:
-    """:func:`gcn_forward` for a 64 x 64 layer with a :class:`StagePlan` (pp_gcn_forward_staged_f32): every distinct source row of a 64-row
-    group is fetched once."""
-    dev = require_device(ptr, idx, val, x, self_coef, weight, bias)
-    x, weight = x.contiguous(), weight.contiguous()
-    if tuple(weight.shape) != (64, 64) or x.size(1) != 64:
-        raise ValueError("gcn_forward_staged: a 64 x 64 layer")
-    if bias is not None:
-        bias = bias.contiguous()
-    with torch.cuda.device(dev):
-        if out is None:
-            y = torch.empty((n_rows, 64), dtype=torch.float32, device=dev)
-        else:
-            if tuple(out.shape) != (n_rows, 64) or out.dtype != torch.float32 or not out.is_contiguous():
-                raise ValueError("gcn_forward_staged: out must be a contiguous fp32 [n_rows, 64] tensor")
-            y = out
-        check(lib().pp_gcn_forward_staged_f32(_p(ptr), _p(idx), _p(val), n_rows, x.size(0), _p(x), _p(self_coef), _p(weight), _p(bias), 1 if act else 0,
-                                              _p(stage.grp_cnt), _p(stage.grp_list), _p(stage.slot), _p(stage.fallback), _p(y), _stream()), "pp_gcn_forward_staged_f32")
-    return y
 
 
 def gcn_backward(ptr, idx, val, n_rows: int, dpre: torch.Tensor, self_coef, x: torch.Tensor, weight: torch.Tensor, fuse_act: bool,

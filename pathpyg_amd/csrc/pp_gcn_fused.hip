@@ -885,464 +885,6 @@ static int launch_gcn_backward_k(int K, int64_t n_tiles, hipStream_t st, const i
 }
 
 
-// =====================================================================================================
-// STAGED forward (round 5): the 64 x 64 layer on a graph whose 64-row groups gather the SAME source rows several times — a De Bruijn layer:
-// the rows (b, .) of one block gather from the same few sources (., b).  On the headline graph the plain kernel issues 1.9 * 10^7 row gathers
-// per launch (4.86 GB) for 9.2 * 10^6 distinct (group, source) pairs (2.36 GB, tools/probes/tile_reuse.py), and the L2 (4 MB per die against
-// ~7 MB of traffic per die and tile time) catches under half of the repeats (counter traffic of the gather 4.0 GB).  Here every distinct source
-// row of a group is fetched ONCE into an LDS stage and the four waves sum their rows' neighbours out of the stage: 7.7 GB of traffic per launch
-// instead of 9.3.  An OPT-IN entry point (pp_gcn_forward_staged_f32): 1.59 ms per launch against 1.65 ms for k_gcn_forward on the headline
-// layer (same box) — the plan costs 0.066 ms, so a step that builds its graph anew gains nothing, an epoch loop over one graph 3-4 %.
-//   k_stage_plan  (once per plan) one wave per 64-row group: its <= 256 column indices go into a wave-private LDS hash table (atomicCAS, open
-//                 addressing), distinct sources are numbered in order of their first entry (ballot + popcount: the same numbering on every
-//                 run) -> grp_list [group][96] source rows, grp_cnt [group], slot [entry] = stage slot of the entry's source.  A group
-//                 with more than 256 entries or more than 96 distinct sources is marked (grp_cnt 255) and appended to a list: the layer
-//                 kernel gathers those the TileGather way in a second loop.
-//   k_gcn_forward_staged  persistent workgroups of four waves, a workgroup walks groups (tile = 4 * group + wave).  Everything a group needs
-//                 is in flight one group ahead: at the top of group A's turn its stage rows (six float4 per thread: 16 lanes per row),
-//                 its self rows, row pointers and (slot, value) entries sit in registers — they were requested while the group before was
-//                 multiplied — and go to LDS between two barriers; then the requests of group B go out in portions between the pieces of
-//                 A's arithmetic (its list and pointers came one turn earlier still): A is summed (first four entries of a lane group's
-//                 four rows as sixteen independent LDS chains), multiplied on the matrix cores and stored.
-// What the kernel's time was made of, each step measured on the GPU (thread-0 cycle counters per phase: -DPP_STAGE_PROF, tools/probes/fwd_stage.py):
-//   * the dedup INSIDE the layer kernel (hash + numbering, four workgroup barriers per group, loads issued and awaited in the same turn): 2.95 ms;
-//   * plan + one-turn-ahead requests, 2 workgroups per CU: 1.88 ms, 39 % of it inside the wait for the next group's LIST — a wait for the previous
-//     group's STORES: the compiler counts outstanding memory operations per path and takes the SAFE count where paths meet, so a store-free
-//     entry path, a `continue` for the waves past the last tile, a branch around a store or a register COPY of a value in flight (rotating
-//     b <- c at the end of a turn) each turn some wait into "everything issued so far".  Hence: every memory instruction of the main loop is a
-//     buffer access whose absence is an out-of-range offset made from a mask the compiler cannot see through, never a branch; the values of a
-//     turn are "used" by empty asm statements at the top, so all waits sit there and none behind the turn's requests; group-wide values are
-//     loaded through a lane-dependent zero so that they do not look uniform (a uniform value is moved to a scalar register at once = waited
-//     for at once); the (value, value) pairs of the entries are pairs in LDS (a packed multiply-add that broadcasts one register names the
-//     register PAIR, whose other half may be the destination of a request in flight); the self-term products are pinned in front of the requests;
-//   * all of that, requests as one burst behind the second barrier: 1.82 ms, 52 % of it issuing 34 requests — every wave of the CU stands at the
-//     request queue at once and the queue is empty while they all compute; requests in four portions between sum / MFMA halves: 1.68 ms;
-//   * a TWO-turn-ahead form (two register sets for the stage rows): 1.76 ms at 256 registers — the allocator splits live ranges and copies
-//     values in flight at the loop's latch; not kept;
-//   * THREE workgroups per CU: the waves' tiles live inside the stage (one barrier more), 96 slots, one register set for the first requests,
-//     the bias in LDS, the stores at the end of their own turn: 167 registers, 43.8 KB of LDS: 1.59 ms.  What is left (35 % top wait, 38 %
-//     MFMA + requests) is the per-CU request concurrency: 12 waves that move in lockstep per workgroup keep ~45 KB in flight per CU where the
-//     16 free-running waves of k_gcn_forward keep ~56 KB (5.65 TB/s of traffic against 4.8 TB/s here);
-//   * the same per WAVE (a wave-private stage of the <= 32 distinct rows of its 16-row tile inside k_gcn_forward, no workgroup barrier, a
-//     plan per tile: 3.03 GB of gathers instead of 2.36): 1.74 ms — two dependent round trips per tile (list -> rows) at 12 waves per CU;
-//     with the list fetched a tile ahead 4 registers spill and the kernel takes 1.89 ms; with TileGather inlined for the tiles the plan
-//     cannot stage 17-20 registers spill (2.12 ms).  Not kept.
-constexpr int kStageSlots = 96, kStageNnz = 256, kStageKeep = kStageSlots / 16;
-constexpr uint8_t kStageFallback = 255;
-
-__global__ __launch_bounds__(kGcnThreads) void k_stage_plan(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t n_rows, int64_t n_groups,
-                                                            uint8_t* __restrict__ grp_cnt, int32_t* __restrict__ grp_list, uint8_t* __restrict__ slot,
-                                                            int32_t* __restrict__ fallback) {
-    __shared__ int s_key[kGcnWaves][kStageNnz], s_first[kGcnWaves][kStageNnz], s_rank[kGcnWaves][kStageNnz];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int64_t gi = (int64_t)blockIdx.x * kGcnWaves + wave;
-    if (gi >= n_groups) return;
-    const int64_t r0 = gi * 64, r1 = r0 + 64 < n_rows ? r0 + 64 : n_rows;
-    const int p0 = ptr[r0], nnz = ptr[r1] - p0;
-    int base = kStageSlots + 1;
-    if (nnz <= kStageNnz) {
-        int* key = s_key[wave];
-        int* first = s_first[wave];
-        int* rank = s_rank[wave];
-#pragma unroll
-        for (int k = 0; k < kStageNnz / kWave; ++k) {
-            key[k * kWave + lane] = -1;
-            first[k * kWave + lane] = 0x7fffffff;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        int j[kStageNnz / kWave], pos[kStageNnz / kWave];
-#pragma unroll
-        for (int k = 0; k < kStageNnz / kWave; ++k) {
-            const int e = k * kWave + lane;
-            j[k] = 0;
-            pos[k] = 0;
-            if (e < nnz) {
-                j[k] = idx[(int64_t)p0 + e];
-                uint32_t s = ((uint32_t)j[k] * 2654435761u) >> 24;
-                for (;;) {                                          // <= 256 keys in 256 entries: every key finds one
-                    const int old = atomicCAS(&key[s], -1, j[k]);
-                    if (old == -1 || old == j[k]) break;
-                    s = (s + 1u) & (kStageNnz - 1);
-                }
-                pos[k] = (int)s;
-                atomicMin(&first[s], e);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        base = 0;
-#pragma unroll
-        for (int k = 0; k < kStageNnz / kWave; ++k) {                // distinct sources, numbered by their first entry
-            const int e = k * kWave + lane;
-            const bool is_first = e < nnz && first[pos[k]] == e;
-            const uint64_t m = __ballot(is_first);
-            const int rk = base + (int)__popcll(m & ((1ull << lane) - 1ull));
-            if (is_first) {
-                rank[pos[k]] = rk;
-                if (rk < kStageSlots) grp_list[gi * kStageSlots + rk] = j[k];
-            }
-            base += (int)__popcll(m);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < kStageNnz / kWave; ++k) {
-            const int e = k * kWave + lane;
-            if (e < nnz) {
-                const int r = rank[pos[k]];
-                slot[(int64_t)p0 + e] = (uint8_t)(r < kStageSlots ? r : 0);
-            }
-        }
-    }
-    if (lane == 0) {
-        const bool fb = base > kStageSlots;
-        grp_cnt[gi] = fb ? kStageFallback : (uint8_t)base;
-        if (fb) fallback[1 + atomicAdd(&fallback[0], 1)] = (int32_t)gi;      // (the order of this list does not reach any result)
-    }
-}
-
-struct StageArgs {
-    const uint8_t* grp_cnt;
-    const int32_t* grp_list;
-    const uint8_t* slot;
-    const int32_t* fallback;                 // [0] = groups on the ordinary path, [1 ..] = those groups
-    unsigned long long* prof = nullptr;      // -DPP_STAGE_PROF: cycle counters of thread 0 per phase, summed over the workgroups
-};
-#ifdef PP_STAGE_PROF
-#define PP_PROF_MARK(i) do { const long long now_ = (long long)__builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(sp.prof + (i), (unsigned long long)(now_ - prof_t)); prof_t = now_; } while (0)
-#else
-#define PP_PROF_MARK(i) do { } while (0)
-#endif
-
-// tile (16 rows, LDS, row stride 68) . W^T + bias, ELU (the second half of k_gcn_forward<64,64>) in pieces, so that requests can go out between them:
-// stage_mfma_part<C0, C1> adds the k-quarters C0 .. C1-1 to out[ct][reg] = row 4*kq + reg, column 4*i + ct; stage_mfma_finish = bias + ELU
-template <int C0, int C1>
-__device__ __forceinline__ void stage_mfma_part(const float* __restrict__ tile, const float* __restrict__ s_b, int i, int kq, f32x4 (&out)[4]) {
-    constexpr int KQ = 16, CT = 4, TS = 68;
-    __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-    for (int c = C0; c < C1; ++c) {
-        const float4 a = *(const float4*)(tile + i * TS + kq * KQ + 4 * c);
-        const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float* bp = s_b + ((kq * KQ + 4 * c + e) * 16 + i) * CT;
-            float bv[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) bv[ct] = bp[ct];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) out[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[ct], out[ct], 0, 0, 0);
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-}
-__device__ __forceinline__ void stage_mfma_finish(const f32x4 (&out)[4], const float* bias_c, int act, float (&y)[4][4]) {
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-#pragma unroll
-        for (int ct = 0; ct < 4; ct += 2) {
-            pp_f32x2 v = {out[ct][reg] + bias_c[ct], out[ct + 1][reg] + bias_c[ct + 1]};
-            if (act) v = elu_fast2(v);
-            y[reg][ct] = v[0];
-            y[reg][ct + 1] = v[1];
-        }
-    }
-}
-__device__ __forceinline__ void stage_mfma(const float* __restrict__ tile, const float* __restrict__ s_b, const float* bias_c, int act, int i, int kq, float (&y)[4][4]) {
-    f32x4 out[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) out[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    stage_mfma_part<0, 4>(tile, s_b, i, kq, out);
-    stage_mfma_finish(out, bias_c, act, y);
-}
-
-#ifndef PP_STAGE_WGS
-#define PP_STAGE_WGS 3
-#endif
-template <bool kStream>
-__global__ __launch_bounds__(kGcnThreads, PP_STAGE_WGS) void k_gcn_forward_staged(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
-                                                                       int64_t n_rows, const float* __restrict__ X, const float* __restrict__ self_coef,
-                                                                       const float* __restrict__ W, const float* __restrict__ bias, int act, StageArgs sp,
-                                                                       float* __restrict__ Y, int64_t n_self) {
-    constexpr int P = 64, Q = 64, kRows = 4, CT = 4, TS = P + 4, kWaves = kGcnWaves;
-    __shared__ __attribute__((aligned(16))) float s_b[P * Q];
-    // (the waves' 16-row tiles live INSIDE the stage: once every wave has summed its rows the stage is dead until the next group's rows are
-    // written, and 17 KB of LDS less is what lets a third workgroup onto the CU)
-    __shared__ __attribute__((aligned(16))) float s_stage[kStageSlots * P];
-    static_assert(kStageSlots * P >= kWaves * 16 * TS, "the tiles fit into the stage");
-    __shared__ int s_gptr[65];
-    // (entry values as PAIRS (v, v): a packed multiply-add that broadcasts ONE register still names the register pair, and the pair's other half
-    // may be the destination of a request in flight — the compiler then waits for that request in the middle of the sums)
-    __shared__ __attribute__((aligned(8))) pp_f32x2 s_gval[kStageNnz];
-    __shared__ uint8_t s_slot[kStageNnz];
-    __shared__ __attribute__((aligned(16))) float s_bias[Q];
-    for (int e = threadIdx.x; e < P * Q; e += kGcnThreads) {
-        const int j = e / P, k = e - j * P;
-        s_b[k * Q + j] = W[e];
-    }
-    if (threadIdx.x < Q) s_bias[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
-    __syncthreads();
-    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const int g = lane >> 4, l = lane & 15, i = lane & 15, kq = lane >> 4, lg = tid >> 4;
-    float* tile = s_stage + wave * 16 * TS;
-    const float* bias_c = s_bias + CT * i;                          // (read where it is added: four registers less across the turn)
-    const int64_t n_tiles = (n_rows + 15) / 16, n_groups = (n_tiles + kWaves - 1) / kWaves;
-    // every die sweeps a contiguous eighth of the groups (as k_gcn_forward)
-    const bool by_die = gridDim.x % 8 == 0;
-    const int64_t per_die = (n_groups + 7) / 8, die_stride = gridDim.x / 8;
-    auto group_at = [&](int64_t it) -> int64_t {
-        if (by_die) {
-            const int64_t q = (int64_t)(blockIdx.x >> 3) + it * die_stride;
-            const int64_t gi = (int64_t)(blockIdx.x & 7) * per_die + q;
-            return (q < per_die && gi < n_groups) ? gi : n_groups;
-        }
-        const int64_t gi = (int64_t)blockIdx.x + it * gridDim.x;
-        return gi < n_groups ? gi : n_groups;
-    };
-    TileGather<P, false> gather(X, ptr, idx, val, self_coef, HeavyRows{nullptr, nullptr}, n_rows, n_self);
-    const buf_t rs_x = gather.rs_x, rs_ptr = gather.rs_ptr, rs_self = gather.rs_self, rs_cnt = buf_of(sp.grp_cnt), rs_list = buf_of(sp.grp_list),
-                rs_slot = buf_of(sp.slot), rs_val = buf_of(val), rs_y = buf_of(Y);
-    const bool has_val = val != nullptr, has_self = self_coef != nullptr;
-    uint32_t vzero = 0u;
-    asm volatile("" : "+v"(vzero));
-    // ---- what is in flight.  "first" loads need the group index only, "second" loads need the first ones
-    int a_mine = 0, a_p0 = 0, a_p1 = 0, a_cnt = 0;                    // group A (this turn): pointers + count; its second loads are below
-    float4 sv[kStageKeep], sr[kRows];
-    float sc[kRows], e_val = 0.f;
-    int e_slot = 0;
-#define PP_STAGE_FIRST(G, MINE, P0, P1, CNT, LST)                                                   \
-    do {                                                                                            \
-        const bool in_ = (G) < n_groups;                                                            \
-        const int64_t r0_ = (G) * 64, rm_ = r0_ + (int64_t)tid, r1_ = r0_ + 64;                     \
-        MINE = (int)buf_load_u32(rs_ptr, (in_ && tid <= 64) ? (uint32_t)(rm_ < n_rows ? rm_ : n_rows) * 4u : kBufOob); \
-        /* (`vzero`: the three group-wide values must not LOOK uniform — the compiler would move them to scalar registers at once, */ \
-        /* i.e. wait for them, and everything requested before them, right behind the request) */ \
-        P0 = (int)buf_load_u32(rs_ptr, in_ ? (uint32_t)r0_ * 4u + vzero : kBufOob);                 \
-        P1 = (int)buf_load_u32(rs_ptr, in_ ? (uint32_t)(r1_ < n_rows ? r1_ : n_rows) * 4u + vzero : kBufOob); \
-        CNT = (int)__builtin_amdgcn_raw_buffer_load_b8(rs_cnt, in_ ? (int)(G) + (int)vzero : (int)kBufOob, 0, 0); \
-        _Pragma("unroll") for (int k_ = 0; k_ < kStageKeep; ++k_)                                   \
-            LST[k_] = (int)buf_load_u32(rs_list, in_ ? (uint32_t)((G) * kStageSlots + lg + 16 * k_) * 4u : kBufOob); \
-    } while (0)
-#define PP_STAGE_ROWS(G, CNT, LST, K0, K1)                                                           \
-    do {                                                                                            \
-        const bool staged_ = (G) < n_groups && (CNT) != (int)kStageFallback;                        \
-        _Pragma("unroll") for (int k_ = K0; k_ < K1; ++k_)                                          \
-            sv[k_] = buf_load_f4(rs_x, (staged_ && lg + 16 * k_ < (CNT)) ? ((uint32_t)LST[k_] << 8) + 16u * l : kBufOob); \
-    } while (0)
-#define PP_STAGE_SELF(G, CNT)                                                                       \
-    do {                                                                                            \
-        const bool staged_ = (G) < n_groups && (CNT) != (int)kStageFallback;                        \
-        _Pragma("unroll") for (int q_ = 0; q_ < kRows; ++q_) {                                      \
-            const int64_t r_ = ((G) * kWaves + wave) * 16 + g * kRows + q_;                         \
-            const bool self_ = staged_ && has_self && r_ < n_self;                                  \
-            sc[q_] = buf_load_f32(rs_self, self_ ? (uint32_t)r_ * 4u : kBufOob);                    \
-            sr[q_] = buf_load_f4(rs_x, self_ ? ((uint32_t)r_ << 8) + 16u * l : kBufOob);            \
-        }                                                                                           \
-    } while (0)
-#define PP_STAGE_ENTRY(G, P0, P1, CNT)                                                              \
-    do {                                                                                            \
-        const bool staged_ = (G) < n_groups && (CNT) != (int)kStageFallback;                        \
-        const bool mine_ = staged_ && tid < (P1) - (P0);                                            \
-        e_slot = (int)__builtin_amdgcn_raw_buffer_load_b8(rs_slot, mine_ ? (P0) + tid : (int)kBufOob, 0, 0); \
-        e_val = buf_load_f32(rs_val, (mine_ && has_val) ? (uint32_t)((P0) + tid) * 4u : kBufOob);   \
-        if (!has_val) e_val = 1.f;                                                                  \
-    } while (0)
-#define PP_STAGE_SECOND(G, P0, P1, CNT, LST)                                                        \
-    do {                                                                                            \
-        PP_STAGE_ROWS(G, CNT, LST, 0, kStageKeep);                                                  \
-        PP_STAGE_SELF(G, CNT);                                                                      \
-        PP_STAGE_ENTRY(G, P0, P1, CNT);                                                             \
-    } while (0)
-    int64_t grp = group_at(0), grp_b = group_at(1);
-    // the first requests of the next group (no value with its load still in flight is ever COPIED: a copy is a use — rotating b <- c at the end
-    // of a turn made the compiler wait there for the loads it had just issued, the next group's rows included)
-    int x_mine = 0, x_p0 = 0, x_p1 = 0, x_cnt = 0, x_lst[kStageKeep];
-    {
-        int lst0[kStageKeep];
-        PP_STAGE_FIRST(grp, a_mine, a_p0, a_p1, a_cnt, lst0);
-        PP_STAGE_SECOND(grp, a_p0, a_p1, a_cnt, lst0);
-        PP_STAGE_FIRST(grp_b, x_mine, x_p0, x_p1, x_cnt, x_lst);
-    }
-    // the stores of a group wait in registers until the NEXT turn's requests go out: a store in flight makes every wait behind it stricter
-    // than its loads need (thread-0 counters with the stores at the end of their own turn: 41 % of the kernel in the waits for the next
-    // group's list, which had long arrived — the wait was for the stores just issued)
-    int64_t p_row0 = 0;
-    uint32_t p_dead = 0xFFFFFFFFu;
-#define PP_STAGE_STORES()                                                                                                         \
-    _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                                          \
-        const uint32_t past = p_row0 + reg < n_rows ? p_dead : 0xFFFFFFFFu;                                                        \
-        const uint32_t off = ((((uint32_t)(p_row0 + reg) << 8) + 16u * i) & ~past) | (kBufOob & past);                             \
-        if constexpr (kStream) buf_store_f4_nt(rs_y, off, make_float4(yp[reg][0], yp[reg][1], yp[reg][2], yp[reg][3]));            \
-        else buf_store_f4(rs_y, off, make_float4(yp[reg][0], yp[reg][1], yp[reg][2], yp[reg][3]));                                 \
-    }
-    [[maybe_unused]] long long prof_t = (long long)__builtin_readcyclecounter();
-    // one turn: group A = `grp` is worked on, B = `grp_b` (first loads in the B set) gets its second loads, the group after it its first loads (C set)
-#define PP_STAGE_TURN(B_MINE, B_P0, B_P1, B_CNT, B_LST, C_MINE, C_P0, C_P1, C_CNT, C_LST)                                        \
-    {                                                                                                                            \
-        const int64_t t = grp * kWaves + wave;                                                                                   \
-        const bool staged = a_cnt != (int)kStageFallback, live = t < n_tiles && staged;                                          \
-        const int nnz = staged ? a_p1 - a_p0 : 0, cnt = staged ? a_cnt : 0;                                                      \
-        PP_PROF_MARK(0);                                                                                                         \
-        /* ALL waiting for memory happens here: everything requested during the last turn is "used" by empty asm statements, so */ \
-        /* the compiler puts its waits in front of them — and none behind this turn's requests, where a wait (its counts are the  */ \
-        /* safe ones wherever two paths meet) would cover the rows just asked for */                                             \
-        _Pragma("unroll") for (int k = 0; k < kStageKeep; ++k)                                                                   \
-            asm volatile("" : "+v"(sv[k].x), "+v"(sv[k].y), "+v"(sv[k].z), "+v"(sv[k].w), "+v"(B_LST[k]));                       \
-        _Pragma("unroll") for (int q = 0; q < kRows; ++q)                                                                        \
-            asm volatile("" : "+v"(sr[q].x), "+v"(sr[q].y), "+v"(sr[q].z), "+v"(sr[q].w), "+v"(sc[q]));                          \
-        asm volatile("" : "+v"(e_slot), "+v"(e_val), "+v"(B_MINE), "+v"(B_P0), "+v"(B_P1), "+v"(B_CNT));                         \
-        __syncthreads();                                             /* every wave is done with the previous group's stage */    \
-        PP_PROF_MARK(1);                                                                                                         \
-        _Pragma("unroll") for (int k = 0; k < kStageKeep; ++k)                                                                   \
-            if (lg + 16 * k < cnt) *(float4*)(s_stage + (lg + 16 * k) * P + 4 * l) = sv[k];                                      \
-        if (tid <= 64) s_gptr[tid] = a_mine - a_p0;                                                                              \
-        if (tid < nnz) {                                                                                                         \
-            s_slot[tid] = (uint8_t)e_slot;                                                                                       \
-            s_gval[tid] = pp_f32x2{e_val, e_val};                                                                                \
-        }                                                                                                                        \
-        pp_f32x2 acc[kRows][2];                                                                                                  \
-        _Pragma("unroll") for (int q = 0; q < kRows; ++q) {                                                                      \
-            acc[q][0] = pp_f32x2{sc[q] * sr[q].x, sc[q] * sr[q].y};                                                              \
-            acc[q][1] = pp_f32x2{sc[q] * sr[q].z, sc[q] * sr[q].w};                                                              \
-            /* (HERE, not where the sums begin: the compiler would sink the products below the next group's requests and wait */ \
-            /* for this group's self rows with a count that covers those requests) */                                           \
-            asm volatile("" : "+v"(acc[q][0]), "+v"(acc[q][1]) : : "memory");                                                    \
-        }                                                                                                                        \
-        PP_PROF_MARK(2);                                                                                                         \
-        __syncthreads();                                                                                                         \
-        PP_PROF_MARK(3);                                                                                                         \
-        /* requests of the coming turns: second loads of group B, first loads of the group after it */                           \
-        const int64_t grp_c = group_at(it + 2);                                                                                  \
-        /* (in four portions between the pieces of this group's arithmetic: a burst of all 34 requests at once has every wave of  */ \
-        /* the CU stand at the request queue for half of the turn and leaves the queue empty while they all compute) */         \
-        PP_STAGE_ROWS(grp_b, B_CNT, B_LST, 0, kStageKeep / 2);                                                                   \
-        PP_STAGE_ENTRY(grp_b, B_P0, B_P1, B_CNT);                                                                                \
-        PP_PROF_MARK(4);                                                                                                         \
-        if (live) {                                                                                                              \
-            int pr[kRows], pn[kRows];                                                                                            \
-            _Pragma("unroll") for (int q = 0; q < kRows; ++q) {                                                                  \
-                pr[q] = s_gptr[wave * 16 + g * kRows + q];                                                                       \
-                pn[q] = s_gptr[wave * 16 + g * kRows + q + 1];                                                                   \
-            }                                                                                                                    \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {          /* first four entries of the four rows: sixteen chains */    \
-                int sl[kRows];                                                                                                   \
-                pp_f32x2 c[kRows];                                                                                               \
-                _Pragma("unroll") for (int q = 0; q < kRows; ++q) {                                                              \
-                    const int e = pr[q] + u;                                                                                     \
-                    const bool in = e < pn[q];                                                                                   \
-                    sl[q] = in ? (int)s_slot[e] : 0;                                                                             \
-                    c[q] = s_gval[in ? e : 0];                                                                                   \
-                    if (!in) c[q] = pp_f32x2{0.f, 0.f};                                                                          \
-                }                                                                                                                \
-                _Pragma("unroll") for (int q = 0; q < kRows; ++q) {                                                              \
-                    const pp_f32x2* xv = (const pp_f32x2*)(s_stage + sl[q] * P + 4 * l);                                         \
-                    acc[q][0] = __builtin_elementwise_fma(c[q], xv[0], acc[q][0]);                                               \
-                    acc[q][1] = __builtin_elementwise_fma(c[q], xv[1], acc[q][1]);                                               \
-                }                                                                                                                \
-            }                                                                                                                    \
-            _Pragma("unroll") for (int q = 0; q < kRows; ++q) {                                                                  \
-                for (int e = pr[q] + 4; e < pn[q]; ++e) {                                                                        \
-                    const pp_f32x2 c = s_gval[e];                                                                                \
-                    const pp_f32x2* xv = (const pp_f32x2*)(s_stage + (int)s_slot[e] * P + 4 * l);                                \
-                    acc[q][0] = __builtin_elementwise_fma(c, xv[0], acc[q][0]);                                                  \
-                    acc[q][1] = __builtin_elementwise_fma(c, xv[1], acc[q][1]);                                                  \
-                }                                                                                                                \
-            }                                                                                                                    \
-        }                                                                                                                        \
-        __syncthreads();                                             /* every wave has read what it needs of the stage */        \
-        _Pragma("unroll") for (int q = 0; q < kRows; ++q)                                                                        \
-            *(float4*)(tile + (g * kRows + q) * TS + 4 * l) = make_float4(acc[q][0][0], acc[q][0][1], acc[q][1][0], acc[q][1][1]); \
-        PP_PROF_MARK(5);                                                                                                         \
-        __builtin_amdgcn_wave_barrier();                                                                                         \
-        PP_STAGE_ROWS(grp_b, B_CNT, B_LST, kStageKeep / 2, kStageKeep);                                                          \
-        f32x4 out[4];                                                                                                            \
-        _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) out[ct] = f32x4{0.f, 0.f, 0.f, 0.f};                                    \
-        stage_mfma_part<0, 2>(tile, s_b, i, kq, out);                /* (a wave past the last tile multiplies stale numbers) */   \
-        PP_STAGE_SELF(grp_b, B_CNT);                                 /* (not earlier: sixteen registers that the sums need) */    \
-        a_mine = B_MINE; a_p0 = B_P0; a_p1 = B_P1; a_cnt = B_CNT;                                                                \
-        stage_mfma_part<2, 4>(tile, s_b, i, kq, out);                                                                            \
-        PP_STAGE_FIRST(grp_c, C_MINE, C_P0, C_P1, C_CNT, C_LST);                                                                 \
-        float y[4][4];                                                                                                           \
-        stage_mfma_finish(out, bias_c, act, y);                                                                                  \
-        /* (a store that does not happen is an out-of-range offset made from a mask the compiler cannot see through: it would split */ \
-        /* the turn into a storing and a non-storing path again) */                                                              \
-        p_row0 = t * 16 + 4 * kq;                                                                                                \
-        p_dead = live ? 0u : 0xFFFFFFFFu;                                                                                        \
-        asm volatile("" : "+v"(p_dead));                                                                                         \
-        _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                                    \
-            const uint32_t past = p_row0 + reg < n_rows ? p_dead : 0xFFFFFFFFu;                                                  \
-            const uint32_t off = ((((uint32_t)(p_row0 + reg) << 8) + 16u * i) & ~past) | (kBufOob & past);                       \
-            if constexpr (kStream) buf_store_f4_nt(rs_y, off, make_float4(y[reg][0], y[reg][1], y[reg][2], y[reg][3]));          \
-            else buf_store_f4(rs_y, off, make_float4(y[reg][0], y[reg][1], y[reg][2], y[reg][3]));                               \
-        }                                                                                                                        \
-        grp = grp_b;                                                                                                             \
-        grp_b = grp_c;                                                                                                           \
-        ++it;                                                                                                                    \
-        PP_PROF_MARK(6);                                                                                                         \
-    }
-    for (int64_t it = 0; grp < n_groups;) {
-        // (ONE set of registers for the first requests: a group's list is dead once its second requests are out, its pointers are copied —
-        // arrived — before the next group's first requests are written over them, as the last requests of the turn)
-        PP_STAGE_TURN(x_mine, x_p0, x_p1, x_cnt, x_lst, x_mine, x_p0, x_p1, x_cnt, x_lst)
-    }
-#undef PP_STAGE_TURN
-#undef PP_STAGE_STORES
-#undef PP_STAGE_FIRST
-#undef PP_STAGE_SECOND
-#undef PP_STAGE_ROWS
-#undef PP_STAGE_SELF
-#undef PP_STAGE_ENTRY
-    __syncthreads();
-    // ---- the groups the plan could not stage (more than 256 entries or 96 distinct sources): gathered the ordinary way
-    const int n_fb = sp.fallback[0];
-    for (int k = blockIdx.x; k < n_fb; k += gridDim.x) {
-        const int64_t t = (int64_t)sp.fallback[1 + k] * kWaves + wave;
-        if (t >= n_tiles) continue;
-        gather.prefetch(t);
-        gather.run(t, n_tiles, tile, nullptr);
-        __builtin_amdgcn_wave_barrier();
-        float y[4][4];
-        stage_mfma(tile, s_b, bias_c, act, i, kq, y);
-        const int64_t row0 = t * 16 + 4 * kq;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-            if (row0 + reg < n_rows) store_row_f4(Y + (row0 + reg) * Q + CT * i, make_float4(y[reg][0], y[reg][1], y[reg][2], y[reg][3]), kStream);
-    }
-}
-
-static int launch_gcn_forward_staged(hipStream_t st, const GcnArgs& a, const StageArgs& sp) {
-    static int resident = 0;
-    if (resident == 0) {
-        int per_cu = 0, dev = 0, cus = 0;
-        PP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gcn_forward_staged<true>, kGcnThreads, 0));
-        PP_HIP(hipGetDevice(&dev));
-        PP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        resident = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
-    }
-    const int64_t n_groups = ceil_div(ceil_div(a.n, 16), kGcnWaves);
-    int64_t blocks = shared_grid(resident);
-    if (blocks > n_groups) blocks = (n_groups + 7) / 8 * 8;
-    const bool stream = a.n * (int64_t)(64 * 4) >= kStreamFromBytes;
-#ifdef PP_STAGE_PROF
-    static unsigned long long* prof = nullptr;
-    if (!prof) PP_HIP(hipMalloc((void**)&prof, 64));
-    PP_HIP(hipMemsetAsync(prof, 0, 64, st));
-    StageArgs spp = sp;
-    spp.prof = prof;
-    k_gcn_forward_staged<true><<<(unsigned)blocks, kGcnThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n, a.X, a.self_coef, a.W, a.bias, a.act, spp, a.Y, a.n_self);
-    unsigned long long h[8];
-    PP_HIP(hipMemcpyAsync(h, prof, 64, hipMemcpyDeviceToHost, st));
-    PP_HIP(hipStreamSynchronize(st));
-    fprintf(stderr, "[stage prof] %lld workgroups; thread-0 cycles summed: loop top %llu | barrier 1 %llu | stage write (waits for the rows) %llu | barrier 2 %llu | "
-            "issue next (waits for the list) %llu | sum rows %llu | mfma + store %llu\n", (long long)blocks, h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
-    return PP_OK;
-#endif
-    if (stream) k_gcn_forward_staged<true><<<(unsigned)blocks, kGcnThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n, a.X, a.self_coef, a.W, a.bias, a.act, sp, a.Y, a.n_self);
-    else k_gcn_forward_staged<false><<<(unsigned)blocks, kGcnThreads, 0, st>>>(a.ptr, a.idx, a.val, a.n, a.X, a.self_coef, a.W, a.bias, a.act, sp, a.Y, a.n_self);
-    return PP_OK;
-}
-
 }  // namespace pp
 
 extern "C" {
@@ -1482,42 +1024,6 @@ int pp_gcn_backward_nnz_f32(const int32_t* ptr, const int32_t* idx, const float*
     if (rc != PP_OK) return rc;
     PP_LAUNCH_CHECK();
     return pp::weight_grad_reduce((const float*)ws, nullptr, blocks, M, K, dW, nullptr, st);
-}
-
-/* see include/pathpyg_amd.h */
-int pp_gcn_stage_slots(void) { return pp::kStageSlots; }
-
-int pp_gcn_stage_plan_i32(const int32_t* ptr, const int32_t* idx, int64_t n_rows, uint8_t* grp_cnt, int32_t* grp_list, uint8_t* slot, int32_t* fallback,
-                          pp_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
-    PP_REQUIRE(n_rows >= 0, PP_ERR_ARG, "pp_gcn_stage_plan_i32: negative size");
-    PP_REQUIRE(n_rows < ((int64_t)1 << 31) - 64, PP_ERR_TOO_LARGE, "pp_gcn_stage_plan_i32: more than 2^31 rows");
-    PP_REQUIRE(fallback != nullptr, PP_ERR_ARG, "pp_gcn_stage_plan_i32: fallback must hold 1 + ceil(n_rows / 64) int32");
-    PP_HIP(hipMemsetAsync(fallback, 0, sizeof(int32_t), st));
-    if (n_rows == 0) return PP_OK;
-    const int64_t n_groups = pp::ceil_div(n_rows, 64);
-    pp::k_stage_plan<<<(unsigned)pp::ceil_div(n_groups, pp::kGcnWaves), pp::kGcnThreads, 0, st>>>(ptr, idx, n_rows, n_groups, grp_cnt, grp_list, slot, fallback);
-    PP_LAUNCH_CHECK();
-    return PP_OK;
-}
-
-int pp_gcn_forward_staged_f32(const int32_t* ptr, const int32_t* idx, const float* val, int64_t n_rows, int64_t n_src, const float* X,
-                              const float* self_coef, const float* W, const float* bias, int act, const uint8_t* grp_cnt, const int32_t* grp_list,
-                              const uint8_t* slot, const int32_t* fallback, float* Y, pp_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
-    PP_REQUIRE(n_rows >= 0 && n_src >= 0, PP_ERR_ARG, "pp_gcn_forward_staged_f32: negative size");
-    PP_REQUIRE(act == 0 || act == 1, PP_ERR_ARG, "pp_gcn_forward_staged_f32: act must be 0 (none) or 1 (elu)");
-    PP_REQUIRE(((uintptr_t)X | (uintptr_t)Y) % 16 == 0, PP_ERR_ARG, "pp_gcn_forward_staged_f32: X and Y must be 16-byte aligned");
-    PP_REQUIRE((uint64_t)n_src * 256u < (uint64_t)pp::kBufOob && n_rows < ((int64_t)1 << 30) - 64, PP_ERR_TOO_LARGE,
-               "pp_gcn_forward_staged_f32: X of 4 GiB or more (use pp_gcn_forward_f32)");
-    PP_REQUIRE(grp_cnt != nullptr && grp_list != nullptr && fallback != nullptr, PP_ERR_ARG, "pp_gcn_forward_staged_f32: no stage plan");      // (slot: NULL for a graph without entries)
-    if (n_rows == 0) return PP_OK;
-    const pp::GcnArgs a{ptr, idx, val, n_rows, X, self_coef, W, bias, act, pp::HeavyRows{nullptr, nullptr}, false, nullptr, Y, nullptr, nullptr, n_rows,
-                        pp::drop_site(0.0, 0, 0, 0)};
-    const int rc = pp::launch_gcn_forward_staged(st, a, pp::StageArgs{grp_cnt, grp_list, slot, fallback});
-    if (rc != PP_OK) return rc;
-    PP_LAUNCH_CHECK();
-    return PP_OK;
 }
 
 }  // extern "C"

@@ -49,6 +49,22 @@ constexpr uint32_t kHeadBit = 0x80000000u;
 __device__ __forceinline__ uint4 mo_inst(uint32_t cf, uint32_t cc, bool head, uint32_t d, float w) {
     return make_uint4(cf, cc | (head ? kHeadBit : 0u), d, __float_as_uint(w));
 }
+// Child records as the children pass leaves them for the types pass.  kFmt 0: the full 16-byte instance (a level below the top: the next
+// level's parents).  The children of the TOP layer are nobody's parents — only their last node and the head flag are read again
+// (kFmt 1: 4 bytes, last node | head bit; node ids stay below 2^31), with event weights also the weight (kFmt 2: 8 bytes).
+template <int kFmt>
+__device__ __forceinline__ void mo_store_child(void* __restrict__ out, int64_t i, uint32_t cf, uint32_t cc, bool head, uint32_t d, uint32_t w_bits) {
+    if constexpr (kFmt == 0) ((uint4*)out)[i] = make_uint4(cf, cc | (head ? kHeadBit : 0u), d, w_bits);
+    else if constexpr (kFmt == 1) ((uint32_t*)out)[i] = d | (head ? kHeadBit : 0u);
+    else ((uint2*)out)[i] = make_uint2(d | (head ? kHeadBit : 0u), w_bits);
+}
+template <int kFmt>
+__device__ __forceinline__ uint4 mo_load_child(const void* __restrict__ in, int64_t i) {
+    if constexpr (kFmt == 0) return ((const uint4*)in)[i];
+    else if constexpr (kFmt == 1) { const uint32_t x = ((const uint32_t*)in)[i]; return make_uint4(0u, x & kHeadBit, x & ~kHeadBit, 0x3f800000u); }
+    else { const uint2 x = ((const uint2*)in)[i]; return make_uint4(0u, x.x & kHeadBit, x.x & ~kHeadBit, x.y); }
+}
+constexpr int mo_fmt(bool weighted, bool last) { return last ? (weighted ? 2 : 1) : 0; }
 
 // ------------------------------------------------------------------ level 1: the events grouped by (source, target), time order inside
 template <typename KeyT>
@@ -189,8 +205,9 @@ __device__ __forceinline__ void mo_append(bool flag, int32_t value, int32_t* __r
     if (flag) list[base + (int32_t)__popcll(mask & lanemask_lt())] = value;
 }
 
+template <int kFmt>
 __global__ __launch_bounds__(kBlock) void k_mo_children(int64_t n_types, const int32_t* __restrict__ tptr, const int32_t* __restrict__ ibase,
-                                                       const uint4* __restrict__ inst, const uint4* __restrict__ tab, uint4* __restrict__ out,
+                                                       const uint4* __restrict__ inst, const uint4* __restrict__ tab, void* __restrict__ out,
                                                        int32_t* __restrict__ deg, uint8_t* __restrict__ cls, int32_t* __restrict__ big_list,
                                                        int32_t* __restrict__ counters) {
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void k_mo_children(int64_t n_types, const i
         if (q < n) {
             const bool h = q == 0 || d[q] != d[q > 0 ? q - 1 : 0];
             heads += h ? 1 : 0;
-            out[c0 + q] = make_uint4(cf[q], cc[q] | (h ? kHeadBit : 0u), d[q], w[q]);
+            mo_store_child<kFmt>(out, c0 + q, cf[q], cc[q], h, d[q], w[q]);
         }
     }
     deg[s] = heads;
@@ -248,8 +265,9 @@ struct MoWaveLds {
     int32_t adj[kMoWaveTypes], deg[kMoWaveTypes], x0s[kMoWaveTypes], pin[kMoWaveTypes];
 };
 
+template <int kFmt>
 __global__ __launch_bounds__(kBlock) void k_mo_children_wave(const int32_t* __restrict__ tptr, const int32_t* __restrict__ ibase,
-                                                            const uint4* __restrict__ inst, const uint4* __restrict__ tab, uint4* __restrict__ out,
+                                                            const uint4* __restrict__ inst, const uint4* __restrict__ tab, void* __restrict__ out,
                                                             int32_t* __restrict__ deg, const uint8_t* __restrict__ cls, int64_t n_types) {
     __shared__ MoWaveLds lds[kWavesPerBlock];
     MoWaveLds& L = lds[wave_id()];
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void k_mo_children_wave(const int32_t* __re
                     const bool h = (key >> 8) != (prev >> 8);
                     const int t_l = (int)(key >> 40), slot = (int)(key & 0xffu);
                     const int k = (int)L.marks[slot] - 1;
-                    out[L.adj[t_l] + pos] = make_uint4(L.ccf[slot], L.ccc[slot] | (h ? kHeadBit : 0u), (uint32_t)(key >> 8), L.nz_w[k]);
+                    mo_store_child<kFmt>(out, L.adj[t_l] + pos, L.ccf[slot], L.ccc[slot], h, (uint32_t)(key >> 8), L.nz_w[k]);
                     if (h) atomicAdd(&L.deg[t_l], 1);
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -374,8 +392,9 @@ __global__ __launch_bounds__(kBlock) void k_mo_children_wave(const int32_t* __re
 }
 
 // types with more children (or instances) than a lane takes: one workgroup each, (last node, slot) keys sorted in LDS
+template <int kFmt>
 __global__ __launch_bounds__(kBlock) void k_mo_children_big(const int32_t* __restrict__ tptr, const int32_t* __restrict__ ibase, const uint4* __restrict__ inst,
-                                                           const uint4* __restrict__ tab, uint4* __restrict__ out, int32_t* __restrict__ deg,
+                                                           const uint4* __restrict__ tab, void* __restrict__ out, int32_t* __restrict__ deg,
                                                            const int32_t* __restrict__ big_list, const int32_t* __restrict__ big_count,
                                                            int64_t* __restrict__ status) {
     __shared__ uint32_t s_src[kMoBigMax];
@@ -426,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_mo_children_big(const int32_t* __res
             const uint32_t c = (uint32_t)key, dd = (uint32_t)(key >> 32);
             const bool h = r == 0 || (uint32_t)(s_key[r - 1] >> 32) != dd;
             const uint4 e = tab[s_src[c]];
-            out[c0 + r] = make_uint4(e.y, e.z | (h ? kHeadBit : 0u), dd, s_w[c]);
+            mo_store_child<kFmt>(out, c0 + r, e.y, e.z, h, dd, s_w[c]);
             heads += h ? 1u : 0u;
         }
         uint32_t total;
@@ -453,7 +472,7 @@ __device__ __forceinline__ int32_t mo_find(const int32_t* __restrict__ cand, int
 template <bool kWeighted, bool kLast>
 __global__ __launch_bounds__(kBlock) void k_mo_types(int64_t n_types, const int32_t* __restrict__ tptr, const int32_t* __restrict__ ibase,
                                                     const int32_t* __restrict__ col, const int32_t* __restrict__ cand_ptr,
-                                                    const int32_t* __restrict__ cand_last, const uint4* __restrict__ child,
+                                                    const int32_t* __restrict__ cand_last, const void* __restrict__ child,
                                                     const int32_t* __restrict__ row_ptr, int32_t* __restrict__ tptr_out,
                                                     int32_t* __restrict__ tlast_out, int32_t* __restrict__ col_out, float* __restrict__ w_out,
                                                     int32_t* __restrict__ csum_out, int all_wave) {
@@ -467,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void k_mo_types(int64_t n_types, const int3
     const int32_t* cand = cand_last + bf;
     uint4 it[kMoSmall];
 #pragma unroll
-    for (int q = 0; q < kMoSmall; ++q) it[q] = q < n ? child[c0 + q] : make_uint4(0u, 0u, 0u, 0u);
+    for (int q = 0; q < kMoSmall; ++q) it[q] = q < n ? mo_load_child<mo_fmt(kWeighted, kLast)>(child, c0 + q) : make_uint4(0u, 0u, 0u, 0u);
     // the first kMoPre candidates in registers (one or two cache lines, requested back to back): the position of a last node among them is
     // the number of smaller ones — no dependent loads; longer blocks (first-order hubs) finish by bisection behind them
     int32_t pre[kMoPre];
@@ -515,7 +534,7 @@ struct MoTypesLds {
 template <bool kWeighted, bool kLast>
 __global__ __launch_bounds__(kBlock) void k_mo_types_wave(int64_t n_types, const int32_t* __restrict__ ibase, const int32_t* __restrict__ col,
                                                          const int32_t* __restrict__ cand_ptr, const int32_t* __restrict__ cand_last,
-                                                         const uint4* __restrict__ child, const int32_t* __restrict__ row_ptr,
+                                                         const void* __restrict__ child, const int32_t* __restrict__ row_ptr,
                                                          const uint8_t* __restrict__ cls, int32_t* __restrict__ tptr_out,
                                                          int32_t* __restrict__ tlast_out, int32_t* __restrict__ col_out, float* __restrict__ w_out,
                                                          int32_t* __restrict__ csum_out, int all_wave) {
@@ -555,7 +574,7 @@ __global__ __launch_bounds__(kBlock) void k_mo_types_wave(int64_t n_types, const
         const bool act = c < c_end && L.mid[lo];
         const uint64_t acts = __ballot(act);
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-        if (act) rec = child[c];
+        if (act) rec = mo_load_child<mo_fmt(kWeighted, kLast)>(child, c);
         const bool head = act && (rec.y & kHeadBit);
         const uint64_t hb = __ballot(head);
         // close or extend the open run (lane 0 speaks for it)
@@ -615,7 +634,7 @@ __global__ __launch_bounds__(kBlock) void k_mo_types_wave(int64_t n_types, const
 
 template <bool kWeighted, bool kLast>
 __global__ __launch_bounds__(kBlock) void k_mo_types_big(const int32_t* __restrict__ ibase, const int32_t* __restrict__ col, const int32_t* __restrict__ cand_ptr,
-                                                        const int32_t* __restrict__ cand_last, const uint4* __restrict__ child,
+                                                        const int32_t* __restrict__ cand_last, const void* __restrict__ child,
                                                         const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ big_list,
                                                         const int32_t* __restrict__ big_count, int32_t* __restrict__ tptr_out,
                                                         int32_t* __restrict__ tlast_out, int32_t* __restrict__ col_out, float* __restrict__ w_out,
@@ -634,7 +653,7 @@ __global__ __launch_bounds__(kBlock) void k_mo_types_big(const int32_t* __restri
         for (int32_t rb = 0; rb < n; rb += kBlock) {
             const int32_t r = rb + tid;
             uint4 it = make_uint4(0u, 0u, 0u, 0u);
-            if (r < n) it = child[c0 + r];
+            if (r < n) it = mo_load_child<mo_fmt(kWeighted, kLast)>(child, c0 + r);
             const bool h = r < n && (it.y & kHeadBit);
             uint32_t total;
             const uint32_t ex = block_exclusive_sum<uint32_t>(h ? 1u : 0u, s_scratch, &total);
@@ -646,7 +665,7 @@ __global__ __launch_bounds__(kBlock) void k_mo_types_big(const int32_t* __restri
                 float acc = __uint_as_float(it.w);
                 int32_t cnt = 1, cs = (int32_t)(it.y & ~kHeadBit);
                 for (int32_t q = r + 1; q < n; ++q) {
-                    const uint4 nx = child[c0 + q];
+                    const uint4 nx = mo_load_child<mo_fmt(kWeighted, kLast)>(child, c0 + q);
                     if (nx.y & kHeadBit) break;
                     acc += __uint_as_float(nx.w);
                     ++cnt;
@@ -800,15 +819,20 @@ int pp_multiorder_step(int64_t n_types, int64_t n_children, const int32_t* tptr,
     PP_HIP(hipMemsetAsync(p.result, 0, 4 * sizeof(int64_t), st));
     PP_HIP(hipMemsetAsync(p.counters, 0, 4 * sizeof(int32_t), st));
     const unsigned grid = (unsigned)ceil_div(n_types, kBlock);
-    k_mo_children<<<grid, kBlock, 0, st>>>(n_types, tptr, ibase, (const uint4*)inst, (const uint4*)tab, (uint4*)child, p.deg, p.cls, p.big_list,
-                                           p.counters);
-    PP_LAUNCH_CHECK();
     const int64_t pieces = ceil_div(n_types, kWavesPerBlock * kMoWaveTypes);
     const unsigned wave_grid = (unsigned)(pieces < 4096 ? pieces : 4096);
-    k_mo_children_wave<<<wave_grid, kBlock, 0, st>>>(tptr, ibase, (const uint4*)inst, (const uint4*)tab, (uint4*)child, p.deg, p.cls, n_types);
-    PP_LAUNCH_CHECK();
-    k_mo_children_big<<<1024, kBlock, 0, st>>>(tptr, ibase, (const uint4*)inst, (const uint4*)tab, (uint4*)child, p.deg, p.big_list, p.counters,
-                                               p.result + 1);
+#define PP_MO_CHILDREN(F)                                                                                                                          \
+    do {                                                                                                                                           \
+        k_mo_children<F><<<grid, kBlock, 0, st>>>(n_types, tptr, ibase, (const uint4*)inst, (const uint4*)tab, child, p.deg, p.cls, p.big_list,    \
+                                                  p.counters);                                                                                     \
+        k_mo_children_wave<F><<<wave_grid, kBlock, 0, st>>>(tptr, ibase, (const uint4*)inst, (const uint4*)tab, child, p.deg, p.cls, n_types);     \
+        k_mo_children_big<F><<<1024, kBlock, 0, st>>>(tptr, ibase, (const uint4*)inst, (const uint4*)tab, child, p.deg, p.big_list, p.counters,    \
+                                                      p.result + 1);                                                                               \
+    } while (0)
+    if (!last) PP_MO_CHILDREN(0);
+    else if (weighted) PP_MO_CHILDREN(2);
+    else PP_MO_CHILDREN(1);
+#undef PP_MO_CHILDREN
     PP_LAUNCH_CHECK();
     int rc = exclusive_scan<int32_t, int32_t>(p.deg, n_types, row_ptr, true, p.result, p.scratch, p.scratch_bytes, st);
     if (rc != PP_OK) return rc;
@@ -820,11 +844,11 @@ int pp_multiorder_step(int64_t n_types, int64_t n_children, const int32_t* tptr,
     const int all_wave = force ? (force[0] == '1' ? 1 : 0) : (last ? 0 : 1);
 #define PP_MO_TYPES(W, L)                                                                                                                          \
     do {                                                                                                                                           \
-        k_mo_types<W, L><<<grid, kBlock, 0, st>>>(n_types, tptr, ibase, col, cand_ptr, cand_last, (const uint4*)child, row_ptr, tptr_out,          \
+        k_mo_types<W, L><<<grid, kBlock, 0, st>>>(n_types, tptr, ibase, col, cand_ptr, cand_last, child, row_ptr, tptr_out,                        \
                                                   tlast_out, col_out, w_out, p.csum, all_wave);                                                              \
         k_mo_types_wave<W, L><<<all_wave ? (unsigned)pieces : wave_grid, kBlock, 0, st>>>(                                                         \
-            n_types, ibase, col, cand_ptr, cand_last, (const uint4*)child, row_ptr, p.cls, tptr_out, tlast_out, col_out, w_out, p.csum, all_wave); \
-        k_mo_types_big<W, L><<<1024, kBlock, 0, st>>>(ibase, col, cand_ptr, cand_last, (const uint4*)child, row_ptr, p.big_list, p.counters,       \
+            n_types, ibase, col, cand_ptr, cand_last, child, row_ptr, p.cls, tptr_out, tlast_out, col_out, w_out, p.csum, all_wave);               \
+        k_mo_types_big<W, L><<<1024, kBlock, 0, st>>>(ibase, col, cand_ptr, cand_last, child, row_ptr, p.big_list, p.counters,                     \
                                                       tptr_out, tlast_out, col_out, w_out, p.csum);                                                \
     } while (0)
     if (weighted) { if (last) PP_MO_TYPES(true, true); else PP_MO_TYPES(true, false); }

@@ -298,15 +298,3 @@ def test_dbgnn_forward_honours_handed_plans_only_while_the_bundle_is_untouched()
     assert _valid_plans(d3) is None                                                     # the bundle's node count no longer matches the plan
     w.mul_(2)
     assert _valid_plans(d) is None
-
-
-def test_staged_layer_applies_to_short_rows_of_a_64_wide_layer_below_4_gib():
-    """`gcn_stage_wanted` (host logic of the opt-in staged layer kernel, csrc/pp_gcn_fused.hip): 64 x 64, at most 3.5 entries per row on average
-    (a 64-row group may hold 256), X addressable with 32-bit offsets."""
-    from pathpyg_amd import _hip
-    assert _hip.gcn_stage_wanted(10**7, 10**7, 19 * 10**6, 64, 64)
-    assert not _hip.gcn_stage_wanted(10**7, 10**7, 36 * 10**6, 64, 64)            # 3.6 entries per row
-    assert not _hip.gcn_stage_wanted(10**7, 17 * 10**6, 19 * 10**6, 64, 64)       # 17e6 * 256 bytes: beyond the buffer range
-    assert not _hip.gcn_stage_wanted(10**7, 10**7, 19 * 10**6, 128, 64)
-    assert not _hip.gcn_stage_wanted(10, 10, 10, 64, 64)                          # not even one group
-    assert not _hip.gcn_stage_wanted(10**6, 10**6, 0, 64, 64)
