@@ -403,7 +403,8 @@ def cpu_baseline(args, seed: int) -> dict:
 # ---------------------------------------------------------------------------------------------------------------------------------
 def hub_streams(dev) -> dict:
     """Graph construction (both layers + both GCN plans + the bipartite grouping) on two streams WITH hub nodes, fused order-2 builder against the
-    generic kernels (lift -> coalesce -> coalesce -> plans), same stream, same box; `plans_identical`: every CSR array of both plans compared."""
+    generic kernels (lift -> coalesce -> coalesce -> plans), same stream, same box; `plans_identical`: every CSR array of both plans compared;
+    `chosen_*`: the builder the callers take (`_hip.debruijn2_wanted`: the generic kernels from 2048 events per node on average)."""
     import pathpyg_amd as pp
     from pathpyg_amd import _hip
     from pathpyg_amd import distributed as ppd
@@ -436,7 +437,9 @@ def hub_streams(dev) -> dict:
         ppd.FUSED_BUILDER = True
         same = built is not None and all(torch.equal(getattr(built.ho, f), getattr(shard.ho.plan, f)) and torch.equal(getattr(built.fo, f), getattr(shard.fo.plan, f))
                                          for f in ("fwd_ptr", "fwd_idx", "fwd_val", "bwd_ptr", "bwd_idx", "bwd_val", "self_coef"))
+        chosen = "fused" if (built is not None and _hip.debruijn2_wanted(m, n)) else "generic"
         report[name] = {"delta": delta, "fused_builder_ms": ms_f, "generic_kernels_ms": ms_g, "builder": "fused" if built is not None else "generic (fallback)",
+                        "chosen_by_from_temporal_graph_and_build_dbgnn_shard": chosen, "chosen_ms": ms_f if chosen == "fused" else ms_g,
                         "plans_identical": bool(same), **({k: built.sizes[k] for k in ("E2", "U2", "A2", "hub_nodes", "hub_tasks")} if built is not None else {})}
         del built, shard, tg, x0
         torch.cuda.empty_cache()

@@ -752,6 +752,18 @@ def _pinned_stats() -> torch.Tensor:
     return buf
 
 
+DENSE_EVENTS_PER_NODE = 2048
+
+
+def debruijn2_wanted(m: int, num_nodes: int) -> bool:
+    """Whether the node-by-node order-2 builder is the one to use for a stream of ``m`` events over ``num_nodes`` nodes.  It works node by node —
+    in-events x out-events of the middle node — and is built for nodes with tens of events per side (hubs are chunked).  On a contact-shaped
+    stream (tens of nodes, 10^4 events per node and side: 96 nodes / 2 * 10^6 events) every node is a hub and the per-node scans cost 1.9 ms where
+    lift -> coalesce -> coalesce -> plans takes 1.0 ms (``hub_streams`` in the bench line): from ``DENSE_EVENTS_PER_NODE`` events per node on average
+    the callers that choose (``MultiOrderModel.from_temporal_graph``, ``distributed.build_dbgnn_shard``) take the generic kernels."""
+    return m <= DENSE_EVENTS_PER_NODE * max(int(num_nodes), 1)
+
+
 def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, weight: torch.Tensor | None = None,
               want_weights: bool = False, unsorted_ok: bool = False):
     """Order-2 De Bruijn model of a TIME-SORTED event stream, fused (pp_debruijn2_lists / _count / _fill, csrc/pp_debruijn.hip): what

@@ -382,7 +382,8 @@ def _second_order_fused(g: TemporalGraph, delta, weight: str, cached: bool):
     over the stream yields both layers as CSR plans — no event graph, no ``[E_2, 2]`` instance tensors, one read-back.  The reference's layer
     tensors (reference multi_order_model.py:153-181: ``edge_index``, ``edge_weight``, ``node_sequence``, ``inverse_idx`` of both layers) are
     :class:`~pathpyg_amd.data.Lazy` views of those plans, identical to what the generic kernels produce, made when somebody reads them.
-    ``None``: the builder does not apply (host-resident stream, a weight attribute that is not float32, an unsorted stream)."""
+    ``None``: the builder does not apply (host-resident stream, a weight attribute that is not float32, an unsorted stream) or is not the one to use
+    (a contact-shaped stream, ``_hip.debruijn2_wanted``)."""
     from .. import _hip
     data = g.data
     ei = _dispatch.plain(data.edge_index)
@@ -395,7 +396,9 @@ def _second_order_fused(g: TemporalGraph, delta, weight: str, cached: bool):
         if not isinstance(w, torch.Tensor) or w.dtype != torch.float32 or not w.is_cuda:
             return None
     n, m_events = int(data.num_nodes), int(ei.size(1))
-    if n == 0 or m_events == 0 or not data.is_sorted_by_time():          # (unsorted: one cheap kernel instead of the builder's whole count pass)
+    if n == 0 or m_events == 0 or not _hip.debruijn2_wanted(m_events, n):
+        return None
+    if not data.is_sorted_by_time():          # (unsorted: one cheap kernel instead of the builder's whole count pass)
         return None
     built = _hip.debruijn2(ei, time, n, delta, w, want_weights=True, unsorted_ok=True)
     if built is None:

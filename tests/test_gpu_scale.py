@@ -583,9 +583,10 @@ def test_config2_20m_scale_free_stream_stays_on_the_fused_builder(pp):
     _compare(fused, generic, hubs=True)
 
 
-def test_contact_network_96_nodes_2m_events_stays_on_the_fused_builder(pp):
+def test_contact_network_96_nodes_2m_events_on_both_builders(pp):
     """The shape of the reference's documented datasets (96 nodes / 2.17*10^6 events): every node has ~2*10^4 in- and
-    out-events.  Fused builder against the oracle (delta = 30) and against the generic kernels (delta = 300, E2 = 6*10^6)."""
+    out-events.  Fused builder against the oracle (delta = 30) and against the generic kernels (delta = 300, E2 = 6*10^6).  The reference API
+    takes the generic kernels on such a stream (`_hip.debruijn2_wanted`: they are the faster ones there, `hub_streams` in the bench line)."""
     from oracle import model as om
     from pathpyg_amd import _hip
     from tests.test_gpu_builder import _build, _compare
@@ -604,7 +605,10 @@ def test_contact_network_96_nodes_2m_events_stays_on_the_fused_builder(pp):
     _compare(_build(sei.cpu(), st.cpu(), n, 300, None, True), _build(sei.cpu(), st.cpu(), n, 300, None, False), hubs=True)
     # through the reference API: layers, bundle, one DBGNN step
     mom = pp.MultiOrderModel.from_temporal_graph(g, delta=300, max_order=2)
-    assert getattr(mom, "_pp_fused", None) is not None
+    assert getattr(mom, "_pp_fused", None) is None and not _hip.debruijn2_wanted(m, n)
+    want = om.layers_from_temporal(sei.cpu(), st.cpu(), n, delta=300, max_order=2)
+    for k in (1, 2):
+        assert torch.equal(mom.layers[k].data.edge_index.cpu(), want[k]["edge_index"]) and torch.equal(mom.layers[k].data.edge_weight.cpu(), want[k]["edge_weight"])
     data = mom.to_dbgnn_data(max_order=2, x=torch.randn(n, 16, device=DEV), x_h=torch.randn(mom.layers[2].n, 16, device=DEV))
     net = pp.nn.DBGNN(num_classes=3, num_features=(16, 16), hidden_dims=[16, 16, 16]).to(DEV)
     out = net(data)

@@ -298,3 +298,13 @@ def test_dbgnn_forward_honours_handed_plans_only_while_the_bundle_is_untouched()
     assert _valid_plans(d3) is None                                                     # the bundle's node count no longer matches the plan
     w.mul_(2)
     assert _valid_plans(d) is None
+
+
+def test_order2_builder_is_not_chosen_for_contact_shaped_streams():
+    """`_hip.debruijn2_wanted` (who builds the order-2 model: host logic of `MultiOrderModel.from_temporal_graph(max_order=2)` and
+    `distributed.build_dbgnn_shard`): node by node up to 2048 events per node on average, the generic kernels beyond (VERDICT r5 #4a)."""
+    from pathpyg_amd import _hip
+    assert _hip.debruijn2_wanted(10**7, 5 * 10**5)              # the headline stream: 20 events per node
+    assert _hip.debruijn2_wanted(2 * 10**7, 10**6)              # BASELINE configs[2]'s scale-free generator (one node with 2 * 10^6 in-events)
+    assert _hip.debruijn2_wanted(28_561, 126)                   # the size of the reference's documented contact datasets: 227 events per node
+    assert not _hip.debruijn2_wanted(2 * 10**6, 96)             # 96 nodes / 2 * 10^6 events: every node a hub on both sides
