@@ -452,7 +452,8 @@ def multi_order(g, nodes: int, delta, dev) -> dict:
     per call, and per LAYER (HIP events around the C calls of the level-by-level builder, pp_multiorder_prepare / pp_multiorder_step): instance
     edges E_k the reference lifts, nodes U_k, edges A_k, the SURVEY §8(d) bytes of the generic pipeline for that layer (line-graph lift
     16 E_{k-1} + 16 E_k, coalesce 20 E_k + 20 A_k; layer 2: the temporal lift's 24 m + 16 E_2) and the bytes this builder moves
-    (16 I_{k-1} + 48 I_k + 20 A_k: parent records in, child records out and in again, the window table read per child, the layer out),
+    (16 I_{k-1} + 48 I_k + 20 A_k: parent records in, child records out and in again, the window table read per child, the layer and the next
+    level's type arrays out; top layer: 16 I_{k-1} + 24 I_k + 8 A_k — 4-byte child records, columns + weights only),
     both over the layer's time against 8 TB/s."""
     import pathpyg_amd as pp
     from pathpyg_amd import _hip
@@ -484,7 +485,8 @@ def multi_order(g, nodes: int, delta, dev) -> dict:
         for k in range(2, k_max + 1):
             b, prev = built[k - 1], built[k - 2]
             table = (24 * m_events + 16 * b.n_instances if k == 2 else 16 * prev.n_instances + 16 * b.n_instances) + 20 * b.n_instances + 20 * b.n_edges
-            moved = 16 * prev.n_instances + 48 * b.n_instances + 20 * b.n_edges
+            top = k == k_max          # (the top layer's children are 4-byte records and only columns + weights come out)
+            moved = 16 * prev.n_instances + (24 if top else 48) * b.n_instances + (8 if top else 20) * b.n_edges
             ms_k = best[k - 1]
             rows.append({"phase": f"layer {k} (pp_multiorder_step)", "ms": ms_k, "U": b.n_nodes, "A": b.n_edges, "E": b.n_instances,
                          "table_bytes": table, "moved_bytes": moved,

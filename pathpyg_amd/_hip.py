@@ -734,7 +734,8 @@ _HUB_PART_BYTES_MAX = 24 << 30         # per-task partial results of the hub nod
 _tls = threading.local()
 
 
-_A2_GUESS: dict = {}                    # (m, n, want_weights) -> A2 of the last build of a stream of that shape (debruijn2 allocates ahead of its read-back)
+_A2_GUESS: dict = {}                    # (m, n, want_weights, delta) -> A2 of the last build of a stream of that shape at that delta (debruijn2 allocates ahead of its read-back;
+#                                         delta is part of the key: a sweep from a large to a small delta would otherwise keep plans that are views of buffers many times too long)
 
 
 def _a2_buffers(a2: int, want_weights: bool, i32: dict, f32: dict) -> tuple:
@@ -821,7 +822,8 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
         # (an epoch loop, a rolling window) and re-allocated when the guess is short or more than a quarter too long.
         ho_self, fo_fwd_idx, fo_fwd_val = torch.empty(m, **f32), torch.empty(m, **i32), torch.empty(m, **f32)
         fo_dst_order, fo_bwd_val, fo_self = torch.empty(m, **i32), torch.empty(m, **f32), torch.empty(n, **f32)
-        guess = _A2_GUESS.get((m, n, want_weights), 0)
+        guess_key = (m, n, want_weights, kind, di, df)
+        guess = _A2_GUESS.get(guess_key, 0)
         a2_bufs = _a2_buffers(guess, want_weights, i32, f32) if guess else None
         launched = False
         if a2_bufs is not None:
@@ -852,9 +854,9 @@ def debruijn2(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delt
             return None
         if not launched and (a2_bufs is None or not (a2 <= guess <= a2 + a2 // 4 + 1024)):
             a2_bufs = _a2_buffers(a2, want_weights, i32, f32)
-        if len(_A2_GUESS) >= 64 and (m, n, want_weights) not in _A2_GUESS:      # (a handful of stream shapes at a time: drop the oldest)
+        if len(_A2_GUESS) >= 64 and guess_key not in _A2_GUESS:      # (a handful of stream shapes at a time: drop the oldest)
             _A2_GUESS.pop(next(iter(_A2_GUESS)))
-        _A2_GUESS[(m, n, want_weights)] = a2
+        _A2_GUESS[guess_key] = a2
         ho_fwd_idx, ho_fwd_val, ho_bwd_idx, ho_bwd_val, pack, ho_fwd_w = (None if b is None else b[:k * a2] for b, k in zip(a2_bufs, (1, 1, 1, 1, 2, 1)))
         ho = CsrPlan(n_dst=u2, n_src=u2, fwd_ptr=ho_fwd_ptr[: u2 + 1], fwd_idx=ho_fwd_idx, fwd_val=ho_fwd_val,
                      bwd_ptr=ho_bwd_ptr[: u2 + 1], bwd_idx=ho_bwd_idx, bwd_val=ho_bwd_val, self_coef=ho_self[:u2], edge_ordered=True)

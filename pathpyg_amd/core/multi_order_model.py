@@ -300,15 +300,22 @@ class MultiOrderModel:
             # a training step that only runs the model never materialises [2, A2] indices (reference multi_order_model.py:511-554 builds
             # them eagerly; PyG's GCNConv re-normalises on every forward)
             u2, a2 = int(n_ho), int(built.sizes["A2"])
+            # (the makers hold the layers' tensors / Lazy objects AS THEY ARE NOW, not the bags: a layer edited after bundling does not leak into a
+            #  bundle whose plans were accepted for the tensors of this moment)
+            ei1, ei2, w2 = g.data.peek("edge_index"), g_ho.data.peek("edge_index"), g_ho.data.peek("edge_weight")
+
+            def now(v):
+                return v.resolve() if isinstance(v, Lazy) else v
+
             out = Data(
                 num_nodes=n,
                 num_ho_nodes=n_ho,
                 x=x,
                 x_h=x_h,
-                edge_index=Lazy(lambda: g.data.edge_index, (2, u2)),
-                edge_index_higher_order=Lazy(lambda: g_ho.data.edge_index, (2, a2)),
+                edge_index=Lazy(lambda: now(ei1), (2, u2)),
+                edge_index_higher_order=Lazy(lambda: now(ei2), (2, a2)),
                 edge_weights=g.data.edge_weight.float(),
-                edge_weights_higher_order=Lazy(lambda: g_ho.data.edge_weight.float(), (a2,)),
+                edge_weights_higher_order=Lazy(lambda: now(w2).float(), (a2,)),
                 bipartite_edge_index=Lazy(lambda: generate_bipartite_edge_index(g, g_ho, mapping=mapping, device=dev), (2, u2)),
                 y=g.data.y,
             )

@@ -35,6 +35,25 @@ class Lazy:
             self.make = None
         return self.value
 
+    def mapped(self, fn) -> "Lazy":
+        """The same deferred tensor seen through ``fn`` (a device move, a copy): still deferred while this one is, ``fn`` of the tensor once made."""
+        if self.value is not None:
+            done = Lazy(None, self.shape)
+            done.value = fn(self.value)
+            done.version = done.value._version
+            return done
+        return Lazy(lambda: fn(self.resolve()), self.shape)
+
+    def __reduce__(self):
+        # a maker is a closure over device plans and does not pickle: the tensor does (torch.save / pickle of a layer's Data or a DBGNN bundle)
+        return (_made, (self.resolve(),))
+
+
+def _made(value) -> "Lazy":
+    out = Lazy(None, tuple(value.shape))
+    out.value, out.version = value, value._version
+    return out
+
 
 class Data:
     def __init__(self, **attrs: Any) -> None:
@@ -164,15 +183,21 @@ class Data:
 
     # ------------------------------------------------------------ device / time helpers
     def to(self, device) -> "Data":
-        for key, value in list(iter(self)):
+        # (deferred tensors stay deferred: `bundle.to(dev)` on a fused model must not materialise every [2, A2] index)
+        for key, value in list(self._store.items()):
             if isinstance(value, torch.Tensor):
                 self._store[key] = value.to(device)
+            elif isinstance(value, Lazy):
+                self._store[key] = value.mapped(lambda t, device=device: t.to(device))
         return self
 
     def clone(self) -> "Data":
         out = Data()
-        for key, value in iter(self):
-            out[key] = value.clone() if isinstance(value, torch.Tensor) else value
+        for key, value in list(self._store.items()):
+            if isinstance(value, Lazy):
+                out[key] = value.mapped(lambda t: t.clone())
+            else:
+                out[key] = value.clone() if isinstance(value, torch.Tensor) else value
         return out
 
     def is_sorted_by_time(self) -> bool:

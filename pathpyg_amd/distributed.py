@@ -1016,7 +1016,7 @@ def build_dbgnn_shard(g, delta, x, x_h, y, comm: Comm, ops=None, weight: str = "
     n, m = int(data.num_nodes), int(ei.size(1))
     unit_weights = weight not in data
     fused = getattr(ops, "debruijn2", None) if FUSED_BUILDER else None
-    if fused is not None and m > 0 and n > 0 and (unit_weights or data[weight].dtype == torch.float32) and _debruijn2_wanted(m, n):
+    if fused is not None and m > 0 and n > 0 and (unit_weights or data[weight].dtype == torch.float32) and (FUSED_BUILDER == "always" or _debruijn2_wanted(m, n)):
         built = fused(ei, data.time, n, delta, None if unit_weights else data[weight])
         if built is not None:              # (None: a hub node — the generic path below)
             from .nn.sharded import GraphShard

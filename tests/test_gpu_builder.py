@@ -33,7 +33,7 @@ def _build(ei, t, n, delta, weight, fused):
         data["edge_weight"] = weight.to(dev)
     g = pp.TemporalGraph(data)
     old = ppd.FUSED_BUILDER
-    ppd.FUSED_BUILDER = fused
+    ppd.FUSED_BUILDER = "always" if fused else False          # ("always": also on contact-shaped streams, where the callers would choose the generic kernels)
     try:
         x = torch.zeros(n, 4, device=dev)
         shard = ppd.build_dbgnn_shard(g, delta, x, lambda num_ho_nodes: torch.zeros(num_ho_nodes, 4, device=dev), None, ppd.Comm()).resolve()

@@ -409,6 +409,20 @@ def test_config4_100m_events_k2_to_k5_lift_properties(pp):
             later |= equal & (ns[1:, c] > ns[:-1, c])
             equal &= ns[1:, c] == ns[:-1, c]
         assert bool(later.all())
+        del ns, later, equal
+    # the same five layers from the level-by-level builder (pp_multiorder_*: what from_temporal_graph runs without event_graph=), which never
+    # makes the instance graphs checked above: every layer tensor equal to the generic kernels', bit for bit, at configs[4]'s stream size
+    del ho
+    torch.cuda.empty_cache()
+    fast = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=5)
+    assert "layers" in getattr(fast, "sizes", {}), "the 10^8-event stream did not take the level-by-level builder"
+    assert [s_[2] for s_ in fast.sizes["layers"]] == [totals[k] for k in (1, 2, 3, 4, 5)]            # instances per level = the lifts' edge counts
+    for k in (1, 2, 3, 4, 5):
+        a, b = fast.layers[k].data, model.layers[k].data
+        assert a.num_nodes == b.num_nodes
+        for key in ("edge_index", "edge_weight", "node_sequence"):
+            assert torch.equal(a[key], b[key]), (k, key)
+        del model.layers[k]
 
 
 def test_config4_f256_property_run_above_10m_events():

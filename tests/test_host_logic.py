@@ -240,10 +240,22 @@ def test_data_lazy_tensors_resolve_on_first_read_and_answer_sizes_before():
     assert made == [1] and torch.equal(ei, torch.arange(6).reshape(2, 3))
     assert d.edge_index is ei and d["edge_index"] is ei and made == [1]               # made once; the bag now holds the tensor itself
     assert d.peek("edge_index") is ei and lazy.value is ei and lazy.version == ei._version
-    # clone / to / iteration resolve whatever is still deferred
-    d2 = Data(edge_index=Lazy(lambda: torch.zeros(2, 5, dtype=torch.long), (2, 5)), num_nodes=3)
-    c = d2.clone()
-    assert isinstance(c.peek("edge_index"), torch.Tensor) and c.num_edges == 5
+    # clone / to keep what is still deferred deferred (a bundle moved to its device must not materialise every [2, A2] index); iteration and
+    # pickling resolve it
+    import pickle
+    calls = []
+
+    def make5():
+        calls.append(1)
+        return torch.zeros(2, 5, dtype=torch.long)
+
+    d2 = Data(edge_index=Lazy(make5, (2, 5)), num_nodes=3)
+    c = d2.clone().to("cpu")
+    assert isinstance(c.peek("edge_index"), Lazy) and c.num_edges == 5 and not calls
+    assert c.edge_index.shape == (2, 5) and calls == [1] and isinstance(d2.peek("edge_index"), Lazy)
+    assert d2.edge_index is not c.edge_index and calls == [1]                         # (made once: the clone copied the original's tensor)
+    back = pickle.loads(pickle.dumps(Data(edge_index=Lazy(make5, (2, 5)), num_nodes=3)))
+    assert torch.equal(back.edge_index, torch.zeros(2, 5, dtype=torch.long)) and back.num_nodes == 3
     assert dict(iter(Data(a=Lazy(lambda: torch.ones(2), (2,)))))["a"].shape == (2,)
 
 
