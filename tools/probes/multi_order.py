@@ -13,6 +13,7 @@ for K in (2, 3, 4, 5):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         mom = pp.MultiOrderModel.from_temporal_graph(tg, delta=delta, max_order=K)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    sizes = {k: (v.n, v.data.edge_index.size(1)) for k, v in mom.layers.items()}
-    print(f"max_order={K}: {dt*1e3:.1f} ms  (nodes, edges) per layer: {sizes}  peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+    sizes = {k: (v.n, v.m) for k, v in mom.layers.items()}
+    how = "level by level (pp_multiorder_*)" if "layers" in getattr(mom, "sizes", {}) else ("fused order-2 builder" if getattr(mom, "_pp_fused", None) is not None else "generic kernels")
+    print(f"max_order={K}: {dt*1e3:.1f} ms  {how}  (nodes, edges) per layer: {sizes}  peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
     del mom
