@@ -821,6 +821,13 @@ def main() -> int:
                          "42.7 ms at 2 ranks, 14.8 ms at 4 against 14.0 ms on one GPU) — this line runs independent streams (weak scaling, "
                          "weight-gradient all-reduce); `--mode partition` forces the split")
     partition = args.mode == "partition"
+    if partition and world >= 8 and mode_note is None:
+        # (say the bound in the line instead of leaving "≥ 6x at 8 GPUs" implied)
+        mode_note = (f"{world} GPUs, node-range partition of ONE stream: on a locality-free (ER) stream every order-2 row crosses a link once per layer and "
+                     "direction — ~3.1 ms of xGMI time per rank-step at fp32, F = 64 (76.8 GB/s x 0.8 per link pair + 15 us per exchange, a model that "
+                     "was never calibrated on hardware) — beside a per-rank device time of 4.2-4.8 ms where 13.8 / 8 = 1.7 ms is ideal (197 launches "
+                     "per rank-step): the projected 8-rank step is 6.0-6.5 ms = 2.1-2.3x of one GPU, and ~4.5x is the link-bound ceiling of this "
+                     "workload at fp32; north_star's >= 6x is out of reach for it (DESIGN §6)")
     comm = ppd.Comm()
     # ---- inputs, resident in HBM before the timed region.  partition: ONE stream replicated on every rank; streams: one per rank
     ei, t = synth_stream(args.events, args.nodes, args.span, seed=1 + (0 if partition else rank), device=dev)
