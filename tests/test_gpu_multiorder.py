@@ -175,3 +175,62 @@ def test_dbgnn_bundle_of_a_higher_layer(pp):
     got = model.to_dbgnn_data(max_order=3, mapping="last", x=x.to(DEV), x_h=x_h.to(DEV))
     for key in ("edge_index", "edge_index_higher_order", "edge_weights", "edge_weights_higher_order", "bipartite_edge_index"):
         assert torch.equal(got[key].cpu(), ref[key]), key
+
+
+def fuzz_against_generic(pp, cases, seed, max_events=60_000, verbose=False):
+    """Streams of random shape (sparse / few nodes / Zipf sources or targets / timestamp ties / float64 time / weights / cached or not), K = 3..5:
+    every tensor of every layer equal to the generic kernels'.  Returns (builds the level-by-level builder took, builds it handed back)."""
+    from pathpyg_amd.core import multi_order_model as mm
+    rng = np.random.default_rng(seed)
+    taken = back = 0
+    for case in range(cases):
+        shape = rng.integers(0, 5)
+        m = int(rng.integers(1, max_events))
+        if shape == 0:        # sparse
+            n = int(rng.integers(max(m // 40, 1), max(m // 4, 2)))
+        elif shape == 1:      # dense, few nodes
+            n = int(rng.integers(1, 40))
+            m = min(m, 8_000)
+        else:
+            n = int(rng.integers(1, 3_000))
+        span = int(rng.integers(1, 4 * m + 2))
+        K = int(rng.integers(3, 6))
+        src = rng.integers(0, n, m)
+        dst = (n * rng.random(m) ** rng.choice([1.0, 3.0, 6.0])).astype(np.int64) if shape >= 3 else rng.integers(0, n, m)
+        if rng.integers(0, 4) == 0:
+            src, dst = dst, src                                            # out-hubs instead of in-hubs
+        float_time = bool(rng.integers(0, 3) == 0)
+        t = np.round(rng.random(m) * span, 1) if float_time else rng.integers(0, span, m)
+        per_node = max(m / n, 1e-9)                                        # a window that yields ~0.3 .. 3 continuations per event
+        delta = max(span * rng.uniform(0.3, 3.0) / per_node, 0.1 if float_time else 1)
+        delta = float(np.round(delta, 1)) if float_time else int(delta)
+        weighted = bool(rng.integers(0, 2))
+        data = pp.Data(edge_index=torch.from_numpy(np.stack((src, dst))).to(DEV), time=torch.from_numpy(t).to(DEV), num_nodes=n)
+        if weighted:
+            data["edge_weight"] = torch.from_numpy(rng.integers(1, 5, m).astype(np.float32)).to(DEV)
+        cached = bool(rng.integers(0, 4))
+        g = pp.TemporalGraph(data)
+        fast = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=K, cached=cached)
+        mm.FUSED_BUILDER = False
+        try:
+            slow = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=K, cached=cached)
+        finally:
+            mm.FUSED_BUILDER = True
+        lbl = _level_by_level(fast)
+        taken += lbl
+        back += not lbl
+        what = f"case {case}: m={m} n={n} span={span} delta={delta} K={K} weighted={weighted} float_time={float_time} shape={shape} level-by-level={lbl}"
+        assert sorted(fast.layers) == sorted(slow.layers), what
+        for k in fast.layers:
+            a, b = fast.layers[k].data, slow.layers[k].data
+            assert a.num_nodes == b.num_nodes, (what, k)
+            for key in ("edge_index", "edge_weight", "node_sequence") + (("inverse_idx",) if case % 8 == 0 else ()):
+                assert torch.equal(a[key], b[key]), (what, k, key)
+        if verbose and case % 25 == 0:
+            print(what, [(l.n, l.m) for l in fast.layers.values()], flush=True)
+    return taken, back
+
+
+def test_fuzz_against_the_generic_kernels(pp):
+    taken, back = fuzz_against_generic(pp, 120, 7)
+    assert taken > 90          # (a handful of dense draws exceed 4096 continuations of one node sequence and go back to the generic kernels)
