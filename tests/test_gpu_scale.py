@@ -597,6 +597,36 @@ def test_config2_20m_scale_free_stream_stays_on_the_fused_builder(pp):
     _compare(fused, generic, hubs=True)
 
 
+@pytest.mark.parametrize("shape", ["headline K=5", "configs[2] K=3"])
+def test_multi_order_at_full_size_equals_the_generic_kernels(pp, shape):
+    """The multi-order half of BASELINE's metric at the sizes `multi_order` in the bench line is quoted on: the headline stream (10^7 events,
+    K = 2..5: layers of 10^7 .. 1.28*10^8 edges) and configs[2] (scale-free, 10^6 nodes / 2*10^7 events, K = 1..3, delta = 1.5*10^6: a layer
+    of 1.4*10^8 edges) — the level-by-level builder (pp_multiorder_*) against the generic kernels (line-graph lift -> radix sort -> segment
+    reduce per order), every layer tensor bit for bit."""
+    from pathpyg_amd.core import multi_order_model as mm
+    if shape.startswith("headline"):
+        n, m, span, delta, K, zipf = 500_000, 10_000_000, 10_000_000, 1_000_000, 5, False
+    else:
+        n, m, span, delta, K, zipf = 1_000_000, 20_000_000, 10_000_000, 1_500_000, 3, True
+    ei, t = _stream(3, m, n, span, zipf=zipf)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei, time=t, num_nodes=n))
+    del ei, t
+    fast = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=K)
+    assert "layers" in getattr(fast, "sizes", {})
+    mm.FUSED_BUILDER = False
+    try:
+        slow = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=K)
+    finally:
+        mm.FUSED_BUILDER = True
+    for k in range(1, K + 1):
+        a, b = fast.layers[k].data, slow.layers[k].data
+        assert a.num_nodes == b.num_nodes
+        for key in ("edge_index", "edge_weight", "node_sequence"):
+            assert torch.equal(a[key], b[key]), (shape, k, key)
+        del slow.layers[k], fast.layers[k]
+        torch.cuda.empty_cache()
+
+
 def test_contact_network_96_nodes_2m_events_on_both_builders(pp):
     """The shape of the reference's documented datasets (96 nodes / 2.17*10^6 events): every node has ~2*10^4 in- and
     out-events.  Fused builder against the oracle (delta = 30) and against the generic kernels (delta = 300, E2 = 6*10^6).  The reference API
