@@ -234,3 +234,21 @@ def fuzz_against_generic(pp, cases, seed, max_events=60_000, verbose=False):
 def test_fuzz_against_the_generic_kernels(pp):
     taken, back = fuzz_against_generic(pp, 120, 7)
     assert taken > 90          # (a handful of dense draws exceed 4096 continuations of one node sequence and go back to the generic kernels)
+
+
+@pytest.mark.parametrize("kind", ["sparse", "hubs", "ties"])
+def test_fractional_event_weights_are_summed_in_the_reference_order(pp, kind):
+    # merged weights = left-to-right fp32 sums over the instance edges in the reference's order (PyG coalesce on CPU): with non-integer
+    # weights any other association would change low bits — the layers must still equal the oracle's bit for bit
+    from oracle import model as om
+    ei, t, _, n, delta = _stream(kind, 23)
+    rng = np.random.default_rng(5)
+    w = torch.from_numpy((rng.random(ei.size(1)) + 0.25).astype(np.float32))
+    g = pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=t.to(DEV), num_nodes=n, edge_weight=w.to(DEV)))
+    sei, st, perm = om.stable_time_sort(ei, t)
+    want = om.layers_from_temporal(sei, st, n, delta=delta, max_order=4, edge_weight=w[perm])
+    model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=4)
+    assert _level_by_level(model)
+    for k in want:
+        assert torch.equal(model.layers[k].data.edge_index.cpu(), want[k]["edge_index"]), k
+        assert torch.equal(model.layers[k].data.edge_weight.cpu(), want[k]["edge_weight"]), k
