@@ -206,6 +206,14 @@ size_t pp_multiorder_prepare_ws_bytes(int64_t m);
 int pp_multiorder_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, const float* weight, void* lift_ws, size_t lift_ws_bytes,
                           void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes,
                           pp_stream_t stream);
+/* The same from a GIVEN event graph (from_temporal_graph(..., event_graph=lift_order_temporal(g, delta)), multi_order_model.py:124-192 with
+ * `event_graph` set): event_graph [2, num_event_edges] int64, sorted by source (as lift_order_temporal / lift_order_edge_index leave it; the order of
+ * a source's targets is kept: it is the reference's instance order).  graph_ws: pp_multiorder_graph_ws_bytes; `tab` has num_event_edges records.
+ * Status bit 0: an event id outside [0, m); bit 1: the event graph is not sorted by source. */
+size_t pp_multiorder_graph_ws_bytes(int64_t m, int64_t num_event_edges);
+int pp_multiorder_prepare_graph(const int64_t* edge_index, int64_t m, int64_t num_nodes, const float* weight, const int64_t* event_graph,
+                                int64_t num_event_edges, void* graph_ws, size_t graph_ws_bytes, void* tab, void* inst, int32_t* tptr,
+                                int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes, pp_stream_t stream);
 const int64_t* pp_multiorder_result_ptr(void* ws);
 size_t pp_multiorder_step_ws_bytes(int64_t n_types, int64_t n_children);
 int pp_multiorder_step(int64_t n_types, int64_t n_children, const int32_t* tptr, const int32_t* ibase, const int32_t* col, const void* inst,

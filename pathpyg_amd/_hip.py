@@ -896,15 +896,16 @@ class MultiOrderLayer:
 
 
 def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes: int, delta, weight: torch.Tensor | None, max_order: int,
-                         clock: list | None = None):
+                         clock: list | None = None, event_graph: torch.Tensor | None = None):
     """All De Bruijn layers 1..max_order of a TIME-SORTED event stream, level by level (pp_multiorder_prepare / _step, csrc/pp_multiorder.hip):
     no instance graph ``[2, E_k]``, no per-instance node sequences, no global sort beyond the two of the first order; one read-back per order.
     Returns ``[MultiOrderLayer]`` (index k - 1 = layer k; ``n_instances`` = E_k, the instance edges the reference would have lifted) or ``None``
     when the generic kernels have to take over: a layer without edges, a node sequence with more than 4096 continuations (dense contact
     streams), 2^31 or more instances at some order, an unsorted stream.  ``clock``: a list that receives one ``(name, start event, end event)``
-    per phase — the windows and level 1 ("prepare"), then every step ("layer k") — for measurements (bench.py)."""
+    per phase — the windows and level 1 ("prepare"), then every step ("layer k") — for measurements (bench.py).  ``event_graph``: a given
+    ``lift_order_temporal(g, delta)`` ([2, E2] int64, sorted by source) instead of ``time`` / ``delta`` (pp_multiorder_prepare_graph)."""
     ei = _edge_index(edge_index)
-    dev = require_device(ei, time, weight)
+    dev = require_device(ei, time, weight, event_graph)
 
     def tick():
         if clock is None:
@@ -931,18 +932,30 @@ def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
     with torch.cuda.device(dev):
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
-        lift_ws = _workspace(L.pp_temporal_ws_bytes(m, n), dev)
         t0 = tick()
-        check(L.pp_temporal_count(_p(ei), _p(time), _DTYPE_CODE[time.dtype], m, m, n, kind, di, df, _p(lift_ws), lift_ws.numel(), _stream()),
-              "pp_temporal_count")
-        tab = torch.empty((m, 4), **i32)
+        if event_graph is None:
+            lift_ws = _workspace(L.pp_temporal_ws_bytes(m, n), dev)
+            check(L.pp_temporal_count(_p(ei), _p(time), _DTYPE_CODE[time.dtype], m, m, n, kind, di, df, _p(lift_ws), lift_ws.numel(), _stream()),
+                  "pp_temporal_count")
+            n_list = m
+        else:
+            eg = _edge_index(event_graph)
+            n_list = eg.size(1)
+            if n_list == 0 or n_list >= _INT32_ROWS:
+                return None
+            lift_ws = _workspace(L.pp_multiorder_graph_ws_bytes(m, n_list), dev)
+        tab = torch.empty((n_list, 4), **i32)
         inst = torch.empty((m, 4), **i32)
         tptr, ibase = torch.empty(m + 1, **i32), torch.empty(m + 1, **i32)
         tlast, w = torch.empty(m, **i32), torch.empty(m, **f32)
         row_ptr = torch.empty(n + 1, **i32)
         ws = _workspace(L.pp_multiorder_prepare_ws_bytes(m), dev)
-        check(L.pp_multiorder_prepare(_p(ei), m, n, _p(weight), _p(lift_ws), lift_ws.numel(), _p(tab), _p(inst), _p(tptr), _p(ibase), _p(tlast), _p(w),
-                                      _p(row_ptr), _p(ws), ws.numel(), _stream()), "pp_multiorder_prepare")
+        if event_graph is None:
+            check(L.pp_multiorder_prepare(_p(ei), m, n, _p(weight), _p(lift_ws), lift_ws.numel(), _p(tab), _p(inst), _p(tptr), _p(ibase), _p(tlast), _p(w),
+                                          _p(row_ptr), _p(ws), ws.numel(), _stream()), "pp_multiorder_prepare")
+        else:
+            check(L.pp_multiorder_prepare_graph(_p(ei), m, n, _p(weight), _p(eg), n_list, _p(lift_ws), lift_ws.numel(), _p(tab), _p(inst), _p(tptr),
+                                                _p(ibase), _p(tlast), _p(w), _p(row_ptr), _p(ws), ws.numel(), _stream()), "pp_multiorder_prepare_graph")
         if clock is not None:
             clock.append(("prepare", t0, tick()))
         types, status, children, _ = ws[:32].view(torch.int64).tolist()

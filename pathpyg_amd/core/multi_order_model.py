@@ -91,8 +91,8 @@ class MultiOrderModel:
             fused = _second_order_fused(g, delta, weight, cached)
             if fused is not None:
                 return fused
-        if max_order >= 3 and event_graph is None and FUSED_BUILDER:
-            fused = _multi_order_fused(g, delta, max_order, weight, cached)
+        if max_order >= 3 and FUSED_BUILDER:
+            fused = _multi_order_fused(g, delta, max_order, weight, cached, event_graph)
             if fused is not None:
                 return fused
         return MultiOrderModel._from_temporal_graph_generic(g, delta, max_order, weight, cached, event_graph)
@@ -455,14 +455,15 @@ def _second_order_fused(g: TemporalGraph, delta, weight: str, cached: bool):
     return out
 
 
-def _multi_order_fused(g: TemporalGraph, delta, max_order: int, weight: str, cached: bool):
+def _multi_order_fused(g: TemporalGraph, delta, max_order: int, weight: str, cached: bool, event_graph=None):
     """``from_temporal_graph(g, delta, max_order >= 3)`` level by level (``_hip.multi_order_temporal`` -> ``pp_multiorder_prepare`` / ``_step``): every
     layer comes out as source-major CSR with merged weights; the reference's layer tensors (reference multi_order_model.py:153-191) are
     :class:`~pathpyg_amd.data.Lazy` views — ``edge_index`` = (row of every CSR entry, column), ``node_sequence`` of layer k = the sequence of the
     entry's row in layer k-1 followed by the entry's last node (De Bruijn property: the nodes of layer k ARE the edges of layer k-1),
     ``inverse_idx`` of the layers from 3 on through the generic kernels (it numbers the reference's instance graph, which this builder never makes).
+    ``event_graph``: a given ``lift_order_temporal(g, delta)`` — its edges are the continuation windows (``pp_multiorder_prepare_graph``).
     ``None``: the builder does not apply (host-resident or unsorted stream, a weight attribute that is not float32, a layer without edges, a node
-    sequence with more than 4096 continuations, 2^31 instances)."""
+    sequence with more than 4096 continuations, 2^31 instances, an event graph that is not sorted by source)."""
     from .. import _hip
     data = g.data
     ei = _dispatch.plain(data.edge_index)
@@ -477,7 +478,11 @@ def _multi_order_fused(g: TemporalGraph, delta, max_order: int, weight: str, cac
     n, m_events = int(data.num_nodes), int(ei.size(1))
     if n == 0 or m_events == 0 or not data.is_sorted_by_time():
         return None
-    built = _hip.multi_order_temporal(ei, time, n, delta, w, max_order)
+    if event_graph is not None:
+        event_graph = _dispatch.plain(event_graph)
+        if not isinstance(event_graph, torch.Tensor) or not event_graph.is_cuda or event_graph.dim() != 2 or event_graph.size(0) != 2:
+            return None
+    built = _hip.multi_order_temporal(ei, time, n, delta, w, max_order, event_graph=event_graph)
     if built is None:
         return None
     dev = ei.device
@@ -509,7 +514,7 @@ def _multi_order_fused(g: TemporalGraph, delta, max_order: int, weight: str, cac
                 def inverse_of(k=k):
                     # the reference numbers the order-k INSTANCES (edges of the order-(k-1) instance graph, lexicographic): only the generic
                     # kernels make that graph
-                    return MultiOrderModel._from_temporal_graph_generic(g, delta, k, weight, False, None).layers[k].data.inverse_idx
+                    return MultiOrderModel._from_temporal_graph_generic(g, delta, k, weight, False, event_graph).layers[k].data.inverse_idx
 
             inverse = Lazy(inverse_of, (built[k - 2].n_instances,))
         if keep:

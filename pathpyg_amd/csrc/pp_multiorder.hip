@@ -169,9 +169,9 @@ __global__ __launch_bounds__(kBlock) void k_mo_sums1_long(const int32_t* __restr
 }
 
 // tab[p]: the event at position p of the per-node out-lists — its head node, its own continuation window, its id
-__global__ __launch_bounds__(kBlock) void k_mo_tab(const uint32_t* __restrict__ ids, const uint4* __restrict__ ev, int64_t m, uint4* __restrict__ tab) {
+__global__ __launch_bounds__(kBlock) void k_mo_tab(const uint32_t* __restrict__ ids, const uint4* __restrict__ ev, int64_t n_list, uint4* __restrict__ tab) {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (p >= m) return;
+    if (p >= n_list) return;
     const uint32_t l = ids[p];
     const uint4 r = ev[l];
     tab[p] = make_uint4(r.x, r.y, r.z, l);
@@ -688,6 +688,50 @@ __global__ __launch_bounds__(kBlock) void k_mo_types_big(const int32_t* __restri
     }
 }
 
+// ------------------------------------------------------------------ continuation windows from a GIVEN event graph (from_temporal_graph(event_graph=...))
+// the list entries (targets of the event graph's edges, in its order) as 32-bit ids; status bit 0: an event id outside [0, m)
+__global__ __launch_bounds__(kBlock) void k_mo_graph_ids(const int64_t* __restrict__ event_graph, int64_t e2, int64_t m, uint32_t* __restrict__ ids,
+                                                        int64_t* __restrict__ status) {
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= e2) return;
+    const int64_t i = event_graph[p];
+    int64_t j = event_graph[e2 + p];
+    if (i < 0 || i >= m || j < 0 || j >= m) { atomicOr((unsigned long long*)status, (unsigned long long)kMoBadIndex); j = 0; }
+    if (p + 1 < e2 && event_graph[p + 1] < i) atomicOr((unsigned long long*)status, (unsigned long long)kMoUnsorted);
+    ids[p] = (uint32_t)j;
+}
+// window of event e = its out-edges in the (source-sorted) event graph: [row pointer, out-degree]
+__global__ __launch_bounds__(kBlock) void k_mo_graph_windows(const int32_t* __restrict__ rowptr, int64_t m, uint32_t* __restrict__ first_pos,
+                                                            int32_t* __restrict__ count) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= m) return;
+    const int32_t a = rowptr[e], b = rowptr[e + 1];
+    first_pos[e] = b > a ? (uint32_t)a : 0u;
+    count[e] = b - a;
+}
+
+struct MoGraphWs {
+    int64_t* result;          // {E2, status}
+    uint32_t *ids, *first_pos;
+    int32_t *count, *outdeg, *rowptr;
+    void* scratch;
+    size_t scratch_bytes, total_bytes;
+};
+static MoGraphWs carve_mo_graph(void* ws, int64_t m, int64_t e2) {
+    Arena a(ws, (size_t)-1);
+    MoGraphWs w;
+    w.result = a.take<int64_t>(2);
+    w.ids = a.take<uint32_t>(e2 + 4);
+    w.first_pos = a.take<uint32_t>(m);
+    w.count = a.take<int32_t>(m);
+    w.outdeg = a.take<int32_t>(m);
+    w.rowptr = a.take<int32_t>(m + 1);
+    w.scratch_bytes = scan_ws_bytes(m + 1);
+    w.scratch = a.take<char>((int64_t)w.scratch_bytes);
+    w.total_bytes = a.used;
+    return w;
+}
+
 struct MoPrepWs {
     int64_t* result;          // {types of level 1, status, children of level 1 (= E2), node pairs with long runs}
     void *keys_a, *keys_b;    // (source, target) keys before / after the sort: uint32 or uint64 [m]
@@ -777,14 +821,11 @@ extern "C" {
 
 size_t pp_multiorder_prepare_ws_bytes(int64_t m) { return carve_mo_prep(nullptr, m).total_bytes; }
 
-int pp_multiorder_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, const float* weight, void* lift_ws, size_t lift_ws_bytes,
-                          void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes,
-                          pp_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
+static int mo_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, const float* weight, const TemporalLists& tl, int64_t n_list,
+                      void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes,
+                      hipStream_t st) {
     PP_REQUIRE(m > 0 && num_nodes > 0, PP_ERR_ARG, "pp_multiorder_prepare: empty stream");
     PP_REQUIRE(m < (int64_t)0x7ffffff0 && num_nodes < ((int64_t)1 << 31), PP_ERR_TOO_LARGE, "pp_multiorder_prepare: m or num_nodes >= 2^31");
-    const TemporalLists tl = temporal_lists(lift_ws, m, num_nodes);
-    PP_REQUIRE(lift_ws_bytes >= tl.total_bytes, PP_ERR_WORKSPACE, "pp_multiorder_prepare: not a pp_temporal_count workspace of this stream");
     MoPrepWs p = carve_mo_prep(ws, m);
     PP_REQUIRE(ws_bytes >= p.total_bytes, PP_ERR_WORKSPACE, "pp_multiorder_prepare: workspace too small");
     PP_HIP(hipMemsetAsync(p.result, 0, 4 * sizeof(int64_t), st));
@@ -805,11 +846,43 @@ int pp_multiorder_prepare(const int64_t* edge_index, int64_t m, int64_t num_node
     PP_LAUNCH_CHECK();
     rc = exclusive_scan<int32_t, int32_t>(p.csum, m, ibase, true, p.result + 2, p.scratch, p.scratch_bytes, st);
     if (rc != PP_OK) return rc;
-    k_mo_tab<<<grid, kBlock, 0, st>>>(tl.ids, p.ev, m, (uint4*)tab);
+    if (n_list > 0) k_mo_tab<<<(unsigned)ceil_div(n_list, kBlock), kBlock, 0, st>>>(tl.ids, p.ev, n_list, (uint4*)tab);
     PP_LAUNCH_CHECK();
     k_mo_finish<<<1, 1, 0, st>>>(p.counters, tl.result, p.result);
     PP_LAUNCH_CHECK();
     return PP_OK;
+}
+
+int pp_multiorder_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, const float* weight, void* lift_ws, size_t lift_ws_bytes,
+                          void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes,
+                          pp_stream_t stream) {
+    PP_REQUIRE(m > 0 && num_nodes > 0, PP_ERR_ARG, "pp_multiorder_prepare: empty stream");
+    const TemporalLists tl = temporal_lists(lift_ws, m, num_nodes);
+    PP_REQUIRE(lift_ws_bytes >= tl.total_bytes, PP_ERR_WORKSPACE, "pp_multiorder_prepare: not a pp_temporal_count workspace of this stream");
+    return mo_prepare(edge_index, m, num_nodes, weight, tl, m, tab, inst, tptr, ibase, tlast, w, rowptr, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t pp_multiorder_graph_ws_bytes(int64_t m, int64_t num_event_edges) { return carve_mo_graph(nullptr, m, num_event_edges).total_bytes; }
+
+int pp_multiorder_prepare_graph(const int64_t* edge_index, int64_t m, int64_t num_nodes, const float* weight, const int64_t* event_graph,
+                                int64_t num_event_edges, void* graph_ws, size_t graph_ws_bytes, void* tab, void* inst, int32_t* tptr,
+                                int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    PP_REQUIRE(m > 0 && num_nodes > 0 && num_event_edges > 0, PP_ERR_ARG, "pp_multiorder_prepare_graph: empty stream or event graph");
+    PP_REQUIRE(m < (int64_t)0x7ffffff0 && num_event_edges < (int64_t)0x7ffffff0, PP_ERR_TOO_LARGE, "pp_multiorder_prepare_graph: 2^31 events or event-graph edges");
+    MoGraphWs gws = carve_mo_graph(graph_ws, m, num_event_edges);
+    PP_REQUIRE(graph_ws_bytes >= gws.total_bytes, PP_ERR_WORKSPACE, "pp_multiorder_prepare_graph: event-graph workspace too small");
+    PP_HIP(hipMemsetAsync(gws.result, 0, 2 * sizeof(int64_t), st));
+    k_mo_graph_ids<<<(unsigned)ceil_div(num_event_edges, kBlock), kBlock, 0, st>>>(event_graph, num_event_edges, m, gws.ids, gws.result + 1);
+    PP_LAUNCH_CHECK();
+    int rc = histogram<int64_t>(event_graph, num_event_edges, m, gws.outdeg, st);
+    if (rc != PP_OK) return rc;
+    rc = exclusive_scan<int32_t, int32_t>(gws.outdeg, m, gws.rowptr, true, gws.result, gws.scratch, gws.scratch_bytes, st);
+    if (rc != PP_OK) return rc;
+    k_mo_graph_windows<<<(unsigned)ceil_div(m, kBlock), kBlock, 0, st>>>(gws.rowptr, m, gws.first_pos, gws.count);
+    PP_LAUNCH_CHECK();
+    const TemporalLists tl{gws.ids, nullptr, gws.first_pos, gws.count, gws.result, gws.total_bytes};
+    return mo_prepare(edge_index, m, num_nodes, weight, tl, num_event_edges, tab, inst, tptr, ibase, tlast, w, rowptr, ws, ws_bytes, st);
 }
 
 const int64_t* pp_multiorder_result_ptr(void* ws) { return (const int64_t*)ws; }

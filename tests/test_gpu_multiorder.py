@@ -252,3 +252,25 @@ def test_fractional_event_weights_are_summed_in_the_reference_order(pp, kind):
     for k in want:
         assert torch.equal(model.layers[k].data.edge_index.cpu(), want[k]["edge_index"]), k
         assert torch.equal(model.layers[k].data.edge_weight.cpu(), want[k]["edge_weight"]), k
+
+
+@pytest.mark.parametrize("kind", ["sparse", "hubs", "contact"])
+def test_given_event_graph_takes_the_level_by_level_builder_too(pp, kind):
+    # from_temporal_graph(..., event_graph=lift_order_temporal(g, delta)) (reference multi_order_model.py:124-192 with `event_graph` set): the
+    # event graph's edges are the continuation windows (pp_multiorder_prepare_graph); also a SUBSET of the event graph (every other edge), which
+    # no delta produces: the layers are those of the given graph
+    from oracle import model as om
+    ei, t, w, n, delta = _stream(kind, 17)
+    g = pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=t.to(DEV), num_nodes=n, edge_weight=w.to(DEV)))
+    sei, st, perm = om.stable_time_sort(ei, t)
+    eg = pp.algorithms.lift_order_temporal(g, delta)
+    for graph in (eg, eg[:, ::2].contiguous()):
+        model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=4, event_graph=graph)
+        assert _level_by_level(model)
+        want = om.layers_from_temporal(sei, st, n, delta=delta, max_order=4, edge_weight=w[perm], event_graph=graph.cpu())
+        for k in want:
+            d = model.layers[k].data
+            for key in ("edge_index", "edge_weight", "node_sequence", "inverse_idx"):
+                assert torch.equal(d[key].cpu(), want[k][key]), (k, key)
+    # an event graph on the host goes to the generic kernels
+    assert not _level_by_level(pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=3, event_graph=eg.cpu()))

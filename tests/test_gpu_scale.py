@@ -396,7 +396,13 @@ def test_config4_100m_events_k2_to_k5_lift_properties(pp):
         del outdeg
     del cur, nxt
     torch.cuda.empty_cache()
-    model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=5, event_graph=ho)
+    from pathpyg_amd.core import multi_order_model as mm
+    mm.FUSED_BUILDER = False            # (the generic kernels: line-graph lift -> radix sort -> segment reduce per order, on the given event graph)
+    try:
+        model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=5, event_graph=ho)
+    finally:
+        mm.FUSED_BUILDER = True
+    assert "layers" not in getattr(model, "sizes", {})
     for k in (1, 2, 3, 4, 5):
         d = model.layers[k].data
         assert _is_lexsorted(d.edge_index)
@@ -416,6 +422,10 @@ def test_config4_100m_events_k2_to_k5_lift_properties(pp):
     torch.cuda.empty_cache()
     fast = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=5)
     assert "layers" in getattr(fast, "sizes", {}), "the 10^8-event stream did not take the level-by-level builder"
+    again = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=5, event_graph=pp.algorithms.lift_order_temporal(g, delta))
+    assert "layers" in getattr(again, "sizes", {}) and again.sizes["layers"] == fast.sizes["layers"]        # (windows from a given event graph)
+    assert torch.equal(again.layers[5].data.edge_index, fast.layers[5].data.edge_index)
+    del again
     assert [s_[2] for s_ in fast.sizes["layers"]] == [totals[k] for k in (1, 2, 3, 4, 5)]            # instances per level = the lifts' edge counts
     for k in (1, 2, 3, 4, 5):
         a, b = fast.layers[k].data, model.layers[k].data
