@@ -958,11 +958,13 @@ def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
                                                 _p(ibase), _p(tlast), _p(w), _p(row_ptr), _p(ws), ws.numel(), _stream()), "pp_multiorder_prepare_graph")
         if clock is not None:
             clock.append(("prepare", t0, tick()))
-        types, status, children, _ = ws[:32].view(torch.int64).tolist()
+        types, status, children, _, pairs = torch.cat((ws[:32], lift_ws[:8])).view(torch.int64).tolist()
         del lift_ws, ws
         _bad_index(status, "MultiOrderModel.from_temporal_graph")
         if status & 2:
             return None                  # (unsorted: the caller sorts and takes the generic path)
+        if children != pairs:            # the instances of level 2 ARE the event graph's edges (a 32-bit count that wrapped: the generic kernels decide)
+            return None
         layers = [MultiOrderLayer(n_nodes=n, n_edges=types, n_instances=m, row_ptr=row_ptr, col=tlast[:types], weight=w[:types], last=tlast[:types])]
         col, cand_ptr, cand_last = tlast, row_ptr, tlast
         for k in range(2, max_order + 1):

@@ -45,10 +45,7 @@ constexpr int kMoBigMax = PP_MO_BIG;     // children of one type a workgroup sor
 constexpr int kMoLongRun = 128;          // level 1: events of one node pair summed by a wave instead of a lane
 constexpr uint32_t kHeadBit = 0x80000000u;
 
-// an instance: {first, count | head bit} of its last event's window in `tab`, last node, weight of its first event
-__device__ __forceinline__ uint4 mo_inst(uint32_t cf, uint32_t cc, bool head, uint32_t d, float w) {
-    return make_uint4(cf, cc | (head ? kHeadBit : 0u), d, __float_as_uint(w));
-}
+// An instance is 16 bytes: {first, count | head bit} of its last event's window in `tab`, last node, weight of its first event.
 // Child records as the children pass leaves them for the types pass.  kFmt 0: the full 16-byte instance (a level below the top: the next
 // level's parents).  The children of the TOP layer are nobody's parents — only their last node and the head flag are read again
 // (kFmt 1: 4 bytes, last node | head bit; node ids stay below 2^31), with event weights also the weight (kFmt 2: 8 bytes).
