@@ -210,12 +210,16 @@ def fuzz_against_generic(pp, cases, seed, max_events=60_000, verbose=False):
             data["edge_weight"] = torch.from_numpy(rng.integers(1, 5, m).astype(np.float32)).to(DEV)
         cached = bool(rng.integers(0, 4))
         g = pp.TemporalGraph(data)
-        fast = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=K, cached=cached)
         mm.FUSED_BUILDER = False
         try:
             slow = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=K, cached=cached)
+        except RuntimeError as err:          # (a dense draw whose instance graph passes 2^31 edges at some order: beyond the generic kernels)
+            if "2^31" not in str(err):
+                raise
+            continue
         finally:
             mm.FUSED_BUILDER = True
+        fast = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=K, cached=cached)
         lbl = _level_by_level(fast)
         taken += lbl
         back += not lbl
