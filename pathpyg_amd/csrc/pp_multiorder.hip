@@ -604,7 +604,10 @@ __global__ __launch_bounds__(kBlock) void k_mo_types_wave(int64_t n_types, const
             // blocks (a first-order node's out-edges: ~20) by bisection — 5 dependent loads instead of a 16-trip loop of them (same-box A/B,
             // headline stream: K = 3 4.4 -> 4.2 ms; configs[2] generator K = 3 11.67 -> 11.37 ms)
             int32_t pos = 0;
-            if (bcount <= 8) {
+            if (bcount <= 2) {                   // (the common block above the first order: two load instructions, not eight)
+                const int32_t c0v = bcount > 0 ? cand[0] : 0x7fffffff, c1v = bcount > 1 ? cand[1] : 0x7fffffff;
+                pos = (c0v < dd ? 1 : 0) + (c1v < dd ? 1 : 0);
+            } else if (bcount <= 8) {
                 int32_t c8[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) c8[q] = q < bcount ? cand[q] : 0x7fffffff;
