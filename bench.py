@@ -521,6 +521,24 @@ def multi_order(g, nodes: int, delta, dev) -> dict:
     report["configs[2] generator: scale-free destinations, 1e6 nodes / 2e7 events"] = c2
     del tg
     torch.cuda.empty_cache()
+    # BASELINE configs[4]'s lift ("100M-edge temporal stream, multi-order k = 2..5 lift") on ONE GPU: 10^8 events / 5 * 10^6 nodes, delta tuned so that
+    # E_k ~ m at every order (the stream of tests/test_gpu_scale.py::test_config4_100m_events_k2_to_k5_lift_properties)
+    n, m, span, d4 = 5_000_000, 100_000_000, 100_000_000, 5_000_000
+    gen = torch.Generator(device=dev).manual_seed(7)
+    src = torch.randint(0, n, (m,), generator=gen, device=dev)
+    dst = torch.randint(0, n, (m,), generator=gen, device=dev)
+    t = torch.randint(0, span, (m,), generator=gen, device=dev)
+    tg = pp.TemporalGraph(pp.Data(edge_index=torch.stack((src, dst)), time=t, num_nodes=n))
+    del src, dst, t
+    c4 = {"delta": d4}
+    torch.cuda.reset_peak_memory_stats(dev)
+    ms, mom = wall(lambda: pp.MultiOrderModel.from_temporal_graph(tg, delta=d4, max_order=5), reps=2)
+    c4["K=5"] = {"ms": ms, "level_by_level": "layers" in getattr(mom, "sizes", {}), "peak_hbm_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+    del mom
+    c4["layers"] = per_layer(tg, n, d4, 5)
+    report["configs[4] stream: 1e8 events / 5e6 nodes, one GPU"] = c4
+    del tg
+    torch.cuda.empty_cache()
     return report
 
 
