@@ -194,7 +194,10 @@ int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t
  * pp_multiorder_prepare: level 1 from a finished pp_temporal_count (same stream, same delta; `lift_ws` is its workspace).  All outputs
  *   have capacity m (tptr / ibase: m + 1, rowptr: num_nodes + 1); `tab` [m] 16-byte records is the continuation table every step reads.
  *   Layer 1 = (rowptr, tlast as columns, w).  pp_multiorder_result_ptr(ws) = {types, status, instances of level 2 (= E2), long runs};
- *   status: bit 0 node index out of range, bit 1 time not ascending (both from pp_temporal_count).
+ *   status: bit 0 node index out of range, bit 1 time not ascending (both from pp_temporal_count).  The (source, target, time) order of the events:
+ *   radix_sort == 0 sorts every node's time-ordered out-list (pp_temporal_count's) by target in LDS — no second global sort; a node with more than
+ *   4096 out-events sets status bit 4 and leaves the outputs incomplete: call again with radix_sort != 0 (one stable radix sort of the stream by the
+ *   (source, target) key).
  * pp_multiorder_step: level k+1 from level k.  cand_ptr / cand_last: row pointers of layer k (over ITS nodes) and the last nodes of
  *   level k's types (the candidates a column is looked up in; for k = 1: rowptr and tlast of pp_multiorder_prepare).  Outputs with capacity
  *   n_children (tptr_out / ibase_out: n_children + 1): child = inst of level k+1, row_ptr [n_types + 1] = row pointers of layer k+1,
@@ -204,8 +207,8 @@ int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t
  *   status bit 2: a type with more than 4096 children — the outputs are incomplete, use the generic kernels (pp_linegraph_*, pp_coalesce_*). */
 size_t pp_multiorder_prepare_ws_bytes(int64_t m);
 int pp_multiorder_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, const float* weight, void* lift_ws, size_t lift_ws_bytes,
-                          void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes,
-                          pp_stream_t stream);
+                          int radix_sort, void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws,
+                          size_t ws_bytes, pp_stream_t stream);
 /* The same from a GIVEN event graph (from_temporal_graph(..., event_graph=lift_order_temporal(g, delta)), multi_order_model.py:124-192 with
  * `event_graph` set): event_graph [2, num_event_edges] int64, sorted by source (as lift_order_temporal / lift_order_edge_index leave it; the order of
  * a source's targets is kept: it is the reference's instance order).  graph_ws: pp_multiorder_graph_ws_bytes; `tab` has num_event_edges records.

@@ -950,15 +950,20 @@ def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
         tlast, w = torch.empty(m, **i32), torch.empty(m, **f32)
         row_ptr = torch.empty(n + 1, **i32)
         ws = _workspace(L.pp_multiorder_prepare_ws_bytes(m), dev)
-        if event_graph is None:
-            check(L.pp_multiorder_prepare(_p(ei), m, n, _p(weight), _p(lift_ws), lift_ws.numel(), _p(tab), _p(inst), _p(tptr), _p(ibase), _p(tlast), _p(w),
-                                          _p(row_ptr), _p(ws), ws.numel(), _stream()), "pp_multiorder_prepare")
-        else:
-            check(L.pp_multiorder_prepare_graph(_p(ei), m, n, _p(weight), _p(eg), n_list, _p(lift_ws), lift_ws.numel(), _p(tab), _p(inst), _p(tptr),
-                                                _p(ibase), _p(tlast), _p(w), _p(row_ptr), _p(ws), ws.numel(), _stream()), "pp_multiorder_prepare_graph")
+        # the (source, target, time) order of the events: every node's out-list sorted in LDS; a node with more than 4096 out-events (status bit 4:
+        # its list is left unsorted) sends the stream to the radix sort — contact-shaped streams go there at once
+        for radix in ((True,) if (event_graph is not None or m > 1024 * n) else (False, True)):
+            if event_graph is None:
+                check(L.pp_multiorder_prepare(_p(ei), m, n, _p(weight), _p(lift_ws), lift_ws.numel(), 1 if radix else 0, _p(tab), _p(inst), _p(tptr),
+                                              _p(ibase), _p(tlast), _p(w), _p(row_ptr), _p(ws), ws.numel(), _stream()), "pp_multiorder_prepare")
+            else:
+                check(L.pp_multiorder_prepare_graph(_p(ei), m, n, _p(weight), _p(eg), n_list, _p(lift_ws), lift_ws.numel(), _p(tab), _p(inst), _p(tptr),
+                                                    _p(ibase), _p(tlast), _p(w), _p(row_ptr), _p(ws), ws.numel(), _stream()), "pp_multiorder_prepare_graph")
+            types, status, children, _, pairs = torch.cat((ws[:32], lift_ws[:8])).view(torch.int64).tolist()
+            if not status & 16:
+                break
         if clock is not None:
             clock.append(("prepare", t0, tick()))
-        types, status, children, _, pairs = torch.cat((ws[:32], lift_ws[:8])).view(torch.int64).tolist()
         del lift_ws, ws
         _bad_index(status, "MultiOrderModel.from_temporal_graph")
         if status & 2:

@@ -121,6 +121,149 @@ __global__ __launch_bounds__(kBlock) void k_mo_types1(const KeyT* __restrict__ s
     }
 }
 
+// ---- the same order WITHOUT a second global sort (the default): pp_temporal_count has the events grouped by source in time order (`ids`, `rowptr`);
+// the (source, target, time) order is that sequence with every node's list stably sorted by target — lists of ~20 entries: ONE WAVE PER 64
+// CONSECUTIVE NODES sorts (node, target, slot) keys in LDS (the bitonic network of k_mo_children_wave), a workgroup a list of up to kMoBigMax
+// events; a longer list sets kMoLongList and the caller takes the radix sort above.  The kernels write the level-1 instances and the head flags
+// in place: position p of node v's list range holds the event of rank p - rowptr[v] in its (target, time) order.
+constexpr int64_t kMoLongList = 16;
+constexpr int kMoListCap = 256;
+struct MoListLds {
+    uint64_t keys[kMoListCap];
+    uint32_t cf[kMoListCap], cc[kMoListCap], w[kMoListCap];
+    int32_t p0s[kWave], pre[kWave];
+};
+
+__global__ __launch_bounds__(kBlock) void k_mo_lists_wave(int64_t n_nodes, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
+                                                         const uint4* __restrict__ ev, uint4* __restrict__ inst, int32_t* __restrict__ head,
+                                                         int32_t* __restrict__ big_list, int32_t* __restrict__ counters, int64_t* __restrict__ status) {
+    __shared__ MoListLds lds[kWavesPerBlock];
+    MoListLds& L = lds[wave_id()];
+    const int lane = lane_id();
+    for (int64_t first = ((int64_t)blockIdx.x * kWavesPerBlock + wave_id()) * kWave; first < n_nodes; first += (int64_t)gridDim.x * kBlock) {
+        const int64_t v = first + lane;
+        int32_t p0 = 0, nv = 0;
+        if (v < n_nodes) { p0 = (int32_t)rowptr[v]; nv = (int32_t)rowptr[v + 1] - p0; }
+        const bool big = nv > kMoListCap;
+        if (nv > kMoBigMax) atomicOr((unsigned long long*)status, (unsigned long long)kMoLongList);
+        {   // lists for the workgroup kernel (one atomic per wave that has one)
+            const bool take = big && nv <= kMoBigMax;
+            const uint64_t mask = __ballot(take);
+            if (mask) {
+                const int leader = __ffsll((long long)mask) - 1;
+                int32_t at = 0;
+                if (lane == leader) at = atomicAdd(counters + 1, (int32_t)__popcll(mask));
+                at = __shfl(at, leader, kWave);
+                if (take) big_list[at + (int32_t)__popcll(mask & lanemask_lt())] = (int32_t)v;
+            }
+        }
+        const int32_t ne = big ? 0 : nv;
+        const int32_t incl = wave_inclusive_sum<int32_t>(ne);
+        if (__shfl(incl, kWave - 1, kWave) == 0) continue;
+        L.p0s[lane] = p0;
+        L.pre[lane] = incl - ne;
+        int l0 = 0;
+        while (l0 < kWave) {
+            const int32_t base = l0 ? __shfl(incl, l0 - 1, kWave) : 0;
+            const uint64_t from = l0 ? ~((1ull << l0) - 1ull) : ~0ull;
+            const uint64_t over = __ballot(incl - base > kMoListCap) & from;
+            const int l1 = over ? __ffsll((long long)over) - 1 : kWave;
+            const int32_t nb = __shfl(incl, l1 - 1, kWave) - base;
+            if (nb > 0) {
+                __builtin_amdgcn_wave_barrier();
+                int np2 = 2;
+                while (np2 < nb) np2 <<= 1;
+                for (int slot = lane; slot < np2; slot += kWave) {
+                    uint64_t key = ~0ull;
+                    if (slot < nb) {
+                        int lo = l0, hi = l1;              // last node of the batch whose entries start at or before the slot
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (L.pre[mid] - base <= slot) lo = mid; else hi = mid;
+                        }
+                        const uint4 r = ev[ids[L.p0s[lo] + (slot - (L.pre[lo] - base))]];
+                        L.cf[slot] = r.y; L.cc[slot] = r.z; L.w[slot] = r.w;
+                        key = ((uint64_t)lo << 40) | ((uint64_t)r.x << 8) | (uint64_t)slot;
+                    }
+                    L.keys[slot] = key;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int k = 2; k <= np2; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int q = lane; q < (np2 >> 1); q += kWave) {
+                            const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), o = i | j;
+                            const uint64_t a = L.keys[i], b = L.keys[o];
+                            if ((a > b) == ((i & k) == 0)) { L.keys[i] = b; L.keys[o] = a; }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                for (int pos = lane; pos < nb; pos += kWave) {
+                    const uint64_t key = L.keys[pos];
+                    const uint64_t prev = pos ? L.keys[pos - 1] : ~0ull;
+                    const bool h = (key >> 8) != (prev >> 8);                  // another node or another target
+                    const int nl = (int)(key >> 40), slot = (int)(key & 0xffu);
+                    const int32_t at = L.p0s[nl] + (pos - (L.pre[nl] - base));
+                    inst[at] = make_uint4(L.cf[slot], L.cc[slot] | (h ? kHeadBit : 0u), (uint32_t)(key >> 8), L.w[slot]);
+                    head[at] = h ? 1 : 0;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            l0 = l1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_mo_lists_big(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint4* __restrict__ ev,
+                                                        uint4* __restrict__ inst, int32_t* __restrict__ head, const int32_t* __restrict__ big_list,
+                                                        const int32_t* __restrict__ counters) {
+    __shared__ uint64_t s_key[kMoBigMax];
+    const int n_big = counters[1];
+    const int tid = threadIdx.x;
+    for (int g = blockIdx.x; g < n_big; g += gridDim.x) {
+        const int32_t v = big_list[g];
+        const int32_t p0 = (int32_t)rowptr[v], n = (int32_t)rowptr[v + 1] - p0;
+        int np2 = 2;
+        while (np2 < n) np2 <<= 1;
+        for (int c = tid; c < np2; c += kBlock) s_key[c] = c < n ? (((uint64_t)ev[ids[p0 + c]].x << 32) | (uint64_t)c) : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= np2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < np2; i += kBlock) {
+                    const int o = i ^ j;
+                    if (o > i) {
+                        const uint64_t a = s_key[i], b = s_key[o];
+                        if ((a > b) == ((i & k) == 0)) { s_key[i] = b; s_key[o] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int r = tid; r < n; r += kBlock) {
+            const uint64_t key = s_key[r];
+            const uint32_t dd = (uint32_t)(key >> 32);
+            const bool h = r == 0 || (uint32_t)(s_key[r - 1] >> 32) != dd;
+            const uint4 e = ev[ids[p0 + (int32_t)(uint32_t)key]];
+            inst[p0 + r] = make_uint4(e.y, e.z | (h ? kHeadBit : 0u), dd, e.w);
+            head[p0 + r] = h ? 1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+// types of level 1 from the instances in place: instance range, last node; row pointers over the first-order nodes = heads before a node's list
+__global__ __launch_bounds__(kBlock) void k_mo_types1_lists(const uint4* __restrict__ inst, const int32_t* __restrict__ head_before, const uint32_t* __restrict__ list_ptr,
+                                                           int64_t m, int64_t n, int32_t* __restrict__ tptr, int32_t* __restrict__ tlast,
+                                                           int32_t* __restrict__ rowptr) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j <= n) rowptr[j] = head_before[list_ptr[j]];
+    if (j >= m) return;
+    const int32_t t = head_before[j];
+    if (head_before[j + 1] != t) { tptr[t] = (int32_t)j; tlast[t] = (int32_t)inst[j].z; }
+    if (j == m - 1) tptr[head_before[m]] = (int32_t)m;
+}
+
 // merged weight (run length, or the left-to-right sum: PyG's coalesce order) and number of children of every level-1 type
 template <bool kWeighted>
 __global__ __launch_bounds__(kBlock) void k_mo_sums1(const int32_t* __restrict__ tptr, const int32_t* __restrict__ n_types, const uint4* __restrict__ inst,
@@ -822,7 +965,7 @@ extern "C" {
 size_t pp_multiorder_prepare_ws_bytes(int64_t m) { return carve_mo_prep(nullptr, m).total_bytes; }
 
 static int mo_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, const float* weight, const TemporalLists& tl, int64_t n_list,
-                      void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes,
+                      bool sort_lists, void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes,
                       hipStream_t st) {
     PP_REQUIRE(m > 0 && num_nodes > 0, PP_ERR_ARG, "pp_multiorder_prepare: empty stream");
     PP_REQUIRE(m < (int64_t)0x7ffffff0 && num_nodes < ((int64_t)1 << 31), PP_ERR_TOO_LARGE, "pp_multiorder_prepare: m or num_nodes >= 2^31");
@@ -835,9 +978,29 @@ static int mo_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, c
     const int64_t* dst = edge_index + m;
     const unsigned grid = (unsigned)ceil_div(m, kBlock);
     const int bits = bits_for((uint64_t)(num_nodes - 1));
-    int rc = 2 * bits <= 32 ? mo_level1<uint32_t>(p, tl, src, dst, weight, m, num_nodes, bits, (uint4*)inst, tptr, tlast, rowptr, st)
+    int rc;
+    if (sort_lists && tl.rowptr != nullptr) {
+        // the per-node lists of pp_temporal_count, every list sorted by target in LDS: no second global sort
+        k_mo_events<<<grid, kBlock, 0, st>>>(dst, tl.first_pos, tl.count, weight, m, num_nodes, p.ev);
+        PP_LAUNCH_CHECK();
+        const int64_t pieces = ceil_div(num_nodes, kBlock);
+        PP_HIP(hipMemsetAsync(p.head, 0, (size_t)m * sizeof(int32_t), st));       // (a list beyond the workgroup kernel stays unwritten: no heads there)
+        k_mo_lists_wave<<<(unsigned)(pieces < 4096 ? pieces : 4096), kBlock, 0, st>>>(num_nodes, tl.rowptr, tl.ids, p.ev, (uint4*)inst, p.head, p.long_list,
+                                                                                      p.counters, p.result + 1);
+        PP_LAUNCH_CHECK();
+        k_mo_lists_big<<<1024, kBlock, 0, st>>>(tl.rowptr, tl.ids, p.ev, (uint4*)inst, p.head, p.long_list, p.counters);
+        PP_LAUNCH_CHECK();
+        rc = exclusive_scan<int32_t, int32_t>(p.head, m, p.head_before, true, p.result, p.scratch, p.scratch_bytes, st);
+        if (rc != PP_OK) return rc;
+        const int64_t longest = m > num_nodes + 1 ? m : num_nodes + 1;
+        k_mo_types1_lists<<<(unsigned)ceil_div(longest, kBlock), kBlock, 0, st>>>((const uint4*)inst, p.head_before, tl.rowptr, m, num_nodes, tptr, tlast, rowptr);
+        PP_LAUNCH_CHECK();
+        PP_HIP(hipMemsetAsync(p.counters, 0, 4 * sizeof(int32_t), st));          // (the list of long lists is done with; k_mo_sums1 fills its own)
+    } else {
+        rc = 2 * bits <= 32 ? mo_level1<uint32_t>(p, tl, src, dst, weight, m, num_nodes, bits, (uint4*)inst, tptr, tlast, rowptr, st)
                             : mo_level1<uint64_t>(p, tl, src, dst, weight, m, num_nodes, bits, (uint4*)inst, tptr, tlast, rowptr, st);
-    if (rc != PP_OK) return rc;
+        if (rc != PP_OK) return rc;
+    }
     if (weight) k_mo_sums1<true><<<grid, kBlock, 0, st>>>(tptr, p.head_before + m, (const uint4*)inst, w, p.csum, p.long_list, p.counters);
     else k_mo_sums1<false><<<grid, kBlock, 0, st>>>(tptr, p.head_before + m, (const uint4*)inst, w, p.csum, p.long_list, p.counters);
     PP_LAUNCH_CHECK();
@@ -854,12 +1017,12 @@ static int mo_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, c
 }
 
 int pp_multiorder_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, const float* weight, void* lift_ws, size_t lift_ws_bytes,
-                          void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws, size_t ws_bytes,
-                          pp_stream_t stream) {
+                          int radix_sort, void* tab, void* inst, int32_t* tptr, int32_t* ibase, int32_t* tlast, float* w, int32_t* rowptr, void* ws,
+                          size_t ws_bytes, pp_stream_t stream) {
     PP_REQUIRE(m > 0 && num_nodes > 0, PP_ERR_ARG, "pp_multiorder_prepare: empty stream");
     const TemporalLists tl = temporal_lists(lift_ws, m, num_nodes);
     PP_REQUIRE(lift_ws_bytes >= tl.total_bytes, PP_ERR_WORKSPACE, "pp_multiorder_prepare: not a pp_temporal_count workspace of this stream");
-    return mo_prepare(edge_index, m, num_nodes, weight, tl, m, tab, inst, tptr, ibase, tlast, w, rowptr, ws, ws_bytes, (hipStream_t)stream);
+    return mo_prepare(edge_index, m, num_nodes, weight, tl, m, radix_sort == 0, tab, inst, tptr, ibase, tlast, w, rowptr, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t pp_multiorder_graph_ws_bytes(int64_t m, int64_t num_event_edges) { return carve_mo_graph(nullptr, m, num_event_edges).total_bytes; }
@@ -882,7 +1045,7 @@ int pp_multiorder_prepare_graph(const int64_t* edge_index, int64_t m, int64_t nu
     k_mo_graph_windows<<<(unsigned)ceil_div(m, kBlock), kBlock, 0, st>>>(gws.rowptr, m, gws.first_pos, gws.count);
     PP_LAUNCH_CHECK();
     const TemporalLists tl{gws.ids, nullptr, gws.first_pos, gws.count, gws.result, gws.total_bytes};
-    return mo_prepare(edge_index, m, num_nodes, weight, tl, num_event_edges, tab, inst, tptr, ibase, tlast, w, rowptr, ws, ws_bytes, st);
+    return mo_prepare(edge_index, m, num_nodes, weight, tl, num_event_edges, false, tab, inst, tptr, ibase, tlast, w, rowptr, ws, ws_bytes, st);
 }
 
 const int64_t* pp_multiorder_result_ptr(void* ws) { return (const int64_t*)ws; }

@@ -278,3 +278,24 @@ def test_given_event_graph_takes_the_level_by_level_builder_too(pp, kind):
                 assert torch.equal(d[key].cpu(), want[k][key]), (k, key)
     # an event graph on the host goes to the generic kernels
     assert not _level_by_level(pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=3, event_graph=eg.cpu()))
+
+
+def test_a_node_with_more_out_events_than_a_workgroup_sorts(pp):
+    # the first level sorts every node's out-list by target in LDS (up to 4096 events per list); one node with 6000 out-events in an otherwise
+    # sparse stream: the list kernel reports it and the radix sort of the (source, target) keys takes the stream — same layers either way
+    from oracle import model as om
+    rng = np.random.default_rng(9)
+    n, m = 3000, 30_000
+    src = rng.integers(0, n, m)
+    src[:6000] = 7
+    ei = torch.from_numpy(np.stack((src, rng.integers(0, n, m))))
+    t = torch.from_numpy(rng.integers(0, 200_000, m))
+    g = pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=t.to(DEV), num_nodes=n))
+    sei, st, _ = om.stable_time_sort(ei, t)
+    want = om.layers_from_temporal(sei, st, n, delta=700, max_order=3)
+    model = pp.MultiOrderModel.from_temporal_graph(g, delta=700, max_order=3)
+    assert _level_by_level(model)
+    for k in want:
+        d = model.layers[k].data
+        for key in ("edge_index", "edge_weight", "node_sequence"):
+            assert torch.equal(d[key].cpu(), want[k][key]), (k, key)
