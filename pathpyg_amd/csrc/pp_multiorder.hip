@@ -20,16 +20,19 @@
 //   * Instances are kept GROUPED BY TYPE, types in lexicographic order of their node sequences, instances of one type in lexicographic
 //     order of their event sequences (= the reference's instance numbering restricted to the type).  The children of all instances of
 //     type s, stably sorted by their new last node d, are then exactly the instances of the types s ++ d, in the right order: the
-//     global sorts of the reference shrink to one tiny sort per type (a lane's registers; a wave's or a workgroup's LDS for the larger ones), the weight of a merged edge is
-//     the count (or the left-to-right sum, PyG's coalesce order) of a run, and everything is written sequentially.
+//     global sorts of the reference shrink to one tiny sort per type (a lane's registers; a wave's or a workgroup's LDS for the larger
+//     ones), the weight of a merged edge is the count (or the left-to-right sum, PyG's coalesce order) of a run, and everything is written
+//     sequentially.  Level 1 is the same idea on the events: pp_temporal_count has them grouped by source in time order, every node's list
+//     is sorted by target in LDS — the only global sort of the whole model is pp_temporal_count's sort by source.
 //   * Layer k+1's edge (s -> c): c is the type suffix(s) ++ d.  suffix(s) is the column u of s in layer k, the candidates are u's
 //     out-edges in layer k (one contiguous id block, last nodes ascending): a bisection in a handful of entries.
 //
-// Per level: k_mo_children (+ k_mo_children_wave, k_mo_children_big) -> scan of the row lengths -> k_mo_types (+ k_mo_types_wave, k_mo_types_big) -> scan of the children
-// counts.  No read-back between them; the caller reads {types, status, children of the next level} once per level.
-// Algorithmic bytes per level (what the generic kernels move — 16 E_k + 16 E_{k+1} for the lift, 8 k E_{k+1} for the
-// sequences, 16 E_{k+1} + 20 A_{k+1} for the aggregation) are reported by bench.py beside the time; the bytes this path moves are
-// 16 I_k + 32 I_{k+1} + 20 A_{k+1} + the window reads.
+// Per level: k_mo_children (+ k_mo_children_wave, k_mo_children_big) -> scan of the row lengths -> k_mo_types (+ k_mo_types_wave,
+// k_mo_types_big) -> scan of the children counts.  No read-back between them; the caller reads {types, status, children of the next
+// level} once per level.  Algorithmic bytes per level (what the generic kernels move — 16 E_k + 16 E_{k+1} for the lift,
+// 20 E_{k+1} + 20 A_{k+1} for the aggregation) are reported by bench.py beside the time (`multi_order`); the bytes this path moves are
+// 16 I_k + 48 I_{k+1} + 20 A_{k+1} (top layer: 16 I_k + 24 I_{k+1} + 8 A_{k+1}) — and one 128-byte line of `tab` per parent instance plus
+// the candidate blocks, which is what bounds it.
 #include <stdlib.h>
 
 #include "pp_internal.h"
