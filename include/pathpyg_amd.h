@@ -191,7 +191,7 @@ int pp_debruijn2_part_fill(int time_dtype, int64_t m, int64_t num_nodes, int64_t
  * (ibase[types] = instances of level k+1);  col [types] column of the type in layer k;  tlast [types] its last node;
  * inst [instances] 16-byte records {window first, window count | head bit, last node, float32 weight of the first event}.
  *
- * pp_multiorder_prepare: level 1 from a finished pp_temporal_count (same stream, same delta; `lift_ws` is its workspace).  All outputs
+ * pp_multiorder_prepare: level 1 from a finished pp_temporal_count or pp_temporal_windows (same stream, same delta; `lift_ws` is its workspace).  All outputs
  *   have capacity m (tptr / ibase: m + 1, rowptr: num_nodes + 1); `tab` [m] 16-byte records is the continuation table every step reads.
  *   Layer 1 = (rowptr, tlast as columns, w).  pp_multiorder_result_ptr(ws) = {types, status, instances of level 2 (= E2), long runs};
  *   status: bit 0 node index out of range, bit 1 time not ascending (both from pp_temporal_count).  The (source, target, time) order of the events:
@@ -243,6 +243,10 @@ int pp_temporal_count(const int64_t* edge_index, const void* time, int time_dtyp
                       int delta_kind, int64_t delta_i, double delta_f, void* ws, size_t ws_bytes, pp_stream_t stream);
 int pp_temporal_fill(int64_t m, int64_t num_nodes, int64_t total, int64_t id_offset, int64_t* out, void* ws, size_t ws_bytes,
                      pp_stream_t stream);
+/* Steps 1-2 of pp_temporal_count only — the per-node event lists and every event's continuation window, no output offsets (result[0] stays 0,
+ * pp_temporal_fill must not follow): what pp_multiorder_prepare reads (the multi-order builder never writes the event graph). */
+int pp_temporal_windows(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i,
+                        double delta_f, void* ws, size_t ws_bytes, pp_stream_t stream);
 
 /* lift_order_edge_index(edge_index, num_nodes) -> [2,E'] int64, src/pathpyG/algorithms/lift_order.py:48-79.
  * edge_index must be grouped by source like the reference demands (:52,55). */

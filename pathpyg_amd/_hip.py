@@ -935,8 +935,8 @@ def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
         t0 = tick()
         if event_graph is None:
             lift_ws = _workspace(L.pp_temporal_ws_bytes(m, n), dev)
-            check(L.pp_temporal_count(_p(ei), _p(time), _DTYPE_CODE[time.dtype], m, m, n, kind, di, df, _p(lift_ws), lift_ws.numel(), _stream()),
-                  "pp_temporal_count")
+            check(L.pp_temporal_windows(_p(ei), _p(time), _DTYPE_CODE[time.dtype], m, n, kind, di, df, _p(lift_ws), lift_ws.numel(), _stream()),
+                  "pp_temporal_windows")
             n_list = m
         else:
             eg = _edge_index(event_graph)
@@ -959,16 +959,16 @@ def multi_order_temporal(edge_index: torch.Tensor, time: torch.Tensor, num_nodes
             else:
                 check(L.pp_multiorder_prepare_graph(_p(ei), m, n, _p(weight), _p(eg), n_list, _p(lift_ws), lift_ws.numel(), _p(tab), _p(inst), _p(tptr),
                                                     _p(ibase), _p(tlast), _p(w), _p(row_ptr), _p(ws), ws.numel(), _stream()), "pp_multiorder_prepare_graph")
-            types, status, children, _, pairs = torch.cat((ws[:32], lift_ws[:8])).view(torch.int64).tolist()
+            types, status, children, _ = ws[:32].view(torch.int64).tolist()
             if not status & 16:
                 break
         if clock is not None:
             clock.append(("prepare", t0, tick()))
         del lift_ws, ws
         _bad_index(status, "MultiOrderModel.from_temporal_graph")
-        if status & 2:
-            return None                  # (unsorted: the caller sorts and takes the generic path)
-        if children != pairs:            # the instances of level 2 ARE the event graph's edges (a 32-bit count that wrapped: the generic kernels decide)
+        if status & (2 | 4):
+            return None                  # (unsorted: the caller sorts and takes the generic path; 2^31 continuations of one node pair's events)
+        if event_graph is not None and children != n_list:      # the instances of level 2 ARE the event graph's edges
             return None
         layers = [MultiOrderLayer(n_nodes=n, n_edges=types, n_instances=m, row_ptr=row_ptr, col=tlast[:types], weight=w[:types], last=tlast[:types])]
         col, cand_ptr, cand_last = tlast, row_ptr, tlast

@@ -673,9 +673,22 @@ extern "C" {
 // ---------------------------------------------------------------- temporal lift
 size_t pp_temporal_ws_bytes(int64_t m, int64_t num_nodes) { return carve_lift(nullptr, m, num_nodes, true).total_bytes; }
 
+static int temporal_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t n_own, int64_t num_nodes,
+                          int delta_kind, int64_t delta_i, double delta_f, void* ws, size_t ws_bytes, bool offsets, hipStream_t st);
+
 int pp_temporal_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t n_own, int64_t num_nodes,
                       int delta_kind, int64_t delta_i, double delta_f, void* ws, size_t ws_bytes, pp_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
+    return temporal_count(edge_index, time, time_dtype, m, n_own, num_nodes, delta_kind, delta_i, delta_f, ws, ws_bytes, true, (hipStream_t)stream);
+}
+
+/* see include/pathpyg_amd.h: the lists and windows of pp_temporal_count without the offsets of the fill */
+int pp_temporal_windows(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t num_nodes, int delta_kind, int64_t delta_i,
+                        double delta_f, void* ws, size_t ws_bytes, pp_stream_t stream) {
+    return temporal_count(edge_index, time, time_dtype, m, m, num_nodes, delta_kind, delta_i, delta_f, ws, ws_bytes, false, (hipStream_t)stream);
+}
+
+static int temporal_count(const int64_t* edge_index, const void* time, int time_dtype, int64_t m, int64_t n_own, int64_t num_nodes,
+                          int delta_kind, int64_t delta_i, double delta_f, void* ws, size_t ws_bytes, bool offsets, hipStream_t st) {
     PP_REQUIRE(m >= 0 && num_nodes >= 0, PP_ERR_ARG, "pp_temporal_count: negative size");
     if (n_own < 0 || n_own > m) n_own = m;
     PP_REQUIRE(m < (int64_t)0x7fffffff && num_nodes < (int64_t)0x7fffffff, PP_ERR_TOO_LARGE, "pp_temporal_count: m or num_nodes >= 2^31");
@@ -702,6 +715,7 @@ int pp_temporal_count(const int64_t* edge_index, const void* time, int time_dtyp
     else
         rc = launch_temporal_count<double>(delta_kind, grid, st, head, (const double*)time, m, n_own, num_nodes, delta_i, delta_f, w);
     if (rc != PP_OK) return rc;
+    if (!offsets) return PP_OK;
     // 3. offsets + total
     return exclusive_scan<int32_t, int64_t>(w.count, m, w.offset, true, w.result, w.scratch, w.scratch_bytes, st, w.tile_src, kWaveTile, w.tile_cap);
 }

@@ -271,26 +271,28 @@ __global__ __launch_bounds__(kBlock) void k_mo_types1_lists(const uint4* __restr
 template <bool kWeighted>
 __global__ __launch_bounds__(kBlock) void k_mo_sums1(const int32_t* __restrict__ tptr, const int32_t* __restrict__ n_types, const uint4* __restrict__ inst,
                                                     float* __restrict__ w, int32_t* __restrict__ csum, int32_t* __restrict__ long_list,
-                                                    int32_t* __restrict__ long_count) {
+                                                    int32_t* __restrict__ long_count, int64_t* __restrict__ status) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= *n_types) return;
     const int32_t x0 = tptr[t], x1 = tptr[t + 1];
     if (x1 - x0 > kMoLongRun) { long_list[atomicAdd(long_count, 1)] = (int32_t)t; return; }
     float acc = 0.f;
-    int32_t c = 0;
+    int64_t c = 0;
     for (int32_t x = x0; x < x1; ++x) {
         const uint4 it = inst[x];
         acc += __uint_as_float(it.w);
-        c += (int32_t)(it.y & ~kHeadBit);
+        c += (int64_t)(it.y & ~kHeadBit);
     }
     w[t] = kWeighted ? acc : (float)(x1 - x0);
-    csum[t] = c;
+    if (c > 0x7fffffff) { atomicOr((unsigned long long*)status, (unsigned long long)kMoOverflow); c = 0x7fffffff; }     // (2^31 instances at level 2: the caller falls back)
+    csum[t] = (int32_t)c;
 }
 
 // node pairs with very many events: one wave per pair, every lane a contiguous chunk left to right, chunks combined in lane order
 template <bool kWeighted>
 __global__ __launch_bounds__(kBlock) void k_mo_sums1_long(const int32_t* __restrict__ tptr, const uint4* __restrict__ inst, const int32_t* __restrict__ long_list,
-                                                         const int32_t* __restrict__ long_count, float* __restrict__ w, int32_t* __restrict__ csum) {
+                                                         const int32_t* __restrict__ long_count, float* __restrict__ w, int32_t* __restrict__ csum,
+                                                         int64_t* __restrict__ status) {
     const int n_long = *long_count;
     for (int g = blockIdx.x * kWavesPerBlock + wave_id(); g < n_long; g += gridDim.x * kWavesPerBlock) {
         const int32_t t = long_list[g];
@@ -298,16 +300,20 @@ __global__ __launch_bounds__(kBlock) void k_mo_sums1_long(const int32_t* __restr
         const int32_t chunk = (x1 - x0 + kWave - 1) / kWave;
         const int32_t b = x0 + lane_id() * chunk, e = b + chunk < x1 ? b + chunk : x1;
         float acc = 0.f;
-        int32_t c = 0;
+        long long c = 0;
         for (int32_t x = b; x < e; ++x) {
             const uint4 it = inst[x];
             acc += __uint_as_float(it.w);
-            c += (int32_t)(it.y & ~kHeadBit);
+            c += (long long)(it.y & ~kHeadBit);
         }
         float total = 0.f;
         for (int l = 0; l < kWave; ++l) total += __shfl(acc, l, kWave);        // fixed order
-        c = wave_sum<int32_t>(c);
-        if (lane_id() == 0) { w[t] = kWeighted ? total : (float)(x1 - x0); csum[t] = c; }
+        c = wave_sum<long long>(c);
+        if (lane_id() == 0) {
+            w[t] = kWeighted ? total : (float)(x1 - x0);
+            if (c > 0x7fffffff) { atomicOr((unsigned long long*)status, (unsigned long long)kMoOverflow); c = 0x7fffffff; }
+            csum[t] = (int32_t)c;
+        }
     }
 }
 
@@ -1004,11 +1010,11 @@ static int mo_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, c
                             : mo_level1<uint64_t>(p, tl, src, dst, weight, m, num_nodes, bits, (uint4*)inst, tptr, tlast, rowptr, st);
         if (rc != PP_OK) return rc;
     }
-    if (weight) k_mo_sums1<true><<<grid, kBlock, 0, st>>>(tptr, p.head_before + m, (const uint4*)inst, w, p.csum, p.long_list, p.counters);
-    else k_mo_sums1<false><<<grid, kBlock, 0, st>>>(tptr, p.head_before + m, (const uint4*)inst, w, p.csum, p.long_list, p.counters);
+    if (weight) k_mo_sums1<true><<<grid, kBlock, 0, st>>>(tptr, p.head_before + m, (const uint4*)inst, w, p.csum, p.long_list, p.counters, p.result + 1);
+    else k_mo_sums1<false><<<grid, kBlock, 0, st>>>(tptr, p.head_before + m, (const uint4*)inst, w, p.csum, p.long_list, p.counters, p.result + 1);
     PP_LAUNCH_CHECK();
-    if (weight) k_mo_sums1_long<true><<<256, kBlock, 0, st>>>(tptr, (const uint4*)inst, p.long_list, p.counters, w, p.csum);
-    else k_mo_sums1_long<false><<<256, kBlock, 0, st>>>(tptr, (const uint4*)inst, p.long_list, p.counters, w, p.csum);
+    if (weight) k_mo_sums1_long<true><<<256, kBlock, 0, st>>>(tptr, (const uint4*)inst, p.long_list, p.counters, w, p.csum, p.result + 1);
+    else k_mo_sums1_long<false><<<256, kBlock, 0, st>>>(tptr, (const uint4*)inst, p.long_list, p.counters, w, p.csum, p.result + 1);
     PP_LAUNCH_CHECK();
     rc = exclusive_scan<int32_t, int32_t>(p.csum, m, ibase, true, p.result + 2, p.scratch, p.scratch_bytes, st);
     if (rc != PP_OK) return rc;
