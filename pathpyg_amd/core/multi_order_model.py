@@ -88,7 +88,12 @@ class MultiOrderModel:
         Same layers as the reference, computed without ever materialising the per-instance node sequences
         (``[E_k, k+1]`` tensors): see :class:`_LiftChain`."""
         if max_order == 2 and event_graph is None and FUSED_BUILDER:
-            fused = _second_order_fused(g, delta, weight, cached)
+            # a stream with a very large hub (BASELINE configs[2]'s generator: a node with 2 * 10^6 in-events): the order-2 builder's hub kernels
+            # cost it 10-11 ms where the level-by-level builder makes both layers in 5.7 ms (it makes no GCN plans: DBGNN.forward builds them
+            # from the layers' tensors when such a model is trained)
+            fused = _multi_order_fused(g, delta, 2, weight, cached) if _has_large_hub(g) else None
+            if fused is None:
+                fused = _second_order_fused(g, delta, weight, cached)
             if fused is not None:
                 return fused
         if max_order >= 3 and FUSED_BUILDER:
@@ -453,6 +458,26 @@ def _second_order_fused(g: TemporalGraph, delta, weight: str, cached: bool):
                                  2: (g2, {"edge_index": lazy2["edge_index"], "edge_weight": lazy2["edge_weight"]})})
     out.sizes = dict(built.sizes)
     return out
+
+
+LARGE_HUB_EVENTS = 65536
+
+
+def _has_large_hub(g: TemporalGraph) -> bool:
+    """Whether some node of a device-resident stream has ``LARGE_HUB_EVENTS`` or more in- or out-events (two histograms and one read-back, kept
+    on the graph object for the tensors they were taken from)."""
+    from .. import _hip
+    ei = _dispatch.plain(g.data.edge_index)
+    if ei is None or not ei.is_cuda or ei.numel() == 0 or ei.size(1) < LARGE_HUB_EVENTS:
+        return False
+    key = (id(ei), ei._version, int(g.data.num_nodes))
+    kept = getattr(g, "_pp_max_degree", None)
+    if kept is None or kept[0] != key:
+        n = int(g.data.num_nodes)
+        ei = ei.contiguous()
+        most = int(torch.maximum(_hip.degree(ei[0], n).max(), _hip.degree(ei[1], n).max()))
+        kept = g._pp_max_degree = (key, most)
+    return kept[1] >= LARGE_HUB_EVENTS
 
 
 def _multi_order_fused(g: TemporalGraph, delta, max_order: int, weight: str, cached: bool, event_graph=None):

@@ -299,3 +299,31 @@ def test_a_node_with_more_out_events_than_a_workgroup_sorts(pp):
         d = model.layers[k].data
         for key in ("edge_index", "edge_weight", "node_sequence"):
             assert torch.equal(d[key].cpu(), want[k][key]), (k, key)
+
+
+def test_order_two_of_a_stream_with_a_very_large_hub(pp):
+    # from_temporal_graph(max_order=2) on a stream with a node of 10^5 in-events takes the level-by-level builder (the order-2 builder's hub kernels are
+    # the slower way there); the layers are the generic kernels', and the DBGNN bundle / forward / backward work from them (plans made on the way)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    n, m, span, delta = 5_000, 400_000, 400_000, 3_000
+    src = torch.randint(0, n, (m,), generator=gen, device=DEV)
+    dst = (n * torch.rand(m, generator=gen, device=DEV, dtype=torch.float64).pow(6.0)).long().clamp_(max=n - 1)
+    t = torch.randint(0, span, (m,), generator=gen, device=DEV)
+    g = pp.TemporalGraph(pp.Data(edge_index=torch.stack((src, dst)), time=t, num_nodes=n))
+    assert int(torch.bincount(dst).max()) >= 65536
+    model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=2)
+    assert _level_by_level(model) and getattr(model, "_pp_fused", None) is None
+    slow = _generic(pp, g, delta, 2)
+    for k in (1, 2):
+        a, b = model.layers[k].data, slow.layers[k].data
+        for key in ("edge_index", "edge_weight", "node_sequence", "inverse_idx"):
+            assert torch.equal(a[key], b[key]), (k, key)
+    data = model.to_dbgnn_data(max_order=2, x=torch.randn(n, 16, device=DEV), x_h=torch.randn(model.layers[2].n, 16, device=DEV))
+    net = pp.nn.DBGNN(num_classes=3, num_features=(16, 16), hidden_dims=[16, 16, 16]).to(DEV)
+    out = net(data)
+    out.sum().backward()
+    assert bool(torch.isfinite(out).all())
+    # a stream without such a hub stays on the order-2 builder
+    ei, tt, _, nn_, dd = _stream("sparse", 3)
+    small = pp.MultiOrderModel.from_temporal_graph(pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=tt.to(DEV), num_nodes=nn_)), delta=dd, max_order=2)
+    assert getattr(small, "_pp_fused", None) is not None
