@@ -139,7 +139,8 @@ struct MoListLds {
 
 __global__ __launch_bounds__(kBlock) void k_mo_lists_wave(int64_t n_nodes, const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids,
                                                          const uint4* __restrict__ ev, uint4* __restrict__ inst, int32_t* __restrict__ head,
-                                                         int32_t* __restrict__ big_list, int32_t* __restrict__ counters, int64_t* __restrict__ status) {
+                                                         uint4* __restrict__ tab, int32_t* __restrict__ big_list, int32_t* __restrict__ counters,
+                                                         int64_t* __restrict__ status) {
     __shared__ MoListLds lds[kWavesPerBlock];
     MoListLds& L = lds[wave_id()];
     const int lane = lane_id();
@@ -184,7 +185,10 @@ __global__ __launch_bounds__(kBlock) void k_mo_lists_wave(int64_t n_nodes, const
                             const int mid = (lo + hi) >> 1;
                             if (L.pre[mid] - base <= slot) lo = mid; else hi = mid;
                         }
-                        const uint4 r = ev[ids[L.p0s[lo] + (slot - (L.pre[lo] - base))]];
+                        const int32_t at = L.p0s[lo] + (slot - (L.pre[lo] - base));
+                        const uint32_t e = ids[at];
+                        const uint4 r = ev[e];
+                        tab[at] = make_uint4(r.x, r.y, r.z, e);          // (the window table's entry of this list position: k_mo_tab's gather, already here)
                         L.cf[slot] = r.y; L.cc[slot] = r.z; L.w[slot] = r.w;
                         key = ((uint64_t)lo << 40) | ((uint64_t)r.x << 8) | (uint64_t)slot;
                     }
@@ -219,8 +223,8 @@ __global__ __launch_bounds__(kBlock) void k_mo_lists_wave(int64_t n_nodes, const
 }
 
 __global__ __launch_bounds__(kBlock) void k_mo_lists_big(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ ids, const uint4* __restrict__ ev,
-                                                        uint4* __restrict__ inst, int32_t* __restrict__ head, const int32_t* __restrict__ big_list,
-                                                        const int32_t* __restrict__ counters) {
+                                                        uint4* __restrict__ inst, int32_t* __restrict__ head, uint4* __restrict__ tab,
+                                                        const int32_t* __restrict__ big_list, const int32_t* __restrict__ counters) {
     __shared__ uint64_t s_key[kMoBigMax];
     const int n_big = counters[1];
     const int tid = threadIdx.x;
@@ -229,7 +233,16 @@ __global__ __launch_bounds__(kBlock) void k_mo_lists_big(const uint32_t* __restr
         const int32_t p0 = (int32_t)rowptr[v], n = (int32_t)rowptr[v + 1] - p0;
         int np2 = 2;
         while (np2 < n) np2 <<= 1;
-        for (int c = tid; c < np2; c += kBlock) s_key[c] = c < n ? (((uint64_t)ev[ids[p0 + c]].x << 32) | (uint64_t)c) : ~0ull;
+        for (int c = tid; c < np2; c += kBlock) {
+            uint64_t key = ~0ull;
+            if (c < n) {
+                const uint32_t e = ids[p0 + c];
+                const uint4 r = ev[e];
+                tab[p0 + c] = make_uint4(r.x, r.y, r.z, e);
+                key = ((uint64_t)r.x << 32) | (uint64_t)c;
+            }
+            s_key[c] = key;
+        }
         __syncthreads();
         for (int k = 2; k <= np2; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -988,16 +1001,18 @@ static int mo_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, c
     const unsigned grid = (unsigned)ceil_div(m, kBlock);
     const int bits = bits_for((uint64_t)(num_nodes - 1));
     int rc;
+    bool tab_done = false;               // (the list kernels write the window table on their way)
     if (sort_lists && tl.rowptr != nullptr) {
         // the per-node lists of pp_temporal_count, every list sorted by target in LDS: no second global sort
         k_mo_events<<<grid, kBlock, 0, st>>>(dst, tl.first_pos, tl.count, weight, m, num_nodes, p.ev);
         PP_LAUNCH_CHECK();
         const int64_t pieces = ceil_div(num_nodes, kBlock);
         PP_HIP(hipMemsetAsync(p.head, 0, (size_t)m * sizeof(int32_t), st));       // (a list beyond the workgroup kernel stays unwritten: no heads there)
-        k_mo_lists_wave<<<(unsigned)(pieces < 4096 ? pieces : 4096), kBlock, 0, st>>>(num_nodes, tl.rowptr, tl.ids, p.ev, (uint4*)inst, p.head, p.long_list,
-                                                                                      p.counters, p.result + 1);
+        k_mo_lists_wave<<<(unsigned)(pieces < 4096 ? pieces : 4096), kBlock, 0, st>>>(num_nodes, tl.rowptr, tl.ids, p.ev, (uint4*)inst, p.head, (uint4*)tab,
+                                                                                      p.long_list, p.counters, p.result + 1);
         PP_LAUNCH_CHECK();
-        k_mo_lists_big<<<1024, kBlock, 0, st>>>(tl.rowptr, tl.ids, p.ev, (uint4*)inst, p.head, p.long_list, p.counters);
+        k_mo_lists_big<<<1024, kBlock, 0, st>>>(tl.rowptr, tl.ids, p.ev, (uint4*)inst, p.head, (uint4*)tab, p.long_list, p.counters);
+        tab_done = true;
         PP_LAUNCH_CHECK();
         rc = exclusive_scan<int32_t, int32_t>(p.head, m, p.head_before, true, p.result, p.scratch, p.scratch_bytes, st);
         if (rc != PP_OK) return rc;
@@ -1018,7 +1033,7 @@ static int mo_prepare(const int64_t* edge_index, int64_t m, int64_t num_nodes, c
     PP_LAUNCH_CHECK();
     rc = exclusive_scan<int32_t, int32_t>(p.csum, m, ibase, true, p.result + 2, p.scratch, p.scratch_bytes, st);
     if (rc != PP_OK) return rc;
-    if (n_list > 0) k_mo_tab<<<(unsigned)ceil_div(n_list, kBlock), kBlock, 0, st>>>(tl.ids, p.ev, n_list, (uint4*)tab);
+    if (n_list > 0 && !tab_done) k_mo_tab<<<(unsigned)ceil_div(n_list, kBlock), kBlock, 0, st>>>(tl.ids, p.ev, n_list, (uint4*)tab);
     PP_LAUNCH_CHECK();
     k_mo_finish<<<1, 1, 0, st>>>(p.counters, tl.result, p.result);
     PP_LAUNCH_CHECK();
