@@ -88,10 +88,11 @@ class MultiOrderModel:
         Same layers as the reference, computed without ever materialising the per-instance node sequences
         (``[E_k, k+1]`` tensors): see :class:`_LiftChain`."""
         if max_order == 2 and event_graph is None and FUSED_BUILDER:
-            # a stream with a very large hub (BASELINE configs[2]'s generator: a node with 2 * 10^6 in-events): the order-2 builder's hub kernels
-            # cost it 10-11 ms where the level-by-level builder makes both layers in 5.7 ms (it makes no GCN plans: DBGNN.forward builds them
-            # from the layers' tensors when such a model is trained)
-            fused = _multi_order_fused(g, delta, 2, weight, cached) if _has_large_hub(g) else None
+            # LIFT_ONLY_ORDER2 (off by default): a stream with a very large hub (BASELINE configs[2]'s generator: a node with 2 * 10^6 in-events) costs
+            # the order-2 builder's hub kernels 10-11 ms where the level-by-level builder makes both layers in 5.3-5.7 ms — but it makes no GCN
+            # plans, and DBGNN.forward building them from the layers' tensors costs 20 ms more than the order-2 builder's own (39 against 25 ms
+            # for model + bundle + one step, tools/probes/hub_k2_routes.py): the default serves the DBGNN workflow, the switch a caller who only lifts
+            fused = _multi_order_fused(g, delta, 2, weight, cached) if (LIFT_ONLY_ORDER2 and _has_large_hub(g)) else None
             if fused is None:
                 fused = _second_order_fused(g, delta, weight, cached)
             if fused is not None:
@@ -461,6 +462,7 @@ def _second_order_fused(g: TemporalGraph, delta, weight: str, cached: bool):
 
 
 LARGE_HUB_EVENTS = 65536
+LIFT_ONLY_ORDER2 = False     # from_temporal_graph(max_order=2) on a stream with a node of LARGE_HUB_EVENTS events: True = the level-by-level builder (no GCN plans)
 
 
 def _has_large_hub(g: TemporalGraph) -> bool:

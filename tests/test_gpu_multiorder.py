@@ -302,8 +302,10 @@ def test_a_node_with_more_out_events_than_a_workgroup_sorts(pp):
 
 
 def test_order_two_of_a_stream_with_a_very_large_hub(pp):
-    # from_temporal_graph(max_order=2) on a stream with a node of 10^5 in-events takes the level-by-level builder (the order-2 builder's hub kernels are
-    # the slower way there); the layers are the generic kernels', and the DBGNN bundle / forward / backward work from them (plans made on the way)
+    # multi_order_model.LIFT_ONLY_ORDER2: from_temporal_graph(max_order=2) on a stream with a node of 10^5 in-events through the level-by-level builder
+    # (the order-2 builder's hub kernels are the slower way to the LAYERS there; the default keeps the order-2 builder because it also makes the GCN
+    # plans); the layers are the generic kernels', and the DBGNN bundle / forward / backward work from them (plans made on the way)
+    from pathpyg_amd.core import multi_order_model as mm
     gen = torch.Generator(device=DEV).manual_seed(4)
     n, m, span, delta = 5_000, 400_000, 400_000, 3_000
     src = torch.randint(0, n, (m,), generator=gen, device=DEV)
@@ -311,7 +313,12 @@ def test_order_two_of_a_stream_with_a_very_large_hub(pp):
     t = torch.randint(0, span, (m,), generator=gen, device=DEV)
     g = pp.TemporalGraph(pp.Data(edge_index=torch.stack((src, dst)), time=t, num_nodes=n))
     assert int(torch.bincount(dst).max()) >= 65536
-    model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=2)
+    assert getattr(pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=2), "_pp_fused", None) is not None          # the default
+    mm.LIFT_ONLY_ORDER2 = True
+    try:
+        model = pp.MultiOrderModel.from_temporal_graph(g, delta=delta, max_order=2)
+    finally:
+        mm.LIFT_ONLY_ORDER2 = False
     assert _level_by_level(model) and getattr(model, "_pp_fused", None) is None
     slow = _generic(pp, g, delta, 2)
     for k in (1, 2):
@@ -323,7 +330,11 @@ def test_order_two_of_a_stream_with_a_very_large_hub(pp):
     out = net(data)
     out.sum().backward()
     assert bool(torch.isfinite(out).all())
-    # a stream without such a hub stays on the order-2 builder
+    # a stream without such a hub stays on the order-2 builder even then
     ei, tt, _, nn_, dd = _stream("sparse", 3)
-    small = pp.MultiOrderModel.from_temporal_graph(pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=tt.to(DEV), num_nodes=nn_)), delta=dd, max_order=2)
+    mm.LIFT_ONLY_ORDER2 = True
+    try:
+        small = pp.MultiOrderModel.from_temporal_graph(pp.TemporalGraph(pp.Data(edge_index=ei.to(DEV), time=tt.to(DEV), num_nodes=nn_)), delta=dd, max_order=2)
+    finally:
+        mm.LIFT_ONLY_ORDER2 = False
     assert getattr(small, "_pp_fused", None) is not None
